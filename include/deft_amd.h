@@ -1,0 +1,176 @@
+/*
+ * deft_amd.h — C ABI of libdeft_amd.so: MI355X (gfx950) tree-attention decode path.
+ *
+ * This is the drop-in boundary for ONE path of LINs-lab/DeFT: paged DeFT-Flatten /
+ * DeFT-Node attention at decode time.  The reference has no native code for this
+ * path (its kernels are Triton, DeFT/deft/layers/attention/tree_attention.py); the
+ * functions below are what the reference's two Python operators and their
+ * companions would bind over ctypes (INTEGRATION.md shows the stubs):
+ *
+ *   deft_flatten_decode_f16   replaces tree_attention_subtree_fwd
+ *                             (tree_attention.py:551-667: kernel2 :859-976 + stage 2 :296-546)
+ *   deft_node_decode_f16      replaces tree_attention_fwd
+ *                             (tree_attention.py:14-68: stage 1 :81-293 + stage 2 :296-546)
+ *   deft_kv_append_f16        replaces KVCacheUpdater.update, paged branch
+ *                             (DeFT/deft/tree_decoding/tree_cache.py:67-76, called from
+ *                              DeFTAttention.store_kv_cache, deft_attention.py:390-403)
+ *   deft_md_*                 replaces TreeMetadata.from_tree_cache
+ *                             (tree_cache.py:618-881), host side, no GPU needed
+ *
+ * Conventions
+ *   - plain pointers and sizes only; device pointers are raw HIP device addresses;
+ *     `stream` is a hipStream_t passed as void* (NULL = the null stream).
+ *   - every function returns 0 on success or a negative DEFT_E* code and never
+ *     throws; deft_last_error() returns a thread-local message for the last failure.
+ *   - all launches are asynchronous on `stream`; no function synchronises, allocates
+ *     device memory or keeps state between calls.  The caller owns every buffer,
+ *     including `workspace` (size it with the *_workspace_bytes functions).
+ *   - strides are in ELEMENTS of the pointed-to type.
+ *   - fp16 tensors are IEEE binary16; index tensors are int64 exactly as the
+ *     reference's TreeMetadata holds them (tree_cache.py:813-857); cache_loc is int32
+ *     (memory_pool.py:80).
+ *   - KV pool layout is the reference's: per layer [slot][2][Hkv][D] fp16
+ *     (memory_pool.py:61-66).  k_base = &kv_data[0][0][0][0], v_base = &kv_data[0][1][0][0],
+ *     kv_stride_slot = 2*Hkv*D, kv_stride_head = D.  Any other strides are accepted
+ *     as long as rows of D elements are contiguous and 16-byte aligned.
+ */
+#ifndef DEFT_AMD_H
+#define DEFT_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DEFT_OK 0
+#define DEFT_EINVAL (-1)       /* bad argument (null pointer, negative size, misalignment) */
+#define DEFT_EUNSUPPORTED (-2) /* geometry the kernels do not cover (see deft_supported) */
+#define DEFT_EHIP (-3)         /* a HIP runtime call failed; message has hipGetErrorString */
+#define DEFT_EWORKSPACE (-4)   /* workspace too small */
+
+#define DEFT_BLOCK_LEN 128 /* BLOCK_CONFIG["BLOCK_LEN"], tree_cache.py:587; kernel tile, tree_attention.py:655 */
+#define DEFT_MAX_Q_LEN 32  /* from_tree_cache(max_q_len=32), tree_cache.py:623; BLOCK_M, tree_attention.py:656 */
+
+int deft_abi_version(void);
+const char* deft_last_error(void);
+
+/* 1 if (Hq, Hkv, D) is covered: Hq % Hkv == 0, D in {64, 128}
+ * (the reference asserts D in {16,32,64,128}, tree_attention.py:100,305,582). */
+int deft_supported(int Hq, int Hkv, int D);
+
+/* ---- DeFT-Flatten ------------------------------------------------------- */
+
+/* Bytes of device scratch deft_flatten_decode_f16 needs for this shape. */
+size_t deft_flatten_workspace_bytes(int NB, int P, int nq, int Hq, int Hkv, int D);
+
+/*
+ * out[nq,Hq,D] = tree attention of q over the flattened-tree blocks.
+ *   q, out              fp16, [nq][Hq][D] with the given token/head strides
+ *   block_q[P]          query row of every partial row, grouped per block
+ *   block_q_cnts[NB]    queries per block (1..32)
+ *   block_q_offset[NB]  exclusive prefix sum of block_q_cnts
+ *   block_bitmasks[NB*128]  bit r set <=> r-th query of the block sees the slot
+ *   block_kv[NB*128]    pool slot per position, -1 padded
+ *   block_lens[NB]      valid positions per block
+ *   scale               1/sqrt(D) in the reference (tree_attention.py:601)
+ * `out` is overwritten (the reference accumulates into a pre-zeroed tensor,
+ * tree_attention.py:546; pre-zeroing is tolerated, not required).
+ */
+int deft_flatten_decode_f16(
+    const void* q, int64_t q_stride_tok, int64_t q_stride_head,
+    const void* k_base, const void* v_base, int64_t kv_stride_slot, int64_t kv_stride_head,
+    void* out, int64_t o_stride_tok, int64_t o_stride_head,
+    const int64_t* block_q, const int64_t* block_q_cnts, const int64_t* block_q_offset,
+    const int64_t* block_bitmasks, const int64_t* block_kv, const int64_t* block_lens,
+    int NB, int P, int nq, int Hq, int Hkv, int D, float scale,
+    void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- DeFT-Node ---------------------------------------------------------- */
+
+size_t deft_node_workspace_bytes(int NE, int P, int64_t total_kv, int nq, int Hq, int Hkv, int D);
+
+/*
+ *   node_kv[total_kv]       pool slots of every entry, concatenated
+ *   node_kv_offset/len[NE]  slice of node_kv per entry
+ *   node_q[P]               query rows of every entry, concatenated
+ *   node_q_offset/len[NE]   slice of node_q per entry (len 1..32)
+ * Long entries are split internally into 128-slot tiles (the reference walks a
+ * node serially in 16-token tiles, tree_attention.py:230); the result is the same
+ * attention output.
+ */
+int deft_node_decode_f16(
+    const void* q, int64_t q_stride_tok, int64_t q_stride_head,
+    const void* k_base, const void* v_base, int64_t kv_stride_slot, int64_t kv_stride_head,
+    void* out, int64_t o_stride_tok, int64_t o_stride_head,
+    const int64_t* node_kv, const int64_t* node_kv_offset, const int64_t* node_kv_len,
+    const int64_t* node_q, const int64_t* node_q_offset, const int64_t* node_q_len,
+    int NE, int P, int64_t total_kv, int nq, int Hq, int Hkv, int D, float scale,
+    void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- paged KV append ---------------------------------------------------- */
+
+/* k_base[cache_loc[i]] = k_new[i], v_base[cache_loc[i]] = v_new[i] for i < n
+ * (rows of Hkv*D fp16; new rows have token stride new_stride_tok and head stride D). */
+int deft_kv_append_f16(
+    void* k_base, void* v_base, int64_t kv_stride_slot, int64_t kv_stride_head,
+    const int32_t* cache_loc, const void* k_new, const void* v_new, int64_t new_stride_tok,
+    int n, int Hkv, int D, void* stream);
+
+/* ---- stage-level entry points (benchmarks / profiling) ------------------- */
+
+/* Flatten stage 1 only: writes normalised fp32 partials + LSE into the workspace
+ * (same layout deft_flatten_decode_f16 uses).  For roofline timing of the dominant
+ * kernel in isolation. */
+int deft_flatten_stage1_f16(
+    const void* q, int64_t q_stride_tok, int64_t q_stride_head,
+    const void* k_base, const void* v_base, int64_t kv_stride_slot, int64_t kv_stride_head,
+    const int64_t* block_q, const int64_t* block_q_cnts, const int64_t* block_q_offset,
+    const int64_t* block_bitmasks, const int64_t* block_kv, const int64_t* block_lens,
+    int NB, int P, int nq, int Hq, int Hkv, int D, float scale,
+    void* workspace, size_t workspace_bytes, void* stream);
+
+/* Copy stage-1 partials out of a workspace (tests): partial_o[Hq][P][D] fp32, partial_lse[Hq][P] fp32. */
+int deft_flatten_read_partials(
+    const void* workspace, size_t workspace_bytes, int NB, int P, int nq, int Hq, int Hkv, int D,
+    float* partial_o_dev, float* partial_lse_dev, void* stream);
+
+/* ---- host-side metadata builder (no GPU) --------------------------------- */
+
+/*
+ * TreeMetadata.from_tree_cache (tree_cache.py:618-881) on a compact tree description.
+ * Nodes are given in any order; children are visited in ascending node id, which is
+ * the reference's dict-insertion (= creation) order (tree_cache.py:251-256, :790).
+ *   node_id[n]       unique ids; the root is the node with parent_id < 0
+ *   parent_id[n]     id of the parent, -1 for the root
+ *   is_leaf[n]       1 for live leaves (TreeCache.leaves)
+ *   kv_offset[n+1]   slice of kv_slots per node (unsorted, as appended)
+ *   kv_slots[...]    pool slots
+ * Query rows are the live leaves sorted by id (tree_cache.py:650-652).
+ * Returns a handle (>0) or a negative error.
+ */
+int64_t deft_md_build(
+    int n_nodes, const int64_t* node_id, const int64_t* parent_id, const uint8_t* is_leaf,
+    const int64_t* kv_offset, const int64_t* kv_slots,
+    int max_q_len, int block_len, int max_block_len);
+
+/* sizes[0..7] = query_num, node_num (NE), total_kv_len, len(node_q), len(node_kv),
+ *               NB, len(block_q) (P), len(block_kv) (= NB*block_len) */
+int deft_md_sizes(int64_t handle, int64_t sizes[8]);
+
+/* Copy the arrays into caller buffers of the sizes reported above (host memory). */
+int deft_md_fetch(
+    int64_t handle,
+    int64_t* node_q, int64_t* node_kv, int64_t* node_q_len, int64_t* node_kv_len,
+    int64_t* node_q_offset, int64_t* node_kv_offset,
+    int64_t* block_q, int64_t* block_q_cnts, int64_t* block_q_offset,
+    int64_t* block_bitmasks, int64_t* block_kv, int64_t* block_lens,
+    int64_t* leaf_ids /* [query_num] node id of each query row */);
+
+int deft_md_free(int64_t handle);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEFT_AMD_H */

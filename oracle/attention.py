@@ -1,0 +1,187 @@
+"""Oracle: DeFT-Flatten / DeFT-Node two-stage attention and ground truth (numpy).
+
+Test infrastructure only (see oracle/__init__.py).  Restates, on CPU:
+
+  flatten_stage1   tree_attention_subtree_fwd_kernel2
+                   DeFT/deft/layers/attention/tree_attention.py:859-976
+  node_stage1      DeFT_splitBynode_Triton_stage1_kernel          :170-293
+  merge_reference  DeFT_splitBynode_Triton_stage2 (+ _2_1, _2_3)  :296-416, :419-445, :484-546
+                   including its quirks: row max initialised to 0 and
+                   accumulation into the fp16 output before the division
+  merge_exact      the mathematically identical merge with the true max and
+                   fp32 accumulation (what the HIP path computes)
+  sequential_truth per-leaf softmax(q K^T / sqrt(D)) V over the leaf's
+                   root->leaf slots, fp64 — the recipe of
+                   DeFT/tests/model/test_DeFT_kernel.py:212-276
+
+Array conventions follow the reference operator (tree_attention.py:14-25, :552-568):
+  q        [nq, Hq, D]   fp16
+  kv_data  [slots, 2, Hkv, D] fp16   (memory_pool.py:61-66; K = [:,0], V = [:,1])
+  out      [nq, Hq, D]   fp16
+GQA: kv_head = head // (Hq // Hkv)   (tree_attention.py:894)
+"""
+from __future__ import annotations
+
+from typing import Dict, Sequence, Tuple
+
+import numpy as np
+
+
+def _kv_views(kv_data: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    return kv_data[:, 0], kv_data[:, 1]
+
+
+def _expand_heads(x: np.ndarray, group: int) -> np.ndarray:
+    """[len, Hkv, D] -> [Hq, len, D] with each KV head repeated `group` times."""
+    return np.repeat(np.transpose(x, (1, 0, 2)), group, axis=0)
+
+
+# ---------------------------------------------------------------------------
+# stage 1, Flatten (tree_attention.py:859-976)
+# ---------------------------------------------------------------------------
+def flatten_stage1(q, kv_data, md: Dict[str, object], block_n: int = 128):
+    nq, Hq, D = q.shape
+    kbuf, vbuf = _kv_views(kv_data)
+    group = Hq // kbuf.shape[1]
+    scale = np.float32(1.0 / (D ** 0.5))
+    block_q = md["block_q"]
+    P = block_q.shape[0]
+    NB = md["block_q_cnts"].shape[0]
+    partial_o = np.zeros((Hq, P, D), dtype=np.float32)
+    partial_lse = np.zeros((Hq, P), dtype=np.float32)
+    for b in range(NB):
+        cnt = int(md["block_q_cnts"][b])
+        off = int(md["block_q_offset"][b])
+        cur_len = int(md["block_lens"][b])
+        rows = block_q[off : off + cnt]
+        slots = md["block_kv"][b * block_n : b * block_n + cur_len]
+        masks = md["block_bitmasks"][b * block_n : b * block_n + cur_len]
+        qt = np.transpose(q[rows].astype(np.float32), (1, 0, 2))  # [Hq, cnt, D]
+        k = _expand_heads(kbuf[slots].astype(np.float32), group)  # [Hq, len, D]
+        v = _expand_heads(vbuf[slots].astype(np.float32), group)
+        s = np.matmul(qt, np.transpose(k, (0, 2, 1))) * scale  # [Hq, cnt, len]  (:944-945)
+        visible = ((masks[None, :] >> np.arange(cnt, dtype=np.int64)[:, None]) & 1).astype(bool)
+        s = np.where(visible[None], s, -np.inf)  # (:946-950)
+        m = s.max(axis=2)  # single-tile softmax (:952-953)
+        p = np.exp(s - m[..., None])
+        acc = np.matmul(p, v)  # (:955)
+        l = p.sum(axis=2)
+        partial_o[:, off : off + cnt] = acc / l[..., None]  # (:964-968)
+        partial_lse[:, off : off + cnt] = m + np.log(l)  # (:972-975)
+    return partial_o, partial_lse
+
+
+# ---------------------------------------------------------------------------
+# stage 1, Node (tree_attention.py:170-293): 16-token tiles, running max
+# ---------------------------------------------------------------------------
+def node_stage1(q, kv_data, md: Dict[str, object], tile: int = 16):
+    nq, Hq, D = q.shape
+    kbuf, vbuf = _kv_views(kv_data)
+    group = Hq // kbuf.shape[1]
+    scale = np.float32(1.0 / (D ** 0.5))
+    node_q = md["node_q"]
+    P = node_q.shape[0]
+    NE = md["node_q_len"].shape[0]
+    partial_o = np.zeros((Hq, P, D), dtype=np.float32)
+    partial_lse = np.zeros((Hq, P), dtype=np.float32)
+    for e in range(NE):
+        q_off, q_len = int(md["node_q_offset"][e]), int(md["node_q_len"][e])
+        kv_off, kv_len = int(md["node_kv_offset"][e]), int(md["node_kv_len"][e])
+        rows = node_q[q_off : q_off + q_len]
+        qt = np.transpose(q[rows].astype(np.float32), (1, 0, 2))  # [Hq, q_len, D]
+        m = np.full((Hq, q_len), -np.inf, dtype=np.float32)
+        l = np.zeros((Hq, q_len), dtype=np.float32)
+        acc = np.zeros((Hq, q_len, D), dtype=np.float32)
+        for t0 in range(0, kv_len, tile):  # (:230)
+            slots = md["node_kv"][kv_off + t0 : kv_off + min(t0 + tile, kv_len)]
+            k = _expand_heads(kbuf[slots].astype(np.float32), group)
+            v = _expand_heads(vbuf[slots].astype(np.float32), group)
+            s = np.matmul(qt, np.transpose(k, (0, 2, 1))) * scale
+            m_new = np.maximum(m, s.max(axis=2))  # (:262-263)
+            p = np.exp(s - m_new[..., None])
+            alpha = np.exp(m - m_new)  # (:268)
+            acc = acc * alpha[..., None] + np.matmul(p, v)  # (:270-272)
+            l = l * alpha + p.sum(axis=2)  # (:274)
+            m = m_new
+        partial_o[:, q_off : q_off + q_len] = acc / l[..., None]  # (:283-287)
+        partial_lse[:, q_off : q_off + q_len] = m + np.log(l)  # (:289-293)
+    return partial_o, partial_lse
+
+
+# ---------------------------------------------------------------------------
+# stage 2 (tree_attention.py:296-416)
+# ---------------------------------------------------------------------------
+def merge_reference(row_to_q, partial_o, partial_lse, nq: int) -> np.ndarray:
+    """The reference merge with its quirks: m = max(0, max lse) (:307-309, :445),
+    fp16 accumulation in partial-row order (:546), division afterwards (:416).
+    (On a GPU the atomic order is nondeterministic; index order is what the
+    Triton interpreter does.)"""
+    Hq, P, D = partial_o.shape
+    row_max = np.zeros((Hq, nq), dtype=np.float32)
+    np.maximum.at(row_max, (slice(None), row_to_q), partial_lse)
+    L = np.zeros((Hq, nq), dtype=np.float32)
+    o = np.zeros((Hq, nq, D), dtype=np.float16)
+    for i in range(P):
+        qi = int(row_to_q[i])
+        w = np.exp(partial_lse[:, i] - row_max[:, qi]).astype(np.float32)
+        L[:, qi] += w
+        o[:, qi] = (o[:, qi] + (w[:, None] * partial_o[:, i]).astype(np.float16)).astype(np.float16)
+    o = (o / L[..., None].astype(np.float16)).astype(np.float16)
+    return np.transpose(o, (1, 0, 2))  # [nq, Hq, D]
+
+
+def merge_exact(row_to_q, partial_o, partial_lse, nq: int) -> np.ndarray:
+    """Same merge with the true row max and fp32 accumulation, one fp16 rounding."""
+    Hq, P, D = partial_o.shape
+    row_max = np.full((Hq, nq), -np.inf, dtype=np.float32)
+    np.maximum.at(row_max, (slice(None), row_to_q), partial_lse)
+    w = np.exp(partial_lse - row_max[:, row_to_q])  # [Hq, P]
+    L = np.zeros((Hq, nq), dtype=np.float32)
+    np.add.at(L, (slice(None), row_to_q), w)
+    o = np.zeros((Hq, nq, D), dtype=np.float32)
+    np.add.at(o, (slice(None), row_to_q), w[..., None] * partial_o)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        o = o / L[..., None]
+    return np.transpose(o, (1, 0, 2)).astype(np.float16)
+
+
+def flatten_forward(q, kv_data, md, merge: str = "exact") -> np.ndarray:
+    po, pl = flatten_stage1(q, kv_data, md)
+    fn = merge_exact if merge == "exact" else merge_reference
+    return fn(md["block_q"], po, pl, q.shape[0])
+
+
+def node_forward(q, kv_data, md, merge: str = "exact") -> np.ndarray:
+    po, pl = node_stage1(q, kv_data, md)
+    fn = merge_exact if merge == "exact" else merge_reference
+    return fn(md["node_q"], po, pl, q.shape[0])
+
+
+# ---------------------------------------------------------------------------
+# ground truth: sequential attention per leaf (test_DeFT_kernel.py:212-276)
+# ---------------------------------------------------------------------------
+def sequential_truth(q, kv_data, paths: Sequence[Sequence[int]], dtype=np.float64) -> np.ndarray:
+    """paths[i] = root->leaf pool slots of query row i.  Returns [nq, Hq, D] in `dtype`."""
+    nq, Hq, D = q.shape
+    kbuf, vbuf = _kv_views(kv_data)
+    group = Hq // kbuf.shape[1]
+    out = np.zeros((nq, Hq, D), dtype=dtype)
+    scale = 1.0 / (D ** 0.5)
+    for i, slots in enumerate(paths):
+        slots = np.asarray(slots, dtype=np.int64)
+        k = _expand_heads(kbuf[slots].astype(dtype), group)  # [Hq, S, D]
+        v = _expand_heads(vbuf[slots].astype(dtype), group)
+        s = np.einsum("hd,hsd->hs", q[i].astype(dtype), k) * scale
+        s -= s.max(axis=1, keepdims=True)
+        p = np.exp(s)
+        p /= p.sum(axis=1, keepdims=True)
+        out[i] = np.einsum("hs,hsd->hd", p, v)
+    return out
+
+
+def kv_append(kv_data: np.ndarray, cache_loc, k_new, v_new) -> None:
+    """KVCacheUpdater.update, paged branch (tree_cache.py:70-76): index_put of one
+    K row and one V row per leaf."""
+    loc = np.asarray(cache_loc, dtype=np.int64)
+    kv_data[loc, 0] = k_new
+    kv_data[loc, 1] = v_new
