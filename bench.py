@@ -1,0 +1,294 @@
+#!/usr/bin/env python3
+"""Benchmark of the DeFT tree-attention decode path on MI355X.
+
+A "step" is ONE tree decode step of the hot path over all layers of the model:
+for each of the 32 layers, the paged KV append of the new token rows followed by
+the DeFT-Flatten (or DeFT-Node) attention operator, each layer on its own KV pool
+(working set = layers x tree KV, far beyond the 256 MB Infinity Cache).  Inputs are
+resident in HBM when the timed region starts; the host-side metadata build is a
+caller of the path, reported separately (`metadata_build_ms`), not timed.
+
+Contract: `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on
+rank 0.  For N > 1 launch with torch.distributed.run (one rank per GPU); every rank
+decodes its own independent tree (weak scaling, no data-path collective).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import deft_amd  # noqa: E402  (fails loudly if libdeft_amd.so is missing)
+from deft_amd._lib import check, lib  # noqa: E402
+from deft_amd.utils.workloads import GEOMETRY, WORKLOADS, Workload, algorithmic_bytes, build_tree  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak
+
+
+class Bench:
+    def __init__(self, w: Workload, layers: int, device: torch.device, seed: int = 0):
+        self.w = w
+        self.Hq, self.Hkv, self.D, _ = GEOMETRY[w.model]
+        self.layers = layers
+        self.device = device
+        t0 = time.perf_counter()
+        self.tree, self.pool = build_tree(w, layers, str(device))
+        self.tree_build_s = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        self.md = deft_amd.TreeMetadata.from_tree_cache(self.tree)
+        torch.cuda.synchronize(device)
+        self.metadata_build_ms = (time.perf_counter() - t0) * 1e3
+        self.nq = self.md.query_num
+        self.n_kv = self.md.total_kv_len
+        g = torch.Generator(device=device)
+        g.manual_seed(seed)
+        st = self.pool._storage
+        for l in range(layers):  # N(0,1) fp16, like the reference's kernel script (test_DeFT_kernel.py:52-54)
+            st[l].normal_(generator=g)
+        self.q = torch.randn((layers, self.nq, self.Hq * self.D), dtype=torch.float16, device=device, generator=g)
+        self.k_new = torch.randn((layers, self.nq, self.Hkv * self.D), dtype=torch.float16, device=device, generator=g)
+        self.v_new = torch.randn((layers, self.nq, self.Hkv * self.D), dtype=torch.float16, device=device, generator=g)
+        leaves = sorted(self.tree.leaves.values(), key=lambda n: n.id)
+        loc = torch.tensor([lf.kv_indices[-1] for lf in leaves], dtype=torch.int32, device=device)
+        self.updater = deft_amd.KVCacheUpdater(True, self.pool, loc, None, False)
+        mode = deft_amd.forward_mode_from_cli(w.mode)
+        self.meta = deft_amd.InputMetadata(mode, self.updater, self.pool)
+        self.attn = [deft_amd.DeFTAttention(self.Hq, self.D, self.D ** -0.5, self.Hkv, l) for l in range(layers)]
+        self.out = None
+        self.graph = None
+        self.launch = "eager"
+
+    def step_eager(self):
+        o = None
+        for l in range(self.layers):
+            o = self.attn[l](self.q[l], self.k_new[l], self.v_new[l], self.meta)
+        self.out = o
+
+    def prepare(self, use_graph: bool = True):
+        deft_amd.register_tree_metadata(self.md)
+        self.step_eager()
+        self.step_eager()
+        torch.cuda.synchronize(self.device)
+        if not use_graph:
+            return
+        try:
+            graph = torch.cuda.CUDAGraph()
+            side = torch.cuda.Stream(device=self.device)
+            side.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(side):
+                with torch.cuda.graph(graph, stream=side):
+                    self.step_eager()
+            torch.cuda.current_stream(self.device).wait_stream(side)
+            graph.replay()
+            torch.cuda.synchronize(self.device)
+            self.graph = graph
+            self.launch = "hipgraph"
+        except Exception as e:  # keep measuring eagerly, say so in the JSON
+            print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); timing eager launches", file=sys.stderr)
+            self.graph = None
+            self.launch = "eager"
+            torch.cuda.synchronize(self.device)
+
+    def step(self):
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            self.step_eager()
+
+    def algorithmic_bytes_per_layer(self) -> int:
+        return algorithmic_bytes(self.n_kv, self.nq, self.Hq, self.Hkv, self.D)
+
+    def time_stage1(self, reps: int):
+        """Average duration of the dominant kernel (Flatten stage 1), one HIP event pair per launch,
+        on the stream the kernel is launched on (torch's current stream)."""
+        if self.w.mode != "flatten":
+            return None
+        md, pool = self.md, self.pool
+        NB, P = md.block_q_cnts.shape[0], md.block_q.shape[0]
+        ws_bytes = lib.deft_flatten_workspace_bytes(NB, P, self.nq, self.Hq, self.Hkv, self.D)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=self.device)
+        stream = torch.cuda.current_stream(self.device)
+        durs = []
+        for r in range(reps + 1):
+            evs = []
+            for l in range(self.layers):
+                q = self.q[l].view(self.nq, self.Hq, self.D)
+                kb, vb = pool.get_key_buffer(l), pool.get_value_buffer(l)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                rc = lib.deft_flatten_stage1_f16(
+                    q.data_ptr(), q.stride(0), q.stride(1), kb.data_ptr(), vb.data_ptr(), kb.stride(0), kb.stride(1),
+                    md.block_q.data_ptr(), md.block_q_cnts.data_ptr(), md.block_q_offset.data_ptr(),
+                    md.block_bitmasks.data_ptr(), md.block_kv.data_ptr(), md.block_lens.data_ptr(),
+                    NB, P, self.nq, self.Hq, self.Hkv, self.D, self.D ** -0.5, ws.data_ptr(), ws_bytes, stream.cuda_stream)
+                e1.record(stream)
+                check(rc, "deft_flatten_stage1_f16")
+                evs.append((e0, e1))
+            torch.cuda.synchronize(self.device)
+            if r > 0:  # first sweep is warm-up
+                durs.extend(a.elapsed_time(b) * 1e3 for a, b in evs)  # us
+        durs.sort()
+        return {"mean_us": sum(durs) / len(durs), "median_us": durs[len(durs) // 2], "launches": len(durs)}
+
+    def cpu_baseline(self, budget_s: float):
+        from oracle.cpu_baseline import time_cpu_baseline  # the checker/baseline, never the product path
+
+        leaves = sorted(self.tree.leaves.values(), key=lambda n: n.id)
+        paths = [self.tree.leaf_path_slots(lf) for lf in leaves]
+        q = self.q[0].view(self.nq, self.Hq, self.D).float().cpu()
+        kv = self.pool.kv_data[0].float().cpu()
+        return time_cpu_baseline(q, kv, paths, self.layers, budget_s=budget_s)
+
+
+def run_timed(b: Bench, steps: int, warmup: int, dist_on: bool):
+    import torch.distributed as dist
+
+    for _ in range(warmup):
+        b.step()
+    if dist_on:
+        dist.barrier()
+    torch.cuda.synchronize(b.device)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        b.step()
+    torch.cuda.synchronize(b.device)
+    if dist_on:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist_on:
+        t = torch.tensor([dt], dtype=torch.float64, device=b.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="northstar_4kx32", choices=sorted(WORKLOADS))
+    ap.add_argument("--branch-len", type=int, default=None, help="override tokens per branch (few_shot trees)")
+    ap.add_argument("--layers", type=int, default=None)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary workloads")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget-s", type=float, default=20.0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist_on = world > 1
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: deft_amd has no CPU path")
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    if dist_on:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+    n_gpus = world if dist_on else 1
+    if args.gpus != n_gpus and rank == 0:
+        print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}; using {n_gpus}", file=sys.stderr)
+
+    w = WORKLOADS[args.workload]
+    if args.branch_len is not None:
+        w = Workload(**{**w.__dict__, "branch_len": args.branch_len})
+    layers = args.layers or GEOMETRY[w.model][3]
+
+    b = Bench(w, layers, device, seed=rank)
+    b.prepare(use_graph=not args.no_graph)
+    dt = run_timed(b, args.steps, args.warmup, dist_on)
+    ms_per_step = dt / args.steps * 1e3
+    tokens_per_s = n_gpus * b.nq / (dt / args.steps)
+
+    s1 = b.time_stage1(reps=3)
+    algo = b.algorithmic_bytes_per_layer()
+    roofline = None
+    if s1 is not None:
+        achieved = algo / (s1["mean_us"] * 1e-6) / 1e9
+        roofline = {"bound": "hbm", "kernel": "deft::stage1_kernel<128,0> (Flatten stage 1)", "achieved": round(achieved, 1),
+                    "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                    "algorithmic_bytes_per_launch": algo, "avg_launch_us": round(s1["mean_us"], 2),
+                    "median_launch_us": round(s1["median_us"], 2), "launches_timed": s1["launches"]}
+    step_achieved = algo * layers / (dt / args.steps) / 1e9
+
+    extras = {}
+    if not args.no_extras and rank == 0 and not dist_on:
+        variants = []
+        if w.kind == "few_shot" and args.branch_len is None:
+            variants += [(f"{w.name}_len1", Workload(**{**w.__dict__, "branch_len": 1})),
+                         (f"{w.name}_len400", Workload(**{**w.__dict__, "branch_len": 400}))]
+        for name in ("fewshot_1kx32", "medusa64_node", "tot50_4k", "forest_8kx8"):
+            if name != w.name:
+                variants.append((name, WORKLOADS[name]))
+        del b.graph
+        b.graph = None
+        for name, wv in variants:
+            try:
+                torch.cuda.empty_cache()
+                bv = Bench(wv, GEOMETRY[wv.model][3], device, seed=1)
+                bv.prepare(use_graph=not args.no_graph)
+                n = max(10, args.steps // 4)
+                dtv = run_timed(bv, n, max(2, args.warmup // 4), False)
+                s1v = bv.time_stage1(reps=1)
+                av = bv.algorithmic_bytes_per_layer()
+                extras[name] = {
+                    "model": wv.model, "mode": wv.mode, "nq": bv.nq, "kv_tokens": bv.n_kv,
+                    "us_per_step": round(dtv / n * 1e6, 1), "us_per_layer": round(dtv / n * 1e6 / bv.layers, 2),
+                    "tokens_per_s": round(bv.nq / (dtv / n), 1),
+                    "step_GBps": round(av * bv.layers / (dtv / n) / 1e9, 1),
+                    "stage1_us": round(s1v["mean_us"], 2) if s1v else None,
+                    "stage1_hbm_frac": round(av / (s1v["mean_us"] * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4) if s1v else None,
+                    "metadata_build_ms": round(bv.metadata_build_ms, 3), "launch": bv.launch,
+                }
+                del bv
+            except Exception as e:  # an extra must never take the headline down
+                extras[name] = {"error": f"{type(e).__name__}: {e}"}
+
+    cpu = None
+    if rank == 0 and not dist_on and not args.no_cpu_baseline:
+        c = b.cpu_baseline(args.cpu_budget_s)
+        cpu = {"value": round(c["tokens_per_s"], 4), "unit": "tokens/s", "cores": c["cores"], "kind": "port",
+               "sample": f"1 of {layers} layer-steps of the same tree ({b.nq} leaves, {b.n_kv} unique KV tokens), "
+                         f"PyTorch SDPA {c['dtype']} per leaf incl. page-table gather, best of {c['reps']}, "
+                         f"x{layers} layers extrapolated",
+               "ms_per_layer_step": round(c["seconds_per_layer_step"] * 1e3, 2)}
+
+    if rank == 0:
+        Hq, Hkv, D, _ = GEOMETRY[w.model]
+        line = {
+            "metric": "tree_tokens_per_s", "value": round(tokens_per_s, 1), "unit": "tokens/s",
+            "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": f"{w.model} DeFT-{w.mode}, {w.kind} tree: {w.prefix}-token shared prefix x {w.width} "
+                                   f"branches x {w.branch_len} tokens, paged KV, {layers} layers "
+                                   f"(Hq={Hq}, Hkv={Hkv}, D={D}); one independent tree per GPU",
+                       "name": w.name, "queries": b.nq, "unique_kv_tokens": b.n_kv, "layers": layers,
+                       "blocks": int(b.md.block_q_cnts.shape[0]), "partial_rows": int(b.md.block_q.shape[0]),
+                       "launch": b.launch},
+            "attention_latency_us_per_step": round(ms_per_step * 1e3, 1),
+            "attention_latency_us_per_layer": round(ms_per_step * 1e3 / layers, 2),
+            "step_algorithmic_GBps": round(step_achieved, 1),
+            "step_hbm_frac": round(step_achieved / HBM_PEAK_GBPS, 4),
+            "metadata_build_ms": round(b.metadata_build_ms, 3),
+            "roofline": roofline, "cpu_baseline": cpu, "other_workloads": extras,
+        }
+        print(json.dumps(line), flush=True)
+    if dist_on:
+        import torch.distributed as dist
+
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,81 @@
+"""ctypes binding of libdeft_amd.so (the C ABI declared in include/deft_amd.h).
+
+The library is built in-tree by `deft_amd/csrc/Makefile` (see `__graft_entry__.build`).
+There is no fallback: if the shared object is missing, importing this module
+raises, and every operator in the package fails with it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libdeft_amd.so")
+
+
+class DeftLibraryError(RuntimeError):
+    pass
+
+
+def _load() -> C.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise DeftLibraryError(
+            f"{LIB_PATH} not found: build it with `make -C deft_amd/csrc` "
+            "(or `python -c 'import __graft_entry__ as g; g.build()'`). "
+            "deft_amd has no CPU or PyTorch fallback for its HIP kernels."
+        )
+    return C.CDLL(LIB_PATH)
+
+
+lib = _load()
+
+_vp, _i64, _i32, _f32, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_size_t
+
+lib.deft_abi_version.restype = C.c_int
+lib.deft_last_error.restype = C.c_char_p
+lib.deft_supported.argtypes = [_i32, _i32, _i32]
+lib.deft_supported.restype = C.c_int
+
+lib.deft_flatten_workspace_bytes.argtypes = [_i32] * 6
+lib.deft_flatten_workspace_bytes.restype = _sz
+lib.deft_node_workspace_bytes.argtypes = [_i32, _i32, _i64, _i32, _i32, _i32, _i32]
+lib.deft_node_workspace_bytes.restype = _sz
+
+_QKV = [_vp, _i64, _i64, _vp, _vp, _i64, _i64]  # q, q strides, k, v, kv strides
+_OUT = [_vp, _i64, _i64]
+_MD6 = [_vp] * 6
+
+lib.deft_flatten_decode_f16.argtypes = _QKV + _OUT + _MD6 + [_i32] * 6 + [_f32, _vp, _sz, _vp]
+lib.deft_flatten_decode_f16.restype = C.c_int
+lib.deft_flatten_stage1_f16.argtypes = _QKV + _MD6 + [_i32] * 6 + [_f32, _vp, _sz, _vp]
+lib.deft_flatten_stage1_f16.restype = C.c_int
+lib.deft_node_decode_f16.argtypes = _QKV + _OUT + _MD6 + [_i32, _i32, _i64, _i32, _i32, _i32, _i32, _f32, _vp, _sz, _vp]
+lib.deft_node_decode_f16.restype = C.c_int
+lib.deft_kv_append_f16.argtypes = [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]
+lib.deft_kv_append_f16.restype = C.c_int
+lib.deft_flatten_read_partials.argtypes = [_vp, _sz] + [_i32] * 6 + [_vp, _vp, _vp]
+lib.deft_flatten_read_partials.restype = C.c_int
+
+lib.deft_md_build.argtypes = [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32]
+lib.deft_md_build.restype = _i64
+lib.deft_md_sizes.argtypes = [_i64, _vp]
+lib.deft_md_sizes.restype = C.c_int
+lib.deft_md_fetch.argtypes = [_i64] + [_vp] * 13
+lib.deft_md_fetch.restype = C.c_int
+lib.deft_md_free.argtypes = [_i64]
+lib.deft_md_free.restype = C.c_int
+
+EXPORTED = (
+    "deft_abi_version", "deft_last_error", "deft_supported",
+    "deft_flatten_workspace_bytes", "deft_flatten_decode_f16", "deft_flatten_stage1_f16",
+    "deft_flatten_read_partials", "deft_node_workspace_bytes", "deft_node_decode_f16",
+    "deft_kv_append_f16", "deft_md_build", "deft_md_sizes", "deft_md_fetch", "deft_md_free",
+)
+
+_ERR_NAMES = {-1: "DEFT_EINVAL", -2: "DEFT_EUNSUPPORTED", -3: "DEFT_EHIP", -4: "DEFT_EWORKSPACE"}
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib.deft_last_error().decode("utf-8", "replace")
+        raise DeftLibraryError(f"{what} failed: {_ERR_NAMES.get(rc, rc)}: {msg}")

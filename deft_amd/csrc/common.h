@@ -1,0 +1,50 @@
+// Shared declarations of libdeft_amd.so (gfx950 only).
+#pragma once
+
+#include <stdarg.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/deft_amd.h"
+
+namespace deft {
+
+// thread-local last-error text behind deft_last_error()
+void set_error(const char* fmt, ...);
+const char* get_error();
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// Workspace carve shared by the Flatten and Node entry points:
+//   partial_o   [Hq][rows][D] f32   normalised stage-1 outputs
+//   partial_lse [Hq][rows]    f32   log-sum-exp of each partial row (natural log)
+//   row_q       [rows]        i32   query row of each partial row, -1 = unused
+//   desc        [tiles][8]    i32   tile descriptors (Node mode only)
+struct Workspace {
+    float* partial_o;
+    float* partial_lse;
+    int32_t* row_q;
+    int32_t* desc;
+    size_t bytes;
+};
+
+inline Workspace carve(void* base, int Hq, int D, int64_t rows, int64_t tiles) {
+    Workspace w;
+    char* p = static_cast<char*>(base);
+    size_t off = 0;
+    w.partial_o = reinterpret_cast<float*>(p + off);
+    off = align_up(off + sizeof(float) * (size_t)Hq * (size_t)rows * (size_t)D, 256);
+    w.partial_lse = reinterpret_cast<float*>(p + off);
+    off = align_up(off + sizeof(float) * (size_t)Hq * (size_t)rows, 256);
+    w.row_q = reinterpret_cast<int32_t*>(p + off);
+    off = align_up(off + sizeof(int32_t) * (size_t)rows, 256);
+    w.desc = reinterpret_cast<int32_t*>(p + off);
+    off = align_up(off + sizeof(int32_t) * 8 * (size_t)tiles, 256);
+    w.bytes = off;
+    return w;
+}
+
+inline int64_t node_max_tiles(int NE, int64_t total_kv) { return (int64_t)NE + total_kv / DEFT_BLOCK_LEN; }
+
+}  // namespace deft

@@ -1,0 +1,686 @@
+// DeFT paged tree-attention decode kernels for MI355X (gfx950 / CDNA4, wave64).
+//
+// What the reference computes (DeFT/deft/layers/attention/tree_attention.py):
+//   stage 1  per (head, KV tile): S = Q K^T / sqrt(D), mask by the per-slot query
+//            bitmask, softmax over the tile, partial = P V / sum, lse = max + log(sum)
+//            (Flatten: kernel2 :859-976, one 128-slot block per program;
+//             Node: :170-293, a serial walk over the node in 16-token tiles)
+//   stage 2  merge all partial rows of a query by their log-sum-exp (:296-546)
+//
+// How it is laid out here:
+//   * one workgroup (4 waves) owns one (KV tile of <=128 pool slots, KV head) and loops
+//     over the Hq/Hkv query heads that share that KV head, so every K/V byte is read
+//     from HBM once per tile (the reference re-reads it per query head, :894).
+//   * K and V rows are gathered through the slot list into LDS with 16-byte
+//     per-lane loads (16 lanes cover one 256-byte row).  K is stored with an XOR
+//     swizzle of its 16-byte chunks so the MFMA A-fragment reads are conflict-free.
+//   * S^T = K Q^T on v_mfma_f32_32x32x16_f16: keys are the M dimension, so K
+//     fragments are 16-byte row pieces straight from LDS and Q fragments are
+//     16-byte row pieces straight from global memory; each lane ends up holding
+//     16 key scores of ONE query, so the row max / row sum are in-lane reductions
+//     plus one cross-half shuffle and a 4-wave exchange through LDS.
+//   * P (fp16) goes through LDS once; O^T = V^T P^T on the same MFMA, each wave
+//     producing 32 of the D output columns for all 32 queries.
+//   * Node mode reuses the same kernel: a prep kernel cuts every node entry into
+//     128-slot tiles (all queries of the entry see all slots), which removes the
+//     reference's serial walk over long nodes.
+//   * the merge is a deterministic gather (no atomics): true max, fp32 accumulate,
+//     one fp16 rounding.
+#include <hip/hip_runtime.h>
+
+#include "common.h"
+
+namespace deft {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef float floatx2 __attribute__((ext_vector_type(2)));
+typedef uint32_t uintx4 __attribute__((ext_vector_type(4)));
+
+constexpr int TILE = DEFT_BLOCK_LEN;  // 128 KV slots per tile
+constexpr int MQ = DEFT_MAX_Q_LEN;    // 32 query rows per tile
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+
+struct Stage1Params {
+    const _Float16* q;
+    int64_t q_st, q_sh;
+    const _Float16* k;
+    const _Float16* v;
+    int64_t kv_ss, kv_sh;
+    // Flatten sources (MODE 0)
+    const int64_t* block_q;
+    const int64_t* block_q_cnts;
+    const int64_t* block_q_offset;
+    const int64_t* block_bitmasks;
+    const int64_t* block_kv;
+    const int64_t* block_lens;
+    // Node sources (MODE 1)
+    const int64_t* node_kv;
+    const int64_t* node_q;
+    const int32_t* desc;  // [tiles][8] = kv_begin, len, q_begin, cnt, prow, -, -, -
+    // outputs
+    float* partial_o;
+    float* partial_lse;
+    int32_t* row_q;
+    int64_t rows;  // partial rows per head (stride of partial_o / partial_lse)
+    int Hkv, G;
+    float scale_log2e;
+};
+
+template <int D>
+struct Stage1Smem {
+    static constexpr int K_OFF = 0;
+    static constexpr int V_OFF = K_OFF + TILE * D * 2;
+    static constexpr int P_OFF = V_OFF + TILE * D * 2;
+    static constexpr int MASK_OFF = P_OFF + MQ * TILE * 2;
+    static constexpr int WMAX_OFF = MASK_OFF + TILE * 4;
+    static constexpr int WSUM_OFF = WMAX_OFF + 4 * MQ * 4;
+    static constexpr int SLOT_OFF = WSUM_OFF + 4 * MQ * 4;
+    static constexpr int BYTES = SLOT_OFF + TILE * 4;
+};
+
+// ---------------------------------------------------------------------------
+// stage 1
+// ---------------------------------------------------------------------------
+template <int D, int MODE>
+__global__ __launch_bounds__(256, 2) void stage1_kernel(Stage1Params p) {
+    constexpr int CH = D / 8;    // 16-byte chunks per K/V row
+    constexpr int KS = D / 16;   // MFMA k-steps of S^T = K Q^T
+    constexpr int MB = D / 32;   // 32-column output blocks of O^T
+    using SM = Stage1Smem<D>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    _Float16* sK = reinterpret_cast<_Float16*>(smem + SM::K_OFF);
+    _Float16* sV = reinterpret_cast<_Float16*>(smem + SM::V_OFF);
+    _Float16* sP = reinterpret_cast<_Float16*>(smem + SM::P_OFF);
+    uint32_t* sMask = reinterpret_cast<uint32_t*>(smem + SM::MASK_OFF);
+    float* sWmax = reinterpret_cast<float*>(smem + SM::WMAX_OFF);
+    float* sWsum = reinterpret_cast<float*>(smem + SM::WSUM_OFF);
+    int* sSlot = reinterpret_cast<int*>(smem + SM::SLOT_OFF);
+
+    const int tid = threadIdx.x;
+    const int w = tid >> 6;
+    const int l = tid & 63;
+    const int c = l & 31;  // query row owned by this lane in the S^T / O^T fragments
+    const int h = l >> 5;
+    const int tile = blockIdx.x / p.Hkv;
+    const int kvh = blockIdx.x - tile * p.Hkv;
+
+    // ---- tile descriptor (wave-uniform) -------------------------------------
+    int len, cnt, prow;
+    const int64_t* slots;
+    const int64_t* masks;
+    const int64_t* qrows;
+    if (MODE == 0) {
+        len = (int)p.block_lens[tile];
+        cnt = (int)p.block_q_cnts[tile];
+        prow = (int)p.block_q_offset[tile];
+        slots = p.block_kv + (int64_t)tile * TILE;
+        masks = p.block_bitmasks + (int64_t)tile * TILE;
+        qrows = p.block_q + prow;
+    } else {
+        const int32_t* d = p.desc + (int64_t)tile * 8;
+        len = d[1];
+        if (len <= 0) return;
+        cnt = d[3];
+        prow = d[4];
+        slots = p.node_kv + d[0];
+        masks = nullptr;
+        qrows = p.node_q + d[2];
+    }
+
+    // ---- slot list and bitmasks -> LDS ---------------------------------------
+    // Padded positions (>= len) re-read the tile's first slot with an empty mask:
+    // their probability is exactly 0 and the row they alias is valid, finite data.
+    if (tid < TILE) {
+        const bool live = tid < len;
+        sSlot[tid] = (int)slots[live ? tid : 0];
+        uint32_t m = 0u;
+        if (live) m = (MODE == 0) ? (uint32_t)masks[tid] : 0xffffffffu;
+        sMask[tid] = m;
+    }
+    __syncthreads();
+
+    // ---- gather K and V rows of this KV head into LDS ---------------------------
+    // wave w stages keys [32w, 32w+32): 16-byte pieces, CH lanes per row.
+    {
+        constexpr int ITER = 32 * CH / 64;
+        uintx4 kreg[ITER], vreg[ITER];
+#pragma unroll
+        for (int i = 0; i < ITER; ++i) {
+            const int idx = i * 64 + l;
+            const int key = 32 * w + idx / CH;
+            const int chunk = idx % CH;
+            const int64_t off = (int64_t)sSlot[key] * p.kv_ss + (int64_t)kvh * p.kv_sh + chunk * 8;
+            kreg[i] = *reinterpret_cast<const uintx4*>(p.k + off);
+            vreg[i] = *reinterpret_cast<const uintx4*>(p.v + off);
+        }
+#pragma unroll
+        for (int i = 0; i < ITER; ++i) {
+            const int idx = i * 64 + l;
+            const int key = 32 * w + idx / CH;
+            const int chunk = idx % CH;
+            const int pos = chunk ^ (key & (CH - 1));
+            *reinterpret_cast<uintx4*>(sK + key * D + pos * 8) = kreg[i];
+            *reinterpret_cast<uintx4*>(sV + key * D + chunk * 8) = vreg[i];
+        }
+    }
+
+    const bool qvalid = c < cnt;
+    const int64_t qrow = qvalid ? qrows[c] : 0;
+
+    for (int g = 0; g < p.G; ++g) {
+        const int hq = kvh * p.G + g;
+
+        // ---- Q fragments (B operand of S^T): 8 halfs of query row c per k-step ----
+        half8 qf[KS];
+        {
+            const _Float16* qp = p.q + qrow * p.q_st + (int64_t)hq * p.q_sh + 8 * h;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+                qf[ks] = qvalid ? *reinterpret_cast<const half8*>(qp + 16 * ks) : z;
+            }
+        }
+        __syncthreads();  // K/V/masks staged (g == 0); sP / sWmax / sWsum free again (g > 0)
+
+        // ---- S^T[key][query] for this wave's 32 keys ------------------------------
+        floatx16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        {
+            const int key = 32 * w + c;
+            const _Float16* krow = sK + key * D;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int pos = (2 * ks + h) ^ (key & (CH - 1));
+                const half8 a = *reinterpret_cast<const half8*>(krow + pos * 8);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qf[ks], acc, 0, 0, 0);
+            }
+        }
+        // acc[r] = S^T[key = 32w + (r&3) + 8*(r>>2) + 4h][query = c]
+
+        // ---- scale, mask, row max ---------------------------------------------------
+        float s[16];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const uintx4 m4 = *reinterpret_cast<const uintx4*>(sMask + 32 * w + 8 * g4 + 4 * h);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = 4 * g4 + i;
+                const bool vis = qvalid && ((m4[i] >> c) & 1u);
+                s[r] = vis ? acc[r] * p.scale_log2e : -INFINITY;
+                mx = fmaxf(mx, s[r]);
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        if (h == 0) sWmax[w * MQ + c] = mx;
+        __syncthreads();
+        const float m = fmaxf(fmaxf(sWmax[c], sWmax[MQ + c]), fmaxf(sWmax[2 * MQ + c], sWmax[3 * MQ + c]));
+        const float msafe = (m == -INFINITY) ? 0.f : m;
+
+        // ---- P = exp2(s - m) as fp16, row sums of the ROUNDED values -------------------
+        float sum = 0.f;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            half4 p4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const _Float16 ph = (_Float16)exp2f(s[4 * g4 + i] - msafe);
+                p4[i] = ph;
+                sum += (float)ph;
+            }
+            // keys 32w + 8*g4 + 4h + (0..3) of query row c; 16-byte chunks XOR-swizzled by row
+            const int pos = (4 * w + g4) ^ (c & 15);
+            *reinterpret_cast<half4*>(sP + c * TILE + pos * 8 + 4 * h) = p4;
+        }
+        sum += __shfl_xor(sum, 32);
+        if (h == 0) sWsum[w * MQ + c] = sum;
+        __syncthreads();
+
+        // ---- O^T[d][query] = sum_key V[key][d] * P[query][key], 32 d-columns per wave ----
+        if (w < MB) {
+            floatx16 o;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[r] = 0.f;
+            const _Float16* vcol = sV + 32 * w + c;
+            const _Float16* prow_p = sP + c * TILE;
+#pragma unroll
+            for (int ks = 0; ks < TILE / 16; ++ks) {
+                half8 a;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a[j] = vcol[(16 * ks + 8 * h + j) * D];
+                const half8 b = *reinterpret_cast<const half8*>(prow_p + (((2 * ks + h) ^ (c & 15)) * 8));
+                o = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, o, 0, 0, 0);
+            }
+            // o[r] = O^T[d = 32w + (r&3) + 8*(r>>2) + 4h][query = c]
+            const float lsum = sWsum[c] + sWsum[MQ + c] + sWsum[2 * MQ + c] + sWsum[3 * MQ + c];
+            const float inv = lsum > 0.f ? 1.f / lsum : 0.f;
+            if (qvalid) {
+                const int64_t prow_idx = (int64_t)hq * p.rows + prow + c;
+                float* po = p.partial_o + prow_idx * D + 32 * w + 4 * h;
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    floatx4 v4 = {o[4 * g4] * inv, o[4 * g4 + 1] * inv, o[4 * g4 + 2] * inv, o[4 * g4 + 3] * inv};
+                    *reinterpret_cast<floatx4*>(po + 8 * g4) = v4;
+                }
+                if (w == 0 && h == 0) {
+                    p.partial_lse[prow_idx] = (lsum > 0.f) ? (m + log2f(lsum)) * LN2 : -INFINITY;
+                    if (hq == 0) p.row_q[prow + c] = (int32_t)qrow;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Node mode: cut entries into 128-slot tiles (one workgroup, once per call)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void node_prep_kernel(const int64_t* node_kv_offset, const int64_t* node_kv_len,
+                                                         const int64_t* node_q_offset, const int64_t* node_q_len, int NE,
+                                                         int64_t max_tiles, int64_t max_rows, int32_t* desc,
+                                                         int32_t* row_q) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int* sTiles = reinterpret_cast<int*>(smem);  // [NE+1] exclusive scan of tiles per entry
+    int* sRows = sTiles + (NE + 1);              // [NE+1] exclusive scan of partial rows per entry
+    const int tid = threadIdx.x;
+    for (int e = tid; e < NE; e += blockDim.x) {
+        const int nt = (int)((node_kv_len[e] + TILE - 1) / TILE);
+        sTiles[e + 1] = nt;
+        sRows[e + 1] = nt * (int)node_q_len[e];
+    }
+    for (int64_t i = tid; i < max_rows; i += blockDim.x) row_q[i] = -1;
+    __syncthreads();
+    if (tid == 0) {
+        sTiles[0] = 0;
+        sRows[0] = 0;
+        for (int e = 0; e < NE; ++e) {
+            sTiles[e + 1] += sTiles[e];
+            sRows[e + 1] += sRows[e];
+        }
+    }
+    __syncthreads();
+    const int total = sTiles[NE];
+    for (int e = tid; e < NE; e += blockDim.x) {
+        const int t0 = sTiles[e];
+        const int nt = sTiles[e + 1] - t0;
+        const int kv0 = (int)node_kv_offset[e];
+        const int kvl = (int)node_kv_len[e];
+        const int q0 = (int)node_q_offset[e];
+        const int ql = (int)node_q_len[e];
+        for (int t = 0; t < nt; ++t) {
+            int32_t* d = desc + (int64_t)(t0 + t) * 8;
+            d[0] = kv0 + t * TILE;
+            d[1] = min(TILE, kvl - t * TILE);
+            d[2] = q0;
+            d[3] = ql;
+            d[4] = sRows[e] + t * ql;
+            d[5] = d[6] = d[7] = 0;
+        }
+    }
+    for (int64_t t = total + tid; t < max_tiles; t += blockDim.x) desc[t * 8 + 1] = 0;
+}
+
+// ---------------------------------------------------------------------------
+// stage 2: merge the partial rows of one (query, head)
+// ---------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(64) void merge_kernel(const float* partial_o, const float* partial_lse, const int32_t* row_q,
+                                                    int64_t rows, _Float16* out, int64_t o_st, int64_t o_sh) {
+    constexpr int VEC = D / 64;  // output columns per lane
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int* sRows = reinterpret_cast<int*>(smem);  // matching partial rows, capacity `rows`
+    const int lane = threadIdx.x;
+    const int qi = blockIdx.x;
+    const int hq = blockIdx.y;
+
+    // 1. partial rows of this query, in ascending row order (deterministic)
+    int n = 0;
+    for (int64_t base = 0; base < rows; base += 64) {
+        const int64_t i = base + lane;
+        const bool hit = (i < rows) && (row_q[i] == qi);
+        const unsigned long long mask = __ballot(hit);
+        if (hit) sRows[n + __popcll(mask & ((1ull << lane) - 1ull))] = (int)i;
+        n += __popcll(mask);
+    }
+    __syncthreads();
+
+    // 2. true maximum of their log-sum-exps
+    const float* lse_h = partial_lse + (int64_t)hq * rows;
+    float m = -INFINITY;
+    for (int i = lane; i < n; i += 64) m = fmaxf(m, lse_h[sRows[i]]);
+#pragma unroll
+    for (int sft = 32; sft > 0; sft >>= 1) m = fmaxf(m, __shfl_xor(m, sft));
+
+    // 3. weighted sum in fp32, one rounding to fp16
+    float acc[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+    float L = 0.f;
+    if (m > -INFINITY) {
+        const float* po_h = partial_o + (int64_t)hq * rows * D + VEC * lane;
+        for (int i = 0; i < n; ++i) {
+            const int r = sRows[i];
+            const float wgt = __expf(lse_h[r] - m);
+            L += wgt;
+            const float* src = po_h + (int64_t)r * D;
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) acc[j] += wgt * src[j];
+        }
+    }
+    const float inv = L > 0.f ? 1.f / L : 0.f;
+    _Float16* dst = out + (int64_t)qi * o_st + (int64_t)hq * o_sh + VEC * lane;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) dst[j] = (_Float16)(acc[j] * inv);
+}
+
+// ---------------------------------------------------------------------------
+// paged KV append: one 16-byte piece per thread
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void kv_append_kernel(_Float16* k_base, _Float16* v_base, int64_t kv_ss, int64_t kv_sh,
+                                                         const int32_t* cache_loc, const _Float16* k_new,
+                                                         const _Float16* v_new, int64_t new_st, int n, int Hkv, int D) {
+    const int ch_per_head = D / 8;
+    const int ch_per_tok = Hkv * ch_per_head;
+    const int64_t total = (int64_t)n * ch_per_tok;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int tok = (int)(i / ch_per_tok);
+        const int rem = (int)(i - (int64_t)tok * ch_per_tok);
+        const int hd = rem / ch_per_head;
+        const int ch = rem - hd * ch_per_head;
+        const int64_t src = (int64_t)tok * new_st + (int64_t)hd * D + ch * 8;
+        const int64_t dst = (int64_t)cache_loc[tok] * kv_ss + (int64_t)hd * kv_sh + ch * 8;
+        *reinterpret_cast<uintx4*>(k_base + dst) = *reinterpret_cast<const uintx4*>(k_new + src);
+        *reinterpret_cast<uintx4*>(v_base + dst) = *reinterpret_cast<const uintx4*>(v_new + src);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// host-side launch helpers
+// ---------------------------------------------------------------------------
+static int check_launch(const char* what) {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: %s", what, hipGetErrorString(e));
+        return DEFT_EHIP;
+    }
+    return DEFT_OK;
+}
+
+template <int D, int MODE>
+static int launch_stage1(const Stage1Params& p, int64_t tiles, hipStream_t stream) {
+    using SM = Stage1Smem<D>;
+    static bool attr_set = false;  // raising the dynamic-LDS cap is idempotent; races are harmless
+    if (!attr_set) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&stage1_kernel<D, MODE>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, SM::BYTES);
+        if (e != hipSuccess) {
+            set_error("hipFuncSetAttribute(stage1): %s", hipGetErrorString(e));
+            return DEFT_EHIP;
+        }
+        attr_set = true;
+    }
+    const int64_t grid = tiles * p.Hkv;
+    if (grid <= 0) return DEFT_OK;
+    if (grid > 0x7fffffffLL) {
+        set_error("stage1 grid too large: %lld", (long long)grid);
+        return DEFT_EINVAL;
+    }
+    hipLaunchKernelGGL((stage1_kernel<D, MODE>), dim3((unsigned)grid), dim3(256), SM::BYTES, stream, p);
+    return check_launch("stage1 launch");
+}
+
+template <int MODE>
+static int dispatch_stage1(int D, const Stage1Params& p, int64_t tiles, hipStream_t stream) {
+    if (D == 128) return launch_stage1<128, MODE>(p, tiles, stream);
+    if (D == 64) return launch_stage1<64, MODE>(p, tiles, stream);
+    set_error("unsupported head_dim %d (supported: 64, 128)", D);
+    return DEFT_EUNSUPPORTED;
+}
+
+static int launch_merge(int D, const Workspace& ws, int64_t rows, void* out, int64_t o_st, int64_t o_sh, int nq, int Hq,
+                        hipStream_t stream) {
+    if (nq <= 0) return DEFT_OK;
+    const size_t lds = sizeof(int) * (size_t)(rows > 0 ? rows : 1);
+    if (lds > 64 * 1024) {
+        set_error("merge: %lld partial rows exceed the LDS row list", (long long)rows);
+        return DEFT_EUNSUPPORTED;
+    }
+    dim3 grid((unsigned)nq, (unsigned)Hq);
+    if (D == 128)
+        hipLaunchKernelGGL((merge_kernel<128>), grid, dim3(64), lds, stream, ws.partial_o, ws.partial_lse, ws.row_q, rows,
+                           static_cast<_Float16*>(out), o_st, o_sh);
+    else
+        hipLaunchKernelGGL((merge_kernel<64>), grid, dim3(64), lds, stream, ws.partial_o, ws.partial_lse, ws.row_q, rows,
+                           static_cast<_Float16*>(out), o_st, o_sh);
+    return check_launch("merge launch");
+}
+
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+static int check_common(const void* q, int64_t q_st, int64_t q_sh, const void* k, const void* v, int64_t kv_ss,
+                        int64_t kv_sh, const void* out, int64_t o_st, int64_t o_sh, int nq, int Hq, int Hkv, int D) {
+    if (!q || !k || !v || !out) {
+        set_error("null tensor pointer");
+        return DEFT_EINVAL;
+    }
+    if (nq < 0 || Hq <= 0 || Hkv <= 0 || Hq % Hkv != 0) {
+        set_error("bad geometry nq=%d Hq=%d Hkv=%d", nq, Hq, Hkv);
+        return DEFT_EINVAL;
+    }
+    if (!deft_supported(Hq, Hkv, D)) {
+        set_error("unsupported geometry Hq=%d Hkv=%d D=%d (D must be 64 or 128)", Hq, Hkv, D);
+        return DEFT_EUNSUPPORTED;
+    }
+    if (!aligned16(q) || !aligned16(k) || !aligned16(v) || (q_st % 8) || (q_sh % 8) || (kv_ss % 8) || (kv_sh % 8)) {
+        set_error("q/k/v rows must be 16-byte aligned (pointers and strides multiples of 8 elements)");
+        return DEFT_EINVAL;
+    }
+    if ((reinterpret_cast<uintptr_t>(out) & 3u) || (o_st % 2) || (o_sh % 2)) {
+        set_error("out rows must be 4-byte aligned");
+        return DEFT_EINVAL;
+    }
+    return DEFT_OK;
+}
+
+}  // namespace deft
+
+using namespace deft;
+
+extern "C" {
+
+int deft_abi_version(void) { return 1; }
+
+int deft_supported(int Hq, int Hkv, int D) { return (Hq > 0 && Hkv > 0 && Hq % Hkv == 0 && (D == 64 || D == 128)) ? 1 : 0; }
+
+size_t deft_flatten_workspace_bytes(int NB, int P, int nq, int Hq, int Hkv, int D) {
+    (void)NB;
+    (void)nq;
+    (void)Hkv;
+    return carve(nullptr, Hq, D, P, 0).bytes;
+}
+
+size_t deft_node_workspace_bytes(int NE, int P, int64_t total_kv, int nq, int Hq, int Hkv, int D) {
+    (void)P;
+    (void)nq;
+    (void)Hkv;
+    const int64_t tiles = node_max_tiles(NE, total_kv);
+    return carve(nullptr, Hq, D, tiles * DEFT_MAX_Q_LEN, tiles).bytes;
+}
+
+int deft_flatten_stage1_f16(const void* q, int64_t q_stride_tok, int64_t q_stride_head, const void* k_base,
+                            const void* v_base, int64_t kv_stride_slot, int64_t kv_stride_head, const int64_t* block_q,
+                            const int64_t* block_q_cnts, const int64_t* block_q_offset, const int64_t* block_bitmasks,
+                            const int64_t* block_kv, const int64_t* block_lens, int NB, int P, int nq, int Hq, int Hkv,
+                            int D, float scale, void* workspace, size_t workspace_bytes, void* stream) {
+    // `workspace` doubles as the (unused) output pointer for the shared argument check
+    int rc = check_common(q, q_stride_tok, q_stride_head, k_base, v_base, kv_stride_slot, kv_stride_head, workspace, 2, 2,
+                          nq, Hq, Hkv, D);
+    if (rc) return rc;
+    if (NB < 0 || P < 0 || (NB > 0 && (!block_q || !block_q_cnts || !block_q_offset || !block_bitmasks || !block_kv ||
+                                       !block_lens))) {
+        set_error("bad Flatten metadata (NB=%d P=%d)", NB, P);
+        return DEFT_EINVAL;
+    }
+    const Workspace ws = carve(workspace, Hq, D, P, 0);
+    if (workspace_bytes < ws.bytes) {
+        set_error("workspace too small: %zu < %zu", workspace_bytes, ws.bytes);
+        return DEFT_EWORKSPACE;
+    }
+    Stage1Params p{};
+    p.q = static_cast<const _Float16*>(q);
+    p.q_st = q_stride_tok;
+    p.q_sh = q_stride_head;
+    p.k = static_cast<const _Float16*>(k_base);
+    p.v = static_cast<const _Float16*>(v_base);
+    p.kv_ss = kv_stride_slot;
+    p.kv_sh = kv_stride_head;
+    p.block_q = block_q;
+    p.block_q_cnts = block_q_cnts;
+    p.block_q_offset = block_q_offset;
+    p.block_bitmasks = block_bitmasks;
+    p.block_kv = block_kv;
+    p.block_lens = block_lens;
+    p.partial_o = ws.partial_o;
+    p.partial_lse = ws.partial_lse;
+    p.row_q = ws.row_q;
+    p.rows = P;
+    p.Hkv = Hkv;
+    p.G = Hq / Hkv;
+    p.scale_log2e = scale * LOG2E;
+    return dispatch_stage1<0>(D, p, NB, static_cast<hipStream_t>(stream));
+}
+
+int deft_flatten_decode_f16(const void* q, int64_t q_stride_tok, int64_t q_stride_head, const void* k_base,
+                            const void* v_base, int64_t kv_stride_slot, int64_t kv_stride_head, void* out,
+                            int64_t o_stride_tok, int64_t o_stride_head, const int64_t* block_q,
+                            const int64_t* block_q_cnts, const int64_t* block_q_offset, const int64_t* block_bitmasks,
+                            const int64_t* block_kv, const int64_t* block_lens, int NB, int P, int nq, int Hq, int Hkv,
+                            int D, float scale, void* workspace, size_t workspace_bytes, void* stream) {
+    int rc = check_common(q, q_stride_tok, q_stride_head, k_base, v_base, kv_stride_slot, kv_stride_head, out,
+                          o_stride_tok, o_stride_head, nq, Hq, Hkv, D);
+    if (rc) return rc;
+    if (!workspace) {
+        set_error("null workspace");
+        return DEFT_EINVAL;
+    }
+    rc = deft_flatten_stage1_f16(q, q_stride_tok, q_stride_head, k_base, v_base, kv_stride_slot, kv_stride_head, block_q,
+                                 block_q_cnts, block_q_offset, block_bitmasks, block_kv, block_lens, NB, P, nq, Hq, Hkv, D,
+                                 scale, workspace, workspace_bytes, stream);
+    if (rc) return rc;
+    const Workspace ws = carve(workspace, Hq, D, P, 0);
+    return launch_merge(D, ws, P, out, o_stride_tok, o_stride_head, nq, Hq, static_cast<hipStream_t>(stream));
+}
+
+int deft_node_decode_f16(const void* q, int64_t q_stride_tok, int64_t q_stride_head, const void* k_base,
+                         const void* v_base, int64_t kv_stride_slot, int64_t kv_stride_head, void* out,
+                         int64_t o_stride_tok, int64_t o_stride_head, const int64_t* node_kv,
+                         const int64_t* node_kv_offset, const int64_t* node_kv_len, const int64_t* node_q,
+                         const int64_t* node_q_offset, const int64_t* node_q_len, int NE, int P, int64_t total_kv, int nq,
+                         int Hq, int Hkv, int D, float scale, void* workspace, size_t workspace_bytes, void* stream) {
+    int rc = check_common(q, q_stride_tok, q_stride_head, k_base, v_base, kv_stride_slot, kv_stride_head, out,
+                          o_stride_tok, o_stride_head, nq, Hq, Hkv, D);
+    if (rc) return rc;
+    if (NE < 0 || P < 0 || total_kv < 0 || total_kv > 0x7fffffffLL ||
+        (NE > 0 && (!node_kv || !node_kv_offset || !node_kv_len || !node_q || !node_q_offset || !node_q_len))) {
+        set_error("bad Node metadata (NE=%d P=%d total_kv=%lld)", NE, P, (long long)total_kv);
+        return DEFT_EINVAL;
+    }
+    if (!workspace) {
+        set_error("null workspace");
+        return DEFT_EINVAL;
+    }
+    const int64_t tiles = node_max_tiles(NE, total_kv);
+    const int64_t rows = tiles * DEFT_MAX_Q_LEN;
+    const Workspace ws = carve(workspace, Hq, D, rows, tiles);
+    if (workspace_bytes < ws.bytes) {
+        set_error("workspace too small: %zu < %zu", workspace_bytes, ws.bytes);
+        return DEFT_EWORKSPACE;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const size_t prep_lds = sizeof(int) * 2 * (size_t)(NE + 1);
+    if (prep_lds > 64 * 1024) {
+        set_error("node mode: %d entries exceed the prep kernel's LDS scan", NE);
+        return DEFT_EUNSUPPORTED;
+    }
+    hipLaunchKernelGGL(node_prep_kernel, dim3(1), dim3(256), prep_lds, st, node_kv_offset, node_kv_len, node_q_offset,
+                       node_q_len, NE, tiles, rows, ws.desc, ws.row_q);
+    rc = check_launch("node prep launch");
+    if (rc) return rc;
+
+    Stage1Params p{};
+    p.q = static_cast<const _Float16*>(q);
+    p.q_st = q_stride_tok;
+    p.q_sh = q_stride_head;
+    p.k = static_cast<const _Float16*>(k_base);
+    p.v = static_cast<const _Float16*>(v_base);
+    p.kv_ss = kv_stride_slot;
+    p.kv_sh = kv_stride_head;
+    p.node_kv = node_kv;
+    p.node_q = node_q;
+    p.desc = ws.desc;
+    p.partial_o = ws.partial_o;
+    p.partial_lse = ws.partial_lse;
+    p.row_q = ws.row_q;
+    p.rows = rows;
+    p.Hkv = Hkv;
+    p.G = Hq / Hkv;
+    p.scale_log2e = scale * LOG2E;
+    rc = dispatch_stage1<1>(D, p, tiles, st);
+    if (rc) return rc;
+    return launch_merge(D, ws, rows, out, o_stride_tok, o_stride_head, nq, Hq, st);
+}
+
+int deft_kv_append_f16(void* k_base, void* v_base, int64_t kv_stride_slot, int64_t kv_stride_head,
+                       const int32_t* cache_loc, const void* k_new, const void* v_new, int64_t new_stride_tok, int n,
+                       int Hkv, int D, void* stream) {
+    if (n == 0) return DEFT_OK;
+    if (!k_base || !v_base || !cache_loc || !k_new || !v_new || n < 0 || Hkv <= 0 || D <= 0 || (D % 8)) {
+        set_error("bad kv_append arguments (n=%d Hkv=%d D=%d)", n, Hkv, D);
+        return DEFT_EINVAL;
+    }
+    if (!aligned16(k_base) || !aligned16(v_base) || !aligned16(k_new) || !aligned16(v_new) || (kv_stride_slot % 8) ||
+        (kv_stride_head % 8) || (new_stride_tok % 8)) {
+        set_error("kv_append rows must be 16-byte aligned");
+        return DEFT_EINVAL;
+    }
+    const int64_t total = (int64_t)n * Hkv * (D / 8);
+    const int64_t blocks = (total + 255) / 256;
+    const unsigned grid = (unsigned)(blocks < 2048 ? blocks : 2048);
+    hipLaunchKernelGGL(kv_append_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<_Float16*>(k_base), static_cast<_Float16*>(v_base), kv_stride_slot, kv_stride_head,
+                       cache_loc, static_cast<const _Float16*>(k_new), static_cast<const _Float16*>(v_new),
+                       new_stride_tok, n, Hkv, D);
+    return check_launch("kv_append launch");
+}
+
+int deft_flatten_read_partials(const void* workspace, size_t workspace_bytes, int NB, int P, int nq, int Hq, int Hkv, int D,
+                               float* partial_o_dev, float* partial_lse_dev, void* stream) {
+    (void)NB;
+    (void)nq;
+    (void)Hkv;
+    if (!workspace || !partial_o_dev || !partial_lse_dev) {
+        set_error("null pointer");
+        return DEFT_EINVAL;
+    }
+    const Workspace ws = carve(const_cast<void*>(workspace), Hq, D, P, 0);
+    if (workspace_bytes < ws.bytes) {
+        set_error("workspace too small");
+        return DEFT_EWORKSPACE;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipError_t e = hipMemcpyAsync(partial_o_dev, ws.partial_o, sizeof(float) * (size_t)Hq * P * D, hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(partial_lse_dev, ws.partial_lse, sizeof(float) * (size_t)Hq * P, hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) {
+        set_error("hipMemcpyAsync: %s", hipGetErrorString(e));
+        return DEFT_EHIP;
+    }
+    return DEFT_OK;
+}
+
+}  // extern "C"

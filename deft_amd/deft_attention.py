@@ -1,0 +1,89 @@
+"""DeFTAttention: the nn.Module the Llama layers call (llama2.py:111), for the two
+DeFT decode modes.
+
+Mirrors DeFT/deft/layers/attention/deft_attention.py:
+  deft_node_forward     :72-108
+  deft_flatten_forward  :110-151
+  forward               :349-388   (dispatch on input_metadata.forward_mode)
+  store_kv_cache        :390-403
+
+The reference brackets both phases with `torch.cuda.synchronize()` timers
+(:117,126,135,149) and does a device-to-host `.item()` per layer for IO accounting
+(:88-91); none of that is on the device path here — a decode step is
+launch-only, so 32 layers can be replayed from one hipGraph.
+"""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from .forward_mode import ForwardMode, InputMetadata
+from .tree_attention import tree_attention_fwd, tree_attention_subtree_fwd
+from .tree_cache import get_global_tree_metadata
+
+
+class DeFTAttention(nn.Module):
+    def __init__(self, num_heads: int, head_dim: int, scaling: float, num_kv_heads: int, layer_id: int) -> None:
+        super().__init__()
+        self.tp_q_head_num = num_heads
+        self.tp_k_head_num = num_kv_heads
+        self.tp_v_head_num = num_kv_heads
+        self.scaling = scaling
+        self.head_dim = head_dim
+        self.layer_id = layer_id
+        if abs(scaling - head_dim ** -0.5) > 1e-6 * scaling:
+            # the reference kernels ignore `scaling` and always use 1/sqrt(head_dim) (tree_attention.py:102, :601)
+            raise ValueError("scaling must be head_dim ** -0.5, as the reference kernels assume")
+
+    def deft_node_forward(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor,
+                          input_metadata: InputMetadata) -> torch.Tensor:
+        k = k.view(-1, self.tp_k_head_num, self.head_dim)
+        v = v.view(-1, self.tp_v_head_num, self.head_dim)
+        o = torch.empty((q.shape[0], self.tp_q_head_num * self.head_dim), dtype=q.dtype, device=q.device)
+        self.store_kv_cache(k, v, input_metadata)
+        md = get_global_tree_metadata()
+        assert md is not None
+        assert input_metadata.token_to_kv_pool is not None
+        pool = input_metadata.token_to_kv_pool
+        tree_attention_fwd(
+            q.view(-1, self.tp_q_head_num, self.head_dim),
+            pool.get_key_buffer(self.layer_id),
+            pool.get_value_buffer(self.layer_id),
+            o.view(-1, self.tp_q_head_num, self.head_dim),
+            md.node_kv, md.node_kv_offset, md.node_kv_len,
+            md.node_q, md.node_q_offset, md.node_q_len,
+        )
+        return o
+
+    def deft_flatten_forward(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor,
+                             input_metadata: InputMetadata) -> torch.Tensor:
+        k = k.view(-1, self.tp_k_head_num, self.head_dim)
+        v = v.view(-1, self.tp_v_head_num, self.head_dim)
+        o = torch.empty((q.shape[0], self.tp_q_head_num * self.head_dim), dtype=q.dtype, device=q.device)
+        self.store_kv_cache(k, v, input_metadata)
+        md = get_global_tree_metadata()
+        assert md is not None
+        assert input_metadata.token_to_kv_pool is not None
+        pool = input_metadata.token_to_kv_pool
+        tree_attention_subtree_fwd(
+            q.view(-1, self.tp_q_head_num, self.head_dim),
+            pool.get_key_buffer(self.layer_id),
+            pool.get_value_buffer(self.layer_id),
+            o.view(-1, self.tp_q_head_num, self.head_dim),
+            md.block_len, md.block_q, md.block_q_cnts, md.block_q_offset,
+            md.block_bitmasks, md.block_kv, md.block_lens,
+        )
+        return o
+
+    def forward(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, input_metadata: InputMetadata) -> torch.Tensor:
+        mode = input_metadata.forward_mode
+        if mode == ForwardMode.TREE_DECODE_FLATTEN:
+            return self.deft_flatten_forward(q, k, v, input_metadata)
+        if mode == ForwardMode.TREE_DECODE_NODE:
+            return self.deft_node_forward(q, k, v, input_metadata)
+        raise NotImplementedError(
+            f"Unsupported forward mode: {mode} (deft_amd covers TREE_DECODE_FLATTEN and TREE_DECODE_NODE with paged KV)"
+        )
+
+    def store_kv_cache(self, cache_k: torch.Tensor, cache_v: torch.Tensor, input_metadata: InputMetadata) -> None:
+        input_metadata.kv_updater.update(self.layer_id, cache_k, cache_v)

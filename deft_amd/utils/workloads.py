@@ -1,0 +1,99 @@
+"""Synthetic decoding trees of the shapes BASELINE.json names, built with the
+product TreeCache in the reference's allocation order (prompt slots contiguous,
+then one `alloc()` per decode step handing consecutive slots to different leaves).
+
+Shapes follow the reference's branch functions
+(DeFT/deft/tree_decoding/generation/branch_func_example.py):
+  few_shot   SimpleTree :12-62 — root branches once into `width` leaves after
+             prefill, then every leaf grows one token per step
+  medusa     SpeculativeDecoding mock :374-442 — root + `tree_size` one-token leaves
+  tot        FromTreeTemplate :293-371 shaped like SURVEY §8d cfg4(i): root ->
+             7 x 128-token nodes -> 42 x 64-token leaves (50 live nodes)
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, Tuple
+
+import torch
+
+from ..memory_pool import ReqToTokenPool, TokenToKVPool
+from ..tree_cache import TreeCache
+
+# (Hq, Hkv, D, layers)
+GEOMETRY: Dict[str, Tuple[int, int, int, int]] = {
+    "llama2-7b": (32, 32, 128, 32),
+    "llama3-8b": (32, 8, 128, 32),
+}
+
+
+@dataclass
+class Workload:
+    name: str
+    model: str
+    mode: str  # "flatten" | "node"
+    kind: str  # few_shot | medusa | tot
+    prefix: int
+    width: int = 32
+    branch_len: int = 1
+
+
+WORKLOADS: Dict[str, Workload] = {
+    # north-star: Llama-2-7B, 4k shared prefix x 32 branches, DeFT-Flatten
+    "northstar_4kx32": Workload("northstar_4kx32", "llama2-7b", "flatten", "few_shot", 4096, 32, 200),
+    # BASELINE configs[1]: 1k shared prefix x 32 branches
+    "fewshot_1kx32": Workload("fewshot_1kx32", "llama2-7b", "flatten", "few_shot", 1024, 32, 200),
+    # configs[2]: Medusa depth-4 width-10 template as the reference mocks it (tree_size64), DeFT-Node
+    "medusa64_node": Workload("medusa64_node", "llama2-7b", "node", "medusa", 1016, 64, 1),
+    # configs[3]: Llama-3-8B ToT tree, 4k prefix, 50 nodes, DeFT-Flatten
+    "tot50_4k": Workload("tot50_4k", "llama3-8b", "flatten", "tot", 4096),
+    # configs[4]: one of the 64 independent 8k-prefix trees (8 branches x 64 tokens), Llama-3-8B
+    "forest_8kx8": Workload("forest_8kx8", "llama3-8b", "flatten", "few_shot", 8192, 8, 64),
+}
+
+
+def tree_tokens(w: Workload) -> int:
+    if w.kind == "few_shot":
+        return w.prefix + w.width * w.branch_len
+    if w.kind == "medusa":
+        return w.prefix + w.width
+    if w.kind == "tot":
+        return w.prefix + 7 * 128 + 42 * 64
+    raise ValueError(w.kind)
+
+
+def build_tree(w: Workload, layers: int, device: str, extra_slots: int = 256):
+    """Returns (tree, kv_pool).  The pool holds `layers` distinct per-layer KV arrays."""
+    Hq, Hkv, D, _ = GEOMETRY[w.model]
+    size = tree_tokens(w) + extra_slots
+    req = ReqToTokenPool(max(w.width, 64) + 8, size + 8, device=device)
+    pool = TokenToKVPool(size, torch.float16, Hkv, D, layers, device=device)
+    tree = TreeCache(torch.float16, Hkv, D, layers, req, pool, None, True, False)
+    tree.init_prompt(torch.arange(1, w.prefix + 1, dtype=torch.int32))
+
+    def step(n):
+        for _ in range(n):
+            for leaf in list(tree.leaves.values()):
+                leaf.append_token(7)
+            tree.alloc()
+
+    if w.kind == "few_shot":
+        tree.branch(tree.root, w.width)
+        step(w.branch_len)
+    elif w.kind == "medusa":
+        tree.branch(tree.root, w.width)
+        step(1)
+    elif w.kind == "tot":
+        tree.branch(tree.root, 7)
+        step(128)
+        for leaf in sorted(tree.leaves.values(), key=lambda n: n.id):
+            tree.branch(leaf, 6)
+        step(64)
+    else:
+        raise ValueError(w.kind)
+    return tree, pool
+
+
+def algorithmic_bytes(n_kv_tokens: int, nq: int, Hq: int, Hkv: int, D: int) -> int:
+    """unique KV read once (K and V, fp16) + Q read + O written."""
+    return 4 * n_kv_tokens * Hkv * D + 4 * nq * Hq * D

@@ -1,0 +1,69 @@
+"""CPU baseline timed by bench.py: PyTorch sequential attention on the host cores.
+
+Test/measurement infrastructure only (see oracle/__init__.py).  The reference has
+no CPU path (device="cuda" is hard-coded, DeFT/deft/memory_pool.py:13-16,57-65);
+BASELINE.json names "the reference's PyTorch-CPU sequential-attention path", which
+is the ground-truth recipe of DeFT/tests/model/test_DeFT_kernel.py:212-276, i.e.
+the semantics of the reference's `--mode seq` operator
+(DeFT/deft/layers/attention/token_attention.py:297-335):
+
+  for each leaf: gather its full root->leaf K and V rows from the paged pool
+  through the page table, then softmax(q K^T / sqrt(D)) V per head with GQA
+  `repeat_interleave` — here `torch.nn.functional.scaled_dot_product_attention`.
+
+Kind "port" (a restatement, not the reference's own binary).  It is a reported
+baseline, not the optimisation target.
+"""
+from __future__ import annotations
+
+import os
+import time
+from typing import Dict, Sequence
+
+import torch
+
+
+def sequential_attention_cpu(q: torch.Tensor, kv_layer: torch.Tensor, paths: Sequence[torch.Tensor]) -> torch.Tensor:
+    """q [nq,Hq,D], kv_layer [slots,2,Hkv,D] (CPU tensors), paths[i] = int64 slot list of leaf i."""
+    nq, Hq, D = q.shape
+    Hkv = kv_layer.shape[2]
+    group = Hq // Hkv
+    out = torch.empty_like(q)
+    for i, slots in enumerate(paths):
+        kv = kv_layer.index_select(0, slots)  # the page-table gather, [S,2,Hkv,D]
+        k = kv[:, 0].transpose(0, 1)  # [Hkv,S,D]
+        v = kv[:, 1].transpose(0, 1)
+        if group > 1:
+            k = k.repeat_interleave(group, dim=0)
+            v = v.repeat_interleave(group, dim=0)
+        o = torch.nn.functional.scaled_dot_product_attention(q[i].unsqueeze(1).unsqueeze(0), k.unsqueeze(0), v.unsqueeze(0))
+        out[i] = o[0, :, 0]
+    return out
+
+
+def time_cpu_baseline(q: torch.Tensor, kv_layer: torch.Tensor, paths, layers: int, budget_s: float = 20.0,
+                      dtype: torch.dtype = torch.float32) -> Dict[str, object]:
+    """Time ONE layer-step on the host (bounded by `budget_s`), extrapolate to `layers` layers."""
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    q = q.to(dtype)
+    kv_layer = kv_layer.to(dtype)
+    paths = [torch.as_tensor(p, dtype=torch.int64) for p in paths]
+    t0 = time.perf_counter()
+    sequential_attention_cpu(q, kv_layer, paths)  # warm-up, also sizes the sample
+    warm = time.perf_counter() - t0
+    reps = max(1, min(5, int(budget_s / max(warm, 1e-6)) - 1))
+    times = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        sequential_attention_cpu(q, kv_layer, paths)
+        times.append(time.perf_counter() - t0)
+    per_layer = min(times) if times else warm
+    nq = q.shape[0]
+    return {
+        "seconds_per_layer_step": per_layer,
+        "tokens_per_s": nq / (per_layer * layers),
+        "cores": cores,
+        "reps": reps,
+        "dtype": str(dtype).replace("torch.", ""),
+    }

@@ -1,0 +1,113 @@
+"""CPU tests of the product's host side: the C-ABI library loads and exports every
+symbol include/deft_amd.h declares, and the tree / pool / native metadata builder
+reproduce the reference's golden vectors bit for bit.  No GPU, no oracle."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import deft_amd
+from deft_amd._lib import EXPORTED, LIB_PATH
+from product_helpers import MD_FIELDS, md_numpy, product_metadata, product_tree
+from scenarios import SCENARIOS
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "deft_amd.h")).read()
+    declared = set(re.findall(r"\b(deft_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(EXPORTED), declared ^ set(EXPORTED)
+    so = ctypes.CDLL(LIB_PATH)
+    for name in declared:
+        assert hasattr(so, name), name
+    assert so.deft_abi_version() == 1
+
+
+def test_supported_geometries():
+    lib = deft_amd.lib
+    assert lib.deft_supported(32, 32, 128) == 1 and lib.deft_supported(32, 8, 128) == 1
+    assert lib.deft_supported(4, 4, 64) == 1
+    assert lib.deft_supported(32, 5, 128) == 0 and lib.deft_supported(32, 8, 96) == 0
+
+
+def test_argument_errors_are_reported_not_thrown():
+    lib = deft_amd.lib
+    rc = lib.deft_flatten_decode_f16(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 4, 4, 128, 0.1, 0, 0, 0)
+    assert rc == -1 and b"null" in lib.deft_last_error()
+    assert lib.deft_md_free(12345) == -1
+    assert lib.deft_md_build(0, 0, 0, 0, 0, 0, 32, 128, -1) == -1
+
+
+@pytest.mark.parametrize("name", list(SCENARIOS))
+def test_tree_state_matches_reference(name, golden):
+    g = golden(name)
+    tree = product_tree(name)
+    ids = sorted(tree.nodes)
+    assert ids == g["node_ids"].tolist()
+    assert [s for i in ids for s in tree.nodes[i].kv_indices] == g["node_kv_by_id"].tolist()
+    assert np.array_equal(tree.token_to_kv_pool.mem_state, g["pool_refcounts"])
+    assert sorted(tree.leaves) == g["leaf_ids"].tolist()
+
+
+@pytest.mark.parametrize("name", list(SCENARIOS))
+def test_native_metadata_bit_exact(name, golden):
+    g = golden(name)
+    tree = product_tree(name)
+    md = product_metadata(name, tree)
+    got = md_numpy(md)
+    for k in MD_FIELDS:
+        assert got[k].dtype == np.int64
+        assert np.array_equal(got[k], g[k]), k
+    assert [md.query_num, md.node_num, md.total_kv_len, md.block_len] == g["scalars"].tolist()
+    assert md.leaf_to_q == {int(l): i for i, l in enumerate(g["leaf_ids"])}
+
+
+def test_page_table_rows_are_root_to_leaf_paths():
+    """ReqToTokenPool rows (memory_pool.py:11-45) list each leaf's path slots in order."""
+    tree = product_tree("multilevel")
+    table = tree.req_to_token_pool.req_to_token
+    for leaf in tree.leaves.values():
+        path = tree.leaf_path_slots(leaf)
+        row = table[tree.leaf_to_req[leaf.id], : len(path)].tolist()
+        assert row == path
+
+
+def test_empty_node_is_rejected_like_upstream():
+    """The reference raises on a live node without KV (range() step 0, tree_cache.py:746-748)."""
+    tree = product_tree("cfgA_256x2")
+    kids = tree.branch(next(iter(tree.leaves.values())), 2)
+    kids[0].append_token(1)
+    kids[1].append_token(1)  # no alloc(): children have no slot yet
+    with pytest.raises(deft_amd.DeftLibraryError, match="no KV slot"):
+        deft_amd.TreeMetadata.from_tree_cache(tree, device="cpu")
+
+
+def test_pool_exhaustion_returns_none_like_upstream():
+    pool = deft_amd.TokenToKVPool(4, torch.float16, 1, 8, 1, device="cpu")
+    assert pool.alloc(3) is not None
+    assert pool.alloc(2) is None  # memory_pool.py:76-77
+    pool.free(np.array([1]))
+    assert pool.alloc(2).tolist() == [1, 3]  # lowest free slots first
+
+
+def test_out_of_scope_modes_fail_loudly():
+    with pytest.raises(NotImplementedError):
+        deft_amd.forward_mode_from_cli("seq")
+    with pytest.raises(NotImplementedError):
+        deft_amd.forward_mode_from_cli("flatten", "unpaged")
+    assert deft_amd.forward_mode_from_cli("deft_flatten") is deft_amd.ForwardMode.TREE_DECODE_FLATTEN
+    assert deft_amd.forward_mode_from_cli("deft_node") is deft_amd.ForwardMode.TREE_DECODE_NODE
+    with pytest.raises(NotImplementedError):
+        deft_amd.TreeCache(torch.float16, 1, 8, 1, None, None, None, use_paged_memory=False)
+
+
+def test_operators_refuse_cpu_tensors():
+    q = torch.zeros(1, 4, 128, dtype=torch.float16)
+    kv = torch.zeros(8, 4, 128, dtype=torch.float16)
+    i64 = torch.zeros(128, dtype=torch.int64)
+    with pytest.raises(deft_amd.DeftLibraryError, match="no CPU path"):
+        deft_amd.tree_attention_subtree_fwd(q, kv, kv, q.clone(), 128, i64[:1], i64[:1], i64[:1], i64, i64, i64[:1])
