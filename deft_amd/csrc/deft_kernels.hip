@@ -28,6 +28,8 @@
 //     one fp16 rounding.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "common.h"
 
 namespace deft {
@@ -69,6 +71,7 @@ struct Stage1Params {
     int64_t rows;  // partial rows per head (stride of partial_o / partial_lse)
     int Hkv, G;
     float scale_log2e;
+    int ablate;  // internal profiling knob (env DEFT_STAGE1_ABLATE): 1 no K/V loads, 2 no compute, 4 no PV
 };
 
 template <int D>
@@ -146,7 +149,7 @@ __global__ __launch_bounds__(256, 2) void stage1_kernel(Stage1Params p) {
 
     // ---- gather K and V rows of this KV head into LDS ---------------------------
     // wave w stages keys [32w, 32w+32): 16-byte pieces, CH lanes per row.
-    {
+    if (!(p.ablate & 1)) {
         constexpr int ITER = 32 * CH / 64;
         uintx4 kreg[ITER], vreg[ITER];
 #pragma unroll
@@ -171,6 +174,11 @@ __global__ __launch_bounds__(256, 2) void stage1_kernel(Stage1Params p) {
 
     const bool qvalid = c < cnt;
     const int64_t qrow = qvalid ? qrows[c] : 0;
+    if (p.ablate & 2) {
+        __syncthreads();
+        if (sK[tid] == (_Float16)12345.f) p.partial_lse[0] = 1.f;  // keeps the staging alive
+        return;
+    }
 
     for (int g = 0; g < p.G; ++g) {
         const int hq = kvh * p.G + g;
@@ -243,7 +251,7 @@ __global__ __launch_bounds__(256, 2) void stage1_kernel(Stage1Params p) {
         __syncthreads();
 
         // ---- O^T[d][query] = sum_key V[key][d] * P[query][key], 32 d-columns per wave ----
-        if (w < MB) {
+        if (w < MB && !(p.ablate & 4)) {
             floatx16 o;
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[r] = 0.f;
@@ -426,11 +434,14 @@ static int launch_stage1(const Stage1Params& p, int64_t tiles, hipStream_t strea
     }
     const int64_t grid = tiles * p.Hkv;
     if (grid <= 0) return DEFT_OK;
+    static const int ablate = getenv("DEFT_STAGE1_ABLATE") ? atoi(getenv("DEFT_STAGE1_ABLATE")) : 0;
+    Stage1Params pp = p;
+    pp.ablate = ablate;
     if (grid > 0x7fffffffLL) {
         set_error("stage1 grid too large: %lld", (long long)grid);
         return DEFT_EINVAL;
     }
-    hipLaunchKernelGGL((stage1_kernel<D, MODE>), dim3((unsigned)grid), dim3(256), SM::BYTES, stream, p);
+    hipLaunchKernelGGL((stage1_kernel<D, MODE>), dim3((unsigned)grid), dim3(256), SM::BYTES, stream, pp);
     return check_launch("stage1 launch");
 }
 
