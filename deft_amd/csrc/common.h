@@ -21,15 +21,18 @@ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 //   partial_lse [Hq][rows]    f32   log-sum-exp of each partial row (natural log)
 //   row_q       [rows]        i32   query row of each partial row, -1 = unused
 //   desc        [tiles][8]    i32   tile descriptors (Node mode only)
+//   plan        [NB+1][2048]  bytes Flatten plan records: row byte offsets, 32-bit masks, {cnt, prow,
+//                                   run_start, len} per block (stage1_stream.h)
 struct Workspace {
     float* partial_o;
     float* partial_lse;
     int32_t* row_q;
     int32_t* desc;
+    char* plan;          // [NB+1][2048] Flatten streaming plan records (stage1_stream.h)
     size_t bytes;
 };
 
-inline Workspace carve(void* base, int Hq, int D, int64_t rows, int64_t tiles) {
+inline Workspace carve(void* base, int Hq, int D, int64_t rows, int64_t tiles, int64_t NB = 0) {
     Workspace w;
     char* p = static_cast<char*>(base);
     size_t off = 0;
@@ -41,6 +44,8 @@ inline Workspace carve(void* base, int Hq, int D, int64_t rows, int64_t tiles) {
     off = align_up(off + sizeof(int32_t) * (size_t)rows, 256);
     w.desc = reinterpret_cast<int32_t*>(p + off);
     off = align_up(off + sizeof(int32_t) * 8 * (size_t)tiles, 256);
+    w.plan = p + off;
+    off = align_up(off + 2048 * (size_t)(NB + 1), 256);
     w.bytes = off;
     return w;
 }

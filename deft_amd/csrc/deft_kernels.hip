@@ -29,6 +29,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <cstring>
 
 #include "common.h"
 
@@ -285,6 +286,10 @@ __global__ __launch_bounds__(256, 2) void stage1_kernel(Stage1Params p) {
     }
 }
 
+}  // namespace deft
+#include "stage1_stream.h"
+namespace deft {
+
 // ---------------------------------------------------------------------------
 // Node mode: cut entries into 128-slot tiles (one workgroup, once per call)
 // ---------------------------------------------------------------------------
@@ -338,7 +343,9 @@ __global__ __launch_bounds__(256) void node_prep_kernel(const int64_t* node_kv_o
 // ---------------------------------------------------------------------------
 template <int D>
 __global__ __launch_bounds__(64) void merge_kernel(const float* partial_o, const float* partial_lse, const int32_t* row_q,
-                                                    int64_t rows, _Float16* out, int64_t o_st, int64_t o_sh) {
+                                                    int64_t rows, _Float16* out, int64_t o_st, int64_t o_sh,
+                                                    unsigned long long* dbg) {
+    if (dbg && threadIdx.x == 0) atomicMin(dbg + 65538, wall_clock64());
     constexpr int VEC = D / 64;  // output columns per lane
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int* sRows = reinterpret_cast<int*>(smem);  // matching partial rows, capacity `rows`
@@ -373,7 +380,9 @@ __global__ __launch_bounds__(64) void merge_kernel(const float* partial_o, const
         const float* po_h = partial_o + (int64_t)hq * rows * D + VEC * lane;
         for (int i = 0; i < n; ++i) {
             const int r = sRows[i];
-            const float wgt = __expf(lse_h[r] - m);
+            const float lse = lse_h[r];
+            if (lse == -INFINITY) continue;  // row folded into its group's partial (wave-uniform branch)
+            const float wgt = __expf(lse - m);
             L += wgt;
             const float* src = po_h + (int64_t)r * D;
 #pragma unroll
@@ -384,6 +393,7 @@ __global__ __launch_bounds__(64) void merge_kernel(const float* partial_o, const
     _Float16* dst = out + (int64_t)qi * o_st + (int64_t)hq * o_sh + VEC * lane;
 #pragma unroll
     for (int j = 0; j < VEC; ++j) dst[j] = (_Float16)(acc[j] * inv);
+    if (dbg && threadIdx.x == 0) atomicMax(dbg + 65539, wall_clock64());
 }
 
 // ---------------------------------------------------------------------------
@@ -410,6 +420,8 @@ __global__ __launch_bounds__(256) void kv_append_kernel(_Float16* k_base, _Float
 // ---------------------------------------------------------------------------
 // host-side launch helpers
 // ---------------------------------------------------------------------------
+static unsigned long long* g_stream_dbg = nullptr;  // internal profiling hook, see deft_debug_set_buffer
+
 static int check_launch(const char* what) {
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
@@ -445,6 +457,61 @@ static int launch_stage1(const Stage1Params& p, int64_t tiles, hipStream_t strea
     return check_launch("stage1 launch");
 }
 
+static int num_cus() {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    return cus;
+}
+
+// Flatten stage 1, streaming form (MHA, head_dim 128).  `plan` is workspace memory.
+static int launch_stage1_stream(const Stage1Params& p, int NB, char* plan, hipStream_t stream) {
+    using SM = StreamSmem<128>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&stage1_stream_kernel<128>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, SM::BYTES);
+        if (e != hipSuccess) {
+            set_error("hipFuncSetAttribute(stage1_stream): %s", hipGetErrorString(e));
+            return DEFT_EHIP;
+        }
+        attr_set = true;
+    }
+    if (NB <= 0) return DEFT_OK;
+    hipLaunchKernelGGL(flatten_plan_kernel, dim3((unsigned)(NB + 1)), dim3(128), 0, stream, p.block_q, p.block_q_cnts,
+                       p.block_q_offset, p.block_bitmasks, p.block_kv, p.block_lens, NB, (int)p.rows, p.kv_ss, plan,
+                       p.row_q, g_stream_dbg);
+    int rc = check_launch("flatten plan launch");
+    if (rc) return rc;
+    static const int wg_per_cu = getenv("DEFT_STREAM_WG_PER_CU") ? atoi(getenv("DEFT_STREAM_WG_PER_CU")) : 2;
+    const int64_t U = (int64_t)NB * p.Hkv;
+    int64_t workers = (int64_t)num_cus() * wg_per_cu;
+    if (workers > U) workers = U;
+    StreamParams sp{};
+    sp.s = p;
+    sp.s.ablate = getenv("DEFT_STAGE1_ABLATE") ? atoi(getenv("DEFT_STAGE1_ABLATE")) : 0;
+    sp.plan = plan;
+    sp.NB = NB;
+    sp.dbg = g_stream_dbg;
+    sp.per = (int)(U / workers);
+    sp.rem = (int)(U % workers);
+    static bool printed = false;
+    if (!printed && getenv("DEFT_DEBUG")) {
+        printed = true;
+        int nb = -1;
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, stage1_stream_kernel<128>, 512, SM::BYTES);
+        fprintf(stderr, "[deft] stream kernel: %d workgroups/CU by the occupancy API (%s), LDS %d B, workers %lld, CUs %d\n", nb,
+                hipGetErrorString(e), SM::BYTES, (long long)workers, num_cus());
+    }
+    hipLaunchKernelGGL((stage1_stream_kernel<128>), dim3((unsigned)workers), dim3(512), SM::BYTES, stream, sp);
+    return check_launch("stage1 stream launch");
+}
+
 template <int MODE>
 static int dispatch_stage1(int D, const Stage1Params& p, int64_t tiles, hipStream_t stream) {
     if (D == 128) return launch_stage1<128, MODE>(p, tiles, stream);
@@ -464,10 +531,10 @@ static int launch_merge(int D, const Workspace& ws, int64_t rows, void* out, int
     dim3 grid((unsigned)nq, (unsigned)Hq);
     if (D == 128)
         hipLaunchKernelGGL((merge_kernel<128>), grid, dim3(64), lds, stream, ws.partial_o, ws.partial_lse, ws.row_q, rows,
-                           static_cast<_Float16*>(out), o_st, o_sh);
+                           static_cast<_Float16*>(out), o_st, o_sh, g_stream_dbg);
     else
         hipLaunchKernelGGL((merge_kernel<64>), grid, dim3(64), lds, stream, ws.partial_o, ws.partial_lse, ws.row_q, rows,
-                           static_cast<_Float16*>(out), o_st, o_sh);
+                           static_cast<_Float16*>(out), o_st, o_sh, g_stream_dbg);
     return check_launch("merge launch");
 }
 
@@ -506,13 +573,16 @@ extern "C" {
 
 int deft_abi_version(void) { return 1; }
 
+// Internal profiling hook (not part of the public header): device buffer of
+// workers*16*8 u64 receiving s_memtime stamps of the streaming kernel's phases.
+void deft_debug_set_buffer(void* dev_ptr) { g_stream_dbg = static_cast<unsigned long long*>(dev_ptr); }
+
 int deft_supported(int Hq, int Hkv, int D) { return (Hq > 0 && Hkv > 0 && Hq % Hkv == 0 && (D == 64 || D == 128)) ? 1 : 0; }
 
 size_t deft_flatten_workspace_bytes(int NB, int P, int nq, int Hq, int Hkv, int D) {
-    (void)NB;
     (void)nq;
     (void)Hkv;
-    return carve(nullptr, Hq, D, P, 0).bytes;
+    return carve(nullptr, Hq, D, P, 0, NB).bytes;
 }
 
 size_t deft_node_workspace_bytes(int NE, int P, int64_t total_kv, int nq, int Hq, int Hkv, int D) {
@@ -537,7 +607,7 @@ int deft_flatten_stage1_f16(const void* q, int64_t q_stride_tok, int64_t q_strid
         set_error("bad Flatten metadata (NB=%d P=%d)", NB, P);
         return DEFT_EINVAL;
     }
-    const Workspace ws = carve(workspace, Hq, D, P, 0);
+    const Workspace ws = carve(workspace, Hq, D, P, 0, NB);
     if (workspace_bytes < ws.bytes) {
         set_error("workspace too small: %zu < %zu", workspace_bytes, ws.bytes);
         return DEFT_EWORKSPACE;
@@ -563,6 +633,9 @@ int deft_flatten_stage1_f16(const void* q, int64_t q_stride_tok, int64_t q_strid
     p.Hkv = Hkv;
     p.G = Hq / Hkv;
     p.scale_log2e = scale * LOG2E;
+    // streaming form for MHA / head_dim 128 (env DEFT_STAGE1_VARIANT=tile forces the tile-per-workgroup form)
+    static const bool force_tile = getenv("DEFT_STAGE1_VARIANT") && !strcmp(getenv("DEFT_STAGE1_VARIANT"), "tile");
+    if (D == 128 && p.G == 1 && !force_tile) return launch_stage1_stream(p, NB, ws.plan, static_cast<hipStream_t>(stream));
     return dispatch_stage1<0>(D, p, NB, static_cast<hipStream_t>(stream));
 }
 
@@ -583,7 +656,7 @@ int deft_flatten_decode_f16(const void* q, int64_t q_stride_tok, int64_t q_strid
                                  block_q_cnts, block_q_offset, block_bitmasks, block_kv, block_lens, NB, P, nq, Hq, Hkv, D,
                                  scale, workspace, workspace_bytes, stream);
     if (rc) return rc;
-    const Workspace ws = carve(workspace, Hq, D, P, 0);
+    const Workspace ws = carve(workspace, Hq, D, P, 0, NB);
     return launch_merge(D, ws, P, out, o_stride_tok, o_stride_head, nq, Hq, static_cast<hipStream_t>(stream));
 }
 
@@ -671,14 +744,13 @@ int deft_kv_append_f16(void* k_base, void* v_base, int64_t kv_stride_slot, int64
 
 int deft_flatten_read_partials(const void* workspace, size_t workspace_bytes, int NB, int P, int nq, int Hq, int Hkv, int D,
                                float* partial_o_dev, float* partial_lse_dev, void* stream) {
-    (void)NB;
     (void)nq;
     (void)Hkv;
     if (!workspace || !partial_o_dev || !partial_lse_dev) {
         set_error("null pointer");
         return DEFT_EINVAL;
     }
-    const Workspace ws = carve(const_cast<void*>(workspace), Hq, D, P, 0);
+    const Workspace ws = carve(const_cast<void*>(workspace), Hq, D, P, 0, NB);
     if (workspace_bytes < ws.bytes) {
         set_error("workspace too small");
         return DEFT_EWORKSPACE;

@@ -1,0 +1,442 @@
+// Flatten stage 1, streaming form: persistent workgroups, LDS-DMA pipeline.
+//
+// Included by deft_kernels.hip (needs its typedefs and Stage1Params).
+//
+// Why a second form of stage 1: the tile-per-workgroup kernel (stage1_kernel) pays
+// three dependent HBM round trips per tile (descriptor -> slot list -> K/V rows)
+// with only two workgroups per CU to hide them, spends ~1400 instructions per wave
+// per tile, and writes one fp32 partial per (tile, head).  Here
+//   * a plan kernel (once per call, or once per decode step when the caller caches
+//     the plan) packs each block's metadata into one 2 KB record: the byte offset
+//     of every KV row in the pool, a 32-bit query mask per slot (0 for padding) and
+//     {cnt, prow, run_start, len};
+//   * a fixed grid of workgroups (2 per CU) each walks a contiguous span of the
+//     (KV head, tile) sequence, head-major.  A workgroup is 4 compute waves + 4
+//     LOADER waves: only the loaders issue DMA, so the compute waves never stall on
+//     a full memory queue (measured: with compute waves issuing their own DMA, half
+//     of every tile's time was spent blocked in the issue of 16 instructions), and a
+//     1 KB DMA instruction costs ~90 cycles to issue, so a tile's 64 are spread over
+//     four waves;
+//   * K and V tiles travel HBM -> LDS by `global_load_lds_dwordx4` (no VGPR
+//     round trip).  K(i+1) is issued as soon as the S^T MFMAs of tile i are done and
+//     V(i+1) as soon as its PV MFMAs are done, so a tile's softmax/PV time hides the
+//     next K and its QK^T/softmax time hides the next V.  The 2 KB plan record of
+//     tile i+2 rides the same DMA queue;
+//   * V^T MFMA fragments come from `ds_read_b64_tr_b16` (2 reads per fragment
+//     instead of 8 16-bit reads + 4 permutes); V is stored with its 16-byte chunks
+//     XOR-ed by 4*(key&3) so the four rows a transpose-read touches sit in different
+//     bank groups, K with chunks XOR-ed by key&15 for the row-per-lane b128 reads;
+//   * consecutive tiles of one head whose query list is identical (the whole shared
+//     prefix of a few-shot tree) are folded with an online softmax in registers
+//     and emit ONE partial, which cuts the fp32 partial traffic of the reference
+//     (17-19 MB per layer-step on the 4k x 32 tree) to a few MB.
+//
+// All DMA issue and all waits on it are inline asm: hipcc neither counts asm VMEM
+// operations nor drains them at a raw s_barrier, which is what lets loads stay in
+// flight across barriers (cdna_hip_programming.md §5.7, "Pipelining across barriers").
+// Wait arithmetic (per loader wave, LPT = its DMA instructions per K or V tile = 32*D/8/64):
+//   issue order   ... K(i) | meta(i+1) V(i) | K(i+1) | meta(i+2) V(i+1) | ...
+//   "K(i) and meta(i+1) landed"  <=>  at most V(i)    outstanding  -> vmcnt(LPT)
+//   "V(i) landed"                <=>  at most K(i+1)  outstanding  -> vmcnt(LPT)
+//   last tile of the span: nothing younger was issued               -> vmcnt(0)
+// Stores are never counted (they may retire early; over-waiting is safe).
+#pragma once
+
+namespace deft {
+
+typedef int32_t intx4 __attribute__((ext_vector_type(4)));
+typedef short short4v __attribute__((ext_vector_type(4)));
+
+// One plan record per Flatten block (+ a sentinel record at index NB):
+constexpr int PLAN_BYTES = 2048;
+constexpr int PLAN_ROWOFF = 0;   // int64[128]  byte offset of each slot's row in the pool (pads alias slot 0)
+constexpr int PLAN_MASK = 1024;  // uint32[128] query bitmask per slot (0 for pads)
+constexpr int PLAN_DESC = 1536;  // int32[4]    cnt, prow, run_start, len
+constexpr int PLAN_QROW = 1600;  // int32[32]   query row of each of the block's partial rows (0 beyond cnt)
+
+struct StreamParams {
+    Stage1Params s;
+    const char* plan;  // [NB+1][PLAN_BYTES]
+    int NB;
+    int per, rem;  // workgroup b owns per + (b < rem) consecutive units of the NB*Hkv head-major sequence
+    unsigned long long* dbg;  // internal: per-phase s_memtime stamps [workgroup][16 tiles][8], or null
+};
+
+template <int D>
+struct StreamSmem {
+    static constexpr int K_OFF = 0;
+    static constexpr int V_OFF = K_OFF + TILE * D * 2;
+    static constexpr int P_OFF = V_OFF + TILE * D * 2;
+    static constexpr int META_OFF = P_OFF + MQ * TILE * 2;  // 2 plan records
+    static constexpr int WMAX_OFF = META_OFF + 2 * PLAN_BYTES;
+    static constexpr int WSUM_OFF = WMAX_OFF + 4 * MQ * 4;
+    static constexpr int BYTES = WSUM_OFF + 4 * MQ * 4;
+};
+
+// 64 lanes x 16 bytes, global (per-lane address) -> LDS (lds_dst + 16*lane).  M0 is not
+// otherwise used by this kernel (checked in the .s), so it is written, not saved.
+__device__ __forceinline__ void dma16(const void* gsrc, uint32_t lds_dst) {
+    asm volatile(
+        "s_mov_b32 m0, %1\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %0, off"
+        :
+        : "v"(gsrc), "s"(lds_dst)
+        : "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int D>
+__global__ __launch_bounds__(512, 4) void stage1_stream_kernel(StreamParams sp) {
+    constexpr int CH = D / 8;
+    constexpr int KS = D / 16;
+    constexpr int DPT = 32 * CH / 64;  // DMA instructions per 32-key slice of a K (or V) tile
+    constexpr int LPT = DPT;           // per loader wave: one slice (4 loaders)
+    static_assert(D == 128, "streaming stage 1 is instantiated for head_dim 128");
+    using SM = StreamSmem<D>;
+    const Stage1Params& p = sp.s;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    _Float16* sP = reinterpret_cast<_Float16*>(smem + SM::P_OFF);
+    float* sWmax = reinterpret_cast<float*>(smem + SM::WMAX_OFF);
+    float* sWsum = reinterpret_cast<float*>(smem + SM::WSUM_OFF);
+
+    const int tid = threadIdx.x;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l = tid & 63;
+    const int c = l & 31;
+    const int h = l >> 5;
+
+    // span of this workgroup in the head-major (KV head, tile) sequence
+    const int bid = blockIdx.x;
+    const int u0 = bid * sp.per + min(bid, sp.rem);
+    const int n_units = sp.per + (bid < sp.rem ? 1 : 0);
+    if (n_units <= 0) return;
+    int kvh = u0 / sp.NB;
+    int t = u0 - kvh * sp.NB;
+
+    // ---- loop-invariant lane constants -------------------------------------------------
+    // DMA: instruction i of a tile stages keys 32w + 4i + (l>>4), LDS chunk position l&15.
+    //   K source chunk = pos ^ (key & 15) = (pos ^ (l>>4)) ^ 4*(i&3);  V source chunk = pos ^ 4*(key&3)
+    const int dpos = l & 15, dkey = l >> 4;
+    int kchunk_b[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) kchunk_b[j] = ((dpos ^ dkey) ^ (4 * j)) * 16;
+    const int vchunk_b = (dpos ^ (4 * (dkey & 3))) * 16;
+    const bool is_loader = w >= 4;  // waves 4..7 stream; waves 0..3 compute
+    const int lw = w - 4;           // loader lw stages keys [32 lw, 32 lw + 32)
+    const uint32_t ldsK = SM::K_OFF + (uint32_t)(lw < 0 ? 0 : lw) * 32u * D * 2u;
+    const uint32_t ldsV = SM::V_OFF + (uint32_t)(lw < 0 ? 0 : lw) * 32u * D * 2u;
+    // S^T A fragments: row 32w + c, chunk (2ks + h) ^ (c & 15)  ->  byte (((h ^ c) & 15) * 16) ^ (32 * ks)
+    const int krow_b = (32 * w + c) * D * 2;
+    const int kcol_b = ((h ^ c) & 15) * 16;
+    // O^T A fragments (transpose reads): lane (g = l>>4, x = l&15) supplies 8 bytes of row
+    //   16ks + 8(g>>1) + (x>>2) [+4], d = 32w + 16(g&1) + 4(x&3), chunk XOR-ed by 4*(row & 3) = 4*(x>>2)
+    const int tg = l >> 4, tx = l & 15;
+    const int vtr_b = SM::V_OFF + (8 * (tg >> 1) + (tx >> 2)) * D * 2 +
+                      (((4 * w + 2 * (tg & 1) + ((tx & 3) >> 1)) ^ (4 * (tx >> 2))) * 16) + (tx & 1) * 8;
+    // P: row c, 16-byte chunks XOR-ed by (c & 15)
+    const int prow_b = SM::P_OFF + c * TILE * 2;
+
+    auto meta = [&](int b) { return smem + SM::META_OFF + b * PLAN_BYTES; };
+    auto issue_meta = [&](int tt, int b) {  // one 1 KB DMA by each of loaders 0 and 1
+        const char* rec = sp.plan + (int64_t)tt * PLAN_BYTES;
+        if (lw < 2) dma16(rec + 1024 * lw + 16 * l, SM::META_OFF + (uint32_t)b * PLAN_BYTES + 1024u * (uint32_t)lw);
+    };
+    int64_t rowoff[LPT];  // pool byte offsets of this loader lane's LPT rows of the NEXT tile (set at D, reused at I)
+    auto load_rowoff = [&](int b) {
+        const int64_t* ro = reinterpret_cast<const int64_t*>(meta(b) + PLAN_ROWOFF);
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) rowoff[i] = ro[32 * lw + 4 * i + dkey];
+    };
+    auto issue_k = [&](int head) {
+        const char* hb = reinterpret_cast<const char*>(p.k) + (int64_t)head * p.kv_sh * 2;
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) dma16(hb + rowoff[i] + kchunk_b[i & 3], ldsK + (uint32_t)i * 1024u);
+    };
+    auto issue_v = [&](int head) {
+        const char* hb = reinterpret_cast<const char*>(p.v) + (int64_t)head * p.kv_sh * 2 + vchunk_b;
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) dma16(hb + rowoff[i], ldsV + (uint32_t)i * 1024u);
+    };
+    auto read_desc = [&](int b) {  // {cnt, prow, run_start, len}, wave-uniform
+        intx4 d = *reinterpret_cast<const intx4*>(meta(b) + PLAN_DESC);
+        intx4 r;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[j] = __builtin_amdgcn_readfirstlane(d[j]);
+        return r;
+    };
+    auto next_tile = [&](int tt) { return tt + 1 == sp.NB ? 0 : tt + 1; };
+    auto stamp = [&](int i, int k) {
+        if (sp.dbg && tid == 0 && i < 16) sp.dbg[((int64_t)bid * 16 + i) * 8 + k] = __builtin_amdgcn_s_memtime();
+    };
+
+    // Q rows of the group that opens at a tile: the loaders stage them in the P buffer, which is idle
+    // between a tile's PV reads (barrier H) and the next tile's P writes (after barrier C).
+    // Layout like K: row c, 16-byte chunks XOR-ed by (c & 15).  Rows beyond cnt alias query row 0
+    // (their mask bits are 0).  2 DMA instructions per loader.
+    auto issue_q = [&](int b, int head) {
+        const int32_t* qr = reinterpret_cast<const int32_t*>(meta(b) + PLAN_QROW);
+        const char* hb = reinterpret_cast<const char*>(p.q) + (int64_t)head * p.q_sh * 2;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = 8 * lw + 4 * i + dkey;
+            const int chunk = dpos ^ (row & 15);
+            dma16(hb + (int64_t)qr[row] * p.q_st * 2 + chunk * 16, SM::P_OFF + (uint32_t)(8 * lw + 4 * i) * 256u);
+        }
+    };
+
+    if (sp.dbg && tid == 0) sp.dbg[((int64_t)bid * 16 + 15) * 8 + 6] = wall_clock64();
+    // ---- prologue -----------------------------------------------------------------
+    if (is_loader) {
+        issue_meta(t, 0);
+        wait_vm<0>();
+    }
+    lds_barrier();
+    if (is_loader) {
+        load_rowoff(0);
+        issue_k(kvh);
+        issue_q(0, kvh);  // the first tile of a span always opens a group
+        if (n_units > 1) issue_meta(next_tile(t), 1);
+        issue_v(kvh);
+
+        // ---- loader loop: same barrier sequence as the compute waves below ---------------
+        for (int i = 0; i < n_units; ++i) {
+            const int mb = i & 1;
+            const int t_next = next_tile(t);
+            const int kvh_next = (t + 1 == sp.NB) ? kvh + 1 : kvh;
+            const bool last = (i + 1 == n_units);
+            wait_vm<LPT>();  // A: K(u) and plan record (u+1) landed
+            lds_barrier();
+            lds_barrier();   // C: compute waves are done with sK
+            if (!last) {
+                load_rowoff(mb ^ 1);
+                issue_k(kvh_next);
+            }
+            if (last) wait_vm<0>(); else wait_vm<LPT>();  // F: V(u) landed
+            lds_barrier();
+            lds_barrier();   // H: compute waves are done with sV and sP
+            if (!last) {
+                const bool next_opens = (t + 1 == sp.NB) || (read_desc(mb ^ 1)[2] != 0);
+                if (next_opens) issue_q(mb ^ 1, kvh_next);
+                if (i + 2 < n_units) issue_meta(next_tile(t_next), mb);
+                issue_v(kvh_next);
+            }
+            t = t_next;
+            kvh = kvh_next;
+        }
+        return;
+    }
+
+    // running state of the current group (query row c of this lane)
+    half8 qf[KS];
+    float m_run = -INFINITY, l_run = 0.f;
+    floatx16 o;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = 0.f;
+    int g_prow = 0;
+    bool qvalid = false;
+
+    for (int i = 0; i < n_units; ++i) {
+        const int mb = i & 1;  // plan record buffer of this unit
+        const int hq = kvh;    // G == 1
+        const int t_next = next_tile(t);
+        const int kvh_next = (t + 1 == sp.NB) ? kvh + 1 : kvh;
+        const bool last = (i + 1 == n_units);
+        const intx4 cur = read_desc(mb);
+        const bool g_start = (i == 0) || (t == 0) || (cur[2] != 0);
+
+        // ---- A: K(u) and plan record (u+1) landed ------------------------------------
+        stamp(i, 0);
+        lds_barrier();
+        stamp(i, 1);
+        if (g_start) {  // new group: its Q rows sit in the P buffer (staged by the loaders)
+            g_prow = cur[1];
+            qvalid = c < cur[0];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                qf[ks] = *reinterpret_cast<const half8*>(smem + prow_b + (((2 * ks + h) ^ (c & 15)) * 16));
+            m_run = -INFINITY;
+            l_run = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[r] = 0.f;
+        }
+        bool g_end = true;  // plan record (u+1) is visible now
+        if (!last) g_end = (t + 1 == sp.NB) || (read_desc(mb ^ 1)[2] != 0);
+
+        // ---- B: S^T for this wave's 32 keys, scale, mask, row max --------------------
+        floatx16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const half8 a = *reinterpret_cast<const half8*>(smem + SM::K_OFF + krow_b + (kcol_b ^ (32 * ks)));
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qf[ks], acc, 0, 0, 0);
+        }
+        float s[16];
+        float mx = -INFINITY;
+        {
+            const uint32_t* masks = reinterpret_cast<const uint32_t*>(meta(mb) + PLAN_MASK);
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const uintx4 m4 = *reinterpret_cast<const uintx4*>(masks + 32 * w + 8 * g4 + 4 * h);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int r = 4 * g4 + j;
+                    s[r] = ((m4[j] >> c) & 1u) ? acc[r] * p.scale_log2e : -INFINITY;
+                    mx = fmaxf(mx, s[r]);
+                }
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        if (h == 0) sWmax[w * MQ + c] = mx;
+
+        // ---- C: every wave is done with sK; tile maxima visible -------------------------
+        stamp(i, 2);
+        lds_barrier();
+        stamp(i, 3);
+
+        // ---- D: (loaders) K(u+1) streams in while this tile's softmax and PV run ------------
+
+        // ---- E: online softmax update, P (fp16) -> LDS -----------------------------------
+        const float m_tile = fmaxf(fmaxf(sWmax[c], sWmax[MQ + c]), fmaxf(sWmax[2 * MQ + c], sWmax[3 * MQ + c]));
+        const float m_new = fmaxf(m_run, m_tile);
+        const float msafe = (m_new == -INFINITY) ? 0.f : m_new;
+        const float alpha = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run - msafe);
+        float sum = 0.f;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            half4 p4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const _Float16 ph = (_Float16)__builtin_amdgcn_exp2f(s[4 * g4 + j] - msafe);
+                p4[j] = ph;
+                sum += (float)ph;
+            }
+            const int pos = (4 * w + g4) ^ (c & 15);
+            *reinterpret_cast<half4*>(sP + c * TILE + pos * 8 + 4 * h) = p4;
+        }
+        sum += __shfl_xor(sum, 32);
+        if (h == 0) sWsum[w * MQ + c] = sum;
+
+        // ---- F: V(u) landed; P and row sums visible ----------------------------------------
+        stamp(i, 4);
+        lds_barrier();
+        stamp(i, 5);
+
+        // ---- G: O^T = alpha * O^T + V^T P^T, 32 output columns per wave --------------------
+        {
+            const float tile_sum = sWsum[c] + sWsum[MQ + c] + sWsum[2 * MQ + c] + sWsum[3 * MQ + c];
+            l_run = l_run * alpha + tile_sum;
+            m_run = m_new;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[r] *= alpha;
+#pragma unroll
+            for (int ks = 0; ks < TILE / 16; ++ks) {
+                typedef __attribute__((address_space(3))) short4v* lds_s4;
+                const short4v a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(uintptr_t)(vtr_b + (16 * ks) * D * 2));
+                const short4v a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(uintptr_t)(vtr_b + (16 * ks + 4) * D * 2));
+                union {
+                    short4v s4[2];
+                    half8 h8;
+                } av;
+                av.s4[0] = a0;
+                av.s4[1] = a1;
+                const half8 b = *reinterpret_cast<const half8*>(smem + prow_b + (((2 * ks + h) ^ (c & 15)) * 16));
+                o = __builtin_amdgcn_mfma_f32_32x32x16_f16(av.h8, b, o, 0, 0, 0);
+            }
+        }
+
+        // ---- H: every wave is done with sV and sP ---------------------------------------------
+        stamp(i, 6);
+        lds_barrier();
+        stamp(i, 7);
+
+        // ---- I: (loaders) plan record (u+2) and V(u+1) stream in during the next tile's QK^T / softmax
+
+        // ---- J: bookkeeping for the merge; partial out at the end of a group --------------------
+        if (!(p.ablate & 8) && !g_start && qvalid && w == 0 && h == 0)
+            p.partial_lse[(int64_t)hq * p.rows + cur[1] + c] = -INFINITY;  // row folded into its group's partial
+        if (!(p.ablate & 16) && g_end && qvalid) {
+            const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+            const int64_t prow_idx = (int64_t)hq * p.rows + g_prow + c;
+            float* po = p.partial_o + prow_idx * D + 32 * w + 4 * h;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                floatx4 v4 = {o[4 * g4] * inv, o[4 * g4 + 1] * inv, o[4 * g4 + 2] * inv, o[4 * g4 + 3] * inv};
+                *reinterpret_cast<floatx4*>(po + 8 * g4) = v4;
+            }
+            if (w == 0 && h == 0)
+                p.partial_lse[prow_idx] = (l_run > 0.f) ? (m_run + __builtin_amdgcn_logf(l_run)) * LN2 : -INFINITY;
+        }
+        t = t_next;
+        kvh = kvh_next;
+    }
+    if (sp.dbg && tid == 0) sp.dbg[((int64_t)bid * 16 + 15) * 8 + 7] = wall_clock64();
+}
+
+// Packs the plan records (see PLAN_* above) and the partial-row -> query map; one workgroup
+// of 128 threads per block, block NB is the sentinel record.
+__global__ __launch_bounds__(128) void flatten_plan_kernel(const int64_t* block_q, const int64_t* block_q_cnts,
+                                                           const int64_t* block_q_offset, const int64_t* block_bitmasks,
+                                                           const int64_t* block_kv, const int64_t* block_lens, int NB, int P,
+                                                           int64_t kv_stride_slot, char* plan, int32_t* row_q,
+                                                           unsigned long long* dbg) {
+    const int t = blockIdx.x;
+    const int k = threadIdx.x;
+    struct Stamp {  // internal profiling: first start / last end of this kernel on the 100 MHz clock
+        unsigned long long* d;
+        bool on;
+        __device__ Stamp(unsigned long long* dd, bool o) : d(dd), on(o) { if (on) atomicMin(d + 65536, wall_clock64()); }
+        __device__ ~Stamp() { if (on) atomicMax(d + 65537, wall_clock64()); }
+    } stamp_(dbg, dbg != nullptr && k == 0);
+    char* rec = plan + (int64_t)t * PLAN_BYTES;
+    int64_t* ro = reinterpret_cast<int64_t*>(rec + PLAN_ROWOFF);
+    uint32_t* mk = reinterpret_cast<uint32_t*>(rec + PLAN_MASK);
+    int32_t* desc = reinterpret_cast<int32_t*>(rec + PLAN_DESC);
+    if (t >= NB) {  // sentinel
+        ro[k] = 0;
+        mk[k] = 0u;
+        if (k == 0) {
+            desc[0] = 0;
+            desc[1] = P;
+            desc[2] = 1;
+            desc[3] = 0;
+        }
+        return;
+    }
+    const int len = (int)block_lens[t];
+    const int cnt = (int)block_q_cnts[t];
+    const int prow = (int)block_q_offset[t];
+    const bool live = k < len;
+    ro[k] = block_kv[(int64_t)t * TILE + (live ? k : 0)] * kv_stride_slot * 2;  // fp16 bytes
+    mk[k] = live ? (uint32_t)block_bitmasks[(int64_t)t * TILE + k] : 0u;
+    __shared__ int s_diff;
+    if (k == 0) s_diff = (t == 0) ? 1 : 0;
+    __syncthreads();
+    if (t > 0 && k < MQ) {
+        const int cntp = (int)block_q_cnts[t - 1];
+        bool differ = (cnt != cntp);
+        if (!differ && k < cnt) differ = block_q[prow + k] != block_q[block_q_offset[t - 1] + k];
+        if (differ) s_diff = 1;  // benign race: every writer stores 1
+    }
+    if (k < MQ) {
+        const int32_t qv = (k < cnt) ? (int32_t)block_q[prow + k] : 0;
+        reinterpret_cast<int32_t*>(rec + PLAN_QROW)[k] = qv;
+        if (k < cnt) row_q[prow + k] = qv;
+    }
+    __syncthreads();
+    if (k == 0) {
+        desc[0] = cnt;
+        desc[1] = prow;
+        desc[2] = s_diff;
+        desc[3] = len;
+    }
+}
+
+}  // namespace deft
