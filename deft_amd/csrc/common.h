@@ -44,12 +44,33 @@ inline Workspace carve(void* base, int Hq, int D, int64_t rows, int64_t tiles, i
     off = align_up(off + sizeof(int32_t) * (size_t)rows, 256);
     w.desc = reinterpret_cast<int32_t*>(p + off);
     off = align_up(off + sizeof(int32_t) * 8 * (size_t)tiles, 256);
-    w.plan = p + off;
-    off = align_up(off + 2048 * (size_t)(NB + 1), 256);
+    w.plan = p + off;  // a whole PlanView when the caller passes no plan
+    off = align_up(off + 2048 * (size_t)(NB + 1) + 768 + sizeof(int32_t) * (size_t)(rows > 0 ? rows : 1), 256);
     w.bytes = off;
     return w;
 }
 
 inline int64_t node_max_tiles(int NE, int64_t total_kv) { return (int64_t)NE + total_kv / DEFT_BLOCK_LEN; }
+
+// Flatten plan buffer: [NB+1] records of 2048 B, row_q[P] (i32), then the stream scheduler's two
+// words {ticket counter, workgroups done} (zero between launches)
+struct PlanView {
+    char* records;
+    int32_t* row_q;
+    int32_t* sched;
+    size_t bytes;
+};
+inline PlanView plan_view(void* base, int64_t NB, int64_t P) {
+    PlanView v;
+    char* p = static_cast<char*>(base);
+    v.records = p;
+    size_t off = align_up(2048 * (size_t)(NB + 1), 256);
+    v.row_q = reinterpret_cast<int32_t*>(p + off);
+    off = align_up(off + sizeof(int32_t) * (size_t)(P > 0 ? P : 1), 256);
+    v.sched = reinterpret_cast<int32_t*>(p + off);
+    off += 256;
+    v.bytes = off;
+    return v;
+}
 
 }  // namespace deft

@@ -339,61 +339,117 @@ __global__ __launch_bounds__(256) void node_prep_kernel(const int64_t* node_kv_o
 }
 
 // ---------------------------------------------------------------------------
-// stage 2: merge the partial rows of one (query, head)
+// stage 2: merge the partial rows of one query, four heads per workgroup
 // ---------------------------------------------------------------------------
+// Deterministic gather (the reference scatters with fp32/fp16 atomics,
+// tree_attention.py:419-546): the four waves first list the partial rows of this query
+// in ascending row order (each wave scans a quarter of row_q), then every wave merges
+// one head: 64 candidate rows at a time it loads their log-sum-exps in parallel, keeps a
+// running true maximum (online rescale), and accumulates only the rows that carry a
+// partial (lse > -inf; rows folded into a group by the streaming stage 1 are skipped),
+// four independent 512-byte row loads in flight per step.  fp32 accumulate, one fp16 rounding.
 template <int D>
-__global__ __launch_bounds__(64) void merge_kernel(const float* partial_o, const float* partial_lse, const int32_t* row_q,
-                                                    int64_t rows, _Float16* out, int64_t o_st, int64_t o_sh,
-                                                    unsigned long long* dbg) {
+__global__ __launch_bounds__(256) void merge_kernel(const float* partial_o, const float* partial_lse, const int32_t* row_q,
+                                                     int64_t rows, _Float16* out, int64_t o_st, int64_t o_sh, int Hq,
+                                                     unsigned long long* dbg) {
     if (dbg && threadIdx.x == 0) atomicMin(dbg + 65538, wall_clock64());
     constexpr int VEC = D / 64;  // output columns per lane
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    int* sRows = reinterpret_cast<int*>(smem);  // matching partial rows, capacity `rows`
-    const int lane = threadIdx.x;
+    int* sCnt = reinterpret_cast<int*>(smem);  // [4] matches found by each wave
+    int* sRows = sCnt + 4;                      // [4][quarter] matching rows, ascending within a quarter
+    const int tid = threadIdx.x;
+    const int w = tid >> 6;
+    const int lane = tid & 63;
     const int qi = blockIdx.x;
-    const int hq = blockIdx.y;
+    const int hq = blockIdx.y * 4 + w;
+    const int quarter = (int)(((rows + 3) / 4 + 63) / 64 * 64);
 
-    // 1. partial rows of this query, in ascending row order (deterministic)
-    int n = 0;
-    for (int64_t base = 0; base < rows; base += 64) {
-        const int64_t i = base + lane;
-        const bool hit = (i < rows) && (row_q[i] == qi);
-        const unsigned long long mask = __ballot(hit);
-        if (hit) sRows[n + __popcll(mask & ((1ull << lane) - 1ull))] = (int)i;
-        n += __popcll(mask);
+    // 1. rows of this query inside this wave's quarter of row_q
+    {
+        int n = 0;
+        const int64_t lo = (int64_t)w * quarter;
+        const int64_t hi = lo + quarter < rows ? lo + quarter : rows;
+        for (int64_t base = lo; base < hi; base += 64) {
+            const int64_t i = base + lane;
+            const bool hit = (i < hi) && (row_q[i] == qi);
+            const unsigned long long mask = __ballot(hit);
+            if (hit) sRows[w * quarter + n + __popcll(mask & ((1ull << lane) - 1ull))] = (int)i;
+            n += __popcll(mask);
+        }
+        if (lane == 0) sCnt[w] = n;
     }
     __syncthreads();
+    if (hq >= Hq) return;
 
-    // 2. true maximum of their log-sum-exps
+    // 2. merge this head's partials
     const float* lse_h = partial_lse + (int64_t)hq * rows;
-    float m = -INFINITY;
-    for (int i = lane; i < n; i += 64) m = fmaxf(m, lse_h[sRows[i]]);
-#pragma unroll
-    for (int sft = 32; sft > 0; sft >>= 1) m = fmaxf(m, __shfl_xor(m, sft));
-
-    // 3. weighted sum in fp32, one rounding to fp16
+    const float* po_h = partial_o + (int64_t)hq * rows * D + VEC * lane;
     float acc[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
-    float L = 0.f;
-    if (m > -INFINITY) {
-        const float* po_h = partial_o + (int64_t)hq * rows * D + VEC * lane;
-        for (int i = 0; i < n; ++i) {
-            const int r = sRows[i];
-            const float lse = lse_h[r];
-            if (lse == -INFINITY) continue;  // row folded into its group's partial (wave-uniform branch)
-            const float wgt = __expf(lse - m);
-            L += wgt;
-            const float* src = po_h + (int64_t)r * D;
+    float m_run = -INFINITY, L = 0.f;
+    // the four per-wave lists, read as one list in ascending row order
+    const int c0 = sCnt[0], c1 = sCnt[1], c2 = sCnt[2], c3 = sCnt[3];
+    const int n = c0 + c1 + c2 + c3;
+    for (int base = 0; base < n; base += 64) {
+        const int g = base + lane;
+        const bool in = g < n;
+        int idx = g, seg = 0;
+        if (idx >= c0) { idx -= c0; seg = 1; if (idx >= c1) { idx -= c1; seg = 2; if (idx >= c2) { idx -= c2; seg = 3; } } }
+        const int r = in ? sRows[seg * quarter + idx] : 0;
+        const float lse = in ? lse_h[r] : -INFINITY;
+        float cm = lse;
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) acc[j] += wgt * src[j];
+        for (int sft = 32; sft > 0; sft >>= 1) cm = fmaxf(cm, __shfl_xor(cm, sft));
+        if (cm == -INFINITY) continue;  // wave-uniform
+        const float m_new = fmaxf(m_run, cm);
+        const float scale = (m_run == -INFINITY) ? 0.f : __expf(m_run - m_new);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[j] *= scale;
+        L *= scale;
+        m_run = m_new;
+        const float wgt = (lse == -INFINITY) ? 0.f : __expf(lse - m_new);
+        float ws = wgt;
+#pragma unroll
+        for (int sft = 32; sft > 0; sft >>= 1) ws += __shfl_xor(ws, sft);
+        L += ws;
+        unsigned long long live = __ballot(wgt > 0.f);
+        while (live) {  // wave-uniform loop, up to four independent row loads per trip
+            int kk[4];
+            float wk[4];
+            int cnt = 0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                kk[u] = 0;
+                wk[u] = 0.f;
+                if (live) {
+                    const int bit = __builtin_ctzll(live);
+                    live &= live - 1;
+                    kk[u] = __shfl(r, bit);
+                    wk[u] = __shfl(wgt, bit);
+                    cnt = u + 1;
+                }
+            }
+            float v[4][VEC];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (u < cnt) {
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) v[u][j] = po_h[(int64_t)kk[u] * D + j];
+                }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (u < cnt) {
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) acc[j] += wk[u] * v[u][j];
+                }
         }
     }
     const float inv = L > 0.f ? 1.f / L : 0.f;
     _Float16* dst = out + (int64_t)qi * o_st + (int64_t)hq * o_sh + VEC * lane;
 #pragma unroll
     for (int j = 0; j < VEC; ++j) dst[j] = (_Float16)(acc[j] * inv);
-    if (dbg && threadIdx.x == 0) atomicMax(dbg + 65539, wall_clock64());
+    if (dbg && lane == 0) atomicMax(dbg + 65539, wall_clock64());
 }
 
 // ---------------------------------------------------------------------------
@@ -470,7 +526,14 @@ static int num_cus() {
 }
 
 // Flatten stage 1, streaming form (MHA, head_dim 128).  `plan` is workspace memory.
-static int launch_stage1_stream(const Stage1Params& p, int NB, char* plan, hipStream_t stream) {
+static int launch_plan(const Stage1Params& p, int NB, const PlanView& pv, hipStream_t stream) {
+    hipLaunchKernelGGL(flatten_plan_kernel, dim3((unsigned)(NB + 1)), dim3(128), 0, stream, p.block_q, p.block_q_cnts,
+                       p.block_q_offset, p.block_bitmasks, p.block_kv, p.block_lens, NB, (int)p.rows, p.kv_ss, pv.records,
+                       pv.row_q, pv.sched, g_stream_dbg);
+    return check_launch("flatten plan launch");
+}
+
+static int launch_stage1_stream(const Stage1Params& p, int NB, const PlanView& pv, hipStream_t stream) {
     using SM = StreamSmem<128>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -483,11 +546,6 @@ static int launch_stage1_stream(const Stage1Params& p, int NB, char* plan, hipSt
         attr_set = true;
     }
     if (NB <= 0) return DEFT_OK;
-    hipLaunchKernelGGL(flatten_plan_kernel, dim3((unsigned)(NB + 1)), dim3(128), 0, stream, p.block_q, p.block_q_cnts,
-                       p.block_q_offset, p.block_bitmasks, p.block_kv, p.block_lens, NB, (int)p.rows, p.kv_ss, plan,
-                       p.row_q, g_stream_dbg);
-    int rc = check_launch("flatten plan launch");
-    if (rc) return rc;
     static const int wg_per_cu = getenv("DEFT_STREAM_WG_PER_CU") ? atoi(getenv("DEFT_STREAM_WG_PER_CU")) : 2;
     const int64_t U = (int64_t)NB * p.Hkv;
     int64_t workers = (int64_t)num_cus() * wg_per_cu;
@@ -495,11 +553,17 @@ static int launch_stage1_stream(const Stage1Params& p, int NB, char* plan, hipSt
     StreamParams sp{};
     sp.s = p;
     sp.s.ablate = getenv("DEFT_STAGE1_ABLATE") ? atoi(getenv("DEFT_STAGE1_ABLATE")) : 0;
-    sp.plan = plan;
+    sp.plan = pv.records;
+    sp.sched = pv.sched;
     sp.NB = NB;
+    sp.U = (int)U;
     sp.dbg = g_stream_dbg;
-    sp.per = (int)(U / workers);
-    sp.rem = (int)(U % workers);
+    // each workgroup walks a static run first (consecutive tiles fold into one partial); the units left over
+    // by the integer division form a shared pool handed out one at a time.  Larger pools were measured
+    // slower (DEFT_STREAM_STATIC_FRAC 0.5: +15 %): every pooled tile is its own group with its own partial
+    static const double static_frac = getenv("DEFT_STREAM_STATIC_FRAC") ? atof(getenv("DEFT_STREAM_STATIC_FRAC")) : 1.0;
+    sp.n_static = (int)((double)(U / workers) * static_frac);
+    sp.pool_base = (int)(workers * sp.n_static);
     static bool printed = false;
     if (!printed && getenv("DEFT_DEBUG")) {
         printed = true;
@@ -520,21 +584,22 @@ static int dispatch_stage1(int D, const Stage1Params& p, int64_t tiles, hipStrea
     return DEFT_EUNSUPPORTED;
 }
 
-static int launch_merge(int D, const Workspace& ws, int64_t rows, void* out, int64_t o_st, int64_t o_sh, int nq, int Hq,
-                        hipStream_t stream) {
+static int launch_merge(int D, const Workspace& ws, const int32_t* row_q, int64_t rows, void* out, int64_t o_st, int64_t o_sh,
+                        int nq, int Hq, hipStream_t stream) {
     if (nq <= 0) return DEFT_OK;
-    const size_t lds = sizeof(int) * (size_t)(rows > 0 ? rows : 1);
+    const int64_t quarter = ((rows + 3) / 4 + 63) / 64 * 64;
+    const size_t lds = sizeof(int) * (size_t)(4 + 4 * quarter);
     if (lds > 64 * 1024) {
         set_error("merge: %lld partial rows exceed the LDS row list", (long long)rows);
         return DEFT_EUNSUPPORTED;
     }
-    dim3 grid((unsigned)nq, (unsigned)Hq);
+    dim3 grid((unsigned)nq, (unsigned)((Hq + 3) / 4));
     if (D == 128)
-        hipLaunchKernelGGL((merge_kernel<128>), grid, dim3(64), lds, stream, ws.partial_o, ws.partial_lse, ws.row_q, rows,
-                           static_cast<_Float16*>(out), o_st, o_sh, g_stream_dbg);
+        hipLaunchKernelGGL((merge_kernel<128>), grid, dim3(256), lds, stream, ws.partial_o, ws.partial_lse, row_q, rows,
+                           static_cast<_Float16*>(out), o_st, o_sh, Hq, g_stream_dbg);
     else
-        hipLaunchKernelGGL((merge_kernel<64>), grid, dim3(64), lds, stream, ws.partial_o, ws.partial_lse, ws.row_q, rows,
-                           static_cast<_Float16*>(out), o_st, o_sh, g_stream_dbg);
+        hipLaunchKernelGGL((merge_kernel<64>), grid, dim3(256), lds, stream, ws.partial_o, ws.partial_lse, row_q, rows,
+                           static_cast<_Float16*>(out), o_st, o_sh, Hq, g_stream_dbg);
     return check_launch("merge launch");
 }
 
@@ -593,11 +658,14 @@ size_t deft_node_workspace_bytes(int NE, int P, int64_t total_kv, int nq, int Hq
     return carve(nullptr, Hq, D, tiles * DEFT_MAX_Q_LEN, tiles).bytes;
 }
 
-int deft_flatten_stage1_f16(const void* q, int64_t q_stride_tok, int64_t q_stride_head, const void* k_base,
-                            const void* v_base, int64_t kv_stride_slot, int64_t kv_stride_head, const int64_t* block_q,
-                            const int64_t* block_q_cnts, const int64_t* block_q_offset, const int64_t* block_bitmasks,
-                            const int64_t* block_kv, const int64_t* block_lens, int NB, int P, int nq, int Hq, int Hkv,
-                            int D, float scale, void* workspace, size_t workspace_bytes, void* stream) {
+// Shared body of the Flatten entry points: stage 1 into the workspace; reports which
+// partial-row -> query map the merge must read.
+static int flatten_stage1_impl(const void* q, int64_t q_stride_tok, int64_t q_stride_head, const void* k_base,
+                               const void* v_base, int64_t kv_stride_slot, int64_t kv_stride_head, const int64_t* block_q,
+                               const int64_t* block_q_cnts, const int64_t* block_q_offset, const int64_t* block_bitmasks,
+                               const int64_t* block_kv, const int64_t* block_lens, int NB, int P, int nq, int Hq, int Hkv,
+                               int D, float scale, const void* plan, void* workspace, size_t workspace_bytes, void* stream,
+                               Workspace* ws_out, const int32_t** row_q_out) {
     // `workspace` doubles as the (unused) output pointer for the shared argument check
     int rc = check_common(q, q_stride_tok, q_stride_head, k_base, v_base, kv_stride_slot, kv_stride_head, workspace, 2, 2,
                           nq, Hq, Hkv, D);
@@ -633,10 +701,67 @@ int deft_flatten_stage1_f16(const void* q, int64_t q_stride_tok, int64_t q_strid
     p.Hkv = Hkv;
     p.G = Hq / Hkv;
     p.scale_log2e = scale * LOG2E;
+    *ws_out = ws;
+    hipStream_t st = static_cast<hipStream_t>(stream);
     // streaming form for MHA / head_dim 128 (env DEFT_STAGE1_VARIANT=tile forces the tile-per-workgroup form)
     static const bool force_tile = getenv("DEFT_STAGE1_VARIANT") && !strcmp(getenv("DEFT_STAGE1_VARIANT"), "tile");
-    if (D == 128 && p.G == 1 && !force_tile) return launch_stage1_stream(p, NB, ws.plan, static_cast<hipStream_t>(stream));
-    return dispatch_stage1<0>(D, p, NB, static_cast<hipStream_t>(stream));
+    if (D == 128 && p.G == 1 && !force_tile) {
+        PlanView pv;
+        if (plan) {
+            pv = plan_view(const_cast<void*>(plan), NB, P);
+        } else {
+            pv = plan_view(ws.plan, NB, P);
+            rc = launch_plan(p, NB, pv, st);
+            if (rc) return rc;
+        }
+        *row_q_out = pv.row_q;
+        return launch_stage1_stream(p, NB, pv, st);
+    }
+    *row_q_out = ws.row_q;
+    return dispatch_stage1<0>(D, p, NB, st);
+}
+
+size_t deft_flatten_plan_bytes(int NB, int P) { return plan_view(nullptr, NB, P).bytes; }
+
+int deft_flatten_build_plan(const int64_t* block_q, const int64_t* block_q_cnts, const int64_t* block_q_offset,
+                            const int64_t* block_bitmasks, const int64_t* block_kv, const int64_t* block_lens, int NB, int P,
+                            int64_t kv_stride_slot, void* plan, size_t plan_bytes, void* stream) {
+    if (NB < 0 || P < 0 || !plan ||
+        (NB > 0 && (!block_q || !block_q_cnts || !block_q_offset || !block_bitmasks || !block_kv || !block_lens))) {
+        set_error("bad plan arguments (NB=%d P=%d)", NB, P);
+        return DEFT_EINVAL;
+    }
+    const PlanView pv = plan_view(plan, NB, P);
+    if (plan_bytes < pv.bytes) {
+        set_error("plan buffer too small: %zu < %zu", plan_bytes, pv.bytes);
+        return DEFT_EWORKSPACE;
+    }
+    Stage1Params p{};
+    p.block_q = block_q;
+    p.block_q_cnts = block_q_cnts;
+    p.block_q_offset = block_q_offset;
+    p.block_bitmasks = block_bitmasks;
+    p.block_kv = block_kv;
+    p.block_lens = block_lens;
+    p.rows = P;
+    p.kv_ss = kv_stride_slot;
+    return launch_plan(p, NB, pv, static_cast<hipStream_t>(stream));
+}
+
+int deft_flatten_stage1_f16(const void* q, int64_t q_stride_tok, int64_t q_stride_head, const void* k_base,
+                            const void* v_base, int64_t kv_stride_slot, int64_t kv_stride_head, const int64_t* block_q,
+                            const int64_t* block_q_cnts, const int64_t* block_q_offset, const int64_t* block_bitmasks,
+                            const int64_t* block_kv, const int64_t* block_lens, int NB, int P, int nq, int Hq, int Hkv,
+                            int D, float scale, const void* plan, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!workspace) {
+        set_error("null workspace");
+        return DEFT_EINVAL;
+    }
+    Workspace ws;
+    const int32_t* row_q = nullptr;
+    return flatten_stage1_impl(q, q_stride_tok, q_stride_head, k_base, v_base, kv_stride_slot, kv_stride_head, block_q,
+                               block_q_cnts, block_q_offset, block_bitmasks, block_kv, block_lens, NB, P, nq, Hq, Hkv, D,
+                               scale, plan, workspace, workspace_bytes, stream, &ws, &row_q);
 }
 
 int deft_flatten_decode_f16(const void* q, int64_t q_stride_tok, int64_t q_stride_head, const void* k_base,
@@ -644,7 +769,7 @@ int deft_flatten_decode_f16(const void* q, int64_t q_stride_tok, int64_t q_strid
                             int64_t o_stride_tok, int64_t o_stride_head, const int64_t* block_q,
                             const int64_t* block_q_cnts, const int64_t* block_q_offset, const int64_t* block_bitmasks,
                             const int64_t* block_kv, const int64_t* block_lens, int NB, int P, int nq, int Hq, int Hkv,
-                            int D, float scale, void* workspace, size_t workspace_bytes, void* stream) {
+                            int D, float scale, const void* plan, void* workspace, size_t workspace_bytes, void* stream) {
     int rc = check_common(q, q_stride_tok, q_stride_head, k_base, v_base, kv_stride_slot, kv_stride_head, out,
                           o_stride_tok, o_stride_head, nq, Hq, Hkv, D);
     if (rc) return rc;
@@ -652,12 +777,13 @@ int deft_flatten_decode_f16(const void* q, int64_t q_stride_tok, int64_t q_strid
         set_error("null workspace");
         return DEFT_EINVAL;
     }
-    rc = deft_flatten_stage1_f16(q, q_stride_tok, q_stride_head, k_base, v_base, kv_stride_slot, kv_stride_head, block_q,
-                                 block_q_cnts, block_q_offset, block_bitmasks, block_kv, block_lens, NB, P, nq, Hq, Hkv, D,
-                                 scale, workspace, workspace_bytes, stream);
+    Workspace ws;
+    const int32_t* row_q = nullptr;
+    rc = flatten_stage1_impl(q, q_stride_tok, q_stride_head, k_base, v_base, kv_stride_slot, kv_stride_head, block_q,
+                             block_q_cnts, block_q_offset, block_bitmasks, block_kv, block_lens, NB, P, nq, Hq, Hkv, D, scale,
+                             plan, workspace, workspace_bytes, stream, &ws, &row_q);
     if (rc) return rc;
-    const Workspace ws = carve(workspace, Hq, D, P, 0, NB);
-    return launch_merge(D, ws, P, out, o_stride_tok, o_stride_head, nq, Hq, static_cast<hipStream_t>(stream));
+    return launch_merge(D, ws, row_q, P, out, o_stride_tok, o_stride_head, nq, Hq, static_cast<hipStream_t>(stream));
 }
 
 int deft_node_decode_f16(const void* q, int64_t q_stride_tok, int64_t q_stride_head, const void* k_base,
@@ -716,7 +842,7 @@ int deft_node_decode_f16(const void* q, int64_t q_stride_tok, int64_t q_stride_h
     p.scale_log2e = scale * LOG2E;
     rc = dispatch_stage1<1>(D, p, tiles, st);
     if (rc) return rc;
-    return launch_merge(D, ws, rows, out, o_stride_tok, o_stride_head, nq, Hq, st);
+    return launch_merge(D, ws, ws.row_q, rows, out, o_stride_tok, o_stride_head, nq, Hq, st);
 }
 
 int deft_kv_append_f16(void* k_base, void* v_base, int64_t kv_stride_slot, int64_t kv_stride_head,

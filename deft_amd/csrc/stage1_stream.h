@@ -58,7 +58,10 @@ struct StreamParams {
     Stage1Params s;
     const char* plan;  // [NB+1][PLAN_BYTES]
     int NB;
-    int per, rem;  // workgroup b owns per + (b < rem) consecutive units of the NB*Hkv head-major sequence
+    int U;         // NB * Hkv units, head-major
+    int n_static;  // workgroup b first walks units [b*n_static, (b+1)*n_static) ...
+    int pool_base; // ... then takes single units pool_base + ticket from the shared pool [pool_base, U)
+    int* sched;    // [2] = {ticket counter, workgroups done}; both 0 between launches
     unsigned long long* dbg;  // internal: per-phase s_memtime stamps [workgroup][16 tiles][8], or null
 };
 
@@ -70,7 +73,8 @@ struct StreamSmem {
     static constexpr int META_OFF = P_OFF + MQ * TILE * 2;  // 2 plan records
     static constexpr int WMAX_OFF = META_OFF + 2 * PLAN_BYTES;
     static constexpr int WSUM_OFF = WMAX_OFF + 4 * MQ * 4;
-    static constexpr int BYTES = WSUM_OFF + 4 * MQ * 4;
+    static constexpr int UNIT_OFF = WSUM_OFF + 4 * MQ * 4;  // int[4] ring of unit ids, -1 = end of stream
+    static constexpr int BYTES = UNIT_OFF + 16;
 };
 
 // 64 lanes x 16 bytes, global (per-lane address) -> LDS (lds_dst + 16*lane).  M0 is not
@@ -112,13 +116,21 @@ __global__ __launch_bounds__(512, 4) void stage1_stream_kernel(StreamParams sp) 
     const int c = l & 31;
     const int h = l >> 5;
 
-    // span of this workgroup in the head-major (KV head, tile) sequence
+    // Work of this workgroup: a static run of consecutive units, then single units taken from a
+    // shared pool with an atomic ticket.  Position i of the stream is known two tiles ahead: compute
+    // wave 0 publishes unit(i+2) in the sUnit ring before barrier H of tile i.
     const int bid = blockIdx.x;
-    const int u0 = bid * sp.per + min(bid, sp.rem);
-    const int n_units = sp.per + (bid < sp.rem ? 1 : 0);
-    if (n_units <= 0) return;
-    int kvh = u0 / sp.NB;
-    int t = u0 - kvh * sp.NB;
+    int* sUnit = reinterpret_cast<int*>(smem + SM::UNIT_OFF);
+    auto take = [&](int pos) -> int {  // lane 0 of compute wave 0 only
+        if (pos < sp.n_static) return bid * sp.n_static + pos;
+        const int u = sp.pool_base + atomicAdd(sp.sched, 1);
+        return u < sp.U ? u : -1;
+    };
+    if (tid == 0) {
+        const int a = take(0);
+        sUnit[0] = a;
+        sUnit[1] = a < 0 ? -1 : take(1);
+    }
 
     // ---- loop-invariant lane constants -------------------------------------------------
     // DMA: instruction i of a tile stages keys 32w + 4i + (l>>4), LDS chunk position l&15.
@@ -171,7 +183,6 @@ __global__ __launch_bounds__(512, 4) void stage1_stream_kernel(StreamParams sp) 
         for (int j = 0; j < 4; ++j) r[j] = __builtin_amdgcn_readfirstlane(d[j]);
         return r;
     };
-    auto next_tile = [&](int tt) { return tt + 1 == sp.NB ? 0 : tt + 1; };
     auto stamp = [&](int i, int k) {
         if (sp.dbg && tid == 0 && i < 16) sp.dbg[((int64_t)bid * 16 + i) * 8 + k] = __builtin_amdgcn_s_memtime();
     };
@@ -192,7 +203,31 @@ __global__ __launch_bounds__(512, 4) void stage1_stream_kernel(StreamParams sp) 
     };
 
     if (sp.dbg && tid == 0) sp.dbg[((int64_t)bid * 16 + 15) * 8 + 6] = wall_clock64();
+    auto finish = [&]() {  // the last workgroup to leave re-arms the scheduler words for the next launch
+        if (tid == 0) {
+            if (sp.dbg) {
+                unsigned hw, xcc;
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+                sp.dbg[((int64_t)bid * 16 + 15) * 8 + 5] = ((unsigned long long)xcc << 32) | hw;
+            }
+            if (sp.dbg) sp.dbg[((int64_t)bid * 16 + 15) * 8 + 7] = wall_clock64();
+            if (atomicAdd(sp.sched + 1, 1) == (int)gridDim.x - 1) {
+                sp.sched[0] = 0;
+                sp.sched[1] = 0;
+            }
+        }
+    };
     // ---- prologue -----------------------------------------------------------------
+    lds_barrier();  // sUnit[0..1] visible
+    int ucur = __builtin_amdgcn_readfirstlane(sUnit[0]);
+    int unext = __builtin_amdgcn_readfirstlane(sUnit[1]);
+    if (ucur < 0) {
+        finish();
+        return;
+    }
+    int kvh = ucur / sp.NB;
+    int t = ucur - kvh * sp.NB;
     if (is_loader) {
         issue_meta(t, 0);
         wait_vm<0>();
@@ -201,16 +236,16 @@ __global__ __launch_bounds__(512, 4) void stage1_stream_kernel(StreamParams sp) 
     if (is_loader) {
         load_rowoff(0);
         issue_k(kvh);
-        issue_q(0, kvh);  // the first tile of a span always opens a group
-        if (n_units > 1) issue_meta(next_tile(t), 1);
+        issue_q(0, kvh);  // the first tile of a stream always opens a group
+        if (unext >= 0) issue_meta(unext % sp.NB, 1);
         issue_v(kvh);
 
         // ---- loader loop: same barrier sequence as the compute waves below ---------------
-        for (int i = 0; i < n_units; ++i) {
+        for (int i = 0;; ++i) {
             const int mb = i & 1;
-            const int t_next = next_tile(t);
-            const int kvh_next = (t + 1 == sp.NB) ? kvh + 1 : kvh;
-            const bool last = (i + 1 == n_units);
+            const bool last = unext < 0;
+            const int kvh_next = last ? 0 : unext / sp.NB;
+            const int t_next = last ? 0 : unext - kvh_next * sp.NB;
             wait_vm<LPT>();  // A: K(u) and plan record (u+1) landed
             lds_barrier();
             lds_barrier();   // C: compute waves are done with sK
@@ -220,13 +255,15 @@ __global__ __launch_bounds__(512, 4) void stage1_stream_kernel(StreamParams sp) 
             }
             if (last) wait_vm<0>(); else wait_vm<LPT>();  // F: V(u) landed
             lds_barrier();
-            lds_barrier();   // H: compute waves are done with sV and sP
-            if (!last) {
-                const bool next_opens = (t + 1 == sp.NB) || (read_desc(mb ^ 1)[2] != 0);
-                if (next_opens) issue_q(mb ^ 1, kvh_next);
-                if (i + 2 < n_units) issue_meta(next_tile(t_next), mb);
-                issue_v(kvh_next);
-            }
+            lds_barrier();   // H: compute waves are done with sV and sP; unit(i+2) published
+            if (last) break;
+            const int u2 = __builtin_amdgcn_readfirstlane(sUnit[(i + 2) & 3]);
+            const bool next_opens = (unext != ucur + 1) || (t_next == 0) || (read_desc(mb ^ 1)[2] != 0);
+            if (next_opens) issue_q(mb ^ 1, kvh_next);
+            if (u2 >= 0) issue_meta(u2 % sp.NB, mb);
+            issue_v(kvh_next);
+            ucur = unext;
+            unext = u2;
             t = t_next;
             kvh = kvh_next;
         }
@@ -242,14 +279,13 @@ __global__ __launch_bounds__(512, 4) void stage1_stream_kernel(StreamParams sp) 
     int g_prow = 0;
     bool qvalid = false;
 
-    for (int i = 0; i < n_units; ++i) {
+    bool prev_adjacent = false;  // unit(i) == unit(i-1) + 1
+    for (int i = 0;; ++i) {
         const int mb = i & 1;  // plan record buffer of this unit
         const int hq = kvh;    // G == 1
-        const int t_next = next_tile(t);
-        const int kvh_next = (t + 1 == sp.NB) ? kvh + 1 : kvh;
-        const bool last = (i + 1 == n_units);
+        const bool last = unext < 0;
         const intx4 cur = read_desc(mb);
-        const bool g_start = (i == 0) || (t == 0) || (cur[2] != 0);
+        const bool g_start = !prev_adjacent || (t == 0) || (cur[2] != 0);
 
         // ---- A: K(u) and plan record (u+1) landed ------------------------------------
         stamp(i, 0);
@@ -266,8 +302,14 @@ __global__ __launch_bounds__(512, 4) void stage1_stream_kernel(StreamParams sp) 
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[r] = 0.f;
         }
+        const bool next_adjacent = !last && (unext == ucur + 1);
         bool g_end = true;  // plan record (u+1) is visible now
-        if (!last) g_end = (t + 1 == sp.NB) || (read_desc(mb ^ 1)[2] != 0);
+        if (next_adjacent) g_end = (t + 1 == sp.NB) || (read_desc(mb ^ 1)[2] != 0);
+        // the ticket for position i+2 travels while this tile computes (compute waves issue no other loads)
+        int ticket = 0;  // consumed just before barrier H, a tile's worth of time after the atomic was issued
+        const bool pooled = (i + 2 >= sp.n_static);
+        if (tid == 0 && !last && pooled)  // asm: hipcc would otherwise wait for the returned value right here
+            asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(ticket) : "v"(sp.sched), "v"(1) : "memory");
 
         // ---- B: S^T for this wave's 32 keys, scale, mask, row max --------------------
         floatx16 acc;
@@ -352,8 +394,13 @@ __global__ __launch_bounds__(512, 4) void stage1_stream_kernel(StreamParams sp) 
             }
         }
 
-        // ---- H: every wave is done with sV and sP ---------------------------------------------
+        // ---- H: every wave is done with sV and sP; unit(i+2) published -------------------------
         stamp(i, 6);
+        if (tid == 0 && !last) {
+            if (pooled) asm volatile("s_waitcnt vmcnt(0)" : "+v"(ticket)::"memory");
+            int u2 = pooled ? sp.pool_base + ticket : bid * sp.n_static + i + 2;
+            sUnit[(i + 2) & 3] = u2 < sp.U ? u2 : -1;
+        }
         lds_barrier();
         stamp(i, 7);
 
@@ -374,10 +421,14 @@ __global__ __launch_bounds__(512, 4) void stage1_stream_kernel(StreamParams sp) 
             if (w == 0 && h == 0)
                 p.partial_lse[prow_idx] = (l_run > 0.f) ? (m_run + __builtin_amdgcn_logf(l_run)) * LN2 : -INFINITY;
         }
-        t = t_next;
-        kvh = kvh_next;
+        if (last) break;
+        prev_adjacent = next_adjacent;
+        ucur = unext;
+        unext = __builtin_amdgcn_readfirstlane(sUnit[(i + 2) & 3]);
+        kvh = ucur / sp.NB;
+        t = ucur - kvh * sp.NB;
     }
-    if (sp.dbg && tid == 0) sp.dbg[((int64_t)bid * 16 + 15) * 8 + 7] = wall_clock64();
+    finish();
 }
 
 // Packs the plan records (see PLAN_* above) and the partial-row -> query map; one workgroup
@@ -386,7 +437,7 @@ __global__ __launch_bounds__(128) void flatten_plan_kernel(const int64_t* block_
                                                            const int64_t* block_q_offset, const int64_t* block_bitmasks,
                                                            const int64_t* block_kv, const int64_t* block_lens, int NB, int P,
                                                            int64_t kv_stride_slot, char* plan, int32_t* row_q,
-                                                           unsigned long long* dbg) {
+                                                           int32_t* sched, unsigned long long* dbg) {
     const int t = blockIdx.x;
     const int k = threadIdx.x;
     struct Stamp {  // internal profiling: first start / last end of this kernel on the 100 MHz clock
@@ -402,6 +453,7 @@ __global__ __launch_bounds__(128) void flatten_plan_kernel(const int64_t* block_
     if (t >= NB) {  // sentinel
         ro[k] = 0;
         mk[k] = 0u;
+        if (k < 2) sched[k] = 0;
         if (k == 0) {
             desc[0] = 0;
             desc[1] = P;

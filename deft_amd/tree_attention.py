@@ -48,6 +48,29 @@ def _check_qkv(query_states, key_buffer, value_buffer, output):
     return nq, Hq, Hkv, D
 
 
+def _flatten_plan(md, NB: int, P: int, kv_stride_slot: int, stream: int):
+    """Device-side repack of the Flatten metadata, built once per decode step.
+
+    The reference builds TreeMetadata once per step and all layers read the same tensor
+    objects (tree_cache.py:1021-1037), so the plan is cached ON the block_q tensor, keyed by
+    the identity and in-place version of all six arrays and by the pool stride.  Fresh
+    tensors (or an in-place edit) simply rebuild it; results never depend on the cache."""
+    block_q = md[0]
+    key = (kv_stride_slot, NB, P) + tuple((t.data_ptr(), t._version) for t in md)
+    cached = getattr(block_q, "_deft_plan", None)
+    if cached is not None and cached[0] == key:
+        return cached[1]
+    nbytes = lib.deft_flatten_plan_bytes(NB, P)
+    plan = torch.empty(nbytes, dtype=torch.uint8, device=block_q.device)
+    check(lib.deft_flatten_build_plan(*[t.data_ptr() for t in md], NB, P, kv_stride_slot, plan.data_ptr(), nbytes, stream),
+          "deft_flatten_build_plan")
+    try:
+        block_q._deft_plan = (key, plan)
+    except Exception:  # tensors that refuse attributes just do not cache
+        pass
+    return plan
+
+
 def _i64(t: torch.Tensor, name: str) -> torch.Tensor:
     if t.dtype != torch.int64 or not t.is_cuda:
         raise TypeError(f"{name} must be an int64 CUDA tensor (TreeMetadata contract)")
@@ -82,12 +105,14 @@ def tree_attention_subtree_fwd(
     ws_bytes = lib.deft_flatten_workspace_bytes(NB, P, nq, Hq, Hkv, D)
     ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=query_states.device)
     scale = 1.0 / (D ** 0.5)  # tree_attention.py:601
+    stream = _stream_ptr(query_states)
+    plan = _flatten_plan(md, NB, P, key_buffer.stride(0), stream)
     rc = lib.deft_flatten_decode_f16(
         query_states.data_ptr(), query_states.stride(0), query_states.stride(1),
         key_buffer.data_ptr(), value_buffer.data_ptr(), key_buffer.stride(0), key_buffer.stride(1),
         output.data_ptr(), output.stride(0), output.stride(1),
         *[t.data_ptr() for t in md],
-        NB, P, nq, Hq, Hkv, D, scale, ws.data_ptr(), ws_bytes, _stream_ptr(query_states),
+        NB, P, nq, Hq, Hkv, D, scale, plan.data_ptr(), ws.data_ptr(), ws_bytes, stream,
     )
     check(rc, "deft_flatten_decode_f16")
 
@@ -169,7 +194,7 @@ def flatten_stage1_partials(query_states, key_buffer, value_buffer, block_q, blo
         key_buffer.data_ptr(), value_buffer.data_ptr(), key_buffer.stride(0), key_buffer.stride(1),
         block_q.data_ptr(), block_q_cnts.data_ptr(), block_q_offset.data_ptr(), block_bitmasks.data_ptr(),
         block_kv.data_ptr(), block_lens.data_ptr(), NB, P, nq, Hq, Hkv, D, 1.0 / (D ** 0.5),
-        ws.data_ptr(), ws_bytes, st,
+        None, ws.data_ptr(), ws_bytes, st,
     )
     check(rc, "deft_flatten_stage1_f16")
     po = torch.empty((Hq, P, D), dtype=torch.float32, device=query_states.device)

@@ -66,6 +66,22 @@ int deft_supported(int Hq, int Hkv, int D);
 size_t deft_flatten_workspace_bytes(int NB, int P, int nq, int Hq, int Hkv, int D);
 
 /*
+ * Optional per-step plan.  The Flatten metadata is the same for every layer of one
+ * decode step (the reference builds TreeMetadata once per step and all 32 layers read
+ * it through a module global, tree_cache.py:1021-1037), so the device-side repack of it
+ * (row byte offsets in the pool, 32-bit query masks, run boundaries, partial-row -> query
+ * map) can be built once per step and handed to every layer's call.  `plan` is caller-
+ * owned device memory of deft_flatten_plan_bytes(NB, P) bytes; it depends on the six
+ * metadata arrays and on kv_stride_slot only.  Passing plan = NULL to the decode call
+ * makes it build the plan itself into the workspace (one more small kernel per call).
+ */
+size_t deft_flatten_plan_bytes(int NB, int P);
+int deft_flatten_build_plan(
+    const int64_t* block_q, const int64_t* block_q_cnts, const int64_t* block_q_offset,
+    const int64_t* block_bitmasks, const int64_t* block_kv, const int64_t* block_lens,
+    int NB, int P, int64_t kv_stride_slot, void* plan, size_t plan_bytes, void* stream);
+
+/*
  * out[nq,Hq,D] = tree attention of q over the flattened-tree blocks.
  *   q, out              fp16, [nq][Hq][D] with the given token/head strides
  *   block_q[P]          query row of every partial row, grouped per block
@@ -85,7 +101,7 @@ int deft_flatten_decode_f16(
     const int64_t* block_q, const int64_t* block_q_cnts, const int64_t* block_q_offset,
     const int64_t* block_bitmasks, const int64_t* block_kv, const int64_t* block_lens,
     int NB, int P, int nq, int Hq, int Hkv, int D, float scale,
-    void* workspace, size_t workspace_bytes, void* stream);
+    const void* plan, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- DeFT-Node ---------------------------------------------------------- */
 
@@ -129,7 +145,7 @@ int deft_flatten_stage1_f16(
     const int64_t* block_q, const int64_t* block_q_cnts, const int64_t* block_q_offset,
     const int64_t* block_bitmasks, const int64_t* block_kv, const int64_t* block_lens,
     int NB, int P, int nq, int Hq, int Hkv, int D, float scale,
-    void* workspace, size_t workspace_bytes, void* stream);
+    const void* plan, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Copy stage-1 partials out of a workspace (tests): partial_o[Hq][P][D] fp32, partial_lse[Hq][P] fp32. */
 int deft_flatten_read_partials(

@@ -36,7 +36,7 @@ def test_supported_geometries():
 
 def test_argument_errors_are_reported_not_thrown():
     lib = deft_amd.lib
-    rc = lib.deft_flatten_decode_f16(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 4, 4, 128, 0.1, 0, 0, 0)
+    rc = lib.deft_flatten_decode_f16(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 4, 4, 128, 0.1, 0, 0, 0, 0)
     assert rc == -1 and b"null" in lib.deft_last_error()
     assert lib.deft_md_free(12345) == -1
     assert lib.deft_md_build(0, 0, 0, 0, 0, 0, 32, 128, -1) == -1

@@ -42,3 +42,20 @@ print("by head quartile:", [round(float(dur[(np.arange(workers) // 16) // 8 == q
 print("by XCD (j % 8):", [round(float(dur[np.arange(workers) % 8 == x].mean()), 1) for x in range(8)])
 print("by tiles (first 64 WGs have 6):", round(float(dur[:64].mean()), 1), round(float(dur[64:].mean()), 1))
 print("sorted deciles:", [round(float(np.percentile(dur, q)), 1) for q in range(0, 101, 10)])
+hwid = d[:, 15, 5]
+xcc = (hwid >> 32) & 0xf
+hw = hwid & 0xffffffff
+cu = (hw >> 8) & 0xf; sh = (hw >> 12) & 1; se = (hw >> 13) & 0x7
+cuid = xcc * 64 + se * 8 + sh * 16 * 0 + cu  # coarse physical CU key
+key = (xcc.astype(np.int64) << 20) | (se.astype(np.int64) << 10) | (sh.astype(np.int64) << 8) | cu.astype(np.int64)
+import collections
+groups = collections.defaultdict(list)
+for j in range(workers):
+    if ok[j]: groups[int(key[j])].append(float(dur[j]))
+sizes = collections.Counter(len(v) for v in groups.values())
+print("distinct CUs used:", len(groups), "WGs per CU histogram:", dict(sizes))
+m1 = [v[0] for v in groups.values() if len(v) == 1]
+m2 = [np.mean(v) for v in groups.values() if len(v) == 2]
+m3 = [np.mean(v) for v in groups.values() if len(v) >= 3]
+print("mean dur with 1 WG on CU:", round(float(np.mean(m1)), 1) if m1 else None, " 2 WGs:", round(float(np.mean(m2)), 1) if m2 else None, " >=3:", round(float(np.mean(m3)), 1) if m3 else None)
+print("by xcc:", [round(float(dur[(xcc == x) & ok].mean()), 1) for x in range(8)], "counts", [int(((xcc == x) & ok).sum()) for x in range(8)])
