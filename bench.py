@@ -118,7 +118,9 @@ class Bench:
         from deft_amd.tree_attention import _flatten_plan
 
         mdl = [md.block_q, md.block_q_cnts, md.block_q_offset, md.block_bitmasks, md.block_kv, md.block_lens]
-        plan = _flatten_plan(mdl, NB, P, pool.get_key_buffer(0).stride(0), stream.cuda_stream)  # once per step
+        q0 = self.q[0].view(self.nq, self.Hq, self.D)
+        plan = _flatten_plan(mdl, NB, P, self.Hq, self.Hkv, (q0.stride(0), q0.stride(1)), pool.get_key_buffer(0).stride(0),
+                             stream.cuda_stream)  # once per step
         def launch_all():
             for l in range(self.layers):
                 q = self.q[l].view(self.nq, self.Hq, self.D)

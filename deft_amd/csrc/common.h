@@ -32,7 +32,7 @@ struct Workspace {
     size_t bytes;
 };
 
-inline Workspace carve(void* base, int Hq, int D, int64_t rows, int64_t tiles, int64_t NB = 0) {
+inline Workspace carve(void* base, int Hq, int D, int64_t rows, int64_t tiles, size_t plan_bytes = 0) {
     Workspace w;
     char* p = static_cast<char*>(base);
     size_t off = 0;
@@ -44,33 +44,44 @@ inline Workspace carve(void* base, int Hq, int D, int64_t rows, int64_t tiles, i
     off = align_up(off + sizeof(int32_t) * (size_t)rows, 256);
     w.desc = reinterpret_cast<int32_t*>(p + off);
     off = align_up(off + sizeof(int32_t) * 8 * (size_t)tiles, 256);
-    w.plan = p + off;  // a whole PlanView when the caller passes no plan
-    off = align_up(off + 2048 * (size_t)(NB + 1) + 768 + sizeof(int32_t) * (size_t)(rows > 0 ? rows : 1), 256);
+    w.plan = p + off;  // a whole plan buffer when the caller passes no plan
+    off = align_up(off + plan_bytes, 256);
     w.bytes = off;
     return w;
 }
 
 inline int64_t node_max_tiles(int NE, int64_t total_kv) { return (int64_t)NE + total_kv / DEFT_BLOCK_LEN; }
 
-// Flatten plan buffer: [NB+1] records of 2048 B, row_q[P] (i32), then the stream scheduler's two
-// words {ticket counter, workgroups done} (zero between launches)
+// Plan buffer (built once per decode step, read by every layer's call):
+//   header      256 B : int32 hdr[0] = records per KV head; scheduler words {ticket, done} at +64
+//   records     (cap+1) x 2048 B (stage1_stream.h PLAN_*), cap = units-per-head capacity
+//   unit list   5 x cap int32 (src, aux, pass, flags, prow)
+//   row_q       rows int32 : partial row -> query row
 struct PlanView {
-    char* records;
-    int32_t* row_q;
+    int32_t* hdr;
     int32_t* sched;
+    char* records;
+    int32_t* units;  // 5 arrays of `cap`
+    int32_t* row_q;
+    int64_t cap;
     size_t bytes;
 };
-inline PlanView plan_view(void* base, int64_t NB, int64_t P) {
+inline PlanView plan_view(void* base, int64_t cap, int64_t rows) {
     PlanView v;
     char* p = static_cast<char*>(base);
-    v.records = p;
-    size_t off = align_up(2048 * (size_t)(NB + 1), 256);
+    v.cap = cap;
+    v.hdr = reinterpret_cast<int32_t*>(p);
+    v.sched = reinterpret_cast<int32_t*>(p + 64);
+    size_t off = 256;
+    v.records = p + off;
+    off = align_up(off + 2048 * (size_t)(cap + 1), 256);
+    v.units = reinterpret_cast<int32_t*>(p + off);
+    off = align_up(off + sizeof(int32_t) * 5 * (size_t)(cap > 0 ? cap : 1), 256);
     v.row_q = reinterpret_cast<int32_t*>(p + off);
-    off = align_up(off + sizeof(int32_t) * (size_t)(P > 0 ? P : 1), 256);
-    v.sched = reinterpret_cast<int32_t*>(p + off);
-    off += 256;
+    off = align_up(off + sizeof(int32_t) * (size_t)(rows > 0 ? rows : 1), 256);
     v.bytes = off;
     return v;
 }
+inline int64_t flatten_unit_cap(int NB, int G) { return (int64_t)NB * G; }
 
 }  // namespace deft

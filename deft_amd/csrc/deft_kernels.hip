@@ -61,9 +61,13 @@ struct Stage1Params {
     const int64_t* block_bitmasks;
     const int64_t* block_kv;
     const int64_t* block_lens;
-    // Node sources (MODE 1)
+    // Node sources (MODE 1 / node plan)
     const int64_t* node_kv;
     const int64_t* node_q;
+    const int64_t* node_kv_offset;
+    const int64_t* node_kv_len;
+    const int64_t* node_q_offset;
+    const int64_t* node_q_len;
     const int32_t* desc;  // [tiles][8] = kv_begin, len, q_begin, cnt, prow, -, -, -
     // outputs
     float* partial_o;
@@ -526,14 +530,38 @@ static int num_cus() {
 }
 
 // Flatten stage 1, streaming form (MHA, head_dim 128).  `plan` is workspace memory.
-static int launch_plan(const Stage1Params& p, int NB, const PlanView& pv, hipStream_t stream) {
-    hipLaunchKernelGGL(flatten_plan_kernel, dim3((unsigned)(NB + 1)), dim3(128), 0, stream, p.block_q, p.block_q_cnts,
-                       p.block_q_offset, p.block_bitmasks, p.block_kv, p.block_lens, NB, (int)p.rows, p.kv_ss, pv.records,
-                       pv.row_q, pv.sched, g_stream_dbg);
-    return check_launch("flatten plan launch");
+static UnitList unit_list(const PlanView& pv) {
+    UnitList ul;
+    ul.src = pv.units;
+    ul.aux = pv.units + pv.cap;
+    ul.pass = pv.units + 2 * pv.cap;
+    ul.flags = pv.units + 3 * pv.cap;
+    ul.prow = pv.units + 4 * pv.cap;
+    return ul;
 }
 
-static int launch_stage1_stream(const Stage1Params& p, int NB, const PlanView& pv, hipStream_t stream) {
+// Flatten plan: unit list (one workgroup) then one record per unit.
+static int launch_plan(const Stage1Params& p, int NB, const PlanView& pv, hipStream_t stream) {
+    if (NB <= 0) return DEFT_OK;
+    const size_t lds = sizeof(int) * 2 * (size_t)NB;
+    if (lds > 64 * 1024) {
+        set_error("plan: %d blocks exceed the unit kernel's LDS", NB);
+        return DEFT_EUNSUPPORTED;
+    }
+    const UnitList ul = unit_list(pv);
+    hipLaunchKernelGGL(flatten_units_kernel, dim3(1), dim3(256), lds, stream, p.block_q, p.block_q_cnts, p.block_q_offset, NB,
+                       p.G, (int)pv.cap, ul, pv.hdr, pv.sched);
+    int rc = check_launch("flatten units launch");
+    if (rc) return rc;
+    hipLaunchKernelGGL(flatten_records_kernel, dim3((unsigned)(pv.cap + 1)), dim3(128), 0, stream, p.block_q, p.block_q_cnts,
+                       p.block_bitmasks, p.block_kv, p.block_lens, p.G, (int)p.rows, p.q_st, p.q_sh, p.kv_ss, ul, pv.hdr,
+                       pv.records, pv.row_q);
+    return check_launch("flatten records launch");
+}
+
+// Stage 1, streaming form (head_dim 128; MHA and GQA).  Units per head are only known on the device
+// (plan header), so the grid is sized from the host-side upper bound.
+static int launch_stage1_stream(const Stage1Params& p, int64_t unit_cap, const PlanView& pv, hipStream_t stream) {
     using SM = StreamSmem<128>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -545,33 +573,18 @@ static int launch_stage1_stream(const Stage1Params& p, int NB, const PlanView& p
         }
         attr_set = true;
     }
-    if (NB <= 0) return DEFT_OK;
+    if (unit_cap <= 0) return DEFT_OK;
     static const int wg_per_cu = getenv("DEFT_STREAM_WG_PER_CU") ? atoi(getenv("DEFT_STREAM_WG_PER_CU")) : 2;
-    const int64_t U = (int64_t)NB * p.Hkv;
+    const int64_t U_max = unit_cap * p.Hkv;
     int64_t workers = (int64_t)num_cus() * wg_per_cu;
-    if (workers > U) workers = U;
+    if (workers > U_max) workers = U_max;
     StreamParams sp{};
     sp.s = p;
     sp.s.ablate = getenv("DEFT_STAGE1_ABLATE") ? atoi(getenv("DEFT_STAGE1_ABLATE")) : 0;
+    sp.hdr = pv.hdr;
     sp.plan = pv.records;
     sp.sched = pv.sched;
-    sp.NB = NB;
-    sp.U = (int)U;
     sp.dbg = g_stream_dbg;
-    // each workgroup walks a static run first (consecutive tiles fold into one partial); the units left over
-    // by the integer division form a shared pool handed out one at a time.  Larger pools were measured
-    // slower (DEFT_STREAM_STATIC_FRAC 0.5: +15 %): every pooled tile is its own group with its own partial
-    static const double static_frac = getenv("DEFT_STREAM_STATIC_FRAC") ? atof(getenv("DEFT_STREAM_STATIC_FRAC")) : 1.0;
-    sp.n_static = (int)((double)(U / workers) * static_frac);
-    sp.pool_base = (int)(workers * sp.n_static);
-    static bool printed = false;
-    if (!printed && getenv("DEFT_DEBUG")) {
-        printed = true;
-        int nb = -1;
-        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, stage1_stream_kernel<128>, 512, SM::BYTES);
-        fprintf(stderr, "[deft] stream kernel: %d workgroups/CU by the occupancy API (%s), LDS %d B, workers %lld, CUs %d\n", nb,
-                hipGetErrorString(e), SM::BYTES, (long long)workers, num_cus());
-    }
     hipLaunchKernelGGL((stage1_stream_kernel<128>), dim3((unsigned)workers), dim3(512), SM::BYTES, stream, sp);
     return check_launch("stage1 stream launch");
 }
@@ -647,15 +660,17 @@ int deft_supported(int Hq, int Hkv, int D) { return (Hq > 0 && Hkv > 0 && Hq % H
 size_t deft_flatten_workspace_bytes(int NB, int P, int nq, int Hq, int Hkv, int D) {
     (void)nq;
     (void)Hkv;
-    return carve(nullptr, Hq, D, P, 0, NB).bytes;
+    if (Hq <= 0 || Hkv <= 0 || Hq % Hkv) return 0;
+    return carve(nullptr, Hq, D, P, 0, plan_view(nullptr, flatten_unit_cap(NB, Hq / Hkv), P).bytes).bytes;
 }
 
 size_t deft_node_workspace_bytes(int NE, int P, int64_t total_kv, int nq, int Hq, int Hkv, int D) {
     (void)P;
     (void)nq;
-    (void)Hkv;
+    if (Hq <= 0 || Hkv <= 0 || Hq % Hkv) return 0;
     const int64_t tiles = node_max_tiles(NE, total_kv);
-    return carve(nullptr, Hq, D, tiles * DEFT_MAX_Q_LEN, tiles).bytes;
+    const int64_t rows = tiles * DEFT_MAX_Q_LEN;
+    return carve(nullptr, Hq, D, rows, tiles, plan_view(nullptr, tiles * (Hq / Hkv), rows).bytes).bytes;
 }
 
 // Shared body of the Flatten entry points: stage 1 into the workspace; reports which
@@ -675,7 +690,8 @@ static int flatten_stage1_impl(const void* q, int64_t q_stride_tok, int64_t q_st
         set_error("bad Flatten metadata (NB=%d P=%d)", NB, P);
         return DEFT_EINVAL;
     }
-    const Workspace ws = carve(workspace, Hq, D, P, 0, NB);
+    const int64_t cap = flatten_unit_cap(NB, Hq / Hkv);
+    const Workspace ws = carve(workspace, Hq, D, P, 0, plan_view(nullptr, cap, P).bytes);
     if (workspace_bytes < ws.bytes) {
         set_error("workspace too small: %zu < %zu", workspace_bytes, ws.bytes);
         return DEFT_EWORKSPACE;
@@ -705,33 +721,37 @@ static int flatten_stage1_impl(const void* q, int64_t q_stride_tok, int64_t q_st
     hipStream_t st = static_cast<hipStream_t>(stream);
     // streaming form for MHA / head_dim 128 (env DEFT_STAGE1_VARIANT=tile forces the tile-per-workgroup form)
     static const bool force_tile = getenv("DEFT_STAGE1_VARIANT") && !strcmp(getenv("DEFT_STAGE1_VARIANT"), "tile");
-    if (D == 128 && p.G == 1 && !force_tile) {
+    if (D == 128 && !force_tile) {
         PlanView pv;
         if (plan) {
-            pv = plan_view(const_cast<void*>(plan), NB, P);
+            pv = plan_view(const_cast<void*>(plan), cap, P);
         } else {
-            pv = plan_view(ws.plan, NB, P);
+            pv = plan_view(ws.plan, cap, P);
             rc = launch_plan(p, NB, pv, st);
             if (rc) return rc;
         }
         *row_q_out = pv.row_q;
-        return launch_stage1_stream(p, NB, pv, st);
+        return launch_stage1_stream(p, cap, pv, st);
     }
     *row_q_out = ws.row_q;
     return dispatch_stage1<0>(D, p, NB, st);
 }
 
-size_t deft_flatten_plan_bytes(int NB, int P) { return plan_view(nullptr, NB, P).bytes; }
+size_t deft_flatten_plan_bytes(int NB, int P, int Hq, int Hkv) {
+    if (Hq <= 0 || Hkv <= 0 || Hq % Hkv) return 0;
+    return plan_view(nullptr, flatten_unit_cap(NB, Hq / Hkv), P).bytes;
+}
 
 int deft_flatten_build_plan(const int64_t* block_q, const int64_t* block_q_cnts, const int64_t* block_q_offset,
                             const int64_t* block_bitmasks, const int64_t* block_kv, const int64_t* block_lens, int NB, int P,
-                            int64_t kv_stride_slot, void* plan, size_t plan_bytes, void* stream) {
-    if (NB < 0 || P < 0 || !plan ||
+                            int Hq, int Hkv, int64_t q_stride_tok, int64_t q_stride_head, int64_t kv_stride_slot,
+                            void* plan, size_t plan_bytes, void* stream) {
+    if (NB < 0 || P < 0 || !plan || Hq <= 0 || Hkv <= 0 || Hq % Hkv ||
         (NB > 0 && (!block_q || !block_q_cnts || !block_q_offset || !block_bitmasks || !block_kv || !block_lens))) {
-        set_error("bad plan arguments (NB=%d P=%d)", NB, P);
+        set_error("bad plan arguments (NB=%d P=%d Hq=%d Hkv=%d)", NB, P, Hq, Hkv);
         return DEFT_EINVAL;
     }
-    const PlanView pv = plan_view(plan, NB, P);
+    const PlanView pv = plan_view(plan, flatten_unit_cap(NB, Hq / Hkv), P);
     if (plan_bytes < pv.bytes) {
         set_error("plan buffer too small: %zu < %zu", plan_bytes, pv.bytes);
         return DEFT_EWORKSPACE;
@@ -744,6 +764,9 @@ int deft_flatten_build_plan(const int64_t* block_q, const int64_t* block_q_cnts,
     p.block_kv = block_kv;
     p.block_lens = block_lens;
     p.rows = P;
+    p.G = Hq / Hkv;
+    p.q_st = q_stride_tok;
+    p.q_sh = q_stride_head;
     p.kv_ss = kv_stride_slot;
     return launch_plan(p, NB, pv, static_cast<hipStream_t>(stream));
 }
@@ -786,12 +809,63 @@ int deft_flatten_decode_f16(const void* q, int64_t q_stride_tok, int64_t q_strid
     return launch_merge(D, ws, row_q, P, out, o_stride_tok, o_stride_head, nq, Hq, static_cast<hipStream_t>(stream));
 }
 
+static int launch_node_plan(const Stage1Params& p, int NE, int64_t rows_cap, const PlanView& pv, hipStream_t stream) {
+    const UnitList ul = unit_list(pv);
+    hipLaunchKernelGGL(node_units_kernel, dim3(1), dim3(256), 0, stream, p.node_kv_len, p.node_q_len, NE, p.G, (int)pv.cap,
+                       rows_cap, ul, pv.hdr, pv.sched, pv.row_q);
+    int rc = check_launch("node units launch");
+    if (rc) return rc;
+    hipLaunchKernelGGL(node_records_kernel, dim3((unsigned)(pv.cap + 1)), dim3(128), 0, stream, p.node_kv, p.node_kv_offset,
+                       p.node_kv_len, p.node_q, p.node_q_offset, p.node_q_len, p.G, (int)p.rows, p.q_st, p.q_sh, p.kv_ss, ul,
+                       pv.hdr, pv.records, pv.row_q);
+    return check_launch("node records launch");
+}
+
+size_t deft_node_plan_bytes(int NE, int P, int64_t total_kv, int Hq, int Hkv) {
+    (void)P;
+    if (Hq <= 0 || Hkv <= 0 || Hq % Hkv) return 0;
+    const int64_t tiles = node_max_tiles(NE, total_kv);
+    return plan_view(nullptr, tiles * (Hq / Hkv), tiles * DEFT_MAX_Q_LEN).bytes;
+}
+
+int deft_node_build_plan(const int64_t* node_kv, const int64_t* node_kv_offset, const int64_t* node_kv_len,
+                         const int64_t* node_q, const int64_t* node_q_offset, const int64_t* node_q_len, int NE, int P,
+                         int64_t total_kv, int Hq, int Hkv, int64_t q_stride_tok, int64_t q_stride_head,
+                         int64_t kv_stride_slot, void* plan, size_t plan_bytes, void* stream) {
+    if (NE < 0 || P < 0 || total_kv < 0 || total_kv > 0x7fffffffLL || !plan || Hq <= 0 || Hkv <= 0 || Hq % Hkv ||
+        (NE > 0 && (!node_kv || !node_kv_offset || !node_kv_len || !node_q || !node_q_offset || !node_q_len))) {
+        set_error("bad node plan arguments (NE=%d P=%d total_kv=%lld)", NE, P, (long long)total_kv);
+        return DEFT_EINVAL;
+    }
+    const int64_t tiles = node_max_tiles(NE, total_kv);
+    const int64_t rows = tiles * DEFT_MAX_Q_LEN;
+    const PlanView pv = plan_view(plan, tiles * (Hq / Hkv), rows);
+    if (plan_bytes < pv.bytes) {
+        set_error("plan buffer too small: %zu < %zu", plan_bytes, pv.bytes);
+        return DEFT_EWORKSPACE;
+    }
+    Stage1Params p{};
+    p.node_kv = node_kv;
+    p.node_kv_offset = node_kv_offset;
+    p.node_kv_len = node_kv_len;
+    p.node_q = node_q;
+    p.node_q_offset = node_q_offset;
+    p.node_q_len = node_q_len;
+    p.rows = rows;
+    p.G = Hq / Hkv;
+    p.q_st = q_stride_tok;
+    p.q_sh = q_stride_head;
+    p.kv_ss = kv_stride_slot;
+    return launch_node_plan(p, NE, rows, pv, static_cast<hipStream_t>(stream));
+}
+
 int deft_node_decode_f16(const void* q, int64_t q_stride_tok, int64_t q_stride_head, const void* k_base,
                          const void* v_base, int64_t kv_stride_slot, int64_t kv_stride_head, void* out,
                          int64_t o_stride_tok, int64_t o_stride_head, const int64_t* node_kv,
                          const int64_t* node_kv_offset, const int64_t* node_kv_len, const int64_t* node_q,
                          const int64_t* node_q_offset, const int64_t* node_q_len, int NE, int P, int64_t total_kv, int nq,
-                         int Hq, int Hkv, int D, float scale, void* workspace, size_t workspace_bytes, void* stream) {
+                         int Hq, int Hkv, int D, float scale, const void* plan, void* workspace, size_t workspace_bytes,
+                         void* stream) {
     int rc = check_common(q, q_stride_tok, q_stride_head, k_base, v_base, kv_stride_slot, kv_stride_head, out,
                           o_stride_tok, o_stride_head, nq, Hq, Hkv, D);
     if (rc) return rc;
@@ -804,24 +878,15 @@ int deft_node_decode_f16(const void* q, int64_t q_stride_tok, int64_t q_stride_h
         set_error("null workspace");
         return DEFT_EINVAL;
     }
+    const int G = Hq / Hkv;
     const int64_t tiles = node_max_tiles(NE, total_kv);
     const int64_t rows = tiles * DEFT_MAX_Q_LEN;
-    const Workspace ws = carve(workspace, Hq, D, rows, tiles);
+    const Workspace ws = carve(workspace, Hq, D, rows, tiles, plan_view(nullptr, tiles * G, rows).bytes);
     if (workspace_bytes < ws.bytes) {
         set_error("workspace too small: %zu < %zu", workspace_bytes, ws.bytes);
         return DEFT_EWORKSPACE;
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const size_t prep_lds = sizeof(int) * 2 * (size_t)(NE + 1);
-    if (prep_lds > 64 * 1024) {
-        set_error("node mode: %d entries exceed the prep kernel's LDS scan", NE);
-        return DEFT_EUNSUPPORTED;
-    }
-    hipLaunchKernelGGL(node_prep_kernel, dim3(1), dim3(256), prep_lds, st, node_kv_offset, node_kv_len, node_q_offset,
-                       node_q_len, NE, tiles, rows, ws.desc, ws.row_q);
-    rc = check_launch("node prep launch");
-    if (rc) return rc;
-
     Stage1Params p{};
     p.q = static_cast<const _Float16*>(q);
     p.q_st = q_stride_tok;
@@ -831,15 +896,43 @@ int deft_node_decode_f16(const void* q, int64_t q_stride_tok, int64_t q_stride_h
     p.kv_ss = kv_stride_slot;
     p.kv_sh = kv_stride_head;
     p.node_kv = node_kv;
+    p.node_kv_offset = node_kv_offset;
+    p.node_kv_len = node_kv_len;
     p.node_q = node_q;
-    p.desc = ws.desc;
+    p.node_q_offset = node_q_offset;
+    p.node_q_len = node_q_len;
     p.partial_o = ws.partial_o;
     p.partial_lse = ws.partial_lse;
     p.row_q = ws.row_q;
     p.rows = rows;
     p.Hkv = Hkv;
-    p.G = Hq / Hkv;
+    p.G = G;
     p.scale_log2e = scale * LOG2E;
+    static const bool force_tile = getenv("DEFT_STAGE1_VARIANT") && !strcmp(getenv("DEFT_STAGE1_VARIANT"), "tile");
+    if (D == 128 && !force_tile) {  // streaming stage 1 on node tiles
+        PlanView pv;
+        if (plan) {
+            pv = plan_view(const_cast<void*>(plan), tiles * G, rows);
+        } else {
+            pv = plan_view(ws.plan, tiles * G, rows);
+            rc = launch_node_plan(p, NE, rows, pv, st);
+            if (rc) return rc;
+        }
+        rc = launch_stage1_stream(p, tiles * G, pv, st);
+        if (rc) return rc;
+        return launch_merge(D, ws, pv.row_q, rows, out, o_stride_tok, o_stride_head, nq, Hq, st);
+    }
+    // tile-per-workgroup form (head_dim 64)
+    const size_t prep_lds = sizeof(int) * 2 * (size_t)(NE + 1);
+    if (prep_lds > 64 * 1024) {
+        set_error("node mode: %d entries exceed the prep kernel's LDS scan", NE);
+        return DEFT_EUNSUPPORTED;
+    }
+    hipLaunchKernelGGL(node_prep_kernel, dim3(1), dim3(256), prep_lds, st, node_kv_offset, node_kv_len, node_q_offset,
+                       node_q_len, NE, tiles, rows, ws.desc, ws.row_q);
+    rc = check_launch("node prep launch");
+    if (rc) return rc;
+    p.desc = ws.desc;
     rc = dispatch_stage1<1>(D, p, tiles, st);
     if (rc) return rc;
     return launch_merge(D, ws, ws.row_q, rows, out, o_stride_tok, o_stride_head, nq, Hq, st);
@@ -876,7 +969,7 @@ int deft_flatten_read_partials(const void* workspace, size_t workspace_bytes, in
         set_error("null pointer");
         return DEFT_EINVAL;
     }
-    const Workspace ws = carve(const_cast<void*>(workspace), Hq, D, P, 0, NB);
+    const Workspace ws = carve(const_cast<void*>(workspace), Hq, D, P, 0, plan_view(nullptr, flatten_unit_cap(NB, Hq / Hkv), P).bytes);
     if (workspace_bytes < ws.bytes) {
         set_error("workspace too small");
         return DEFT_EWORKSPACE;

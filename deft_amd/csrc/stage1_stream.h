@@ -47,21 +47,23 @@ namespace deft {
 typedef int32_t intx4 __attribute__((ext_vector_type(4)));
 typedef short short4v __attribute__((ext_vector_type(4)));
 
-// One plan record per Flatten block (+ a sentinel record at index NB):
+// One plan record per work unit of ONE KV head (+ a sentinel record after the last one).  A unit is a
+// 128-slot KV tile together with up to 32 "virtual query rows": row v = (query qi, head g of the GQA
+// group), g fastest.  A tile whose cnt * G rows exceed 32 appears once per 32-row pass; passes of a run
+// of tiles with one query list are ordered pass-major so that consecutive records fold.
 constexpr int PLAN_BYTES = 2048;
 constexpr int PLAN_ROWOFF = 0;   // int64[128]  byte offset of each slot's row in the pool (pads alias slot 0)
-constexpr int PLAN_MASK = 1024;  // uint32[128] query bitmask per slot (0 for pads)
-constexpr int PLAN_DESC = 1536;  // int32[4]    cnt, prow, run_start, len
-constexpr int PLAN_QROW = 1600;  // int32[32]   query row of each of the block's partial rows (0 beyond cnt)
+constexpr int PLAN_MASK = 1024;  // uint32[128] bit v set <=> virtual row v sees the slot (0 for pads)
+constexpr int PLAN_DESC = 1536;  // int32[4]    n_vrows, -, run_start, len
+constexpr int PLAN_QSRC = 1600;  // int32[32]   element offset of row v's Q vector from q + kvh*G*q_stride_head
+constexpr int PLAN_OROW = 1728;  // int32[32]   partial row of row v, relative to kvh*G*rows: g*rows + prow + qi
+constexpr int PLAN_HDR = 256;    // plan header: int32 {records per head R, ...}, scheduler words at +64
 
 struct StreamParams {
     Stage1Params s;
-    const char* plan;  // [NB+1][PLAN_BYTES]
-    int NB;
-    int U;         // NB * Hkv units, head-major
-    int n_static;  // workgroup b first walks units [b*n_static, (b+1)*n_static) ...
-    int pool_base; // ... then takes single units pool_base + ticket from the shared pool [pool_base, U)
-    int* sched;    // [2] = {ticket counter, workgroups done}; both 0 between launches
+    const int32_t* hdr;  // plan header: hdr[0] = R, records per KV head
+    const char* plan;    // [R+1][PLAN_BYTES]
+    int* sched;          // [2] = {ticket counter, workgroups done}; both 0 between launches
     unsigned long long* dbg;  // internal: per-phase s_memtime stamps [workgroup][16 tiles][8], or null
 };
 
@@ -120,11 +122,23 @@ __global__ __launch_bounds__(512, 4) void stage1_stream_kernel(StreamParams sp) 
     // shared pool with an atomic ticket.  Position i of the stream is known two tiles ahead: compute
     // wave 0 publishes unit(i+2) in the sUnit ring before barrier H of tile i.
     const int bid = blockIdx.x;
+    const int RH = sp.hdr[0];  // records per KV head (written by the plan kernels)
+    const int U = RH * p.Hkv;  // units, head-major
+    // Few units per workgroup (< 4): balanced static split, no tickets (a returning atomic in the
+    // prologue costs a memory round trip per workgroup).  Otherwise floor(U/W) static units each and
+    // the remainder from the ticket pool.
+    const int W = (int)gridDim.x;
+    const int per = U / W, rem = U - per * W;
+    const bool use_pool = per >= 4;
+    const int n_static = use_pool ? per : per + (bid < rem ? 1 : 0);
+    const int my_base = use_pool ? bid * per : bid * per + min(bid, rem);
+    const int pool_base = use_pool ? per * W : U;
     int* sUnit = reinterpret_cast<int*>(smem + SM::UNIT_OFF);
     auto take = [&](int pos) -> int {  // lane 0 of compute wave 0 only
-        if (pos < sp.n_static) return bid * sp.n_static + pos;
-        const int u = sp.pool_base + atomicAdd(sp.sched, 1);
-        return u < sp.U ? u : -1;
+        if (pos < n_static) return my_base + pos;
+        if (!use_pool) return -1;
+        const int u = pool_base + atomicAdd(sp.sched, 1);
+        return u < U ? u : -1;
     };
     if (tid == 0) {
         const int a = take(0);
@@ -189,16 +203,16 @@ __global__ __launch_bounds__(512, 4) void stage1_stream_kernel(StreamParams sp) 
 
     // Q rows of the group that opens at a tile: the loaders stage them in the P buffer, which is idle
     // between a tile's PV reads (barrier H) and the next tile's P writes (after barrier C).
-    // Layout like K: row c, 16-byte chunks XOR-ed by (c & 15).  Rows beyond cnt alias query row 0
-    // (their mask bits are 0).  2 DMA instructions per loader.
+    // Layout like K: row c, 16-byte chunks XOR-ed by (c & 15).  Rows beyond n_vrows alias the first
+    // query vector of the group (their mask bits are 0).  2 DMA instructions per loader.
     auto issue_q = [&](int b, int head) {
-        const int32_t* qr = reinterpret_cast<const int32_t*>(meta(b) + PLAN_QROW);
-        const char* hb = reinterpret_cast<const char*>(p.q) + (int64_t)head * p.q_sh * 2;
+        const int32_t* qs = reinterpret_cast<const int32_t*>(meta(b) + PLAN_QSRC);
+        const char* hb = reinterpret_cast<const char*>(p.q) + (int64_t)head * p.G * p.q_sh * 2;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int row = 8 * lw + 4 * i + dkey;
             const int chunk = dpos ^ (row & 15);
-            dma16(hb + (int64_t)qr[row] * p.q_st * 2 + chunk * 16, SM::P_OFF + (uint32_t)(8 * lw + 4 * i) * 256u);
+            dma16(hb + (int64_t)qs[row] * 2 + chunk * 16, SM::P_OFF + (uint32_t)(8 * lw + 4 * i) * 256u);
         }
     };
 
@@ -226,8 +240,8 @@ __global__ __launch_bounds__(512, 4) void stage1_stream_kernel(StreamParams sp) 
         finish();
         return;
     }
-    int kvh = ucur / sp.NB;
-    int t = ucur - kvh * sp.NB;
+    int kvh = ucur / RH;
+    int t = ucur - kvh * RH;  // record index within the head
     if (is_loader) {
         issue_meta(t, 0);
         wait_vm<0>();
@@ -237,15 +251,15 @@ __global__ __launch_bounds__(512, 4) void stage1_stream_kernel(StreamParams sp) 
         load_rowoff(0);
         issue_k(kvh);
         issue_q(0, kvh);  // the first tile of a stream always opens a group
-        if (unext >= 0) issue_meta(unext % sp.NB, 1);
+        if (unext >= 0) issue_meta(unext % RH, 1);
         issue_v(kvh);
 
         // ---- loader loop: same barrier sequence as the compute waves below ---------------
         for (int i = 0;; ++i) {
             const int mb = i & 1;
             const bool last = unext < 0;
-            const int kvh_next = last ? 0 : unext / sp.NB;
-            const int t_next = last ? 0 : unext - kvh_next * sp.NB;
+            const int kvh_next = last ? 0 : unext / RH;
+            const int t_next = last ? 0 : unext - kvh_next * RH;
             wait_vm<LPT>();  // A: K(u) and plan record (u+1) landed
             lds_barrier();
             lds_barrier();   // C: compute waves are done with sK
@@ -260,7 +274,7 @@ __global__ __launch_bounds__(512, 4) void stage1_stream_kernel(StreamParams sp) 
             const int u2 = __builtin_amdgcn_readfirstlane(sUnit[(i + 2) & 3]);
             const bool next_opens = (unext != ucur + 1) || (t_next == 0) || (read_desc(mb ^ 1)[2] != 0);
             if (next_opens) issue_q(mb ^ 1, kvh_next);
-            if (u2 >= 0) issue_meta(u2 % sp.NB, mb);
+            if (u2 >= 0) issue_meta(u2 % RH, mb);
             issue_v(kvh_next);
             ucur = unext;
             unext = u2;
@@ -276,15 +290,15 @@ __global__ __launch_bounds__(512, 4) void stage1_stream_kernel(StreamParams sp) 
     floatx16 o;
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[r] = 0.f;
-    int g_prow = 0;
+    int g_orow = 0;  // this lane's partial row of the open group, relative to kvh * G * rows
     bool qvalid = false;
 
     bool prev_adjacent = false;  // unit(i) == unit(i-1) + 1
     for (int i = 0;; ++i) {
         const int mb = i & 1;  // plan record buffer of this unit
-        const int hq = kvh;    // G == 1
         const bool last = unext < 0;
         const intx4 cur = read_desc(mb);
+        const int orow_c = reinterpret_cast<const int32_t*>(meta(mb) + PLAN_OROW)[c];
         const bool g_start = !prev_adjacent || (t == 0) || (cur[2] != 0);
 
         // ---- A: K(u) and plan record (u+1) landed ------------------------------------
@@ -292,7 +306,7 @@ __global__ __launch_bounds__(512, 4) void stage1_stream_kernel(StreamParams sp) 
         lds_barrier();
         stamp(i, 1);
         if (g_start) {  // new group: its Q rows sit in the P buffer (staged by the loaders)
-            g_prow = cur[1];
+            g_orow = orow_c;
             qvalid = c < cur[0];
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
@@ -304,10 +318,10 @@ __global__ __launch_bounds__(512, 4) void stage1_stream_kernel(StreamParams sp) 
         }
         const bool next_adjacent = !last && (unext == ucur + 1);
         bool g_end = true;  // plan record (u+1) is visible now
-        if (next_adjacent) g_end = (t + 1 == sp.NB) || (read_desc(mb ^ 1)[2] != 0);
+        if (next_adjacent) g_end = (t + 1 == RH) || (read_desc(mb ^ 1)[2] != 0);
         // the ticket for position i+2 travels while this tile computes (compute waves issue no other loads)
         int ticket = 0;  // consumed just before barrier H, a tile's worth of time after the atomic was issued
-        const bool pooled = (i + 2 >= sp.n_static);
+        const bool pooled = use_pool && (i + 2 >= n_static);
         if (tid == 0 && !last && pooled)  // asm: hipcc would otherwise wait for the returned value right here
             asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(ticket) : "v"(sp.sched), "v"(1) : "memory");
 
@@ -398,8 +412,8 @@ __global__ __launch_bounds__(512, 4) void stage1_stream_kernel(StreamParams sp) 
         stamp(i, 6);
         if (tid == 0 && !last) {
             if (pooled) asm volatile("s_waitcnt vmcnt(0)" : "+v"(ticket)::"memory");
-            int u2 = pooled ? sp.pool_base + ticket : bid * sp.n_static + i + 2;
-            sUnit[(i + 2) & 3] = u2 < sp.U ? u2 : -1;
+            int u2 = pooled ? pool_base + ticket : (i + 2 < n_static ? my_base + i + 2 : U);
+            sUnit[(i + 2) & 3] = u2 < U ? u2 : -1;
         }
         lds_barrier();
         stamp(i, 7);
@@ -407,11 +421,12 @@ __global__ __launch_bounds__(512, 4) void stage1_stream_kernel(StreamParams sp) 
         // ---- I: (loaders) plan record (u+2) and V(u+1) stream in during the next tile's QK^T / softmax
 
         // ---- J: bookkeeping for the merge; partial out at the end of a group --------------------
+        const int64_t head_rows = (int64_t)kvh * p.G * p.rows;
         if (!(p.ablate & 8) && !g_start && qvalid && w == 0 && h == 0)
-            p.partial_lse[(int64_t)hq * p.rows + cur[1] + c] = -INFINITY;  // row folded into its group's partial
+            p.partial_lse[head_rows + orow_c] = -INFINITY;  // row folded into its group's partial
         if (!(p.ablate & 16) && g_end && qvalid) {
             const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
-            const int64_t prow_idx = (int64_t)hq * p.rows + g_prow + c;
+            const int64_t prow_idx = head_rows + g_orow;
             float* po = p.partial_o + prow_idx * D + 32 * w + 4 * h;
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
@@ -425,68 +440,202 @@ __global__ __launch_bounds__(512, 4) void stage1_stream_kernel(StreamParams sp) 
         prev_adjacent = next_adjacent;
         ucur = unext;
         unext = __builtin_amdgcn_readfirstlane(sUnit[(i + 2) & 3]);
-        kvh = ucur / sp.NB;
-        t = ucur - kvh * sp.NB;
+        kvh = ucur / RH;
+        t = ucur - kvh * RH;
     }
     finish();
 }
 
-// Packs the plan records (see PLAN_* above) and the partial-row -> query map; one workgroup
-// of 128 threads per block, block NB is the sentinel record.
-__global__ __launch_bounds__(128) void flatten_plan_kernel(const int64_t* block_q, const int64_t* block_q_cnts,
-                                                           const int64_t* block_q_offset, const int64_t* block_bitmasks,
-                                                           const int64_t* block_kv, const int64_t* block_lens, int NB, int P,
-                                                           int64_t kv_stride_slot, char* plan, int32_t* row_q,
-                                                           int32_t* sched, unsigned long long* dbg) {
-    const int t = blockIdx.x;
+// ---------------------------------------------------------------------------
+// Plan kernels (once per decode step): metadata -> unit list -> records
+// ---------------------------------------------------------------------------
+struct UnitList {   // all int32, capacity `cap` each
+    int32_t* src;   // Flatten: block index; Node: entry index
+    int32_t* aux;   // Flatten: 0;           Node: 128-slot tile index within the entry
+    int32_t* pass;  // 32-row pass of the unit's virtual query rows
+    int32_t* flags; // bit 0: opens a run (query list differs from the previous unit's)
+    int32_t* prow;  // first partial row of the unit's tile
+};
+
+// Flatten: one workgroup.  Phase 1 (parallel over blocks): does block t open a run, how many passes.
+// Phase 2 (one thread): emit units run by run, pass-major inside a run so that consecutive units fold.
+__global__ __launch_bounds__(256) void flatten_units_kernel(const int64_t* block_q, const int64_t* block_q_cnts,
+                                                            const int64_t* block_q_offset, int NB, int G, int cap,
+                                                            UnitList ul, int32_t* hdr, int32_t* sched) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int* sOpen = reinterpret_cast<int*>(smem);  // [NB]
+    int* sPass = sOpen + NB;                    // [NB]
+    for (int t = threadIdx.x; t < NB; t += blockDim.x) {
+        const int cnt = (int)block_q_cnts[t];
+        bool open = (t == 0);
+        if (t > 0) {
+            open = cnt != (int)block_q_cnts[t - 1];
+            const int64_t a = block_q_offset[t], b = block_q_offset[t - 1];
+            for (int i = 0; !open && i < cnt; ++i) open = block_q[a + i] != block_q[b + i];
+        }
+        sOpen[t] = open ? 1 : 0;
+        sPass[t] = (cnt * G + MQ - 1) / MQ;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int r = 0;
+        for (int ta = 0; ta < NB;) {
+            int tb = ta + 1;
+            while (tb < NB && !sOpen[tb]) ++tb;
+            const int np = sPass[ta];
+            for (int ps = 0; ps < np; ++ps)
+                for (int t = ta; t < tb && r < cap; ++t, ++r) {
+                    ul.src[r] = t;
+                    ul.aux[r] = 0;
+                    ul.pass[r] = ps;
+                    ul.flags[r] = (t == ta) ? 1 : 0;
+                    ul.prow[r] = (int)block_q_offset[t];
+                }
+            ta = tb;
+        }
+        hdr[0] = r;
+        sched[0] = 0;
+        sched[1] = 0;
+    }
+}
+
+// One workgroup of 128 threads per unit (+ the sentinel): pack its record.
+__global__ __launch_bounds__(128) void flatten_records_kernel(const int64_t* block_q, const int64_t* block_q_cnts,
+                                                              const int64_t* block_bitmasks, const int64_t* block_kv,
+                                                              const int64_t* block_lens, int G, int rows, int64_t q_st,
+                                                              int64_t q_sh, int64_t kv_stride_slot, UnitList ul,
+                                                              const int32_t* hdr, char* plan, int32_t* row_q) {
+    const int r = blockIdx.x;
     const int k = threadIdx.x;
-    struct Stamp {  // internal profiling: first start / last end of this kernel on the 100 MHz clock
-        unsigned long long* d;
-        bool on;
-        __device__ Stamp(unsigned long long* dd, bool o) : d(dd), on(o) { if (on) atomicMin(d + 65536, wall_clock64()); }
-        __device__ ~Stamp() { if (on) atomicMax(d + 65537, wall_clock64()); }
-    } stamp_(dbg, dbg != nullptr && k == 0);
-    char* rec = plan + (int64_t)t * PLAN_BYTES;
+    const int R = hdr[0];
+    if (r > R) return;
+    char* rec = plan + (int64_t)r * PLAN_BYTES;
     int64_t* ro = reinterpret_cast<int64_t*>(rec + PLAN_ROWOFF);
     uint32_t* mk = reinterpret_cast<uint32_t*>(rec + PLAN_MASK);
     int32_t* desc = reinterpret_cast<int32_t*>(rec + PLAN_DESC);
-    if (t >= NB) {  // sentinel
+    if (r == R) {  // sentinel
         ro[k] = 0;
         mk[k] = 0u;
-        if (k < 2) sched[k] = 0;
         if (k == 0) {
             desc[0] = 0;
-            desc[1] = P;
+            desc[1] = 0;
             desc[2] = 1;
             desc[3] = 0;
         }
         return;
     }
+    const int t = ul.src[r];
+    const int ps = ul.pass[r];
+    const int prow = ul.prow[r];
     const int len = (int)block_lens[t];
     const int cnt = (int)block_q_cnts[t];
-    const int prow = (int)block_q_offset[t];
+    const int nv = min(MQ, cnt * G - MQ * ps);  // virtual rows of this pass
     const bool live = k < len;
     ro[k] = block_kv[(int64_t)t * TILE + (live ? k : 0)] * kv_stride_slot * 2;  // fp16 bytes
-    mk[k] = live ? (uint32_t)block_bitmasks[(int64_t)t * TILE + k] : 0u;
-    __shared__ int s_diff;
-    if (k == 0) s_diff = (t == 0) ? 1 : 0;
-    __syncthreads();
-    if (t > 0 && k < MQ) {
-        const int cntp = (int)block_q_cnts[t - 1];
-        bool differ = (cnt != cntp);
-        if (!differ && k < cnt) differ = block_q[prow + k] != block_q[block_q_offset[t - 1] + k];
-        if (differ) s_diff = 1;  // benign race: every writer stores 1
-    }
+    const uint32_t qmask = live ? (uint32_t)block_bitmasks[(int64_t)t * TILE + k] : 0u;
+    uint32_t vm = 0u;
+    for (int v = 0; v < nv; ++v) vm |= ((qmask >> ((MQ * ps + v) / G)) & 1u) << v;
+    mk[k] = vm;
     if (k < MQ) {
-        const int32_t qv = (k < cnt) ? (int32_t)block_q[prow + k] : 0;
-        reinterpret_cast<int32_t*>(rec + PLAN_QROW)[k] = qv;
-        if (k < cnt) row_q[prow + k] = qv;
+        int qs = 0, orow = 0;
+        if (k < nv) {
+            const int qi = (MQ * ps + k) / G, g = (MQ * ps + k) % G;
+            qs = (int)(block_q[prow + qi] * q_st + g * q_sh);
+            orow = g * rows + prow + qi;
+        } else if (nv > 0) {
+            qs = (int)(block_q[prow + (MQ * ps) / G] * q_st + ((MQ * ps) % G) * q_sh);  // alias a real row
+        }
+        reinterpret_cast<int32_t*>(rec + PLAN_QSRC)[k] = qs;
+        reinterpret_cast<int32_t*>(rec + PLAN_OROW)[k] = orow;
+        if (ps == 0 && k < cnt) row_q[prow + k] = (int32_t)block_q[prow + k];
     }
-    __syncthreads();
     if (k == 0) {
-        desc[0] = cnt;
+        desc[0] = nv;
         desc[1] = prow;
-        desc[2] = s_diff;
+        desc[2] = ul.flags[r] & 1;
+        desc[3] = len;
+    }
+}
+
+// Node mode (tree_attention.py:14-293): every entry (a node's KV x up to 32 of its queries) is cut into
+// 128-slot tiles; all live slots are visible to all of the entry's queries.  Consecutive tiles of one
+// entry fold, which is the reference's serial online-softmax walk (:230-276) without the serialisation.
+__global__ __launch_bounds__(256) void node_units_kernel(const int64_t* node_kv_len, const int64_t* node_q_len, int NE, int G,
+                                                         int cap, int64_t rows_cap, UnitList ul, int32_t* hdr,
+                                                         int32_t* sched, int32_t* row_q) {
+    for (int64_t i = threadIdx.x; i < rows_cap; i += blockDim.x) row_q[i] = -1;
+    if (threadIdx.x == 0) {
+        int r = 0, rowbase = 0;
+        for (int e = 0; e < NE; ++e) {
+            const int nt = (int)((node_kv_len[e] + TILE - 1) / TILE);
+            const int ql = (int)node_q_len[e];
+            const int np = (ql * G + MQ - 1) / MQ;
+            for (int ps = 0; ps < np; ++ps)
+                for (int tt = 0; tt < nt && r < cap; ++tt, ++r) {
+                    ul.src[r] = e;
+                    ul.aux[r] = tt;
+                    ul.pass[r] = ps;
+                    ul.flags[r] = (tt == 0) ? 1 : 0;
+                    ul.prow[r] = rowbase + tt * ql;
+                }
+            rowbase += nt * ql;
+        }
+        hdr[0] = r;
+        sched[0] = 0;
+        sched[1] = 0;
+    }
+}
+
+__global__ __launch_bounds__(128) void node_records_kernel(const int64_t* node_kv, const int64_t* node_kv_offset,
+                                                           const int64_t* node_kv_len, const int64_t* node_q,
+                                                           const int64_t* node_q_offset, const int64_t* node_q_len, int G,
+                                                           int rows, int64_t q_st, int64_t q_sh, int64_t kv_stride_slot,
+                                                           UnitList ul, const int32_t* hdr, char* plan, int32_t* row_q) {
+    const int r = blockIdx.x;
+    const int k = threadIdx.x;
+    const int R = hdr[0];
+    if (r > R) return;
+    char* rec = plan + (int64_t)r * PLAN_BYTES;
+    int64_t* ro = reinterpret_cast<int64_t*>(rec + PLAN_ROWOFF);
+    uint32_t* mk = reinterpret_cast<uint32_t*>(rec + PLAN_MASK);
+    int32_t* desc = reinterpret_cast<int32_t*>(rec + PLAN_DESC);
+    if (r == R) {  // sentinel
+        ro[k] = 0;
+        mk[k] = 0u;
+        if (k == 0) {
+            desc[0] = 0;
+            desc[1] = 0;
+            desc[2] = 1;
+            desc[3] = 0;
+        }
+        return;
+    }
+    const int e = ul.src[r], tt = ul.aux[r], ps = ul.pass[r], prow = ul.prow[r];
+    const int64_t kv0 = node_kv_offset[e] + (int64_t)tt * TILE;
+    const int len = (int)min((int64_t)TILE, node_kv_len[e] - (int64_t)tt * TILE);
+    const int64_t q0 = node_q_offset[e];
+    const int ql = (int)node_q_len[e];
+    const int nv = min(MQ, ql * G - MQ * ps);
+    const bool live = k < len;
+    ro[k] = node_kv[kv0 + (live ? k : 0)] * kv_stride_slot * 2;
+    mk[k] = live ? (nv >= 32 ? 0xffffffffu : ((1u << nv) - 1u)) : 0u;
+    if (k < MQ) {
+        int qs = 0, orow = 0;
+        if (k < nv) {
+            const int qi = (MQ * ps + k) / G, g = (MQ * ps + k) % G;
+            qs = (int)(node_q[q0 + qi] * q_st + g * q_sh);
+            orow = g * rows + prow + qi;
+        } else if (nv > 0) {
+            qs = (int)(node_q[q0 + (MQ * ps) / G] * q_st + ((MQ * ps) % G) * q_sh);
+        }
+        reinterpret_cast<int32_t*>(rec + PLAN_QSRC)[k] = qs;
+        reinterpret_cast<int32_t*>(rec + PLAN_OROW)[k] = orow;
+        if (ps == 0 && k < ql) row_q[prow + k] = (int32_t)node_q[q0 + k];
+    }
+    if (k == 0) {
+        desc[0] = nv;
+        desc[1] = prow;
+        desc[2] = ul.flags[r] & 1;
         desc[3] = len;
     }
 }

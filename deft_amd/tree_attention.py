@@ -48,25 +48,44 @@ def _check_qkv(query_states, key_buffer, value_buffer, output):
     return nq, Hq, Hkv, D
 
 
-def _flatten_plan(md, NB: int, P: int, kv_stride_slot: int, stream: int):
+def _flatten_plan(md, NB: int, P: int, Hq: int, Hkv: int, q_strides, kv_stride_slot: int, stream: int):
     """Device-side repack of the Flatten metadata, built once per decode step.
 
     The reference builds TreeMetadata once per step and all layers read the same tensor
     objects (tree_cache.py:1021-1037), so the plan is cached ON the block_q tensor, keyed by
-    the identity and in-place version of all six arrays and by the pool stride.  Fresh
+    the identity and in-place version of all six arrays, the head counts and the q / pool
+    strides.  Fresh
     tensors (or an in-place edit) simply rebuild it; results never depend on the cache."""
     block_q = md[0]
-    key = (kv_stride_slot, NB, P) + tuple((t.data_ptr(), t._version) for t in md)
+    key = (kv_stride_slot, NB, P, Hq, Hkv, tuple(q_strides)) + tuple((t.data_ptr(), t._version) for t in md)
     cached = getattr(block_q, "_deft_plan", None)
     if cached is not None and cached[0] == key:
         return cached[1]
-    nbytes = lib.deft_flatten_plan_bytes(NB, P)
-    plan = torch.empty(nbytes, dtype=torch.uint8, device=block_q.device)
-    check(lib.deft_flatten_build_plan(*[t.data_ptr() for t in md], NB, P, kv_stride_slot, plan.data_ptr(), nbytes, stream),
-          "deft_flatten_build_plan")
+    nbytes = lib.deft_flatten_plan_bytes(NB, P, Hq, Hkv)
+    plan = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=block_q.device)
+    check(lib.deft_flatten_build_plan(*[t.data_ptr() for t in md], NB, P, Hq, Hkv, q_strides[0], q_strides[1],
+                                      kv_stride_slot, plan.data_ptr(), nbytes, stream), "deft_flatten_build_plan")
     try:
         block_q._deft_plan = (key, plan)
     except Exception:  # tensors that refuse attributes just do not cache
+        pass
+    return plan
+
+
+def _node_plan(md, NE: int, P: int, total_kv: int, Hq: int, Hkv: int, q_strides, kv_stride_slot: int, stream: int):
+    """Node-mode counterpart of `_flatten_plan`; cached on the KVMapQ_List (node_q) tensor."""
+    node_q = md[3]
+    key = (kv_stride_slot, NE, P, total_kv, Hq, Hkv, tuple(q_strides)) + tuple((t.data_ptr(), t._version) for t in md)
+    cached = getattr(node_q, "_deft_plan", None)
+    if cached is not None and cached[0] == key:
+        return cached[1]
+    nbytes = lib.deft_node_plan_bytes(NE, P, total_kv, Hq, Hkv)
+    plan = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=node_q.device)
+    check(lib.deft_node_build_plan(*[t.data_ptr() for t in md], NE, P, total_kv, Hq, Hkv, q_strides[0], q_strides[1],
+                                   kv_stride_slot, plan.data_ptr(), nbytes, stream), "deft_node_build_plan")
+    try:
+        node_q._deft_plan = (key, plan)
+    except Exception:
         pass
     return plan
 
@@ -106,7 +125,7 @@ def tree_attention_subtree_fwd(
     ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=query_states.device)
     scale = 1.0 / (D ** 0.5)  # tree_attention.py:601
     stream = _stream_ptr(query_states)
-    plan = _flatten_plan(md, NB, P, key_buffer.stride(0), stream)
+    plan = _flatten_plan(md, NB, P, Hq, Hkv, (query_states.stride(0), query_states.stride(1)), key_buffer.stride(0), stream)
     rc = lib.deft_flatten_decode_f16(
         query_states.data_ptr(), query_states.stride(0), query_states.stride(1),
         key_buffer.data_ptr(), value_buffer.data_ptr(), key_buffer.stride(0), key_buffer.stride(1),
@@ -140,12 +159,15 @@ def tree_attention_fwd(
     ws_bytes = lib.deft_node_workspace_bytes(NE, P, total_kv, nq, Hq, Hkv, D)
     ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=query_states.device)
     scale = 1.0 / (D ** 0.5)  # tree_attention.py:102
+    stream = _stream_ptr(query_states)
+    plan = _node_plan(md, NE, P, total_kv, Hq, Hkv, (query_states.stride(0), query_states.stride(1)),
+                      key_buffer.stride(0), stream)
     rc = lib.deft_node_decode_f16(
         query_states.data_ptr(), query_states.stride(0), query_states.stride(1),
         key_buffer.data_ptr(), value_buffer.data_ptr(), key_buffer.stride(0), key_buffer.stride(1),
         output.data_ptr(), output.stride(0), output.stride(1),
         *[t.data_ptr() for t in md],
-        NE, P, total_kv, nq, Hq, Hkv, D, scale, ws.data_ptr(), ws_bytes, _stream_ptr(query_states),
+        NE, P, total_kv, nq, Hq, Hkv, D, scale, plan.data_ptr(), ws.data_ptr(), ws_bytes, stream,
     )
     check(rc, "deft_node_decode_f16")
 

@@ -71,15 +71,17 @@ size_t deft_flatten_workspace_bytes(int NB, int P, int nq, int Hq, int Hkv, int 
  * it through a module global, tree_cache.py:1021-1037), so the device-side repack of it
  * (row byte offsets in the pool, 32-bit query masks, run boundaries, partial-row -> query
  * map) can be built once per step and handed to every layer's call.  `plan` is caller-
- * owned device memory of deft_flatten_plan_bytes(NB, P) bytes; it depends on the six
- * metadata arrays and on kv_stride_slot only.  Passing plan = NULL to the decode call
+ * owned device memory of deft_flatten_plan_bytes(NB, P, Hq, Hkv) bytes; it depends on the
+ * six metadata arrays, the head counts and the q / pool strides only (not on the layer).
+ * Two words of it are scheduler state that every launch leaves zeroed again.  Passing plan = NULL to the decode call
  * makes it build the plan itself into the workspace (one more small kernel per call).
  */
-size_t deft_flatten_plan_bytes(int NB, int P);
+size_t deft_flatten_plan_bytes(int NB, int P, int Hq, int Hkv);
 int deft_flatten_build_plan(
     const int64_t* block_q, const int64_t* block_q_cnts, const int64_t* block_q_offset,
     const int64_t* block_bitmasks, const int64_t* block_kv, const int64_t* block_lens,
-    int NB, int P, int64_t kv_stride_slot, void* plan, size_t plan_bytes, void* stream);
+    int NB, int P, int Hq, int Hkv, int64_t q_stride_tok, int64_t q_stride_head, int64_t kv_stride_slot,
+    void* plan, size_t plan_bytes, void* stream);
 
 /*
  * out[nq,Hq,D] = tree attention of q over the flattened-tree blocks.
@@ -107,6 +109,15 @@ int deft_flatten_decode_f16(
 
 size_t deft_node_workspace_bytes(int NE, int P, int64_t total_kv, int nq, int Hq, int Hkv, int D);
 
+/* Optional per-step plan for Node mode; same contract as the Flatten plan above. */
+size_t deft_node_plan_bytes(int NE, int P, int64_t total_kv, int Hq, int Hkv);
+int deft_node_build_plan(
+    const int64_t* node_kv, const int64_t* node_kv_offset, const int64_t* node_kv_len,
+    const int64_t* node_q, const int64_t* node_q_offset, const int64_t* node_q_len,
+    int NE, int P, int64_t total_kv, int Hq, int Hkv,
+    int64_t q_stride_tok, int64_t q_stride_head, int64_t kv_stride_slot,
+    void* plan, size_t plan_bytes, void* stream);
+
 /*
  *   node_kv[total_kv]       pool slots of every entry, concatenated
  *   node_kv_offset/len[NE]  slice of node_kv per entry
@@ -123,7 +134,7 @@ int deft_node_decode_f16(
     const int64_t* node_kv, const int64_t* node_kv_offset, const int64_t* node_kv_len,
     const int64_t* node_q, const int64_t* node_q_offset, const int64_t* node_q_len,
     int NE, int P, int64_t total_kv, int nq, int Hq, int Hkv, int D, float scale,
-    void* workspace, size_t workspace_bytes, void* stream);
+    const void* plan, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- paged KV append ---------------------------------------------------- */
 
