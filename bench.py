@@ -190,9 +190,9 @@ def run_timed(b: Bench, steps: int, warmup: int, dist_on: bool):
         dist.barrier()
     dt = time.perf_counter() - t0
     if dist_on:
-        t = torch.tensor([dt], dtype=torch.float64, device=b.device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        from deft_amd.utils.sharding import max_over_ranks
+
+        dt = max_over_ranks(dt, b.device)  # control plane only; the data path has no collective
     return dt
 
 
@@ -243,10 +243,22 @@ def main():
     roofline = None
     if s1 is not None:
         achieved = algo / (s1["mean_us"] * 1e-6) / 1e9
-        roofline = {"bound": "hbm", "kernel": "deft::stage1_kernel<128,0> (Flatten stage 1)", "achieved": round(achieved, 1),
-                    "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+        traffic = None  # HBM bytes per launch from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE, x2 gfx950 correction)
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_fetch_size.json")))
+            if w.name == "northstar_4kx32" and w.branch_len == 200:
+                k = [v for n, v in pmc["kernels"].items() if "stage1_stream_kernel" in n]
+                traffic = k[0]["hbm_read_bytes_per_launch"] if k else None
+        except Exception:
+            traffic = None
+        roofline = {"bound": "hbm", "kernel": "deft::stage1_stream_kernel<128> (Flatten stage 1)",
+                    "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                    "traffic_source": "profiles/r1_pmc_fetch_size.json (read bytes; separate --pmc pass)" if traffic else None,
                     "algorithmic_bytes_per_launch": algo, "avg_launch_us": round(s1["mean_us"], 2),
-                    "median_launch_us": round(s1["median_us"], 2), "launches_timed": s1["launches"]}
+                    "median_launch_us": round(s1["median_us"], 2), "launches_timed": s1["launches"],
+                    "timing": "HIP events around a hipGraph of one launch per layer pool" if s1.get("launch") == "hipgraph"
+                              else "HIP events around eager launches"}
     step_achieved = algo * layers / (dt / args.steps) / 1e9
 
     extras = {}

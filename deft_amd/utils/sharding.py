@@ -1,0 +1,49 @@
+"""Forest sharding for N > 1 GPUs: independent decoding trees share nothing, so the path
+partitions by tree with NO data-path collective.  One process per GPU; each rank
+owns the KV pools, metadata and plans of its trees.  The only communication is control-plane:
+the timing barrier / max-over-ranks in bench.py and, if a consumer wants every rank's outputs,
+one all-gather of <= 1 MB per rank (not on the hot path)."""
+from __future__ import annotations
+
+from typing import List, Sequence
+
+import torch
+import torch.distributed as dist
+
+
+def shard_trees(kv_tokens_per_tree: Sequence[int], world_size: int) -> List[List[int]]:
+    """Greedy longest-processing-time partition of trees over ranks, balanced by unique KV tokens
+    (attention time is proportional to KV bytes).  Deterministic: every rank computes the same
+    assignment locally, nothing is exchanged."""
+    order = sorted(range(len(kv_tokens_per_tree)), key=lambda i: (-kv_tokens_per_tree[i], i))
+    loads = [0] * world_size
+    shards: List[List[int]] = [[] for _ in range(world_size)]
+    for i in order:
+        r = min(range(world_size), key=lambda k: (loads[k], k))
+        shards[r].append(i)
+        loads[r] += kv_tokens_per_tree[i]
+    return [sorted(s) for s in shards]
+
+
+def max_over_ranks(seconds: float, device: torch.device) -> float:
+    """Slowest rank's time (bench contract: barrier, time, MAX over ranks)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return seconds
+    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def all_gather_outputs(o_local: torch.Tensor) -> List[torch.Tensor]:
+    """Optional, off the hot path: every rank receives every rank's attention outputs
+    (RCCL all-gather on GPUs, gloo on CPU).  Shapes may differ per rank (ragged forests)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [o_local]
+    world = dist.get_world_size()
+    shapes = [None] * world
+    dist.all_gather_object(shapes, tuple(o_local.shape))
+    outs = [torch.empty(s, dtype=o_local.dtype, device=o_local.device) for s in shapes]
+    dist.all_gather(outs, o_local.contiguous()) if len(set(shapes)) == 1 else [
+        dist.broadcast(outs[r] if r != dist.get_rank() else outs[r].copy_(o_local), src=r) for r in range(world)
+    ]
+    return outs
