@@ -530,6 +530,15 @@ static int num_cus() {
 }
 
 // Flatten stage 1, streaming form (MHA, head_dim 128).  `plan` is workspace memory.
+// Optional fused paged append (deft_*_decode_append_f16): this step's new K/V rows and their pool slots.
+struct AppendArgs {
+    const _Float16* k_new = nullptr;
+    const _Float16* v_new = nullptr;
+    const int32_t* cache_loc = nullptr;
+    int64_t new_st = 0;
+    int n_new = 0;
+};
+
 static UnitList unit_list(const PlanView& pv) {
     UnitList ul;
     ul.src = pv.units;
@@ -541,7 +550,7 @@ static UnitList unit_list(const PlanView& pv) {
 }
 
 // Flatten plan: unit list (one workgroup) then one record per unit.
-static int launch_plan(const Stage1Params& p, int NB, const PlanView& pv, hipStream_t stream) {
+static int launch_plan(const Stage1Params& p, int NB, const PlanView& pv, const AppendArgs& ap, hipStream_t stream) {
     if (NB <= 0) return DEFT_OK;
     const size_t lds = sizeof(int) * 2 * (size_t)NB;
     if (lds > 64 * 1024) {
@@ -555,13 +564,14 @@ static int launch_plan(const Stage1Params& p, int NB, const PlanView& pv, hipStr
     if (rc) return rc;
     hipLaunchKernelGGL(flatten_records_kernel, dim3((unsigned)(pv.cap + 1)), dim3(128), 0, stream, p.block_q, p.block_q_cnts,
                        p.block_bitmasks, p.block_kv, p.block_lens, p.G, (int)p.rows, p.q_st, p.q_sh, p.kv_ss, ul, pv.hdr,
-                       pv.records, pv.row_q);
+                       pv.records, pv.row_q, ap.cache_loc, ap.n_new, ap.new_st * 2);
     return check_launch("flatten records launch");
 }
 
 // Stage 1, streaming form (head_dim 128; MHA and GQA).  Units per head are only known on the device
 // (plan header), so the grid is sized from the host-side upper bound.
-static int launch_stage1_stream(const Stage1Params& p, int64_t unit_cap, const PlanView& pv, hipStream_t stream) {
+static int launch_stage1_stream(const Stage1Params& p, int64_t unit_cap, const PlanView& pv, const AppendArgs& ap,
+                                hipStream_t stream) {
     using SM = StreamSmem<128>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -585,6 +595,15 @@ static int launch_stage1_stream(const Stage1Params& p, int64_t unit_cap, const P
     sp.plan = pv.records;
     sp.sched = pv.sched;
     sp.dbg = g_stream_dbg;
+    sp.k_new = ap.k_new;
+    sp.v_new = ap.v_new;
+    sp.cache_loc = ap.cache_loc;
+    sp.new_st = ap.new_st;
+    sp.n_new = ap.k_new ? ap.n_new : 0;
+    if (sp.n_new > workers) {
+        set_error("fused append: %d new rows exceed the %lld workgroups of the launch", sp.n_new, (long long)workers);
+        return DEFT_EUNSUPPORTED;
+    }
     hipLaunchKernelGGL((stage1_stream_kernel<128>), dim3((unsigned)workers), dim3(512), SM::BYTES, stream, sp);
     return check_launch("stage1 stream launch");
 }
@@ -673,6 +692,16 @@ size_t deft_node_workspace_bytes(int NE, int P, int64_t total_kv, int nq, int Hq
     return carve(nullptr, Hq, D, rows, tiles, plan_view(nullptr, tiles * (Hq / Hkv), rows).bytes).bytes;
 }
 
+static int check_append(const AppendArgs& ap, int Hkv, int D) {
+    if (!ap.k_new && !ap.v_new && !ap.cache_loc) return DEFT_OK;
+    if (!ap.k_new || !ap.v_new || !ap.cache_loc || ap.n_new < 0 || (ap.new_st % 8) || ap.new_st < (int64_t)Hkv * D ||
+        !aligned16(ap.k_new) || !aligned16(ap.v_new)) {
+        set_error("bad fused-append arguments (n_new=%d new_stride=%lld)", ap.n_new, (long long)ap.new_st);
+        return DEFT_EINVAL;
+    }
+    return DEFT_OK;
+}
+
 // Shared body of the Flatten entry points: stage 1 into the workspace; reports which
 // partial-row -> query map the merge must read.
 static int flatten_stage1_impl(const void* q, int64_t q_stride_tok, int64_t q_stride_head, const void* k_base,
@@ -680,7 +709,7 @@ static int flatten_stage1_impl(const void* q, int64_t q_stride_tok, int64_t q_st
                                const int64_t* block_q_cnts, const int64_t* block_q_offset, const int64_t* block_bitmasks,
                                const int64_t* block_kv, const int64_t* block_lens, int NB, int P, int nq, int Hq, int Hkv,
                                int D, float scale, const void* plan, void* workspace, size_t workspace_bytes, void* stream,
-                               Workspace* ws_out, const int32_t** row_q_out) {
+                               const AppendArgs& ap, Workspace* ws_out, const int32_t** row_q_out) {
     // `workspace` doubles as the (unused) output pointer for the shared argument check
     int rc = check_common(q, q_stride_tok, q_stride_head, k_base, v_base, kv_stride_slot, kv_stride_head, workspace, 2, 2,
                           nq, Hq, Hkv, D);
@@ -727,11 +756,16 @@ static int flatten_stage1_impl(const void* q, int64_t q_stride_tok, int64_t q_st
             pv = plan_view(const_cast<void*>(plan), cap, P);
         } else {
             pv = plan_view(ws.plan, cap, P);
-            rc = launch_plan(p, NB, pv, st);
+            rc = launch_plan(p, NB, pv, ap, st);
             if (rc) return rc;
         }
         *row_q_out = pv.row_q;
-        return launch_stage1_stream(p, cap, pv, st);
+        return launch_stage1_stream(p, cap, pv, ap, st);
+    }
+    if (ap.k_new) {  // tile-per-workgroup form: separate append launch first
+        rc = deft_kv_append_f16(const_cast<void*>(k_base), const_cast<void*>(v_base), kv_stride_slot, kv_stride_head,
+                                ap.cache_loc, ap.k_new, ap.v_new, ap.new_st, ap.n_new, Hkv, D, stream);
+        if (rc) return rc;
     }
     *row_q_out = ws.row_q;
     return dispatch_stage1<0>(D, p, NB, st);
@@ -745,8 +779,9 @@ size_t deft_flatten_plan_bytes(int NB, int P, int Hq, int Hkv) {
 int deft_flatten_build_plan(const int64_t* block_q, const int64_t* block_q_cnts, const int64_t* block_q_offset,
                             const int64_t* block_bitmasks, const int64_t* block_kv, const int64_t* block_lens, int NB, int P,
                             int Hq, int Hkv, int64_t q_stride_tok, int64_t q_stride_head, int64_t kv_stride_slot,
-                            void* plan, size_t plan_bytes, void* stream) {
-    if (NB < 0 || P < 0 || !plan || Hq <= 0 || Hkv <= 0 || Hq % Hkv ||
+                            const int32_t* cache_loc, int n_new, int64_t new_stride_tok, void* plan, size_t plan_bytes,
+                            void* stream) {
+    if (NB < 0 || P < 0 || !plan || n_new < 0 || Hq <= 0 || Hkv <= 0 || Hq % Hkv ||
         (NB > 0 && (!block_q || !block_q_cnts || !block_q_offset || !block_bitmasks || !block_kv || !block_lens))) {
         set_error("bad plan arguments (NB=%d P=%d Hq=%d Hkv=%d)", NB, P, Hq, Hkv);
         return DEFT_EINVAL;
@@ -768,7 +803,11 @@ int deft_flatten_build_plan(const int64_t* block_q, const int64_t* block_q_cnts,
     p.q_st = q_stride_tok;
     p.q_sh = q_stride_head;
     p.kv_ss = kv_stride_slot;
-    return launch_plan(p, NB, pv, static_cast<hipStream_t>(stream));
+    AppendArgs ap;
+    ap.cache_loc = cache_loc;
+    ap.n_new = cache_loc ? n_new : 0;
+    ap.new_st = new_stride_tok;
+    return launch_plan(p, NB, pv, ap, static_cast<hipStream_t>(stream));
 }
 
 int deft_flatten_stage1_f16(const void* q, int64_t q_stride_tok, int64_t q_stride_head, const void* k_base,
@@ -784,17 +823,20 @@ int deft_flatten_stage1_f16(const void* q, int64_t q_stride_tok, int64_t q_strid
     const int32_t* row_q = nullptr;
     return flatten_stage1_impl(q, q_stride_tok, q_stride_head, k_base, v_base, kv_stride_slot, kv_stride_head, block_q,
                                block_q_cnts, block_q_offset, block_bitmasks, block_kv, block_lens, NB, P, nq, Hq, Hkv, D,
-                               scale, plan, workspace, workspace_bytes, stream, &ws, &row_q);
+                               scale, plan, workspace, workspace_bytes, stream, AppendArgs(), &ws, &row_q);
 }
 
-int deft_flatten_decode_f16(const void* q, int64_t q_stride_tok, int64_t q_stride_head, const void* k_base,
-                            const void* v_base, int64_t kv_stride_slot, int64_t kv_stride_head, void* out,
-                            int64_t o_stride_tok, int64_t o_stride_head, const int64_t* block_q,
-                            const int64_t* block_q_cnts, const int64_t* block_q_offset, const int64_t* block_bitmasks,
-                            const int64_t* block_kv, const int64_t* block_lens, int NB, int P, int nq, int Hq, int Hkv,
-                            int D, float scale, const void* plan, void* workspace, size_t workspace_bytes, void* stream) {
+static int flatten_decode_impl(const void* q, int64_t q_stride_tok, int64_t q_stride_head, const void* k_base,
+                               const void* v_base, int64_t kv_stride_slot, int64_t kv_stride_head, void* out,
+                               int64_t o_stride_tok, int64_t o_stride_head, const int64_t* block_q,
+                               const int64_t* block_q_cnts, const int64_t* block_q_offset, const int64_t* block_bitmasks,
+                               const int64_t* block_kv, const int64_t* block_lens, int NB, int P, int nq, int Hq, int Hkv,
+                               int D, float scale, const void* plan, void* workspace, size_t workspace_bytes, void* stream,
+                               const AppendArgs& ap) {
     int rc = check_common(q, q_stride_tok, q_stride_head, k_base, v_base, kv_stride_slot, kv_stride_head, out,
                           o_stride_tok, o_stride_head, nq, Hq, Hkv, D);
+    if (rc) return rc;
+    rc = check_append(ap, Hkv, D);
     if (rc) return rc;
     if (!workspace) {
         set_error("null workspace");
@@ -804,12 +846,47 @@ int deft_flatten_decode_f16(const void* q, int64_t q_stride_tok, int64_t q_strid
     const int32_t* row_q = nullptr;
     rc = flatten_stage1_impl(q, q_stride_tok, q_stride_head, k_base, v_base, kv_stride_slot, kv_stride_head, block_q,
                              block_q_cnts, block_q_offset, block_bitmasks, block_kv, block_lens, NB, P, nq, Hq, Hkv, D, scale,
-                             plan, workspace, workspace_bytes, stream, &ws, &row_q);
+                             plan, workspace, workspace_bytes, stream, ap, &ws, &row_q);
     if (rc) return rc;
     return launch_merge(D, ws, row_q, P, out, o_stride_tok, o_stride_head, nq, Hq, static_cast<hipStream_t>(stream));
 }
 
-static int launch_node_plan(const Stage1Params& p, int NE, int64_t rows_cap, const PlanView& pv, hipStream_t stream) {
+int deft_flatten_decode_f16(const void* q, int64_t q_stride_tok, int64_t q_stride_head, const void* k_base,
+                            const void* v_base, int64_t kv_stride_slot, int64_t kv_stride_head, void* out,
+                            int64_t o_stride_tok, int64_t o_stride_head, const int64_t* block_q,
+                            const int64_t* block_q_cnts, const int64_t* block_q_offset, const int64_t* block_bitmasks,
+                            const int64_t* block_kv, const int64_t* block_lens, int NB, int P, int nq, int Hq, int Hkv,
+                            int D, float scale, const void* plan, void* workspace, size_t workspace_bytes, void* stream) {
+    return flatten_decode_impl(q, q_stride_tok, q_stride_head, k_base, v_base, kv_stride_slot, kv_stride_head, out,
+                               o_stride_tok, o_stride_head, block_q, block_q_cnts, block_q_offset, block_bitmasks, block_kv,
+                               block_lens, NB, P, nq, Hq, Hkv, D, scale, plan, workspace, workspace_bytes, stream,
+                               AppendArgs());
+}
+
+int deft_flatten_decode_append_f16(const void* q, int64_t q_stride_tok, int64_t q_stride_head, void* k_base, void* v_base,
+                                   int64_t kv_stride_slot, int64_t kv_stride_head, void* out, int64_t o_stride_tok,
+                                   int64_t o_stride_head, const int64_t* block_q, const int64_t* block_q_cnts,
+                                   const int64_t* block_q_offset, const int64_t* block_bitmasks, const int64_t* block_kv,
+                                   const int64_t* block_lens, int NB, int P, int nq, int Hq, int Hkv, int D, float scale,
+                                   const int32_t* cache_loc, const void* k_new, const void* v_new, int64_t new_stride_tok,
+                                   int n_new, const void* plan, void* workspace, size_t workspace_bytes, void* stream) {
+    AppendArgs ap;
+    ap.k_new = static_cast<const _Float16*>(k_new);
+    ap.v_new = static_cast<const _Float16*>(v_new);
+    ap.cache_loc = cache_loc;
+    ap.new_st = new_stride_tok;
+    ap.n_new = n_new;
+    if (!k_new || !v_new || !cache_loc) {
+        set_error("fused append needs k_new, v_new and cache_loc");
+        return DEFT_EINVAL;
+    }
+    return flatten_decode_impl(q, q_stride_tok, q_stride_head, k_base, v_base, kv_stride_slot, kv_stride_head, out,
+                               o_stride_tok, o_stride_head, block_q, block_q_cnts, block_q_offset, block_bitmasks, block_kv,
+                               block_lens, NB, P, nq, Hq, Hkv, D, scale, plan, workspace, workspace_bytes, stream, ap);
+}
+
+static int launch_node_plan(const Stage1Params& p, int NE, int64_t rows_cap, const PlanView& pv, const AppendArgs& ap,
+                            hipStream_t stream) {
     const UnitList ul = unit_list(pv);
     hipLaunchKernelGGL(node_units_kernel, dim3(1), dim3(256), 0, stream, p.node_kv_len, p.node_q_len, NE, p.G, (int)pv.cap,
                        rows_cap, ul, pv.hdr, pv.sched, pv.row_q);
@@ -817,7 +894,7 @@ static int launch_node_plan(const Stage1Params& p, int NE, int64_t rows_cap, con
     if (rc) return rc;
     hipLaunchKernelGGL(node_records_kernel, dim3((unsigned)(pv.cap + 1)), dim3(128), 0, stream, p.node_kv, p.node_kv_offset,
                        p.node_kv_len, p.node_q, p.node_q_offset, p.node_q_len, p.G, (int)p.rows, p.q_st, p.q_sh, p.kv_ss, ul,
-                       pv.hdr, pv.records, pv.row_q);
+                       pv.hdr, pv.records, pv.row_q, ap.cache_loc, ap.n_new, ap.new_st * 2);
     return check_launch("node records launch");
 }
 
@@ -856,7 +933,7 @@ int deft_node_build_plan(const int64_t* node_kv, const int64_t* node_kv_offset, 
     p.q_st = q_stride_tok;
     p.q_sh = q_stride_head;
     p.kv_ss = kv_stride_slot;
-    return launch_node_plan(p, NE, rows, pv, static_cast<hipStream_t>(stream));
+    return launch_node_plan(p, NE, rows, pv, AppendArgs(), static_cast<hipStream_t>(stream));
 }
 
 int deft_node_decode_f16(const void* q, int64_t q_stride_tok, int64_t q_stride_head, const void* k_base,
@@ -915,10 +992,10 @@ int deft_node_decode_f16(const void* q, int64_t q_stride_tok, int64_t q_stride_h
             pv = plan_view(const_cast<void*>(plan), tiles * G, rows);
         } else {
             pv = plan_view(ws.plan, tiles * G, rows);
-            rc = launch_node_plan(p, NE, rows, pv, st);
+            rc = launch_node_plan(p, NE, rows, pv, AppendArgs(), st);
             if (rc) return rc;
         }
-        rc = launch_stage1_stream(p, tiles * G, pv, st);
+        rc = launch_stage1_stream(p, tiles * G, pv, AppendArgs(), st);
         if (rc) return rc;
         return launch_merge(D, ws, pv.row_q, rows, out, o_stride_tok, o_stride_head, nq, Hq, st);
     }

@@ -64,6 +64,13 @@ struct StreamParams {
     const int32_t* hdr;  // plan header: hdr[0] = R, records per KV head
     const char* plan;    // [R+1][PLAN_BYTES]
     int* sched;          // [2] = {ticket counter, workgroups done}; both 0 between launches
+    // fused paged append (optional): rows whose plan offset has bit 63 set are read from k_new / v_new
+    // (offset = row index * new_st * 2 bytes) and workgroup b < n_new also copies row b into the pool
+    const _Float16* k_new;
+    const _Float16* v_new;
+    const int32_t* cache_loc;
+    int64_t new_st;
+    int n_new;
     unsigned long long* dbg;  // internal: per-phase s_memtime stamps [workgroup][16 tiles][8], or null
 };
 
@@ -180,15 +187,21 @@ __global__ __launch_bounds__(512, 4) void stage1_stream_kernel(StreamParams sp) 
 #pragma unroll
         for (int i = 0; i < LPT; ++i) rowoff[i] = ro[32 * lw + 4 * i + dkey];
     };
+    constexpr int64_t NEW_ROW = (int64_t)1 << 63;  // plan offset flag: row lives in k_new / v_new
     auto issue_k = [&](int head) {
         const char* hb = reinterpret_cast<const char*>(p.k) + (int64_t)head * p.kv_sh * 2;
+        const char* nb = reinterpret_cast<const char*>(sp.k_new) + (int64_t)head * D * 2;
 #pragma unroll
-        for (int i = 0; i < LPT; ++i) dma16(hb + rowoff[i] + kchunk_b[i & 3], ldsK + (uint32_t)i * 1024u);
+        for (int i = 0; i < LPT; ++i) {
+            const char* src = rowoff[i] < 0 ? nb + (rowoff[i] & ~NEW_ROW) : hb + rowoff[i];
+            dma16(src + kchunk_b[i & 3], ldsK + (uint32_t)i * 1024u);
+        }
     };
     auto issue_v = [&](int head) {
         const char* hb = reinterpret_cast<const char*>(p.v) + (int64_t)head * p.kv_sh * 2 + vchunk_b;
+        const char* nb = reinterpret_cast<const char*>(sp.v_new) + (int64_t)head * D * 2 + vchunk_b;
 #pragma unroll
-        for (int i = 0; i < LPT; ++i) dma16(hb + rowoff[i], ldsV + (uint32_t)i * 1024u);
+        for (int i = 0; i < LPT; ++i) dma16(rowoff[i] < 0 ? nb + (rowoff[i] & ~NEW_ROW) : hb + rowoff[i], ldsV + (uint32_t)i * 1024u);
     };
     auto read_desc = [&](int b) {  // {cnt, prow, run_start, len}, wave-uniform
         intx4 d = *reinterpret_cast<const intx4*>(meta(b) + PLAN_DESC);
@@ -232,6 +245,21 @@ __global__ __launch_bounds__(512, 4) void stage1_stream_kernel(StreamParams sp) 
             }
         }
     };
+    // ---- fused paged append: workgroup b writes new-token row b into the pool (nobody reads those
+    //      pool rows in this launch: the loaders take them from k_new / v_new) -------------------
+    if (bid < sp.n_new) {
+        const int64_t dst = (int64_t)sp.cache_loc[bid] * p.kv_ss;
+        const int chunks = p.Hkv * (D / 8);  // 16-byte pieces per K (or V) row
+        for (int i = tid; i < chunks; i += blockDim.x) {
+            const int hd = i / (D / 8), ch = i - hd * (D / 8);
+            const int64_t so = (int64_t)bid * sp.new_st + hd * D + ch * 8;
+            const int64_t d_o = dst + (int64_t)hd * p.kv_sh + ch * 8;
+            const uintx4 kk = *reinterpret_cast<const uintx4*>(sp.k_new + so);
+            const uintx4 vv = *reinterpret_cast<const uintx4*>(sp.v_new + so);
+            *reinterpret_cast<uintx4*>(const_cast<_Float16*>(p.k) + d_o) = kk;
+            *reinterpret_cast<uintx4*>(const_cast<_Float16*>(p.v) + d_o) = vv;
+        }
+    }
     // ---- prologue -----------------------------------------------------------------
     lds_barrier();  // sUnit[0..1] visible
     int ucur = __builtin_amdgcn_readfirstlane(sUnit[0]);
@@ -449,6 +477,15 @@ __global__ __launch_bounds__(512, 4) void stage1_stream_kernel(StreamParams sp) 
 // ---------------------------------------------------------------------------
 // Plan kernels (once per decode step): metadata -> unit list -> records
 // ---------------------------------------------------------------------------
+// Byte offset of a pool slot's row, or (bit 63 | offset into k_new / v_new) when the slot is one of
+// this step's new tokens and the caller uses the fused append.
+__device__ __forceinline__ int64_t plan_rowoff(int64_t slot, int64_t kv_stride_slot, const int32_t* cache_loc, int n_new,
+                                               int64_t new_row_bytes) {
+    for (int i = 0; i < n_new; ++i)
+        if ((int64_t)cache_loc[i] == slot) return ((int64_t)1 << 63) | ((int64_t)i * new_row_bytes);
+    return slot * kv_stride_slot * 2;  // fp16 bytes
+}
+
 struct UnitList {   // all int32, capacity `cap` each
     int32_t* src;   // Flatten: block index; Node: entry index
     int32_t* aux;   // Flatten: 0;           Node: 128-slot tile index within the entry
@@ -504,7 +541,8 @@ __global__ __launch_bounds__(128) void flatten_records_kernel(const int64_t* blo
                                                               const int64_t* block_bitmasks, const int64_t* block_kv,
                                                               const int64_t* block_lens, int G, int rows, int64_t q_st,
                                                               int64_t q_sh, int64_t kv_stride_slot, UnitList ul,
-                                                              const int32_t* hdr, char* plan, int32_t* row_q) {
+                                                              const int32_t* hdr, char* plan, int32_t* row_q,
+                                                              const int32_t* cache_loc, int n_new, int64_t new_row_bytes) {
     const int r = blockIdx.x;
     const int k = threadIdx.x;
     const int R = hdr[0];
@@ -531,7 +569,7 @@ __global__ __launch_bounds__(128) void flatten_records_kernel(const int64_t* blo
     const int cnt = (int)block_q_cnts[t];
     const int nv = min(MQ, cnt * G - MQ * ps);  // virtual rows of this pass
     const bool live = k < len;
-    ro[k] = block_kv[(int64_t)t * TILE + (live ? k : 0)] * kv_stride_slot * 2;  // fp16 bytes
+    ro[k] = plan_rowoff(block_kv[(int64_t)t * TILE + (live ? k : 0)], kv_stride_slot, cache_loc, n_new, new_row_bytes);
     const uint32_t qmask = live ? (uint32_t)block_bitmasks[(int64_t)t * TILE + k] : 0u;
     uint32_t vm = 0u;
     for (int v = 0; v < nv; ++v) vm |= ((qmask >> ((MQ * ps + v) / G)) & 1u) << v;
@@ -590,7 +628,8 @@ __global__ __launch_bounds__(128) void node_records_kernel(const int64_t* node_k
                                                            const int64_t* node_kv_len, const int64_t* node_q,
                                                            const int64_t* node_q_offset, const int64_t* node_q_len, int G,
                                                            int rows, int64_t q_st, int64_t q_sh, int64_t kv_stride_slot,
-                                                           UnitList ul, const int32_t* hdr, char* plan, int32_t* row_q) {
+                                                           UnitList ul, const int32_t* hdr, char* plan, int32_t* row_q,
+                                                           const int32_t* cache_loc, int n_new, int64_t new_row_bytes) {
     const int r = blockIdx.x;
     const int k = threadIdx.x;
     const int R = hdr[0];
@@ -617,7 +656,7 @@ __global__ __launch_bounds__(128) void node_records_kernel(const int64_t* node_k
     const int ql = (int)node_q_len[e];
     const int nv = min(MQ, ql * G - MQ * ps);
     const bool live = k < len;
-    ro[k] = node_kv[kv0 + (live ? k : 0)] * kv_stride_slot * 2;
+    ro[k] = plan_rowoff(node_kv[kv0 + (live ? k : 0)], kv_stride_slot, cache_loc, n_new, new_row_bytes);
     mk[k] = live ? (nv >= 32 ? 0xffffffffu : ((1u << nv) - 1u)) : 0u;
     if (k < MQ) {
         int qs = 0, orow = 0;

@@ -22,7 +22,8 @@ import torch
 
 from ._lib import DeftLibraryError, check, lib
 
-__all__ = ["tree_attention_subtree_fwd", "tree_attention_fwd", "kv_append", "flatten_stage1_partials"]
+__all__ = ["tree_attention_subtree_fwd", "tree_attention_fwd", "flatten_append_attention", "kv_append",
+           "flatten_stage1_partials"]
 
 
 def _stream_ptr(t: torch.Tensor) -> int:
@@ -48,7 +49,8 @@ def _check_qkv(query_states, key_buffer, value_buffer, output):
     return nq, Hq, Hkv, D
 
 
-def _flatten_plan(md, NB: int, P: int, Hq: int, Hkv: int, q_strides, kv_stride_slot: int, stream: int):
+def _flatten_plan(md, NB: int, P: int, Hq: int, Hkv: int, q_strides, kv_stride_slot: int, stream: int,
+                  cache_loc=None, new_stride: int = 0):
     """Device-side repack of the Flatten metadata, built once per decode step.
 
     The reference builds TreeMetadata once per step and all layers read the same tensor
@@ -58,13 +60,17 @@ def _flatten_plan(md, NB: int, P: int, Hq: int, Hkv: int, q_strides, kv_stride_s
     tensors (or an in-place edit) simply rebuild it; results never depend on the cache."""
     block_q = md[0]
     key = (kv_stride_slot, NB, P, Hq, Hkv, tuple(q_strides)) + tuple((t.data_ptr(), t._version) for t in md)
+    if cache_loc is not None:  # fused-append plans mark this step's new slots
+        key += (cache_loc.data_ptr(), cache_loc._version, cache_loc.shape[0], new_stride)
     cached = getattr(block_q, "_deft_plan", None)
     if cached is not None and cached[0] == key:
         return cached[1]
     nbytes = lib.deft_flatten_plan_bytes(NB, P, Hq, Hkv)
     plan = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=block_q.device)
     check(lib.deft_flatten_build_plan(*[t.data_ptr() for t in md], NB, P, Hq, Hkv, q_strides[0], q_strides[1],
-                                      kv_stride_slot, plan.data_ptr(), nbytes, stream), "deft_flatten_build_plan")
+                                      kv_stride_slot, cache_loc.data_ptr() if cache_loc is not None else None,
+                                      cache_loc.shape[0] if cache_loc is not None else 0, new_stride,
+                                      plan.data_ptr(), nbytes, stream), "deft_flatten_build_plan")
     try:
         block_q._deft_plan = (key, plan)
     except Exception:  # tensors that refuse attributes just do not cache
@@ -134,6 +140,47 @@ def tree_attention_subtree_fwd(
         NB, P, nq, Hq, Hkv, D, scale, plan.data_ptr(), ws.data_ptr(), ws_bytes, stream,
     )
     check(rc, "deft_flatten_decode_f16")
+
+
+@torch.inference_mode()
+def flatten_append_attention(query_states, kv_layer, output, cache_loc, cache_k, cache_v, block_len, block_q, block_q_cnts,
+                             block_q_offset, block_bitmasks, block_kv, block_lens) -> None:
+    """`store_kv_cache` + `tree_attention_subtree_fwd` in ONE launch sequence
+    (DeFTAttention.deft_flatten_forward, deft_attention.py:110-151): kv_layer[cache_loc, 0/1] = cache_k / cache_v
+    and output = Flatten attention that already sees those rows.  kv_layer is one layer of the pool,
+    [size, 2, Hkv, D] fp16 (memory_pool.py:61-66)."""
+    key_buffer, value_buffer = kv_layer[:, 0], kv_layer[:, 1]
+    nq, Hq, Hkv, D = _check_qkv(query_states, key_buffer, value_buffer, output)
+    if block_len != 128:
+        raise ValueError(f"block_len must be 128 (got {block_len})")
+    NB, P = block_q_cnts.shape[0], block_q.shape[0]
+    md = [_i64(t, n) for t, n in ((block_q, "block_q"), (block_q_cnts, "block_q_cnts"),
+                                  (block_q_offset, "block_q_offset"), (block_bitmasks, "block_bitmasks"),
+                                  (block_kv, "block_kv"), (block_lens, "block_lens"))]
+    n = cache_loc.shape[0]
+    k = cache_k.reshape(n, Hkv, D)
+    v = cache_v.reshape(n, Hkv, D)
+    if k.stride(2) != 1 or k.stride(1) != D:
+        k = k.contiguous()
+    if v.stride() != k.stride():
+        k, v = k.contiguous(), v.contiguous()
+    if cache_loc.dtype != torch.int32 or not cache_loc.is_cuda:
+        cache_loc = cache_loc.to(device=query_states.device, dtype=torch.int32)
+    ws_bytes = lib.deft_flatten_workspace_bytes(NB, P, nq, Hq, Hkv, D)
+    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=query_states.device)
+    stream = _stream_ptr(query_states)
+    plan = _flatten_plan(md, NB, P, Hq, Hkv, (query_states.stride(0), query_states.stride(1)), key_buffer.stride(0), stream,
+                         cache_loc=cache_loc, new_stride=k.stride(0))
+    rc = lib.deft_flatten_decode_append_f16(
+        query_states.data_ptr(), query_states.stride(0), query_states.stride(1),
+        key_buffer.data_ptr(), value_buffer.data_ptr(), key_buffer.stride(0), key_buffer.stride(1),
+        output.data_ptr(), output.stride(0), output.stride(1),
+        *[t.data_ptr() for t in md],
+        NB, P, nq, Hq, Hkv, D, 1.0 / (D ** 0.5),
+        cache_loc.data_ptr(), k.data_ptr(), v.data_ptr(), k.stride(0), n,
+        plan.data_ptr(), ws.data_ptr(), ws_bytes, stream,
+    )
+    check(rc, "deft_flatten_decode_append_f16")
 
 
 @torch.inference_mode()

@@ -81,6 +81,7 @@ int deft_flatten_build_plan(
     const int64_t* block_q, const int64_t* block_q_cnts, const int64_t* block_q_offset,
     const int64_t* block_bitmasks, const int64_t* block_kv, const int64_t* block_lens,
     int NB, int P, int Hq, int Hkv, int64_t q_stride_tok, int64_t q_stride_head, int64_t kv_stride_slot,
+    const int32_t* cache_loc /* nullable */, int n_new, int64_t new_stride_tok,
     void* plan, size_t plan_bytes, void* stream);
 
 /*
@@ -103,6 +104,23 @@ int deft_flatten_decode_f16(
     const int64_t* block_q, const int64_t* block_q_cnts, const int64_t* block_q_offset,
     const int64_t* block_bitmasks, const int64_t* block_kv, const int64_t* block_lens,
     int NB, int P, int nq, int Hq, int Hkv, int D, float scale,
+    const void* plan, void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * DeFTAttention.deft_flatten_forward in one call (deft_attention.py:110-151): the paged append of
+ * this step's K/V rows (store_kv_cache, :390-403 -> tree_cache.py:67-76) fused into the attention
+ * launch.  k_base / v_base are written at cache_loc[i] (i < n_new) with k_new[i] / v_new[i]
+ * (rows of Hkv*D fp16, token stride new_stride_tok) and the attention sees the new rows.
+ * `plan` may be NULL (built per call) or a plan built with the same cache_loc arguments.
+ */
+int deft_flatten_decode_append_f16(
+    const void* q, int64_t q_stride_tok, int64_t q_stride_head,
+    void* k_base, void* v_base, int64_t kv_stride_slot, int64_t kv_stride_head,
+    void* out, int64_t o_stride_tok, int64_t o_stride_head,
+    const int64_t* block_q, const int64_t* block_q_cnts, const int64_t* block_q_offset,
+    const int64_t* block_bitmasks, const int64_t* block_kv, const int64_t* block_lens,
+    int NB, int P, int nq, int Hq, int Hkv, int D, float scale,
+    const int32_t* cache_loc, const void* k_new, const void* v_new, int64_t new_stride_tok, int n_new,
     const void* plan, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- DeFT-Node ---------------------------------------------------------- */
