@@ -351,7 +351,7 @@ __global__ __launch_bounds__(256) void node_prep_kernel(const int64_t* node_kv_o
 // one head: 64 candidate rows at a time it loads their log-sum-exps in parallel, keeps a
 // running true maximum (online rescale), and accumulates only the rows that carry a
 // partial (lse > -inf; rows folded into a group by the streaming stage 1 are skipped),
-// four independent 512-byte row loads in flight per step.  fp32 accumulate, one fp16 rounding.
+// eight independent 512-byte row loads in flight per step.  fp32 accumulate, one fp16 rounding.
 template <int D>
 __global__ __launch_bounds__(256) void merge_kernel(const float* partial_o, const float* partial_lse, const int32_t* row_q,
                                                      int64_t rows, _Float16* out, int64_t o_st, int64_t o_sh, int Hq,
@@ -368,17 +368,26 @@ __global__ __launch_bounds__(256) void merge_kernel(const float* partial_o, cons
     const int hq = blockIdx.y * 4 + w;
     const int quarter = (int)(((rows + 3) / 4 + 63) / 64 * 64);
 
-    // 1. rows of this query inside this wave's quarter of row_q
+    // 1. rows of this query inside this wave's quarter of row_q (eight independent loads per lane in
+    //    flight, then ordered ballots: one L2 round trip per 512 rows instead of one per 64)
     {
         int n = 0;
         const int64_t lo = (int64_t)w * quarter;
         const int64_t hi = lo + quarter < rows ? lo + quarter : rows;
-        for (int64_t base = lo; base < hi; base += 64) {
-            const int64_t i = base + lane;
-            const bool hit = (i < hi) && (row_q[i] == qi);
-            const unsigned long long mask = __ballot(hit);
-            if (hit) sRows[w * quarter + n + __popcll(mask & ((1ull << lane) - 1ull))] = (int)i;
-            n += __popcll(mask);
+        for (int64_t base = lo; base < hi; base += 512) {
+            int val[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int64_t i = base + 64 * u + lane;
+                val[u] = (i < hi) ? row_q[i] : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const bool hit = val[u] == qi;
+                const unsigned long long mask = __ballot(hit);
+                if (hit) sRows[w * quarter + n + __popcll(mask & ((1ull << lane) - 1ull))] = (int)(base + 64 * u + lane);
+                n += __popcll(mask);
+            }
         }
         if (lane == 0) sCnt[w] = n;
     }
@@ -418,12 +427,13 @@ __global__ __launch_bounds__(256) void merge_kernel(const float* partial_o, cons
         for (int sft = 32; sft > 0; sft >>= 1) ws += __shfl_xor(ws, sft);
         L += ws;
         unsigned long long live = __ballot(wgt > 0.f);
-        while (live) {  // wave-uniform loop, up to four independent row loads per trip
-            int kk[4];
-            float wk[4];
+        while (live) {  // wave-uniform loop, up to eight independent row loads per trip
+            constexpr int NU = 8;
+            int kk[NU];
+            float wk[NU];
             int cnt = 0;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < NU; ++u) {
                 kk[u] = 0;
                 wk[u] = 0.f;
                 if (live) {
@@ -434,15 +444,15 @@ __global__ __launch_bounds__(256) void merge_kernel(const float* partial_o, cons
                     cnt = u + 1;
                 }
             }
-            float v[4][VEC];
+            float v[NU][VEC];
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < NU; ++u)
                 if (u < cnt) {
 #pragma unroll
                     for (int j = 0; j < VEC; ++j) v[u][j] = po_h[(int64_t)kk[u] * D + j];
                 }
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < NU; ++u)
                 if (u < cnt) {
 #pragma unroll
                     for (int j = 0; j < VEC; ++j) acc[j] += wk[u] * v[u][j];
