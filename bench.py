@@ -299,9 +299,10 @@ def main():
         c = b.cpu_baseline(args.cpu_budget_s)
         cpu = {"value": round(c["tokens_per_s"], 4), "unit": "tokens/s", "cores": c["cores"], "kind": "port",
                "sample": f"1 of {layers} layer-steps of the same tree ({b.nq} leaves, {b.n_kv} unique KV tokens), "
-                         f"PyTorch SDPA {c['dtype']} per leaf incl. page-table gather, best of {c['reps']}, "
+                         f"PyTorch SDPA {c['dtype']} per leaf incl. page-table gather, {c['cores']} threads (best of 8/16/32/all), "
+                         f"best of {c['reps']}, "
                          f"x{layers} layers extrapolated",
-               "ms_per_layer_step": round(c["seconds_per_layer_step"] * 1e3, 2)}
+               "ms_per_layer_step": round(c["seconds_per_layer_step"] * 1e3, 2), "host_cores": c["host_cores"]}
 
     if rank == 0:
         Hq, Hkv, D, _ = GEOMETRY[w.model]
