@@ -125,32 +125,64 @@ __global__ __launch_bounds__(512, 4) void stage1_stream_kernel(StreamParams sp) 
     const int c = l & 31;
     const int h = l >> 5;
 
-    // Work of this workgroup: a static run of consecutive units, then single units taken from a
-    // shared pool with an atomic ticket.  Position i of the stream is known two tiles ahead: compute
+    // Work distribution.  Position i of a workgroup's unit stream is known two tiles ahead: lane 0 of compute
     // wave 0 publishes unit(i+2) in the sUnit ring before barrier H of tile i.
+    //  * default: balanced static split of the head-major unit sequence, no atomics;
+    //  * experimental (DEFT_STAGE1_ABLATE bit 32): guided chunks from one atomic ticket counter — 60 % of
+    //    every head's units in chunks of 4, 25 % in chunks of 2, 15 % one by one — meant to even out the
+    //    workgroups' finish times (equal static shares finish +-20 % apart: a 9 us tail on a 29 us bulk).
+    //    Measured 4-6 us SLOWER than the static split on the 4k x 32 tree: the returning atomic of a compute
+    //    wave queues behind ~100 KB of loader DMA in the CU's memory FIFO, and every chunk is its own group
+    //    (own Q fetch, own partial).  Kept for the next round (ticket prefetch two tiles ahead).
     const int bid = blockIdx.x;
     const int RH = sp.hdr[0];  // records per KV head (written by the plan kernels)
     const int U = RH * p.Hkv;  // units, head-major
-    // Few units per workgroup (< 4): balanced static split, no tickets (a returning atomic in the
-    // prologue costs a memory round trip per workgroup).  Otherwise floor(U/W) static units each and
-    // the remainder from the ticket pool.
     const int W = (int)gridDim.x;
     const int per = U / W, rem = U - per * W;
-    const bool use_pool = per >= 4;
-    const int n_static = use_pool ? per : per + (bid < rem ? 1 : 0);
-    const int my_base = use_pool ? bid * per : bid * per + min(bid, rem);
-    const int pool_base = use_pool ? per * W : U;
-    int* sUnit = reinterpret_cast<int*>(smem + SM::UNIT_OFF);
-    auto take = [&](int pos) -> int {  // lane 0 of compute wave 0 only
-        if (pos < n_static) return my_base + pos;
-        if (!use_pool) return -1;
-        const int u = pool_base + atomicAdd(sp.sched, 1);
-        return u < U ? u : -1;
+    const bool guided = per >= 4 && (p.ablate & 32);  // off by default: measured slower, see below
+    const int n_static = per + (bid < rem ? 1 : 0);
+    const int my_base = bid * per + min(bid, rem);
+    // chunks are laid out per KV head and tickets walk the heads round-robin (ticket k -> head k % Hkv,
+    // chunk k / Hkv of that head): at any moment the active chunks cover all heads evenly.  Handing out the
+    // head-major sequence in order instead makes every workgroup read the same few heads at the same time,
+    // i.e. the same 256-byte column of every token row, which serialises on a few HBM channels (-10 %).
+    const int R1 = guided ? (int)(0.60f * RH) / 4 * 4 : 0;
+    const int R2 = guided ? R1 + (int)(0.25f * RH) / 2 * 2 : 0;
+    const int n1 = R1 / 4, n2 = (R2 - R1) / 2, n3 = RH - R2;
+    auto chunk_of = [&](int k, int& cs, int& ce) {
+        const int head = k % p.Hkv, ci = k / p.Hkv;
+        int st, len;
+        if (ci < n1) { st = 4 * ci; len = 4; }
+        else if (ci < n1 + n2) { st = R1 + 2 * (ci - n1); len = 2; }
+        else if (ci < n1 + n2 + n3) { st = R2 + (ci - n1 - n2); len = 1; }
+        else { cs = -1; ce = -1; return; }
+        cs = head * RH + st;
+        ce = cs + len;
     };
+    int* sUnit = reinterpret_cast<int*>(smem + SM::UNIT_OFF);
+    int pub_u = -1, pub_end = -1;  // publisher state (lane 0 of compute wave 0): last published unit, end of its chunk
     if (tid == 0) {
-        const int a = take(0);
+        int a, b2;
+        if (guided) {
+            int cs, ce;
+            chunk_of(atomicAdd(sp.sched, 1), cs, ce);
+            a = cs;
+            if (ce - cs >= 2) {
+                b2 = cs + 1;
+            } else if (cs >= 0) {
+                chunk_of(atomicAdd(sp.sched, 1), cs, ce);
+                b2 = cs;
+            } else {
+                b2 = -1;
+            }
+            pub_u = b2;
+            pub_end = ce;
+        } else {
+            a = n_static > 0 ? my_base : -1;
+            b2 = n_static > 1 ? my_base + 1 : -1;
+        }
         sUnit[0] = a;
-        sUnit[1] = a < 0 ? -1 : take(1);
+        sUnit[1] = a < 0 ? -1 : b2;
     }
 
     // ---- loop-invariant lane constants -------------------------------------------------
@@ -347,10 +379,11 @@ __global__ __launch_bounds__(512, 4) void stage1_stream_kernel(StreamParams sp) 
         const bool next_adjacent = !last && (unext == ucur + 1);
         bool g_end = true;  // plan record (u+1) is visible now
         if (next_adjacent) g_end = (t + 1 == RH) || (read_desc(mb ^ 1)[2] != 0);
-        // the ticket for position i+2 travels while this tile computes (compute waves issue no other loads)
-        int ticket = 0;  // consumed just before barrier H, a tile's worth of time after the atomic was issued
-        const bool pooled = use_pool && (i + 2 >= n_static);
-        if (tid == 0 && !last && pooled)  // asm: hipcc would otherwise wait for the returned value right here
+        // a ticket for position i+2 (when it opens a new chunk) travels while this tile computes; compute
+        // waves issue no other loads, so the wait before barrier H costs nothing
+        int ticket = 0;
+        const bool need_ticket = guided && !last && (pub_u + 1 >= pub_end);
+        if (tid == 0 && need_ticket)  // asm: hipcc would otherwise wait for the returned value right here
             asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(ticket) : "v"(sp.sched), "v"(1) : "memory");
 
         // ---- B: S^T for this wave's 32 keys, scale, mask, row max --------------------
@@ -439,9 +472,17 @@ __global__ __launch_bounds__(512, 4) void stage1_stream_kernel(StreamParams sp) 
         // ---- H: every wave is done with sV and sP; unit(i+2) published -------------------------
         stamp(i, 6);
         if (tid == 0 && !last) {
-            if (pooled) asm volatile("s_waitcnt vmcnt(0)" : "+v"(ticket)::"memory");
-            int u2 = pooled ? pool_base + ticket : (i + 2 < n_static ? my_base + i + 2 : U);
-            sUnit[(i + 2) & 3] = u2 < U ? u2 : -1;
+            int u2;
+            if (!guided) {
+                u2 = (i + 2 < n_static) ? my_base + i + 2 : -1;
+            } else if (need_ticket) {
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(ticket)::"memory");
+                chunk_of(ticket, u2, pub_end);
+                pub_u = u2;
+            } else {
+                u2 = ++pub_u;
+            }
+            sUnit[(i + 2) & 3] = u2;
         }
         lds_barrier();
         stamp(i, 7);
