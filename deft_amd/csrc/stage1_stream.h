@@ -74,12 +74,19 @@ struct StreamParams {
     unsigned long long* dbg;  // internal: per-phase s_memtime stamps [workgroup][16 tiles][8], or null
 };
 
-template <int D>
+// DB = false: two workgroups per CU, one K and one V stage each (K(i+1) streams in after tile i's QK^T, V(i+1)
+//              after its PV), Q staged in the idle P buffer.
+// DB = true : one workgroup per CU, K and V double-buffered (tile i+1 streams in during the whole of tile i),
+//             Q in its own buffer.
+template <int D, bool DB>
 struct StreamSmem {
+    static constexpr int STAGE = TILE * D * 2;  // one K (or V) tile
+    static constexpr int NBUF = DB ? 2 : 1;
     static constexpr int K_OFF = 0;
-    static constexpr int V_OFF = K_OFF + TILE * D * 2;
-    static constexpr int P_OFF = V_OFF + TILE * D * 2;
-    static constexpr int META_OFF = P_OFF + MQ * TILE * 2;  // 2 plan records
+    static constexpr int V_OFF = K_OFF + NBUF * STAGE;
+    static constexpr int P_OFF = V_OFF + NBUF * STAGE;
+    static constexpr int Q_OFF = DB ? P_OFF + MQ * TILE * 2 : P_OFF;
+    static constexpr int META_OFF = Q_OFF + MQ * TILE * 2;  // 2 plan records
     static constexpr int WMAX_OFF = META_OFF + 2 * PLAN_BYTES;
     static constexpr int WSUM_OFF = WMAX_OFF + 4 * MQ * 4;
     static constexpr int UNIT_OFF = WSUM_OFF + 4 * MQ * 4;  // int[4] ring of unit ids, -1 = end of stream
@@ -105,14 +112,14 @@ __device__ __forceinline__ void wait_vm() {
 
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <int D>
-__global__ __launch_bounds__(512, 4) void stage1_stream_kernel(StreamParams sp) {
+template <int D, bool DB>
+__global__ __launch_bounds__(512, DB ? 2 : 4) void stage1_stream_kernel(StreamParams sp) {
     constexpr int CH = D / 8;
     constexpr int KS = D / 16;
     constexpr int DPT = 32 * CH / 64;  // DMA instructions per 32-key slice of a K (or V) tile
     constexpr int LPT = DPT;           // per loader wave: one slice (4 loaders)
     static_assert(D == 128, "streaming stage 1 is instantiated for head_dim 128");
-    using SM = StreamSmem<D>;
+    using SM = StreamSmem<D, DB>;
     const Stage1Params& p = sp.s;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     _Float16* sP = reinterpret_cast<_Float16*>(smem + SM::P_OFF);
@@ -139,7 +146,7 @@ __global__ __launch_bounds__(512, 4) void stage1_stream_kernel(StreamParams sp) 
     const int U = RH * p.Hkv;  // units, head-major
     const int W = (int)gridDim.x;
     const int per = U / W, rem = U - per * W;
-    const bool guided = per >= 4 && (p.ablate & 32);  // off by default: measured slower, see below
+    const bool guided = !DB && per >= 4 && (p.ablate & 32);  // off by default: measured slower, see below
     const int n_static = per + (bid < rem ? 1 : 0);
     const int my_base = bid * per + min(bid, rem);
     // chunks are laid out per KV head and tickets walk the heads round-robin (ticket k -> head k % Hkv,
@@ -220,20 +227,21 @@ __global__ __launch_bounds__(512, 4) void stage1_stream_kernel(StreamParams sp) 
         for (int i = 0; i < LPT; ++i) rowoff[i] = ro[32 * lw + 4 * i + dkey];
     };
     constexpr int64_t NEW_ROW = (int64_t)1 << 63;  // plan offset flag: row lives in k_new / v_new
-    auto issue_k = [&](int head) {
+    auto issue_k = [&](int head, int kb) {
         const char* hb = reinterpret_cast<const char*>(p.k) + (int64_t)head * p.kv_sh * 2;
         const char* nb = reinterpret_cast<const char*>(sp.k_new) + (int64_t)head * D * 2;
 #pragma unroll
         for (int i = 0; i < LPT; ++i) {
             const char* src = rowoff[i] < 0 ? nb + (rowoff[i] & ~NEW_ROW) : hb + rowoff[i];
-            dma16(src + kchunk_b[i & 3], ldsK + (uint32_t)i * 1024u);
+            dma16(src + kchunk_b[i & 3], ldsK + (uint32_t)kb * SM::STAGE + (uint32_t)i * 1024u);
         }
     };
-    auto issue_v = [&](int head) {
+    auto issue_v = [&](int head, int kb) {
         const char* hb = reinterpret_cast<const char*>(p.v) + (int64_t)head * p.kv_sh * 2 + vchunk_b;
         const char* nb = reinterpret_cast<const char*>(sp.v_new) + (int64_t)head * D * 2 + vchunk_b;
 #pragma unroll
-        for (int i = 0; i < LPT; ++i) dma16(rowoff[i] < 0 ? nb + (rowoff[i] & ~NEW_ROW) : hb + rowoff[i], ldsV + (uint32_t)i * 1024u);
+        for (int i = 0; i < LPT; ++i)
+            dma16(rowoff[i] < 0 ? nb + (rowoff[i] & ~NEW_ROW) : hb + rowoff[i], ldsV + (uint32_t)kb * SM::STAGE + (uint32_t)i * 1024u);
     };
     auto read_desc = [&](int b) {  // {cnt, prow, run_start, len}, wave-uniform
         intx4 d = *reinterpret_cast<const intx4*>(meta(b) + PLAN_DESC);
@@ -257,7 +265,7 @@ __global__ __launch_bounds__(512, 4) void stage1_stream_kernel(StreamParams sp) 
         for (int i = 0; i < 2; ++i) {
             const int row = 8 * lw + 4 * i + dkey;
             const int chunk = dpos ^ (row & 15);
-            dma16(hb + (int64_t)qs[row] * 2 + chunk * 16, SM::P_OFF + (uint32_t)(8 * lw + 4 * i) * 256u);
+            dma16(hb + (int64_t)qs[row] * 2 + chunk * 16, SM::Q_OFF + (uint32_t)(8 * lw + 4 * i) * 256u);
         }
     };
 
@@ -279,12 +287,15 @@ __global__ __launch_bounds__(512, 4) void stage1_stream_kernel(StreamParams sp) 
     };
     // ---- fused paged append: workgroup b writes new-token row b into the pool (nobody reads those
     //      pool rows in this launch: the loaders take them from k_new / v_new) -------------------
-    if (bid < sp.n_new) {
-        const int64_t dst = (int64_t)sp.cache_loc[bid] * p.kv_ss;
+    // (the copy jobs go to the LAST workgroups of the grid: with a balanced static split those own one
+    //  unit less than the first ones whenever the units do not divide evenly)
+    const int copy_job = (int)gridDim.x - 1 - bid;
+    if (copy_job < sp.n_new) {
+        const int64_t dst = (int64_t)sp.cache_loc[copy_job] * p.kv_ss;
         const int chunks = p.Hkv * (D / 8);  // 16-byte pieces per K (or V) row
         for (int i = tid; i < chunks; i += blockDim.x) {
             const int hd = i / (D / 8), ch = i - hd * (D / 8);
-            const int64_t so = (int64_t)bid * sp.new_st + hd * D + ch * 8;
+            const int64_t so = (int64_t)copy_job * sp.new_st + hd * D + ch * 8;
             const int64_t d_o = dst + (int64_t)hd * p.kv_sh + ch * 8;
             const uintx4 kk = *reinterpret_cast<const uintx4*>(sp.k_new + so);
             const uintx4 vv = *reinterpret_cast<const uintx4*>(sp.v_new + so);
@@ -309,10 +320,10 @@ __global__ __launch_bounds__(512, 4) void stage1_stream_kernel(StreamParams sp) 
     lds_barrier();
     if (is_loader) {
         load_rowoff(0);
-        issue_k(kvh);
+        issue_k(kvh, 0);
         issue_q(0, kvh);  // the first tile of a stream always opens a group
         if (unext >= 0) issue_meta(unext % RH, 1);
-        issue_v(kvh);
+        issue_v(kvh, 0);
 
         // ---- loader loop: same barrier sequence as the compute waves below ---------------
         for (int i = 0;; ++i) {
@@ -320,24 +331,49 @@ __global__ __launch_bounds__(512, 4) void stage1_stream_kernel(StreamParams sp) 
             const bool last = unext < 0;
             const int kvh_next = last ? 0 : unext / RH;
             const int t_next = last ? 0 : unext - kvh_next * RH;
-            wait_vm<LPT>();  // A: K(u) and plan record (u+1) landed
-            lds_barrier();
-            lds_barrier();   // C: compute waves are done with sK
-            if (!last) {
-                load_rowoff(mb ^ 1);
-                issue_k(kvh_next);
+            if constexpr (DB) {
+                // everything issued so far has had at least half a tile to land: K(u), V(u), Q, plan record (u+1)
+                wait_vm<0>();
+                lds_barrier();  // A
+                if (!last) {    // tile u+1 streams into the other stage during the whole of tile u
+                    load_rowoff(mb ^ 1);
+                    issue_k(kvh_next, mb ^ 1);
+                    issue_v(kvh_next, mb ^ 1);
+                }
+                lds_barrier();  // C: compute waves hold this group's Q in registers, masks of record u are
+                                //    consumed, unit(i+2) is published
+                int u2 = -1;
+                if (!last) {
+                    u2 = __builtin_amdgcn_readfirstlane(sUnit[(i + 2) & 3]);
+                    const bool next_opens = (unext != ucur + 1) || (t_next == 0) || (read_desc(mb ^ 1)[2] != 0);
+                    if (next_opens) issue_q(mb ^ 1, kvh_next);
+                    if (u2 >= 0) issue_meta(u2 % RH, mb);
+                }
+                lds_barrier();  // F
+                lds_barrier();  // H
+                if (last) break;
+                ucur = unext;
+                unext = u2;
+            } else {
+                wait_vm<LPT>();  // A: K(u) and plan record (u+1) landed
+                lds_barrier();
+                lds_barrier();   // C: compute waves are done with sK
+                if (!last) {
+                    load_rowoff(mb ^ 1);
+                    issue_k(kvh_next, 0);
+                }
+                if (last) wait_vm<0>(); else wait_vm<LPT>();  // F: V(u) landed
+                lds_barrier();
+                lds_barrier();   // H: compute waves are done with sV and sP; unit(i+2) published
+                if (last) break;
+                const int u2 = __builtin_amdgcn_readfirstlane(sUnit[(i + 2) & 3]);
+                const bool next_opens = (unext != ucur + 1) || (t_next == 0) || (read_desc(mb ^ 1)[2] != 0);
+                if (next_opens) issue_q(mb ^ 1, kvh_next);
+                if (u2 >= 0) issue_meta(u2 % RH, mb);
+                issue_v(kvh_next, 0);
+                ucur = unext;
+                unext = u2;
             }
-            if (last) wait_vm<0>(); else wait_vm<LPT>();  // F: V(u) landed
-            lds_barrier();
-            lds_barrier();   // H: compute waves are done with sV and sP; unit(i+2) published
-            if (last) break;
-            const int u2 = __builtin_amdgcn_readfirstlane(sUnit[(i + 2) & 3]);
-            const bool next_opens = (unext != ucur + 1) || (t_next == 0) || (read_desc(mb ^ 1)[2] != 0);
-            if (next_opens) issue_q(mb ^ 1, kvh_next);
-            if (u2 >= 0) issue_meta(u2 % RH, mb);
-            issue_v(kvh_next);
-            ucur = unext;
-            unext = u2;
             t = t_next;
             kvh = kvh_next;
         }
@@ -370,7 +406,7 @@ __global__ __launch_bounds__(512, 4) void stage1_stream_kernel(StreamParams sp) 
             qvalid = c < cur[0];
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
-                qf[ks] = *reinterpret_cast<const half8*>(smem + prow_b + (((2 * ks + h) ^ (c & 15)) * 16));
+                qf[ks] = *reinterpret_cast<const half8*>(smem + SM::Q_OFF + c * TILE * 2 + (((2 * ks + h) ^ (c & 15)) * 16));
             m_run = -INFINITY;
             l_run = 0.f;
 #pragma unroll
@@ -392,7 +428,7 @@ __global__ __launch_bounds__(512, 4) void stage1_stream_kernel(StreamParams sp) 
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            const half8 a = *reinterpret_cast<const half8*>(smem + SM::K_OFF + krow_b + (kcol_b ^ (32 * ks)));
+            const half8 a = *reinterpret_cast<const half8*>(smem + SM::K_OFF + (DB ? mb * SM::STAGE : 0) + krow_b + (kcol_b ^ (32 * ks)));
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qf[ks], acc, 0, 0, 0);
         }
         float s[16];
@@ -415,6 +451,7 @@ __global__ __launch_bounds__(512, 4) void stage1_stream_kernel(StreamParams sp) 
 
         // ---- C: every wave is done with sK; tile maxima visible -------------------------
         stamp(i, 2);
+        if (DB && tid == 0 && !last) sUnit[(i + 2) & 3] = (i + 2 < n_static) ? my_base + i + 2 : -1;  // static split only
         lds_barrier();
         stamp(i, 3);
 
@@ -456,8 +493,9 @@ __global__ __launch_bounds__(512, 4) void stage1_stream_kernel(StreamParams sp) 
 #pragma unroll
             for (int ks = 0; ks < TILE / 16; ++ks) {
                 typedef __attribute__((address_space(3))) short4v* lds_s4;
-                const short4v a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(uintptr_t)(vtr_b + (16 * ks) * D * 2));
-                const short4v a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(uintptr_t)(vtr_b + (16 * ks + 4) * D * 2));
+                const int vb = vtr_b + (DB ? mb * SM::STAGE : 0);
+                const short4v a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(uintptr_t)(vb + (16 * ks) * D * 2));
+                const short4v a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(uintptr_t)(vb + (16 * ks + 4) * D * 2));
                 union {
                     short4v s4[2];
                     half8 h8;
@@ -471,7 +509,7 @@ __global__ __launch_bounds__(512, 4) void stage1_stream_kernel(StreamParams sp) 
 
         // ---- H: every wave is done with sV and sP; unit(i+2) published -------------------------
         stamp(i, 6);
-        if (tid == 0 && !last) {
+        if (!DB && tid == 0 && !last) {
             int u2;
             if (!guided) {
                 u2 = (i + 2 < n_static) ? my_base + i + 2 : -1;

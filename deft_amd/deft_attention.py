@@ -14,6 +14,8 @@ launch-only, so 32 layers can be replayed from one hipGraph.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 from torch import nn
 
@@ -65,7 +67,8 @@ class DeFTAttention(nn.Module):
         assert input_metadata.token_to_kv_pool is not None
         pool = input_metadata.token_to_kv_pool
         updater = input_metadata.kv_updater
-        if updater is not None and updater.cache_loc is not None and updater.token_to_kv_pool is pool:
+        if (updater is not None and updater.cache_loc is not None and updater.token_to_kv_pool is pool
+                and not os.environ.get("DEFT_NO_FUSED_APPEND")):
             # store_kv_cache (:121) and the operator (:136-148) in one fused call
             flatten_append_attention(
                 q.view(-1, self.tp_q_head_num, self.head_dim), pool.kv_data[self.layer_id],

@@ -11,11 +11,11 @@ import deft_amd
 bl = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 w = Workload(**{**WORKLOADS["northstar_4kx32"].__dict__, "branch_len": bl})
 b = Bench(w, 8, torch.device("cuda", 0)); b.prepare(use_graph=True)
-workers = 512
+workers = 256 if os.environ.get("DEFT_STREAM_DB") == "1" else 512
 lib.deft_debug_set_buffer.argtypes = [ctypes.c_void_p]
 res = []
 for rep in range(5):
-    dbg = torch.zeros(workers * 128 + 8, dtype=torch.int64, device="cuda")
+    dbg = torch.zeros(65536 + 8, dtype=torch.int64, device="cuda")
     dbg[65536] = 2**62; dbg[65538] = 2**62
     torch.cuda.synchronize()
     lib.deft_debug_set_buffer(dbg.data_ptr())

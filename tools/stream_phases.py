@@ -9,7 +9,7 @@ from deft_amd.utils.workloads import WORKLOADS, Workload, GEOMETRY
 bl = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 w = Workload(**{**WORKLOADS["northstar_4kx32"].__dict__, "branch_len": bl})
 b = Bench(w, 4, torch.device("cuda", 0))
-workers = 512
+workers = 256 if os.environ.get("DEFT_STREAM_DB") == "1" else 512
 dbg = torch.zeros(workers * 16 * 8 + workers * 2, dtype=torch.int64, device="cuda")
 lib.deft_debug_set_buffer.argtypes = [ctypes.c_void_p]
 b.time_stage1(reps=1)
