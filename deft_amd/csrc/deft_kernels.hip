@@ -597,6 +597,8 @@ static int launch_stage1_stream_impl(const Stage1Params& p, int64_t unit_cap, co
     if (unit_cap <= 0) return DEFT_OK;
     const int64_t U_max = unit_cap * p.Hkv;
     int64_t workers = (int64_t)num_cus() * (DB ? 1 : 2);
+    static const int workers_env = getenv("DEFT_STREAM_WORKERS") ? atoi(getenv("DEFT_STREAM_WORKERS")) : 0;  // experiments
+    if (workers_env > 0) workers = workers_env;
     if (workers > U_max) workers = U_max;
     StreamParams sp{};
     sp.s = p;

@@ -76,8 +76,10 @@ struct StreamParams {
 
 // DB = false: two workgroups per CU, one K and one V stage each (K(i+1) streams in after tile i's QK^T, V(i+1)
 //              after its PV), Q staged in the idle P buffer.
-// DB = true : one workgroup per CU, K and V double-buffered (tile i+1 streams in during the whole of tile i),
-//             Q in its own buffer.
+// DB = true : one workgroup per CU, two K and two V stages, loads run TWO tiles ahead: K(i+2) is issued when
+//             tile i's QK^T is done, V(i+2) when its PV is done, so tile i+1 has had a whole tile's time to
+//             land (a 64 KB burst takes ~3 us under load; with one tile in flight the CU idles on it).
+//             Q in its own buffer, three plan records resident.  Static unit split only.
 template <int D, bool DB>
 struct StreamSmem {
     static constexpr int STAGE = TILE * D * 2;  // one K (or V) tile
@@ -86,8 +88,9 @@ struct StreamSmem {
     static constexpr int V_OFF = K_OFF + NBUF * STAGE;
     static constexpr int P_OFF = V_OFF + NBUF * STAGE;
     static constexpr int Q_OFF = DB ? P_OFF + MQ * TILE * 2 : P_OFF;
-    static constexpr int META_OFF = Q_OFF + MQ * TILE * 2;  // 2 plan records
-    static constexpr int WMAX_OFF = META_OFF + 2 * PLAN_BYTES;
+    static constexpr int NMETA = DB ? 3 : 2;                // plan records resident in LDS
+    static constexpr int META_OFF = Q_OFF + MQ * TILE * 2;
+    static constexpr int WMAX_OFF = META_OFF + NMETA * PLAN_BYTES;
     static constexpr int WSUM_OFF = WMAX_OFF + 4 * MQ * 4;
     static constexpr int UNIT_OFF = WSUM_OFF + 4 * MQ * 4;  // int[4] ring of unit ids, -1 = end of stream
     static constexpr int BYTES = UNIT_OFF + 16;
@@ -313,48 +316,67 @@ __global__ __launch_bounds__(512, DB ? 2 : 4) void stage1_stream_kernel(StreamPa
     }
     int kvh = ucur / RH;
     int t = ucur - kvh * RH;  // record index within the head
-    if (is_loader) {
-        issue_meta(t, 0);
-        wait_vm<0>();
-    }
-    lds_barrier();
-    if (is_loader) {
-        load_rowoff(0);
-        issue_k(kvh, 0);
-        issue_q(0, kvh);  // the first tile of a stream always opens a group
-        if (unext >= 0) issue_meta(unext % RH, 1);
-        issue_v(kvh, 0);
+    if constexpr (DB) {
+        // ======================= two tiles ahead, static units u(i) = my_base + i =======================
+        auto exists = [&](int i) { return i < n_static; };
+        auto head_of = [&](int i) { return (my_base + i) / RH; };
+        auto rec_of = [&](int i) { return (my_base + i) % RH; };
+        if (is_loader) {
+            issue_meta(rec_of(0), 0);
+            if (exists(1)) issue_meta(rec_of(1), 1);
+            if (exists(2)) issue_meta(rec_of(2), 2);
+            wait_vm<0>();
+        }
+        lds_barrier();
+        if (is_loader) {
+            load_rowoff(0);
+            issue_q(0, head_of(0));  // the first tile of a stream always opens a group
+            issue_k(head_of(0), 0);
+            issue_v(head_of(0), 0);
+            if (exists(1)) {
+                load_rowoff(1);
+                issue_k(head_of(1), 1);
+                issue_v(head_of(1), 1);
+            }
+            for (int i = 0; i < n_static; ++i) {
+                // A(i): everything of tile i (and the plan records up to i+2) has landed; tile i+1 may be in flight
+                if (exists(i + 1)) wait_vm<2 * LPT>(); else wait_vm<0>();
+                lds_barrier();
+                lds_barrier();  // C(i): QK^T(i) done (K stage i&1 free), Q(i) in registers, masks(i) consumed
+                if (exists(i + 1)) {
+                    const bool next_opens = (rec_of(i + 1) == 0) || (read_desc((i + 1) % 3)[2] != 0);
+                    if (next_opens) issue_q((i + 1) % 3, head_of(i + 1));
+                }
+                if (exists(i + 3)) issue_meta(rec_of(i + 3), i % 3);
+                if (exists(i + 2)) {
+                    load_rowoff((i + 2) % 3);
+                    issue_k(head_of(i + 2), i & 1);
+                }
+                lds_barrier();  // F(i)
+                lds_barrier();  // H(i): PV(i) done (V stage i&1 free)
+                if (exists(i + 2)) issue_v(head_of(i + 2), i & 1);
+            }
+            return;
+        }
+    } else {
+        if (is_loader) {
+            issue_meta(t, 0);
+            wait_vm<0>();
+        }
+        lds_barrier();
+        if (is_loader) {
+            load_rowoff(0);
+            issue_k(kvh, 0);
+            issue_q(0, kvh);  // the first tile of a stream always opens a group
+            if (unext >= 0) issue_meta(unext % RH, 1);
+            issue_v(kvh, 0);
 
-        // ---- loader loop: same barrier sequence as the compute waves below ---------------
-        for (int i = 0;; ++i) {
-            const int mb = i & 1;
-            const bool last = unext < 0;
-            const int kvh_next = last ? 0 : unext / RH;
-            const int t_next = last ? 0 : unext - kvh_next * RH;
-            if constexpr (DB) {
-                // everything issued so far has had at least half a tile to land: K(u), V(u), Q, plan record (u+1)
-                wait_vm<0>();
-                lds_barrier();  // A
-                if (!last) {    // tile u+1 streams into the other stage during the whole of tile u
-                    load_rowoff(mb ^ 1);
-                    issue_k(kvh_next, mb ^ 1);
-                    issue_v(kvh_next, mb ^ 1);
-                }
-                lds_barrier();  // C: compute waves hold this group's Q in registers, masks of record u are
-                                //    consumed, unit(i+2) is published
-                int u2 = -1;
-                if (!last) {
-                    u2 = __builtin_amdgcn_readfirstlane(sUnit[(i + 2) & 3]);
-                    const bool next_opens = (unext != ucur + 1) || (t_next == 0) || (read_desc(mb ^ 1)[2] != 0);
-                    if (next_opens) issue_q(mb ^ 1, kvh_next);
-                    if (u2 >= 0) issue_meta(u2 % RH, mb);
-                }
-                lds_barrier();  // F
-                lds_barrier();  // H
-                if (last) break;
-                ucur = unext;
-                unext = u2;
-            } else {
+            // ---- loader loop: same barrier sequence as the compute waves below ---------------
+            for (int i = 0;; ++i) {
+                const int mb = i & 1;
+                const bool last = unext < 0;
+                const int kvh_next = last ? 0 : unext / RH;
+                const int t_next = last ? 0 : unext - kvh_next * RH;
                 wait_vm<LPT>();  // A: K(u) and plan record (u+1) landed
                 lds_barrier();
                 lds_barrier();   // C: compute waves are done with sK
@@ -373,11 +395,11 @@ __global__ __launch_bounds__(512, DB ? 2 : 4) void stage1_stream_kernel(StreamPa
                 issue_v(kvh_next, 0);
                 ucur = unext;
                 unext = u2;
+                t = t_next;
+                kvh = kvh_next;
             }
-            t = t_next;
-            kvh = kvh_next;
+            return;
         }
-        return;
     }
 
     // running state of the current group (query row c of this lane)
@@ -391,7 +413,9 @@ __global__ __launch_bounds__(512, DB ? 2 : 4) void stage1_stream_kernel(StreamPa
 
     bool prev_adjacent = false;  // unit(i) == unit(i-1) + 1
     for (int i = 0;; ++i) {
-        const int mb = i & 1;  // plan record buffer of this unit
+        const int mb = DB ? i % 3 : (i & 1);                    // plan record slot of this unit
+        const int mn = DB ? (i + 1) % 3 : ((i & 1) ^ 1);        // ... of the next unit
+        const int stg = DB ? (i & 1) : 0;                       // K/V stage of this unit
         const bool last = unext < 0;
         const intx4 cur = read_desc(mb);
         const int orow_c = reinterpret_cast<const int32_t*>(meta(mb) + PLAN_OROW)[c];
@@ -414,7 +438,7 @@ __global__ __launch_bounds__(512, DB ? 2 : 4) void stage1_stream_kernel(StreamPa
         }
         const bool next_adjacent = !last && (unext == ucur + 1);
         bool g_end = true;  // plan record (u+1) is visible now
-        if (next_adjacent) g_end = (t + 1 == RH) || (read_desc(mb ^ 1)[2] != 0);
+        if (next_adjacent) g_end = (t + 1 == RH) || (read_desc(mn)[2] != 0);
         // a ticket for position i+2 (when it opens a new chunk) travels while this tile computes; compute
         // waves issue no other loads, so the wait before barrier H costs nothing
         int ticket = 0;
@@ -428,7 +452,7 @@ __global__ __launch_bounds__(512, DB ? 2 : 4) void stage1_stream_kernel(StreamPa
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            const half8 a = *reinterpret_cast<const half8*>(smem + SM::K_OFF + (DB ? mb * SM::STAGE : 0) + krow_b + (kcol_b ^ (32 * ks)));
+            const half8 a = *reinterpret_cast<const half8*>(smem + SM::K_OFF + stg * SM::STAGE + krow_b + (kcol_b ^ (32 * ks)));
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qf[ks], acc, 0, 0, 0);
         }
         float s[16];
@@ -451,7 +475,6 @@ __global__ __launch_bounds__(512, DB ? 2 : 4) void stage1_stream_kernel(StreamPa
 
         // ---- C: every wave is done with sK; tile maxima visible -------------------------
         stamp(i, 2);
-        if (DB && tid == 0 && !last) sUnit[(i + 2) & 3] = (i + 2 < n_static) ? my_base + i + 2 : -1;  // static split only
         lds_barrier();
         stamp(i, 3);
 
@@ -493,7 +516,7 @@ __global__ __launch_bounds__(512, DB ? 2 : 4) void stage1_stream_kernel(StreamPa
 #pragma unroll
             for (int ks = 0; ks < TILE / 16; ++ks) {
                 typedef __attribute__((address_space(3))) short4v* lds_s4;
-                const int vb = vtr_b + (DB ? mb * SM::STAGE : 0);
+                const int vb = vtr_b + stg * SM::STAGE;
                 const short4v a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(uintptr_t)(vb + (16 * ks) * D * 2));
                 const short4v a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(uintptr_t)(vb + (16 * ks + 4) * D * 2));
                 union {
@@ -546,7 +569,10 @@ __global__ __launch_bounds__(512, DB ? 2 : 4) void stage1_stream_kernel(StreamPa
         if (last) break;
         prev_adjacent = next_adjacent;
         ucur = unext;
-        unext = __builtin_amdgcn_readfirstlane(sUnit[(i + 2) & 3]);
+        if constexpr (DB)
+            unext = (i + 2 < n_static) ? my_base + i + 2 : -1;
+        else
+            unext = __builtin_amdgcn_readfirstlane(sUnit[(i + 2) & 3]);
         kvh = ucur / RH;
         t = ucur - kvh * RH;
     }

@@ -1,0 +1,94 @@
+// Probe 2: legal LDS rings.  Persistent WGs (1 per CU) of NW loader waves; a "stage" is `rows` token rows x {K or V}
+// piece of 256 B (K and V alternate), ring of R stages of (rows*256) bytes, keep R-1 stages in flight.
+// Walk order: head-major spans like the streaming kernel.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+__device__ __forceinline__ void dma16(const void* g, unsigned lds) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds) : "memory");
+}
+// stage index s of a workgroup: tile = s / (2*128/rows) ..., each tile has 128/rows K-stages then 128/rows V-stages
+template <int NW, int ROWS, int R>
+__global__ __launch_bounds__(NW * 64) void k(const char* base, unsigned* out, int ntile, int nhead) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63;
+    constexpr int SPT = 2 * 128 / ROWS;          // stages per tile
+    constexpr int IPS = ROWS / 4 / NW;           // DMA instructions per wave per stage (4 rows per instruction)
+    static_assert(IPS >= 1, "");
+    const long long U = (long long)ntile * nhead;
+    const int u0 = (int)(U * blockIdx.x / gridDim.x), u1 = (int)(U * (blockIdx.x + 1) / gridDim.x);
+    const int S = (u1 - u0) * SPT;
+    auto issue = [&](int s) {
+        const int u = u0 + s / SPT, part = s % SPT;
+        const int head = u / ntile, tile = u % ntile;
+        const int isv = part >= SPT / 2, sub = part % (SPT / 2);
+#pragma unroll
+        for (int i = 0; i < IPS; ++i) {
+            const int row = sub * ROWS + (w * IPS + i) * 4 + (l >> 4);
+            const char* src = base + ((size_t)tile * 128 + row) * 16384 + (isv ? 8192 : 0) + (size_t)head * 256 + (l & 15) * 16;
+            dma16(src, (s % R) * (ROWS * 256) + ((w * IPS + i) * 4) * 256);
+        }
+    };
+    unsigned acc = 0;
+    for (int a = 0; a < R - 1 && a < S; ++a) issue(a);
+    for (int s = 0; s < S; ++s) {
+        const int younger = (S - 1 - s) < (R - 2) ? (S - 1 - s) : (R - 2);   // stages issued after s that may stay in flight
+        // vmcnt must be an immediate: handle up to 7 younger stages
+        switch (younger * IPS) {
+            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+            case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+            case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+            case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+            case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+            case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+            case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+            case 24: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+            case 32: asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); break;
+            case 48: asm volatile("s_waitcnt vmcnt(48)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // stage s visible to everyone
+        acc += ((unsigned*)smem)[(s % R) * (ROWS * 64) + tid];
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // everyone done with stage s -> its slot is free
+        if (s + R - 1 < S) issue(s + R - 1);
+    }
+    if (acc == 0x12345678u) out[0] = acc;
+}
+template <int NW, int ROWS, int R>
+void run(const char* d, unsigned* o, size_t layer, int layers, int ntile, int nhead, int wgs) {
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    const int lds = R * ROWS * 256;
+    hipFuncSetAttribute((const void*)k<NW, ROWS, R>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    float best = 1e9;
+    for (int rep = 0; rep < 3; ++rep) {
+        hipEventRecord(e0);
+        for (int l2 = 0; l2 < layers; ++l2) hipLaunchKernelGGL((k<NW, ROWS, R>), dim3(wgs), dim3(NW * 64), lds, 0, d + l2 * layer, o, ntile, nhead);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        if (rep && ms < best) best = ms;
+    }
+    double bytes = (double)ntile * nhead * 65536 * layers;
+    printf("waves %d rows/stage %3d ring %d (LDS %3d KB, in flight <= %3d KB) wgs %d: %.1f us/layer %.2f TB/s (%s)\n", NW, ROWS, R,
+           lds / 1024, (R - 1) * ROWS * 256 / 1024, wgs, best / layers * 1e3, bytes / (best * 1e-3) / 1e12, hipGetErrorString(hipGetLastError()));
+}
+int main() {
+    const int ntile = 82, nhead = 32, layers = 16;
+    const size_t layer = (size_t)ntile * 128 * 16384;
+    char* d; unsigned* o;
+    hipMalloc(&d, layer * layers); hipMalloc(&o, 4);
+    hipMemset(d, 1, layer * layers);
+    run<4, 128, 2>(d, o, layer, layers, ntile, nhead, 256);   // K|V tile stages of 32 KB, 1 in flight
+    run<4, 128, 3>(d, o, layer, layers, ntile, nhead, 256);
+    run<4, 128, 4>(d, o, layer, layers, ntile, nhead, 256);
+    run<4, 128, 5>(d, o, layer, layers, ntile, nhead, 256);   // 160 KB
+    run<8, 128, 5>(d, o, layer, layers, ntile, nhead, 256);
+    run<4, 32, 16>(d, o, layer, layers, ntile, nhead, 256);   // 8 KB stages, ring 16 = 128 KB
+    run<4, 32, 19>(d, o, layer, layers, ntile, nhead, 256);   // 152 KB
+    run<8, 32, 19>(d, o, layer, layers, ntile, nhead, 256);
+    run<4, 128, 2>(d, o, layer, layers, ntile, nhead, 512);   // 2 WGs/CU x 64 KB
+    run<4, 64, 4>(d, o, layer, layers, ntile, nhead, 512);    // 2 WGs/CU x 64 KB ring of 16 KB stages
+    run<4, 64, 4>(d, o, layer, layers, ntile, nhead, 768);    // 3 WGs/CU? (64 KB each = 192: only 2 fit)
+    run<4, 32, 6>(d, o, layer, layers, ntile, nhead, 768);    // 3 WGs/CU x 48 KB
+    return 0;
+}
