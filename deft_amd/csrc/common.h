@@ -53,7 +53,8 @@ inline Workspace carve(void* base, int Hq, int D, int64_t rows, int64_t tiles, s
 inline int64_t node_max_tiles(int NE, int64_t total_kv) { return (int64_t)NE + total_kv / DEFT_BLOCK_LEN; }
 
 // Plan buffer (built once per decode step, read by every layer's call):
-//   header      256 B : int32 hdr[0] = records per KV head; scheduler words {ticket, done} at +64
+//   header      4 KB  : int32 hdr[0] = records per KV head; sched[0] = workgroups-done counter at +64;
+//                       8 ticket counters at +512 + 256 k (one cache line each; workgroup b uses k = b % 8)
 //   records     (cap+1) x 2048 B (stage1_stream.h PLAN_*), cap = units-per-head capacity
 //   unit list   5 x cap int32 (src, aux, pass, flags, prow)
 //   row_q       rows int32 : partial row -> query row
@@ -72,7 +73,7 @@ inline PlanView plan_view(void* base, int64_t cap, int64_t rows) {
     v.cap = cap;
     v.hdr = reinterpret_cast<int32_t*>(p);
     v.sched = reinterpret_cast<int32_t*>(p + 64);
-    size_t off = 256;
+    size_t off = 4096;
     v.records = p + off;
     off = align_up(off + 2048 * (size_t)(cap + 1), 256);
     v.units = reinterpret_cast<int32_t*>(p + off);

@@ -580,13 +580,12 @@ static int launch_plan(const Stage1Params& p, int NB, const PlanView& pv, const 
 
 // Stage 1, streaming form (head_dim 128; MHA and GQA).  Units per head are only known on the device
 // (plan header), so the grid is sized from the host-side upper bound.
-template <bool DB>
-static int launch_stage1_stream_impl(const Stage1Params& p, int64_t unit_cap, const PlanView& pv, const AppendArgs& ap,
-                                     hipStream_t stream) {
-    using SM = StreamSmem<128, DB>;
+static int launch_stage1_stream(const Stage1Params& p, int64_t unit_cap, const PlanView& pv, const AppendArgs& ap,
+                                hipStream_t stream) {
+    using SM = StreamSmem<128>;
     static bool attr_set = false;
     if (!attr_set) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&stage1_stream_kernel<128, DB>),
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&stage1_stream_kernel<128>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, SM::BYTES);
         if (e != hipSuccess) {
             set_error("hipFuncSetAttribute(stage1_stream): %s", hipGetErrorString(e));
@@ -596,14 +595,17 @@ static int launch_stage1_stream_impl(const Stage1Params& p, int64_t unit_cap, co
     }
     if (unit_cap <= 0) return DEFT_OK;
     const int64_t U_max = unit_cap * p.Hkv;
-    int64_t workers = (int64_t)num_cus() * (DB ? 1 : 2);
+    int64_t workers = (int64_t)num_cus();  // one workgroup per CU
     static const int workers_env = getenv("DEFT_STREAM_WORKERS") ? atoi(getenv("DEFT_STREAM_WORKERS")) : 0;  // experiments
     if (workers_env > 0) workers = workers_env;
     if (workers > U_max) workers = U_max;
     StreamParams sp{};
     sp.s = p;
+    // profiling knobs, read at every launch so that one process can A/B them on the same pools
     sp.s.ablate = getenv("DEFT_STAGE1_ABLATE") ? atoi(getenv("DEFT_STAGE1_ABLATE")) : 0;
+    sp.dyn_pct = getenv("DEFT_STREAM_DYN") ? atoi(getenv("DEFT_STREAM_DYN")) : 30;
     sp.hdr = pv.hdr;
+    sp.cap = (int)pv.cap + 1;
     sp.plan = pv.records;
     sp.sched = pv.sched;
     sp.dbg = g_stream_dbg;
@@ -616,19 +618,8 @@ static int launch_stage1_stream_impl(const Stage1Params& p, int64_t unit_cap, co
         set_error("fused append: %d new rows exceed the %lld workgroups of the launch", sp.n_new, (long long)workers);
         return DEFT_EUNSUPPORTED;
     }
-    hipLaunchKernelGGL((stage1_stream_kernel<128, DB>), dim3((unsigned)workers), dim3(512), SM::BYTES, stream, sp);
+    hipLaunchKernelGGL((stage1_stream_kernel<128>), dim3((unsigned)workers), dim3(512), SM::BYTES, stream, sp);
     return check_launch("stage1 stream launch");
-}
-
-// Stage 1, streaming form (head_dim 128; MHA and GQA).  Units per head are only known on the device
-// (plan header), so the grid is sized from the host-side upper bound.
-static int launch_stage1_stream(const Stage1Params& p, int64_t unit_cap, const PlanView& pv, const AppendArgs& ap,
-                                hipStream_t stream) {
-    // default: one workgroup per CU with double-buffered K/V stages (measured 1-7 % faster than two
-    // single-buffered workgroups per CU and with a tighter spread of workgroup finish times)
-    static const bool db = getenv("DEFT_STREAM_DB") ? atoi(getenv("DEFT_STREAM_DB")) != 0 : true;
-    return db ? launch_stage1_stream_impl<true>(p, unit_cap, pv, ap, stream)
-              : launch_stage1_stream_impl<false>(p, unit_cap, pv, ap, stream);
 }
 
 template <int MODE>

@@ -1,45 +1,33 @@
-// Flatten stage 1, streaming form: persistent workgroups, LDS-DMA pipeline.
+// Stage 1 (Flatten and Node), streaming form: persistent workgroups, LDS-DMA pipeline.
 //
 // Included by deft_kernels.hip (needs its typedefs and Stage1Params).
 //
-// Why a second form of stage 1: the tile-per-workgroup kernel (stage1_kernel) pays
-// three dependent HBM round trips per tile (descriptor -> slot list -> K/V rows)
-// with only two workgroups per CU to hide them, spends ~1400 instructions per wave
-// per tile, and writes one fp32 partial per (tile, head).  Here
-//   * a plan kernel (once per call, or once per decode step when the caller caches
-//     the plan) packs each block's metadata into one 2 KB record: the byte offset
-//     of every KV row in the pool, a 32-bit query mask per slot (0 for padding) and
-//     {cnt, prow, run_start, len};
-//   * a fixed grid of workgroups (2 per CU) each walks a contiguous span of the
-//     (KV head, tile) sequence, head-major.  A workgroup is 4 compute waves + 4
-//     LOADER waves: only the loaders issue DMA, so the compute waves never stall on
-//     a full memory queue (measured: with compute waves issuing their own DMA, half
-//     of every tile's time was spent blocked in the issue of 16 instructions), and a
-//     1 KB DMA instruction costs ~90 cycles to issue, so a tile's 64 are spread over
-//     four waves;
-//   * K and V tiles travel HBM -> LDS by `global_load_lds_dwordx4` (no VGPR
-//     round trip).  K(i+1) is issued as soon as the S^T MFMAs of tile i are done and
-//     V(i+1) as soon as its PV MFMAs are done, so a tile's softmax/PV time hides the
-//     next K and its QK^T/softmax time hides the next V.  The 2 KB plan record of
-//     tile i+2 rides the same DMA queue;
-//   * V^T MFMA fragments come from `ds_read_b64_tr_b16` (2 reads per fragment
-//     instead of 8 16-bit reads + 4 permutes); V is stored with its 16-byte chunks
-//     XOR-ed by 4*(key&3) so the four rows a transpose-read touches sit in different
-//     bank groups, K with chunks XOR-ed by key&15 for the row-per-lane b128 reads;
-//   * consecutive tiles of one head whose query list is identical (the whole shared
-//     prefix of a few-shot tree) are folded with an online softmax in registers
-//     and emit ONE partial, which cuts the fp32 partial traffic of the reference
-//     (17-19 MB per layer-step on the 4k x 32 tree) to a few MB.
+//   * plan kernels (once per decode step) pack each 128-slot KV tile's metadata into one 2 KB record:
+//     the byte offset of every KV row in the pool, a 32-bit virtual-query mask per slot and the
+//     query / partial-row maps (PLAN_* below);
+//   * ONE workgroup per CU = 4 compute waves + 4 LOADER waves.  Only the loaders issue DMA, so the
+//     compute waves never sit in the CU's vector-memory FIFO (measured: with compute waves issuing
+//     their own DMA, half of every tile's time was spent blocked in the issue of 16 instructions);
+//   * K and V tiles travel HBM -> LDS by `global_load_lds_dwordx4` (no VGPR round trip), double
+//     buffered, TWO tiles ahead of the compute waves: K(i+2) is issued when tile i's QK^T is done,
+//     V(i+2) when its PV is done.  Plan records and the Q rows of a group ride the same queue;
+//   * V^T MFMA fragments come from `ds_read_b64_tr_b16`; V is stored with its 16-byte chunks XOR-ed
+//     by 4*(key&3), K with chunks XOR-ed by key&15 for the row-per-lane b128 reads;
+//   * tiles of one (KV head, run) that a workgroup meets back to back are folded with an online
+//     softmax in registers and emit ONE partial;
+//   * work distribution: the first rounds are a static INTERLEAVED walk (unit i of workgroup b is
+//     chunk i*W + b of the tile-major / head-fastest sequence: the whole chip advances through the
+//     pool as one front, and with W % Hkv == 0 a workgroup stays on one head so prefix tiles fold);
+//     the last ~30 % of the units are handed out one by one from an atomic ticket counter so that
+//     workgroups finish together (static shares finish 9 us apart on a 30 us kernel: ramp-up skew
+//     and 10-vs-11-tile shares).  The ticket atomic is issued by a LOADER wave a tile before it is
+//     needed and retires under that wave's normal counted wait, so it never stalls anyone.
 //
-// All DMA issue and all waits on it are inline asm: hipcc neither counts asm VMEM
-// operations nor drains them at a raw s_barrier, which is what lets loads stay in
-// flight across barriers (cdna_hip_programming.md §5.7, "Pipelining across barriers").
-// Wait arithmetic (per loader wave, LPT = its DMA instructions per K or V tile = 32*D/8/64):
-//   issue order   ... K(i) | meta(i+1) V(i) | K(i+1) | meta(i+2) V(i+1) | ...
-//   "K(i) and meta(i+1) landed"  <=>  at most V(i)    outstanding  -> vmcnt(LPT)
-//   "V(i) landed"                <=>  at most K(i+1)  outstanding  -> vmcnt(LPT)
-//   last tile of the span: nothing younger was issued               -> vmcnt(0)
-// Stores are never counted (they may retire early; over-waiting is safe).
+// All DMA issue and all waits on it are inline asm: hipcc neither counts asm VMEM operations nor
+// drains them at a raw s_barrier, which is what lets loads stay in flight across barriers
+// (cdna_hip_programming.md §5.7).  Per loader wave, LPT = its DMA instructions per K or V tile:
+//   issue order  ... | [ticket] Q(i+1) rec(i+3) K(i+2) | V(i+2) | ...      (after C(i) | after H(i))
+//   "tile i+1 and everything older landed"  <=>  at most K(i+2), V(i+2) outstanding -> vmcnt(2 LPT)
 #pragma once
 
 namespace deft {
@@ -54,16 +42,20 @@ typedef short short4v __attribute__((ext_vector_type(4)));
 constexpr int PLAN_BYTES = 2048;
 constexpr int PLAN_ROWOFF = 0;   // int64[128]  byte offset of each slot's row in the pool (pads alias slot 0)
 constexpr int PLAN_MASK = 1024;  // uint32[128] bit v set <=> virtual row v sees the slot (0 for pads)
-constexpr int PLAN_DESC = 1536;  // int32[4]    n_vrows, -, run_start, len
+constexpr int PLAN_DESC = 1536;  // int32[4]    n_vrows, prow, opens_run, run_id
 constexpr int PLAN_QSRC = 1600;  // int32[32]   element offset of row v's Q vector from q + kvh*G*q_stride_head
 constexpr int PLAN_OROW = 1728;  // int32[32]   partial row of row v, relative to kvh*G*rows: g*rows + prow + qi
-constexpr int PLAN_HDR = 256;    // plan header: int32 {records per head R, ...}, scheduler words at +64
+constexpr int PLAN_HDR = 4096;   // plan header: int32 R (records per head) at +0, done counter at +64, ticket counters
+constexpr int NTICKET = 8;       // ... NTICKET of them at +512 + 256 k: sched[112 + 64 k] (sched = header + 64 bytes)
+__host__ __device__ inline int ticket_word(int k) { return 112 + 64 * k; }
 
 struct StreamParams {
     Stage1Params s;
     const int32_t* hdr;  // plan header: hdr[0] = R, records per KV head
     const char* plan;    // [R+1][PLAN_BYTES]
-    int* sched;          // [2] = {ticket counter, workgroups done}; both 0 between launches
+    int cap;             // records the plan buffer holds (>= R + 1): bound for speculative record prefetch
+    int dyn_pct;         // share (%) of a workgroup's units handed out by ticket at the end of the walk; 0 = static
+    int* sched;          // sched[0] = workgroups done, sched[ticket_word(k)] = ticket counter k; all 0 between launches
     // fused paged append (optional): rows whose plan offset has bit 63 set are read from k_new / v_new
     // (offset = row index * new_st * 2 bytes) and workgroup b < n_new also copies row b into the pool
     const _Float16* k_new;
@@ -74,26 +66,28 @@ struct StreamParams {
     unsigned long long* dbg;  // internal: per-phase s_memtime stamps [workgroup][16 tiles][8], or null
 };
 
-// DB = false: two workgroups per CU, one K and one V stage each (K(i+1) streams in after tile i's QK^T, V(i+1)
-//              after its PV), Q staged in the idle P buffer.
-// DB = true : one workgroup per CU, two K and two V stages, loads run TWO tiles ahead: K(i+2) is issued when
-//             tile i's QK^T is done, V(i+2) when its PV is done, so tile i+1 has had a whole tile's time to
-//             land (a 64 KB burst takes ~3 us under load; with one tile in flight the CU idles on it).
-//             Q in its own buffer, three plan records resident.  Static unit split only.
-template <int D, bool DB>
+template <int D>
 struct StreamSmem {
     static constexpr int STAGE = TILE * D * 2;  // one K (or V) tile
-    static constexpr int NBUF = DB ? 2 : 1;
-    static constexpr int K_OFF = 0;
-    static constexpr int V_OFF = K_OFF + NBUF * STAGE;
-    static constexpr int P_OFF = V_OFF + NBUF * STAGE;
-    static constexpr int Q_OFF = DB ? P_OFF + MQ * TILE * 2 : P_OFF;
-    static constexpr int NMETA = DB ? 3 : 2;                // plan records resident in LDS
+    static constexpr int K_OFF = 0;             // two K stages
+    static constexpr int V_OFF = K_OFF + 2 * STAGE;
+    static constexpr int P_OFF = V_OFF + 2 * STAGE;         // P^T fp16 [32][128]
+    static constexpr int Q_OFF = P_OFF + MQ * TILE * 2;     // Q rows of the opening group [32][D]
+    static constexpr int NMETA = 3;                         // plan records resident in LDS
     static constexpr int META_OFF = Q_OFF + MQ * TILE * 2;
     static constexpr int WMAX_OFF = META_OFF + NMETA * PLAN_BYTES;
     static constexpr int WSUM_OFF = WMAX_OFF + 4 * MQ * 4;
-    static constexpr int UNIT_OFF = WSUM_OFF + 4 * MQ * 4;  // int[4] ring of unit ids, -1 = end of stream
-    static constexpr int BYTES = UNIT_OFF + 16;
+    static constexpr int UNIT_OFF = WSUM_OFF + 4 * MQ * 4;  // int[8] ring of unit ids (chunk index), -1 = end
+    // Outbox for the partials of small groups (<= OB_GROUP rows): rows wait in LDS and leave in one burst.
+    // A store by a compute wave waits ~0.5 us in the CU's vector-memory FIFO behind the loaders' DMA,
+    // whatever its size, and the compute waves are the critical path of the barrier-coupled pipeline.
+    static constexpr int OB_ROWS = 16;
+    static constexpr int OB_GROUP = 4;
+    static constexpr int OB_OFF = UNIT_OFF + 32;                 // float [OB_ROWS][D]
+    static constexpr int OB_LSE_OFF = OB_OFF + OB_ROWS * D * 4;  // float [OB_ROWS]
+    static constexpr int OB_DST_OFF = OB_LSE_OFF + OB_ROWS * 4;  // int32 [OB_ROWS]: partial row index (head-major)
+    static constexpr int BYTES = OB_DST_OFF + OB_ROWS * 4;
+    static_assert(BYTES <= 160 * 1024, "LDS budget");
 };
 
 // 64 lanes x 16 bytes, global (per-lane address) -> LDS (lds_dst + 16*lane).  M0 is not
@@ -115,96 +109,73 @@ __device__ __forceinline__ void wait_vm() {
 
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <int D, bool DB>
-__global__ __launch_bounds__(512, DB ? 2 : 4) void stage1_stream_kernel(StreamParams sp) {
-    constexpr int CH = D / 8;
+template <int D>
+__global__ __launch_bounds__(512, 2) void stage1_stream_kernel(StreamParams sp) {
     constexpr int KS = D / 16;
-    constexpr int DPT = 32 * CH / 64;  // DMA instructions per 32-key slice of a K (or V) tile
-    constexpr int LPT = DPT;           // per loader wave: one slice (4 loaders)
+    constexpr int LPT = 32 * (D / 8) / 64;  // DMA instructions per loader wave per K (or V) tile: its 32 keys
     static_assert(D == 128, "streaming stage 1 is instantiated for head_dim 128");
-    using SM = StreamSmem<D, DB>;
+    using SM = StreamSmem<D>;
     const Stage1Params& p = sp.s;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     _Float16* sP = reinterpret_cast<_Float16*>(smem + SM::P_OFF);
     float* sWmax = reinterpret_cast<float*>(smem + SM::WMAX_OFF);
     float* sWsum = reinterpret_cast<float*>(smem + SM::WSUM_OFF);
+    int* sUnit = reinterpret_cast<int*>(smem + SM::UNIT_OFF);
 
     const int tid = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l = tid & 63;
     const int c = l & 31;
     const int h = l >> 5;
-
-    // Work distribution.  Position i of a workgroup's unit stream is known two tiles ahead: lane 0 of compute
-    // wave 0 publishes unit(i+2) in the sUnit ring before barrier H of tile i.
-    //  * default: balanced static split of the head-major unit sequence, no atomics;
-    //  * experimental (DEFT_STAGE1_ABLATE bit 32): guided chunks from one atomic ticket counter — 60 % of
-    //    every head's units in chunks of 4, 25 % in chunks of 2, 15 % one by one — meant to even out the
-    //    workgroups' finish times (equal static shares finish +-20 % apart: a 9 us tail on a 29 us bulk).
-    //    Measured 4-6 us SLOWER than the static split on the 4k x 32 tree: the returning atomic of a compute
-    //    wave queues behind ~100 KB of loader DMA in the CU's memory FIFO, and every chunk is its own group
-    //    (own Q fetch, own partial).  Kept for the next round (ticket prefetch two tiles ahead).
     const int bid = blockIdx.x;
-    const int RH = sp.hdr[0];  // records per KV head (written by the plan kernels)
-    const int U = RH * p.Hkv;  // units, head-major
     const int W = (int)gridDim.x;
-    const int per = U / W, rem = U - per * W;
-    const bool guided = !DB && per >= 4 && (p.ablate & 32);  // off by default: measured slower, see below
-    const int n_static = per + (bid < rem ? 1 : 0);
-    const int my_base = bid * per + min(bid, rem);
-    // chunks are laid out per KV head and tickets walk the heads round-robin (ticket k -> head k % Hkv,
-    // chunk k / Hkv of that head): at any moment the active chunks cover all heads evenly.  Handing out the
-    // head-major sequence in order instead makes every workgroup read the same few heads at the same time,
-    // i.e. the same 256-byte column of every token row, which serialises on a few HBM channels (-10 %).
-    const int R1 = guided ? (int)(0.60f * RH) / 4 * 4 : 0;
-    const int R2 = guided ? R1 + (int)(0.25f * RH) / 2 * 2 : 0;
-    const int n1 = R1 / 4, n2 = (R2 - R1) / 2, n3 = RH - R2;
-    auto chunk_of = [&](int k, int& cs, int& ce) {
-        const int head = k % p.Hkv, ci = k / p.Hkv;
-        int st, len;
-        if (ci < n1) { st = 4 * ci; len = 4; }
-        else if (ci < n1 + n2) { st = R1 + 2 * (ci - n1); len = 2; }
-        else if (ci < n1 + n2 + n3) { st = R2 + (ci - n1 - n2); len = 1; }
-        else { cs = -1; ce = -1; return; }
-        cs = head * RH + st;
-        ce = cs + len;
+    const unsigned Hkv = (unsigned)p.Hkv;
+    auto head_of = [&](int u) { return (int)((unsigned)u % Hkv); };  // unit id = chunk index = record * Hkv + head
+    auto rec_of = [&](int u) { return (int)((unsigned)u / Hkv); };
+    const bool is_loader = w >= 4;  // waves 4..7 stream; waves 0..3 compute
+    const int lw = w - 4;           // loader lw stages keys [32 lw, 32 lw + 32)
+
+    auto meta = [&](int b) { return smem + SM::META_OFF + b * PLAN_BYTES; };
+    auto issue_meta = [&](int rec, int b) {  // loader 0 only: 2 x 1 KB
+        const char* src = sp.plan + (int64_t)rec * PLAN_BYTES + 16 * l;
+        dma16(src, SM::META_OFF + (uint32_t)b * PLAN_BYTES);
+        dma16(src + 1024, SM::META_OFF + (uint32_t)b * PLAN_BYTES + 1024u);
     };
-    int* sUnit = reinterpret_cast<int*>(smem + SM::UNIT_OFF);
-    int pub_u = -1, pub_end = -1;  // publisher state (lane 0 of compute wave 0): last published unit, end of its chunk
-    if (tid == 0) {
-        int a, b2;
-        if (guided) {
-            int cs, ce;
-            chunk_of(atomicAdd(sp.sched, 1), cs, ce);
-            a = cs;
-            if (ce - cs >= 2) {
-                b2 = cs + 1;
-            } else if (cs >= 0) {
-                chunk_of(atomicAdd(sp.sched, 1), cs, ce);
-                b2 = cs;
-            } else {
-                b2 = -1;
-            }
-            pub_u = b2;
-            pub_end = ce;
-        } else {
-            a = n_static > 0 ? my_base : -1;
-            b2 = n_static > 1 ? my_base + 1 : -1;
+
+    // Ramp: the plan records of the first three (static) units are fetched BEFORE the record count is known
+    // (their addresses depend only on the grid; the plan buffer holds sp.cap records, unwritten ones are never
+    // used), so the header read and the record fetch are one round trip instead of two.
+    if (w == 4) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int rec = rec_of(j * W + bid);
+            if (rec < sp.cap) issue_meta(rec, j);
         }
-        sUnit[0] = a;
-        sUnit[1] = a < 0 ? -1 : b2;
     }
+    if (sp.dbg && tid == 0) {
+        sp.dbg[((int64_t)bid * 16 + 15) * 8 + 6] = wall_clock64();
+        sp.dbg[((int64_t)bid * 16 + 15) * 8 + 0] = __builtin_amdgcn_s_memtime();
+    }
+    const int RH = sp.hdr[0];  // records per KV head (written by the plan kernels)
+    const int U = RH * p.Hkv;  // units
+    // static rounds J (every workgroup owns unit i*W + bid for i < J), then tickets: unit J*W + ticket
+    const int per = U / W;
+    int J = per - (per * sp.dyn_pct + 99) / 100;
+    const bool dynamic = per >= 6 && J >= 3 && sp.dyn_pct > 0;
+    if (!dynamic) J = 0x3fffffff;
+    auto static_unit = [&](int i) {
+        const int u = i * W + bid;
+        return (i < J && u < U) ? u : -1;
+    };
 
     // ---- loop-invariant lane constants -------------------------------------------------
-    // DMA: instruction i of a tile stages keys 32w + 4i + (l>>4), LDS chunk position l&15.
+    // DMA: instruction i of a tile stages keys 32 lw + 4i + (l>>4), LDS chunk position l&15.
     //   K source chunk = pos ^ (key & 15) = (pos ^ (l>>4)) ^ 4*(i&3);  V source chunk = pos ^ 4*(key&3)
     const int dpos = l & 15, dkey = l >> 4;
     int kchunk_b[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) kchunk_b[j] = ((dpos ^ dkey) ^ (4 * j)) * 16;
     const int vchunk_b = (dpos ^ (4 * (dkey & 3))) * 16;
-    const bool is_loader = w >= 4;  // waves 4..7 stream; waves 0..3 compute
-    const int lw = w - 4;           // loader lw stages keys [32 lw, 32 lw + 32)
     const uint32_t ldsK = SM::K_OFF + (uint32_t)(lw < 0 ? 0 : lw) * 32u * D * 2u;
     const uint32_t ldsV = SM::V_OFF + (uint32_t)(lw < 0 ? 0 : lw) * 32u * D * 2u;
     // S^T A fragments: row 32w + c, chunk (2ks + h) ^ (c & 15)  ->  byte (((h ^ c) & 15) * 16) ^ (32 * ks)
@@ -218,12 +189,7 @@ __global__ __launch_bounds__(512, DB ? 2 : 4) void stage1_stream_kernel(StreamPa
     // P: row c, 16-byte chunks XOR-ed by (c & 15)
     const int prow_b = SM::P_OFF + c * TILE * 2;
 
-    auto meta = [&](int b) { return smem + SM::META_OFF + b * PLAN_BYTES; };
-    auto issue_meta = [&](int tt, int b) {  // one 1 KB DMA by each of loaders 0 and 1
-        const char* rec = sp.plan + (int64_t)tt * PLAN_BYTES;
-        if (lw < 2) dma16(rec + 1024 * lw + 16 * l, SM::META_OFF + (uint32_t)b * PLAN_BYTES + 1024u * (uint32_t)lw);
-    };
-    int64_t rowoff[LPT];  // pool byte offsets of this loader lane's LPT rows of the NEXT tile (set at D, reused at I)
+    int64_t rowoff[LPT];  // pool byte offsets of this loader lane's LPT rows of one tile
     auto load_rowoff = [&](int b) {
         const int64_t* ro = reinterpret_cast<const int64_t*>(meta(b) + PLAN_ROWOFF);
 #pragma unroll
@@ -246,7 +212,7 @@ __global__ __launch_bounds__(512, DB ? 2 : 4) void stage1_stream_kernel(StreamPa
         for (int i = 0; i < LPT; ++i)
             dma16(rowoff[i] < 0 ? nb + (rowoff[i] & ~NEW_ROW) : hb + rowoff[i], ldsV + (uint32_t)kb * SM::STAGE + (uint32_t)i * 1024u);
     };
-    auto read_desc = [&](int b) {  // {cnt, prow, run_start, len}, wave-uniform
+    auto read_desc = [&](int b) {  // {n_vrows, prow, opens_run, run_id}, wave-uniform
         intx4 d = *reinterpret_cast<const intx4*>(meta(b) + PLAN_DESC);
         intx4 r;
 #pragma unroll
@@ -254,13 +220,11 @@ __global__ __launch_bounds__(512, DB ? 2 : 4) void stage1_stream_kernel(StreamPa
         return r;
     };
     auto stamp = [&](int i, int k) {
-        if (sp.dbg && tid == 0 && i < 16) sp.dbg[((int64_t)bid * 16 + i) * 8 + k] = __builtin_amdgcn_s_memtime();
+        if (sp.dbg && tid == 0 && i < 15) sp.dbg[((int64_t)bid * 16 + i) * 8 + k] = __builtin_amdgcn_s_memtime();
     };
-
-    // Q rows of the group that opens at a tile: the loaders stage them in the P buffer, which is idle
-    // between a tile's PV reads (barrier H) and the next tile's P writes (after barrier C).
-    // Layout like K: row c, 16-byte chunks XOR-ed by (c & 15).  Rows beyond n_vrows alias the first
-    // query vector of the group (their mask bits are 0).  2 DMA instructions per loader.
+    // Q rows of the group that opens at a tile, staged by the loaders in the Q buffer.  Layout like K: row c,
+    // 16-byte chunks XOR-ed by (c & 15).  Rows beyond n_vrows alias the first query vector of the group (their
+    // mask bits are 0).  2 DMA instructions per loader.
     auto issue_q = [&](int b, int head) {
         const int32_t* qs = reinterpret_cast<const int32_t*>(meta(b) + PLAN_QSRC);
         const char* hb = reinterpret_cast<const char*>(p.q) + (int64_t)head * p.G * p.q_sh * 2;
@@ -271,8 +235,6 @@ __global__ __launch_bounds__(512, DB ? 2 : 4) void stage1_stream_kernel(StreamPa
             dma16(hb + (int64_t)qs[row] * 2 + chunk * 16, SM::Q_OFF + (uint32_t)(8 * lw + 4 * i) * 256u);
         }
     };
-
-    if (sp.dbg && tid == 0) sp.dbg[((int64_t)bid * 16 + 15) * 8 + 6] = wall_clock64();
     auto finish = [&]() {  // the last workgroup to leave re-arms the scheduler words for the next launch
         if (tid == 0) {
             if (sp.dbg) {
@@ -280,19 +242,19 @@ __global__ __launch_bounds__(512, DB ? 2 : 4) void stage1_stream_kernel(StreamPa
                 asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
                 asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
                 sp.dbg[((int64_t)bid * 16 + 15) * 8 + 5] = ((unsigned long long)xcc << 32) | hw;
+                sp.dbg[((int64_t)bid * 16 + 15) * 8 + 7] = wall_clock64();
+                sp.dbg[((int64_t)bid * 16 + 15) * 8 + 1] = __builtin_amdgcn_s_memtime();
             }
-            if (sp.dbg) sp.dbg[((int64_t)bid * 16 + 15) * 8 + 7] = wall_clock64();
-            if (atomicAdd(sp.sched + 1, 1) == (int)gridDim.x - 1) {
+            if (atomicAdd(sp.sched, 1) == W - 1) {
                 sp.sched[0] = 0;
-                sp.sched[1] = 0;
+                for (int k = 0; k < NTICKET; ++k) sp.sched[ticket_word(k)] = 0;
             }
         }
     };
-    // ---- fused paged append: workgroup b writes new-token row b into the pool (nobody reads those
-    //      pool rows in this launch: the loaders take them from k_new / v_new) -------------------
-    // (the copy jobs go to the LAST workgroups of the grid: with a balanced static split those own one
-    //  unit less than the first ones whenever the units do not divide evenly)
-    const int copy_job = (int)gridDim.x - 1 - bid;
+
+    // ---- fused paged append: the last n_new workgroups each copy one new-token row into the pool (nobody
+    //      reads those pool rows in this launch: the loaders take them from k_new / v_new) -------------------
+    const int copy_job = W - 1 - bid;
     if (copy_job < sp.n_new) {
         const int64_t dst = (int64_t)sp.cache_loc[copy_job] * p.kv_ss;
         const int chunks = p.Hkv * (D / 8);  // 16-byte pieces per K (or V) row
@@ -306,127 +268,140 @@ __global__ __launch_bounds__(512, DB ? 2 : 4) void stage1_stream_kernel(StreamPa
             *reinterpret_cast<uintx4*>(const_cast<_Float16*>(p.v) + d_o) = vv;
         }
     }
+
     // ---- prologue -----------------------------------------------------------------
-    lds_barrier();  // sUnit[0..1] visible
-    int ucur = __builtin_amdgcn_readfirstlane(sUnit[0]);
-    int unext = __builtin_amdgcn_readfirstlane(sUnit[1]);
-    if (ucur < 0) {
+    if (tid == 0) {
+        sUnit[0] = static_unit(0);
+        sUnit[1] = static_unit(1);
+        sUnit[2] = static_unit(2);
+    }
+    if (is_loader) wait_vm<0>();  // the three speculative plan records
+    lds_barrier();                // sUnit[0..2] and plan records 0..2 visible
+    if (static_unit(0) < 0) {
         finish();
         return;
     }
-    int kvh = ucur / RH;
-    int t = ucur - kvh * RH;  // record index within the head
-    if constexpr (DB) {
-        // ======================= two tiles ahead, static units u(i) = my_base + i =======================
-        auto exists = [&](int i) { return i < n_static; };
-        auto head_of = [&](int i) { return (my_base + i) / RH; };
-        auto rec_of = [&](int i) { return (my_base + i) % RH; };
-        if (is_loader) {
-            issue_meta(rec_of(0), 0);
-            if (exists(1)) issue_meta(rec_of(1), 1);
-            if (exists(2)) issue_meta(rec_of(2), 2);
-            wait_vm<0>();
-        }
-        lds_barrier();
-        if (is_loader) {
-            load_rowoff(0);
-            issue_q(0, head_of(0));  // the first tile of a stream always opens a group
-            issue_k(head_of(0), 0);
-            issue_v(head_of(0), 0);
-            if (exists(1)) {
-                load_rowoff(1);
-                issue_k(head_of(1), 1);
-                issue_v(head_of(1), 1);
-            }
-            for (int i = 0; i < n_static; ++i) {
-                // A(i): everything of tile i (and the plan records up to i+2) has landed; tile i+1 may be in flight
-                if (exists(i + 1)) wait_vm<2 * LPT>(); else wait_vm<0>();
-                lds_barrier();
-                lds_barrier();  // C(i): QK^T(i) done (K stage i&1 free), Q(i) in registers, masks(i) consumed
-                if (exists(i + 1)) {
-                    const bool next_opens = (rec_of(i + 1) == 0) || (read_desc((i + 1) % 3)[2] != 0);
-                    if (next_opens) issue_q((i + 1) % 3, head_of(i + 1));
-                }
-                if (exists(i + 3)) issue_meta(rec_of(i + 3), i % 3);
-                if (exists(i + 2)) {
-                    load_rowoff((i + 2) % 3);
-                    issue_k(head_of(i + 2), i & 1);
-                }
-                lds_barrier();  // F(i)
-                lds_barrier();  // H(i): PV(i) done (V stage i&1 free)
-                if (exists(i + 2)) issue_v(head_of(i + 2), i & 1);
-            }
-            return;
-        }
-    } else {
-        if (is_loader) {
-            issue_meta(t, 0);
-            wait_vm<0>();
-        }
-        lds_barrier();
-        if (is_loader) {
-            load_rowoff(0);
-            issue_k(kvh, 0);
-            issue_q(0, kvh);  // the first tile of a stream always opens a group
-            if (unext >= 0) issue_meta(unext % RH, 1);
-            issue_v(kvh, 0);
 
-            // ---- loader loop: same barrier sequence as the compute waves below ---------------
-            for (int i = 0;; ++i) {
-                const int mb = i & 1;
-                const bool last = unext < 0;
-                const int kvh_next = last ? 0 : unext / RH;
-                const int t_next = last ? 0 : unext - kvh_next * RH;
-                wait_vm<LPT>();  // A: K(u) and plan record (u+1) landed
-                lds_barrier();
-                lds_barrier();   // C: compute waves are done with sK
-                if (!last) {
-                    load_rowoff(mb ^ 1);
-                    issue_k(kvh_next, 0);
-                }
-                if (last) wait_vm<0>(); else wait_vm<LPT>();  // F: V(u) landed
-                lds_barrier();
-                lds_barrier();   // H: compute waves are done with sV and sP; unit(i+2) published
-                if (last) break;
-                const int u2 = __builtin_amdgcn_readfirstlane(sUnit[(i + 2) & 3]);
-                const bool next_opens = (unext != ucur + 1) || (t_next == 0) || (read_desc(mb ^ 1)[2] != 0);
-                if (next_opens) issue_q(mb ^ 1, kvh_next);
-                if (u2 >= 0) issue_meta(u2 % RH, mb);
-                issue_v(kvh_next, 0);
-                ucur = unext;
-                unext = u2;
-                t = t_next;
-                kvh = kvh_next;
+    if (is_loader) {
+        // ============================ loader waves ============================
+        int u0 = static_unit(0), u1 = static_unit(1), u2 = static_unit(2);
+        // Ticket prefetch (loader 0, lane 0).  The unit of stream position q >= J is J*W + ticket; its ticket is
+        // requested after barrier H(q-5) (positions 3 and 4: in the prologue), as the LAST operation of that
+        // iteration, so the counted wait at A(q-4) may leave it outstanding and the wait at A(q-3) -- it is older
+        // than that tile's K/V -- retires it; it is read at C(q-3).  Two tickets are in flight, in the FIXED
+        // registers v200 / v201 (by parity of q), named in the asm text and declared clobbered, never bound to a
+        // C++ variable: hipcc would otherwise copy the variable (loop phi moves) while the atomic is still in
+        // flight and read a stale register -- the hardware has no interlock for that, only s_waitcnt.  The kernel
+        // uses ~130 VGPRs, so the allocator never touches v200/v201 (`make asm`, grep v20[01]).
+        const bool publisher = lw == 0;
+        // NTICKET counters, one cache line each, workgroup b uses counter b % NTICKET (its XCD under round-robin
+        // dispatch) and that counter's stripe of the dynamic units: one counter for all 256 workgroups serialises
+        // at ~80 atomics/us, which is slower than the tiles are consumed.
+        const int tk_lane = bid % NTICKET;
+        int* const tk_ptr = sp.sched + ticket_word(tk_lane);
+        auto fetch_ticket = [&](int q) {
+            if (l == 0) {
+                if (q & 1) asm volatile("global_atomic_add v201, %0, %1, off sc0" ::"v"(tk_ptr), "v"(1) : "memory", "v201");
+                else asm volatile("global_atomic_add v200, %0, %1, off sc0" ::"v"(tk_ptr), "v"(1) : "memory", "v200");
             }
-            return;
+        };
+        auto read_ticket = [&](int q) {
+            int t;
+            if (q & 1) asm volatile("v_readfirstlane_b32 %0, v201" : "=s"(t)::"memory");
+            else asm volatile("v_readfirstlane_b32 %0, v200" : "=s"(t)::"memory");
+            return t;
+        };
+        if (publisher && dynamic) {
+            if (J <= 3) fetch_ticket(3);
+            if (J <= 4) fetch_ticket(4);
         }
+        load_rowoff(0);
+        issue_q(0, head_of(u0));  // the first tile of a stream always opens a group
+        issue_k(head_of(u0), 0);
+        issue_v(head_of(u0), 0);
+        if (u1 >= 0) {
+            load_rowoff(1);
+            issue_k(head_of(u1), 1);
+            issue_v(head_of(u1), 1);
+        }
+        int head_prev = head_of(u0), run_prev = read_desc(0)[3];
+        int pos3_done = 0;     // publisher: the stream has ended (no unit(i+3) to look for)
+        bool tk_recent = false;  // publisher: a ticket was requested after barrier H(i-1)
+        for (int i = 0;; ++i) {
+            // A(i): everything of tile i (and the plan records up to i+2, and the ticket of position i+3) has landed
+            if (u1 < 0) wait_vm<0>();
+            else if (tk_recent) wait_vm<2 * LPT + 1>();
+            else wait_vm<2 * LPT>();
+            lds_barrier();
+            lds_barrier();  // C(i): QK^T(i) done (K stage i&1 free), Q(i) in registers, masks(i) consumed
+            if (publisher) {  // unit(i+3): static round or ticket; its plan record
+                int u3 = -1;
+                if (!pos3_done) {
+                    if (i + 3 < J) {
+                        u3 = static_unit(i + 3);
+                    } else if (dynamic) {
+                        u3 = J * W + read_ticket(i + 3) * NTICKET + tk_lane;
+                        if (u3 >= U) u3 = -1;
+                    }
+                    if (u3 < 0) pos3_done = 1;
+                }
+                if (l == 0) sUnit[(i + 3) & 7] = u3;
+                if (u3 >= 0) issue_meta(rec_of(u3), i % 3);
+            }
+            if (u1 >= 0) {
+                const int hn = head_of(u1), rn = read_desc((i + 1) % 3)[3];
+                if (hn != head_prev || rn != run_prev) issue_q((i + 1) % 3, hn);  // tile i+1 opens a group
+                head_prev = hn;
+                run_prev = rn;
+            }
+            if (u2 >= 0) {
+                load_rowoff((i + 2) % 3);
+                issue_k(head_of(u2), i & 1);
+            }
+            lds_barrier();  // F(i)
+            lds_barrier();  // H(i): PV(i) done (V stage i&1 free)
+            if (u2 >= 0) issue_v(head_of(u2), i & 1);
+            if (u1 < 0) break;
+            tk_recent = publisher && dynamic && !pos3_done && i + 5 >= J;
+            if (tk_recent) fetch_ticket(i + 5);
+            u0 = u1;
+            u1 = u2;
+            u2 = __builtin_amdgcn_readfirstlane(sUnit[(i + 3) & 7]);  // published at C(i)
+        }
+        return;
     }
 
-    // running state of the current group (query row c of this lane)
+    // ============================ compute waves ============================
     half8 qf[KS];
     float m_run = -INFINITY, l_run = 0.f;
     floatx16 o;
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[r] = 0.f;
-    int g_orow = 0;  // this lane's partial row of the open group, relative to kvh * G * rows
+    int g_orow = 0;   // this lane's partial row of the open group, relative to kvh * G * rows
+    int g_nv = 0;     // virtual rows of the open group
+    int ob_used = 0;  // outbox rows in use
     bool qvalid = false;
-
-    bool prev_adjacent = false;  // unit(i) == unit(i-1) + 1
+    int prev_head = -1, prev_run = -1;
+    int ucur = static_unit(0);
+    int unext = static_unit(1);
     for (int i = 0;; ++i) {
-        const int mb = DB ? i % 3 : (i & 1);                    // plan record slot of this unit
-        const int mn = DB ? (i + 1) % 3 : ((i & 1) ^ 1);        // ... of the next unit
-        const int stg = DB ? (i & 1) : 0;                       // K/V stage of this unit
+        const int mb = i % 3, mn = (i + 1) % 3;  // plan record slots of this unit and the next
+        const int stg = i & 1;                   // K/V stage of this unit
         const bool last = unext < 0;
+        const int kvh = head_of(ucur);
         const intx4 cur = read_desc(mb);
         const int orow_c = reinterpret_cast<const int32_t*>(meta(mb) + PLAN_OROW)[c];
-        const bool g_start = !prev_adjacent || (t == 0) || (cur[2] != 0);
+        // ticket-assigned tiles (positions >= J) never fold with their neighbours: which tiles meet in one workgroup
+        // depends on arrival order there, and the partials -- hence the output bits -- must not
+        const bool g_start = (i == 0) || i >= J || kvh != prev_head || cur[3] != prev_run;
 
-        // ---- A: K(u) and plan record (u+1) landed ------------------------------------
+        // ---- A: tile i, plan record (i+1) and unit(i+2) are there -------------------------
         stamp(i, 0);
         lds_barrier();
         stamp(i, 1);
-        if (g_start) {  // new group: its Q rows sit in the P buffer (staged by the loaders)
+        if (g_start) {  // new group: its Q rows were staged by the loaders
             g_orow = orow_c;
+            g_nv = cur[0];
             qvalid = c < cur[0];
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
@@ -436,24 +411,19 @@ __global__ __launch_bounds__(512, DB ? 2 : 4) void stage1_stream_kernel(StreamPa
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[r] = 0.f;
         }
-        const bool next_adjacent = !last && (unext == ucur + 1);
-        bool g_end = true;  // plan record (u+1) is visible now
-        if (next_adjacent) g_end = (t + 1 == RH) || (read_desc(mn)[2] != 0);
-        // a ticket for position i+2 (when it opens a new chunk) travels while this tile computes; compute
-        // waves issue no other loads, so the wait before barrier H costs nothing
-        int ticket = 0;
-        const bool need_ticket = guided && !last && (pub_u + 1 >= pub_end);
-        if (tid == 0 && need_ticket)  // asm: hipcc would otherwise wait for the returned value right here
-            asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(ticket) : "v"(sp.sched), "v"(1) : "memory");
+        const bool g_end = last || i + 1 >= J || head_of(unext) != kvh || read_desc(mn)[3] != cur[3];
+        const int u2 = __builtin_amdgcn_readfirstlane(sUnit[(i + 2) & 7]);  // published at C(i-1) (or the prologue)
 
         // ---- B: S^T for this wave's 32 keys, scale, mask, row max --------------------
         floatx16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        if (!(p.ablate & 1)) {  // profiling knob: 1 = skip QK^T, 2 = skip softmax/P, 4 = skip PV
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const half8 a = *reinterpret_cast<const half8*>(smem + SM::K_OFF + stg * SM::STAGE + krow_b + (kcol_b ^ (32 * ks)));
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qf[ks], acc, 0, 0, 0);
+            for (int ks = 0; ks < KS; ++ks) {
+                const half8 a = *reinterpret_cast<const half8*>(smem + SM::K_OFF + stg * SM::STAGE + krow_b + (kcol_b ^ (32 * ks)));
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qf[ks], acc, 0, 0, 0);
+            }
         }
         float s[16];
         float mx = -INFINITY;
@@ -478,36 +448,35 @@ __global__ __launch_bounds__(512, DB ? 2 : 4) void stage1_stream_kernel(StreamPa
         lds_barrier();
         stamp(i, 3);
 
-        // ---- D: (loaders) K(u+1) streams in while this tile's softmax and PV run ------------
-
         // ---- E: online softmax update, P (fp16) -> LDS -----------------------------------
         const float m_tile = fmaxf(fmaxf(sWmax[c], sWmax[MQ + c]), fmaxf(sWmax[2 * MQ + c], sWmax[3 * MQ + c]));
         const float m_new = fmaxf(m_run, m_tile);
         const float msafe = (m_new == -INFINITY) ? 0.f : m_new;
         const float alpha = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run - msafe);
         float sum = 0.f;
+        if (!(p.ablate & 2))
 #pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-            half4 p4;
+            for (int g4 = 0; g4 < 4; ++g4) {
+                half4 p4;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const _Float16 ph = (_Float16)__builtin_amdgcn_exp2f(s[4 * g4 + j] - msafe);
-                p4[j] = ph;
-                sum += (float)ph;
+                for (int j = 0; j < 4; ++j) {
+                    const _Float16 ph = (_Float16)__builtin_amdgcn_exp2f(s[4 * g4 + j] - msafe);
+                    p4[j] = ph;
+                    sum += (float)ph;
+                }
+                const int pos = (4 * w + g4) ^ (c & 15);
+                *reinterpret_cast<half4*>(sP + c * TILE + pos * 8 + 4 * h) = p4;
             }
-            const int pos = (4 * w + g4) ^ (c & 15);
-            *reinterpret_cast<half4*>(sP + c * TILE + pos * 8 + 4 * h) = p4;
-        }
         sum += __shfl_xor(sum, 32);
         if (h == 0) sWsum[w * MQ + c] = sum;
 
-        // ---- F: V(u) landed; P and row sums visible ----------------------------------------
+        // ---- F: V(i) landed; P and row sums visible ----------------------------------------
         stamp(i, 4);
         lds_barrier();
         stamp(i, 5);
 
         // ---- G: O^T = alpha * O^T + V^T P^T, 32 output columns per wave --------------------
-        {
+        if (!(p.ablate & 4)) {
             const float tile_sum = sWsum[c] + sWsum[MQ + c] + sWsum[2 * MQ + c] + sWsum[3 * MQ + c];
             l_run = l_run * alpha + tile_sum;
             m_run = m_new;
@@ -530,31 +499,30 @@ __global__ __launch_bounds__(512, DB ? 2 : 4) void stage1_stream_kernel(StreamPa
             }
         }
 
-        // ---- H: every wave is done with sV and sP; unit(i+2) published -------------------------
-        stamp(i, 6);
-        if (!DB && tid == 0 && !last) {
-            int u2;
-            if (!guided) {
-                u2 = (i + 2 < n_static) ? my_base + i + 2 : -1;
-            } else if (need_ticket) {
-                asm volatile("s_waitcnt vmcnt(0)" : "+v"(ticket)::"memory");
-                chunk_of(ticket, u2, pub_end);
-                pub_u = u2;
-            } else {
-                u2 = ++pub_u;
-            }
-            sUnit[(i + 2) & 3] = u2;
-        }
-        lds_barrier();
-        stamp(i, 7);
-
-        // ---- I: (loaders) plan record (u+2) and V(u+1) stream in during the next tile's QK^T / softmax
-
-        // ---- J: bookkeeping for the merge; partial out at the end of a group --------------------
+        // ---- J: bookkeeping for the merge; partial out at the end of a group.  BEFORE barrier H (the loaders
+        //      are parked there, their V burst has not been issued yet).  Small groups go to the LDS outbox.
         const int64_t head_rows = (int64_t)kvh * p.G * p.rows;
         if (!(p.ablate & 8) && !g_start && qvalid && w == 0 && h == 0)
             p.partial_lse[head_rows + orow_c] = -INFINITY;  // row folded into its group's partial
-        if (!(p.ablate & 16) && g_end && qvalid) {
+        const bool to_outbox = g_end && g_nv <= SM::OB_GROUP && !(p.ablate & 64);  // wave-uniform
+        if (to_outbox) {
+            if (qvalid) {
+                const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+                float* ob = reinterpret_cast<float*>(smem + SM::OB_OFF) + (ob_used + c) * D + 32 * w + 4 * h;
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    floatx4 v4 = {o[4 * g4] * inv, o[4 * g4 + 1] * inv, o[4 * g4 + 2] * inv, o[4 * g4 + 3] * inv};
+                    *reinterpret_cast<floatx4*>(ob + 8 * g4) = v4;
+                }
+                if (w == 0 && h == 0) {
+                    reinterpret_cast<float*>(smem + SM::OB_LSE_OFF)[ob_used + c] =
+                        (l_run > 0.f) ? (m_run + __builtin_amdgcn_logf(l_run)) * LN2 : -INFINITY;
+                    reinterpret_cast<int32_t*>(smem + SM::OB_DST_OFF)[ob_used + c] = (int32_t)(head_rows + g_orow);
+                }
+            }
+            ob_used += g_nv;
+        }
+        if (!(p.ablate & 16) && g_end && qvalid && !to_outbox) {
             const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
             const int64_t prow_idx = head_rows + g_orow;
             float* po = p.partial_o + prow_idx * D + 32 * w + 4 * h;
@@ -566,15 +534,29 @@ __global__ __launch_bounds__(512, DB ? 2 : 4) void stage1_stream_kernel(StreamPa
             if (w == 0 && h == 0)
                 p.partial_lse[prow_idx] = (l_run > 0.f) ? (m_run + __builtin_amdgcn_logf(l_run)) * LN2 : -INFINITY;
         }
+
+        // ---- H: every wave is done with sV and sP -------------------------
+        stamp(i, 6);
+        lds_barrier();
+        stamp(i, 7);
+        // outbox flush: when another small group might not fit, and at the end of the stream (the loaders are
+        // done then and the FIFO is empty).  Reads here, next outbox writes after barriers A..F of tile i+1.
+        if (ob_used > SM::OB_ROWS - SM::OB_GROUP || (last && ob_used > 0)) {
+            if (!(p.ablate & 16)) {
+                const int32_t* dst = reinterpret_cast<const int32_t*>(smem + SM::OB_DST_OFF);
+                for (int r = w; r < ob_used; r += 4) {
+                    const floatx2 v2 = *reinterpret_cast<const floatx2*>(smem + SM::OB_OFF + r * D * 4 + l * 8);
+                    *reinterpret_cast<floatx2*>(p.partial_o + (int64_t)dst[r] * D + 2 * l) = v2;
+                }
+                if (w == 0 && l < ob_used) p.partial_lse[dst[l]] = reinterpret_cast<const float*>(smem + SM::OB_LSE_OFF)[l];
+            }
+            ob_used = 0;
+        }
         if (last) break;
-        prev_adjacent = next_adjacent;
+        prev_head = kvh;
+        prev_run = cur[3];
         ucur = unext;
-        if constexpr (DB)
-            unext = (i + 2 < n_static) ? my_base + i + 2 : -1;
-        else
-            unext = __builtin_amdgcn_readfirstlane(sUnit[(i + 2) & 3]);
-        kvh = ucur / RH;
-        t = ucur - kvh * RH;
+        unext = u2;
     }
     finish();
 }
@@ -595,7 +577,7 @@ struct UnitList {   // all int32, capacity `cap` each
     int32_t* src;   // Flatten: block index; Node: entry index
     int32_t* aux;   // Flatten: 0;           Node: 128-slot tile index within the entry
     int32_t* pass;  // 32-row pass of the unit's virtual query rows
-    int32_t* flags; // bit 0: opens a run (query list differs from the previous unit's)
+    int32_t* flags; // bit 0: opens a run (query list differs from the previous unit's); bits 1..: unit index of the run's first unit
     int32_t* prow;  // first partial row of the unit's tile
 };
 
@@ -625,19 +607,21 @@ __global__ __launch_bounds__(256) void flatten_units_kernel(const int64_t* block
             int tb = ta + 1;
             while (tb < NB && !sOpen[tb]) ++tb;
             const int np = sPass[ta];
-            for (int ps = 0; ps < np; ++ps)
+            for (int ps = 0; ps < np; ++ps) {
+                const int first = r;
                 for (int t = ta; t < tb && r < cap; ++t, ++r) {
                     ul.src[r] = t;
                     ul.aux[r] = 0;
                     ul.pass[r] = ps;
-                    ul.flags[r] = (t == ta) ? 1 : 0;
+                    ul.flags[r] = (first << 1) | ((t == ta) ? 1 : 0);
                     ul.prow[r] = (int)block_q_offset[t];
                 }
+            }
             ta = tb;
         }
         hdr[0] = r;
         sched[0] = 0;
-        sched[1] = 0;
+        for (int k = 0; k < NTICKET; ++k) sched[ticket_word(k)] = 0;
     }
 }
 
@@ -663,7 +647,7 @@ __global__ __launch_bounds__(128) void flatten_records_kernel(const int64_t* blo
             desc[0] = 0;
             desc[1] = 0;
             desc[2] = 1;
-            desc[3] = 0;
+            desc[3] = -1;
         }
         return;
     }
@@ -696,7 +680,7 @@ __global__ __launch_bounds__(128) void flatten_records_kernel(const int64_t* blo
         desc[0] = nv;
         desc[1] = prow;
         desc[2] = ul.flags[r] & 1;
-        desc[3] = len;
+        desc[3] = ul.flags[r] >> 1;  // run id: tiles with equal ids share one query list and may fold
     }
 }
 
@@ -713,19 +697,21 @@ __global__ __launch_bounds__(256) void node_units_kernel(const int64_t* node_kv_
             const int nt = (int)((node_kv_len[e] + TILE - 1) / TILE);
             const int ql = (int)node_q_len[e];
             const int np = (ql * G + MQ - 1) / MQ;
-            for (int ps = 0; ps < np; ++ps)
+            for (int ps = 0; ps < np; ++ps) {
+                const int first = r;
                 for (int tt = 0; tt < nt && r < cap; ++tt, ++r) {
                     ul.src[r] = e;
                     ul.aux[r] = tt;
                     ul.pass[r] = ps;
-                    ul.flags[r] = (tt == 0) ? 1 : 0;
+                    ul.flags[r] = (first << 1) | ((tt == 0) ? 1 : 0);
                     ul.prow[r] = rowbase + tt * ql;
                 }
+            }
             rowbase += nt * ql;
         }
         hdr[0] = r;
         sched[0] = 0;
-        sched[1] = 0;
+        for (int k = 0; k < NTICKET; ++k) sched[ticket_word(k)] = 0;
     }
 }
 
@@ -750,7 +736,7 @@ __global__ __launch_bounds__(128) void node_records_kernel(const int64_t* node_k
             desc[0] = 0;
             desc[1] = 0;
             desc[2] = 1;
-            desc[3] = 0;
+            desc[3] = -1;
         }
         return;
     }
@@ -780,7 +766,7 @@ __global__ __launch_bounds__(128) void node_records_kernel(const int64_t* node_k
         desc[0] = nv;
         desc[1] = prow;
         desc[2] = ul.flags[r] & 1;
-        desc[3] = len;
+        desc[3] = ul.flags[r] >> 1;  // run id: tiles with equal ids share one query list and may fold
     }
 }
 

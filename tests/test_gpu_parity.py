@@ -312,3 +312,41 @@ def test_full_size_properties_northstar_tree():
         s = torch.einsum("hd,hsd->hs", q[r].float(), k) / 128 ** 0.5
         ref = torch.einsum("hs,hsd->hd", torch.softmax(s, dim=-1), v)
         assert (o1[r].float() - ref).abs().max().item() < TOL
+
+
+@pytest.mark.parametrize("dyn", ["0", "30", "100"])
+def test_ticket_tail_matches_static_walk(dyn, monkeypatch):
+    """The streaming kernel hands the last DEFT_STREAM_DYN % of every workgroup's tiles out by atomic ticket.  The
+    Which workgroup computes a ticket tile depends on arrival order, the attention output must not: 4k x 32 tree with 200-token branches (82 tiles per head = 10.25 per workgroup), every share
+    against the static walk and three leaves against torch fp32 sequential attention."""
+    from deft_amd.utils.workloads import Workload, build_tree
+
+    w = Workload("t", "llama2-7b", "flatten", "few_shot", 4096, 32, 200)
+    tree, pool = build_tree(w, 1, "cuda")
+    md = deft_amd.TreeMetadata.from_tree_cache(tree)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    pool._storage.normal_(generator=g)
+    q = torch.randn((32, 32, 128), dtype=torch.float16, device="cuda", generator=g)
+    kb, vb = pool.get_key_buffer(0), pool.get_value_buffer(0)
+    monkeypatch.setenv("DEFT_STREAM_DYN", "0")
+    o_static = torch.zeros_like(q)
+    deft_amd.tree_attention_subtree_fwd(q, kb, vb, o_static, *_flatten_args(md))
+    torch.cuda.synchronize()
+    monkeypatch.setenv("DEFT_STREAM_DYN", dyn)
+    outs = []
+    for _ in range(3):
+        o = torch.zeros_like(q)
+        deft_amd.tree_attention_subtree_fwd(q, kb, vb, o, *_flatten_args(md))
+        outs.append(o)
+    torch.cuda.synchronize()
+    for o in outs:
+        assert (o.float() - o_static.float()).abs().max().item() < TOL_EXACT
+        assert torch.equal(o, outs[0])  # ticket-assigned tiles never fold: bit-identical run to run
+    leaves = sorted(tree.leaves.values(), key=lambda n: n.id)
+    for r in (0, 17, 31):
+        slots = torch.tensor(tree.leaf_path_slots(leaves[r]), device="cuda")
+        k = kb[slots].float().transpose(0, 1)
+        v = vb[slots].float().transpose(0, 1)
+        s = torch.einsum("hd,hsd->hs", q[r].float(), k) / 128 ** 0.5
+        ref = torch.einsum("hs,hsd->hd", torch.softmax(s, dim=-1), v)
+        assert (outs[-1][r].float() - ref).abs().max().item() < TOL

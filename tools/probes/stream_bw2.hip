@@ -8,7 +8,7 @@ __device__ __forceinline__ void dma16(const void* g, unsigned lds) {
 }
 // stage index s of a workgroup: tile = s / (2*128/rows) ..., each tile has 128/rows K-stages then 128/rows V-stages
 template <int NW, int ROWS, int R>
-__global__ __launch_bounds__(NW * 64) void k(const char* base, unsigned* out, int ntile, int nhead) {
+__global__ __launch_bounds__(NW * 64) void k(const char* base, unsigned* out, int ntile, int nhead, int order) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63;
     constexpr int SPT = 2 * 128 / ROWS;          // stages per tile
@@ -16,10 +16,15 @@ __global__ __launch_bounds__(NW * 64) void k(const char* base, unsigned* out, in
     static_assert(IPS >= 1, "");
     const long long U = (long long)ntile * nhead;
     const int u0 = (int)(U * blockIdx.x / gridDim.x), u1 = (int)(U * (blockIdx.x + 1) / gridDim.x);
-    const int S = (u1 - u0) * SPT;
+    // order 1: interleaved walk (unit j of workgroup b = global chunk j*grid + b in tile-major / head-fastest order:
+    // the whole chip advances as ONE front, every workgroup stays on one head when grid % nhead == 0)
+    const int nmine = order ? (int)((U - blockIdx.x + gridDim.x - 1) / gridDim.x) : (u1 - u0);
+    const int S = nmine * SPT;
     auto issue = [&](int s) {
-        const int u = u0 + s / SPT, part = s % SPT;
-        const int head = u / ntile, tile = u % ntile;
+        const int part = s % SPT;
+        int head, tile;
+        if (order) { const int c = (s / SPT) * gridDim.x + blockIdx.x; tile = c / nhead; head = c % nhead; }
+        else { const int u = u0 + s / SPT; head = u / ntile; tile = u % ntile; }
         const int isv = part >= SPT / 2, sub = part % (SPT / 2);
 #pragma unroll
         for (int i = 0; i < IPS; ++i) {
@@ -56,20 +61,20 @@ __global__ __launch_bounds__(NW * 64) void k(const char* base, unsigned* out, in
     if (acc == 0x12345678u) out[0] = acc;
 }
 template <int NW, int ROWS, int R>
-void run(const char* d, unsigned* o, size_t layer, int layers, int ntile, int nhead, int wgs) {
+void run(const char* d, unsigned* o, size_t layer, int layers, int ntile, int nhead, int wgs, int order = 0) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const int lds = R * ROWS * 256;
     hipFuncSetAttribute((const void*)k<NW, ROWS, R>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     float best = 1e9;
     for (int rep = 0; rep < 3; ++rep) {
         hipEventRecord(e0);
-        for (int l2 = 0; l2 < layers; ++l2) hipLaunchKernelGGL((k<NW, ROWS, R>), dim3(wgs), dim3(NW * 64), lds, 0, d + l2 * layer, o, ntile, nhead);
+        for (int l2 = 0; l2 < layers; ++l2) hipLaunchKernelGGL((k<NW, ROWS, R>), dim3(wgs), dim3(NW * 64), lds, 0, d + l2 * layer, o, ntile, nhead, order);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         if (rep && ms < best) best = ms;
     }
     double bytes = (double)ntile * nhead * 65536 * layers;
-    printf("waves %d rows/stage %3d ring %d (LDS %3d KB, in flight <= %3d KB) wgs %d: %.1f us/layer %.2f TB/s (%s)\n", NW, ROWS, R,
+    printf("order %d waves %d rows/stage %3d ring %d (LDS %3d KB, in flight <= %3d KB) wgs %d: %.1f us/layer %.2f TB/s (%s)\n", order, NW, ROWS, R,
            lds / 1024, (R - 1) * ROWS * 256 / 1024, wgs, best / layers * 1e3, bytes / (best * 1e-3) / 1e12, hipGetErrorString(hipGetLastError()));
 }
 int main() {
@@ -90,5 +95,10 @@ int main() {
     run<4, 64, 4>(d, o, layer, layers, ntile, nhead, 512);    // 2 WGs/CU x 64 KB ring of 16 KB stages
     run<4, 64, 4>(d, o, layer, layers, ntile, nhead, 768);    // 3 WGs/CU? (64 KB each = 192: only 2 fit)
     run<4, 32, 6>(d, o, layer, layers, ntile, nhead, 768);    // 3 WGs/CU x 48 KB
+    run<4, 128, 3>(d, o, layer, layers, ntile, nhead, 256, 1);
+    run<4, 128, 5>(d, o, layer, layers, ntile, nhead, 256, 1);
+    run<8, 128, 5>(d, o, layer, layers, ntile, nhead, 256, 1);
+    run<4, 128, 2>(d, o, layer, layers, ntile, nhead, 512, 1);
+    run<4, 64, 4>(d, o, layer, layers, ntile, nhead, 512, 1);
     return 0;
 }
