@@ -27,7 +27,7 @@ sys.path.insert(0, ROOT)
 
 import deft_amd  # noqa: E402  (fails loudly if libdeft_amd.so is missing)
 from deft_amd._lib import check, lib  # noqa: E402
-from deft_amd.utils.workloads import GEOMETRY, WORKLOADS, Workload, algorithmic_bytes, build_tree  # noqa: E402
+from deft_amd.utils.workloads import GEOMETRY, WORKLOADS, Workload, algorithmic_bytes, build_forest, build_tree  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 
@@ -39,10 +39,14 @@ class Bench:
         self.layers = layers
         self.device = device
         t0 = time.perf_counter()
-        self.tree, self.pool = build_tree(w, layers, str(device))
+        if w.trees > 1:  # a batch of independent trees in one pool, one operator call per layer
+            self.forest, self.pool = build_forest(w, w.trees, layers, str(device))
+        else:
+            tree, self.pool = build_tree(w, layers, str(device))
+            self.forest = deft_amd.Forest([tree])
         self.tree_build_s = time.perf_counter() - t0
         t0 = time.perf_counter()
-        self.md = deft_amd.TreeMetadata.from_tree_cache(self.tree)
+        self.md = self.forest.metadata()
         torch.cuda.synchronize(device)
         self.metadata_build_ms = (time.perf_counter() - t0) * 1e3
         self.nq = self.md.query_num
@@ -55,7 +59,7 @@ class Bench:
         self.q = torch.randn((layers, self.nq, self.Hq * self.D), dtype=torch.float16, device=device, generator=g)
         self.k_new = torch.randn((layers, self.nq, self.Hkv * self.D), dtype=torch.float16, device=device, generator=g)
         self.v_new = torch.randn((layers, self.nq, self.Hkv * self.D), dtype=torch.float16, device=device, generator=g)
-        leaves = sorted(self.tree.leaves.values(), key=lambda n: n.id)
+        leaves = [lf for t in self.forest.trees for lf in sorted(t.leaves.values(), key=lambda n: n.id)]
         loc = torch.tensor([lf.kv_indices[-1] for lf in leaves], dtype=torch.int32, device=device)
         self.updater = deft_amd.KVCacheUpdater(True, self.pool, loc, None, False)
         mode = deft_amd.forward_mode_from_cli(w.mode)
@@ -148,27 +152,31 @@ class Bench:
             torch.cuda.current_stream(self.device).wait_stream(side)
         except Exception:
             graph = None
-        sweeps = []
-        for r in range(reps + 1):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(stream)
+        def sweep():
             if graph is not None:
                 graph.replay()
             else:
                 launch_all()
+
+        for _ in range(5):  # warm-up sweeps: clocks and TLBs settle within the first few (first sweeps are ~1 us slower)
+            sweep()
+        sweeps = []
+        for r in range(reps):  # `reps` groups of 4 sweeps, back to back inside one event pair each
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for _ in range(4):
+                sweep()
             e1.record(stream)
             torch.cuda.synchronize(self.device)
-            if r > 0:  # first sweep is warm-up
-                sweeps.append(e0.elapsed_time(e1) * 1e3 / self.layers)  # us per launch
+            sweeps.append(e0.elapsed_time(e1) * 1e3 / (4 * self.layers))  # us per launch
         sweeps.sort()
         return {"mean_us": sum(sweeps) / len(sweeps), "median_us": sweeps[len(sweeps) // 2],
-                "launches": len(sweeps) * self.layers, "launch": "hipgraph" if graph is not None else "eager"}
+                "launches": len(sweeps) * 4 * self.layers, "launch": "hipgraph" if graph is not None else "eager"}
 
     def cpu_baseline(self, budget_s: float):
         from oracle.cpu_baseline import time_cpu_baseline  # the checker/baseline, never the product path
 
-        leaves = sorted(self.tree.leaves.values(), key=lambda n: n.id)
-        paths = [self.tree.leaf_path_slots(lf) for lf in leaves]
+        paths = self.forest.leaf_paths()
         q = self.q[0].view(self.nq, self.Hq, self.D).float().cpu()
         kv = self.pool.kv_data[0].float().cpu()
         return time_cpu_baseline(q, kv, paths, self.layers, budget_s=budget_s)
@@ -267,7 +275,7 @@ def main():
         if w.kind == "few_shot" and args.branch_len is None:
             variants += [(f"{w.name}_len1", Workload(**{**w.__dict__, "branch_len": 1})),
                          (f"{w.name}_len400", Workload(**{**w.__dict__, "branch_len": 400}))]
-        for name in ("fewshot_1kx32", "medusa64_node", "tot50_4k", "forest_8kx8"):
+        for name in ("fewshot_1kx32", "medusa64_node", "tot50_4k", "forest_8kx8_single", "forest_8kx8"):
             if name != w.name:
                 variants.append((name, WORKLOADS[name]))
         del b.graph
@@ -282,7 +290,7 @@ def main():
                 s1v = bv.time_stage1(reps=1)
                 av = bv.algorithmic_bytes_per_layer()
                 extras[name] = {
-                    "model": wv.model, "mode": wv.mode, "nq": bv.nq, "kv_tokens": bv.n_kv,
+                    "model": wv.model, "mode": wv.mode, "trees": wv.trees, "nq": bv.nq, "kv_tokens": bv.n_kv,
                     "us_per_step": round(dtv / n * 1e6, 1), "us_per_layer": round(dtv / n * 1e6 / bv.layers, 2),
                     "tokens_per_s": round(bv.nq / (dtv / n), 1),
                     "step_GBps": round(av * bv.layers / (dtv / n) / 1e9, 1),
@@ -312,7 +320,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": f"{w.model} DeFT-{w.mode}, {w.kind} tree: {w.prefix}-token shared prefix x {w.width} "
                                    f"branches x {w.branch_len} tokens, paged KV, {layers} layers "
-                                   f"(Hq={Hq}, Hkv={Hkv}, D={D}); one independent tree per GPU",
+                                   f"(Hq={Hq}, Hkv={Hkv}, D={D}); {w.trees} independent tree(s) per GPU",
                        "name": w.name, "queries": b.nq, "unique_kv_tokens": b.n_kv, "layers": layers,
                        "blocks": int(b.md.block_q_cnts.shape[0]), "partial_rows": int(b.md.block_q.shape[0]),
                        "launch": b.launch},

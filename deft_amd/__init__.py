@@ -6,6 +6,7 @@ if it has not been built; nothing here falls back to PyTorch or the CPU.
 """
 from ._lib import LIB_PATH, DeftLibraryError, lib  # noqa: F401
 from .deft_attention import DeFTAttention  # noqa: F401
+from .forest import Forest, concat_metadata_host  # noqa: F401
 from .forward_mode import ForwardMode, InputMetadata, forward_mode_from_cli  # noqa: F401
 from .memory_pool import ReqToTokenPool, TokenToKVPool  # noqa: F401
 from .tree_attention import kv_append, tree_attention_fwd, tree_attention_subtree_fwd  # noqa: F401

@@ -36,6 +36,7 @@ class Workload:
     prefix: int
     width: int = 32
     branch_len: int = 1
+    trees: int = 1  # independent trees per GPU, decoded as one batch (deft_amd.Forest)
 
 
 WORKLOADS: Dict[str, Workload] = {
@@ -47,8 +48,10 @@ WORKLOADS: Dict[str, Workload] = {
     "medusa64_node": Workload("medusa64_node", "llama2-7b", "node", "medusa", 1016, 64, 1),
     # configs[3]: Llama-3-8B ToT tree, 4k prefix, 50 nodes, DeFT-Flatten
     "tot50_4k": Workload("tot50_4k", "llama3-8b", "flatten", "tot", 4096),
-    # configs[4]: one of the 64 independent 8k-prefix trees (8 branches x 64 tokens), Llama-3-8B
-    "forest_8kx8": Workload("forest_8kx8", "llama3-8b", "flatten", "few_shot", 8192, 8, 64),
+    # configs[4]: 64 independent 8k-prefix trees (8 branches x 64 tokens) over 8 GPUs, Llama-3-8B:
+    # one GPU's share = 8 trees, decoded as ONE batch; and a single tree of the same shape for comparison
+    "forest_8kx8": Workload("forest_8kx8", "llama3-8b", "flatten", "few_shot", 8192, 8, 64, 8),
+    "forest_8kx8_single": Workload("forest_8kx8_single", "llama3-8b", "flatten", "few_shot", 8192, 8, 64),
 }
 
 
@@ -62,12 +65,16 @@ def tree_tokens(w: Workload) -> int:
     raise ValueError(w.kind)
 
 
-def build_tree(w: Workload, layers: int, device: str, extra_slots: int = 256):
-    """Returns (tree, kv_pool).  The pool holds `layers` distinct per-layer KV arrays."""
+def build_tree(w: Workload, layers: int, device: str, extra_slots: int = 256, pools=None):
+    """Returns (tree, kv_pool).  The pool holds `layers` distinct per-layer KV arrays.
+    `pools` = (req_pool, kv_pool) grows the tree inside existing pools (forests)."""
     Hq, Hkv, D, _ = GEOMETRY[w.model]
-    size = tree_tokens(w) + extra_slots
-    req = ReqToTokenPool(max(w.width, 64) + 8, size + 8, device=device)
-    pool = TokenToKVPool(size, torch.float16, Hkv, D, layers, device=device)
+    if pools is None:
+        size = tree_tokens(w) + extra_slots
+        req = ReqToTokenPool(max(w.width, 64) + 8, size + 8, device=device)
+        pool = TokenToKVPool(size, torch.float16, Hkv, D, layers, device=device)
+    else:
+        req, pool = pools
     tree = TreeCache(torch.float16, Hkv, D, layers, req, pool, None, True, False)
     tree.init_prompt(torch.arange(1, w.prefix + 1, dtype=torch.int32))
 
@@ -97,3 +104,17 @@ def build_tree(w: Workload, layers: int, device: str, extra_slots: int = 256):
 def algorithmic_bytes(n_kv_tokens: int, nq: int, Hq: int, Hkv: int, D: int) -> int:
     """unique KV read once (K and V, fp16) + Q read + O written."""
     return 4 * n_kv_tokens * Hkv * D + 4 * nq * Hq * D
+
+
+def build_forest(w: Workload, n_trees: int, layers: int, device: str, extra_slots: int = 256):
+    """`n_trees` independent trees of shape `w` in ONE pool (BASELINE configs[4]: a GPU's share of the 64-tree
+    batch).  Trees are built one after the other, so each tree's prompt is contiguous and its decode-step slots
+    interleave across its own leaves only.  Returns (Forest, kv_pool)."""
+    from ..forest import Forest
+
+    Hq, Hkv, D, _ = GEOMETRY[w.model]
+    size = n_trees * tree_tokens(w) + extra_slots
+    req = ReqToTokenPool(n_trees * (max(w.width, 64) + 8), tree_tokens(w) + 16, device=device)
+    pool = TokenToKVPool(size, torch.float16, Hkv, D, layers, device=device)
+    trees = [build_tree(w, layers, device, pools=(req, pool))[0] for _ in range(n_trees)]
+    return Forest(trees), pool

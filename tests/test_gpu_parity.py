@@ -350,3 +350,47 @@ def test_ticket_tail_matches_static_walk(dyn, monkeypatch):
         s = torch.einsum("hd,hsd->hs", q[r].float(), k) / 128 ** 0.5
         ref = torch.einsum("hs,hsd->hd", torch.softmax(s, dim=-1), v)
         assert (outs[-1][r].float() - ref).abs().max().item() < TOL
+
+
+@pytest.mark.parametrize("mode", ["flatten", "node"])
+@pytest.mark.parametrize("geom", [(8, 2, 128), (4, 4, 128)])
+def test_forest_batch_equals_its_trees_one_by_one(geom, mode):
+    """Several trees in one pool, ONE operator call over the concatenated metadata (deft_amd.Forest) against
+    fp64 sequential attention per leaf (oracle) and against each tree attended on its own."""
+    Hq, Hkv, D = geom
+    names = ["multilevel", "wide40", "chain_300", "edge_fill", "spec_mock"]
+    req = deft_amd.ReqToTokenPool(256, 4096, device="cuda")
+    pool = deft_amd.TokenToKVPool(8192, torch.float16, Hkv, D, 1, device="cuda")
+    trees = []
+    for n in names:
+        t = deft_amd.TreeCache(torch.float16, Hkv, D, 1, req, pool, None, True, False)
+        SCENARIOS[n].script(t, lambda k: torch.arange(1, k + 1, dtype=torch.int32))
+        trees.append(t)
+    forest = deft_amd.Forest(trees)
+    md = forest.metadata()
+    g = torch.Generator(device="cuda").manual_seed(11)
+    pool._storage.normal_(generator=g)
+    q = torch.randn((md.query_num, Hq, D), dtype=torch.float16, device="cuda", generator=g)
+    kb, vb = pool.get_key_buffer(0), pool.get_value_buffer(0)
+
+    def attend(m, qq):
+        o = torch.full_like(qq, float("nan"))
+        if mode == "flatten":
+            deft_amd.tree_attention_subtree_fwd(qq, kb, vb, o, *_flatten_args(m))
+        else:
+            deft_amd.tree_attention_fwd(qq, kb, vb, o, m.node_kv, m.node_kv_offset, m.node_kv_len, m.node_q,
+                                        m.node_q_offset, m.node_q_len)
+        return o
+
+    o = attend(md, q)
+    torch.cuda.synchronize()
+    assert torch.isfinite(o.float()).all()
+    kv_np = pool.kv_data[0].cpu().numpy()
+    truth = oa.sequential_truth(q.cpu().numpy(), kv_np, forest.leaf_paths())
+    assert max_abs(o.cpu().numpy(), truth) < TOL_EXACT
+    for t, tree in enumerate(trees):
+        m1 = deft_amd.TreeMetadata.from_tree_cache(tree)
+        lo = md.q_bases[t]
+        o1 = attend(m1, q[lo : lo + m1.query_num].contiguous())
+        torch.cuda.synchronize()
+        assert (o1.float() - o[lo : lo + m1.query_num].float()).abs().max().item() < TOL_EXACT

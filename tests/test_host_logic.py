@@ -111,3 +111,58 @@ def test_operators_refuse_cpu_tensors():
     i64 = torch.zeros(128, dtype=torch.int64)
     with pytest.raises(deft_amd.DeftLibraryError, match="no CPU path"):
         deft_amd.tree_attention_subtree_fwd(q, kv, kv, q.clone(), 128, i64[:1], i64[:1], i64[:1], i64, i64, i64[:1])
+
+
+def test_forest_metadata_is_the_offset_concatenation_of_its_trees():
+    """deft_amd.Forest: several trees in one pool -> one TreeMetadata whose arrays are the per-tree arrays one
+    after the other, query rows / offsets shifted per tree.  Checked against each tree's own
+    metadata (itself pinned bit-exact to the reference goldens above)."""
+    names = ["multilevel", "wide40", "chain_300", "edge_fill"]
+    req = deft_amd.ReqToTokenPool(256, 4096, device="cpu")
+    pool = deft_amd.TokenToKVPool(8192, torch.float16, 1, 8, 1, device="cpu")
+    trees = []
+    for n in names:
+        t = deft_amd.TreeCache(torch.float16, 1, 8, 1, req, pool, None, True, False)
+        SCENARIOS[n].script(t, lambda k: torch.arange(1, k + 1, dtype=torch.int32))
+        trees.append(t)
+    forest = deft_amd.Forest(trees)
+    md = forest.metadata(device="cpu")
+    singles = [deft_amd.TreeMetadata.from_tree_cache(t, device="cpu") for t in trees]
+    assert md.query_num == sum(s.query_num for s in singles) == forest.query_num
+    assert md.node_num == sum(s.node_num for s in singles)
+    assert md.total_kv_len == sum(s.total_kv_len for s in singles)
+    qb = nq = nkv = bq = 0
+    pos = {k: 0 for k in MD_FIELDS}
+    for t, s in enumerate(singles):
+        assert md.q_bases[t] == qb
+        for k in MD_FIELDS:
+            a = getattr(s, k).numpy().copy()
+            if k in ("node_q", "block_q"):
+                a += qb
+            elif k == "node_q_offset":
+                a += nq
+            elif k == "node_kv_offset":
+                a += nkv
+            elif k == "block_q_offset":
+                a += bq
+            got = getattr(md, k).numpy()[pos[k] : pos[k] + len(a)]
+            assert np.array_equal(got, a), (t, k)
+            pos[k] += len(a)
+        for leaf, qi in s.leaf_to_q.items():
+            assert md.leaf_to_q[(t, leaf)] == qb + qi
+        qb += s.query_num
+        nq += len(s.node_q)
+        nkv += len(s.node_kv)
+        bq += len(s.block_q)
+    for k in MD_FIELDS:
+        assert pos[k] == len(getattr(md, k))
+    # a forest step hands out one slot per live leaf, in batch query order
+    before = [len(l.kv_indices) for t in trees for l in sorted(t.leaves.values(), key=lambda n: n.id)]
+    for t in trees:
+        for leaf in t.leaves.values():
+            leaf.append_token(9)
+    upd = forest.alloc()
+    leaves = [l for t in trees for l in sorted(t.leaves.values(), key=lambda n: n.id)]
+    assert upd.cache_loc.tolist() == [l.kv_indices[-1] for l in leaves]
+    assert [len(l.kv_indices) for l in leaves] == [b + 1 for b in before]
+    assert len(forest.leaf_paths()) == forest.query_num

@@ -8,13 +8,13 @@ from bench import Bench
 from deft_amd.utils.workloads import WORKLOADS, Workload, GEOMETRY
 ap = argparse.ArgumentParser()
 ap.add_argument("--workload", default="northstar_4kx32")
-ap.add_argument("--branch-len", type=int, default=200)
+ap.add_argument("--branch-len", type=int, default=None)
 ap.add_argument("--reps", type=int, default=6)
 ap.add_argument("--rounds", type=int, default=3)
 ap.add_argument("knobs", nargs="+")
 a = ap.parse_args()
 w = WORKLOADS[a.workload]
-if w.kind == "few_shot":
+if a.branch_len is not None:
     w = Workload(**{**w.__dict__, "branch_len": a.branch_len})
 b = Bench(w, GEOMETRY[w.model][3], torch.device("cuda", 0)); b.prepare(use_graph=False)
 names = [k.split("=")[0] for k in a.knobs]

@@ -10,7 +10,7 @@ from deft_amd.utils.workloads import WORKLOADS, Workload, GEOMETRY
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--workload", default="northstar_4kx32")
-ap.add_argument("--branch-len", type=int, nargs="*", default=[200])
+ap.add_argument("--branch-len", type=int, nargs="*", default=[None])
 ap.add_argument("--steps", type=int, default=30)
 ap.add_argument("--tag", default="")
 args = ap.parse_args()
@@ -18,8 +18,9 @@ dev = torch.device("cuda", 0)
 out = {"tag": args.tag, "ablate": os.environ.get("DEFT_STAGE1_ABLATE", "0"), "variant": os.environ.get("DEFT_STAGE1_VARIANT", "")}
 for bl in args.branch_len:
     w = WORKLOADS[args.workload]
-    if w.kind == "few_shot":
+    if bl is not None:
         w = Workload(**{**w.__dict__, "branch_len": bl})
+    bl = w.branch_len
     b = Bench(w, GEOMETRY[w.model][3], dev)
     b.prepare(use_graph=True)
     dt = run_timed(b, args.steps, 5, False)
