@@ -75,6 +75,21 @@ lib.deft_md_fetch.argtypes = [_i64] + [_vp] * 13
 lib.deft_md_fetch.restype = C.c_int
 lib.deft_md_free.argtypes = [_i64]
 lib.deft_md_free.restype = C.c_int
+lib.deft_tree_create.argtypes = []
+lib.deft_tree_create.restype = _i64
+lib.deft_tree_free.argtypes = [_i64]
+lib.deft_tree_add_node.argtypes = [_i64, _i64, _i64]
+lib.deft_tree_remove_node.argtypes = [_i64, _i64]
+lib.deft_tree_set_leaf.argtypes = [_i64, _i64, C.c_int]
+lib.deft_tree_append_slots.argtypes = [_i64, C.c_int, _vp, _vp]
+lib.deft_tree_extend_node.argtypes = [_i64, _i64, C.c_int, _vp]
+lib.deft_tree_clear_node_kv.argtypes = [_i64, _i64]
+lib.deft_tree_stats.argtypes = [_i64, _vp]
+lib.deft_tree_build_md.argtypes = [_i64, C.c_int, C.c_int, C.c_int]
+lib.deft_tree_build_md.restype = _i64
+for _f in ("deft_tree_free", "deft_tree_add_node", "deft_tree_remove_node", "deft_tree_set_leaf", "deft_tree_append_slots",
+           "deft_tree_extend_node", "deft_tree_clear_node_kv", "deft_tree_stats"):
+    getattr(lib, _f).restype = C.c_int
 
 EXPORTED = (
     "deft_abi_version", "deft_last_error", "deft_supported",
@@ -83,6 +98,8 @@ EXPORTED = (
     "deft_flatten_read_partials", "deft_node_workspace_bytes", "deft_node_plan_bytes", "deft_node_build_plan",
     "deft_node_decode_f16",
     "deft_kv_append_f16", "deft_md_build", "deft_md_sizes", "deft_md_fetch", "deft_md_free",
+    "deft_tree_create", "deft_tree_free", "deft_tree_add_node", "deft_tree_remove_node", "deft_tree_set_leaf",
+    "deft_tree_append_slots", "deft_tree_extend_node", "deft_tree_clear_node_kv", "deft_tree_stats", "deft_tree_build_md",
 )
 
 _ERR_NAMES = {-1: "DEFT_EINVAL", -2: "DEFT_EUNSUPPORTED", -3: "DEFT_EHIP", -4: "DEFT_EWORKSPACE"}

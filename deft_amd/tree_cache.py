@@ -128,6 +128,21 @@ class TreeCache:
         self.use_tree_index = False
         self.layer_num = layer_num
         self.deleted_token_num = 0
+        # native mirror of the tree (csrc/host.cpp): mutations are forwarded so that from_tree_cache does not
+        # re-marshal every node's slot list each decode step
+        self._native = int(lib.deft_tree_create())
+
+    def __del__(self):  # noqa: D105
+        h = getattr(self, "_native", 0)
+        if h:
+            try:
+                lib.deft_tree_free(h)
+            except Exception:
+                pass
+            self._native = 0
+
+    def _mirror(self, rc: int, what: str) -> None:
+        check(rc, what)
 
     # ---- :192-230 -------------------------------------------------------------
     def init_prompt(self, prompt_ids) -> KVCacheUpdater:
@@ -147,6 +162,11 @@ class TreeCache:
         loc = self.token_to_kv_pool.alloc_host(len(ids))
         assert loc is not None
         self.root.kv_indices = loc.tolist()
+        self._mirror(lib.deft_tree_add_node(self._native, 0, -1), "deft_tree_add_node")
+        self._mirror(lib.deft_tree_set_leaf(self._native, 0, 1), "deft_tree_set_leaf")
+        loc64 = np.ascontiguousarray(loc, dtype=np.int64)
+        self._mirror(lib.deft_tree_extend_node(self._native, 0, len(loc64), loc64.ctypes.data_as(C.c_void_p)),
+                     "deft_tree_extend_node")
         cache_loc = torch.from_numpy(loc).to(self.token_to_kv_pool.device)
         self.req_to_token_pool.req_to_token[req_id, : len(ids)] = cache_loc.to(self.req_to_token_pool.req_to_token.device)
         return KVCacheUpdater(True, self.token_to_kv_pool, cache_loc, None, True)
@@ -159,17 +179,23 @@ class TreeCache:
         node.position_offset = parent.position_offset + len(parent.positions)
         parent.children[node.id] = node
         self.nodes[node.id] = node
+        self._mirror(lib.deft_tree_add_node(self._native, node.id, parent.id), "deft_tree_add_node")
         return node
 
     # ---- :261-283 -------------------------------------------------------------
     def alloc(self) -> KVCacheUpdater:
         loc = self.token_to_kv_pool.alloc_host(len(self.leaves))
         assert loc is not None
-        reqs, poss = [], []
+        reqs, poss, ids = [], [], []
         for idx, leaf in enumerate(sorted(self.leaves.values(), key=lambda x: x.id)):
             leaf.append_index(int(loc[idx]))
             reqs.append(self.leaf_to_req[leaf.id])
             poss.append(leaf.positions[-1])
+            ids.append(leaf.id)
+        ids64 = np.asarray(ids, dtype=np.int64)
+        loc64 = np.ascontiguousarray(loc, dtype=np.int64)
+        self._mirror(lib.deft_tree_append_slots(self._native, len(ids), ids64.ctypes.data_as(C.c_void_p),
+                                                loc64.ctypes.data_as(C.c_void_p)), "deft_tree_append_slots")
         cache_loc = torch.from_numpy(loc).to(self.token_to_kv_pool.device, non_blocking=True)
         table = self.req_to_token_pool.req_to_token
         idx = torch.from_numpy(np.asarray([reqs, poss], dtype=np.int64)).to(table.device, non_blocking=True)
@@ -183,6 +209,9 @@ class TreeCache:
             node_A.append_token(token=token_id)
         for kv_idx in node_B.kv_indices:
             node_A.append_index(index=kv_idx)
+        b64 = np.asarray(node_B.kv_indices, dtype=np.int64)
+        self._mirror(lib.deft_tree_extend_node(self._native, node_A.id, len(b64), b64.ctypes.data_as(C.c_void_p)),
+                     "deft_tree_extend_node")
         self.token_to_kv_pool.add_refs(node_B.kv_indices)
         if pruneB_flag:
             self.cut(node_B)
@@ -190,6 +219,7 @@ class TreeCache:
     def reset_node_KV(self, node: TreeNode, diff: int) -> None:
         self.token_to_kv_pool.free(node.kv_indices)
         node.kv_indices = []
+        self._mirror(lib.deft_tree_clear_node_kv(self._native, node.id), "deft_tree_clear_node_kv")
         node.position_offset += diff
         node.positions = [pos + diff for pos in node.positions]
 
@@ -197,6 +227,7 @@ class TreeCache:
     def branch(self, node: TreeNode, branch_cnt: int) -> List[TreeNode]:
         assert node.id in self.leaves
         self.leaves.pop(node.id)
+        self._mirror(lib.deft_tree_set_leaf(self._native, node.id, 0), "deft_tree_set_leaf")
         path_len = node.positions[-1] + 1
         req = self.leaf_to_req.pop(node.id)
         is_first = True
@@ -205,6 +236,7 @@ class TreeCache:
             child = self.new_node(node)
             new_nodes.append(child)
             self.leaves[child.id] = child
+            self._mirror(lib.deft_tree_set_leaf(self._native, child.id, 1), "deft_tree_set_leaf")
             if is_first:
                 self.leaf_to_req[child.id] = req
                 is_first = False
@@ -232,6 +264,7 @@ class TreeCache:
         cur: Optional[TreeNode] = node
         while cur is not None and len(cur.refs) == 0:
             deleted_nodes.append(self.nodes.pop(cur.id))
+            self._mirror(lib.deft_tree_remove_node(self._native, cur.id), "deft_tree_remove_node")
             self.token_to_kv_pool.free(cur.kv_indices)
             parent = cur.parent
             if parent is not None:
@@ -262,6 +295,8 @@ class TreeCache:
         self.nodes.clear()
         self.leaves.clear()
         self.node_cnt = 0
+        lib.deft_tree_free(self._native)
+        self._native = int(lib.deft_tree_create())
 
     def get_tree_token_number(self) -> int:  # :569-584
         return sum(len(n.token_ids) for n in self.nodes.values()) + self.deleted_token_num
@@ -285,8 +320,20 @@ _FIELDS = (
 )
 
 
-def build_metadata_host(tree: TreeCache, max_q_len: int, block_len: int, max_block_len: int) -> Dict[str, object]:
-    """Run the native builder; returns numpy int64 arrays that alias ONE packed buffer."""
+def _mirror_consistent(tree: TreeCache) -> bool:
+    """The mirror sees every mutation made through TreeCache's methods; code that edits `node.kv_indices` or
+    `tree.leaves` directly (the reference's scripts are free to) is caught here by counts and sends the build
+    down the marshalling path."""
+    if not getattr(tree, "_native", 0):
+        return False
+    stats = np.zeros(3, dtype=np.int64)
+    if lib.deft_tree_stats(tree._native, stats.ctypes.data_as(C.c_void_p)) != 0:
+        return False
+    return (int(stats[0]) == len(tree.nodes) and int(stats[1]) == len(tree.leaves)
+            and int(stats[2]) == sum(len(nd.kv_indices) for nd in tree.nodes.values()))
+
+
+def _marshal_and_build(tree: TreeCache, max_q_len: int, block_len: int, max_block_len: int) -> int:
     nodes = list(tree.nodes.values())
     n = len(nodes)
     node_id = np.fromiter((nd.id for nd in nodes), dtype=np.int64, count=n)
@@ -299,8 +346,18 @@ def build_metadata_host(tree: TreeCache, max_q_len: int, block_len: int, max_blo
         kv_slots[kv_offset[i] : kv_offset[i + 1]] = nd.kv_indices
 
     ptr = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
-    handle = lib.deft_md_build(n, ptr(node_id), ptr(parent_id), ptr(is_leaf), ptr(kv_offset), ptr(kv_slots),
-                               int(max_q_len), int(block_len), int(max_block_len))
+    return int(lib.deft_md_build(n, ptr(node_id), ptr(parent_id), ptr(is_leaf), ptr(kv_offset), ptr(kv_slots),
+                                 int(max_q_len), int(block_len), int(max_block_len)))
+
+
+def build_metadata_host(tree: TreeCache, max_q_len: int, block_len: int, max_block_len: int,
+                        use_mirror: bool = True, alloc=None) -> Dict[str, object]:
+    """Run the native builder; returns numpy int64 arrays that alias ONE packed buffer."""
+    ptr = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    if use_mirror and _mirror_consistent(tree):
+        handle = int(lib.deft_tree_build_md(tree._native, int(max_q_len), int(block_len), int(max_block_len)))
+    else:
+        handle = _marshal_and_build(tree, max_q_len, block_len, max_block_len)
     if handle <= 0:
         check(int(handle), "deft_md_build")
     try:
@@ -314,7 +371,7 @@ def build_metadata_host(tree: TreeCache, max_q_len: int, block_len: int, max_blo
             "block_bitmasks": n_block_kv, "block_kv": n_block_kv, "block_lens": NB,
         }
         total = sum(lens.values())
-        packed = np.empty(total, dtype=np.int64)
+        packed = np.empty(total, dtype=np.int64) if alloc is None else alloc(total)  # e.g. a pinned staging buffer
         views, off = {}, 0
         for k in _FIELDS:
             views[k] = packed[off : off + lens[k]]
@@ -366,11 +423,29 @@ class TreeMetadata:
         block_len = BLOCK_CONFIG["BLOCK_LEN"]
         if max_block_len == -1:
             max_block_len = BLOCK_CONFIG["MAX_BLOCK_LEN"]
-        host = build_metadata_host(tree, max_q_len, block_len, max_block_len)
         dev = torch.device(device) if device is not None else tree.token_to_kv_pool.device
-        packed = torch.from_numpy(host["_packed"])
-        if dev.type != "cpu":
-            packed = packed.pin_memory().to(dev, non_blocking=True)  # ONE H2D copy for all twelve arrays
+        if dev.type == "cpu":
+            host = build_metadata_host(tree, max_q_len, block_len, max_block_len)
+            packed = torch.from_numpy(host["_packed"])
+        else:
+            # the builder writes straight into a pinned staging buffer kept on the tree (two, alternating, each
+            # guarded by the event of its last upload); ONE H2D copy for all twelve arrays
+            stages = tree.__dict__.setdefault("_md_stages", [None, None])
+            k = tree.__dict__["_md_stage_idx"] = 1 - tree.__dict__.get("_md_stage_idx", 0)
+
+            def alloc(total: int):
+                st = stages[k]
+                if st is None or st[0].numel() < total:
+                    st = stages[k] = [torch.empty(max(2 * total, 1 << 14), dtype=torch.int64).pin_memory(), None]
+                if st[1] is not None:
+                    st[1].synchronize()
+                return st[0].numpy()[:total]
+
+            host = build_metadata_host(tree, max_q_len, block_len, max_block_len, alloc=alloc)
+            st = stages[k]
+            packed = st[0][: host["_packed"].shape[0]].to(dev, non_blocking=True)
+            st[1] = torch.cuda.Event()
+            st[1].record(torch.cuda.current_stream(dev))
         views, off = {}, 0
         for k in _FIELDS:
             n = host["_lens"][k]

@@ -215,6 +215,24 @@ int deft_md_fetch(
 
 int deft_md_free(int64_t handle);
 
+/*
+ * Persistent mirror of the decoding tree (host only).  The host-side TreeCache forwards its mutations
+ * (tree_cache.py:192-403: init_prompt / new_node / alloc / branch / cut / merge_nodes / reset_node_KV) so that a
+ * decode step's metadata is built without re-marshalling the whole tree: deft_tree_build_md(tree, ...) ==
+ * deft_md_build(<the mirrored arrays>, ...), handle consumed with deft_md_sizes / _fetch / _free as above.
+ * deft_tree_stats: {nodes, leaves, total KV slots}, for the caller's consistency check.
+ */
+int64_t deft_tree_create(void);
+int deft_tree_free(int64_t tree);
+int deft_tree_add_node(int64_t tree, int64_t id, int64_t parent_id /* -1 = root */);
+int deft_tree_remove_node(int64_t tree, int64_t id);
+int deft_tree_set_leaf(int64_t tree, int64_t id, int is_leaf);
+int deft_tree_append_slots(int64_t tree, int n, const int64_t* ids, const int64_t* slots); /* one slot per id */
+int deft_tree_extend_node(int64_t tree, int64_t id, int n, const int64_t* slots);
+int deft_tree_clear_node_kv(int64_t tree, int64_t id);
+int deft_tree_stats(int64_t tree, int64_t stats[3]);
+int64_t deft_tree_build_md(int64_t tree, int max_q_len, int block_len, int max_block_len);
+
 #ifdef __cplusplus
 }
 #endif

@@ -166,3 +166,32 @@ def test_forest_metadata_is_the_offset_concatenation_of_its_trees():
     assert upd.cache_loc.tolist() == [l.kv_indices[-1] for l in leaves]
     assert [len(l.kv_indices) for l in leaves] == [b + 1 for b in before]
     assert len(forest.leaf_paths()) == forest.query_num
+
+
+@pytest.mark.parametrize("name", sorted(SCENARIOS))
+def test_native_tree_mirror_tracks_every_mutation(name):
+    """TreeCache forwards init_prompt / branch / alloc / cut / merge_nodes / reset_node_KV to the native mirror
+    (deft_tree_*); the metadata built from the mirror equals the one built by marshalling the Python tree."""
+    from deft_amd import tree_cache as tc
+
+    tree = product_tree(name)
+    sc = SCENARIOS[name]
+    assert tc._mirror_consistent(tree)
+    a = tc.build_metadata_host(tree, sc.max_q_len, sc.block_len, sc.max_block_len, use_mirror=True)
+    b = tc.build_metadata_host(tree, sc.max_q_len, sc.block_len, sc.max_block_len, use_mirror=False)
+    for k in MD_FIELDS:
+        assert np.array_equal(a[k], b[k]), k
+    assert a["leaf_to_q"] == b["leaf_to_q"] and a["query_num"] == b["query_num"]
+
+
+def test_native_tree_mirror_detects_out_of_band_edits():
+    """Code that edits node.kv_indices directly (not through TreeCache) must not get stale metadata."""
+    from deft_amd import tree_cache as tc
+
+    tree = product_tree("multilevel")
+    leaf = sorted(tree.leaves.values(), key=lambda n: n.id)[0]
+    slot = tree.token_to_kv_pool.alloc_host(1)
+    leaf.kv_indices.append(int(slot[0]))  # bypasses the mirror
+    assert not tc._mirror_consistent(tree)
+    md = deft_amd.TreeMetadata.from_tree_cache(tree, device="cpu")
+    assert int(slot[0]) in md.block_kv.tolist()
