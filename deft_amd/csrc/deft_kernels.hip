@@ -614,10 +614,6 @@ static int launch_stage1_stream(const Stage1Params& p, int64_t unit_cap, const P
     sp.cache_loc = ap.cache_loc;
     sp.new_st = ap.new_st;
     sp.n_new = ap.k_new ? ap.n_new : 0;
-    if (sp.n_new > workers) {
-        set_error("fused append: %d new rows exceed the %lld workgroups of the launch", sp.n_new, (long long)workers);
-        return DEFT_EUNSUPPORTED;
-    }
     hipLaunchKernelGGL((stage1_stream_kernel<128>), dim3((unsigned)workers), dim3(512), SM::BYTES, stream, sp);
     return check_launch("stage1 stream launch");
 }
@@ -922,7 +918,8 @@ size_t deft_node_plan_bytes(int NE, int P, int64_t total_kv, int Hq, int Hkv) {
 int deft_node_build_plan(const int64_t* node_kv, const int64_t* node_kv_offset, const int64_t* node_kv_len,
                          const int64_t* node_q, const int64_t* node_q_offset, const int64_t* node_q_len, int NE, int P,
                          int64_t total_kv, int Hq, int Hkv, int64_t q_stride_tok, int64_t q_stride_head,
-                         int64_t kv_stride_slot, void* plan, size_t plan_bytes, void* stream) {
+                         int64_t kv_stride_slot, const int32_t* cache_loc, int n_new, int64_t new_stride_tok, void* plan,
+                         size_t plan_bytes, void* stream) {
     if (NE < 0 || P < 0 || total_kv < 0 || total_kv > 0x7fffffffLL || !plan || Hq <= 0 || Hkv <= 0 || Hq % Hkv ||
         (NE > 0 && (!node_kv || !node_kv_offset || !node_kv_len || !node_q || !node_q_offset || !node_q_len))) {
         set_error("bad node plan arguments (NE=%d P=%d total_kv=%lld)", NE, P, (long long)total_kv);
@@ -947,16 +944,28 @@ int deft_node_build_plan(const int64_t* node_kv, const int64_t* node_kv_offset, 
     p.q_st = q_stride_tok;
     p.q_sh = q_stride_head;
     p.kv_ss = kv_stride_slot;
-    return launch_node_plan(p, NE, rows, pv, AppendArgs(), static_cast<hipStream_t>(stream));
+    AppendArgs ap;  // only the slots of this step's new rows and their stride matter to the plan
+    if (cache_loc) {
+        if (n_new < 0 || new_stride_tok < 0) {
+            set_error("bad node plan append arguments (n_new=%d)", n_new);
+            return DEFT_EINVAL;
+        }
+        ap.cache_loc = cache_loc;
+        ap.n_new = n_new;
+        ap.new_st = new_stride_tok;
+    }
+    return launch_node_plan(p, NE, rows, pv, ap, static_cast<hipStream_t>(stream));
 }
 
-int deft_node_decode_f16(const void* q, int64_t q_stride_tok, int64_t q_stride_head, const void* k_base,
-                         const void* v_base, int64_t kv_stride_slot, int64_t kv_stride_head, void* out,
-                         int64_t o_stride_tok, int64_t o_stride_head, const int64_t* node_kv,
-                         const int64_t* node_kv_offset, const int64_t* node_kv_len, const int64_t* node_q,
-                         const int64_t* node_q_offset, const int64_t* node_q_len, int NE, int P, int64_t total_kv, int nq,
-                         int Hq, int Hkv, int D, float scale, const void* plan, void* workspace, size_t workspace_bytes,
-                         void* stream) {
+}  // extern "C"
+
+static int node_decode_impl(const void* q, int64_t q_stride_tok, int64_t q_stride_head, const void* k_base,
+                            const void* v_base, int64_t kv_stride_slot, int64_t kv_stride_head, void* out,
+                            int64_t o_stride_tok, int64_t o_stride_head, const int64_t* node_kv,
+                            const int64_t* node_kv_offset, const int64_t* node_kv_len, const int64_t* node_q,
+                            const int64_t* node_q_offset, const int64_t* node_q_len, int NE, int P, int64_t total_kv, int nq,
+                            int Hq, int Hkv, int D, float scale, const void* plan, void* workspace, size_t workspace_bytes,
+                            void* stream, const AppendArgs& ap) {
     int rc = check_common(q, q_stride_tok, q_stride_head, k_base, v_base, kv_stride_slot, kv_stride_head, out,
                           o_stride_tok, o_stride_head, nq, Hq, Hkv, D);
     if (rc) return rc;
@@ -969,6 +978,8 @@ int deft_node_decode_f16(const void* q, int64_t q_stride_tok, int64_t q_stride_h
         set_error("null workspace");
         return DEFT_EINVAL;
     }
+    rc = check_append(ap, Hkv, D);
+    if (rc) return rc;
     const int G = Hq / Hkv;
     const int64_t tiles = node_max_tiles(NE, total_kv);
     const int64_t rows = tiles * DEFT_MAX_Q_LEN;
@@ -1006,14 +1017,19 @@ int deft_node_decode_f16(const void* q, int64_t q_stride_tok, int64_t q_stride_h
             pv = plan_view(const_cast<void*>(plan), tiles * G, rows);
         } else {
             pv = plan_view(ws.plan, tiles * G, rows);
-            rc = launch_node_plan(p, NE, rows, pv, AppendArgs(), st);
+            rc = launch_node_plan(p, NE, rows, pv, ap, st);
             if (rc) return rc;
         }
-        rc = launch_stage1_stream(p, tiles * G, pv, AppendArgs(), st);
+        rc = launch_stage1_stream(p, tiles * G, pv, ap, st);
         if (rc) return rc;
         return launch_merge(D, ws, pv.row_q, rows, out, o_stride_tok, o_stride_head, nq, Hq, st);
     }
     // tile-per-workgroup form (head_dim 64)
+    if (ap.k_new) {  // separate append launch first
+        rc = deft_kv_append_f16(const_cast<void*>(k_base), const_cast<void*>(v_base), kv_stride_slot, kv_stride_head,
+                                ap.cache_loc, ap.k_new, ap.v_new, ap.new_st, ap.n_new, Hkv, D, stream);
+        if (rc) return rc;
+    }
     const size_t prep_lds = sizeof(int) * 2 * (size_t)(NE + 1);
     if (prep_lds > 64 * 1024) {
         set_error("node mode: %d entries exceed the prep kernel's LDS scan", NE);
@@ -1027,6 +1043,44 @@ int deft_node_decode_f16(const void* q, int64_t q_stride_tok, int64_t q_stride_h
     rc = dispatch_stage1<1>(D, p, tiles, st);
     if (rc) return rc;
     return launch_merge(D, ws, ws.row_q, rows, out, o_stride_tok, o_stride_head, nq, Hq, st);
+}
+
+extern "C" {
+
+int deft_node_decode_f16(const void* q, int64_t q_stride_tok, int64_t q_stride_head, const void* k_base,
+                         const void* v_base, int64_t kv_stride_slot, int64_t kv_stride_head, void* out,
+                         int64_t o_stride_tok, int64_t o_stride_head, const int64_t* node_kv,
+                         const int64_t* node_kv_offset, const int64_t* node_kv_len, const int64_t* node_q,
+                         const int64_t* node_q_offset, const int64_t* node_q_len, int NE, int P, int64_t total_kv, int nq,
+                         int Hq, int Hkv, int D, float scale, const void* plan, void* workspace, size_t workspace_bytes,
+                         void* stream) {
+    return node_decode_impl(q, q_stride_tok, q_stride_head, k_base, v_base, kv_stride_slot, kv_stride_head, out,
+                            o_stride_tok, o_stride_head, node_kv, node_kv_offset, node_kv_len, node_q, node_q_offset,
+                            node_q_len, NE, P, total_kv, nq, Hq, Hkv, D, scale, plan, workspace, workspace_bytes, stream,
+                            AppendArgs());
+}
+
+int deft_node_decode_append_f16(const void* q, int64_t q_stride_tok, int64_t q_stride_head, void* k_base, void* v_base,
+                                int64_t kv_stride_slot, int64_t kv_stride_head, void* out, int64_t o_stride_tok,
+                                int64_t o_stride_head, const int64_t* node_kv, const int64_t* node_kv_offset,
+                                const int64_t* node_kv_len, const int64_t* node_q, const int64_t* node_q_offset,
+                                const int64_t* node_q_len, int NE, int P, int64_t total_kv, int nq, int Hq, int Hkv, int D,
+                                float scale, const int32_t* cache_loc, const void* k_new, const void* v_new,
+                                int64_t new_stride_tok, int n_new, const void* plan, void* workspace,
+                                size_t workspace_bytes, void* stream) {
+    AppendArgs ap;
+    ap.k_new = static_cast<const _Float16*>(k_new);
+    ap.v_new = static_cast<const _Float16*>(v_new);
+    ap.cache_loc = cache_loc;
+    ap.new_st = new_stride_tok;
+    ap.n_new = n_new;
+    if (!k_new || !v_new || !cache_loc) {
+        set_error("fused append needs k_new, v_new and cache_loc");
+        return DEFT_EINVAL;
+    }
+    return node_decode_impl(q, q_stride_tok, q_stride_head, k_base, v_base, kv_stride_slot, kv_stride_head, out,
+                            o_stride_tok, o_stride_head, node_kv, node_kv_offset, node_kv_len, node_q, node_q_offset,
+                            node_q_len, NE, P, total_kv, nq, Hq, Hkv, D, scale, plan, workspace, workspace_bytes, stream, ap);
 }
 
 int deft_kv_append_f16(void* k_base, void* v_base, int64_t kv_stride_slot, int64_t kv_stride_head,

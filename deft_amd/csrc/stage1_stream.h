@@ -252,10 +252,9 @@ __global__ __launch_bounds__(512, 2) void stage1_stream_kernel(StreamParams sp) 
         }
     };
 
-    // ---- fused paged append: the last n_new workgroups each copy one new-token row into the pool (nobody
+    // ---- fused paged append: new-token row j is copied into the pool by workgroup W-1 - j % W (nobody
     //      reads those pool rows in this launch: the loaders take them from k_new / v_new) -------------------
-    const int copy_job = W - 1 - bid;
-    if (copy_job < sp.n_new) {
+    for (int copy_job = W - 1 - bid; copy_job < sp.n_new; copy_job += W) {
         const int64_t dst = (int64_t)sp.cache_loc[copy_job] * p.kv_ss;
         const int chunks = p.Hkv * (D / 8);  // 16-byte pieces per K (or V) row
         for (int i = tid; i < chunks; i += blockDim.x) {
@@ -687,24 +686,50 @@ __global__ __launch_bounds__(128) void flatten_records_kernel(const int64_t* blo
 // Node mode (tree_attention.py:14-293): every entry (a node's KV x up to 32 of its queries) is cut into
 // 128-slot tiles; all live slots are visible to all of the entry's queries.  Consecutive tiles of one
 // entry fold, which is the reference's serial online-softmax walk (:230-276) without the serialisation.
+// Small entries (one tile, one pass) that follow each other are PACKED into one tile as long as their slots fit
+// in 128 and their virtual query rows in 32 -- per-slot row masks make that the same arithmetic (a Medusa step
+// has 64 one-token nodes: 2 tiles instead of 64).  A packed unit has aux = -(entries in it).
 __global__ __launch_bounds__(256) void node_units_kernel(const int64_t* node_kv_len, const int64_t* node_q_len, int NE, int G,
                                                          int cap, int64_t rows_cap, UnitList ul, int32_t* hdr,
                                                          int32_t* sched, int32_t* row_q) {
     for (int64_t i = threadIdx.x; i < rows_cap; i += blockDim.x) row_q[i] = -1;
     if (threadIdx.x == 0) {
         int r = 0, rowbase = 0;
+        int pack_r = -1, pack_n = 0, pack_keys = 0, pack_rows = 0;  // open pack: its unit, entries, slots, virtual rows
         for (int e = 0; e < NE; ++e) {
-            const int nt = (int)((node_kv_len[e] + TILE - 1) / TILE);
+            const int len = (int)node_kv_len[e];
+            const int nt = (len + TILE - 1) / TILE;
             const int ql = (int)node_q_len[e];
             const int np = (ql * G + MQ - 1) / MQ;
-            for (int ps = 0; ps < np; ++ps) {
-                const int first = r;
-                for (int tt = 0; tt < nt && r < cap; ++tt, ++r) {
+            if (nt == 1 && np == 1 && r < cap) {
+                if (pack_r >= 0 && pack_n < MQ && pack_keys + len <= TILE && pack_rows + ql * G <= MQ) {
+                    ++pack_n;
+                    pack_keys += len;
+                    pack_rows += ql * G;
+                    ul.aux[pack_r] = -pack_n;
+                } else {
+                    pack_r = r;
+                    pack_n = 1;
+                    pack_keys = len;
+                    pack_rows = ql * G;
                     ul.src[r] = e;
-                    ul.aux[r] = tt;
-                    ul.pass[r] = ps;
-                    ul.flags[r] = (first << 1) | ((tt == 0) ? 1 : 0);
-                    ul.prow[r] = rowbase + tt * ql;
+                    ul.aux[r] = 0;  // a pack of one is an ordinary unit
+                    ul.pass[r] = 0;
+                    ul.flags[r] = (r << 1) | 1;
+                    ul.prow[r] = rowbase;
+                    ++r;
+                }
+            } else {
+                pack_r = -1;
+                for (int ps = 0; ps < np; ++ps) {
+                    const int first = r;
+                    for (int tt = 0; tt < nt && r < cap; ++tt, ++r) {
+                        ul.src[r] = e;
+                        ul.aux[r] = tt;
+                        ul.pass[r] = ps;
+                        ul.flags[r] = (first << 1) | ((tt == 0) ? 1 : 0);
+                        ul.prow[r] = rowbase + tt * ql;
+                    }
                 }
             }
             rowbase += nt * ql;
@@ -740,7 +765,61 @@ __global__ __launch_bounds__(128) void node_records_kernel(const int64_t* node_k
         }
         return;
     }
-    const int e = ul.src[r], tt = ul.aux[r], ps = ul.pass[r], prow = ul.prow[r];
+    const int e0 = ul.src[r], aux = ul.aux[r], ps = ul.pass[r], prow = ul.prow[r];
+    if (aux < 0) {
+        // ---- packed unit: entries e0 .. e0 - aux - 1, each one tile and one pass -------------------------
+        const int cnt = -aux;
+        // slot k -> (entry j, position inside it); virtual row k -> (entry j, query, head of the group)
+        int kj = -1, kpos = 0, kvb = 0, knv = 0;  // for the slot role
+        int vj = -1, vloc = 0, vrowbase = 0;      // for the row role (k < MQ)
+        int keys = 0, vrows = 0, rowsum = 0;
+        int first_slot_e = e0;
+        for (int j = 0; j < cnt; ++j) {
+            const int e = e0 + j;
+            const int len = (int)node_kv_len[e];
+            const int nv = (int)node_q_len[e] * G;
+            if (kj < 0 && k < keys + len) {
+                kj = e;
+                kpos = k - keys;
+                kvb = vrows;
+                knv = nv;
+            }
+            if (vj < 0 && k < vrows + nv) {
+                vj = e;
+                vloc = k - vrows;
+                vrowbase = rowsum;
+            }
+            keys += len;
+            vrows += nv;
+            rowsum += (int)node_q_len[e];
+        }
+        const bool live = kj >= 0;
+        const int64_t slot = live ? node_kv[node_kv_offset[kj] + kpos] : node_kv[node_kv_offset[first_slot_e]];
+        ro[k] = plan_rowoff(slot, kv_stride_slot, cache_loc, n_new, new_row_bytes);
+        mk[k] = live ? ((knv >= 32 ? 0xffffffffu : ((1u << knv) - 1u)) << kvb) : 0u;
+        if (k < MQ) {
+            int qs, orow = 0;
+            if (vj >= 0) {
+                const int qi = vloc / G, g = vloc % G;
+                const int64_t qrow = node_q[node_q_offset[vj] + qi];
+                qs = (int)(qrow * q_st + g * q_sh);
+                orow = g * rows + prow + vrowbase + qi;
+                if (g == 0) row_q[prow + vrowbase + qi] = (int32_t)qrow;
+            } else {
+                qs = (int)(node_q[node_q_offset[e0]] * q_st);  // alias a real row
+            }
+            reinterpret_cast<int32_t*>(rec + PLAN_QSRC)[k] = qs;
+            reinterpret_cast<int32_t*>(rec + PLAN_OROW)[k] = orow;
+        }
+        if (k == 0) {
+            desc[0] = vrows;
+            desc[1] = prow;
+            desc[2] = 1;
+            desc[3] = ul.flags[r] >> 1;
+        }
+        return;
+    }
+    const int e = e0, tt = aux;
     const int64_t kv0 = node_kv_offset[e] + (int64_t)tt * TILE;
     const int len = (int)min((int64_t)TILE, node_kv_len[e] - (int64_t)tt * TILE);
     const int64_t q0 = node_q_offset[e];
@@ -766,7 +845,7 @@ __global__ __launch_bounds__(128) void node_records_kernel(const int64_t* node_k
         desc[0] = nv;
         desc[1] = prow;
         desc[2] = ul.flags[r] & 1;
-        desc[3] = ul.flags[r] >> 1;  // run id: tiles with equal ids share one query list and may fold
+        desc[3] = ul.flags[r] >> 1;
     }
 }
 

@@ -20,7 +20,8 @@ import torch
 from torch import nn
 
 from .forward_mode import ForwardMode, InputMetadata
-from .tree_attention import flatten_append_attention, tree_attention_fwd, tree_attention_subtree_fwd
+from .tree_attention import (flatten_append_attention, node_append_attention, tree_attention_fwd,
+                             tree_attention_subtree_fwd)
 from .tree_cache import get_global_tree_metadata
 
 
@@ -42,11 +43,21 @@ class DeFTAttention(nn.Module):
         k = k.view(-1, self.tp_k_head_num, self.head_dim)
         v = v.view(-1, self.tp_v_head_num, self.head_dim)
         o = torch.empty((q.shape[0], self.tp_q_head_num * self.head_dim), dtype=q.dtype, device=q.device)
-        self.store_kv_cache(k, v, input_metadata)
         md = get_global_tree_metadata()
         assert md is not None
         assert input_metadata.token_to_kv_pool is not None
         pool = input_metadata.token_to_kv_pool
+        updater = input_metadata.kv_updater
+        if (updater is not None and updater.cache_loc is not None and updater.token_to_kv_pool is pool
+                and not os.environ.get("DEFT_NO_FUSED_APPEND")):
+            # store_kv_cache (:83) and the operator (:94-105) in one fused call
+            node_append_attention(
+                q.view(-1, self.tp_q_head_num, self.head_dim), pool.kv_data[self.layer_id],
+                o.view(-1, self.tp_q_head_num, self.head_dim), updater.cache_loc, k, v,
+                md.node_kv, md.node_kv_offset, md.node_kv_len, md.node_q, md.node_q_offset, md.node_q_len,
+            )
+            return o
+        self.store_kv_cache(k, v, input_metadata)
         tree_attention_fwd(
             q.view(-1, self.tp_q_head_num, self.head_dim),
             pool.get_key_buffer(self.layer_id),

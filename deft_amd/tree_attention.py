@@ -78,17 +78,22 @@ def _flatten_plan(md, NB: int, P: int, Hq: int, Hkv: int, q_strides, kv_stride_s
     return plan
 
 
-def _node_plan(md, NE: int, P: int, total_kv: int, Hq: int, Hkv: int, q_strides, kv_stride_slot: int, stream: int):
+def _node_plan(md, NE: int, P: int, total_kv: int, Hq: int, Hkv: int, q_strides, kv_stride_slot: int, stream: int,
+               cache_loc=None, new_stride: int = 0):
     """Node-mode counterpart of `_flatten_plan`; cached on the KVMapQ_List (node_q) tensor."""
     node_q = md[3]
     key = (kv_stride_slot, NE, P, total_kv, Hq, Hkv, tuple(q_strides)) + tuple((t.data_ptr(), t._version) for t in md)
+    if cache_loc is not None:  # fused-append plans mark this step's new slots
+        key += (cache_loc.data_ptr(), cache_loc._version, cache_loc.shape[0], new_stride)
     cached = getattr(node_q, "_deft_plan", None)
     if cached is not None and cached[0] == key:
         return cached[1]
     nbytes = lib.deft_node_plan_bytes(NE, P, total_kv, Hq, Hkv)
     plan = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=node_q.device)
     check(lib.deft_node_build_plan(*[t.data_ptr() for t in md], NE, P, total_kv, Hq, Hkv, q_strides[0], q_strides[1],
-                                   kv_stride_slot, plan.data_ptr(), nbytes, stream), "deft_node_build_plan")
+                                   kv_stride_slot, cache_loc.data_ptr() if cache_loc is not None else None,
+                                   cache_loc.shape[0] if cache_loc is not None else 0, new_stride,
+                                   plan.data_ptr(), nbytes, stream), "deft_node_build_plan")
     try:
         node_q._deft_plan = (key, plan)
     except Exception:
@@ -217,6 +222,46 @@ def tree_attention_fwd(
         NE, P, total_kv, nq, Hq, Hkv, D, scale, plan.data_ptr(), ws.data_ptr(), ws_bytes, stream,
     )
     check(rc, "deft_node_decode_f16")
+
+
+@torch.inference_mode()
+def node_append_attention(query_states, kv_layer, output, cache_loc, cache_k, cache_v, KV_indices, KV_indices_offset,
+                          KV_len, KVMapQ_List, KVMapQ_List_Offset, KVMapQ_List_Len) -> None:
+    """`store_kv_cache` + `tree_attention_fwd` in ONE launch sequence (DeFTAttention.deft_node_forward,
+    deft_attention.py:72-108): kv_layer[cache_loc, 0/1] = cache_k / cache_v and output = Node attention that
+    already sees those rows."""
+    key_buffer, value_buffer = kv_layer[:, 0], kv_layer[:, 1]
+    nq, Hq, Hkv, D = _check_qkv(query_states, key_buffer, value_buffer, output)
+    NE = KV_indices_offset.shape[0]
+    P = KVMapQ_List.shape[0]
+    total_kv = KV_indices.shape[0]
+    md = [_i64(t, n) for t, n in ((KV_indices, "KV_indices"), (KV_indices_offset, "KV_indices_offset"),
+                                  (KV_len, "KV_len"), (KVMapQ_List, "KVMapQ_List"),
+                                  (KVMapQ_List_Offset, "KVMapQ_List_Offset"), (KVMapQ_List_Len, "KVMapQ_List_Len"))]
+    n = cache_loc.shape[0]
+    k = cache_k.reshape(n, Hkv, D)
+    v = cache_v.reshape(n, Hkv, D)
+    if k.stride(2) != 1 or k.stride(1) != D:
+        k = k.contiguous()
+    if v.stride() != k.stride():
+        k, v = k.contiguous(), v.contiguous()
+    if cache_loc.dtype != torch.int32 or not cache_loc.is_cuda:
+        cache_loc = cache_loc.to(device=query_states.device, dtype=torch.int32)
+    ws_bytes = lib.deft_node_workspace_bytes(NE, P, total_kv, nq, Hq, Hkv, D)
+    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=query_states.device)
+    stream = _stream_ptr(query_states)
+    plan = _node_plan(md, NE, P, total_kv, Hq, Hkv, (query_states.stride(0), query_states.stride(1)),
+                      key_buffer.stride(0), stream, cache_loc=cache_loc, new_stride=k.stride(0))
+    rc = lib.deft_node_decode_append_f16(
+        query_states.data_ptr(), query_states.stride(0), query_states.stride(1),
+        key_buffer.data_ptr(), value_buffer.data_ptr(), key_buffer.stride(0), key_buffer.stride(1),
+        output.data_ptr(), output.stride(0), output.stride(1),
+        *[t.data_ptr() for t in md],
+        NE, P, total_kv, nq, Hq, Hkv, D, 1.0 / (D ** 0.5),
+        cache_loc.data_ptr(), k.data_ptr(), v.data_ptr(), k.stride(0), n,
+        plan.data_ptr(), ws.data_ptr(), ws_bytes, stream,
+    )
+    check(rc, "deft_node_decode_append_f16")
 
 
 @torch.inference_mode()

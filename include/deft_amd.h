@@ -134,6 +134,7 @@ int deft_node_build_plan(
     const int64_t* node_q, const int64_t* node_q_offset, const int64_t* node_q_len,
     int NE, int P, int64_t total_kv, int Hq, int Hkv,
     int64_t q_stride_tok, int64_t q_stride_head, int64_t kv_stride_slot,
+    const int32_t* cache_loc /* nullable */, int n_new, int64_t new_stride_tok,
     void* plan, size_t plan_bytes, void* stream);
 
 /*
@@ -152,6 +153,20 @@ int deft_node_decode_f16(
     const int64_t* node_kv, const int64_t* node_kv_offset, const int64_t* node_kv_len,
     const int64_t* node_q, const int64_t* node_q_offset, const int64_t* node_q_len,
     int NE, int P, int64_t total_kv, int nq, int Hq, int Hkv, int D, float scale,
+    const void* plan, void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * DeFTAttention.deft_node_forward in one call (deft_attention.py:72-108): the paged append of this step's K/V rows
+ * fused into the Node attention launch; same contract as deft_flatten_decode_append_f16.
+ */
+int deft_node_decode_append_f16(
+    const void* q, int64_t q_stride_tok, int64_t q_stride_head,
+    void* k_base, void* v_base, int64_t kv_stride_slot, int64_t kv_stride_head,
+    void* out, int64_t o_stride_tok, int64_t o_stride_head,
+    const int64_t* node_kv, const int64_t* node_kv_offset, const int64_t* node_kv_len,
+    const int64_t* node_q, const int64_t* node_q_offset, const int64_t* node_q_len,
+    int NE, int P, int64_t total_kv, int nq, int Hq, int Hkv, int D, float scale,
+    const int32_t* cache_loc, const void* k_new, const void* v_new, int64_t new_stride_tok, int n_new,
     const void* plan, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- paged KV append ---------------------------------------------------- */

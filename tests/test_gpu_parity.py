@@ -214,14 +214,15 @@ def _flatten_args(md):
     return (md.block_len, md.block_q, md.block_q_cnts, md.block_q_offset, md.block_bitmasks, md.block_kv, md.block_lens)
 
 
+@pytest.mark.parametrize("mode", ["flatten", "node"])
+@pytest.mark.parametrize("name", ["multilevel", "spec_mock"])
 @pytest.mark.parametrize("geom", [(4, 4, 128), (8, 2, 128), (4, 4, 64)])
-def test_fused_append_equals_append_then_attention(geom):
-    """deft_flatten_decode_append_f16 == deft_kv_append_f16 followed by deft_flatten_decode_f16, bit for bit,
-    and the pool holds the new rows afterwards (deft_attention.py:110-151 in one launch sequence)."""
-    from deft_amd.tree_attention import flatten_append_attention
+def test_fused_append_equals_append_then_attention(geom, name, mode):
+    """deft_{flatten,node}_decode_append_f16 == deft_kv_append_f16 followed by deft_{flatten,node}_decode_f16, bit
+    for bit, and the pool holds the new rows afterwards (deft_attention.py:72-151 in one launch sequence)."""
+    from deft_amd.tree_attention import flatten_append_attention, node_append_attention
     from deft_amd.utils.synthetic import dyadic_normal
 
-    name = "multilevel"
     Hq, Hkv, D = geom
     outs, pools = [], []
     for fused in (False, True):
@@ -238,11 +239,18 @@ def test_fused_append_equals_append_then_attention(geom):
         v_new = torch.from_numpy(dyadic_normal((nq, Hkv, D), 6)).cuda()
         q = torch.from_numpy(q_np).cuda()
         o = torch.zeros((nq, Hq, D), dtype=torch.float16, device="cuda")
-        if fused:
+        node_args = (md.node_kv, md.node_kv_offset, md.node_kv_len, md.node_q, md.node_q_offset, md.node_q_len)
+        if fused and mode == "flatten":
             flatten_append_attention(q, pool.kv_data[0], o, updater.cache_loc, k_new, v_new, *_flatten_args(md))
+        elif fused:
+            node_append_attention(q, pool.kv_data[0], o, updater.cache_loc, k_new, v_new, *node_args)
         else:
             deft_amd.kv_append(pool.kv_data[0], updater.cache_loc, k_new, v_new)
-            deft_amd.tree_attention_subtree_fwd(q, pool.get_key_buffer(0), pool.get_value_buffer(0), o, *_flatten_args(md))
+            if mode == "flatten":
+                deft_amd.tree_attention_subtree_fwd(q, pool.get_key_buffer(0), pool.get_value_buffer(0), o,
+                                                    *_flatten_args(md))
+            else:
+                deft_amd.tree_attention_fwd(q, pool.get_key_buffer(0), pool.get_value_buffer(0), o, *node_args)
         torch.cuda.synchronize()
         outs.append(o.cpu().numpy())
         pools.append(pool.kv_data[0].cpu().numpy())
