@@ -43,7 +43,7 @@ inline Workspace carve(void* base, int Hq, int D, int64_t rows, int64_t tiles, s
     w.row_q = reinterpret_cast<int32_t*>(p + off);
     off = align_up(off + sizeof(int32_t) * (size_t)rows, 256);
     w.desc = reinterpret_cast<int32_t*>(p + off);
-    off = align_up(off + sizeof(int32_t) * 8 * (size_t)tiles, 256);
+    off = align_up(off + sizeof(int32_t) * 17 * (size_t)tiles, 256);
     w.plan = p + off;  // a whole plan buffer when the caller passes no plan
     off = align_up(off + plan_bytes, 256);
     w.bytes = off;
@@ -56,13 +56,13 @@ inline int64_t node_max_tiles(int NE, int64_t total_kv) { return (int64_t)NE + t
 //   header      4 KB  : int32 hdr[0] = records per KV head; sched[0] = workgroups-done counter at +64;
 //                       8 ticket counters at +512 + 256 k (one cache line each; workgroup b uses k = b % 8)
 //   records     (cap+1) x 2048 B (stage1_stream.h PLAN_*), cap = units-per-head capacity
-//   unit list   5 x cap int32 (src, aux, pass, flags, prow)
+//   unit list   17 x cap int32 (src, aux, pass, flags, prow; tile-parallel order: perm, chunk tiles, first follower; union groups: n, 4 queries, 4 rows)
 //   row_q       rows int32 : partial row -> query row
 struct PlanView {
     int32_t* hdr;
     int32_t* sched;
     char* records;
-    int32_t* units;  // 5 arrays of `cap`
+    int32_t* units;  // 17 arrays of `cap`
     int32_t* row_q;
     int64_t cap;
     size_t bytes;
@@ -77,7 +77,7 @@ inline PlanView plan_view(void* base, int64_t cap, int64_t rows) {
     v.records = p + off;
     off = align_up(off + 2048 * (size_t)(cap + 1), 256);
     v.units = reinterpret_cast<int32_t*>(p + off);
-    off = align_up(off + sizeof(int32_t) * 5 * (size_t)(cap > 0 ? cap : 1), 256);
+    off = align_up(off + sizeof(int32_t) * 17 * (size_t)(cap > 0 ? cap : 1), 256);
     v.row_q = reinterpret_cast<int32_t*>(p + off);
     off = align_up(off + sizeof(int32_t) * (size_t)(rows > 0 ? rows : 1), 256);
     v.bytes = off;

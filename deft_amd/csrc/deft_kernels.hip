@@ -292,6 +292,7 @@ __global__ __launch_bounds__(256, 2) void stage1_kernel(Stage1Params p) {
 
 }  // namespace deft
 #include "stage1_stream.h"
+#include "stage1_np.h"
 namespace deft {
 
 // ---------------------------------------------------------------------------
@@ -556,7 +557,32 @@ static UnitList unit_list(const PlanView& pv) {
     ul.pass = pv.units + 2 * pv.cap;
     ul.flags = pv.units + 3 * pv.cap;
     ul.prow = pv.units + 4 * pv.cap;
+    ul.perm = pv.units + 5 * pv.cap;
+    ul.ch_n = pv.units + 6 * pv.cap;
+    ul.ch_fb = pv.units + 7 * pv.cap;
+    ul.gn = pv.units + 8 * pv.cap;
+    ul.gq = pv.units + 9 * pv.cap;
+    ul.grow = pv.units + 13 * pv.cap;
     return ul;
+}
+
+// Which stage-1 form serves head_dim 128: 1 = tile-parallel (stage1_np.h), 0 = streaming (stage1_stream.h).
+// The plan's record order depends on it, so the answer must be the same when a plan is built and when it is used:
+// it is a function of the environment only (read at every call so that one process can A/B both forms; callers
+// that cache plans key them by deft_stage1_kind()).
+static int stage1_kind() {
+    const char* e = getenv("DEFT_STAGE1_KERNEL");
+    if (e && !strcmp(e, "stream")) return 0;
+    if (e && !strcmp(e, "np")) return 1;
+    return 0;
+}
+static int np_chunk_env() {
+    const char* e = getenv("DEFT_NP_CHUNK");
+    return e ? atoi(e) : 0;
+}
+static int np_union_env() {  // tiles per union group of leaf tiles (1 = off)
+    const char* e = getenv("DEFT_NP_UNION");
+    return e ? atoi(e) : 4;
 }
 
 // Flatten plan: unit list (one workgroup) then one record per unit.
@@ -568,13 +594,14 @@ static int launch_plan(const Stage1Params& p, int NB, const PlanView& pv, const 
         return DEFT_EUNSUPPORTED;
     }
     const UnitList ul = unit_list(pv);
+    const int np = stage1_kind();
     hipLaunchKernelGGL(flatten_units_kernel, dim3(1), dim3(256), lds, stream, p.block_q, p.block_q_cnts, p.block_q_offset, NB,
-                       p.G, (int)pv.cap, ul, pv.hdr, pv.sched);
+                       p.G, (int)pv.cap, ul, pv.hdr, pv.sched, np, p.Hkv, 2 * num_cus(), np_chunk_env(), np ? np_union_env() : 1);
     int rc = check_launch("flatten units launch");
     if (rc) return rc;
     hipLaunchKernelGGL(flatten_records_kernel, dim3((unsigned)(pv.cap + 1)), dim3(128), 0, stream, p.block_q, p.block_q_cnts,
                        p.block_bitmasks, p.block_kv, p.block_lens, p.G, (int)p.rows, p.q_st, p.q_sh, p.kv_ss, ul, pv.hdr,
-                       pv.records, pv.row_q, ap.cache_loc, ap.n_new, ap.new_st * 2);
+                       pv.records, pv.row_q, ap.cache_loc, ap.n_new, ap.new_st * 2, np);
     return check_launch("flatten records launch");
 }
 
@@ -616,6 +643,46 @@ static int launch_stage1_stream(const Stage1Params& p, int64_t unit_cap, const P
     sp.n_new = ap.k_new ? ap.n_new : 0;
     hipLaunchKernelGGL((stage1_stream_kernel<128>), dim3((unsigned)workers), dim3(512), SM::BYTES, stream, sp);
     return check_launch("stage1 stream launch");
+}
+
+// Stage 1, tile-parallel form (head_dim 128): one workgroup per record slot and KV head; slots that are not
+// chunk leaders exit at once (they are at the end of the grid).
+static int launch_stage1_np(const Stage1Params& p, int64_t unit_cap, const PlanView& pv, const AppendArgs& ap,
+                            hipStream_t stream) {
+    using SM = NpSmem<128>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&stage1_np_kernel<128>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, SM::BYTES);
+        if (e != hipSuccess) {
+            set_error("hipFuncSetAttribute(stage1_np): %s", hipGetErrorString(e));
+            return DEFT_EHIP;
+        }
+        attr_set = true;
+    }
+    if (unit_cap <= 0) return DEFT_OK;
+    int64_t grid = unit_cap * p.Hkv;
+    if (grid > 0x7fffffffLL) {
+        set_error("stage1 grid too large: %lld", (long long)grid);
+        return DEFT_EINVAL;
+    }
+    if (getenv("DEFT_NP_GRID")) grid = (int64_t)atoi(getenv("DEFT_NP_GRID")) * p.Hkv;  // experiments: exact leader count
+    NpParams npp{};
+    npp.s = p;
+    npp.s.ablate = getenv("DEFT_STAGE1_ABLATE") ? atoi(getenv("DEFT_STAGE1_ABLATE")) : 0;
+    npp.plan = pv.records;
+    npp.k_new = ap.k_new;
+    npp.v_new = ap.v_new;
+    npp.cache_loc = ap.cache_loc;
+    npp.new_st = ap.new_st;
+    npp.n_new = ap.k_new ? ap.n_new : 0;
+    hipLaunchKernelGGL((stage1_np_kernel<128>), dim3((unsigned)grid), dim3(256), SM::BYTES, stream, npp);
+    return check_launch("stage1 np launch");
+}
+
+static int launch_stage1_d128(const Stage1Params& p, int64_t unit_cap, const PlanView& pv, const AppendArgs& ap,
+                              hipStream_t stream) {
+    return stage1_kind() ? launch_stage1_np(p, unit_cap, pv, ap, stream) : launch_stage1_stream(p, unit_cap, pv, ap, stream);
 }
 
 template <int MODE>
@@ -679,6 +746,8 @@ using namespace deft;
 extern "C" {
 
 int deft_abi_version(void) { return 1; }
+
+int deft_stage1_kind(void) { return stage1_kind(); }
 
 // Internal profiling hook (not part of the public header): device buffer of
 // workers*16*8 u64 receiving s_memtime stamps of the streaming kernel's phases.
@@ -770,7 +839,7 @@ static int flatten_stage1_impl(const void* q, int64_t q_stride_tok, int64_t q_st
             if (rc) return rc;
         }
         *row_q_out = pv.row_q;
-        return launch_stage1_stream(p, cap, pv, ap, st);
+        return launch_stage1_d128(p, cap, pv, ap, st);
     }
     if (ap.k_new) {  // tile-per-workgroup form: separate append launch first
         rc = deft_kv_append_f16(const_cast<void*>(k_base), const_cast<void*>(v_base), kv_stride_slot, kv_stride_head,
@@ -810,6 +879,7 @@ int deft_flatten_build_plan(const int64_t* block_q, const int64_t* block_q_cnts,
     p.block_lens = block_lens;
     p.rows = P;
     p.G = Hq / Hkv;
+    p.Hkv = Hkv;
     p.q_st = q_stride_tok;
     p.q_sh = q_stride_head;
     p.kv_ss = kv_stride_slot;
@@ -898,13 +968,14 @@ int deft_flatten_decode_append_f16(const void* q, int64_t q_stride_tok, int64_t 
 static int launch_node_plan(const Stage1Params& p, int NE, int64_t rows_cap, const PlanView& pv, const AppendArgs& ap,
                             hipStream_t stream) {
     const UnitList ul = unit_list(pv);
+    const int np = stage1_kind();
     hipLaunchKernelGGL(node_units_kernel, dim3(1), dim3(256), 0, stream, p.node_kv_len, p.node_q_len, NE, p.G, (int)pv.cap,
-                       rows_cap, ul, pv.hdr, pv.sched, pv.row_q);
+                       rows_cap, ul, pv.hdr, pv.sched, pv.row_q, np, p.Hkv, 2 * num_cus(), np_chunk_env());
     int rc = check_launch("node units launch");
     if (rc) return rc;
     hipLaunchKernelGGL(node_records_kernel, dim3((unsigned)(pv.cap + 1)), dim3(128), 0, stream, p.node_kv, p.node_kv_offset,
                        p.node_kv_len, p.node_q, p.node_q_offset, p.node_q_len, p.G, (int)p.rows, p.q_st, p.q_sh, p.kv_ss, ul,
-                       pv.hdr, pv.records, pv.row_q, ap.cache_loc, ap.n_new, ap.new_st * 2);
+                       pv.hdr, pv.records, pv.row_q, ap.cache_loc, ap.n_new, ap.new_st * 2, np);
     return check_launch("node records launch");
 }
 
@@ -941,6 +1012,7 @@ int deft_node_build_plan(const int64_t* node_kv, const int64_t* node_kv_offset, 
     p.node_q_len = node_q_len;
     p.rows = rows;
     p.G = Hq / Hkv;
+    p.Hkv = Hkv;
     p.q_st = q_stride_tok;
     p.q_sh = q_stride_head;
     p.kv_ss = kv_stride_slot;
@@ -1020,7 +1092,7 @@ static int node_decode_impl(const void* q, int64_t q_stride_tok, int64_t q_strid
             rc = launch_node_plan(p, NE, rows, pv, ap, st);
             if (rc) return rc;
         }
-        rc = launch_stage1_stream(p, tiles * G, pv, ap, st);
+        rc = launch_stage1_d128(p, tiles * G, pv, ap, st);
         if (rc) return rc;
         return launch_merge(D, ws, pv.row_q, rows, out, o_stride_tok, o_stride_head, nq, Hq, st);
     }

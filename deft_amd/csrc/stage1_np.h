@@ -1,0 +1,344 @@
+// Stage 1 (Flatten and Node), tile-parallel form: one workgroup per CHUNK of KV tiles, two workgroups per CU,
+// placed by the hardware dispatcher.
+//
+// Included by deft_kernels.hip after stage1_stream.h (shares its plan records, dma16, wait_vm, lds_barrier).
+//
+// The streaming form (stage1_stream.h) reaches the practical HBM rate in its steady state but pays ~8 us per launch
+// around it: a dependent ramp, and a tail in which persistent workgroups that prefetch five tiles ahead cannot
+// rebalance.  A plain gather dispatched by the hardware (tools/probes/gather_dma.hip) has neither.  This kernel keeps
+// that shape and still folds the shared prefix:
+//
+//   * a workgroup = 4 waves = one chunk: a leader record and its followers (np_record_order), all tiles of ONE run,
+//     i.e. with one query list, taken at a stride through the run;
+//   * every wave is its own pipeline.  Wave w stages keys [32w, 32w+32) of the tile -- 8 KB of K and 8 KB of V --
+//     into its private LDS slices with global_load_lds_dwordx4 and consumes exactly those rows, so there is no
+//     barrier between load and use, only its own counted s_waitcnt.  K(i+1) is issued as soon as QK^T(i) is done,
+//     V(i+1) after PV(i);
+//   * the softmax is wave-private as well: S^T = K Q^T puts the wave's 32 keys on the MFMA M dimension, so a lane
+//     holds 16 key scores of one query; P^T (fp16) stays in registers and IS the B operand of O^T += V^T P^T
+//     (the contraction order of keys is permuted identically on the V^T side, read with ds_read_b64_tr_b16);
+//     each wave keeps (m, l, O[128 x 32]) for its key subset over the whole chunk;
+//   * at the end the four waves merge their states through LDS (two barriers per WORKGROUP, not per tile) and write
+//     one normalised partial row per virtual query row; the rows of follower tiles are dead in the plan (row_q = -1);
+//   * no record staging: a workgroup's record index is its block index, so the descriptor (scalar load), the row
+//     offsets and masks (4-byte LDS-DMA into a per-wave area) and nothing else stand between launch and the first
+//     K/V request.  Records beyond the leaders exit at once; they sit at the end of the grid.
+#pragma once
+
+namespace deft {
+
+struct NpParams {
+    Stage1Params s;
+    const char* plan;  // [cap+1][PLAN_BYTES], leaders first (np_record_order)
+    // fused paged append (optional), as in StreamParams
+    const _Float16* k_new;
+    const _Float16* v_new;
+    const int32_t* cache_loc;
+    int64_t new_st;
+    int n_new;
+};
+
+template <int D>
+struct NpSmem {
+    static constexpr int SLICE = 32 * D * 2;            // one wave's 32 keys of K (or V)
+    static constexpr int K_OFF = 0;                     // [4][SLICE]
+    static constexpr int V_OFF = 4 * SLICE;             // [4][SLICE]
+    static constexpr int Q_OFF = 8 * SLICE;             // Q rows [32][D] fp16, chunks XOR-ed by (row & 15)
+    static constexpr int AUX_OFF = Q_OFF + MQ * D * 2;  // per wave 2 slots x 512 B: int64 rowoff[32] | u32 vmask[32] | i32 qsrc[32]
+    static constexpr int AUX_SLOT = 512;
+    static constexpr int X_OFF = AUX_OFF + 4 * 2 * AUX_SLOT;  // float m[4][32], l[4][32]
+    static constexpr int OROW_OFF = X_OFF + 2 * 4 * MQ * 4;   // int32 orow[32] of the leader record
+    static constexpr int BYTES = OROW_OFF + MQ * 4;
+    static_assert(2 * BYTES <= 160 * 1024, "two workgroups per CU");
+};
+
+// 64 lanes x 4 bytes, global (per-lane address) -> LDS (lds_dst + 4*lane)
+__device__ __forceinline__ void dma4(const void* gsrc, uint32_t lds_dst) {
+    asm volatile(
+        "s_mov_b32 m0, %1\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dword %0, off"
+        :
+        : "v"(gsrc), "s"(lds_dst)
+        : "memory");
+}
+
+template <int D>
+__global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
+    constexpr int KS = D / 16;
+    constexpr int LPT = 32 * (D / 8) / 64;  // DMA instructions per wave per K (or V) slice
+    static_assert(D == 128 && LPT == 8, "tile-parallel stage 1 is instantiated for head_dim 128");
+    using SM = NpSmem<D>;
+    const Stage1Params& p = np.s;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l = tid & 63;
+    const int c = l & 31;
+    const int h = l >> 5;
+    const int bid = blockIdx.x;
+    const int rec0 = bid / p.Hkv;  // head fastest: neighbours in the grid share a record and a stretch of the pool
+    const int kvh = bid - rec0 * p.Hkv;
+
+    // ---- fused paged append: new-token row j is copied into the pool by workgroup (grid-1-j) % grid -- the end of
+    //      the grid is unused record capacity (nobody reads those pool rows in this launch: rows flagged NEW in the
+    //      plan are taken from k_new / v_new) ------------------------------------------------------------------
+    for (int copy_job = (int)gridDim.x - 1 - bid; copy_job < np.n_new; copy_job += (int)gridDim.x) {
+        const int64_t dst = (int64_t)np.cache_loc[copy_job] * p.kv_ss;
+        const int chunks = p.Hkv * (D / 8);
+        for (int i = tid; i < chunks; i += blockDim.x) {
+            const int hd = i / (D / 8), ch = i - hd * (D / 8);
+            const int64_t so = (int64_t)copy_job * np.new_st + hd * D + ch * 8;
+            const int64_t d_o = dst + (int64_t)hd * p.kv_sh + ch * 8;
+            const uintx4 kk = *reinterpret_cast<const uintx4*>(np.k_new + so);
+            const uintx4 vv = *reinterpret_cast<const uintx4*>(np.v_new + so);
+            *reinterpret_cast<uintx4*>(const_cast<_Float16*>(p.k) + d_o) = kk;
+            *reinterpret_cast<uintx4*>(const_cast<_Float16*>(p.v) + d_o) = vv;
+        }
+    }
+
+    const char* rec_lead = np.plan + (int64_t)rec0 * PLAN_BYTES;
+    const int32_t* desc0 = reinterpret_cast<const int32_t*>(rec_lead + PLAN_DESC);
+    const int n = __builtin_amdgcn_readfirstlane(desc0[4]);  // tiles of this chunk; 0 = follower / unused record
+    if (n <= 0) return;
+    const int nv = __builtin_amdgcn_readfirstlane(desc0[0]);
+    const int fb = __builtin_amdgcn_readfirstlane(desc0[5]);
+    auto rec_of = [&](int i) { return np.plan + (int64_t)(i == 0 ? rec0 : fb + i - 1) * PLAN_BYTES; };
+
+    // leader's partial rows (one per virtual query row), parked in LDS for the epilogue.  Issued and consumed before
+    // any asm DMA so that the compiler's own s_waitcnt for it cannot stall behind K/V traffic.
+    if (w == 0 && l < MQ) {
+        reinterpret_cast<int32_t*>(smem + SM::OROW_OFF)[l] = reinterpret_cast<const int32_t*>(rec_lead + PLAN_OROW)[l];
+    }
+
+    // ---- loop-invariant lane constants (same LDS layouts as stage1_stream.h) ----------------
+    const int dpos = l & 15, dkey = l >> 4;
+    int kchunk_b[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) kchunk_b[j] = ((dpos ^ dkey) ^ (4 * j)) * 16;
+    const int vchunk_b = (dpos ^ (4 * (dkey & 3))) * 16;
+    const uint32_t ldsK = SM::K_OFF + (uint32_t)w * SM::SLICE;
+    const uint32_t ldsV = SM::V_OFF + (uint32_t)w * SM::SLICE;
+    const uint32_t aux0 = SM::AUX_OFF + (uint32_t)w * 2u * SM::AUX_SLOT;
+    // S^T A fragments: key row c of this wave's slice, chunk (2ks + h) ^ (c & 15)
+    const int krow_b = SM::K_OFF + w * SM::SLICE + c * D * 2;
+    const int kcol_b = ((h ^ c) & 15) * 16;
+    // O^T A fragments (transpose reads).  MFMA k-index 8h' + e of k-step t is key 16t + 4h' + e (e < 4) and
+    // 16t + 8 + 4h' + (e - 4): exactly the keys whose probabilities lane (c, h') holds in acc registers 8t .. 8t+7.
+    // Lane (tg = l>>4, tx = l&15) addresses row 4(tg>>1) + (tx>>2) [+16t, +8], columns 32 blk + 16(tg&1) + 4(tx&3),
+    // 16-byte chunk XOR-ed by 4*(row & 3) = 4*(tx>>2).
+    const int tg = l >> 4, tx = l & 15;
+    const int vtr_row_b = SM::V_OFF + w * SM::SLICE + (4 * (tg >> 1) + (tx >> 2)) * D * 2 + (tx & 1) * 8;
+    int vtr_col_b[4];
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk) vtr_col_b[blk] = (4 * (blk ^ (tx >> 2)) + 2 * (tg & 1) + ((tx & 3) >> 1)) * 16;
+
+    constexpr int64_t NEW_ROW = (int64_t)1 << 63;
+    const char* kb_pool = reinterpret_cast<const char*>(p.k) + (int64_t)kvh * p.kv_sh * 2;
+    const char* vb_pool = reinterpret_cast<const char*>(p.v) + (int64_t)kvh * p.kv_sh * 2 + vchunk_b;
+    const char* kb_new = reinterpret_cast<const char*>(np.k_new) + (int64_t)kvh * D * 2;
+    const char* vb_new = reinterpret_cast<const char*>(np.v_new) + (int64_t)kvh * D * 2 + vchunk_b;
+
+    int64_t rowoff[LPT];
+    auto issue_aux = [&](int i, int slot) {  // 2 DMA: this wave's 32 row offsets; its 32 key masks | the 32 q offsets
+        const char* rec = rec_of(i);
+        dma4(rec + PLAN_ROWOFF + 32 * w * 8 + 4 * l, aux0 + (uint32_t)slot * SM::AUX_SLOT);
+        const char* src2 = (l < 32) ? rec + PLAN_MASK + (32 * w + l) * 4 : rec + PLAN_QSRC + (l - 32) * 4;
+        dma4(src2, aux0 + (uint32_t)slot * SM::AUX_SLOT + 256u);
+    };
+    auto load_rowoff = [&](int slot) {
+        const int64_t* ro = reinterpret_cast<const int64_t*>(smem + aux0 + slot * SM::AUX_SLOT);
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) rowoff[i] = ro[4 * i + dkey];
+    };
+    auto issue_k = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of the slice being overwritten
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) {
+            const char* src = rowoff[i] < 0 ? kb_new + (rowoff[i] & ~NEW_ROW) : kb_pool + rowoff[i];
+            dma16(src + kchunk_b[i & 3], ldsK + (uint32_t)i * 1024u);
+        }
+    };
+    auto issue_v = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < LPT; ++i)
+            dma16(rowoff[i] < 0 ? vb_new + (rowoff[i] & ~NEW_ROW) : vb_pool + rowoff[i], ldsV + (uint32_t)i * 1024u);
+    };
+    auto issue_q = [&]() {  // rows 8w .. 8w+7 of the shared Q buffer, offsets from aux slot 0
+        const int32_t* qs = reinterpret_cast<const int32_t*>(smem + aux0 + 256 + 128);
+        const char* hb = reinterpret_cast<const char*>(p.q) + (int64_t)kvh * p.G * p.q_sh * 2;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = 8 * w + 4 * i + dkey;
+            const int chunk = dpos ^ (row & 15);
+            dma16(hb + (int64_t)qs[row] * 2 + chunk * 16, SM::Q_OFF + (uint32_t)(8 * w + 4 * i) * 256u);
+        }
+    };
+
+    // ---- prologue: aux(0) -> Q, K(0), aux(1), V(0) -----------------------------------------------------
+    issue_aux(0, 0);
+    wait_vm<0>();
+    load_rowoff(0);
+    issue_q();
+    issue_k();
+    if (n > 1) issue_aux(1, 1);
+    issue_v();
+
+    half8 qf[KS];
+    float m_run = -INFINITY, l_run = 0.f;
+    floatx16 o[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[b][r] = 0.f;
+
+    for (int i = 0; i < n; ++i) {
+        const bool has1 = i + 1 < n, has2 = i + 2 < n;
+        const int slot = i & 1;
+        // ---- K(i) (and Q) landed: younger than it are aux(i+1) [2] and V(i) [8] -------------------------
+        if (has1) wait_vm<LPT + 2>();
+        else wait_vm<LPT>();
+        if (i == 0) {
+            lds_barrier();  // Q rows of all four waves visible
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                qf[ks] = *reinterpret_cast<const half8*>(smem + SM::Q_OFF + c * D * 2 + (((2 * ks + h) ^ (c & 15)) * 16));
+        }
+        // key masks of this lane's 16 keys (keys 8 g4 + 4 h + j of the wave's 32)
+        uintx4 m4[4];
+        {
+            const uint32_t* masks = reinterpret_cast<const uint32_t*>(smem + aux0 + slot * SM::AUX_SLOT + 256);
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) m4[g4] = *reinterpret_cast<const uintx4*>(masks + 8 * g4 + 4 * h);
+        }
+        // ---- S^T for this wave's 32 keys ---------------------------------------------------------------
+        floatx16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        if (!(p.ablate & 1)) {  // profiling knob (env DEFT_STAGE1_ABLATE): 1 skip QK^T, 4 skip PV, 16 skip the epilogue
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const half8 a = *reinterpret_cast<const half8*>(smem + krow_b + (kcol_b ^ (32 * ks)));
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qf[ks], acc, 0, 0, 0);
+            }
+        }
+        float s[16];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = 4 * g4 + j;
+                s[r] = ((m4[g4][j] >> c) & 1u) ? acc[r] * p.scale_log2e : -INFINITY;
+                mx = fmaxf(mx, s[r]);
+            }
+        // ---- the K slice is free: next tile's row offsets -> K(i+1), aux(i+2) ---------------------------
+        if (has1) {
+            wait_vm<LPT>();  // aux(i+1) landed (younger: V(i))
+            load_rowoff(slot ^ 1);
+            issue_k();
+            if (has2) issue_aux(i + 2, slot);
+        }
+        // ---- wave-private online softmax ----------------------------------------------------------------
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);
+        const float msafe = (m_new == -INFINITY) ? 0.f : m_new;
+        const float alpha = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run - msafe);
+        half8 pb[2];
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const _Float16 ph = (_Float16)__builtin_amdgcn_exp2f(s[r] - msafe);
+            pb[r >> 3][r & 7] = ph;
+            sum += (float)ph;  // row sums over the ROUNDED probabilities: the weights sum to 1 exactly
+        }
+        sum += __shfl_xor(sum, 32);
+        l_run = l_run * alpha + sum;
+        m_run = m_new;
+        if (i > 0 && __builtin_amdgcn_ballot_w64(alpha != 1.f) != 0ull) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[b][r] *= alpha;
+        }
+        // ---- V(i) landed: younger are K(i+1) [8] and aux(i+2) [2] ---------------------------------------
+        if (has2) wait_vm<LPT + 2>();
+        else if (has1) wait_vm<LPT>();
+        else wait_vm<0>();
+        // ---- O^T += V^T P^T: four 32-column blocks x two 16-key steps ------------------------------------
+        if (!(p.ablate & 4))
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int blk = 0; blk < 4; ++blk) {
+                typedef __attribute__((address_space(3))) short4v* lds_s4;
+                const int vb = vtr_row_b + vtr_col_b[blk] + (16 * t) * D * 2;
+                union {
+                    short4v s4[2];
+                    half8 h8;
+                } av;
+                av.s4[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(uintptr_t)(vb));
+                av.s4[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(uintptr_t)(vb + 8 * D * 2));
+                o[blk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av.h8, pb[t], o[blk], 0, 0, 0);
+            }
+        }
+        if (has1) issue_v();  // V(i+1); rowoff still holds tile i+1's offsets
+    }
+
+    if (p.ablate & 16) return;
+    // ---- epilogue: merge the four waves' (m, l, O) and write one partial row per virtual query row.  ONE barrier:
+    //      every wave parks its unscaled O (and m, l) in its own slices -- nobody else ever touched them -- and
+    //      the readers rescale while they sum.  Rows of follower tiles are dead by construction: the plan gave
+    //      them row_q = -1, so nothing is written for them.
+    float* xm = reinterpret_cast<float*>(smem + SM::X_OFF);
+    float* xl = xm + 4 * MQ;
+    if (h == 0) {
+        xm[w * MQ + c] = m_run;
+        xl[w * MQ + c] = l_run;
+    }
+    // query row c < 16 in the K slice, c >= 16 in the V slice; [row][128] floats, 16-byte chunk index XOR-ed by the row
+    if (c < nv && !(p.ablate & 64)) {
+        char* dst = smem + (c < 16 ? SM::K_OFF : SM::V_OFF) + w * SM::SLICE + (c & 15) * (D * 4);
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k4 = 8 * blk + 2 * j + h;  // d = 32 blk + 8 j + 4 h + (0..3)
+                floatx4 v4 = {o[blk][4 * j], o[blk][4 * j + 1], o[blk][4 * j + 2], o[blk][4 * j + 3]};
+                *reinterpret_cast<floatx4*>(dst + ((k4 ^ c) & 31) * 16) = v4;
+            }
+    }
+    if (!(p.ablate & 64)) lds_barrier();
+    const int64_t head_rows = (int64_t)kvh * p.G * p.rows;
+    const int32_t* orow = reinterpret_cast<const int32_t*>(smem + SM::OROW_OFF);
+    // wave w sums the 16-byte chunks 8w .. 8w+7 of every row: lane = (row within a group of 8, chunk)
+    const int k4 = 8 * w + (l & 7);
+    for (int q0 = 0; q0 < nv; q0 += 8) {
+        const int qr = q0 + (l >> 3);
+        if (qr < nv) {
+            float mw[4];
+#pragma unroll
+            for (int ww = 0; ww < 4; ++ww) mw[ww] = xm[ww * MQ + qr];
+            const float M = fmaxf(fmaxf(mw[0], mw[1]), fmaxf(mw[2], mw[3]));
+            float L = 0.f;
+            floatx4 a = {0.f, 0.f, 0.f, 0.f};
+            const int off = (qr < 16 ? SM::K_OFF : SM::V_OFF) + (qr & 15) * (D * 4) + ((k4 ^ qr) & 31) * 16;
+#pragma unroll
+            for (int ww = 0; ww < 4; ++ww) {
+                const float f = (mw[ww] == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(mw[ww] - M);
+                L += f * xl[ww * MQ + qr];
+                const floatx4 b = *reinterpret_cast<const floatx4*>(smem + off + ww * SM::SLICE);
+                a += b * f;
+            }
+            const float inv = L > 0.f ? 1.f / L : 0.f;
+            const int64_t row = head_rows + orow[qr];
+            if (p.ablate & 32) continue;
+            *reinterpret_cast<floatx4*>(p.partial_o + row * D + 4 * k4) = a * inv;
+            if (k4 == 0) p.partial_lse[row] = (L > 0.f) ? (M + __builtin_amdgcn_logf(L)) * LN2 : -INFINITY;
+        }
+    }
+}
+
+}  // namespace deft

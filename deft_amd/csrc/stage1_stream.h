@@ -42,7 +42,7 @@ typedef short short4v __attribute__((ext_vector_type(4)));
 constexpr int PLAN_BYTES = 2048;
 constexpr int PLAN_ROWOFF = 0;   // int64[128]  byte offset of each slot's row in the pool (pads alias slot 0)
 constexpr int PLAN_MASK = 1024;  // uint32[128] bit v set <=> virtual row v sees the slot (0 for pads)
-constexpr int PLAN_DESC = 1536;  // int32[4]    n_vrows, prow, opens_run, run_id
+constexpr int PLAN_DESC = 1536;  // int32[8]    n_vrows, prow, opens_run, run_id, chunk tiles (0 = follower), first follower record, -, -
 constexpr int PLAN_QSRC = 1600;  // int32[32]   element offset of row v's Q vector from q + kvh*G*q_stride_head
 constexpr int PLAN_OROW = 1728;  // int32[32]   partial row of row v, relative to kvh*G*rows: g*rows + prow + qi
 constexpr int PLAN_HDR = 4096;   // plan header: int32 R (records per head) at +0, done counter at +64, ticket counters
@@ -578,13 +578,83 @@ struct UnitList {   // all int32, capacity `cap` each
     int32_t* pass;  // 32-row pass of the unit's virtual query rows
     int32_t* flags; // bit 0: opens a run (query list differs from the previous unit's); bits 1..: unit index of the run's first unit
     int32_t* prow;  // first partial row of the unit's tile
+    // tile-parallel record order (stage1_np.h), indexed by RECORD: which unit the record packs, and its chunk
+    int32_t* perm;   // record -> unit
+    int32_t* ch_n;   // tiles of the chunk this record leads (itself included); 0 = follower
+    int32_t* ch_fb;  // record index of the chunk's first follower (followers are consecutive records)
+    // union groups (Flatten, tile-parallel order), indexed by GROUP id = aux - 1: consecutive leaf tiles whose query
+    // lists differ but are small are folded by ONE workgroup over the union of their queries
+    int32_t* gn;    // queries in the union (<= UNION_CAP)
+    int32_t* gq;    // [UNION_CAP][cap] query rows of the union, ascending
+    int32_t* grow;  // [UNION_CAP][cap] the partial row that carries each union query (its first occurrence in the group)
 };
+constexpr int UNION_CAP = 4;
+
+// Record order for the tile-parallel stage 1 (one workgroup per chunk, stage1_np.h).  A run of `nt` units with
+// one query list is cut into S = ceil(nt / C) chunks; chunk p folds units p, p + S, p + 2S, ... of the run
+// (interleaved: the chunks of a run advance through the pool side by side, one contiguous front).  Records are
+// renumbered: the leaders of all chunks first (run by run, so the long shared-prefix chunks are dispatched first),
+// then the followers, those of one chunk consecutive.  hdr[1] = number of leaders.  One thread.
+__device__ inline void np_record_order(const UnitList& ul, int R, int Hkv, int slots, int chunk_c, int32_t* hdr) {
+    int C = chunk_c;
+    if (C <= 0) {  // the largest chunk that still leaves >= 3 workgroups per resident slot
+        C = 1;
+        for (int cand = 8; cand > 1; cand >>= 1) {
+            int64_t n = 0;
+            for (int r = 0; r < R;) {
+                const int id = ul.flags[r] >> 1;
+                int e = r + 1;
+                while (e < R && (ul.flags[e] >> 1) == id) ++e;
+                n += ul.aux[r] > 0 ? 1 : (e - r + cand - 1) / cand;
+                r = e;
+            }
+            if (n * Hkv >= 3LL * slots) {
+                C = cand;
+                break;
+            }
+        }
+    }
+    int NL = 0;
+    for (int r = 0; r < R;) {
+        const int id = ul.flags[r] >> 1;
+        int e = r + 1;
+        while (e < R && (ul.flags[e] >> 1) == id) ++e;
+        NL += ul.aux[r] > 0 ? 1 : (e - r + C - 1) / C;
+        r = e;
+    }
+    int li = 0, fi = NL;
+    for (int r = 0; r < R;) {
+        const int id = ul.flags[r] >> 1;
+        int e = r + 1;
+        while (e < R && (ul.flags[e] >> 1) == id) ++e;
+        const int nt = e - r, S = ul.aux[r] > 0 ? 1 : (nt + C - 1) / C;  // a union group (Flatten aux > 0) is one chunk
+        for (int p = 0; p < S; ++p) {
+            const int cnt = (nt - p + S - 1) / S;
+            ul.perm[li] = r + p;
+            ul.ch_n[li] = cnt;
+            ul.ch_fb[li] = fi;
+            ++li;
+            for (int j = 1; j < cnt; ++j, ++fi) {
+                ul.perm[fi] = r + p + j * S;
+                ul.ch_n[fi] = 0;
+                ul.ch_fb[fi] = 0;
+            }
+        }
+        r = e;
+    }
+    hdr[1] = NL;
+}
 
 // Flatten: one workgroup.  Phase 1 (parallel over blocks): does block t open a run, how many passes.
 // Phase 2 (one thread): emit units run by run, pass-major inside a run so that consecutive units fold.
+// Tile-parallel order only (union_len > 1): short runs of leaf tiles with small, different query lists -- a branch's
+// tail shares a block with the next branch's head, so their lists go {a}, {a,b}, {b}, {b,c} ... -- are grouped, up
+// to union_len tiles and UNION_CAP queries, into ONE run over the union of their queries (per-slot masks keep a
+// query away from keys that are not on its path), so that one workgroup folds them and writes one partial per query.
 __global__ __launch_bounds__(256) void flatten_units_kernel(const int64_t* block_q, const int64_t* block_q_cnts,
                                                             const int64_t* block_q_offset, int NB, int G, int cap,
-                                                            UnitList ul, int32_t* hdr, int32_t* sched) {
+                                                            UnitList ul, int32_t* hdr, int32_t* sched, int np, int Hkv,
+                                                            int slots, int chunk_c, int union_len) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int* sOpen = reinterpret_cast<int*>(smem);  // [NB]
     int* sPass = sOpen + NB;                    // [NB]
@@ -601,12 +671,61 @@ __global__ __launch_bounds__(256) void flatten_units_kernel(const int64_t* block
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        int r = 0;
+        int r = 0, ng = 0;
+        const int ucap = (UNION_CAP * G <= MQ) ? UNION_CAP : MQ / G;  // union queries whose virtual rows fit one pass
         for (int ta = 0; ta < NB;) {
             int tb = ta + 1;
             while (tb < NB && !sOpen[tb]) ++tb;
-            const int np = sPass[ta];
-            for (int ps = 0; ps < np; ++ps) {
+            const int passes = sPass[ta];
+            const int cnt_a = (int)block_q_cnts[ta];
+            if (np && union_len > 1 && ucap >= 2 && cnt_a <= ucap && tb - ta < union_len && r < cap) {
+                // ---- union group starting at ta ----------------------------------------------------
+                int uq[UNION_CAP], urow[UNION_CAP], un = 0;
+                int te = ta;
+                while (te < NB && te - ta < union_len && r + (te - ta) < cap) {
+                    const int cnt = (int)block_q_cnts[te];
+                    if (cnt > ucap) break;
+                    const int64_t off = block_q_offset[te];
+                    int add = 0;  // queries of block te that are new to the union
+                    for (int i = 0; i < cnt; ++i) {
+                        const int qv = (int)block_q[off + i];
+                        bool found = false;
+                        for (int j = 0; j < un; ++j) found |= (uq[j] == qv);
+                        add += found ? 0 : 1;
+                    }
+                    if (un + add > ucap) break;
+                    for (int i = 0; i < cnt; ++i) {
+                        const int qv = (int)block_q[off + i];
+                        bool found = false;
+                        for (int j = 0; j < un; ++j) found |= (uq[j] == qv);
+                        if (!found) {  // first occurrence: this tile's row carries the query's partial
+                            uq[un] = qv;
+                            urow[un] = (int)off + i;
+                            ++un;
+                        }
+                    }
+                    ++te;
+                }
+                if (te - ta >= 2) {
+                    ul.gn[ng] = un;
+                    for (int j = 0; j < UNION_CAP; ++j) {
+                        ul.gq[j * cap + ng] = j < un ? uq[j] : 0;
+                        ul.grow[j * cap + ng] = j < un ? urow[j] : 0;
+                    }
+                    const int first = r;
+                    for (int t = ta; t < te; ++t, ++r) {
+                        ul.src[r] = t;
+                        ul.aux[r] = ng + 1;
+                        ul.pass[r] = 0;
+                        ul.flags[r] = (first << 1) | ((t == ta) ? 1 : 0);
+                        ul.prow[r] = (int)block_q_offset[t];
+                    }
+                    ++ng;
+                    ta = te;
+                    continue;
+                }
+            }
+            for (int ps = 0; ps < passes; ++ps) {
                 const int first = r;
                 for (int t = ta; t < tb && r < cap; ++t, ++r) {
                     ul.src[r] = t;
@@ -619,8 +738,10 @@ __global__ __launch_bounds__(256) void flatten_units_kernel(const int64_t* block
             ta = tb;
         }
         hdr[0] = r;
+        hdr[1] = 0;
         sched[0] = 0;
         for (int k = 0; k < NTICKET; ++k) sched[ticket_word(k)] = 0;
+        if (np) np_record_order(ul, r, Hkv, slots, chunk_c, hdr);
     }
 }
 
@@ -630,15 +751,19 @@ __global__ __launch_bounds__(128) void flatten_records_kernel(const int64_t* blo
                                                               const int64_t* block_lens, int G, int rows, int64_t q_st,
                                                               int64_t q_sh, int64_t kv_stride_slot, UnitList ul,
                                                               const int32_t* hdr, char* plan, int32_t* row_q,
-                                                              const int32_t* cache_loc, int n_new, int64_t new_row_bytes) {
+                                                              const int32_t* cache_loc, int n_new, int64_t new_row_bytes,
+                                                              int np) {
     const int r = blockIdx.x;
     const int k = threadIdx.x;
     const int R = hdr[0];
-    if (r > R) return;
     char* rec = plan + (int64_t)r * PLAN_BYTES;
     int64_t* ro = reinterpret_cast<int64_t*>(rec + PLAN_ROWOFF);
     uint32_t* mk = reinterpret_cast<uint32_t*>(rec + PLAN_MASK);
     int32_t* desc = reinterpret_cast<int32_t*>(rec + PLAN_DESC);
+    if (r > R) {  // unused capacity: a tile-parallel workgroup that lands here must see "not a chunk leader"
+        if (k == 0) desc[4] = 0;
+        return;
+    }
     if (r == R) {  // sentinel
         ro[k] = 0;
         mk[k] = 0u;
@@ -647,18 +772,58 @@ __global__ __launch_bounds__(128) void flatten_records_kernel(const int64_t* blo
             desc[1] = 0;
             desc[2] = 1;
             desc[3] = -1;
+            desc[4] = 0;
         }
         return;
     }
-    const int t = ul.src[r];
-    const int ps = ul.pass[r];
-    const int prow = ul.prow[r];
+    const int u = np ? ul.perm[r] : r;  // unit packed into this record
+    const int t = ul.src[u];
+    const int ps = ul.pass[u];
+    const int prow = ul.prow[u];
     const int len = (int)block_lens[t];
     const int cnt = (int)block_q_cnts[t];
-    const int nv = min(MQ, cnt * G - MQ * ps);  // virtual rows of this pass
     const bool live = k < len;
     ro[k] = plan_rowoff(block_kv[(int64_t)t * TILE + (live ? k : 0)], kv_stride_slot, cache_loc, n_new, new_row_bytes);
     const uint32_t qmask = live ? (uint32_t)block_bitmasks[(int64_t)t * TILE + k] : 0u;
+    if (ul.aux[u] > 0) {
+        // ---- member of a union group: virtual row v = (union query v / G, head v % G); a query that is not in
+        //      this block's own list sees none of its slots ------------------------------------------------
+        const int gid = ul.aux[u] - 1;
+        const int cap = (int)(ul.gq - ul.gn);  // arrays are `cap` apart
+        const int un = ul.gn[gid];
+        const int nvu = un * G;
+        uint32_t vmu = 0u;
+        for (int j = 0; j < un; ++j) {
+            const int qv = ul.gq[j * cap + gid];
+            int idx = -1;
+            for (int i = 0; i < cnt; ++i)
+                if ((int)block_q[prow + i] == qv) idx = i;
+            if (idx >= 0 && ((qmask >> idx) & 1u)) vmu |= ((G >= 32 ? 0xffffffffu : ((1u << G) - 1u)) << (j * G));
+        }
+        mk[k] = vmu;
+        if (k < MQ) {
+            const int kk = k < nvu ? k : 0;  // rows beyond the union alias its first row (their mask bits are 0)
+            const int j = kk / G, g = kk % G;
+            reinterpret_cast<int32_t*>(rec + PLAN_QSRC)[k] = (int)(ul.gq[j * cap + gid] * q_st + g * q_sh);
+            reinterpret_cast<int32_t*>(rec + PLAN_OROW)[k] = k < nvu ? g * rows + ul.grow[j * cap + gid] : 0;
+            if (k < cnt) {  // this tile's own partial rows: live iff the group parks a query's partial there
+                int qlive = -1;
+                for (int j2 = 0; j2 < un; ++j2)
+                    if (ul.grow[j2 * cap + gid] == prow + k) qlive = ul.gq[j2 * cap + gid];
+                row_q[prow + k] = qlive;
+            }
+        }
+        if (k == 0) {
+            desc[0] = nvu;
+            desc[1] = prow;
+            desc[2] = ul.flags[u] & 1;
+            desc[3] = ul.flags[u] >> 1;
+            desc[4] = ul.ch_n[r];
+            desc[5] = ul.ch_fb[r];
+        }
+        return;
+    }
+    const int nv = min(MQ, cnt * G - MQ * ps);  // virtual rows of this pass
     uint32_t vm = 0u;
     for (int v = 0; v < nv; ++v) vm |= ((qmask >> ((MQ * ps + v) / G)) & 1u) << v;
     mk[k] = vm;
@@ -673,13 +838,21 @@ __global__ __launch_bounds__(128) void flatten_records_kernel(const int64_t* blo
         }
         reinterpret_cast<int32_t*>(rec + PLAN_QSRC)[k] = qs;
         reinterpret_cast<int32_t*>(rec + PLAN_OROW)[k] = orow;
-        if (ps == 0 && k < cnt) row_q[prow + k] = (int32_t)block_q[prow + k];
+        if (!np) {
+            if (ps == 0 && k < cnt) row_q[prow + k] = (int32_t)block_q[prow + k];
+        } else if (k < nv && (MQ * ps + k) % G == 0) {
+            // tile-parallel order: folding is decided here, so only a chunk leader's rows are live
+            const int qi = (MQ * ps + k) / G;
+            row_q[prow + qi] = ul.ch_n[r] > 0 ? (int32_t)block_q[prow + qi] : -1;
+        }
     }
     if (k == 0) {
         desc[0] = nv;
         desc[1] = prow;
-        desc[2] = ul.flags[r] & 1;
-        desc[3] = ul.flags[r] >> 1;  // run id: tiles with equal ids share one query list and may fold
+        desc[2] = ul.flags[u] & 1;
+        desc[3] = ul.flags[u] >> 1;  // run id: tiles with equal ids share one query list and may fold
+        desc[4] = np ? ul.ch_n[r] : 0;
+        desc[5] = np ? ul.ch_fb[r] : 0;
     }
 }
 
@@ -691,7 +864,8 @@ __global__ __launch_bounds__(128) void flatten_records_kernel(const int64_t* blo
 // has 64 one-token nodes: 2 tiles instead of 64).  A packed unit has aux = -(entries in it).
 __global__ __launch_bounds__(256) void node_units_kernel(const int64_t* node_kv_len, const int64_t* node_q_len, int NE, int G,
                                                          int cap, int64_t rows_cap, UnitList ul, int32_t* hdr,
-                                                         int32_t* sched, int32_t* row_q) {
+                                                         int32_t* sched, int32_t* row_q, int np, int Hkv, int slots,
+                                                         int chunk_c) {
     for (int64_t i = threadIdx.x; i < rows_cap; i += blockDim.x) row_q[i] = -1;
     if (threadIdx.x == 0) {
         int r = 0, rowbase = 0;
@@ -735,8 +909,10 @@ __global__ __launch_bounds__(256) void node_units_kernel(const int64_t* node_kv_
             rowbase += nt * ql;
         }
         hdr[0] = r;
+        hdr[1] = 0;
         sched[0] = 0;
         for (int k = 0; k < NTICKET; ++k) sched[ticket_word(k)] = 0;
+        if (np) np_record_order(ul, r, Hkv, slots, chunk_c, hdr);
     }
 }
 
@@ -745,15 +921,19 @@ __global__ __launch_bounds__(128) void node_records_kernel(const int64_t* node_k
                                                            const int64_t* node_q_offset, const int64_t* node_q_len, int G,
                                                            int rows, int64_t q_st, int64_t q_sh, int64_t kv_stride_slot,
                                                            UnitList ul, const int32_t* hdr, char* plan, int32_t* row_q,
-                                                           const int32_t* cache_loc, int n_new, int64_t new_row_bytes) {
+                                                           const int32_t* cache_loc, int n_new, int64_t new_row_bytes,
+                                                           int np) {
     const int r = blockIdx.x;
     const int k = threadIdx.x;
     const int R = hdr[0];
-    if (r > R) return;
     char* rec = plan + (int64_t)r * PLAN_BYTES;
     int64_t* ro = reinterpret_cast<int64_t*>(rec + PLAN_ROWOFF);
     uint32_t* mk = reinterpret_cast<uint32_t*>(rec + PLAN_MASK);
     int32_t* desc = reinterpret_cast<int32_t*>(rec + PLAN_DESC);
+    if (r > R) {  // unused capacity (see flatten_records_kernel)
+        if (k == 0) desc[4] = 0;
+        return;
+    }
     if (r == R) {  // sentinel
         ro[k] = 0;
         mk[k] = 0u;
@@ -762,10 +942,16 @@ __global__ __launch_bounds__(128) void node_records_kernel(const int64_t* node_k
             desc[1] = 0;
             desc[2] = 1;
             desc[3] = -1;
+            desc[4] = 0;
         }
         return;
     }
-    const int e0 = ul.src[r], aux = ul.aux[r], ps = ul.pass[r], prow = ul.prow[r];
+    const int u = np ? ul.perm[r] : r;  // unit packed into this record
+    if (k == 0) {
+        desc[4] = np ? ul.ch_n[r] : 0;
+        desc[5] = np ? ul.ch_fb[r] : 0;
+    }
+    const int e0 = ul.src[u], aux = ul.aux[u], ps = ul.pass[u], prow = ul.prow[u];
     if (aux < 0) {
         // ---- packed unit: entries e0 .. e0 - aux - 1, each one tile and one pass -------------------------
         const int cnt = -aux;
@@ -815,7 +1001,7 @@ __global__ __launch_bounds__(128) void node_records_kernel(const int64_t* node_k
             desc[0] = vrows;
             desc[1] = prow;
             desc[2] = 1;
-            desc[3] = ul.flags[r] >> 1;
+            desc[3] = ul.flags[u] >> 1;
         }
         return;
     }
@@ -839,13 +1025,18 @@ __global__ __launch_bounds__(128) void node_records_kernel(const int64_t* node_k
         }
         reinterpret_cast<int32_t*>(rec + PLAN_QSRC)[k] = qs;
         reinterpret_cast<int32_t*>(rec + PLAN_OROW)[k] = orow;
-        if (ps == 0 && k < ql) row_q[prow + k] = (int32_t)node_q[q0 + k];
+        if (!np) {
+            if (ps == 0 && k < ql) row_q[prow + k] = (int32_t)node_q[q0 + k];
+        } else if (k < nv && (MQ * ps + k) % G == 0) {
+            const int qi = (MQ * ps + k) / G;
+            row_q[prow + qi] = ul.ch_n[r] > 0 ? (int32_t)node_q[q0 + qi] : -1;
+        }
     }
     if (k == 0) {
         desc[0] = nv;
         desc[1] = prow;
-        desc[2] = ul.flags[r] & 1;
-        desc[3] = ul.flags[r] >> 1;
+        desc[2] = ul.flags[u] & 1;
+        desc[3] = ul.flags[u] >> 1;
     }
 }
 

@@ -56,6 +56,12 @@ extern "C" {
 int deft_abi_version(void);
 const char* deft_last_error(void);
 
+/* Which stage-1 form serves head_dim 128 in this process: 0 = streaming (persistent workgroups), 1 = tile-parallel
+ * (one workgroup per chunk of tiles).  A plan (deft_*_build_plan) is laid out for the form that was current when it
+ * was built; callers that cache plans across calls key them by this value.  It only changes with the environment
+ * variable DEFT_STAGE1_KERNEL (stream | np), which exists for A/B measurements. */
+int deft_stage1_kind(void);
+
 /* 1 if (Hq, Hkv, D) is covered: Hq % Hkv == 0, D in {64, 128}
  * (the reference asserts D in {16,32,64,128}, tree_attention.py:100,305,582). */
 int deft_supported(int Hq, int Hkv, int D);
