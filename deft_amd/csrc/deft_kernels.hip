@@ -574,15 +574,15 @@ static int stage1_kind() {
     const char* e = getenv("DEFT_STAGE1_KERNEL");
     if (e && !strcmp(e, "stream")) return 0;
     if (e && !strcmp(e, "np")) return 1;
-    return 0;
+    return 1;
 }
 static int np_chunk_env() {
     const char* e = getenv("DEFT_NP_CHUNK");
     return e ? atoi(e) : 0;
 }
-static int np_union_env() {  // tiles per union group of leaf tiles (1 = off)
+static int np_union_env() {  // tiles per union group of leaf tiles (1 = off, 0 = chosen by the plan kernel)
     const char* e = getenv("DEFT_NP_UNION");
-    return e ? atoi(e) : 4;
+    return e ? atoi(e) : 0;
 }
 
 // Flatten plan: unit list (one workgroup) then one record per unit.
@@ -596,7 +596,8 @@ static int launch_plan(const Stage1Params& p, int NB, const PlanView& pv, const 
     const UnitList ul = unit_list(pv);
     const int np = stage1_kind();
     hipLaunchKernelGGL(flatten_units_kernel, dim3(1), dim3(256), lds, stream, p.block_q, p.block_q_cnts, p.block_q_offset, NB,
-                       p.G, (int)pv.cap, ul, pv.hdr, pv.sched, np, p.Hkv, 2 * num_cus(), np_chunk_env(), np ? np_union_env() : 1);
+                       p.G, (int)pv.cap, ul, pv.hdr, pv.sched, np, p.Hkv, 2 * num_cus(), np_chunk_env(), np ? np_union_env() : 1,
+                       getenv("DEFT_NP_TAPER") ? atoi(getenv("DEFT_NP_TAPER")) : 0);
     int rc = check_launch("flatten units launch");
     if (rc) return rc;
     hipLaunchKernelGGL(flatten_records_kernel, dim3((unsigned)(pv.cap + 1)), dim3(128), 0, stream, p.block_q, p.block_q_cnts,
@@ -676,6 +677,7 @@ static int launch_stage1_np(const Stage1Params& p, int64_t unit_cap, const PlanV
     npp.cache_loc = ap.cache_loc;
     npp.new_st = ap.new_st;
     npp.n_new = ap.k_new ? ap.n_new : 0;
+    npp.dbg = g_stream_dbg;
     hipLaunchKernelGGL((stage1_np_kernel<128>), dim3((unsigned)grid), dim3(256), SM::BYTES, stream, npp);
     return check_launch("stage1 np launch");
 }

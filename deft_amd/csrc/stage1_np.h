@@ -36,6 +36,7 @@ struct NpParams {
     const int32_t* cache_loc;
     int64_t new_st;
     int n_new;
+    unsigned long long* dbg;  // internal: per-workgroup wall-clock stamps [workgroup][8], or null
 };
 
 template <int D>
@@ -78,6 +79,8 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
     const int c = l & 31;
     const int h = l >> 5;
     const int bid = blockIdx.x;
+    unsigned long long t_start = 0, t_k0 = 0, t_epi = 0;
+    if (np.dbg) t_start = wall_clock64();
     const int rec0 = bid / p.Hkv;  // head fastest: neighbours in the grid share a record and a stretch of the pool
     const int kvh = bid - rec0 * p.Hkv;
 
@@ -201,6 +204,7 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
         if (has1) wait_vm<LPT + 2>();
         else wait_vm<LPT>();
         if (i == 0) {
+            if (np.dbg) t_k0 = wall_clock64();
             lds_barrier();  // Q rows of all four waves visible
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
@@ -288,6 +292,7 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
     }
 
     if (p.ablate & 16) return;
+    if (np.dbg) t_epi = wall_clock64();
     // ---- epilogue: merge the four waves' (m, l, O) and write one partial row per virtual query row.  ONE barrier:
     //      every wave parks its unscaled O (and m, l) in its own slices -- nobody else ever touched them -- and
     //      the readers rescale while they sum.  Rows of follower tiles are dead by construction: the plan gave
@@ -338,6 +343,18 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
             *reinterpret_cast<floatx4*>(p.partial_o + row * D + 4 * k4) = a * inv;
             if (k4 == 0) p.partial_lse[row] = (L > 0.f) ? (M + __builtin_amdgcn_logf(L)) * LN2 : -INFINITY;
         }
+    }
+    if (np.dbg && tid == 0) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        unsigned long long* d = np.dbg + (int64_t)bid * 8;
+        d[0] = t_start;
+        d[1] = t_k0;
+        d[2] = t_epi;
+        d[3] = wall_clock64();
+        d[4] = (unsigned long long)n;
+        d[5] = ((unsigned long long)xcc << 32) | hw;
     }
 }
 

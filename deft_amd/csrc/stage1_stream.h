@@ -597,21 +597,29 @@ constexpr int UNION_CAP = 4;
 // then the followers, those of one chunk consecutive.  hdr[1] = number of leaders.  One thread.
 __device__ inline void np_record_order(const UnitList& ul, int R, int Hkv, int slots, int chunk_c, int32_t* hdr) {
     int C = chunk_c;
-    if (C <= 0) {  // the largest chunk that still leaves >= 3 workgroups per resident slot
-        C = 1;
-        for (int cand = 8; cand > 1; cand >>= 1) {
+    if (C <= 0) {
+        // Measured on MI355X (tools/np_sweep.sh): per-workgroup cost (descriptor round trip, 32-row epilogue) favours
+        // long chunks, the critical path and the number of resident slots bound them.  8 tiles for long shared
+        // prefixes, 4 from 8 tiles on, halved while fewer than ~0.3 workgroups per slot would be left.
+        int lmax = 0;
+        for (int r = 0; r < R;) {
+            const int id = ul.flags[r] >> 1;
+            int e = r + 1;
+            while (e < R && (ul.flags[e] >> 1) == id) ++e;
+            if (ul.aux[r] <= 0 && e - r > lmax) lmax = e - r;
+            r = e;
+        }
+        C = lmax >= 32 ? 8 : (lmax >= 8 ? 4 : (lmax >= 4 ? 2 : 1));
+        for (; C > 1; C >>= 1) {
             int64_t n = 0;
             for (int r = 0; r < R;) {
                 const int id = ul.flags[r] >> 1;
                 int e = r + 1;
                 while (e < R && (ul.flags[e] >> 1) == id) ++e;
-                n += ul.aux[r] > 0 ? 1 : (e - r + cand - 1) / cand;
+                n += ul.aux[r] > 0 ? 1 : (e - r + C - 1) / C;
                 r = e;
             }
-            if (n * Hkv >= 3LL * slots) {
-                C = cand;
-                break;
-            }
+            if (10 * n * Hkv >= 3LL * slots) break;
         }
     }
     int NL = 0;
@@ -654,7 +662,7 @@ __device__ inline void np_record_order(const UnitList& ul, int R, int Hkv, int s
 __global__ __launch_bounds__(256) void flatten_units_kernel(const int64_t* block_q, const int64_t* block_q_cnts,
                                                             const int64_t* block_q_offset, int NB, int G, int cap,
                                                             UnitList ul, int32_t* hdr, int32_t* sched, int np, int Hkv,
-                                                            int slots, int chunk_c, int union_len) {
+                                                            int slots, int chunk_c, int union_len, int taper) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int* sOpen = reinterpret_cast<int*>(smem);  // [NB]
     int* sPass = sOpen + NB;                    // [NB]
@@ -678,11 +686,20 @@ __global__ __launch_bounds__(256) void flatten_units_kernel(const int64_t* block
             while (tb < NB && !sOpen[tb]) ++tb;
             const int passes = sPass[ta];
             const int cnt_a = (int)block_q_cnts[ta];
-            if (np && union_len > 1 && ucap >= 2 && cnt_a <= ucap && tb - ta < union_len && r < cap) {
+            // taper: the workgroups dispatched last should be short, so that the launch ends together -- the last
+            // `slots` leaf tiles (per head) stay single, the `2 slots` before them go in pairs
+            int ulen = union_len;
+            if (ulen <= 0) ulen = G > 1 ? 1 : ((int64_t)NB * Hkv < 2048 ? 4 : 2);  // measured, tools/np_sweep.sh
+            if (taper) {
+                const int64_t rest = (int64_t)(NB - ta) * Hkv;
+                if (rest <= (int64_t)slots) ulen = 1;
+                else if (rest <= 3LL * slots) ulen = min(ulen, 2);
+            }
+            if (np && ulen > 1 && ucap >= 2 && cnt_a <= ucap && tb - ta < ulen && r < cap) {  // (np: tile-parallel order)
                 // ---- union group starting at ta ----------------------------------------------------
                 int uq[UNION_CAP], urow[UNION_CAP], un = 0;
                 int te = ta;
-                while (te < NB && te - ta < union_len && r + (te - ta) < cap) {
+                while (te < NB && te - ta < ulen && r + (te - ta) < cap) {
                     const int cnt = (int)block_q_cnts[te];
                     if (cnt > ucap) break;
                     const int64_t off = block_q_offset[te];

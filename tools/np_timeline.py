@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Per-workgroup timeline of the tile-parallel stage-1 kernel: start, first K ready, epilogue, end (100 MHz clock)."""
+import ctypes, os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+os.environ.setdefault("DEFT_STAGE1_KERNEL", "np")
+from bench import Bench
+from deft_amd._lib import lib
+from deft_amd.utils.workloads import WORKLOADS, Workload
+bl = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+w = Workload(**{**WORKLOADS["northstar_4kx32"].__dict__, "branch_len": bl})
+b = Bench(w, 8, torch.device("cuda", 0)); b.prepare(use_graph=False)
+lib.deft_debug_set_buffer.argtypes = [ctypes.c_void_p]
+NW = 8192
+for rep in range(3):
+    dbg = torch.zeros(NW * 8 + 8, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    lib.deft_debug_set_buffer(dbg.data_ptr())
+    l = rep % b.layers
+    b.attn[l](b.q[l], b.k_new[l], b.v_new[l], b.meta)
+    torch.cuda.synchronize()
+    lib.deft_debug_set_buffer(None)
+    if rep == 0: continue
+    d = dbg.cpu().numpy()[: NW * 8].reshape(NW, 8)
+    ok = d[:, 3] > 0
+    d = d[ok]
+    t0 = d[:, 0].min()
+    st, k0, ep, en, n = [(d[:, i] - t0) / 100.0 for i in range(4)] + [d[:, 4]]
+    pct = lambda x: [round(float(np.percentile(x, q)), 2) for q in (0, 10, 50, 90, 100)]
+    print(f"rep {rep}: {len(d)} workgroups, span {en.max():.2f} us")
+    for nn in sorted(set(n.tolist())):
+        m = n == nn
+        print(f"  n={int(nn)}: {int(m.sum()):4d} WGs  start {pct(st[m])}  ramp(start->K0) {pct((k0 - st)[m])}  body {pct((ep - k0)[m])}  "
+              f"epilogue {pct((en - ep)[m])}  total {pct((en - st)[m])}  end {pct(en[m])}")
+    # occupancy over time: workgroups alive per microsecond
+    edges = np.arange(0, en.max() + 1, 2.0)
+    alive = [(int(((st <= t) & (en > t)).sum())) for t in edges]
+    print("  alive WGs every 2 us:", alive)
+    cu = d[:, 5]
+    print("  distinct (xcc,hw_id) CU slots:", len(set((int(x) >> 32, (int(x) >> 8) & 0xff, (int(x) >> 13) & 7) for x in cu)))
