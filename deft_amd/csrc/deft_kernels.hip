@@ -667,9 +667,21 @@ static int launch_stage1_np(const Stage1Params& p, int64_t unit_cap, const PlanV
         set_error("stage1 grid too large: %lld", (long long)grid);
         return DEFT_EINVAL;
     }
-    if (getenv("DEFT_NP_GRID")) grid = (int64_t)atoi(getenv("DEFT_NP_GRID")) * p.Hkv;  // experiments: exact leader count
+    // Default: one workgroup per record slot, placed by the hardware dispatcher.  DEFT_NP_PERSIST=1 (experiment) keeps
+    // two resident workgroups per CU that draw chunks from a chip-wide ticket queue instead: it evens out the
+    // XCDs (the odd ones stream ~20 % slower and the dispatcher deals workgroups round-robin) but measured equal or
+    // slower on every workload (profiles/r1_np_*.txt): with ~2 chunks per workgroup there is little left to balance.
+    const int persist = getenv("DEFT_NP_PERSIST") ? atoi(getenv("DEFT_NP_PERSIST")) : 0;
+    if (persist) {
+        int64_t resident = 2LL * num_cus();
+        if (getenv("DEFT_NP_WORKERS")) resident = atoi(getenv("DEFT_NP_WORKERS"));
+        if (grid > resident) grid = resident;
+    }
     NpParams npp{};
     npp.s = p;
+    npp.hdr = pv.hdr;
+    npp.sched = pv.sched;
+    npp.persist = persist;
     npp.s.ablate = getenv("DEFT_STAGE1_ABLATE") ? atoi(getenv("DEFT_STAGE1_ABLATE")) : 0;
     npp.plan = pv.records;
     npp.k_new = ap.k_new;

@@ -29,7 +29,10 @@ namespace deft {
 
 struct NpParams {
     Stage1Params s;
-    const char* plan;  // [cap+1][PLAN_BYTES], leaders first (np_record_order)
+    const char* plan;    // [cap+1][PLAN_BYTES], leaders first (np_record_order)
+    const int32_t* hdr;  // plan header: hdr[1] = number of chunk leaders
+    int* sched;          // sched[0] = workgroups done, sched[ticket_word(0)] = chunk ticket; all 0 between launches
+    int persist;         // 1: resident workgroups draw further chunks from the ticket counter; 0: one chunk per workgroup
     // fused paged append (optional), as in StreamParams
     const _Float16* k_new;
     const _Float16* v_new;
@@ -49,7 +52,8 @@ struct NpSmem {
     static constexpr int AUX_SLOT = 512;
     static constexpr int X_OFF = AUX_OFF + 4 * 2 * AUX_SLOT;  // float m[4][32], l[4][32]
     static constexpr int OROW_OFF = X_OFF + 2 * 4 * MQ * 4;   // int32 orow[32] of the leader record
-    static constexpr int BYTES = OROW_OFF + MQ * 4;
+    static constexpr int NEXT_OFF = OROW_OFF + 2 * MQ * 4;    // int32 next work item (orow is staged twice: one 64-lane DMA)
+    static constexpr int BYTES = NEXT_OFF + 16;
     static_assert(2 * BYTES <= 160 * 1024, "two workgroups per CU");
 };
 
@@ -79,15 +83,12 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
     const int c = l & 31;
     const int h = l >> 5;
     const int bid = blockIdx.x;
+    const int W = (int)gridDim.x;
     unsigned long long t_start = 0, t_k0 = 0, t_epi = 0;
-    if (np.dbg) t_start = wall_clock64();
-    const int rec0 = bid / p.Hkv;  // head fastest: neighbours in the grid share a record and a stretch of the pool
-    const int kvh = bid - rec0 * p.Hkv;
 
-    // ---- fused paged append: new-token row j is copied into the pool by workgroup (grid-1-j) % grid -- the end of
-    //      the grid is unused record capacity (nobody reads those pool rows in this launch: rows flagged NEW in the
-    //      plan are taken from k_new / v_new) ------------------------------------------------------------------
-    for (int copy_job = (int)gridDim.x - 1 - bid; copy_job < np.n_new; copy_job += (int)gridDim.x) {
+    // ---- fused paged append: new-token row j is copied into the pool by workgroup (grid-1-j) % grid (nobody reads
+    //      those pool rows in this launch: rows flagged NEW in the plan are taken from k_new / v_new) ------------
+    for (int copy_job = W - 1 - bid; copy_job < np.n_new; copy_job += W) {
         const int64_t dst = (int64_t)np.cache_loc[copy_job] * p.kv_ss;
         const int chunks = p.Hkv * (D / 8);
         for (int i = tid; i < chunks; i += blockDim.x) {
@@ -101,19 +102,25 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
         }
     }
 
-    const char* rec_lead = np.plan + (int64_t)rec0 * PLAN_BYTES;
-    const int32_t* desc0 = reinterpret_cast<const int32_t*>(rec_lead + PLAN_DESC);
-    const int n = __builtin_amdgcn_readfirstlane(desc0[4]);  // tiles of this chunk; 0 = follower / unused record
-    if (n <= 0) return;
-    const int nv = __builtin_amdgcn_readfirstlane(desc0[0]);
-    const int fb = __builtin_amdgcn_readfirstlane(desc0[5]);
+    // Work items = (chunk leader record, KV head), head fastest: neighbours share a record and a stretch of the pool,
+    // long shared-prefix chunks come first.  Item `bid` is this workgroup's first; resident workgroups then draw
+    // items W, W+1, ... from chip-wide ticket counters -- the XCDs of an MI355X do not stream at the same rate (the odd
+    // ones ~20 % slower, tools/np_timeline.py) and the hardware dispatcher deals workgroups to XCDs round-robin,
+    // so only a chip-wide queue lets them finish together.
+    const int NI = __builtin_amdgcn_readfirstlane(np.hdr[1]) * p.Hkv;
+    int item = bid;
+    int rec0 = 0, kvh = 0, fb = 0;
     auto rec_of = [&](int i) { return np.plan + (int64_t)(i == 0 ? rec0 : fb + i - 1) * PLAN_BYTES; };
-
-    // leader's partial rows (one per virtual query row), parked in LDS for the epilogue.  Issued and consumed before
-    // any asm DMA so that the compiler's own s_waitcnt for it cannot stall behind K/V traffic.
-    if (w == 0 && l < MQ) {
-        reinterpret_cast<int32_t*>(smem + SM::OROW_OFF)[l] = reinterpret_cast<const int32_t*>(rec_lead + PLAN_OROW)[l];
-    }
+    // NTICKET counters, one cache line each (one counter serialises at ~80 atomics/us: 512 requests at launch would
+    // take 6 us).  Workgroup b uses counter (b >> 3) % NTICKET and that counter's stripe of the items, so every
+    // stripe is served by workgroups of ALL eight XCDs (b % 8 is the XCD under round-robin dispatch).
+    const int tk_lane = (p.ablate & 256) ? 0 : (bid >> 3) % NTICKET;
+    auto finish = [&]() {  // the last workgroup to leave re-arms the scheduler words for the next launch
+        if (np.persist && !(p.ablate & 512) && tid == 0 && atomicAdd(np.sched, 1) == W - 1) {
+            np.sched[0] = 0;
+            for (int k = 0; k < NTICKET; ++k) np.sched[ticket_word(k)] = 0;
+        }
+    };
 
     // ---- loop-invariant lane constants (same LDS layouts as stage1_stream.h) ----------------
     const int dpos = l & 15, dkey = l >> 4;
@@ -138,10 +145,7 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
     for (int blk = 0; blk < 4; ++blk) vtr_col_b[blk] = (4 * (blk ^ (tx >> 2)) + 2 * (tg & 1) + ((tx & 3) >> 1)) * 16;
 
     constexpr int64_t NEW_ROW = (int64_t)1 << 63;
-    const char* kb_pool = reinterpret_cast<const char*>(p.k) + (int64_t)kvh * p.kv_sh * 2;
-    const char* vb_pool = reinterpret_cast<const char*>(p.v) + (int64_t)kvh * p.kv_sh * 2 + vchunk_b;
-    const char* kb_new = reinterpret_cast<const char*>(np.k_new) + (int64_t)kvh * D * 2;
-    const char* vb_new = reinterpret_cast<const char*>(np.v_new) + (int64_t)kvh * D * 2 + vchunk_b;
+    const char *kb_pool = nullptr, *vb_pool = nullptr, *kb_new = nullptr, *vb_new = nullptr;  // per work item (KV head)
 
     int64_t rowoff[LPT];
     auto issue_aux = [&](int i, int slot) {  // 2 DMA: this wave's 32 row offsets; its 32 key masks | the 32 q offsets
@@ -180,6 +184,22 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
         }
     };
 
+    for (;;) {
+    if ((unsigned)item >= (unsigned)NI) break;  // uniform
+    if (np.dbg) t_start = wall_clock64();
+    rec0 = item / p.Hkv;
+    kvh = item - rec0 * p.Hkv;
+    const char* rec_lead = np.plan + (int64_t)rec0 * PLAN_BYTES;
+    const int32_t* desc0 = reinterpret_cast<const int32_t*>(rec_lead + PLAN_DESC);
+    const int n = __builtin_amdgcn_readfirstlane(desc0[4]);  // tiles of this chunk (> 0: items only name leaders)
+    const int nv = __builtin_amdgcn_readfirstlane(desc0[0]);
+    fb = __builtin_amdgcn_readfirstlane(desc0[5]);
+    kb_pool = reinterpret_cast<const char*>(p.k) + (int64_t)kvh * p.kv_sh * 2;
+    vb_pool = reinterpret_cast<const char*>(p.v) + (int64_t)kvh * p.kv_sh * 2 + vchunk_b;
+    kb_new = reinterpret_cast<const char*>(np.k_new) + (int64_t)kvh * D * 2;
+    vb_new = reinterpret_cast<const char*>(np.v_new) + (int64_t)kvh * D * 2 + vchunk_b;
+    // leader's partial rows (one per virtual query row), parked in LDS for the epilogue (wave 0, one DMA)
+    if (w == 0) dma4(rec_lead + PLAN_OROW + 4 * (l & 31), SM::OROW_OFF);
     // ---- prologue: aux(0) -> Q, K(0), aux(1), V(0) -----------------------------------------------------
     issue_aux(0, 0);
     wait_vm<0>();
@@ -203,6 +223,15 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
         // ---- K(i) (and Q) landed: younger than it are aux(i+1) [2] and V(i) [8] -------------------------
         if (has1) wait_vm<LPT + 2>();
         else wait_vm<LPT>();
+        // Next item's ticket: requested by wave 0 at the start of the chunk's LAST tile (claiming earlier would hand
+        // the whole queue out at launch: a workgroup only sees ~2 chunks) and retired by this tile's final vmcnt(0).
+        // It lands in the FIXED register v255 named in the asm text (never a C++ variable the compiler could copy
+        // while the atomic is in flight); the kernel's own allocation -- including register TUPLES, which a textual
+        // grep for the name misses -- stays below it (tools/check_asm.sh).
+        if (np.persist && !has1 && w == 0 && l == 0) {
+            int* tk = np.sched + ticket_word(tk_lane);
+            asm volatile("global_atomic_add v255, %0, %1, off sc0" ::"v"(tk), "v"(1) : "memory", "v255");
+        }
         if (i == 0) {
             if (np.dbg) t_k0 = wall_clock64();
             lds_barrier();  // Q rows of all four waves visible
@@ -291,7 +320,17 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
         if (has1) issue_v();  // V(i+1); rowoff still holds tile i+1's offsets
     }
 
-    if (p.ablate & 16) return;
+    if (np.persist && w == 0) {
+        int t;
+        asm volatile("v_readfirstlane_b32 %0, v255" : "=s"(t)::"memory");
+        if (l == 0) *reinterpret_cast<int*>(smem + SM::NEXT_OFF) = W + t * NTICKET + tk_lane;
+    }
+    if (p.ablate & 16) {
+        if (!np.persist) break;
+        lds_barrier();
+        item = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int*>(smem + SM::NEXT_OFF));
+        continue;
+    }
     if (np.dbg) t_epi = wall_clock64();
     // ---- epilogue: merge the four waves' (m, l, O) and write one partial row per virtual query row.  ONE barrier:
     //      every wave parks its unscaled O (and m, l) in its own slices -- nobody else ever touched them -- and
@@ -344,18 +383,24 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
             if (k4 == 0) p.partial_lse[row] = (L > 0.f) ? (M + __builtin_amdgcn_logf(L)) * LN2 : -INFINITY;
         }
     }
-    if (np.dbg && tid == 0) {
+    if (np.dbg && tid == 0 && item < 8192) {
         unsigned hw, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        unsigned long long* d = np.dbg + (int64_t)bid * 8;
+        unsigned long long* d = np.dbg + (int64_t)item * 8;
         d[0] = t_start;
         d[1] = t_k0;
         d[2] = t_epi;
         d[3] = wall_clock64();
         d[4] = (unsigned long long)n;
         d[5] = ((unsigned long long)xcc << 32) | hw;
+        d[6] = (unsigned long long)(long long)*reinterpret_cast<const int*>(smem + SM::NEXT_OFF);
     }
+    if (!np.persist) break;
+    lds_barrier();  // every wave is done reading the others' slices; the next item is visible
+    item = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int*>(smem + SM::NEXT_OFF));
+    }  // work items
+    finish();
 }
 
 }  // namespace deft

@@ -37,4 +37,21 @@ for rep in range(3):
     alive = [(int(((st <= t) & (en > t)).sum())) for t in edges]
     print("  alive WGs every 2 us:", alive)
     cu = d[:, 5]
+    xcc = (cu.astype(np.int64) >> 32) & 0xf
+    se = (cu.astype(np.int64) >> 13) & 0x7
+    cuid = (cu.astype(np.int64) >> 8) & 0xf
+    for nn in sorted(set(n.tolist())):
+        m = n == nn
+        print(f"  n={int(nn)} total by XCC:", [round(float(np.mean((en - st)[m & (xcc == x)])), 1) if (m & (xcc == x)).any() else None for x in range(8)])
+    # per-CU sum of busy time
+    key = xcc * 1000 + se * 16 + cuid
+    tot = {}
+    for k_, t_ in zip(key.tolist(), (en - st).tolist()):
+        tot[k_] = tot.get(k_, 0.0) + t_
+    v = np.array(list(tot.values()))
+    print("  per-CU summed WG time:", pct(v), " CUs:", len(v))
+    last = {}
+    for k_, t_ in zip(key.tolist(), en.tolist()):
+        last[k_] = max(last.get(k_, 0.0), t_)
+    print("  per-CU last end:", pct(np.array(list(last.values()))))
     print("  distinct (xcc,hw_id) CU slots:", len(set((int(x) >> 32, (int(x) >> 8) & 0xff, (int(x) >> 13) & 7) for x in cu)))
