@@ -67,7 +67,13 @@ class Bench:
         loc = torch.tensor([lf.kv_indices[-1] for lf in leaves], dtype=torch.int32, device=device)
         self.updater = deft_amd.KVCacheUpdater(True, self.pool, loc, None, False)
         mode = deft_amd.forward_mode_from_cli(w.mode)
-        self.meta = deft_amd.InputMetadata(mode, self.updater, self.pool)
+        if w.mode == "seq":  # sequential comparator: every leaf attends to its own full path through the page table
+            tree = self.forest.trees[0]
+            lens = [len(tree.leaf_path_slots(lf)) for lf in leaves]
+            positions = torch.tensor(lens, dtype=torch.int64, device=device) - 1
+            self.meta = deft_amd.InputMetadata.from_tree(tree, tree.req_to_token_pool, self.pool, mode, positions, self.updater)
+        else:
+            self.meta = deft_amd.InputMetadata(mode, self.updater, self.pool)
         self.attn = [deft_amd.DeFTAttention(self.Hq, self.D, self.D ** -0.5, self.Hkv, l) for l in range(layers)]
         self.out = None
         self.graph = None
@@ -279,7 +285,8 @@ def main():
         if w.kind == "few_shot" and args.branch_len is None:
             variants += [(f"{w.name}_len1", Workload(**{**w.__dict__, "branch_len": 1})),
                          (f"{w.name}_len400", Workload(**{**w.__dict__, "branch_len": 400}))]
-        for name in ("fewshot_1kx32", "medusa64_node", "tot50_4k", "forest_8kx8_single", "forest_8kx8"):
+        for name in ("fewshot_1kx32", "medusa64_node", "tot50_4k", "forest_8kx8_single", "forest_8kx8",
+                     "northstar_4kx32_seq", "fewshot_1kx32_seq"):
             if name != w.name:
                 variants.append((name, WORKLOADS[name]))
         del b.graph

@@ -1051,7 +1051,7 @@ static int node_decode_impl(const void* q, int64_t q_stride_tok, int64_t q_strid
                             const int64_t* node_kv_offset, const int64_t* node_kv_len, const int64_t* node_q,
                             const int64_t* node_q_offset, const int64_t* node_q_len, int NE, int P, int64_t total_kv, int nq,
                             int Hq, int Hkv, int D, float scale, const void* plan, void* workspace, size_t workspace_bytes,
-                            void* stream, const AppendArgs& ap) {
+                            void* stream, const AppendArgs& ap, int rows_per_tile = DEFT_MAX_Q_LEN) {
     int rc = check_common(q, q_stride_tok, q_stride_head, k_base, v_base, kv_stride_slot, kv_stride_head, out,
                           o_stride_tok, o_stride_head, nq, Hq, Hkv, D);
     if (rc) return rc;
@@ -1068,7 +1068,7 @@ static int node_decode_impl(const void* q, int64_t q_stride_tok, int64_t q_strid
     if (rc) return rc;
     const int G = Hq / Hkv;
     const int64_t tiles = node_max_tiles(NE, total_kv);
-    const int64_t rows = tiles * DEFT_MAX_Q_LEN;
+    const int64_t rows = tiles * rows_per_tile;  // every entry has at most rows_per_tile queries
     const Workspace ws = carve(workspace, Hq, D, rows, tiles, plan_view(nullptr, tiles * G, rows).bytes);
     if (workspace_bytes < ws.bytes) {
         set_error("workspace too small: %zu < %zu", workspace_bytes, ws.bytes);
@@ -1214,6 +1214,176 @@ int deft_flatten_read_partials(const void* workspace, size_t workspace_bytes, in
         return DEFT_EHIP;
     }
     return DEFT_OK;
+}
+
+}  // extern "C"
+
+
+// ---------------------------------------------------------------------------
+// Sequential (per-request) paged attention: the reference's comparator,
+// token_attention_fwd (DeFT/deft/layers/attention/token_attention.py:297-335) behind
+// DeFTAttention.radix_attention_forward (deft_attention.py:153-188).  Every request attends
+// to its own full path through the page table; shared prefixes are re-read per request -- that
+// IS the baseline DeFT is measured against.  Implemented on the Node machinery: request i is
+// an entry with node_kv = req_to_token[b_req_idx[i], :b_seq_len[i]] and the single query row i,
+// so the same stage-1 / merge kernels run (the reference materialises a [Hq, total_tokens]
+// logit matrix instead, token_attention.py:312-314).
+// ---------------------------------------------------------------------------
+namespace deft {
+
+__global__ __launch_bounds__(256) void seq_to_node_kernel(const int32_t* req_to_token, int64_t req_stride,
+                                                           const int32_t* b_req_idx, const int32_t* b_start_loc,
+                                                           const int32_t* b_seq_len, int nq, int64_t* node_kv,
+                                                           int64_t* node_kv_offset, int64_t* node_kv_len, int64_t* node_q,
+                                                           int64_t* node_q_offset, int64_t* node_q_len) {
+    const int i = blockIdx.x;
+    if (i >= nq) return;
+    const int64_t start = b_start_loc[i];
+    const int len = b_seq_len[i];
+    const int32_t* row = req_to_token + (int64_t)b_req_idx[i] * req_stride;
+    for (int j = blockIdx.y * blockDim.x + threadIdx.x; j < len; j += gridDim.y * blockDim.x) node_kv[start + j] = row[j];
+    if (blockIdx.y == 0 && threadIdx.x == 0) {
+        node_kv_offset[i] = start;
+        node_kv_len[i] = len;
+        node_q[i] = i;
+        node_q_offset[i] = i;
+        node_q_len[i] = 1;
+    }
+}
+
+struct SeqPlan {  // [node plan | node_kv | node_kv_offset | node_kv_len | node_q | node_q_offset | node_q_len]
+    void* node_plan;
+    size_t node_plan_bytes;
+    int64_t *node_kv, *node_kv_offset, *node_kv_len, *node_q, *node_q_offset, *node_q_len;
+    size_t bytes;
+};
+static SeqPlan seq_plan_view(void* base, int nq, int64_t total, int Hq, int Hkv) {
+    SeqPlan v;
+    char* p = static_cast<char*>(base);
+    const int64_t tiles = node_max_tiles(nq, total);
+    v.node_plan = p;
+    v.node_plan_bytes = plan_view(nullptr, tiles * (Hq / Hkv), tiles).bytes;
+    size_t off = align_up(v.node_plan_bytes, 256);
+    auto take = [&](int64_t n) {
+        int64_t* r = reinterpret_cast<int64_t*>(p + off);
+        off = align_up(off + sizeof(int64_t) * (size_t)(n > 0 ? n : 1), 256);
+        return r;
+    };
+    v.node_kv = take(total);
+    v.node_kv_offset = take(nq);
+    v.node_kv_len = take(nq);
+    v.node_q = take(nq);
+    v.node_q_offset = take(nq);
+    v.node_q_len = take(nq);
+    v.bytes = off;
+    return v;
+}
+
+}  // namespace deft
+
+extern "C" {
+
+size_t deft_seq_plan_bytes(int nq, int64_t total_tokens, int Hq, int Hkv) {
+    if (nq < 0 || total_tokens < 0 || Hq <= 0 || Hkv <= 0 || Hq % Hkv) return 0;
+    return seq_plan_view(nullptr, nq, total_tokens, Hq, Hkv).bytes;
+}
+
+size_t deft_seq_workspace_bytes(int nq, int64_t total_tokens, int Hq, int Hkv, int D) {
+    if (nq < 0 || total_tokens < 0 || Hq <= 0 || Hkv <= 0 || Hq % Hkv) return 0;
+    const int64_t tiles = node_max_tiles(nq, total_tokens);
+    return carve(nullptr, Hq, D, tiles, tiles, plan_view(nullptr, tiles * (Hq / Hkv), tiles).bytes).bytes;
+}
+
+int deft_seq_build_plan(const int32_t* req_to_token, int64_t req_stride, const int32_t* b_req_idx,
+                        const int32_t* b_start_loc, const int32_t* b_seq_len, int nq, int64_t total_tokens, int Hq,
+                        int Hkv, int64_t q_stride_tok, int64_t q_stride_head, int64_t kv_stride_slot,
+                        const int32_t* cache_loc, int n_new, int64_t new_stride_tok, void* plan, size_t plan_bytes,
+                        void* stream) {
+    if (nq < 0 || total_tokens < 0 || total_tokens > 0x7fffffffLL || !plan || Hq <= 0 || Hkv <= 0 || Hq % Hkv ||
+        (nq > 0 && (!req_to_token || !b_req_idx || !b_start_loc || !b_seq_len))) {
+        set_error("bad sequential plan arguments (nq=%d total_tokens=%lld)", nq, (long long)total_tokens);
+        return DEFT_EINVAL;
+    }
+    const SeqPlan sp = seq_plan_view(plan, nq, total_tokens, Hq, Hkv);
+    if (plan_bytes < sp.bytes) {
+        set_error("plan buffer too small: %zu < %zu", plan_bytes, sp.bytes);
+        return DEFT_EWORKSPACE;
+    }
+    if (nq == 0) return DEFT_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const unsigned gy = (unsigned)((total_tokens / nq + 255) / 256 < 1 ? 1 : ((total_tokens / nq + 255) / 256 > 64 ? 64 : (total_tokens / nq + 255) / 256));
+    hipLaunchKernelGGL(seq_to_node_kernel, dim3((unsigned)nq, gy), dim3(256), 0, st, req_to_token, req_stride, b_req_idx,
+                       b_start_loc, b_seq_len, nq, sp.node_kv, sp.node_kv_offset, sp.node_kv_len, sp.node_q,
+                       sp.node_q_offset, sp.node_q_len);
+    int rc = check_launch("seq_to_node launch");
+    if (rc) return rc;
+    const int64_t tiles = node_max_tiles(nq, total_tokens);
+    const PlanView pv = plan_view(sp.node_plan, tiles * (Hq / Hkv), tiles);
+    Stage1Params p{};
+    p.node_kv = sp.node_kv;
+    p.node_kv_offset = sp.node_kv_offset;
+    p.node_kv_len = sp.node_kv_len;
+    p.node_q = sp.node_q;
+    p.node_q_offset = sp.node_q_offset;
+    p.node_q_len = sp.node_q_len;
+    p.rows = tiles;
+    p.G = Hq / Hkv;
+    p.Hkv = Hkv;
+    p.q_st = q_stride_tok;
+    p.q_sh = q_stride_head;
+    p.kv_ss = kv_stride_slot;
+    AppendArgs ap;
+    if (cache_loc) {
+        ap.cache_loc = cache_loc;
+        ap.n_new = n_new;
+        ap.new_st = new_stride_tok;
+    }
+    return launch_node_plan(p, nq, tiles, pv, ap, st);
+}
+
+static int seq_decode_impl(const void* q, int64_t q_stride_tok, int64_t q_stride_head, const void* k_base,
+                           const void* v_base, int64_t kv_stride_slot, int64_t kv_stride_head, void* out,
+                           int64_t o_stride_tok, int64_t o_stride_head, const void* plan, int nq, int64_t total_tokens,
+                           int Hq, int Hkv, int D, float scale, void* workspace, size_t workspace_bytes, void* stream,
+                           const AppendArgs& ap) {
+    if (!plan || nq < 0 || total_tokens < 0 || Hq <= 0 || Hkv <= 0 || Hq % Hkv) {
+        set_error("bad sequential decode arguments (nq=%d total_tokens=%lld)", nq, (long long)total_tokens);
+        return DEFT_EINVAL;
+    }
+    const SeqPlan sp = seq_plan_view(const_cast<void*>(plan), nq, total_tokens, Hq, Hkv);
+    return node_decode_impl(q, q_stride_tok, q_stride_head, k_base, v_base, kv_stride_slot, kv_stride_head, out,
+                            o_stride_tok, o_stride_head, sp.node_kv, sp.node_kv_offset, sp.node_kv_len, sp.node_q,
+                            sp.node_q_offset, sp.node_q_len, nq, nq, total_tokens, nq, Hq, Hkv, D, scale,
+                            D == 128 ? sp.node_plan : nullptr, workspace, workspace_bytes, stream, ap, 1);
+}
+
+int deft_seq_decode_f16(const void* q, int64_t q_stride_tok, int64_t q_stride_head, const void* k_base, const void* v_base,
+                        int64_t kv_stride_slot, int64_t kv_stride_head, void* out, int64_t o_stride_tok,
+                        int64_t o_stride_head, const void* plan, int nq, int64_t total_tokens, int Hq, int Hkv, int D,
+                        float scale, void* workspace, size_t workspace_bytes, void* stream) {
+    return seq_decode_impl(q, q_stride_tok, q_stride_head, k_base, v_base, kv_stride_slot, kv_stride_head, out,
+                           o_stride_tok, o_stride_head, plan, nq, total_tokens, Hq, Hkv, D, scale, workspace,
+                           workspace_bytes, stream, AppendArgs());
+}
+
+int deft_seq_decode_append_f16(const void* q, int64_t q_stride_tok, int64_t q_stride_head, void* k_base, void* v_base,
+                               int64_t kv_stride_slot, int64_t kv_stride_head, void* out, int64_t o_stride_tok,
+                               int64_t o_stride_head, const void* plan, int nq, int64_t total_tokens, int Hq, int Hkv,
+                               int D, float scale, const int32_t* cache_loc, const void* k_new, const void* v_new,
+                               int64_t new_stride_tok, int n_new, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!k_new || !v_new || !cache_loc) {
+        set_error("fused append needs k_new, v_new and cache_loc");
+        return DEFT_EINVAL;
+    }
+    AppendArgs ap;
+    ap.k_new = static_cast<const _Float16*>(k_new);
+    ap.v_new = static_cast<const _Float16*>(v_new);
+    ap.cache_loc = cache_loc;
+    ap.new_st = new_stride_tok;
+    ap.n_new = n_new;
+    return seq_decode_impl(q, q_stride_tok, q_stride_head, k_base, v_base, kv_stride_slot, kv_stride_head, out,
+                           o_stride_tok, o_stride_head, plan, nq, total_tokens, Hq, Hkv, D, scale, workspace,
+                           workspace_bytes, stream, ap);
 }
 
 }  // extern "C"

@@ -4,6 +4,7 @@ DeFT decode modes.
 Mirrors DeFT/deft/layers/attention/deft_attention.py:
   deft_node_forward     :72-108
   deft_flatten_forward  :110-151
+  radix_attention_forward :153-188  (sequential per-leaf attention: the comparator, `--mode seq`)
   forward               :349-388   (dispatch on input_metadata.forward_mode)
   store_kv_cache        :390-403
 
@@ -20,6 +21,7 @@ import torch
 from torch import nn
 
 from .forward_mode import ForwardMode, InputMetadata
+from .token_attention import seq_append_attention, token_attention_fwd
 from .tree_attention import (flatten_append_attention, node_append_attention, tree_attention_fwd,
                              tree_attention_subtree_fwd)
 from .tree_cache import get_global_tree_metadata
@@ -98,14 +100,52 @@ class DeFTAttention(nn.Module):
         )
         return o
 
+    def radix_attention_forward(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor,
+                                input_metadata: InputMetadata) -> torch.Tensor:
+        """Sequential per-request attention through the page table (deft_attention.py:153-188): the comparator."""
+        k = k.view(-1, self.tp_k_head_num, self.head_dim)
+        v = v.view(-1, self.tp_v_head_num, self.head_dim)
+        o = torch.empty((q.shape[0], self.tp_q_head_num * self.head_dim), dtype=q.dtype, device=q.device)
+        assert input_metadata.token_to_kv_pool is not None
+        assert input_metadata.req_to_token_pool is not None
+        pool = input_metadata.token_to_kv_pool
+        updater = input_metadata.kv_updater
+        table = input_metadata.req_to_token_pool.req_to_token
+        if (updater is not None and updater.cache_loc is not None and updater.token_to_kv_pool is pool
+                and not os.environ.get("DEFT_NO_FUSED_APPEND")):
+            seq_append_attention(
+                q.view(-1, self.tp_q_head_num, self.head_dim), pool.kv_data[self.layer_id],
+                o.view(-1, self.tp_q_head_num, self.head_dim), updater.cache_loc, k, v, table,
+                input_metadata.req_pool_indices, input_metadata.start_loc, input_metadata.seq_lens,
+                input_metadata.total_num_tokens,
+            )
+            return o
+        self.store_kv_cache(k, v, input_metadata)
+        token_attention_fwd(
+            q.view(-1, self.tp_q_head_num, self.head_dim),
+            pool.get_key_buffer(self.layer_id),
+            pool.get_value_buffer(self.layer_id),
+            o.view(-1, self.tp_q_head_num, self.head_dim),
+            table,
+            input_metadata.req_pool_indices,
+            input_metadata.start_loc,
+            input_metadata.seq_lens,
+            input_metadata.max_seq_len,
+            input_metadata.other_kv_index,
+            input_metadata.total_num_tokens,
+        )
+        return o
+
     def forward(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, input_metadata: InputMetadata) -> torch.Tensor:
         mode = input_metadata.forward_mode
+        if mode == ForwardMode.DECODE:
+            return self.radix_attention_forward(q, k, v, input_metadata)
         if mode == ForwardMode.TREE_DECODE_FLATTEN:
             return self.deft_flatten_forward(q, k, v, input_metadata)
         if mode == ForwardMode.TREE_DECODE_NODE:
             return self.deft_node_forward(q, k, v, input_metadata)
         raise NotImplementedError(
-            f"Unsupported forward mode: {mode} (deft_amd covers TREE_DECODE_FLATTEN and TREE_DECODE_NODE with paged KV)"
+            f"Unsupported forward mode: {mode} (deft_amd covers TREE_DECODE_FLATTEN, TREE_DECODE_NODE and DECODE with paged KV)"
         )
 
     def store_kv_cache(self, cache_k: torch.Tensor, cache_v: torch.Tensor, input_metadata: InputMetadata) -> None:

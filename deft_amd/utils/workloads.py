@@ -31,7 +31,7 @@ GEOMETRY: Dict[str, Tuple[int, int, int, int]] = {
 class Workload:
     name: str
     model: str
-    mode: str  # "flatten" | "node"
+    mode: str  # "flatten" | "node" | "seq" (the sequential per-leaf comparator, `--mode seq`)
     kind: str  # few_shot | medusa | tot
     prefix: int
     width: int = 32
@@ -44,6 +44,9 @@ WORKLOADS: Dict[str, Workload] = {
     "northstar_4kx32": Workload("northstar_4kx32", "llama2-7b", "flatten", "few_shot", 4096, 32, 200),
     # BASELINE configs[1]: 1k shared prefix x 32 branches
     "fewshot_1kx32": Workload("fewshot_1kx32", "llama2-7b", "flatten", "few_shot", 1024, 32, 200),
+    # the same two trees through the sequential comparator (token_attention_fwd): what DeFT is measured against
+    "northstar_4kx32_seq": Workload("northstar_4kx32_seq", "llama2-7b", "seq", "few_shot", 4096, 32, 200),
+    "fewshot_1kx32_seq": Workload("fewshot_1kx32_seq", "llama2-7b", "seq", "few_shot", 1024, 32, 200),
     # configs[2]: Medusa depth-4 width-10 template as the reference mocks it (tree_size64), DeFT-Node
     "medusa64_node": Workload("medusa64_node", "llama2-7b", "node", "medusa", 1016, 64, 1),
     # configs[3]: Llama-3-8B ToT tree, 4k prefix, 50 nodes, DeFT-Flatten

@@ -175,6 +175,38 @@ int deft_node_decode_append_f16(
     const int32_t* cache_loc, const void* k_new, const void* v_new, int64_t new_stride_tok, int n_new,
     const void* plan, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- sequential (per-request) paged attention: the reference's comparator ---------------------------------
+ *
+ * Replaces token_attention_fwd (DeFT/deft/layers/attention/token_attention.py:297-335) behind
+ * DeFTAttention.radix_attention_forward (deft_attention.py:153-188), i.e. `--mode seq --mem paged`: request i attends
+ * to req_to_token[b_req_idx[i], 0 : b_seq_len[i]] (ReqToTokenPool, memory_pool.py:11-45; int32 like the reference),
+ * b_start_loc = exclusive prefix sum of b_seq_len (model_runner.py:177-178), one query row per request.
+ * The plan (page table -> per-request slot lists + tile records) is built once per decode step and shared by all
+ * layers, like the Flatten / Node plans.
+ */
+size_t deft_seq_plan_bytes(int nq, int64_t total_tokens, int Hq, int Hkv);
+size_t deft_seq_workspace_bytes(int nq, int64_t total_tokens, int Hq, int Hkv, int D);
+int deft_seq_build_plan(
+    const int32_t* req_to_token, int64_t req_stride /* elements per request row */,
+    const int32_t* b_req_idx, const int32_t* b_start_loc, const int32_t* b_seq_len, int nq, int64_t total_tokens,
+    int Hq, int Hkv, int64_t q_stride_tok, int64_t q_stride_head, int64_t kv_stride_slot,
+    const int32_t* cache_loc /* nullable */, int n_new, int64_t new_stride_tok,
+    void* plan, size_t plan_bytes, void* stream);
+int deft_seq_decode_f16(
+    const void* q, int64_t q_stride_tok, int64_t q_stride_head,
+    const void* k_base, const void* v_base, int64_t kv_stride_slot, int64_t kv_stride_head,
+    void* out, int64_t o_stride_tok, int64_t o_stride_head,
+    const void* plan, int nq, int64_t total_tokens, int Hq, int Hkv, int D, float scale,
+    void* workspace, size_t workspace_bytes, void* stream);
+/* store_kv_cache + token_attention_fwd in one call (radix_attention_forward, deft_attention.py:153-188) */
+int deft_seq_decode_append_f16(
+    const void* q, int64_t q_stride_tok, int64_t q_stride_head,
+    void* k_base, void* v_base, int64_t kv_stride_slot, int64_t kv_stride_head,
+    void* out, int64_t o_stride_tok, int64_t o_stride_head,
+    const void* plan, int nq, int64_t total_tokens, int Hq, int Hkv, int D, float scale,
+    const int32_t* cache_loc, const void* k_new, const void* v_new, int64_t new_stride_tok, int n_new,
+    void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- paged KV append ---------------------------------------------------- */
 
 /* k_base[cache_loc[i]] = k_new[i], v_base[cache_loc[i]] = v_new[i] for i < n

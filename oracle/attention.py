@@ -10,6 +10,8 @@ Test infrastructure only (see oracle/__init__.py).  Restates, on CPU:
                    accumulation into the fp16 output before the division
   merge_exact      the mathematically identical merge with the true max and
                    fp32 accumulation (what the HIP path computes)
+  token_attention_forward  the sequential comparator, token_attention.py:297-335
+                   (fp16 logits and all), bit-exact on tests/golden/seq_*.npz
   sequential_truth per-leaf softmax(q K^T / sqrt(D)) V over the leaf's
                    root->leaf slots, fp64 — the recipe of
                    DeFT/tests/model/test_DeFT_kernel.py:212-276
@@ -185,3 +187,44 @@ def kv_append(kv_data: np.ndarray, cache_loc, k_new, v_new) -> None:
     loc = np.asarray(cache_loc, dtype=np.int64)
     kv_data[loc, 0] = k_new
     kv_data[loc, 1] = v_new
+
+
+# ---------------------------------------------------------------------------
+# sequential comparator: token_attention_fwd
+# (DeFT/deft/layers/attention/token_attention.py:297-335; stage 1 :12-80, stage 2 :83-150)
+# ---------------------------------------------------------------------------
+def token_attention_forward(q, kv_data, req_rows, b_seq_len, block_n: int = 64):
+    """Restates the reference's two kernels bit for bit (pinned on tests/golden/seq_*.npz: max |diff| = 0).
+
+    Stage 1 (:51-79): `q[None, :] * k` multiplies two fp16 tensors, so every product is rounded to fp16; `tl.sum`
+    accumulates them in fp32 and hands back fp16; `att_value *= sm_scale` is again an fp16 multiply; the logits are
+    stored in `att_m`, which has the dtype of q (:312-314).  Stage 2 (:121-146) walks each request's logits in blocks
+    of 64 with an fp32 online softmax and fp32 P.V.  The fp16 logits cost the reference ~1.3e-3 against fp64 truth on
+    the 40-leaf tree; the HIP path keeps fp32 logits, so it is compared to these vectors at 2.5e-3 and to the truth
+    at 5e-4.  req_rows[i] = page-table row of request i (req_to_token[b_req_idx[i]])."""
+    nq, Hq, D = q.shape
+    kbuf, vbuf = _kv_views(kv_data)
+    group = Hq // kbuf.shape[1]
+    scale16 = np.float16(1.0 / (D ** 0.5))
+    out = np.zeros((nq, Hq, D), dtype=np.float16)
+    for i in range(nq):
+        n = int(b_seq_len[i])
+        slots = np.asarray(req_rows[i][:n], dtype=np.int64)
+        k16 = np.repeat(np.transpose(kbuf[slots], (1, 0, 2)), group, axis=0)  # [Hq, n, D] fp16
+        v = _expand_heads(vbuf[slots].astype(np.float32), group)
+        prod = q[i][:, None, :] * k16  # fp16 x fp16 -> fp16
+        dots = prod.astype(np.float32).sum(axis=2, dtype=np.float32).astype(np.float16)
+        logits = (dots * scale16).astype(np.float16).astype(np.float32)
+        e_max = np.full((Hq,), -np.inf, dtype=np.float32)
+        e_sum = np.zeros((Hq,), dtype=np.float32)
+        acc = np.zeros((Hq, D), dtype=np.float32)
+        for s in range(0, n, block_n):
+            qk = logits[:, s : s + block_n]
+            n_e_max = np.maximum(qk.max(axis=1), e_max)
+            old = np.exp(e_max - n_e_max).astype(np.float32)
+            p = np.exp(qk - n_e_max[:, None]).astype(np.float32)
+            e_sum = e_sum * old + p.sum(axis=1, dtype=np.float32)
+            acc = acc * old[:, None] + np.einsum("hn,hnd->hd", p, v[:, s : s + block_n], dtype=np.float32)
+            e_max = n_e_max
+        out[i] = (acc / e_sum[:, None]).astype(np.float16)
+    return out

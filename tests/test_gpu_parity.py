@@ -402,3 +402,74 @@ def test_forest_batch_equals_its_trees_one_by_one(geom, mode):
         o1 = attend(m1, q[lo : lo + m1.query_num].contiguous())
         torch.cuda.synchronize()
         assert (o1.float() - o[lo : lo + m1.query_num].float()).abs().max().item() < TOL_EXACT
+
+
+# ---------------------------------------------------------------------------
+# sequential comparator (token_attention_fwd / radix_attention_forward, `--mode seq`)
+# ---------------------------------------------------------------------------
+SEQ_GOLDEN = {"cfgA_256x2": [(4, 4, 128), (8, 2, 128)], "multilevel": [(4, 4, 128), (8, 2, 128), (4, 4, 64)],
+              "wide40": [(8, 2, 128)], "chain_300": [(4, 4, 128)]}
+TOL_SEQ_REF = 2.5e-3  # the reference keeps its logits in fp16 (token_attention.py:312-314): 1.3e-3 from truth by itself
+
+
+def _seq_metadata(tree, device="cuda"):
+    leaves = sorted(tree.leaves.values(), key=lambda n: n.id)
+    lens = [len(tree.leaf_path_slots(lf)) for lf in leaves]
+    positions = torch.tensor(lens, dtype=torch.int64, device=device) - 1
+    return deft_amd.InputMetadata.from_tree(tree, tree.req_to_token_pool, tree.token_to_kv_pool,
+                                            deft_amd.ForwardMode.DECODE, positions, None), lens
+
+
+@pytest.mark.parametrize("name,geom", [(n, g) for n in sorted(SEQ_GOLDEN) for g in SEQ_GOLDEN[n]])
+def test_sequential_attention_matches_reference_and_truth(name, geom):
+    import os
+    Hq, Hkv, D = geom
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "seq_" + name + ".npz"))
+    tree = product_tree(name, device="cuda", heads=(Hkv, D))
+    meta, lens = _seq_metadata(tree)
+    assert lens == g["b_seq_len"].tolist() and meta.start_loc.tolist() == g["b_start_loc"].tolist()
+    table = tree.req_to_token_pool.req_to_token
+    for i, r in enumerate(meta.req_pool_indices.tolist()):  # the product page table = the reference's
+        assert table[r, : lens[i]].tolist() == g["req_rows"][i][: lens[i]].tolist()
+    q_np, kv_np = seeded_inputs(name, geom, len(lens))
+    tree.token_to_kv_pool.kv_data[0].copy_(torch.from_numpy(kv_np))
+    pool = tree.token_to_kv_pool
+    q = torch.from_numpy(q_np).cuda()
+    o = torch.full((len(lens), Hq, D), float("nan"), dtype=torch.float16, device="cuda")
+    deft_amd.token_attention_fwd(q, pool.get_key_buffer(0), pool.get_value_buffer(0), o, table, meta.req_pool_indices,
+                                 meta.start_loc, meta.seq_lens, meta.max_seq_len, meta.other_kv_index,
+                                 meta.total_num_tokens)
+    torch.cuda.synchronize()
+    out = o.cpu().numpy()
+    assert np.isfinite(out.astype(np.float32)).all()
+    assert max_abs(out, g["o_seq_%d_%d_%d" % geom]) < TOL_SEQ_REF
+    otree = oracle_tree(name)
+    assert max_abs(out, oa.sequential_truth(q_np, kv_np, leaf_paths(otree))) < TOL_EXACT
+    # and it is the same function of the inputs as the tree operators
+    tree_out = _run(name, geom, "flatten")[0]
+    assert max_abs(out, tree_out) < TOL_EXACT
+
+
+def test_sequential_module_path_with_fused_append():
+    """DeFTAttention.forward in ForwardMode.DECODE: store_kv_cache + token attention (deft_attention.py:153-188)."""
+    name, geom = "multilevel", (8, 2, 128)
+    Hq, Hkv, D = geom
+    tree = product_tree(name, device="cuda", heads=(Hkv, D))
+    q_np, kv_np = seeded_inputs(name, geom, len(tree.leaves))
+    pool = tree.token_to_kv_pool
+    pool.kv_data[0].copy_(torch.from_numpy(kv_np))
+    leaves = sorted(tree.leaves.values(), key=lambda n: n.id)
+    loc = torch.tensor([lf.kv_indices[-1] for lf in leaves], dtype=torch.int32, device="cuda")
+    k_new = pool.kv_data[0][loc.long(), 0].clone()
+    v_new = pool.kv_data[0][loc.long(), 1].clone()
+    pool.kv_data[0][loc.long()] = 0  # the step's own rows are not in the pool yet
+    updater = deft_amd.KVCacheUpdater(True, pool, loc, None, False)
+    meta, lens = _seq_metadata(tree)
+    meta.kv_updater = updater
+    attn = deft_amd.DeFTAttention(Hq, D, D ** -0.5, Hkv, 0)
+    q = torch.from_numpy(q_np).cuda().view(len(lens), Hq * D)
+    out = attn(q, k_new.view(len(lens), -1), v_new.view(len(lens), -1), meta)
+    torch.cuda.synchronize()
+    assert torch.equal(pool.kv_data[0].cpu(), torch.from_numpy(kv_np))  # rows appended
+    truth = oa.sequential_truth(q_np, kv_np, leaf_paths(oracle_tree(name)))
+    assert max_abs(out.view(len(lens), Hq, D).cpu().numpy(), truth) < TOL_EXACT

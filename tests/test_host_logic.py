@@ -96,9 +96,10 @@ def test_pool_exhaustion_returns_none_like_upstream():
 
 def test_out_of_scope_modes_fail_loudly():
     with pytest.raises(NotImplementedError):
-        deft_amd.forward_mode_from_cli("seq")
+        deft_amd.forward_mode_from_cli("tree")
     with pytest.raises(NotImplementedError):
         deft_amd.forward_mode_from_cli("flatten", "unpaged")
+    assert deft_amd.forward_mode_from_cli("seq") is deft_amd.ForwardMode.DECODE  # the sequential comparator
     assert deft_amd.forward_mode_from_cli("deft_flatten") is deft_amd.ForwardMode.TREE_DECODE_FLATTEN
     assert deft_amd.forward_mode_from_cli("deft_node") is deft_amd.ForwardMode.TREE_DECODE_NODE
     with pytest.raises(NotImplementedError):

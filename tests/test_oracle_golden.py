@@ -5,6 +5,8 @@ made by tools/gen_golden.py from /root/reference under Triton's CPU interpreter)
   * attention: within 1e-3 of the reference's fp16 output (north-star tolerance)
     and of fp64 sequential ground truth
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -128,3 +130,25 @@ def test_reference_merge_quirk_documented():
         assert float(exact[0, 0, 0]) == 2.0
         got = float(quirk[0, 0, 0])
         assert (np.isnan(got) or got == want_quirk) if lse < -70 else got == want_quirk
+
+
+SEQ_GOLDEN = {"cfgA_256x2": [(4, 4, 128), (8, 2, 128)], "multilevel": [(4, 4, 128), (8, 2, 128), (4, 4, 64)],
+              "wide40": [(8, 2, 128)], "chain_300": [(4, 4, 128)]}
+
+
+@pytest.mark.parametrize("name", sorted(SEQ_GOLDEN))
+def test_sequential_comparator_oracle_is_bit_exact_on_reference_outputs(name):
+    """tests/golden/seq_*.npz = the reference's token_attention_fwd run on its own page table (tools/gen_golden_seq.py)."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "seq_" + name + ".npz"))
+    otree = oracle_tree(name)
+    paths = leaf_paths(otree)
+    lens = g["b_seq_len"]
+    assert [len(p) for p in paths] == lens.tolist()  # the oracle tree's page table = the reference's
+    for i, p in enumerate(paths):
+        assert g["req_rows"][i][: lens[i]].tolist() == list(p)
+    assert g["b_start_loc"].tolist() == np.concatenate([[0], np.cumsum(lens)[:-1]]).tolist()
+    for geom in SEQ_GOLDEN[name]:
+        q, kv = seeded_inputs(name, geom, len(lens))
+        o = oa.token_attention_forward(q, kv, g["req_rows"], lens)
+        assert np.array_equal(o, g["o_seq_%d_%d_%d" % geom])
+        assert max_abs(o, oa.sequential_truth(q, kv, paths)) < 2.5e-3  # the reference's fp16 logits
