@@ -1,0 +1,440 @@
+"""Tree-template replay: drive the tree cache, the metadata builder and the attention operators through the
+reference's three workloads (few-shot prompting, multi-step reasoning, speculative decoding) without a language
+model — the caller of the hot path on the other side of `TreeMetadata`.
+
+What is mirrored, and from where:
+
+  ExecuteTreeNode / ExecuteTree   DeFT/deft/data_loader.py:9-77    a tree TEMPLATE: per node the iteration at which it
+                                  starts / ends and its children; `branch_record[iter][node] = children`,
+                                  `prune_record[iter] = [nodes]` are what the branch controller consults each step
+  build_tree(s) / load_trees      data_loader.py:80-132            dataset/generation/Reasoning/*.json
+  load_prompts / generate_accepted_len_list   :181-235             dataset/generation/Speculative_Decoding/*.json
+  branch_from_tree_template       DeFT/deft/tree_decoding/generation/branch_func_example.py:293-371
+  branch_speculative_decoding     branch_func_example.py:374-442   (the reference's mock: all `tree_size` leaves are
+                                  kept, the accepted tokens are squeezed into the root)
+  branch_few_shot                 branch_func_example.py:12-62     SimpleTree: branch once after prefill, then greedy
+  decode loop                     DeFT/deft/tree_decoding/generation/tree_generate.py:89-260
+
+The model forward is replaced by synthetic q / k / v of the model's geometry and synthetic next-token scores (the
+branch functions only use the ARG-TOP-K of the logits, never their values), so a replay exercises exactly the
+tree-state transitions, page-table updates, per-step metadata builds and attention calls the reference performs, and
+reports the reference's metrics (perf_metrics.py:98-116, :195-210): attention latency, decode latency of the replayed
+part, TPOT = latency / generated tokens.
+
+The dataset files themselves are not shipped (they belong to the reference repository); `load_trees(path)` /
+`load_prompts(path)` read them where the user has them, and `synthetic_*` build templates of the same form.
+"""
+from __future__ import annotations
+
+import json
+import random
+import time
+from dataclasses import dataclass, field
+from typing import Any, Callable, Dict, List, Optional
+
+import numpy as np
+import torch
+
+from .forward_mode import ForwardMode, InputMetadata, forward_mode_from_cli
+from .memory_pool import ReqToTokenPool, TokenToKVPool
+from .tree_cache import TreeCache, TreeMetadata, register_tree_metadata
+
+__all__ = [
+    "ExecuteTreeNode", "ExecuteTree", "build_tree", "build_trees", "load_dataset", "load_trees", "load_prompts",
+    "generate_accepted_len_list", "synthetic_reasoning_template", "synthetic_speculative_template",
+    "synthetic_few_shot_template", "branch_from_tree_template", "branch_speculative_decoding", "branch_few_shot",
+    "ReplayReport", "TemplateReplay",
+]
+
+
+# ---------------------------------------------------------------------------
+# templates (data_loader.py)
+# ---------------------------------------------------------------------------
+class ExecuteTreeNode:
+    def __init__(self, id: int, value: int, start_offset: int, end_offset: int) -> None:
+        self.id = id
+        self.value = value  # tokens generated inside this node
+        self.start_offset = start_offset  # iteration at which the node appears
+        self.end_offset = end_offset  # iteration at which it branches or is pruned
+        self.children: List["ExecuteTreeNode"] = []
+        self.depth = 0
+        self.width = 0
+
+    def __repr__(self) -> str:
+        return (f"(id: {self.id}, value: {self.value}, start: {self.start_offset}, end: {self.end_offset}, "
+                f"children: {[c.id for c in self.children]})")
+
+
+class ExecuteTree:
+    def __init__(self, root: ExecuteTreeNode, nodes: List[ExecuteTreeNode], prompt: Optional[str] = None) -> None:
+        self.root = root
+        self.prompt = prompt
+        self.nodes = nodes
+        self.branch_record: Dict[int, Dict[int, List[int]]] = {}
+        self.prune_record: Dict[int, List[int]] = {}
+        self.max_depth = 0
+        self.max_width = 0
+        self.width_per_depth: Dict[int, int] = {}
+        self.build_tree_metadata(self.root, 0)
+        self.node_num = len(nodes)
+        self.accepted_len_list: Optional[List[int]] = None  # speculative decoding only
+
+    def build_tree_metadata(self, root: ExecuteTreeNode, depth: int) -> int:
+        """data_loader.py:51-77: a leaf is pruned at its end; an inner node branches at its end and is itself
+        released when the last node of its subtree ends."""
+        end_iter = root.end_offset
+        self.max_depth = max(self.max_depth, depth)
+        self.width_per_depth.setdefault(depth, 0)
+        root.depth = depth
+        root.width = self.width_per_depth[depth]
+        self.width_per_depth[depth] += 1
+        self.max_width = max(self.max_width, self.width_per_depth[depth])
+        if not root.children:
+            self.prune_record.setdefault(end_iter, []).append(root.id)
+            return end_iter
+        self.branch_record.setdefault(end_iter, {})[root.id] = [c.id for c in root.children]
+        for child in root.children:
+            end_iter = max(end_iter, self.build_tree_metadata(child, depth + 1))
+        self.prune_record[end_iter].append(root.id)
+        return end_iter
+
+
+def build_tree(data: Any) -> List[ExecuteTreeNode]:
+    nodes = [ExecuteTreeNode(i, 0, 0, 0) for i in range(len(data))]
+    for item in data.values():
+        n = nodes[int(item["id"])]
+        n.value = int(item["value"])
+        n.start_offset = int(item["start"])
+        n.end_offset = int(item["end"])
+        for child in item["children"]:
+            n.children.append(nodes[int(child)])
+    return nodes
+
+
+def build_trees(dataset: Any) -> List[ExecuteTree]:
+    trees = []
+    for item in dataset:
+        if "data" in item:
+            if item.get("incompleted"):
+                continue  # data_loader.py:101-104
+            nodes = build_tree(item["data"])
+        else:
+            nodes = build_tree(item)
+        trees.append(ExecuteTree(nodes[0], nodes, item.get("prompt") if isinstance(item, dict) else None))
+    return trees
+
+
+def load_dataset(path: str) -> Any:
+    if path.endswith(".json"):
+        with open(path, "r") as f:
+            return json.load(f)
+    if path.endswith(".pkl"):
+        import pickle
+
+        with open(path, "rb") as f:
+            return pickle.load(f)
+    raise NotImplementedError(f"Unsupported file format: {path}")
+
+
+def load_trees(path: str) -> List[ExecuteTree]:
+    return build_trees(load_dataset(path))
+
+
+def load_prompts(path: str) -> List[ExecuteTree]:
+    """Speculative-decoding records (data_loader.py:181-197): one flat template of `Token_Tree_size` nodes per
+    record, carrying the record's accepted lengths."""
+    dataset = load_dataset(path)
+    trees: List[ExecuteTree] = []
+    for rec in dataset["Records"]:
+        nodes = [ExecuteTreeNode(i, 0, 0, 0) for i in range(int(dataset["Token_Tree_size"]))]
+        tree = ExecuteTree(nodes[0], nodes, rec["prompt"])
+        tree.accepted_len_list = list(rec["Accept_length"])
+        trees.append(tree)
+    return trees
+
+
+def generate_accepted_len_list(max_gen_len: int, tree: ExecuteTree, rng: Optional[random.Random] = None) -> None:
+    """data_loader.py:200-235: truncate the record at max_gen_len accepted tokens, or extend it with lengths drawn
+    between the record's min and max."""
+    rng = rng or random
+    assert tree.accepted_len_list
+    out, s = [], 0
+    hi, lo = max(tree.accepted_len_list), min(tree.accepted_len_list)
+    for length in tree.accepted_len_list:
+        if s + length > max_gen_len:
+            break
+        out.append(length)
+        s += length
+    while s < max_gen_len:
+        length = min(rng.randint(lo, hi), max_gen_len - s)
+        out.append(length)
+        s += length
+    tree.accepted_len_list = out
+
+
+# ---- synthetic templates of the same form -------------------------------------------------
+def synthetic_reasoning_template(widths=(7, 6), lens=(128, 64)) -> ExecuteTree:
+    """A tree-of-thoughts template: level d has widths[d] children per node, each generating lens[d] tokens
+    (7 x 128 then 42 x 64 = 50 live nodes).  Node ids in creation (BFS) order, like the
+    reference's files."""
+    data: Dict[str, Dict[str, Any]] = {"0": {"id": 0, "value": 0, "start": 0, "end": 0, "children": []}}
+    frontier = [0]
+    end_of = {0: 0}
+    for width, n_tok in zip(widths, lens):
+        nxt = []
+        for parent in frontier:
+            for _ in range(width):
+                nid = len(data)
+                start = end_of[parent] + 1
+                data[str(nid)] = {"id": nid, "value": n_tok, "start": start, "end": start + n_tok - 1, "children": []}
+                end_of[nid] = start + n_tok - 1
+                data[str(parent)]["children"].append(nid)
+                nxt.append(nid)
+        frontier = nxt
+    nodes = build_tree(data)
+    return ExecuteTree(nodes[0], nodes, None)
+
+
+def synthetic_speculative_template(tree_size: int = 64, steps: int = 100, accept=(1, 4), seed: int = 0) -> ExecuteTree:
+    rng = random.Random(seed)
+    nodes = [ExecuteTreeNode(i, 0, 0, 0) for i in range(tree_size)]
+    tree = ExecuteTree(nodes[0], nodes, None)
+    tree.accepted_len_list = [rng.randint(accept[0], accept[1]) for _ in range(steps)]
+    return tree
+
+
+def synthetic_few_shot_template(width: int = 32) -> ExecuteTree:
+    """SimpleTree (branch_func_example.py:12-62): the root branches into `width` leaves after the prefill."""
+    data: Dict[str, Dict[str, Any]] = {"0": {"id": 0, "value": 0, "start": 0, "end": 0, "children": list(range(1, width + 1))}}
+    for i in range(1, width + 1):
+        data[str(i)] = {"id": i, "value": 1 << 30, "start": 1, "end": 1 << 30, "children": []}
+    nodes = build_tree(data)
+    return ExecuteTree(nodes[0], nodes, None)
+
+
+# ---------------------------------------------------------------------------
+# branch functions (branch_func_example.py) on deft_amd.TreeCache
+# ---------------------------------------------------------------------------
+def _scores(logits) -> "np.ndarray":
+    """The branch functions only use the arg-top-k of the scores.  numpy on purpose: a torch CPU op on a [32, vocab]
+    tensor wakes the whole intra-op thread pool of a 256-core host and costs milliseconds per decode step."""
+    if isinstance(logits, torch.Tensor):
+        return logits.detach().float().cpu().numpy()
+    return np.asarray(logits)
+
+
+def _topk_ids(logits, row: int, k: int) -> List[int]:
+    x = _scores(logits)[row]
+    k = min(k, x.shape[-1])
+    idx = np.argpartition(-x, k - 1)[:k]
+    return idx[np.argsort(-x[idx], kind="stable")].tolist()
+
+
+def _greedy(logits) -> List[int]:
+    return _scores(logits).argmax(axis=1).tolist()
+
+
+def branch_from_tree_template(tree: TreeCache, iter: int, max_gen_len: int, logits: torch.Tensor,
+                              execution_graph: ExecuteTree) -> bool:
+    """branch_func_example.py:293-371: a leaf whose id is a parent in branch_record[iter] branches (its children get
+    the top-k tokens of its row), a leaf in prune_record[iter] is cut, every other leaf appends its argmax."""
+    branch_pairs = execution_graph.branch_record.get(iter, {})
+    prune_nodes = execution_graph.prune_record.get(iter, [])
+    stop = 0 in prune_nodes  # the root is released: the whole template has run (:315-319)
+    leaves = [tree.root] if iter == 0 else list(tree.leaves.values())
+    greedy = _greedy(logits)
+    for leaf in leaves:
+        if leaf.id in branch_pairs:
+            width = len(branch_pairs[leaf.id])
+            assert width > 0
+            q_idx = 0 if iter == 0 else tree.leaf_to_q[leaf.id]
+            ids = _topk_ids(logits, q_idx, width)
+            for j, child in enumerate(tree.branch(tree.nodes[leaf.id], width)):
+                child.append_token(int(ids[j % len(ids)]))
+        elif leaf.id in prune_nodes:
+            tree.cut(tree.nodes[leaf.id], record_deleted=True)
+        else:
+            leaf.append_token(int(greedy[tree.leaf_to_q[leaf.id]]))
+    return stop or iter == max_gen_len - 1
+
+
+def branch_speculative_decoding(tree: TreeCache, iter: int, max_gen_len: int, logits: torch.Tensor,
+                                execution_graph: ExecuteTree) -> bool:
+    """branch_func_example.py:374-442, the reference's mock of Medusa-style verification: at iter 0 the root
+    branches into `tree_size` one-token leaves; afterwards the first `Accept_length[iter]` leaves are merged into the
+    root (their KV slots move to the root), every leaf's own KV is released and its positions shift."""
+    accepted = execution_graph.accepted_len_list
+    assert accepted is not None
+    if iter == len(accepted):
+        return True
+    size = execution_graph.node_num
+    if iter == 0:
+        ids = _topk_ids(logits, 0, size)
+        for j, leaf in enumerate(tree.branch(tree.root, size)):
+            leaf.append_token(int(ids[j % len(ids)]))
+        return False
+    verified = accepted[iter]
+    leaves = list(tree.leaves.values())
+    assert len(leaves) == size
+    before = len(tree.root.kv_indices)
+    for i in range(min(verified, len(leaves))):
+        tree.merge_nodes(tree.root, leaves[i], pruneB_flag=False)
+    diff = len(tree.root.kv_indices) - before
+    for leaf in leaves:
+        tree.reset_node_KV(leaf, diff)
+    assert diff == min(verified, len(leaves))
+    return False
+
+
+def branch_few_shot(tree: TreeCache, iter: int, max_gen_len: int, logits: torch.Tensor, execution_graph: ExecuteTree) -> bool:
+    """branch_func_example.py:12-62 (SimpleTree): branch into `width` leaves after the prefill, then greedy."""
+    width = len(execution_graph.root.children)
+    if iter == 0:
+        ids = _topk_ids(logits, 0, width)
+        for j, leaf in enumerate(tree.branch(tree.root, width)):
+            leaf.append_token(int(ids[j % len(ids)]))
+    else:
+        greedy = _greedy(logits)
+        for leaf in tree.leaves.values():
+            leaf.append_token(int(greedy[tree.leaf_to_q[leaf.id]]))
+    return iter == max_gen_len - 1
+
+
+BRANCH_FUNCS: Dict[str, Callable[..., bool]] = {
+    "reasoning": branch_from_tree_template, "speculative_decoding": branch_speculative_decoding,
+    "few_shot": branch_few_shot,
+}
+
+
+# ---------------------------------------------------------------------------
+# the decode loop (tree_generate.py:89-260) around the attention path
+# ---------------------------------------------------------------------------
+@dataclass
+class ReplayReport:
+    task: str
+    mode: str
+    steps: int = 0
+    prompt_len: int = 0
+    generated_tokens: int = 0  # TreeCache.get_tree_token_number() - prompt (tree_cache.py:569-584)
+    decoded_rows: int = 0      # sum over steps of live leaves = query rows pushed through attention
+    attention_ms: float = 0.0  # GPU time of the per-layer append + attention calls, all layers, all steps
+    metadata_ms: float = 0.0   # host time of alloc + TreeMetadata.from_tree_cache (+ upload), all steps
+    branch_ms: float = 0.0     # host time of the branch function
+    wall_ms: float = 0.0
+    per_step: List[Dict[str, float]] = field(default_factory=list)
+
+    def summary(self) -> Dict[str, Any]:
+        gen = max(self.generated_tokens, 1)
+        return {
+            "task": self.task, "mode": self.mode, "steps": self.steps, "prompt_len": self.prompt_len,
+            "generated_tokens": self.generated_tokens, "decoded_rows": self.decoded_rows,
+            "attention_latency_ms": round(self.attention_ms, 3), "metadata_ms": round(self.metadata_ms, 3),
+            "branch_ms": round(self.branch_ms, 3), "wall_ms": round(self.wall_ms, 3),
+            "attention_TPOT_ms_per_token": round(self.attention_ms / gen, 5),  # perf_metrics.py:203-210 on attention latency
+            "attention_us_per_step": round(self.attention_ms * 1e3 / max(self.steps, 1), 2),
+            "max_live_leaves": int(max((s["nq"] for s in self.per_step), default=0)),
+            "max_tree_kv_tokens": int(max((s["kv_tokens"] for s in self.per_step), default=0)),
+        }
+
+
+class TemplateReplay:
+    """One decoding tree replayed step by step.  `attention=False` runs the tree / page-table / metadata work only
+    (no GPU needed); with attention every layer of every step goes through DeFTAttention exactly as the model's
+    layers would call it (llama2.py:108-113)."""
+
+    def __init__(self, num_heads: int, num_kv_heads: int, head_dim: int, layers: int, mode: str = "flatten",
+                 device: str = "cuda", attention: bool = True, seed: int = 0, vocab: int = 4096) -> None:
+        self.Hq, self.Hkv, self.D, self.layers = num_heads, num_kv_heads, head_dim, layers
+        self.mode = mode
+        self.forward_mode: ForwardMode = forward_mode_from_cli(mode)
+        self.device = device
+        self.attention = attention
+        self.vocab = vocab
+        self.rng = np.random.default_rng(seed)
+        if attention:
+            from .deft_attention import DeFTAttention
+
+            self.attn = [DeFTAttention(num_heads, head_dim, head_dim ** -0.5, num_kv_heads, l) for l in range(layers)]
+
+    def _pools(self, max_tokens: int, max_leaves: int):
+        req = ReqToTokenPool(max_leaves + 8, max_tokens + 8, device=self.device)
+        pool = TokenToKVPool(max_tokens, torch.float16, self.Hkv, self.D, self.layers if self.attention else 0,
+                             device=self.device)
+        return req, pool
+
+    def run(self, template: ExecuteTree, task: str, prompt_len: int, max_gen_len: int, max_tokens: Optional[int] = None,
+            max_leaves: int = 512, max_rows: int = 512) -> ReplayReport:
+        branch = BRANCH_FUNCS[task]
+        if task == "speculative_decoding":
+            max_gen_len = min(max_gen_len, len(template.accepted_len_list or []) + 1)
+        if max_tokens is None:
+            budget = sum(max(n.value, 0) for n in template.nodes if n.value < (1 << 29))
+            if task == "speculative_decoding":
+                budget = sum(template.accepted_len_list or []) + 2 * template.node_num * 2
+            if task == "few_shot":
+                budget = len(template.root.children) * max_gen_len
+            max_tokens = prompt_len + budget + max_leaves + 1024
+        req, pool = self._pools(max_tokens, max_leaves)
+        tree = TreeCache(torch.float16, self.Hkv, self.D, self.layers, req, pool, None, True, False)
+        rep = ReplayReport(task=task, mode=self.mode, prompt_len=prompt_len)
+        dev = self.device
+        if self.attention:
+            g = torch.Generator(device=dev)
+            g.manual_seed(1)
+            for l in range(self.layers):  # prefill stand-in: the prompt's KV is whatever the pool holds
+                pool._storage[l].normal_(generator=g)
+            q_all = torch.randn((self.layers, max_rows, self.Hq * self.D), dtype=torch.float16, device=dev, generator=g)
+            k_all = torch.randn((self.layers, max_rows, self.Hkv * self.D), dtype=torch.float16, device=dev, generator=g)
+            v_all = torch.randn((self.layers, max_rows, self.Hkv * self.D), dtype=torch.float16, device=dev, generator=g)
+        t_wall = time.perf_counter()
+        tree.init_prompt(torch.arange(1, prompt_len + 1, dtype=torch.int32))
+        logits = self.rng.random((1, self.vocab), dtype=np.float32)
+        stop = branch(tree, 0, max_gen_len, logits, template)  # tree_generate.py:188-197
+        it = 1
+        while not stop and it < max_gen_len:
+            # ---- prepare: positions, KV slots for this step's tokens, metadata (tree_generate.py:93-131) -------
+            t0 = time.perf_counter()
+            leaves = sorted(tree.leaves.values(), key=lambda x: x.id)
+            nq = len(leaves)
+            if nq == 0:
+                break
+            assert nq <= max_rows, f"{nq} live leaves exceed max_rows={max_rows}"
+            tree.leaf_to_q = {leaf.id: i for i, leaf in enumerate(leaves)}
+            updater = tree.alloc()
+            md = None
+            if self.forward_mode != ForwardMode.DECODE:
+                md = TreeMetadata.from_tree_cache(tree, device=dev)
+                register_tree_metadata(md)
+                meta = InputMetadata(self.forward_mode, updater, pool)
+            else:
+                positions = torch.tensor([lf.positions[-1] for lf in leaves], dtype=torch.int64, device=dev)
+                meta = InputMetadata.from_tree(tree, req, pool, self.forward_mode, positions, updater)
+            t_md = (time.perf_counter() - t0) * 1e3
+            # ---- forward: the attention path of every layer ---------------------------------------------------
+            t_attn = 0.0
+            if self.attention:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for l in range(self.layers):
+                    self.attn[l](q_all[l, :nq], k_all[l, :nq], v_all[l, :nq], meta)
+                e1.record()
+                e1.synchronize()
+                t_attn = e0.elapsed_time(e1)
+            # ---- branch (tree_generate.py:226-236) ------------------------------------------------------------
+            t1 = time.perf_counter()
+            logits = self.rng.random((nq, self.vocab), dtype=np.float32)
+            kv_tokens = md.total_kv_len if md is not None else sum(len(n.kv_indices) for n in tree.nodes.values())
+            stop = branch(tree, it, max_gen_len, logits, template)
+            t_br = (time.perf_counter() - t1) * 1e3
+            rep.per_step.append({"iter": it, "nq": nq, "kv_tokens": int(kv_tokens), "attention_ms": t_attn,
+                                 "metadata_ms": t_md, "branch_ms": t_br})
+            rep.steps += 1
+            rep.decoded_rows += nq
+            rep.attention_ms += t_attn
+            rep.metadata_ms += t_md
+            rep.branch_ms += t_br
+            it += 1
+        rep.wall_ms = (time.perf_counter() - t_wall) * 1e3
+        rep.generated_tokens = tree.get_tree_token_number() - prompt_len
+        self.tree, self.pool, self.req = tree, pool, req  # left for inspection by tests
+        return rep

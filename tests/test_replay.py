@@ -1,0 +1,140 @@
+"""Template replay (deft_amd/replay.py): the template model is pinned bit-exactly on what the reference's own
+data_loader derives (tests/golden/templates.json, tools/gen_golden_templates.py); the decode loop is exercised on CPU
+(tree / page table / metadata only) and on the GPU with every step's attention checked against fp64 truth."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import deft_amd
+from deft_amd import replay as rp
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "templates.json")))
+
+
+@pytest.mark.parametrize("name", sorted(GOLD["reasoning"]))
+def test_template_records_match_reference(name):
+    g = GOLD["reasoning"][name]
+    nodes = rp.build_tree(g["data"])
+    tree = rp.ExecuteTree(nodes[0], nodes)
+    assert tree.node_num == g["node_num"] and tree.max_depth == g["max_depth"] and tree.max_width == g["max_width"]
+    assert {str(k): {str(p): c for p, c in v.items()} for k, v in tree.branch_record.items()} == g["branch_record"]
+    assert {str(k): v for k, v in tree.prune_record.items()} == g["prune_record"]
+    assert {str(k): v for k, v in tree.width_per_depth.items()} == g["width_per_depth"]
+
+
+def test_load_trees_and_prompts_from_files(tmp_path):
+    g = GOLD["reasoning"]["docmergeToT"]
+    p = tmp_path / "toy.json"
+    p.write_text(json.dumps([{"incompleted": True, "prompt": "x", "data": g["data"]},
+                             {"incompleted": False, "prompt": "y", "data": g["data"]}]))
+    trees = rp.load_trees(str(p))
+    assert len(trees) == 1 and trees[0].prompt == "y" and trees[0].node_num == g["node_num"]  # incompleted skipped
+    sd = GOLD["speculative"]["tree_size64"]
+    p2 = tmp_path / "sd.json"
+    p2.write_text(json.dumps({"Tree_ID": 1, "Tree_Structure": [], "Token_Tree_size": sd["Token_Tree_size"],
+                              "Records": [{"prompt": "q", "Accept_length": sd["Accept_length_0"]}]}))
+    t = rp.load_prompts(str(p2))[0]
+    assert t.node_num == sd["node_num"] == 64 and t.accepted_len_list == sd["Accept_length_0"]
+    import random
+    rp.generate_accepted_len_list(50, t, random.Random(0))
+    assert sum(t.accepted_len_list) == 50
+    with pytest.raises(NotImplementedError):
+        rp.load_dataset("x.csv")
+
+
+def _cpu_replay(task, template, prompt_len, max_gen_len, mode="flatten"):
+    r = rp.TemplateReplay(8, 2, 128, layers=1, mode=mode, device="cpu", attention=False)
+    return r, r.run(template, task, prompt_len, max_gen_len)
+
+
+def test_reasoning_replay_follows_the_template_and_frees_everything():
+    tpl = rp.synthetic_reasoning_template(widths=(3, 2), lens=(5, 4))
+    r, rep = _cpu_replay("reasoning", tpl, prompt_len=40, max_gen_len=64)
+    # 3 nodes x 5 tokens, then 6 x 4: live leaves 3 for 5 steps ... the replay stops when the root is released
+    nqs = [int(s["nq"]) for s in rep.per_step]
+    assert nqs[:4] == [3, 3, 3, 3] and max(nqs) == 6 and rep.steps == len(nqs)
+    assert rep.generated_tokens == 3 * 5 + 6 * 4
+    assert len(r.tree.leaves) == 0 and len(r.tree.nodes) == 0  # every node cut, root included
+    assert int((r.pool.mem_state != 0).sum()) == 0  # all KV slots back in the pool
+
+
+def test_reference_template_replay_runs_to_completion():
+    g = GOLD["reasoning"]["docmergeToT"]
+    nodes = rp.build_tree(g["data"])
+    tpl = rp.ExecuteTree(nodes[0], nodes)
+    r, rep = _cpu_replay("reasoning", tpl, prompt_len=nodes[0].value, max_gen_len=100000)
+    assert rep.generated_tokens == sum(n.value for n in nodes[1:])
+    assert len(r.tree.nodes) == 0 and int((r.pool.mem_state != 0).sum()) == 0
+    assert 1 <= rep.summary()["max_live_leaves"] <= tpl.node_num  # leaves of several depths are live at once
+
+
+def test_speculative_replay_squeezes_accepted_tokens_into_the_root():
+    tpl = rp.synthetic_speculative_template(tree_size=8, steps=6, accept=(1, 3), seed=3)
+    r, rep = _cpu_replay("speculative_decoding", tpl, prompt_len=30, max_gen_len=100, mode="node")
+    acc = tpl.accepted_len_list
+    assert rep.steps == len(acc)  # iterations 1 .. len(acc); the branch function stops at iter == len(acc) (:383-394)
+    assert len(r.tree.root.kv_indices) == 30 + sum(acc[1:])  # branch_func_example.py:436-440
+    assert all(int(s["nq"]) == 8 for s in rep.per_step)
+
+
+def test_few_shot_replay_counts():
+    tpl = rp.synthetic_few_shot_template(width=5)
+    r, rep = _cpu_replay("few_shot", tpl, prompt_len=16, max_gen_len=7)
+    assert rep.steps == 6 and rep.decoded_rows == 30 and rep.generated_tokens == 5 * 7
+    md = deft_amd.TreeMetadata.from_tree_cache(r.tree, device="cpu")
+    assert md.query_num == 5 and md.total_kv_len == 16 + 5 * 6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("task,mode", [("reasoning", "flatten"), ("reasoning", "node"), ("reasoning", "seq"),
+                                       ("speculative_decoding", "node"), ("few_shot", "flatten")])
+def test_replay_attention_matches_truth_every_step(task, mode):
+    """Run a small template with attention on the GPU and check, at every step, the output of layer 0 against fp64
+    per-leaf attention over the leaf's page-table row (what the tree holds at that step)."""
+    Hq, Hkv, D = 8, 2, 128
+    tpl = {"reasoning": rp.synthetic_reasoning_template(widths=(3, 2), lens=(6, 5)),
+           "speculative_decoding": rp.synthetic_speculative_template(tree_size=12, steps=5, accept=(1, 3), seed=1),
+           "few_shot": rp.synthetic_few_shot_template(width=6)}[task]
+    r = rp.TemplateReplay(Hq, Hkv, D, layers=2, mode=mode, device="cuda", attention=True)
+    seen = {"steps": 0}
+    attn0 = r.attn[0]
+    orig = attn0.forward
+
+    def checked(q, k, v, meta):
+        out = orig(q, k, v, meta)
+        torch.cuda.synchronize()
+        tree = r._tree_ref()
+        leaves = sorted(tree.leaves.values(), key=lambda n: n.id)
+        kv = tree.token_to_kv_pool.kv_data[0].float().cpu().numpy().astype(np.float64)
+        qn = q.view(-1, Hq, D).float().cpu().numpy().astype(np.float64)
+        on = out.view(-1, Hq, D).float().cpu().numpy()
+        for i, lf in enumerate(leaves):
+            slots = tree.leaf_path_slots(lf)
+            for hq in range(Hq):
+                kh = hq // (Hq // Hkv)
+                s = kv[slots, 0, kh] @ qn[i, hq] / np.sqrt(D)
+                p = np.exp(s - s.max())
+                ref = (p / p.sum()) @ kv[slots, 1, kh]
+                assert np.abs(on[i, hq] - ref).max() < 5e-4
+        seen["steps"] += 1
+        return out
+
+    attn0.forward = checked
+    holder = {}
+    r._tree_ref = lambda: holder["tree"]
+    real_tree_cls = rp.TreeCache
+
+    class Spy(real_tree_cls):
+        def __init__(self, *a, **kw):
+            super().__init__(*a, **kw)
+            holder["tree"] = self
+
+    rp.TreeCache = Spy
+    try:
+        rep = r.run(tpl, task, prompt_len=200, max_gen_len=12)
+    finally:
+        rp.TreeCache = real_tree_cls
+    assert seen["steps"] == rep.steps > 3 and rep.attention_ms > 0

@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Replay the reference's three workloads through the attention path and print its latency table per mode
+(attention-only: the model forward is synthetic, see deft_amd/replay.py).
+
+  tools/replay.py --task reasoning --modes flatten node seq                      # synthetic ToT 4k prompt, 7x128 -> 42x64
+  tools/replay.py --task reasoning --template .../Reasoning/sorting128ToT.json  # a file of the reference's dataset
+  tools/replay.py --task speculative_decoding --modes node flatten seq --tree-size 64
+  tools/replay.py --task few_shot --width 32 --prompt-len 4096 --max-gen-len 200
+"""
+import argparse, json, os, sys
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+from deft_amd import replay as rp
+from deft_amd.utils.workloads import GEOMETRY
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--task", default="reasoning", choices=sorted(rp.BRANCH_FUNCS))
+ap.add_argument("--modes", nargs="+", default=["flatten", "node", "seq"])
+ap.add_argument("--model", default="llama2-7b", choices=sorted(GEOMETRY))
+ap.add_argument("--layers", type=int, default=None)
+ap.add_argument("--template", default=None, help="a dataset/generation/** file of the reference repository")
+ap.add_argument("--tree-index", type=int, default=0)
+ap.add_argument("--prompt-len", type=int, default=None)
+ap.add_argument("--max-gen-len", type=int, default=400)
+ap.add_argument("--width", type=int, default=32)
+ap.add_argument("--tree-size", type=int, default=64)
+ap.add_argument("--sd-steps", type=int, default=100)
+ap.add_argument("--out", default=None)
+a = ap.parse_args()
+Hq, Hkv, D, L = GEOMETRY[a.model]
+L = a.layers or L
+
+
+def template():
+    if a.task == "reasoning":
+        if a.template:
+            return rp.load_trees(a.template)[a.tree_index]
+        return rp.synthetic_reasoning_template()
+    if a.task == "speculative_decoding":
+        if a.template:
+            t = rp.load_prompts(a.template)[a.tree_index]
+            return t
+        return rp.synthetic_speculative_template(a.tree_size, a.sd_steps)
+    return rp.synthetic_few_shot_template(a.width)
+
+
+rows = []
+for mode in a.modes:
+    tpl = template()
+    prompt_len = a.prompt_len or (tpl.root.value if a.template and a.task == "reasoning" and tpl.root.value > 0 else
+                                  (1016 if a.task == "speculative_decoding" else 4096))
+    r = rp.TemplateReplay(Hq, Hkv, D, L, mode=mode, device="cuda", attention=True)
+    rep = r.run(tpl, a.task, prompt_len, a.max_gen_len, max_rows=max(512, a.width, a.tree_size))
+    s = rep.summary(); s["model"] = a.model; s["layers"] = L
+    rows.append(s)
+    print(json.dumps(s), flush=True)
+    del r
+    torch.cuda.empty_cache()
+base = next((x for x in rows if x["mode"] == "seq"), None)
+print(f"\n{'mode':10s} {'steps':>6s} {'gen tok':>8s} {'attn ms':>10s} {'us/step':>9s} {'TPOT ms':>9s} {'md ms/step':>10s} {'vs seq':>7s}")
+for s in rows:
+    sp = f"{base['attention_latency_ms'] / s['attention_latency_ms']:.2f}x" if base else "-"
+    print(f"{s['mode']:10s} {s['steps']:6d} {s['generated_tokens']:8d} {s['attention_latency_ms']:10.2f} {s['attention_us_per_step']:9.1f} "
+          f"{s['attention_TPOT_ms_per_token']:9.4f} {s['metadata_ms'] / max(s['steps'], 1):10.3f} {sp:>7s}")
+if a.out:
+    json.dump(rows, open(a.out, "w"), indent=1)
