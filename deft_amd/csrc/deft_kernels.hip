@@ -1387,3 +1387,59 @@ int deft_seq_decode_append_f16(const void* q, int64_t q_stride_tok, int64_t q_st
 }
 
 }  // extern "C"
+
+
+// ---------------------------------------------------------------------------
+// Rotary position embedding of this step's q and k rows, in place: the op right in front of the attention path
+// (LlamaAttention.forward, DeFT/deft/models/llama2.py:108-110 -> RotaryEmbedding.forward_cuda,
+// DeFT/deft/layers/rotary_embedding.py:157-177, which calls flashinfer.rope.apply_rope_with_cos_sin_cache_inplace:
+// NeoX pairing (d, d + rot/2), cos|sin cache in fp32 (llama2.py:86-93 passes dtype=float32), arithmetic in fp32,
+// one rounding back to fp16).  flashinfer is not part of the reference tree; its published algorithm is restated
+// in oracle/rope.py.  No FMA contraction, so the fp32 products and sums are the oracle's.
+// ---------------------------------------------------------------------------
+namespace deft {
+
+__global__ __launch_bounds__(256) void rope_qk_kernel(_Float16* q, int64_t q_st, int64_t q_sh, int Hq, _Float16* k,
+                                                       int64_t k_st, int64_t k_sh, int Hk, const int64_t* positions,
+                                                       const float* cos_sin, int64_t cache_stride, int n, int D, int rot,
+                                                       int neox) {
+#pragma clang fp contract(off)
+    const int half = rot / 2;
+    const int per_tok = (Hq + Hk) * half;
+    const int64_t total = (int64_t)n * per_tok;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int tok = (int)(i / per_tok);
+        const int rem = (int)(i - (int64_t)tok * per_tok);
+        const int hd = rem / half;
+        const int j = rem - hd * half;
+        _Float16* row = hd < Hq ? q + (int64_t)tok * q_st + (int64_t)hd * q_sh : k + (int64_t)tok * k_st + (int64_t)(hd - Hq) * k_sh;
+        const float* cs = cos_sin + positions[tok] * cache_stride;
+        const float c = cs[j], sn = cs[half + j];
+        const int i1 = neox ? j : 2 * j, i2 = neox ? j + half : 2 * j + 1;
+        const float x1 = (float)row[i1], x2 = (float)row[i2];
+        const float o1 = x1 * c - x2 * sn;
+        const float o2 = x2 * c + x1 * sn;
+        row[i1] = (_Float16)o1;
+        row[i2] = (_Float16)o2;
+    }
+}
+
+}  // namespace deft
+
+extern "C" int deft_rope_qk_f16(void* q, int64_t q_stride_tok, int64_t q_stride_head, int Hq, void* k, int64_t k_stride_tok,
+                                int64_t k_stride_head, int Hk, const int64_t* positions, const float* cos_sin_cache,
+                                int64_t cache_stride, int n, int D, int rotary_dim, int is_neox_style, void* stream) {
+    if (n == 0) return DEFT_OK;
+    if (!q || !k || !positions || !cos_sin_cache || n < 0 || Hq <= 0 || Hk < 0 || D <= 0 || rotary_dim <= 0 ||
+        rotary_dim > D || (rotary_dim & 1) || cache_stride < rotary_dim) {
+        set_error("bad rope arguments (n=%d Hq=%d Hk=%d D=%d rotary_dim=%d)", n, Hq, Hk, D, rotary_dim);
+        return DEFT_EINVAL;
+    }
+    const int64_t total = (int64_t)n * (Hq + Hk) * (rotary_dim / 2);
+    const int64_t blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(deft::rope_qk_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), static_cast<_Float16*>(q), q_stride_tok, q_stride_head, Hq,
+                       static_cast<_Float16*>(k), k_stride_tok, k_stride_head, Hk, positions, cos_sin_cache, cache_stride, n,
+                       D, rotary_dim, is_neox_style ? 1 : 0);
+    return deft::check_launch("rope launch");
+}

@@ -175,6 +175,19 @@ int deft_node_decode_append_f16(
     const int32_t* cache_loc, const void* k_new, const void* v_new, int64_t new_stride_tok, int n_new,
     const void* plan, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- rotary position embedding of this step's q / k rows (the op in front of the path) -----------------
+ *
+ * In place, like RotaryEmbedding.forward_cuda (DeFT/deft/layers/rotary_embedding.py:157-177 ->
+ * flashinfer.rope.apply_rope_with_cos_sin_cache_inplace; LlamaAttention.forward, llama2.py:108-110):
+ * q[n][Hq][D], k[n][Hk][D] fp16 (strided views of the fused qkv are fine), positions[n] int64,
+ * cos_sin_cache[max_pos][rotary_dim] fp32 = cos(rotary_dim/2) | sin(rotary_dim/2)  (rotary_embedding.py:119-127,
+ * created with dtype=float32 at llama2.py:86-93).  fp32 arithmetic, one rounding to fp16.
+ */
+int deft_rope_qk_f16(void* q, int64_t q_stride_tok, int64_t q_stride_head, int Hq,
+                     void* k, int64_t k_stride_tok, int64_t k_stride_head, int Hk,
+                     const int64_t* positions, const float* cos_sin_cache, int64_t cache_stride,
+                     int n, int D, int rotary_dim, int is_neox_style, void* stream);
+
 /* ---- sequential (per-request) paged attention: the reference's comparator ---------------------------------
  *
  * Replaces token_attention_fwd (DeFT/deft/layers/attention/token_attention.py:297-335) behind

@@ -1,0 +1,72 @@
+"""Rotary embedding in front of the path (deft_rope_qk_f16 / deft_amd.RotaryEmbedding).
+
+flashinfer, which the reference's decode path calls for this op (rotary_embedding.py:31, :157-177), is not part of the
+reference tree: parity is against the restated algorithm (oracle/rope.py, fp32 arithmetic) -- bit-exact -- and
+against an fp64 evaluation of the same rotation (<= 1 fp16 ulp)."""
+import numpy as np
+import pytest
+import torch
+
+import deft_amd
+from deft_amd.utils.synthetic import dyadic_normal
+from oracle import rope as orope
+
+
+def test_oracle_cache_matches_the_reference_formula():
+    rot, maxpos, base = 128, 512, 10000.0
+    cache = orope.cos_sin_cache(rot, maxpos, base)
+    inv = 1.0 / (base ** (torch.arange(0, rot, 2, dtype=torch.float) / rot))  # rotary_embedding.py:109-116
+    freqs = torch.einsum("i,j -> ij", torch.arange(maxpos, dtype=torch.float), inv)
+    ref = torch.cat((freqs.cos(), freqs.sin()), dim=-1).numpy()
+    assert np.abs(cache - ref).max() < 1e-4  # fp32 angles up to 511 rad: numpy's and torch's cos differ by ulps of the ANGLE
+    mod = deft_amd.RotaryEmbedding(128, rot, maxpos, base, True)
+    assert np.array_equal(mod.cos_sin_cache.numpy(), ref)
+
+
+@pytest.mark.parametrize("neox", [True, False])
+def test_oracle_rotation_is_the_rotation(neox):
+    n, H, D = 5, 3, 128
+    x = dyadic_normal((n, H, D), 11)
+    pos = np.array([0, 1, 17, 300, 511])
+    cache = orope.cos_sin_cache(D, 512)
+    out = orope.apply_rope(x, pos, cache, D, neox).astype(np.float64)
+    xf = x.astype(np.float64)
+    ang = pos[:, None] * (1.0 / (10000.0 ** (np.arange(0, D, 2) / D)))[None, :]
+    c, s = np.cos(ang)[:, None, :], np.sin(ang)[:, None, :]
+    x1, x2 = (xf[..., : D // 2], xf[..., D // 2:]) if neox else (xf[..., 0::2], xf[..., 1::2])
+    o1, o2 = x1 * c - x2 * s, x2 * c + x1 * s
+    ref = np.concatenate([o1, o2], -1) if neox else np.stack([o1, o2], -1).reshape(n, H, D)
+    assert np.abs(out - ref).max() < 4e-3  # fp16 rounding of values up to ~4, fp32 cache angles up to 511 rad
+    norm_in = (xf ** 2).sum(-1)
+    assert np.abs((out ** 2).sum(-1) - norm_in).max() / norm_in.max() < 2e-3  # a rotation keeps the norm
+
+
+def test_module_refuses_cpu_tensors_and_scaled_variants():
+    mod = deft_amd.get_rope(128, 128, 64, 10000.0)
+    q = torch.zeros(2, 4 * 128, dtype=torch.float16)
+    with pytest.raises(deft_amd.DeftLibraryError, match="no CPU path"):
+        mod(torch.zeros(2, dtype=torch.int64), q, q.clone())
+    with pytest.raises(NotImplementedError):
+        deft_amd.get_rope(128, 128, 64, 10000.0, rope_scaling={"type": "linear", "factor": 2.0})
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("Hq,Hkv,D,rot,neox", [(32, 32, 128, 128, True), (32, 8, 128, 128, True), (8, 2, 64, 64, True),
+                                               (4, 4, 128, 64, True), (4, 4, 128, 128, False)])
+def test_gpu_rope_is_bit_exact_on_fused_qkv_views(Hq, Hkv, D, rot, neox):
+    n, maxpos = 37, 4400
+    qkv_np = dyadic_normal((n, (Hq + 2 * Hkv) * D), 5)
+    pos_np = np.random.default_rng(0).integers(0, maxpos, size=n)
+    qkv = torch.from_numpy(qkv_np).cuda()
+    q, k, v = qkv.split([Hq * D, Hkv * D, Hkv * D], dim=-1)  # strided views, as llama2.py:108-109 hands them over
+    mod = deft_amd.RotaryEmbedding(D, rot, maxpos, 10000.0, neox).cuda()
+    q2, k2 = mod(torch.from_numpy(pos_np).cuda(), q, k)
+    torch.cuda.synchronize()
+    assert q2.data_ptr() == q.data_ptr() and k2.data_ptr() == k.data_ptr()  # in place
+    cache = mod.cos_sin_cache.cpu().numpy()
+    q_ref = orope.apply_rope(qkv_np[:, : Hq * D].reshape(n, Hq, D), pos_np, cache, rot, neox)
+    k_ref = orope.apply_rope(qkv_np[:, Hq * D: (Hq + Hkv) * D].reshape(n, Hkv, D), pos_np, cache, rot, neox)
+    out = qkv.cpu().numpy()
+    assert np.array_equal(out[:, : Hq * D].reshape(n, Hq, D), q_ref)
+    assert np.array_equal(out[:, Hq * D: (Hq + Hkv) * D].reshape(n, Hkv, D), k_ref)
+    assert np.array_equal(out[:, (Hq + Hkv) * D:], qkv_np[:, (Hq + Hkv) * D:])  # v untouched
