@@ -261,18 +261,22 @@ def main():
     roofline = None
     if s1 is not None:
         achieved = algo / (s1["mean_us"] * 1e-6) / 1e9
-        traffic = None  # HBM bytes per launch from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE, x2 gfx950 correction)
+        # HBM bytes per launch from the committed PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE, own pass,
+        # x2 gfx950 correction, /opt/skills/guides/MI355X_MICROARCH.md "HBM"); null for workloads that were not profiled
+        kind = "stage1_np_kernel" if lib.deft_stage1_kind() == 1 else "stage1_stream_kernel"
+        pmc_file = "r1b_pmc_fetch_size_np.json" if kind == "stage1_np_kernel" else "r1_pmc_fetch_size.json"
+        traffic = None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_fetch_size.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
             if w.name == "northstar_4kx32" and w.branch_len == 200:
-                k = [v for n, v in pmc["kernels"].items() if "stage1_stream_kernel" in n]
+                k = [v for n, v in pmc["kernels"].items() if kind in n]
                 traffic = k[0]["hbm_read_bytes_per_launch"] if k else None
         except Exception:
             traffic = None
-        roofline = {"bound": "hbm", "kernel": "deft::stage1_stream_kernel<128> (Flatten stage 1)",
+        roofline = {"bound": "hbm", "kernel": f"deft::{kind}<128> (Flatten stage 1)",
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                    "traffic_source": "profiles/r1_pmc_fetch_size.json (read bytes; separate --pmc pass)" if traffic else None,
+                    "traffic_source": f"profiles/{pmc_file} (read bytes; separate --pmc pass)" if traffic else None,
                     "algorithmic_bytes_per_launch": algo, "avg_launch_us": round(s1["mean_us"], 2),
                     "median_launch_us": round(s1["median_us"], 2), "launches_timed": s1["launches"],
                     "timing": "HIP events around a hipGraph of one launch per layer pool" if s1.get("launch") == "hipgraph"
