@@ -588,16 +588,19 @@ static int np_union_env() {  // tiles per union group of leaf tiles (1 = off, 0 
 // Flatten plan: unit list (one workgroup) then one record per unit.
 static int launch_plan(const Stage1Params& p, int NB, const PlanView& pv, const AppendArgs& ap, hipStream_t stream) {
     if (NB <= 0) return DEFT_OK;
-    const size_t lds = sizeof(int) * 2 * (size_t)NB;
-    if (lds > 64 * 1024) {
+    if (sizeof(int) * 4 * (size_t)NB > 48 * 1024) {
         set_error("plan: %d blocks exceed the unit kernel's LDS", NB);
         return DEFT_EUNSUPPORTED;
     }
+    // block tables + a run table for the tile-parallel record order (as many runs as fit; beyond that the kernel scans)
+    int64_t run_cap = pv.cap;
+    while (sizeof(int) * (4 * (size_t)NB + 3 * (size_t)run_cap) > 60 * 1024 && run_cap > 0) run_cap /= 2;
+    const size_t lds = sizeof(int) * (4 * (size_t)NB + 3 * (size_t)run_cap);
     const UnitList ul = unit_list(pv);
     const int np = stage1_kind();
     hipLaunchKernelGGL(flatten_units_kernel, dim3(1), dim3(256), lds, stream, p.block_q, p.block_q_cnts, p.block_q_offset, NB,
                        p.G, (int)pv.cap, ul, pv.hdr, pv.sched, np, p.Hkv, 2 * num_cus(), np_chunk_env(), np ? np_union_env() : 1,
-                       getenv("DEFT_NP_TAPER") ? atoi(getenv("DEFT_NP_TAPER")) : 0);
+                       getenv("DEFT_NP_TAPER") ? atoi(getenv("DEFT_NP_TAPER")) : 0, (int)run_cap);
     int rc = check_launch("flatten units launch");
     if (rc) return rc;
     hipLaunchKernelGGL(flatten_records_kernel, dim3((unsigned)(pv.cap + 1)), dim3(128), 0, stream, p.block_q, p.block_q_cnts,
@@ -983,8 +986,11 @@ static int launch_node_plan(const Stage1Params& p, int NE, int64_t rows_cap, con
                             hipStream_t stream) {
     const UnitList ul = unit_list(pv);
     const int np = stage1_kind();
-    hipLaunchKernelGGL(node_units_kernel, dim3(1), dim3(256), 0, stream, p.node_kv_len, p.node_q_len, NE, p.G, (int)pv.cap,
-                       rows_cap, ul, pv.hdr, pv.sched, pv.row_q, np, p.Hkv, 2 * num_cus(), np_chunk_env());
+    int64_t run_cap = pv.cap;
+    while (sizeof(int) * 3 * (size_t)run_cap > 60 * 1024 && run_cap > 0) run_cap /= 2;
+    hipLaunchKernelGGL(node_units_kernel, dim3(1), dim3(256), sizeof(int) * 3 * (size_t)(run_cap > 0 ? run_cap : 1), stream,
+                       p.node_kv_len, p.node_q_len, NE, p.G, (int)pv.cap, rows_cap, ul, pv.hdr, pv.sched, pv.row_q, np, p.Hkv,
+                       2 * num_cus(), np_chunk_env(), (int)run_cap);
     int rc = check_launch("node units launch");
     if (rc) return rc;
     hipLaunchKernelGGL(node_records_kernel, dim3((unsigned)(pv.cap + 1)), dim3(128), 0, stream, p.node_kv, p.node_kv_offset,

@@ -595,47 +595,66 @@ constexpr int UNION_CAP = 4;
 // (interleaved: the chunks of a run advance through the pool side by side, one contiguous front).  Records are
 // renumbered: the leaders of all chunks first (run by run, so the long shared-prefix chunks are dispatched first),
 // then the followers, those of one chunk consecutive.  hdr[1] = number of leaders.  One thread.
-__device__ inline void np_record_order(const UnitList& ul, int R, int Hkv, int slots, int chunk_c, int32_t* hdr) {
+// The runs come from a table the emitting thread kept in LDS (run k = units r0[k] .. r0[k] + nt[k] - 1, uni[k] = it is
+// a union group): walking the unit arrays in global memory instead costs one dependent load per unit (~100 us for the
+// north-star tree, once per decode step).
+struct RunTable {
+    int* r0;
+    int* nt;
+    int* uni;
+    int n;    // runs recorded
+    int cap;  // capacity; n > cap = overflow, fall back to scanning the unit arrays
+};
+__device__ inline void run_push(RunTable& rt, int r0, int nt, int uni) {
+    if (rt.n < rt.cap) {
+        rt.r0[rt.n] = r0;
+        rt.nt[rt.n] = nt;
+        rt.uni[rt.n] = uni;
+    }
+    ++rt.n;
+}
+
+__device__ inline void np_record_order(const UnitList& ul, int R, int Hkv, int slots, int chunk_c, int32_t* hdr, RunTable rt) {
+    if (rt.n > rt.cap) {  // rebuild the table is impossible: scan (slow path, huge trees only)
+        rt.n = 0;
+        rt.cap = 0;
+    }
+    const bool have = rt.cap > 0;
+    // run iteration: either the LDS table or a scan over flags / aux
+    auto for_runs = [&](auto&& fn) {
+        if (have) {
+            for (int k = 0; k < rt.n; ++k) fn(rt.r0[k], rt.nt[k], rt.uni[k]);
+        } else {
+            for (int r = 0; r < R;) {
+                const int id = ul.flags[r] >> 1;
+                int e = r + 1;
+                while (e < R && (ul.flags[e] >> 1) == id) ++e;
+                fn(r, e - r, ul.aux[r] > 0 ? 1 : 0);
+                r = e;
+            }
+        }
+    };
     int C = chunk_c;
     if (C <= 0) {
         // Measured on MI355X (tools/np_sweep.sh): per-workgroup cost (descriptor round trip, 32-row epilogue) favours
         // long chunks, the critical path and the number of resident slots bound them.  8 tiles for long shared
         // prefixes, 4 from 8 tiles on, halved while fewer than ~0.3 workgroups per slot would be left.
         int lmax = 0;
-        for (int r = 0; r < R;) {
-            const int id = ul.flags[r] >> 1;
-            int e = r + 1;
-            while (e < R && (ul.flags[e] >> 1) == id) ++e;
-            if (ul.aux[r] <= 0 && e - r > lmax) lmax = e - r;
-            r = e;
-        }
+        for_runs([&](int, int nt, int uni) {
+            if (!uni && nt > lmax) lmax = nt;
+        });
         C = lmax >= 32 ? 8 : (lmax >= 8 ? 4 : (lmax >= 4 ? 2 : 1));
         for (; C > 1; C >>= 1) {
             int64_t n = 0;
-            for (int r = 0; r < R;) {
-                const int id = ul.flags[r] >> 1;
-                int e = r + 1;
-                while (e < R && (ul.flags[e] >> 1) == id) ++e;
-                n += ul.aux[r] > 0 ? 1 : (e - r + C - 1) / C;
-                r = e;
-            }
+            for_runs([&](int, int nt, int uni) { n += uni ? 1 : (nt + C - 1) / C; });
             if (10 * n * Hkv >= 3LL * slots) break;
         }
     }
     int NL = 0;
-    for (int r = 0; r < R;) {
-        const int id = ul.flags[r] >> 1;
-        int e = r + 1;
-        while (e < R && (ul.flags[e] >> 1) == id) ++e;
-        NL += ul.aux[r] > 0 ? 1 : (e - r + C - 1) / C;
-        r = e;
-    }
+    for_runs([&](int, int nt, int uni) { NL += uni ? 1 : (nt + C - 1) / C; });
     int li = 0, fi = NL;
-    for (int r = 0; r < R;) {
-        const int id = ul.flags[r] >> 1;
-        int e = r + 1;
-        while (e < R && (ul.flags[e] >> 1) == id) ++e;
-        const int nt = e - r, S = ul.aux[r] > 0 ? 1 : (nt + C - 1) / C;  // a union group (Flatten aux > 0) is one chunk
+    for_runs([&](int r, int nt, int uni) {
+        const int S = uni ? 1 : (nt + C - 1) / C;  // a union group is one chunk
         for (int p = 0; p < S; ++p) {
             const int cnt = (nt - p + S - 1) / S;
             ul.perm[li] = r + p;
@@ -648,8 +667,7 @@ __device__ inline void np_record_order(const UnitList& ul, int R, int Hkv, int s
                 ul.ch_fb[fi] = 0;
             }
         }
-        r = e;
-    }
+    });
     hdr[1] = NL;
 }
 
@@ -662,12 +680,17 @@ __device__ inline void np_record_order(const UnitList& ul, int R, int Hkv, int s
 __global__ __launch_bounds__(256) void flatten_units_kernel(const int64_t* block_q, const int64_t* block_q_cnts,
                                                             const int64_t* block_q_offset, int NB, int G, int cap,
                                                             UnitList ul, int32_t* hdr, int32_t* sched, int np, int Hkv,
-                                                            int slots, int chunk_c, int union_len, int taper) {
+                                                            int slots, int chunk_c, int union_len, int taper, int run_cap) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int* sOpen = reinterpret_cast<int*>(smem);  // [NB]
     int* sPass = sOpen + NB;                    // [NB]
+    int* sCnt = sPass + NB;                     // [NB] block_q_cnts
+    int* sOff = sCnt + NB;                      // [NB] block_q_offset
+    RunTable rt{sOff + NB, sOff + NB + run_cap, sOff + NB + 2 * run_cap, 0, run_cap};
     for (int t = threadIdx.x; t < NB; t += blockDim.x) {
         const int cnt = (int)block_q_cnts[t];
+        sCnt[t] = cnt;
+        sOff[t] = (int)block_q_offset[t];
         bool open = (t == 0);
         if (t > 0) {
             open = cnt != (int)block_q_cnts[t - 1];
@@ -685,7 +708,7 @@ __global__ __launch_bounds__(256) void flatten_units_kernel(const int64_t* block
             int tb = ta + 1;
             while (tb < NB && !sOpen[tb]) ++tb;
             const int passes = sPass[ta];
-            const int cnt_a = (int)block_q_cnts[ta];
+            const int cnt_a = sCnt[ta];
             // taper: the workgroups dispatched last should be short, so that the launch ends together -- the last
             // `slots` leaf tiles (per head) stay single, the `2 slots` before them go in pairs
             int ulen = union_len;
@@ -700,9 +723,9 @@ __global__ __launch_bounds__(256) void flatten_units_kernel(const int64_t* block
                 int uq[UNION_CAP], urow[UNION_CAP], un = 0;
                 int te = ta;
                 while (te < NB && te - ta < ulen && r + (te - ta) < cap) {
-                    const int cnt = (int)block_q_cnts[te];
+                    const int cnt = sCnt[te];
                     if (cnt > ucap) break;
-                    const int64_t off = block_q_offset[te];
+                    const int64_t off = sOff[te];
                     int add = 0;  // queries of block te that are new to the union
                     for (int i = 0; i < cnt; ++i) {
                         const int qv = (int)block_q[off + i];
@@ -735,8 +758,9 @@ __global__ __launch_bounds__(256) void flatten_units_kernel(const int64_t* block
                         ul.aux[r] = ng + 1;
                         ul.pass[r] = 0;
                         ul.flags[r] = (first << 1) | ((t == ta) ? 1 : 0);
-                        ul.prow[r] = (int)block_q_offset[t];
+                        ul.prow[r] = sOff[t];
                     }
+                    run_push(rt, first, te - ta, 1);
                     ++ng;
                     ta = te;
                     continue;
@@ -749,8 +773,9 @@ __global__ __launch_bounds__(256) void flatten_units_kernel(const int64_t* block
                     ul.aux[r] = 0;
                     ul.pass[r] = ps;
                     ul.flags[r] = (first << 1) | ((t == ta) ? 1 : 0);
-                    ul.prow[r] = (int)block_q_offset[t];
+                    ul.prow[r] = sOff[t];
                 }
+                if (r > first) run_push(rt, first, r - first, 0);
             }
             ta = tb;
         }
@@ -758,7 +783,7 @@ __global__ __launch_bounds__(256) void flatten_units_kernel(const int64_t* block
         hdr[1] = 0;
         sched[0] = 0;
         for (int k = 0; k < NTICKET; ++k) sched[ticket_word(k)] = 0;
-        if (np) np_record_order(ul, r, Hkv, slots, chunk_c, hdr);
+        if (np) np_record_order(ul, r, Hkv, slots, chunk_c, hdr, rt);
     }
 }
 
@@ -882,9 +907,12 @@ __global__ __launch_bounds__(128) void flatten_records_kernel(const int64_t* blo
 __global__ __launch_bounds__(256) void node_units_kernel(const int64_t* node_kv_len, const int64_t* node_q_len, int NE, int G,
                                                          int cap, int64_t rows_cap, UnitList ul, int32_t* hdr,
                                                          int32_t* sched, int32_t* row_q, int np, int Hkv, int slots,
-                                                         int chunk_c) {
+                                                         int chunk_c, int run_cap) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int* sRun = reinterpret_cast<int*>(smem);
     for (int64_t i = threadIdx.x; i < rows_cap; i += blockDim.x) row_q[i] = -1;
     if (threadIdx.x == 0) {
+        RunTable rt{sRun, sRun + run_cap, sRun + 2 * run_cap, 0, run_cap};
         int r = 0, rowbase = 0;
         int pack_r = -1, pack_n = 0, pack_keys = 0, pack_rows = 0;  // open pack: its unit, entries, slots, virtual rows
         for (int e = 0; e < NE; ++e) {
@@ -908,6 +936,7 @@ __global__ __launch_bounds__(256) void node_units_kernel(const int64_t* node_kv_
                     ul.pass[r] = 0;
                     ul.flags[r] = (r << 1) | 1;
                     ul.prow[r] = rowbase;
+                    run_push(rt, r, 1, 0);
                     ++r;
                 }
             } else {
@@ -921,6 +950,7 @@ __global__ __launch_bounds__(256) void node_units_kernel(const int64_t* node_kv_
                         ul.flags[r] = (first << 1) | ((tt == 0) ? 1 : 0);
                         ul.prow[r] = rowbase + tt * ql;
                     }
+                    if (r > first) run_push(rt, first, r - first, 0);
                 }
             }
             rowbase += nt * ql;
@@ -929,7 +959,7 @@ __global__ __launch_bounds__(256) void node_units_kernel(const int64_t* node_kv_
         hdr[1] = 0;
         sched[0] = 0;
         for (int k = 0; k < NTICKET; ++k) sched[ticket_word(k)] = 0;
-        if (np) np_record_order(ul, r, Hkv, slots, chunk_c, hdr);
+        if (np) np_record_order(ul, r, Hkv, slots, chunk_c, hdr, rt);
     }
 }
 
