@@ -5,6 +5,7 @@ own operator surface.  Importing the package loads libdeft_amd.so and fails loud
 if it has not been built; nothing here falls back to PyTorch or the CPU.
 """
 from ._lib import LIB_PATH, DeftLibraryError, lib  # noqa: F401
+from .context_attention import context_attention_fwd  # noqa: F401
 from .deft_attention import DeFTAttention  # noqa: F401
 from .forest import Forest, concat_metadata_host  # noqa: F401
 from .forward_mode import ForwardMode, InputMetadata, forward_mode_from_cli  # noqa: F401

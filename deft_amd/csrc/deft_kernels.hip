@@ -293,6 +293,7 @@ __global__ __launch_bounds__(256, 2) void stage1_kernel(Stage1Params p) {
 }  // namespace deft
 #include "stage1_stream.h"
 #include "stage1_np.h"
+#include "prefill.h"
 namespace deft {
 
 // ---------------------------------------------------------------------------
@@ -1448,4 +1449,65 @@ extern "C" int deft_rope_qk_f16(void* q, int64_t q_stride_tok, int64_t q_stride_
                        static_cast<_Float16*>(k), k_stride_tok, k_stride_head, Hk, positions, cos_sin_cache, cache_stride, n,
                        D, rotary_dim, is_neox_style ? 1 : 0);
     return deft::check_launch("rope launch");
+}
+
+
+// ---------------------------------------------------------------------------
+// Causal prefill attention (prefill.h): context_attention_fwd
+// (DeFT/deft/layers/attention/context_flashattention_nopad.py:130-195)
+// ---------------------------------------------------------------------------
+extern "C" int deft_prefill_f16(const void* q, int64_t q_stride_tok, int64_t q_stride_head, const void* k,
+                                int64_t k_stride_tok, int64_t k_stride_head, const void* v, int64_t v_stride_tok,
+                                int64_t v_stride_head, void* out, int64_t o_stride_tok, int64_t o_stride_head,
+                                const int32_t* b_start_loc, const int32_t* b_seq_len, int batch, int max_input_len, int Hq,
+                                int Hkv, int D, float scale, void* stream) {
+    using namespace deft;
+    if (batch == 0 || max_input_len == 0) return DEFT_OK;
+    if (!q || !k || !v || !out || !b_start_loc || !b_seq_len || batch < 0 || max_input_len < 0 || Hq <= 0 || Hkv <= 0 ||
+        Hq % Hkv) {
+        set_error("bad prefill arguments (batch=%d max_input_len=%d Hq=%d Hkv=%d)", batch, max_input_len, Hq, Hkv);
+        return DEFT_EINVAL;
+    }
+    if (D != 128) {
+        set_error("prefill: unsupported head_dim %d (supported: 128)", D);
+        return DEFT_EUNSUPPORTED;
+    }
+    if (!aligned16(q) || !aligned16(k) || !aligned16(v) || (reinterpret_cast<uintptr_t>(out) & 7u) || (q_stride_tok % 8) ||
+        (q_stride_head % 8) || (k_stride_tok % 8) || (k_stride_head % 8) || (v_stride_tok % 8) || (v_stride_head % 8) ||
+        (o_stride_tok % 4) || (o_stride_head % 4)) {
+        set_error("prefill: q/k/v rows must be 16-byte aligned, out rows 8-byte aligned");
+        return DEFT_EINVAL;
+    }
+    using SM = PrefillSmem<128>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&prefill_kernel<128>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, SM::BYTES);
+        if (e != hipSuccess) {
+            set_error("hipFuncSetAttribute(prefill): %s", hipGetErrorString(e));
+            return DEFT_EHIP;
+        }
+        attr_set = true;
+    }
+    PrefillParams p{};
+    p.q = static_cast<const _Float16*>(q);
+    p.k = static_cast<const _Float16*>(k);
+    p.v = static_cast<const _Float16*>(v);
+    p.o = static_cast<_Float16*>(out);
+    p.q_st = q_stride_tok;
+    p.q_sh = q_stride_head;
+    p.k_st = k_stride_tok;
+    p.k_sh = k_stride_head;
+    p.v_st = v_stride_tok;
+    p.v_sh = v_stride_head;
+    p.o_st = o_stride_tok;
+    p.o_sh = o_stride_head;
+    p.b_start_loc = b_start_loc;
+    p.b_seq_len = b_seq_len;
+    p.G = Hq / Hkv;
+    p.scale_log2e = scale * LOG2E;
+    p.nblk = (max_input_len + 255) / 256;
+    hipLaunchKernelGGL((prefill_kernel<128>), dim3((unsigned)p.nblk, (unsigned)Hq, (unsigned)batch), dim3(512), SM::BYTES,
+                       static_cast<hipStream_t>(stream), p);
+    return check_launch("prefill launch");
 }

@@ -1,0 +1,207 @@
+// Causal prefill attention over the prompt (TTFT): the caller of the decode path on its time axis.
+//
+// Included by deft_kernels.hip (needs its typedefs, dma16 / wait_vm / lds_barrier from stage1_stream.h).
+//
+// Replaces context_attention_fwd (DeFT/deft/layers/attention/context_flashattention_nopad.py:130-195; kernel :12-127)
+// behind DeFTAttention.prefill_forward_triton (deft_attention.py:50-70): a batch of sequences packed without padding,
+// q[T, Hq, D], k / v[T, Hkv, D], token i of sequence b attends to tokens 0..i of b.  Compute-bound (MFMA), unlike the
+// decode path; arithmetic as there: fp16 operands, fp32 accumulation, scale 1/sqrt(D) after the dot, fp32 online
+// softmax, P rounded to fp16 for the PV product with row sums over the ROUNDED values, one fp16 rounding at the end.
+//
+//   * one workgroup = 8 waves = 256 consecutive queries of one (sequence, query head); wave w owns queries 32w..32w+31;
+//   * K / V tiles of 128 keys are staged in LDS by LDS-DMA, double buffered: while a tile is consumed the next one
+//     lands (every wave stages 16 of its 128 keys); one barrier per tile;
+//   * S^T = K Q^T on v_mfma_f32_32x32x16_f16 with the keys on M: a lane holds 16 key scores of ONE query, so the
+//     softmax is in-lane (+ one half-wave swap), P^T stays in registers and is the B operand of O^T += V^T P^T, V^T
+//     fragments read with ds_read_b64_tr_b16 -- the decode kernel's inner loop (stage1_np.h), four 32-key blocks per tile;
+//   * causal structure: query block m needs key tiles 0 .. 2m+1; only the last two touch the diagonal and are masked,
+//     a wave skips 32-key blocks that lie entirely above its queries; workgroups are launched longest first.
+#pragma once
+
+namespace deft {
+
+struct PrefillParams {
+    const _Float16* q;
+    const _Float16* k;
+    const _Float16* v;
+    _Float16* o;
+    int64_t q_st, q_sh, k_st, k_sh, v_st, v_sh, o_st, o_sh;  // elements
+    const int32_t* b_start_loc;
+    const int32_t* b_seq_len;
+    int G;  // query heads per KV head
+    float scale_log2e;
+    int nblk;  // query blocks per sequence in the grid: ceil(max_input_len / 256)
+};
+
+template <int D>
+struct PrefillSmem {
+    static constexpr int STAGE = TILE * D * 2;  // one K (or V) tile of 128 keys
+    static constexpr int K_OFF = 0;             // two stages
+    static constexpr int V_OFF = 2 * STAGE;     // two stages
+    static constexpr int BYTES = 4 * STAGE;     // 128 KB
+    static_assert(BYTES <= 160 * 1024, "LDS budget");
+};
+
+template <int D>
+__global__ __launch_bounds__(512, 1) void prefill_kernel(PrefillParams p) {
+    constexpr int KS = D / 16;
+    constexpr int QB = 256;  // queries per workgroup
+    static_assert(D == 128, "prefill is instantiated for head_dim 128");
+    using SM = PrefillSmem<D>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l = tid & 63;
+    const int c = l & 31;
+    const int h = l >> 5;
+    const int m = p.nblk - 1 - (int)blockIdx.x;  // longest query blocks first
+    const int head = blockIdx.y;
+    const int b = blockIdx.z;
+    const int len = p.b_seq_len[b];
+    const int64_t start = p.b_start_loc[b];
+    if (m * QB >= len) return;
+    const int kvh = head / p.G;
+
+    // ---- lane constants (LDS layouts of stage1_np.h: K chunks XOR-ed by key & 15, V chunks by 4*(key & 3)) ----------
+    const int dpos = l & 15, dkey = l >> 4;
+    const int tg = l >> 4, tx = l & 15;
+    int vtr_col_b[4];
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk) vtr_col_b[blk] = (4 * (blk ^ (tx >> 2)) + 2 * (tg & 1) + ((tx & 3) >> 1)) * 16;
+    const int vtr_row_b = (4 * (tg >> 1) + (tx >> 2)) * D * 2 + (tx & 1) * 8;
+    const int krow_b = c * D * 2;
+    const int kcol_b = ((h ^ c) & 15) * 16;
+
+    const char* kbase = reinterpret_cast<const char*>(p.k + start * p.k_st + (int64_t)kvh * p.k_sh);
+    const char* vbase = reinterpret_cast<const char*>(p.v + start * p.v_st + (int64_t)kvh * p.v_sh);
+    auto issue_tile = [&](int t, int stg) {  // 4 K + 4 V instructions per wave: keys 16w + 4i + dkey of tile t
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int key = 16 * w + 4 * i + dkey;
+            int tok = TILE * t + key;
+            tok = tok < len ? tok : len - 1;  // padding aliases the last token; masked by the causal test
+            const int kc = (dpos ^ (key & 15)) * 16;
+            const int vc = (dpos ^ (4 * (key & 3))) * 16;
+            dma16(kbase + (int64_t)tok * p.k_st * 2 + kc, SM::K_OFF + (uint32_t)stg * SM::STAGE + (uint32_t)(16 * w + 4 * i) * 256u);
+            dma16(vbase + (int64_t)tok * p.v_st * 2 + vc, SM::V_OFF + (uint32_t)stg * SM::STAGE + (uint32_t)(16 * w + 4 * i) * 256u);
+        }
+    };
+
+    const int ntiles = min(2 * m + 2, (len + TILE - 1) / TILE);
+    issue_tile(0, 0);
+
+    // ---- this lane's query and its Q fragments (B operand: 8 halves at d = 16 ks + 8 h) ----------------------
+    const int qi = m * QB + 32 * w + c;  // query index inside the sequence
+    const int qrow = qi < len ? qi : len - 1;
+    half8 qf[KS];
+    {
+        const _Float16* qp = p.q + (start + qrow) * p.q_st + (int64_t)head * p.q_sh + 8 * h;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const half8*>(qp + 16 * ks);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // Q fragments and tile 0 (the compiler's own wait would do the same)
+
+    float m_run = -INFINITY, l_run = 0.f;
+    floatx16 o[4];
+#pragma unroll
+    for (int bk = 0; bk < 4; ++bk)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[bk][r] = 0.f;
+    const int q_lo = m * QB + 32 * w;  // first query of this wave
+
+    for (int t = 0; t < ntiles; ++t) {
+        const int stg = t & 1;
+        wait_vm<0>();   // tile t landed (this wave's part)
+        lds_barrier();  // ... everyone's part; and every wave is done with tile t-1's stage
+        if (t + 1 < ntiles) issue_tile(t + 1, stg ^ 1);
+        const int key0 = TILE * t;
+        if (key0 > q_lo + 31) continue;  // the whole tile lies above this wave's queries (wave-uniform)
+        const bool diag = key0 + TILE - 1 > q_lo;  // some key of the tile is beyond some query of the wave
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            const int kb0 = key0 + 32 * kb;
+            if (kb0 > q_lo + 31) break;  // wave-uniform: this and the following 32-key blocks are fully masked
+            // ---- S^T for keys kb0 .. kb0+31 ------------------------------------------------------------
+            floatx16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            const int kblk = SM::K_OFF + stg * SM::STAGE + 32 * kb * D * 2 + krow_b;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const half8 a = *reinterpret_cast<const half8*>(smem + kblk + (kcol_b ^ (32 * ks)));
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qf[ks], acc, 0, 0, 0);
+            }
+            float s[16];
+            float mx = -INFINITY;
+            if (diag) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kb0 + 8 * (r >> 2) + 4 * h + (r & 3);
+                    s[r] = key <= qi ? acc[r] * p.scale_log2e : -INFINITY;  // causal; keys >= len are > every valid query
+                    mx = fmaxf(mx, s[r]);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    s[r] = acc[r] * p.scale_log2e;
+                    mx = fmaxf(mx, s[r]);
+                }
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float m_new = fmaxf(m_run, mx);
+            const float msafe = (m_new == -INFINITY) ? 0.f : m_new;
+            const float alpha = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run - msafe);
+            half8 pb[2];
+            float sum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const _Float16 ph = (_Float16)__builtin_amdgcn_exp2f(s[r] - msafe);
+                pb[r >> 3][r & 7] = ph;
+                sum += (float)ph;
+            }
+            sum += __shfl_xor(sum, 32);
+            l_run = l_run * alpha + sum;
+            m_run = m_new;
+            if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0ull) {
+#pragma unroll
+                for (int bk = 0; bk < 4; ++bk)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[bk][r] *= alpha;
+            }
+            // ---- O^T += V^T P^T ------------------------------------------------------------------------
+            const int vblk = SM::V_OFF + stg * SM::STAGE + 32 * kb * D * 2 + vtr_row_b;
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+#pragma unroll
+                for (int bk = 0; bk < 4; ++bk) {
+                    typedef __attribute__((address_space(3))) short4v* lds_s4;
+                    const int vb = vblk + vtr_col_b[bk] + (16 * tt) * D * 2;
+                    union {
+                        short4v s4[2];
+                        half8 h8;
+                    } av;
+                    av.s4[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(uintptr_t)(vb));
+                    av.s4[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(uintptr_t)(vb + 8 * D * 2));
+                    o[bk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av.h8, pb[tt], o[bk], 0, 0, 0);
+                }
+            }
+        }
+    }
+    wait_vm<0>();
+    // ---- normalise and store: lane (c, h) holds d = 32 bk + 8 j + 4 h + (0..3) of query c ---------------------
+    if (qi < len) {
+        const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+        _Float16* op = p.o + (start + qi) * p.o_st + (int64_t)head * p.o_sh + 4 * h;
+#pragma unroll
+        for (int bk = 0; bk < 4; ++bk)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                half4 v4 = {(_Float16)(o[bk][4 * j] * inv), (_Float16)(o[bk][4 * j + 1] * inv),
+                            (_Float16)(o[bk][4 * j + 2] * inv), (_Float16)(o[bk][4 * j + 3] * inv)};
+                *reinterpret_cast<half4*>(op + 32 * bk + 8 * j) = v4;
+            }
+    }
+}
+
+}  // namespace deft

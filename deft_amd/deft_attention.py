@@ -4,6 +4,7 @@ DeFT decode modes.
 Mirrors DeFT/deft/layers/attention/deft_attention.py:
   deft_node_forward     :72-108
   deft_flatten_forward  :110-151
+  prefill_forward_triton  :50-70    (causal attention over the prompt, then store_kv_cache)
   radix_attention_forward :153-188  (sequential per-leaf attention: the comparator, `--mode seq`)
   forward               :349-388   (dispatch on input_metadata.forward_mode)
   store_kv_cache        :390-403
@@ -21,6 +22,7 @@ import torch
 from torch import nn
 
 from .forward_mode import ForwardMode, InputMetadata
+from .context_attention import context_attention_fwd
 from .token_attention import seq_append_attention, token_attention_fwd
 from .tree_attention import (flatten_append_attention, node_append_attention, tree_attention_fwd,
                              tree_attention_subtree_fwd)
@@ -100,6 +102,19 @@ class DeFTAttention(nn.Module):
         )
         return o
 
+    def prefill_forward_triton(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor,
+                               input_metadata: InputMetadata) -> torch.Tensor:
+        """Causal attention over the prompt, then the prompt's K/V go to the pool (deft_attention.py:50-70; the name
+        is the reference's, the kernel here is HIP)."""
+        o = torch.empty_like(q)
+        k3 = k.view(-1, self.tp_k_head_num, self.head_dim)
+        v3 = v.view(-1, self.tp_v_head_num, self.head_dim)
+        context_attention_fwd(q.view(-1, self.tp_q_head_num, self.head_dim), k3, v3,
+                              o.view(-1, self.tp_q_head_num, self.head_dim), input_metadata.start_loc,
+                              input_metadata.seq_lens, input_metadata.max_seq_len)
+        self.store_kv_cache(k3, v3, input_metadata)
+        return o
+
     def radix_attention_forward(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor,
                                 input_metadata: InputMetadata) -> torch.Tensor:
         """Sequential per-request attention through the page table (deft_attention.py:153-188): the comparator."""
@@ -140,12 +155,14 @@ class DeFTAttention(nn.Module):
         mode = input_metadata.forward_mode
         if mode == ForwardMode.DECODE:
             return self.radix_attention_forward(q, k, v, input_metadata)
+        if mode == ForwardMode.PREFILL:
+            return self.prefill_forward_triton(q, k, v, input_metadata)
         if mode == ForwardMode.TREE_DECODE_FLATTEN:
             return self.deft_flatten_forward(q, k, v, input_metadata)
         if mode == ForwardMode.TREE_DECODE_NODE:
             return self.deft_node_forward(q, k, v, input_metadata)
         raise NotImplementedError(
-            f"Unsupported forward mode: {mode} (deft_amd covers TREE_DECODE_FLATTEN, TREE_DECODE_NODE and DECODE with paged KV)"
+            f"Unsupported forward mode: {mode} (deft_amd covers TREE_DECODE_FLATTEN, TREE_DECODE_NODE, DECODE and PREFILL with paged KV)"
         )
 
     def store_kv_cache(self, cache_k: torch.Tensor, cache_v: torch.Tensor, input_metadata: InputMetadata) -> None:

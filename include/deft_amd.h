@@ -175,6 +175,20 @@ int deft_node_decode_append_f16(
     const int32_t* cache_loc, const void* k_new, const void* v_new, int64_t new_stride_tok, int n_new,
     const void* plan, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- causal prefill attention over the prompt (TTFT) -------------------------------------------------------
+ *
+ * Replaces context_attention_fwd (DeFT/deft/layers/attention/context_flashattention_nopad.py:130-195) behind
+ * DeFTAttention.prefill_forward_triton (deft_attention.py:50-70): sequences packed without padding,
+ * q[T][Hq][D], k / v[T][Hkv][D] fp16, token i of sequence b attends to tokens 0..i of b;
+ * b_start_loc / b_seq_len int32 [batch] (model_runner.py:110-114).  head_dim 128.
+ */
+int deft_prefill_f16(const void* q, int64_t q_stride_tok, int64_t q_stride_head,
+                     const void* k, int64_t k_stride_tok, int64_t k_stride_head,
+                     const void* v, int64_t v_stride_tok, int64_t v_stride_head,
+                     void* out, int64_t o_stride_tok, int64_t o_stride_head,
+                     const int32_t* b_start_loc, const int32_t* b_seq_len, int batch, int max_input_len,
+                     int Hq, int Hkv, int D, float scale, void* stream);
+
 /* ---- rotary position embedding of this step's q / k rows (the op in front of the path) -----------------
  *
  * In place, like RotaryEmbedding.forward_cuda (DeFT/deft/layers/rotary_embedding.py:157-177 ->

@@ -228,3 +228,65 @@ def token_attention_forward(q, kv_data, req_rows, b_seq_len, block_n: int = 64):
             e_max = n_e_max
         out[i] = (acc / e_sum[:, None]).astype(np.float16)
     return out
+
+
+# ---------------------------------------------------------------------------
+# causal prefill: context_attention_fwd
+# (DeFT/deft/layers/attention/context_flashattention_nopad.py:130-195; kernel :12-127)
+# ---------------------------------------------------------------------------
+def context_attention_forward(q, k, v, b_start_loc, b_seq_len, block: int = 128):
+    """Restates the reference kernel: per (sequence, head, 128-query block) a loop over 128-key blocks with the
+    lightllm-style online softmax that keeps `acc` NORMALISED after every block (:89-101: p is scaled by
+    beta / l_new before it is rounded to fp16 for the PV dot, acc by l_old / l_new * alpha).  fp16 operands, fp32
+    dots.  q [T, Hq, D], k / v [T, Hkv, D] fp16 -> out [T, Hq, D] fp16."""
+    T, Hq, D = q.shape
+    group = Hq // k.shape[1]
+    scale = np.float32(1.0 / (D ** 0.5))
+    out = np.zeros((T, Hq, D), dtype=np.float16)
+    for b in range(len(b_seq_len)):
+        s0, n = int(b_start_loc[b]), int(b_seq_len[b])
+        for hq in range(Hq):
+            kh = hq // group
+            kk = k[s0 : s0 + n, kh].astype(np.float32)
+            vv = v[s0 : s0 + n, kh].astype(np.float32)
+            for m0 in range(0, n, block):
+                rows = np.arange(m0, min(m0 + block, n))
+                qq = q[s0 + rows, hq].astype(np.float32)
+                m_i = np.full(len(rows), -np.inf, dtype=np.float32)
+                l_i = np.zeros(len(rows), dtype=np.float32)
+                acc = np.zeros((len(rows), D), dtype=np.float32)
+                for n0 in range(0, m0 + block, block):
+                    cols = np.arange(n0, min(n0 + block, n))
+                    if len(cols) == 0:
+                        break
+                    qk = (qq @ kk[cols].T).astype(np.float32) * scale
+                    qk = np.where(rows[:, None] >= cols[None, :], qk, -np.inf).astype(np.float32)
+                    m_ij = qk.max(axis=1)
+                    p = np.exp(qk - m_ij[:, None]).astype(np.float32)
+                    l_ij = p.sum(axis=1, dtype=np.float32)
+                    m_new = np.maximum(m_i, m_ij)
+                    alpha = np.exp(m_i - m_new).astype(np.float32)
+                    beta = np.exp(m_ij - m_new).astype(np.float32)
+                    l_new = alpha * l_i + beta * l_ij
+                    p = (p * (beta / l_new)[:, None]).astype(np.float16).astype(np.float32)
+                    acc = acc * (l_i / l_new * alpha)[:, None] + p @ vv[cols]
+                    l_i, m_i = l_new, m_new
+                out[s0 + rows, hq] = acc.astype(np.float16)
+    return out
+
+
+def causal_truth(q, k, v, b_start_loc, b_seq_len):
+    """fp64 causal attention per sequence (ground truth for the prefill path)."""
+    T, Hq, D = q.shape
+    group = Hq // k.shape[1]
+    out = np.zeros((T, Hq, D), dtype=np.float64)
+    for b in range(len(b_seq_len)):
+        s0, n = int(b_start_loc[b]), int(b_seq_len[b])
+        mask = np.tril(np.ones((n, n), dtype=bool))
+        for hq in range(Hq):
+            kh = hq // group
+            s = q[s0 : s0 + n, hq].astype(np.float64) @ k[s0 : s0 + n, kh].astype(np.float64).T / np.sqrt(D)
+            s = np.where(mask, s, -np.inf)
+            p = np.exp(s - s.max(axis=1, keepdims=True))
+            out[s0 : s0 + n, hq] = (p / p.sum(axis=1, keepdims=True)) @ v[s0 : s0 + n, kh].astype(np.float64)
+    return out
