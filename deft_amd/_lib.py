@@ -9,6 +9,11 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+# PyTorch-ROCm ships its own libamdhip64; load it FIRST so that libdeft_amd.so's DT_NEEDED entry resolves to the
+# runtime torch has initialised.  Loaded the other way round the process holds two HIP runtimes and the one this
+# library is bound to reports "no ROCm-capable device is detected" at the first launch.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdeft_amd.so")
 
