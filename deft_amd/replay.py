@@ -363,7 +363,12 @@ class TemplateReplay:
         return req, pool
 
     def run(self, template: ExecuteTree, task: str, prompt_len: int, max_gen_len: int, max_tokens: Optional[int] = None,
-            max_leaves: int = 512, max_rows: int = 512) -> ReplayReport:
+            max_leaves: int = 512, max_rows: int = 512, pipelined: bool = False) -> ReplayReport:
+        """`pipelined=True`: no per-step synchronisation -- the host builds step t+1's tree state and metadata while the
+        GPU still runs step t (the path is launch-only; the synthetic scores do not depend on the GPU's output, as
+        in a real engine between branch events, where the tree's SHAPE one step ahead is known).  Per-step attention
+        times are then not available; `attention_ms` is the GPU span of the whole replay and `wall_ms` what a caller
+        would see."""
         branch = BRANCH_FUNCS[task]
         if task == "speculative_decoding":
             max_gen_len = min(max_gen_len, len(template.accepted_len_list or []) + 1)
@@ -391,6 +396,7 @@ class TemplateReplay:
         logits = self.rng.random((1, self.vocab), dtype=np.float32)
         stop = branch(tree, 0, max_gen_len, logits, template)  # tree_generate.py:188-197
         it = 1
+        first_event = last_event = None
         while not stop and it < max_gen_len:
             # ---- prepare: positions, KV slots for this step's tokens, metadata (tree_generate.py:93-131) -------
             t0 = time.perf_counter()
@@ -415,11 +421,15 @@ class TemplateReplay:
             if self.attention:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
+                if pipelined and first_event is None:
+                    first_event = e0
                 for l in range(self.layers):
                     self.attn[l](q_all[l, :nq], k_all[l, :nq], v_all[l, :nq], meta)
                 e1.record()
-                e1.synchronize()
-                t_attn = e0.elapsed_time(e1)
+                last_event = e1
+                if not pipelined:
+                    e1.synchronize()
+                    t_attn = e0.elapsed_time(e1)
             # ---- branch (tree_generate.py:226-236) ------------------------------------------------------------
             t1 = time.perf_counter()
             logits = self.rng.random((nq, self.vocab), dtype=np.float32)
@@ -434,6 +444,9 @@ class TemplateReplay:
             rep.metadata_ms += t_md
             rep.branch_ms += t_br
             it += 1
+        if pipelined and last_event is not None:
+            last_event.synchronize()
+            rep.attention_ms = first_event.elapsed_time(last_event)
         rep.wall_ms = (time.perf_counter() - t_wall) * 1e3
         rep.generated_tokens = tree.get_tree_token_number() - prompt_len
         self.tree, self.pool, self.req = tree, pool, req  # left for inspection by tests

@@ -25,6 +25,7 @@ ap.add_argument("--max-gen-len", type=int, default=400)
 ap.add_argument("--width", type=int, default=32)
 ap.add_argument("--tree-size", type=int, default=64)
 ap.add_argument("--sd-steps", type=int, default=100)
+ap.add_argument("--pipelined", action="store_true", help="no per-step sync: host runs ahead of the GPU")
 ap.add_argument("--out", default=None)
 a = ap.parse_args()
 Hq, Hkv, D, L = GEOMETRY[a.model]
@@ -50,7 +51,7 @@ for mode in a.modes:
     prompt_len = a.prompt_len or (tpl.root.value if a.template and a.task == "reasoning" and tpl.root.value > 0 else
                                   (1016 if a.task == "speculative_decoding" else 4096))
     r = rp.TemplateReplay(Hq, Hkv, D, L, mode=mode, device="cuda", attention=True)
-    rep = r.run(tpl, a.task, prompt_len, a.max_gen_len, max_rows=max(512, a.width, a.tree_size))
+    rep = r.run(tpl, a.task, prompt_len, a.max_gen_len, max_rows=max(512, a.width, a.tree_size), pipelined=a.pipelined)
     s = rep.summary(); s["model"] = a.model; s["layers"] = L
     rows.append(s)
     print(json.dumps(s), flush=True)
