@@ -336,6 +336,7 @@ def test_ticket_tail_matches_static_walk(dyn, monkeypatch):
     pool._storage.normal_(generator=g)
     q = torch.randn((32, 32, 128), dtype=torch.float16, device="cuda", generator=g)
     kb, vb = pool.get_key_buffer(0), pool.get_value_buffer(0)
+    monkeypatch.setenv("DEFT_STAGE1_KERNEL", "stream")  # the streaming form (the default is the tile-parallel one)
     monkeypatch.setenv("DEFT_STREAM_DYN", "0")
     o_static = torch.zeros_like(q)
     deft_amd.tree_attention_subtree_fwd(q, kb, vb, o_static, *_flatten_args(md))
@@ -358,6 +359,56 @@ def test_ticket_tail_matches_static_walk(dyn, monkeypatch):
         s = torch.einsum("hd,hsd->hs", q[r].float(), k) / 128 ** 0.5
         ref = torch.einsum("hs,hsd->hd", torch.softmax(s, dim=-1), v)
         assert (outs[-1][r].float() - ref).abs().max().item() < TOL
+
+
+@pytest.mark.parametrize("env", [{}, {"DEFT_NP_CHUNK": "1", "DEFT_NP_UNION": "1"}, {"DEFT_NP_CHUNK": "8", "DEFT_NP_UNION": "4"},
+                                 {"DEFT_NP_CHUNK": "2", "DEFT_NP_UNION": "8"}, {"DEFT_NP_PERSIST": "1"},
+                                 {"DEFT_STAGE1_KERNEL": "stream"}])
+def test_full_size_fold_structure_does_not_change_the_result(env, monkeypatch):
+    """BASELINE's north-star tree (Llama-2-7B, 4096 x 32 x 200 tokens) through every way of cutting it into
+    workgroups: no folding at all, the default chunks and union groups, long chunks with large unions, resident
+    workgroups with the ticket queue, and the streaming form.  Folding changes the order of fp32 additions, nothing
+    else: all agree within the exact-merge tolerance, each is bit-deterministic, and the sequential comparator over
+    the page table (every leaf its own full path) agrees with them; three leaves against torch fp32 attention."""
+    from deft_amd.utils.workloads import Workload, build_tree
+
+    w = Workload("t", "llama2-7b", "flatten", "few_shot", 4096, 32, 200)
+    tree, pool = build_tree(w, 1, "cuda")
+    md = deft_amd.TreeMetadata.from_tree_cache(tree)
+    g = torch.Generator(device="cuda").manual_seed(7)
+    pool._storage.normal_(generator=g)
+    q = torch.randn((32, 32, 128), dtype=torch.float16, device="cuda", generator=g)
+    kb, vb = pool.get_key_buffer(0), pool.get_value_buffer(0)
+    o_ref = torch.zeros_like(q)
+    deft_amd.tree_attention_subtree_fwd(q, kb, vb, o_ref, *_flatten_args(md))  # default settings
+    torch.cuda.synchronize()
+    for k_, v_ in env.items():
+        monkeypatch.setenv(k_, v_)
+    outs = []
+    for _ in range(2):
+        o = torch.full_like(q, float("nan"))
+        deft_amd.tree_attention_subtree_fwd(q, kb, vb, o, *_flatten_args(md))
+        outs.append(o)
+    o_node = torch.full_like(q, float("nan"))
+    deft_amd.tree_attention_fwd(q, kb, vb, o_node, md.node_kv, md.node_kv_offset, md.node_kv_len, md.node_q,
+                                md.node_q_offset, md.node_q_len)
+    meta, lens = _seq_metadata(tree)
+    o_seq = torch.full_like(q, float("nan"))
+    deft_amd.token_attention_fwd(q, kb, vb, o_seq, tree.req_to_token_pool.req_to_token, meta.req_pool_indices,
+                                 meta.start_loc, meta.seq_lens, meta.max_seq_len, None, meta.total_num_tokens)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1])
+    for o in (outs[0], o_node, o_seq):
+        assert torch.isfinite(o.float()).all()
+        assert (o.float() - o_ref.float()).abs().max().item() < TOL_EXACT
+    leaves = sorted(tree.leaves.values(), key=lambda n: n.id)
+    for r in (0, 17, 31):
+        slots = torch.tensor(tree.leaf_path_slots(leaves[r]), device="cuda")
+        k = kb[slots].float().transpose(0, 1)
+        v = vb[slots].float().transpose(0, 1)
+        sc = torch.einsum("hd,hsd->hs", q[r].float(), k) / 128 ** 0.5
+        ref = torch.einsum("hs,hsd->hd", torch.softmax(sc, dim=-1), v)
+        assert (outs[0][r].float() - ref).abs().max().item() < TOL_EXACT
 
 
 @pytest.mark.parametrize("mode", ["flatten", "node"])

@@ -108,3 +108,44 @@ def test_prefill_then_decode_through_the_module():
     assert _close_to_truth(out.view(n, Hq, D).cpu().numpy(), truth)
     slots = tree.root.kv_indices
     assert np.array_equal(pool.kv_data[0][slots, 0].cpu().numpy(), kn[:n]) and np.array_equal(pool.kv_data[0][slots, 1].cpu().numpy(), vn[:n])
+
+
+@pytest.mark.gpu
+def test_prefill_full_size_properties():
+    """Llama-2-7B geometry, 4096-token prompt (the north-star prefix): the last token's row equals decode attention of
+    that token over the prompt's K/V (the Node operator on one entry), rows only depend on earlier tokens (changing
+    the second half of K/V leaves the first half of the output bit-identical), and the operator is linear in V."""
+    Hq, Hkv, D, S = 32, 32, 128, 4096
+    g = torch.Generator(device="cuda").manual_seed(11)
+    q = torch.randn((S, Hq, D), dtype=torch.float16, device="cuda", generator=g)
+    k = torch.randn((S, Hkv, D), dtype=torch.float16, device="cuda", generator=g)
+    v = torch.randn((S, Hkv, D), dtype=torch.float16, device="cuda", generator=g)
+    start = torch.zeros(1, dtype=torch.int32, device="cuda")
+    lens = torch.tensor([S], dtype=torch.int32, device="cuda")
+
+    def run(kk, vv):
+        o = torch.full_like(q, float("nan"))
+        deft_amd.context_attention_fwd(q, kk, vv, o, start, lens, S)
+        return o
+
+    o = run(k, v)
+    torch.cuda.synchronize()
+    assert torch.isfinite(o.float()).all()
+    # decode attention of the last token over all S keys
+    idx = torch.arange(S, device="cuda")
+    one = torch.zeros(1, dtype=torch.int64, device="cuda")
+    o_dec = torch.empty((1, Hq, D), dtype=torch.float16, device="cuda")
+    deft_amd.tree_attention_fwd(q[S - 1:], k, v, o_dec, idx, one, torch.tensor([S], device="cuda"), one, one, one + 1)
+    torch.cuda.synchronize()
+    assert (o[S - 1].float() - o_dec[0].float()).abs().max().item() < 5e-4
+    # causality: garbage in the second half of K/V cannot reach the first half of the output
+    k2, v2 = k.clone(), v.clone()
+    k2[S // 2:] = 7.0
+    v2[S // 2:] = -3.0
+    o2 = run(k2, v2)
+    torch.cuda.synchronize()
+    assert torch.equal(o2[: S // 2], o[: S // 2])
+    # linearity in V (exactly representable scaling): attention(2 V) = 2 attention(V) up to fp16 rounding of the output
+    o3 = run(k, v * 2)
+    torch.cuda.synchronize()
+    assert (o3.float() - 2 * o.float()).abs().max().item() < 2e-3
