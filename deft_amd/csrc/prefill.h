@@ -14,8 +14,10 @@
 //   * S^T = K Q^T on v_mfma_f32_32x32x16_f16 with the keys on M: a lane holds 16 key scores of ONE query, so the
 //     softmax is in-lane (+ one half-wave swap), P^T stays in registers and is the B operand of O^T += V^T P^T, V^T
 //     fragments read with ds_read_b64_tr_b16 -- the decode kernel's inner loop (stage1_np.h), four 32-key blocks per tile;
+//   * one online-softmax step per 128-key tile: 32 QK^T MFMAs on four independent accumulators, one max / rescale,
+//     32 PV MFMAs;
 //   * causal structure: query block m needs key tiles 0 .. 2m+1; only the last two touch the diagonal and are masked,
-//     a wave skips 32-key blocks that lie entirely above its queries; workgroups are launched longest first.
+//     a wave skips tiles that lie entirely above its queries; workgroups are launched longest first.
 #pragma once
 
 namespace deft {
@@ -118,72 +120,81 @@ __global__ __launch_bounds__(512, 1) void prefill_kernel(PrefillParams p) {
         const int key0 = TILE * t;
         if (key0 > q_lo + 31) continue;  // the whole tile lies above this wave's queries (wave-uniform)
         const bool diag = key0 + TILE - 1 > q_lo;  // some key of the tile is beyond some query of the wave
+        // ---- S^T for all 128 keys of the tile: four independent accumulator chains (32 keys each) -----------
+        floatx16 acc[4];
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb) {
-            const int kb0 = key0 + 32 * kb;
-            if (kb0 > q_lo + 31) break;  // wave-uniform: this and the following 32-key blocks are fully masked
-            // ---- S^T for keys kb0 .. kb0+31 ------------------------------------------------------------
-            floatx16 acc;
+        for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            const int kblk = SM::K_OFF + stg * SM::STAGE + 32 * kb * D * 2 + krow_b;
+            for (int r = 0; r < 16; ++r) acc[kb][r] = 0.f;
+        const int kblk = SM::K_OFF + stg * SM::STAGE + krow_b;
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const half8 a = *reinterpret_cast<const half8*>(smem + kblk + (kcol_b ^ (32 * ks)));
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qf[ks], acc, 0, 0, 0);
+        for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                const half8 a = *reinterpret_cast<const half8*>(smem + kblk + 32 * kb * D * 2 + (kcol_b ^ (32 * ks)));
+                acc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qf[ks], acc[kb], 0, 0, 0);
             }
-            float s[16];
-            float mx = -INFINITY;
-            if (diag) {
+        }
+        // ---- one online-softmax step per tile (one rescale of O per 128 keys) ----------------------------------
+        float mx = -INFINITY;
+        if (diag) {
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int key = kb0 + 8 * (r >> 2) + 4 * h + (r & 3);
-                    s[r] = key <= qi ? acc[r] * p.scale_log2e : -INFINITY;  // causal; keys >= len are > every valid query
-                    mx = fmaxf(mx, s[r]);
+                    const int key = key0 + 32 * kb + 8 * (r >> 2) + 4 * h + (r & 3);
+                    acc[kb][r] = key <= qi ? acc[kb][r] * p.scale_log2e : -INFINITY;  // causal; keys >= len are > every valid query
+                    mx = fmaxf(mx, acc[kb][r]);
                 }
-            } else {
+        } else {
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    s[r] = acc[r] * p.scale_log2e;
-                    mx = fmaxf(mx, s[r]);
+                    acc[kb][r] *= p.scale_log2e;
+                    mx = fmaxf(mx, acc[kb][r]);
                 }
-            }
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
-            const float m_new = fmaxf(m_run, mx);
-            const float msafe = (m_new == -INFINITY) ? 0.f : m_new;
-            const float alpha = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run - msafe);
-            half8 pb[2];
-            float sum = 0.f;
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);
+        const float msafe = (m_new == -INFINITY) ? 0.f : m_new;
+        const float alpha = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run - msafe);
+        half8 pb[4][2];
+        float sum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const _Float16 ph = (_Float16)__builtin_amdgcn_exp2f(s[r] - msafe);
-                pb[r >> 3][r & 7] = ph;
+                const _Float16 ph = (_Float16)__builtin_amdgcn_exp2f(acc[kb][r] - msafe);
+                pb[kb][r >> 3][r & 7] = ph;
                 sum += (float)ph;
             }
-            sum += __shfl_xor(sum, 32);
-            l_run = l_run * alpha + sum;
-            m_run = m_new;
-            if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0ull) {
+        sum += __shfl_xor(sum, 32);
+        l_run = l_run * alpha + sum;
+        m_run = m_new;
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0ull) {
 #pragma unroll
-                for (int bk = 0; bk < 4; ++bk)
+            for (int bk = 0; bk < 4; ++bk)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) o[bk][r] *= alpha;
-            }
-            // ---- O^T += V^T P^T ------------------------------------------------------------------------
-            const int vblk = SM::V_OFF + stg * SM::STAGE + 32 * kb * D * 2 + vtr_row_b;
+                for (int r = 0; r < 16; ++r) o[bk][r] *= alpha;
+        }
+        // ---- O^T += V^T P^T: 32 MFMAs on four independent accumulators -------------------------------------------
+        const int vblk = SM::V_OFF + stg * SM::STAGE + vtr_row_b;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) {
 #pragma unroll
                 for (int bk = 0; bk < 4; ++bk) {
                     typedef __attribute__((address_space(3))) short4v* lds_s4;
-                    const int vb = vblk + vtr_col_b[bk] + (16 * tt) * D * 2;
+                    const int vb = vblk + 32 * kb * D * 2 + vtr_col_b[bk] + (16 * tt) * D * 2;
                     union {
                         short4v s4[2];
                         half8 h8;
                     } av;
                     av.s4[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(uintptr_t)(vb));
                     av.s4[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(uintptr_t)(vb + 8 * D * 2));
-                    o[bk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av.h8, pb[tt], o[bk], 0, 0, 0);
+                    o[bk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av.h8, pb[kb][tt], o[bk], 0, 0, 0);
                 }
             }
         }
