@@ -767,6 +767,14 @@ int deft_abi_version(void) { return 1; }
 
 int deft_stage1_kind(void) { return stage1_kind(); }
 
+// Everything a plan's layout depends on besides the caller's arguments: the stage-1 form and the experiment knobs
+// of the plan kernels, folded into one integer (callers that cache plans key them by it; a C getenv costs ~0.1 us,
+// Python's os.environ.get several us per lookup).
+int deft_plan_variant(void) {
+    const char* t = getenv("DEFT_NP_TAPER");
+    return stage1_kind() | ((np_chunk_env() & 0xff) << 4) | ((np_union_env() & 0xff) << 12) | ((t ? atoi(t) & 0xf : 0) << 20);
+}
+
 // Internal profiling hook (not part of the public header): device buffer of
 // workers*16*8 u64 receiving s_memtime stamps of the streaming kernel's phases.
 void deft_debug_set_buffer(void* dev_ptr) { g_stream_dbg = static_cast<unsigned long long*>(dev_ptr); }

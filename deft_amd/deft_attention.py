@@ -21,12 +21,112 @@ import os
 import torch
 from torch import nn
 
+from ._lib import check, lib
 from .forward_mode import ForwardMode, InputMetadata
 from .context_attention import context_attention_fwd
 from .token_attention import seq_append_attention, token_attention_fwd
 from .tree_attention import (flatten_append_attention, node_append_attention, tree_attention_fwd,
                              tree_attention_subtree_fwd)
 from .tree_cache import get_global_tree_metadata
+
+
+def _fused_append_enabled() -> bool:
+    # DEFT_NO_FUSED_APPEND=1 restores the two-call form (store_kv_cache, then the operator).  Looked up through the
+    # process environment table directly: os.environ.get costs several microseconds per call on this path.
+    return os.getenv("DEFT_NO_FUSED_APPEND") in (None, "", "0")
+
+
+class _DecodeStep:
+    """Everything about one decode step that is the same for all layers, resolved once: metadata pointers, the
+    per-step plan, the pool geometry, the step's cache_loc.  The 32 attention modules of a step share one instance
+    (parked on the TreeMetadata object the runner registers, tree_cache.py:1021-1037), so a layer's call costs a
+    handful of pointer computations and one ctypes call -- not the argument checks, views and cache lookups of the
+    general operator (deft_amd.tree_attention.*_append_attention: ~36 us of host time per call, this path ~12 us;
+    tools/host_overhead.py).  Same launches, same results."""
+
+    def __init__(self, mode: ForwardMode, md, pool, cache_loc: torch.Tensor, q: torch.Tensor, k: torch.Tensor,
+                 Hq: int, Hkv: int, D: int) -> None:
+        from .tree_attention import _flatten_plan, _node_plan
+
+        kv0 = pool.kv_data[0]
+        if not (q.is_cuda and kv0.is_cuda and q.dtype == torch.float16 and kv0.dtype == torch.float16):
+            raise TypeError("decode step needs fp16 CUDA tensors")
+        self.mode, self.md, self.pool, self.cache_loc = mode, md, pool, cache_loc
+        self.cache_loc_version = cache_loc._version
+        self.Hq, self.Hkv, self.D, self.nq = Hq, Hkv, D, q.shape[0]
+        self.q_shape, self.q_stride, self.k_stride = tuple(q.shape), q.stride(0), k.stride(0)
+        self.device = q.device
+        self.dev_index = q.device.index if q.device.index is not None else torch.cuda.current_device()
+        self.kv_ss, self.kv_sh = kv0.stride(0), kv0.stride(2)
+        self.v_off_bytes = kv0.stride(1) * 2
+        self.layer_ptrs = [t.data_ptr() for t in pool.kv_data]
+        self.scale = 1.0 / (D ** 0.5)
+        stream = torch._C._cuda_getCurrentRawStream(self.dev_index)
+        if cache_loc.dtype != torch.int32 or not cache_loc.is_cuda:
+            raise TypeError("cache_loc must be an int32 CUDA tensor")
+        self.n_new = cache_loc.shape[0]
+        if mode == ForwardMode.TREE_DECODE_FLATTEN:
+            mdl = [md.block_q, md.block_q_cnts, md.block_q_offset, md.block_bitmasks, md.block_kv, md.block_lens]
+            self.NB, self.P = md.block_q_cnts.shape[0], md.block_q.shape[0]
+            self.plan = _flatten_plan(mdl, self.NB, self.P, Hq, Hkv, (self.q_stride, D), self.kv_ss, stream,
+                                      cache_loc=cache_loc, new_stride=self.k_stride)
+            self.ws_bytes = lib.deft_flatten_workspace_bytes(self.NB, self.P, self.nq, Hq, Hkv, D)
+            self.tail = (self.NB, self.P, self.nq, Hq, Hkv, D, self.scale)
+            self.fn = lib.deft_flatten_decode_append_f16
+        else:
+            mdl = [md.node_kv, md.node_kv_offset, md.node_kv_len, md.node_q, md.node_q_offset, md.node_q_len]
+            NE, P, total = md.node_kv_offset.shape[0], md.node_q.shape[0], md.node_kv.shape[0]
+            self.plan = _node_plan(mdl, NE, P, total, Hq, Hkv, (self.q_stride, D), self.kv_ss, stream,
+                                   cache_loc=cache_loc, new_stride=self.k_stride)
+            self.ws_bytes = lib.deft_node_workspace_bytes(NE, P, total, self.nq, Hq, Hkv, D)
+            self.tail = (NE, P, total, self.nq, Hq, Hkv, D, self.scale)
+            self.fn = lib.deft_node_decode_append_f16
+        for t in mdl:
+            if t.dtype != torch.int64 or not t.is_cuda or not t.is_contiguous():
+                raise TypeError("TreeMetadata arrays must be contiguous int64 CUDA tensors")
+        self.md_ptrs = tuple(t.data_ptr() for t in mdl)
+        self.md_keep = mdl
+        self.cache_loc_ptr = cache_loc.data_ptr()
+        self.plan_ptr = self.plan.data_ptr()
+        self.ws = {}  # raw stream -> workspace (calls on one stream are ordered; streams must not share scratch)
+
+    def matches(self, mode, md, pool, cache_loc, q, k) -> bool:
+        return (mode is self.mode and md is self.md and pool is self.pool and cache_loc is self.cache_loc
+                and cache_loc._version == self.cache_loc_version and tuple(q.shape) == self.q_shape
+                and q.stride(0) == self.q_stride and k.stride(0) == self.k_stride and q.dtype == torch.float16)
+
+    def run(self, layer_id: int, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
+        Hq, D = self.Hq, self.D
+        if q.stride(1) != 1 or k.stride(1) != 1 or v.stride(1) != 1 or v.stride(0) != self.k_stride or k.dtype != torch.float16:
+            raise ValueError("q / k / v rows must be contiguous fp16, k and v with the same row stride")
+        o = torch.empty((self.nq, Hq * D), dtype=torch.float16, device=self.device)
+        stream = torch._C._cuda_getCurrentRawStream(self.dev_index)
+        ws = self.ws.get(stream)
+        if ws is None:
+            ws = self.ws[stream] = torch.empty(max(self.ws_bytes, 1), dtype=torch.uint8, device=self.device)
+        kptr = self.layer_ptrs[layer_id]
+        rc = self.fn(q.data_ptr(), self.q_stride, D, kptr, kptr + self.v_off_bytes, self.kv_ss, self.kv_sh,
+                     o.data_ptr(), Hq * D, D, *self.md_ptrs, *self.tail,
+                     self.cache_loc_ptr, k.data_ptr(), v.data_ptr(), self.k_stride, self.n_new,
+                     self.plan_ptr, ws.data_ptr(), self.ws_bytes, stream)
+        check(rc, "decode step")
+        return o
+
+
+def _decode_step(mode, md, input_metadata, q, k, Hq, Hkv, D):
+    """The step object for this (metadata, pool, cache_loc), or None when the fused path does not apply."""
+    updater = input_metadata.kv_updater
+    pool = input_metadata.token_to_kv_pool
+    if (updater is None or updater.cache_loc is None or updater.token_to_kv_pool is not pool or not _fused_append_enabled()
+            or q.dim() != 2 or k.dim() != 2 or not q.is_cuda):
+        return None
+    step = md.__dict__.get("_deft_step")
+    if step is None or not step.matches(mode, md, pool, updater.cache_loc, q, k):
+        cl = updater.cache_loc
+        if cl.dtype != torch.int32 or not cl.is_cuda:
+            return None
+        step = md.__dict__["_deft_step"] = _DecodeStep(mode, md, pool, cl, q, k, Hq, Hkv, D)
+    return step
 
 
 class DeFTAttention(nn.Module):
@@ -44,16 +144,20 @@ class DeFTAttention(nn.Module):
 
     def deft_node_forward(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor,
                           input_metadata: InputMetadata) -> torch.Tensor:
-        k = k.view(-1, self.tp_k_head_num, self.head_dim)
-        v = v.view(-1, self.tp_v_head_num, self.head_dim)
-        o = torch.empty((q.shape[0], self.tp_q_head_num * self.head_dim), dtype=q.dtype, device=q.device)
         md = get_global_tree_metadata()
         assert md is not None
         assert input_metadata.token_to_kv_pool is not None
+        step = _decode_step(ForwardMode.TREE_DECODE_NODE, md, input_metadata, q, k, self.tp_q_head_num,
+                            self.tp_k_head_num, self.head_dim)
+        if step is not None:
+            return step.run(self.layer_id, q, k, v)
+        k = k.view(-1, self.tp_k_head_num, self.head_dim)
+        v = v.view(-1, self.tp_v_head_num, self.head_dim)
+        o = torch.empty((q.shape[0], self.tp_q_head_num * self.head_dim), dtype=q.dtype, device=q.device)
         pool = input_metadata.token_to_kv_pool
         updater = input_metadata.kv_updater
         if (updater is not None and updater.cache_loc is not None and updater.token_to_kv_pool is pool
-                and not os.environ.get("DEFT_NO_FUSED_APPEND")):
+                and _fused_append_enabled()):
             # store_kv_cache (:83) and the operator (:94-105) in one fused call
             node_append_attention(
                 q.view(-1, self.tp_q_head_num, self.head_dim), pool.kv_data[self.layer_id],
@@ -74,16 +178,20 @@ class DeFTAttention(nn.Module):
 
     def deft_flatten_forward(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor,
                              input_metadata: InputMetadata) -> torch.Tensor:
-        k = k.view(-1, self.tp_k_head_num, self.head_dim)
-        v = v.view(-1, self.tp_v_head_num, self.head_dim)
-        o = torch.empty((q.shape[0], self.tp_q_head_num * self.head_dim), dtype=q.dtype, device=q.device)
         md = get_global_tree_metadata()
         assert md is not None
         assert input_metadata.token_to_kv_pool is not None
+        step = _decode_step(ForwardMode.TREE_DECODE_FLATTEN, md, input_metadata, q, k, self.tp_q_head_num,
+                            self.tp_k_head_num, self.head_dim)
+        if step is not None:
+            return step.run(self.layer_id, q, k, v)
+        k = k.view(-1, self.tp_k_head_num, self.head_dim)
+        v = v.view(-1, self.tp_v_head_num, self.head_dim)
+        o = torch.empty((q.shape[0], self.tp_q_head_num * self.head_dim), dtype=q.dtype, device=q.device)
         pool = input_metadata.token_to_kv_pool
         updater = input_metadata.kv_updater
         if (updater is not None and updater.cache_loc is not None and updater.token_to_kv_pool is pool
-                and not os.environ.get("DEFT_NO_FUSED_APPEND")):
+                and _fused_append_enabled()):
             # store_kv_cache (:121) and the operator (:136-148) in one fused call
             flatten_append_attention(
                 q.view(-1, self.tp_q_head_num, self.head_dim), pool.kv_data[self.layer_id],
@@ -127,7 +235,7 @@ class DeFTAttention(nn.Module):
         updater = input_metadata.kv_updater
         table = input_metadata.req_to_token_pool.req_to_token
         if (updater is not None and updater.cache_loc is not None and updater.token_to_kv_pool is pool
-                and not os.environ.get("DEFT_NO_FUSED_APPEND")):
+                and _fused_append_enabled()):
             seq_append_attention(
                 q.view(-1, self.tp_q_head_num, self.head_dim), pool.kv_data[self.layer_id],
                 o.view(-1, self.tp_q_head_num, self.head_dim), updater.cache_loc, k, v, table,

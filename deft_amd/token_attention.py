@@ -46,7 +46,7 @@ def _seq_plan(req_to_token, b_req_idx, b_start_loc, b_seq_len, total_num_tokens:
     when a plan is actually built."""
     nq = b_req_idx.shape[0]
     versions = tuple((t.data_ptr(), _version(t)) for t in (req_to_token, b_req_idx, b_start_loc, b_seq_len))
-    key = (lib.deft_stage1_kind(), nq, int(total_num_tokens), Hq, Hkv, tuple(q_strides), kv_stride_slot) + versions
+    key = (lib.deft_plan_variant(), nq, int(total_num_tokens), Hq, Hkv, tuple(q_strides), kv_stride_slot) + versions
     if cache_loc is not None:
         key += (cache_loc.data_ptr(), _version(cache_loc), cache_loc.shape[0], new_stride)
     cacheable = all(v >= 0 for _, v in versions)

@@ -18,8 +18,6 @@ HIP library must be loadable.
 """
 from __future__ import annotations
 
-import os
-
 import torch
 
 from ._lib import DeftLibraryError, check, lib
@@ -61,7 +59,7 @@ def _flatten_plan(md, NB: int, P: int, Hq: int, Hkv: int, q_strides, kv_stride_s
     strides.  Fresh
     tensors (or an in-place edit) simply rebuild it; results never depend on the cache."""
     block_q = md[0]
-    key = (lib.deft_stage1_kind(), os.environ.get("DEFT_NP_CHUNK", "") + "/" + os.environ.get("DEFT_NP_UNION", "") + "/" + os.environ.get("DEFT_NP_TAPER", ""), kv_stride_slot, NB, P, Hq, Hkv, tuple(q_strides)) + tuple((t.data_ptr(), t._version) for t in md)
+    key = (lib.deft_plan_variant(), kv_stride_slot, NB, P, Hq, Hkv, tuple(q_strides)) + tuple((t.data_ptr(), t._version) for t in md)
     if cache_loc is not None:  # fused-append plans mark this step's new slots
         key += (cache_loc.data_ptr(), cache_loc._version, cache_loc.shape[0], new_stride)
     cached = getattr(block_q, "_deft_plan", None)
@@ -84,7 +82,7 @@ def _node_plan(md, NE: int, P: int, total_kv: int, Hq: int, Hkv: int, q_strides,
                cache_loc=None, new_stride: int = 0):
     """Node-mode counterpart of `_flatten_plan`; cached on the KVMapQ_List (node_q) tensor."""
     node_q = md[3]
-    key = (lib.deft_stage1_kind(), os.environ.get("DEFT_NP_CHUNK", "") + "/" + os.environ.get("DEFT_NP_UNION", "") + "/" + os.environ.get("DEFT_NP_TAPER", ""), kv_stride_slot, NE, P, total_kv, Hq, Hkv, tuple(q_strides)) + tuple((t.data_ptr(), t._version) for t in md)
+    key = (lib.deft_plan_variant(), kv_stride_slot, NE, P, total_kv, Hq, Hkv, tuple(q_strides)) + tuple((t.data_ptr(), t._version) for t in md)
     if cache_loc is not None:  # fused-append plans mark this step's new slots
         key += (cache_loc.data_ptr(), cache_loc._version, cache_loc.shape[0], new_stride)
     cached = getattr(node_q, "_deft_plan", None)

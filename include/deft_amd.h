@@ -61,6 +61,9 @@ const char* deft_last_error(void);
  * was built; callers that cache plans across calls key them by this value.  It only changes with the environment
  * variable DEFT_STAGE1_KERNEL (stream | np), which exists for A/B measurements. */
 int deft_stage1_kind(void);
+/* deft_stage1_kind() plus the experiment knobs of the plan kernels (DEFT_NP_CHUNK / _UNION / _TAPER) in one integer:
+ * the key for cached plans. */
+int deft_plan_variant(void);
 
 /* 1 if (Hq, Hkv, D) is covered: Hq % Hkv == 0, D in {64, 128}
  * (the reference asserts D in {16,32,64,128}, tree_attention.py:100,305,582). */
