@@ -2,6 +2,7 @@
 """Kernel-boundary anatomy of one Flatten call on the 100 MHz device clock:
 plan kernel | gap | stream kernel (first WG start .. last WG end) | gap | merge kernel."""
 import ctypes, os, sys, json
+os.environ.setdefault("DEFT_STAGE1_KERNEL", "stream")  # this tool reads the streaming form's stamps
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 from bench import Bench

@@ -3,6 +3,7 @@
 (start -> tile 0 ready), per-tile period, tail.  s_memtime ticks are converted with the measured 2.39 GHz... the
 ratio is re-derived here from the two clocks each workgroup stamps at start and end."""
 import ctypes, os, sys, json
+os.environ.setdefault("DEFT_STAGE1_KERNEL", "stream")  # this tool reads the streaming form's stamps
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 from bench import Bench

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Per-phase cycle breakdown of the streaming stage-1 kernel (s_memtime stamps)."""
 import ctypes, os, sys, json
+os.environ.setdefault("DEFT_STAGE1_KERNEL", "stream")  # this tool reads the streaming form's stamps
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 from bench import Bench
