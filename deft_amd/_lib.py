@@ -15,7 +15,7 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libdeft_amd.so")
+LIB_PATH = os.environ.get("DEFT_AMD_LIB") or os.path.join(_HERE, "lib", "libdeft_amd.so")  # override: A/B of two builds
 
 
 class DeftLibraryError(RuntimeError):

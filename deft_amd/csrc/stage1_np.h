@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
     // items W, W+1, ... from chip-wide ticket counters -- the XCDs of an MI355X do not stream at the same rate (the odd
     // ones ~20 % slower, tools/np_timeline.py) and the hardware dispatcher deals workgroups to XCDs round-robin,
     // so only a chip-wide queue lets them finish together.
-    int NI = 0x7fffffff;  // leaders x heads; read together with the first item's descriptor (one round trip)
+    const int NI = __builtin_amdgcn_readfirstlane(np.hdr[1]) * p.Hkv;
     int item = bid;
     int rec0 = 0, kvh = 0, fb = 0;
     auto rec_of = [&](int i) { return np.plan + (int64_t)(i == 0 ? rec0 : fb + i - 1) * PLAN_BYTES; };
@@ -184,45 +184,24 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
         }
     };
 
-    for (bool first = true;; first = false) {
+    for (;;) {
     if ((unsigned)item >= (unsigned)NI) break;  // uniform
     if (np.dbg) t_start = wall_clock64();
     rec0 = item / p.Hkv;
     kvh = item - rec0 * p.Hkv;
     const char* rec_lead = np.plan + (int64_t)rec0 * PLAN_BYTES;
-    // ONE round trip between launch and the first K/V request: the row offsets / masks / partial rows of tile 0 are
-    // requested (LDS-DMA) before anything is known about the record -- its address only depends on the block index,
-    // and every record slot of the grid is allocated memory -- and the descriptor and the leader count travel
-    // beside them as scalar loads (asm: the compiler would use vector loads here and wait for each in turn).
-    if (w == 0) dma4(rec_lead + PLAN_OROW + 4 * (l & 31), SM::OROW_OFF);  // leader's partial rows, for the epilogue
-    issue_aux(0, 0);
-    typedef int int8v __attribute__((ext_vector_type(8)));
-    int8v dsc;
-    {
-        const int32_t* desc0 = reinterpret_cast<const int32_t*>(rec_lead + PLAN_DESC);
-        if (first) {
-            int nl;
-            asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dword %1, %3, 0x4\n\ts_waitcnt lgkmcnt(0)"
-                         : "=&s"(dsc), "=&s"(nl)
-                         : "s"(desc0), "s"(np.hdr)
-                         : "memory");
-            NI = nl * p.Hkv;
-        } else {
-            asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(dsc) : "s"(desc0) : "memory");
-        }
-    }
-    if ((unsigned)item >= (unsigned)NI) {  // (first item only) a record slot beyond the leaders
-        wait_vm<0>();
-        break;
-    }
-    const int n = dsc[4];  // tiles of this chunk (> 0: items only name leaders)
-    const int nv = dsc[0];
-    fb = dsc[5];
+    const int32_t* desc0 = reinterpret_cast<const int32_t*>(rec_lead + PLAN_DESC);
+    const int n = __builtin_amdgcn_readfirstlane(desc0[4]);  // tiles of this chunk (> 0: items only name leaders)
+    const int nv = __builtin_amdgcn_readfirstlane(desc0[0]);
+    fb = __builtin_amdgcn_readfirstlane(desc0[5]);
     kb_pool = reinterpret_cast<const char*>(p.k) + (int64_t)kvh * p.kv_sh * 2;
     vb_pool = reinterpret_cast<const char*>(p.v) + (int64_t)kvh * p.kv_sh * 2 + vchunk_b;
     kb_new = reinterpret_cast<const char*>(np.k_new) + (int64_t)kvh * D * 2;
     vb_new = reinterpret_cast<const char*>(np.v_new) + (int64_t)kvh * D * 2 + vchunk_b;
+    // leader's partial rows (one per virtual query row), parked in LDS for the epilogue (wave 0, one DMA)
+    if (w == 0) dma4(rec_lead + PLAN_OROW + 4 * (l & 31), SM::OROW_OFF);
     // ---- prologue: aux(0) -> Q, K(0), aux(1), V(0) -----------------------------------------------------
+    issue_aux(0, 0);
     wait_vm<0>();
     load_rowoff(0);
     issue_q();
