@@ -676,6 +676,18 @@ static int launch_stage1_np(const Stage1Params& p, int64_t unit_cap, const PlanV
     // XCDs (the odd ones stream ~20 % slower and the dispatcher deals workgroups round-robin) but measured equal or
     // slower on every workload (profiles/r1_np_*.txt): with ~2 chunks per workgroup there is little left to balance.
     const int persist = getenv("DEFT_NP_PERSIST") ? atoi(getenv("DEFT_NP_PERSIST")) : 0;
+    // The grid is sized by record CAPACITY (the leader count lives on the device); slots beyond the leaders exit at
+    // once but still cost a dispatch each -- tens of thousands for the sequential comparator's one-query entries --
+    // so the grid is capped at a few times the resident slots and a workgroup whose index has more than one item takes
+    // them in a loop (item, item + grid, ...).  Measured (same box, tools: DEFT_NP_GRIDCAP=0,1,2,3,8): 3 x slots is
+    // never worse and up to 22 % better for MHA (sequential north-star tree 261 -> 204 us, 400-token branches
+    // 56.8 -> 54.2); GQA, where every workgroup's tiles come from L2 after the first pass, prefers resident
+    // workgroups only (ToT-50 28.1 -> 24.0 us, 8-tree forest 65.5 -> 60.9).
+    {
+        const int capx = getenv("DEFT_NP_GRIDCAP") ? atoi(getenv("DEFT_NP_GRIDCAP")) : (p.G > 1 ? 1 : 3);
+        const int64_t cap_wgs = (int64_t)capx * 2LL * num_cus();
+        if (cap_wgs > 0 && grid > cap_wgs) grid = cap_wgs;
+    }
     if (persist) {
         int64_t resident = 2LL * num_cus();
         if (getenv("DEFT_NP_WORKERS")) resident = atoi(getenv("DEFT_NP_WORKERS"));

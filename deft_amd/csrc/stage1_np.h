@@ -326,9 +326,8 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
         if (l == 0) *reinterpret_cast<int*>(smem + SM::NEXT_OFF) = W + t * NTICKET + tk_lane;
     }
     if (p.ablate & 16) {
-        if (!np.persist) break;
         lds_barrier();
-        item = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int*>(smem + SM::NEXT_OFF));
+        item = np.persist ? __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int*>(smem + SM::NEXT_OFF)) : item + W;
         continue;
     }
     if (np.dbg) t_epi = wall_clock64();
@@ -396,9 +395,12 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
         d[5] = ((unsigned long long)xcc << 32) | hw;
         d[6] = (unsigned long long)(long long)*reinterpret_cast<const int*>(smem + SM::NEXT_OFF);
     }
-    if (!np.persist) break;
+    // Next item: from the ticket queue (resident mode), or -- hardware dispatch with a capped grid -- simply item + W:
+    // record capacity beyond the chunk leaders would otherwise be launched as workgroups that only find out that
+    // they have nothing to do (tens of thousands of them for the sequential comparator's one-query entries).
+    if (item + W >= NI && !np.persist) break;
     lds_barrier();  // every wave is done reading the others' slices; the next item is visible
-    item = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int*>(smem + SM::NEXT_OFF));
+    item = np.persist ? __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int*>(smem + SM::NEXT_OFF)) : item + W;
     }  // work items
     finish();
 }
