@@ -657,8 +657,11 @@ static int launch_stage1_np(const Stage1Params& p, int64_t unit_cap, const PlanV
     using SM = NpSmem<128>;
     static bool attr_set = false;
     if (!attr_set) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&stage1_np_kernel<128>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, SM::BYTES);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&stage1_np_kernel<128, false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, SM::BYTES);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&stage1_np_kernel<128, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, SM::BYTES);
         if (e != hipSuccess) {
             set_error("hipFuncSetAttribute(stage1_np): %s", hipGetErrorString(e));
             return DEFT_EHIP;
@@ -706,7 +709,10 @@ static int launch_stage1_np(const Stage1Params& p, int64_t unit_cap, const PlanV
     npp.new_st = ap.new_st;
     npp.n_new = ap.k_new ? ap.n_new : 0;
     npp.dbg = g_stream_dbg;
-    hipLaunchKernelGGL((stage1_np_kernel<128>), dim3((unsigned)grid), dim3(256), SM::BYTES, stream, npp);
+    if (persist)
+        hipLaunchKernelGGL((stage1_np_kernel<128, true>), dim3((unsigned)grid), dim3(256), SM::BYTES, stream, npp);
+    else
+        hipLaunchKernelGGL((stage1_np_kernel<128, false>), dim3((unsigned)grid), dim3(256), SM::BYTES, stream, npp);
     return check_launch("stage1 np launch");
 }
 

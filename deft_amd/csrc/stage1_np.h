@@ -68,7 +68,7 @@ __device__ __forceinline__ void dma4(const void* gsrc, uint32_t lds_dst) {
         : "memory");
 }
 
-template <int D>
+template <int D, bool PERSIST>
 __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
     constexpr int KS = D / 16;
     constexpr int LPT = 32 * (D / 8) / 64;  // DMA instructions per wave per K (or V) slice
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
     // stripe is served by workgroups of ALL eight XCDs (b % 8 is the XCD under round-robin dispatch).
     const int tk_lane = (p.ablate & 256) ? 0 : (bid >> 3) % NTICKET;
     auto finish = [&]() {  // the last workgroup to leave re-arms the scheduler words for the next launch
-        if (np.persist && !(p.ablate & 512) && tid == 0 && atomicAdd(np.sched, 1) == W - 1) {
+        if (PERSIST && !(p.ablate & 512) && tid == 0 && atomicAdd(np.sched, 1) == W - 1) {
             np.sched[0] = 0;
             for (int k = 0; k < NTICKET; ++k) np.sched[ticket_word(k)] = 0;
         }
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
         // It lands in the FIXED register v255 named in the asm text (never a C++ variable the compiler could copy
         // while the atomic is in flight); the kernel's own allocation -- including register TUPLES, which a textual
         // grep for the name misses -- stays below it (tools/check_asm.sh).
-        if (np.persist && !has1 && w == 0 && l == 0) {
+        if (PERSIST && !has1 && w == 0 && l == 0) {
             int* tk = np.sched + ticket_word(tk_lane);
             asm volatile("global_atomic_add v255, %0, %1, off sc0" ::"v"(tk), "v"(1) : "memory", "v255");
         }
@@ -320,14 +320,14 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
         if (has1) issue_v();  // V(i+1); rowoff still holds tile i+1's offsets
     }
 
-    if (np.persist && w == 0) {
+    if (PERSIST && w == 0) {
         int t;
         asm volatile("v_readfirstlane_b32 %0, v255" : "=s"(t)::"memory");
         if (l == 0) *reinterpret_cast<int*>(smem + SM::NEXT_OFF) = W + t * NTICKET + tk_lane;
     }
     if (p.ablate & 16) {
         lds_barrier();
-        item = np.persist ? __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int*>(smem + SM::NEXT_OFF)) : item + W;
+        item = PERSIST ? __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int*>(smem + SM::NEXT_OFF)) : item + W;
         continue;
     }
     if (np.dbg) t_epi = wall_clock64();
@@ -398,9 +398,9 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
     // Next item: from the ticket queue (resident mode), or -- hardware dispatch with a capped grid -- simply item + W:
     // record capacity beyond the chunk leaders would otherwise be launched as workgroups that only find out that
     // they have nothing to do (tens of thousands of them for the sequential comparator's one-query entries).
-    if (item + W >= NI && !np.persist) break;
+    if (item + W >= NI && !PERSIST) break;
     lds_barrier();  // every wave is done reading the others' slices; the next item is visible
-    item = np.persist ? __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int*>(smem + SM::NEXT_OFF)) : item + W;
+    item = PERSIST ? __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int*>(smem + SM::NEXT_OFF)) : item + W;
     }  // work items
     finish();
 }

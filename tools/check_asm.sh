@@ -16,5 +16,5 @@ check() {  # kernel symbol, first reserved register, allowed literal uses
   echo "$sym: highest compiler-allocated VGPR v$max, reserved from v$lo"
   [ "$max" -lt "$lo" ]
 }
-check _ZN4deft16stage1_np_kernelILi128EEEvNS_8NpParamsE 255 255 255
+check _ZN4deft16stage1_np_kernelILi128ELb1EEEvNS_8NpParamsE 255 255 255
 check _ZN4deft20stage1_stream_kernelILi128EEEvNS_12StreamParamsE 200 200 201
