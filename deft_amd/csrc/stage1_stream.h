@@ -712,7 +712,7 @@ __global__ __launch_bounds__(256) void flatten_units_kernel(const int64_t* block
             // taper: the workgroups dispatched last should be short, so that the launch ends together -- the last
             // `slots` leaf tiles (per head) stay single, the `2 slots` before them go in pairs
             int ulen = union_len;
-            if (ulen <= 0) ulen = G > 1 ? 1 : ((int64_t)NB * Hkv < 2048 ? 4 : 2);  // measured, tools/np_sweep.sh
+            if (ulen <= 0) ulen = G > 1 ? 1 : ((int64_t)NB * Hkv < 2048 ? 4 : 3);  // measured, tools/np_sweep.sh / tools/ab.py
             if (taper) {
                 const int64_t rest = (int64_t)(NB - ta) * Hkv;
                 if (rest <= (int64_t)slots) ulen = 1;
