@@ -701,6 +701,7 @@ static int launch_stage1_np(const Stage1Params& p, int64_t unit_cap, const PlanV
     npp.hdr = pv.hdr;
     npp.sched = pv.sched;
     npp.persist = persist;
+    npp.fast_n = getenv("DEFT_NP_FAST") ? atoi(getenv("DEFT_NP_FAST")) : 2 * num_cus();
     npp.s.ablate = getenv("DEFT_STAGE1_ABLATE") ? atoi(getenv("DEFT_STAGE1_ABLATE")) : 0;
     npp.plan = pv.records;
     npp.k_new = ap.k_new;

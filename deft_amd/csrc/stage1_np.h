@@ -33,6 +33,7 @@ struct NpParams {
     const int32_t* hdr;  // plan header: hdr[1] = number of chunk leaders
     int* sched;          // sched[0] = workgroups done, sched[ticket_word(0)] = chunk ticket; all 0 between launches
     int persist;         // 1: resident workgroups draw further chunks from the ticket counter; 0: one chunk per workgroup
+    int fast_n;          // workgroups < fast_n (the ones resident at launch) request tile 0's offsets before anything else
     // fused paged append (optional), as in StreamParams
     const _Float16* k_new;
     const _Float16* v_new;
@@ -107,9 +108,9 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
     // items W, W+1, ... from chip-wide ticket counters -- the XCDs of an MI355X do not stream at the same rate (the odd
     // ones ~20 % slower, tools/np_timeline.py) and the hardware dispatcher deals workgroups to XCDs round-robin,
     // so only a chip-wide queue lets them finish together.
-    const int NI = __builtin_amdgcn_readfirstlane(np.hdr[1]) * p.Hkv;
+    int NI = 0x7fffffff;  // leaders x heads, read with the first item's descriptor
     int item = bid;
-    int rec0 = 0, kvh = 0, fb = 0;
+    int rec0 = 0, kvh = 0, fb = 0, sd4 = 0, sd0 = 0, sd5 = 0;
     auto rec_of = [&](int i) { return np.plan + (int64_t)(i == 0 ? rec0 : fb + i - 1) * PLAN_BYTES; };
     // NTICKET counters, one cache line each (one counter serialises at ~80 atomics/us: 512 requests at launch would
     // take 6 us).  Workgroup b uses counter (b >> 3) % NTICKET and that counter's stripe of the items, so every
@@ -184,24 +185,52 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
         }
     };
 
-    for (;;) {
-    if ((unsigned)item >= (unsigned)NI) break;  // uniform
+    for (bool first = true;; first = false) {
     if (np.dbg) t_start = wall_clock64();
     rec0 = item / p.Hkv;
     kvh = item - rec0 * p.Hkv;
     const char* rec_lead = np.plan + (int64_t)rec0 * PLAN_BYTES;
     const int32_t* desc0 = reinterpret_cast<const int32_t*>(rec_lead + PLAN_DESC);
-    const int n = __builtin_amdgcn_readfirstlane(desc0[4]);  // tiles of this chunk (> 0: items only name leaders)
-    const int nv = __builtin_amdgcn_readfirstlane(desc0[0]);
-    fb = __builtin_amdgcn_readfirstlane(desc0[5]);
+    // The workgroups that are resident when the launch starts set the ramp: for them tile 0's offsets / masks /
+    // partial rows are requested (LDS-DMA) before anything is known about the record -- its address only depends
+    // on the block index, every record slot of the grid is allocated memory -- so that the leader count, the
+    // descriptor and the offsets come back in ONE round trip instead of three dependent ones.  Later workgroups
+    // find the plan in L2 and keep the order in which a slot without work exits after a single load.
+    const bool spec = first && bid < np.fast_n;  // uniform
+    if (spec) {
+        if (w == 0) dma4(rec_lead + PLAN_OROW + 4 * (l & 31), SM::OROW_OFF);
+        issue_aux(0, 0);
+    }
+    if (first) {
+        const int nl = np.hdr[1];
+        const int d4 = desc0[4], d0 = desc0[0], d5 = desc0[5];  // speculative for slots beyond the leaders: valid memory
+        NI = __builtin_amdgcn_readfirstlane(nl) * p.Hkv;
+        if (item >= NI) {
+            if (spec) wait_vm<0>();
+            break;
+        }
+        sd4 = __builtin_amdgcn_readfirstlane(d4);
+        sd0 = __builtin_amdgcn_readfirstlane(d0);
+        sd5 = __builtin_amdgcn_readfirstlane(d5);
+    } else {
+        if ((unsigned)item >= (unsigned)NI) break;  // resident mode: a ticket beyond the last item
+        sd4 = __builtin_amdgcn_readfirstlane(desc0[4]);
+        sd0 = __builtin_amdgcn_readfirstlane(desc0[0]);
+        sd5 = __builtin_amdgcn_readfirstlane(desc0[5]);
+    }
+    const int n = sd4;  // tiles of this chunk (> 0: items only name leaders)
+    const int nv = sd0;
+    fb = sd5;
     kb_pool = reinterpret_cast<const char*>(p.k) + (int64_t)kvh * p.kv_sh * 2;
     vb_pool = reinterpret_cast<const char*>(p.v) + (int64_t)kvh * p.kv_sh * 2 + vchunk_b;
     kb_new = reinterpret_cast<const char*>(np.k_new) + (int64_t)kvh * D * 2;
     vb_new = reinterpret_cast<const char*>(np.v_new) + (int64_t)kvh * D * 2 + vchunk_b;
     // leader's partial rows (one per virtual query row), parked in LDS for the epilogue (wave 0, one DMA)
-    if (w == 0) dma4(rec_lead + PLAN_OROW + 4 * (l & 31), SM::OROW_OFF);
+    if (!spec) {
+        if (w == 0) dma4(rec_lead + PLAN_OROW + 4 * (l & 31), SM::OROW_OFF);
+        issue_aux(0, 0);
+    }
     // ---- prologue: aux(0) -> Q, K(0), aux(1), V(0) -----------------------------------------------------
-    issue_aux(0, 0);
     wait_vm<0>();
     load_rowoff(0);
     issue_q();
