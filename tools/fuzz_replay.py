@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Randomised replays: random tree templates (widths, node lengths, prompt length), geometries and modes; at every
+step the attention output of layer 0 is compared with fp64 per-leaf attention over the leaf's page-table row,
+computed with torch on the GPU.  tools/fuzz_replay.py [seconds] [seed]"""
+import os, sys, time, random
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+from deft_amd import replay as rp
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+t_end = time.time() + budget
+runs = steps = 0
+worst = 0.0
+while time.time() < t_end:
+    Hq, Hkv = rng.choice([(32, 32), (32, 8), (8, 2), (4, 4), (16, 1)])
+    D = 128
+    mode = rng.choice(["flatten", "flatten", "node", "seq"])
+    task = rng.choice(["reasoning", "reasoning", "few_shot", "speculative_decoding"])
+    if task == "reasoning":
+        depth = rng.randint(1, 3)
+        tpl = rp.synthetic_reasoning_template(widths=[rng.randint(1, 6) for _ in range(depth)],
+                                              lens=[rng.choice([1, 2, 3, 7, 40, 130, 200]) for _ in range(depth)])
+        gen = 600
+    elif task == "few_shot":
+        tpl = rp.synthetic_few_shot_template(rng.choice([1, 2, 5, 33, 40, 64]))
+        gen = rng.choice([3, 10, 140])
+    else:
+        tpl = rp.synthetic_speculative_template(rng.choice([4, 16, 64]), rng.randint(3, 8), (1, rng.randint(1, 4)), rng.randint(0, 999))
+        gen = 100
+    prompt = rng.choice([1, 5, 127, 128, 129, 300, 1000, 4096])
+    r = rp.TemplateReplay(Hq, Hkv, D, layers=1, mode=mode, device="cuda", attention=True, seed=rng.randint(0, 10 ** 6))
+    holder = {}
+    real = rp.TreeCache
+
+    class Spy(real):
+        def __init__(self, *a, **kw):
+            super().__init__(*a, **kw); holder["tree"] = self
+
+    attn0 = r.attn[0]; orig = attn0.forward
+    def checked(q, k, v, meta, orig=orig):
+        global steps, worst
+        out = orig(q, k, v, meta)
+        tree = holder["tree"]
+        leaves = sorted(tree.leaves.values(), key=lambda n: n.id)
+        kv = tree.token_to_kv_pool.kv_data[0].double()
+        qd = q.view(-1, Hq, D).double(); od = out.view(-1, Hq, D).double()
+        for i, lf in enumerate(leaves):
+            path = tree.leaf_path_slots(lf)
+            if mode == "seq":  # the comparator reads the PAGE TABLE; the reference's speculative-decoding mock squeezes
+                # accepted tokens into the root without rewriting the other leaves' rows (branch_func_example.py:420-437),
+                # so there -- and only there -- the table is not the tree path
+                req = tree.leaf_to_req[lf.id]
+                row = tree.req_to_token_pool.req_to_token[req, : len(path)].tolist()
+                if task != "speculative_decoding":
+                    assert row == path, (mode, task, i)
+                path = row
+            slots = torch.tensor(path, device="cuda")
+            kk = kv[slots, 0].repeat_interleave(Hq // Hkv, dim=1).transpose(0, 1)  # [Hq, S, D]
+            vv = kv[slots, 1].repeat_interleave(Hq // Hkv, dim=1).transpose(0, 1)
+            s = torch.einsum("hd,hsd->hs", qd[i], kk) / D ** 0.5
+            ref = torch.einsum("hs,hsd->hd", torch.softmax(s, dim=-1), vv)
+            err = (od[i] - ref).abs().max().item()
+            worst = max(worst, err)
+            assert err < 5e-4 + 2.0 ** -11 * ref.abs().max().item(), (err, mode, task, Hq, Hkv, prompt, i, len(slots))
+        steps += 1
+        return out
+    attn0.forward = checked
+    rp.TreeCache = Spy
+    try:
+        r.run(tpl, task, prompt, gen, max_rows=512)
+    finally:
+        rp.TreeCache = real
+    runs += 1
+print(f"fuzz ok: {runs} replays, {steps} checked steps, worst |err| {worst:.2e}")
