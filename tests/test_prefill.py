@@ -149,3 +149,20 @@ def test_prefill_full_size_properties():
     o3 = run(k, v * 2)
     torch.cuda.synchronize()
     assert (o3.float() - 2 * o.float()).abs().max().item() < 2e-3
+
+
+@pytest.mark.gpu
+def test_gpu_prefill_random_ragged_batches():
+    rng = np.random.default_rng(5)
+    for trial in range(6):
+        Hq, Hkv = [(8, 8), (8, 2), (16, 1)][trial % 3]
+        D = 128
+        lens = [int(x) for x in rng.integers(1, 700, size=int(rng.integers(1, 6)))]
+        T = sum(lens)
+        q, k, v = dyadic_normal((T, Hq, D), 20 + trial), dyadic_normal((T, Hkv, D), 40 + trial), dyadic_normal((T, Hkv, D), 60 + trial)
+        start = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int32)
+        o = torch.full((T, Hq, D), float("nan"), dtype=torch.float16, device="cuda")
+        deft_amd.context_attention_fwd(torch.from_numpy(q).cuda(), torch.from_numpy(k).cuda(), torch.from_numpy(v).cuda(), o,
+                                       torch.from_numpy(start).cuda(), torch.tensor(lens, dtype=torch.int32).cuda(), max(lens))
+        torch.cuda.synchronize()
+        assert _close_to_truth(o.cpu().numpy(), oa.causal_truth(q, k, v, start, np.asarray(lens))), (trial, lens)

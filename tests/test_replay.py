@@ -138,3 +138,16 @@ def test_replay_attention_matches_truth_every_step(task, mode):
     finally:
         rp.TreeCache = real_tree_cls
     assert seen["steps"] == rep.steps > 3 and rep.attention_ms > 0
+
+
+@pytest.mark.gpu
+def test_random_replays_match_truth_every_step():
+    """A short, seeded run of tools/fuzz_replay.py: random templates / geometries / modes, every step of layer 0 against
+    fp64 attention over the leaf's page-table row."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_replay.py"), "12", "7"], capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0 and "fuzz ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
