@@ -320,6 +320,9 @@ class ReplayReport:
     attention_ms: float = 0.0  # GPU time of the per-layer append + attention calls, all layers, all steps
     metadata_ms: float = 0.0   # host time of alloc + TreeMetadata.from_tree_cache (+ upload), all steps
     branch_ms: float = 0.0     # host time of the branch function
+    kv_io_bytes: int = 0       # the reference's KV-IO counter: kv_len * Hq * D * 4 per layer call (perf_metrics.py:116-118;
+    #                            kv_len = node slots / total_kv_len / total_num_tokens, deft_attention.py:88-91, :129-133, :168-171)
+    mask_io_bytes: int = 0     # Flatten only: total_kv_len * 8 per layer call (perf_metrics.py:120-122)
     wall_ms: float = 0.0
     per_step: List[Dict[str, float]] = field(default_factory=list)
 
@@ -332,6 +335,7 @@ class ReplayReport:
             "branch_ms": round(self.branch_ms, 3), "wall_ms": round(self.wall_ms, 3),
             "attention_TPOT_ms_per_token": round(self.attention_ms / gen, 5),  # perf_metrics.py:203-210 on attention latency
             "attention_us_per_step": round(self.attention_ms * 1e3 / max(self.steps, 1), 2),
+            "KV_IO_TB": round(self.kv_io_bytes / 1e12, 4), "Mask_IO_GB": round(self.mask_io_bytes / 1e9, 4),
             "max_live_leaves": int(max((s["nq"] for s in self.per_step), default=0)),
             "max_tree_kv_tokens": int(max((s["kv_tokens"] for s in self.per_step), default=0)),
         }
@@ -438,6 +442,14 @@ class TemplateReplay:
             t_br = (time.perf_counter() - t1) * 1e3
             rep.per_step.append({"iter": it, "nq": nq, "kv_tokens": int(kv_tokens), "attention_ms": t_attn,
                                  "metadata_ms": t_md, "branch_ms": t_br})
+            if self.forward_mode == ForwardMode.TREE_DECODE_FLATTEN:
+                io_len = int(md.total_kv_len)
+                rep.mask_io_bytes += io_len * 8 * self.layers
+            elif self.forward_mode == ForwardMode.TREE_DECODE_NODE:
+                io_len = int(md.node_kv.shape[0])
+            else:
+                io_len = int(meta.total_num_tokens)
+            rep.kv_io_bytes += io_len * self.Hq * self.D * 4 * self.layers
             rep.steps += 1
             rep.decoded_rows += nq
             rep.attention_ms += t_attn

@@ -58,10 +58,10 @@ for mode in a.modes:
     del r
     torch.cuda.empty_cache()
 base = next((x for x in rows if x["mode"] == "seq"), None)
-print(f"\n{'mode':10s} {'steps':>6s} {'gen tok':>8s} {'attn ms':>10s} {'us/step':>9s} {'TPOT ms':>9s} {'md ms/step':>10s} {'vs seq':>7s}")
+print(f"\n{'mode':10s} {'steps':>6s} {'gen tok':>8s} {'attn ms':>10s} {'us/step':>9s} {'TPOT ms':>9s} {'md ms/step':>10s} {'KV-IO TB':>9s} {'vs seq':>7s}")
 for s in rows:
     sp = f"{base['attention_latency_ms'] / s['attention_latency_ms']:.2f}x" if base else "-"
     print(f"{s['mode']:10s} {s['steps']:6d} {s['generated_tokens']:8d} {s['attention_latency_ms']:10.2f} {s['attention_us_per_step']:9.1f} "
-          f"{s['attention_TPOT_ms_per_token']:9.4f} {s['metadata_ms'] / max(s['steps'], 1):10.3f} {sp:>7s}")
+          f"{s['attention_TPOT_ms_per_token']:9.4f} {s['metadata_ms'] / max(s['steps'], 1):10.3f} {s['KV_IO_TB']:9.3f} {sp:>7s}")
 if a.out:
     json.dump(rows, open(a.out, "w"), indent=1)
