@@ -196,3 +196,19 @@ def test_native_tree_mirror_detects_out_of_band_edits():
     assert not tc._mirror_consistent(tree)
     md = deft_amd.TreeMetadata.from_tree_cache(tree, device="cpu")
     assert int(slot[0]) in md.block_kv.tolist()
+
+
+def test_fixed_asm_registers_stay_clear_of_the_compiler():
+    """The ticket prefetches of the streaming form (v200 / v201) and of the resident-workgroup mode of the tile-parallel
+    form (v255) land in registers named in inline asm; the compiler's own allocation -- single registers and tuples --
+    must stay below them (tools/check_asm.sh rebuilds the device assembly and checks)."""
+    import os
+    import shutil
+    import subprocess
+
+    if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        pytest.skip("hipcc not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(["bash", os.path.join(root, "tools", "check_asm.sh")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("reserved from") == 2
