@@ -354,6 +354,7 @@ __global__ __launch_bounds__(256) void node_prep_kernel(const int64_t* node_kv_o
 // running true maximum (online rescale), and accumulates only the rows that carry a
 // partial (lse > -inf; rows folded into a group by the streaming stage 1 are skipped),
 // eight independent 512-byte row loads in flight per step.  fp32 accumulate, one fp16 rounding.
+constexpr int64_t MERGE_SEG = 15872;  // rows of row_q listed per pass: 4 x 3968 ints + 4 counters stay under 64 KB of LDS
 template <int D>
 __global__ __launch_bounds__(256) void merge_kernel(const float* partial_o, const float* partial_lse, const int32_t* row_q,
                                                      int64_t rows, _Float16* out, int64_t o_st, int64_t o_sh, int Hq,
@@ -368,14 +369,26 @@ __global__ __launch_bounds__(256) void merge_kernel(const float* partial_o, cons
     const int lane = tid & 63;
     const int qi = blockIdx.x;
     const int hq = blockIdx.y * 4 + w;
-    const int quarter = (int)(((rows + 3) / 4 + 63) / 64 * 64);
+    const float* lse_h = partial_lse + (int64_t)(hq < Hq ? hq : 0) * rows;
+    const float* po_h = partial_o + (int64_t)(hq < Hq ? hq : 0) * rows * D + VEC * lane;
+    float acc[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+    float m_run = -INFINITY, L = 0.f;
 
-    // 1. rows of this query inside this wave's quarter of row_q (eight independent loads per lane in
+    // The row list is built MERGE_SEG rows of row_q at a time (one pass for every tree up to 16k partial rows;
+    // longer workspaces take further passes that carry the running maximum / sum / accumulator across).
+    for (int64_t seg0 = 0; seg0 < rows; seg0 += MERGE_SEG) {
+    const int64_t seg_rows = rows - seg0 < MERGE_SEG ? rows - seg0 : MERGE_SEG;
+    const int quarter = (int)(((seg_rows + 3) / 4 + 63) / 64 * 64);
+    if (seg0) __syncthreads();  // the previous pass's list is still being read
+
+    // 1. rows of this query inside this wave's quarter of the segment (eight independent loads per lane in
     //    flight, then ordered ballots: one L2 round trip per 512 rows instead of one per 64)
     {
         int n = 0;
-        const int64_t lo = (int64_t)w * quarter;
-        const int64_t hi = lo + quarter < rows ? lo + quarter : rows;
+        const int64_t lo = seg0 + (int64_t)w * quarter;
+        const int64_t hi = lo + quarter < seg0 + seg_rows ? lo + quarter : seg0 + seg_rows;
         for (int64_t base = lo; base < hi; base += 512) {
             int val[8];
 #pragma unroll
@@ -394,18 +407,11 @@ __global__ __launch_bounds__(256) void merge_kernel(const float* partial_o, cons
         if (lane == 0) sCnt[w] = n;
     }
     __syncthreads();
-    if (hq >= Hq) return;
 
     // 2. merge this head's partials
-    const float* lse_h = partial_lse + (int64_t)hq * rows;
-    const float* po_h = partial_o + (int64_t)hq * rows * D + VEC * lane;
-    float acc[VEC];
-#pragma unroll
-    for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
-    float m_run = -INFINITY, L = 0.f;
     // the four per-wave lists, read as one list in ascending row order
     const int c0 = sCnt[0], c1 = sCnt[1], c2 = sCnt[2], c3 = sCnt[3];
-    const int n = c0 + c1 + c2 + c3;
+    const int n = hq < Hq ? c0 + c1 + c2 + c3 : 0;
     for (int base = 0; base < n; base += 64) {
         const int g = base + lane;
         const bool in = g < n;
@@ -461,6 +467,8 @@ __global__ __launch_bounds__(256) void merge_kernel(const float* partial_o, cons
                 }
         }
     }
+    }  // segments
+    if (hq >= Hq) return;
     const float inv = L > 0.f ? 1.f / L : 0.f;
     _Float16* dst = out + (int64_t)qi * o_st + (int64_t)hq * o_sh + VEC * lane;
 #pragma unroll
@@ -733,12 +741,9 @@ static int dispatch_stage1(int D, const Stage1Params& p, int64_t tiles, hipStrea
 static int launch_merge(int D, const Workspace& ws, const int32_t* row_q, int64_t rows, void* out, int64_t o_st, int64_t o_sh,
                         int nq, int Hq, hipStream_t stream) {
     if (nq <= 0) return DEFT_OK;
-    const int64_t quarter = ((rows + 3) / 4 + 63) / 64 * 64;
+    const int64_t seg = rows < MERGE_SEG ? rows : MERGE_SEG;
+    const int64_t quarter = ((seg + 3) / 4 + 63) / 64 * 64;
     const size_t lds = sizeof(int) * (size_t)(4 + 4 * quarter);
-    if (lds > 64 * 1024) {
-        set_error("merge: %lld partial rows exceed the LDS row list", (long long)rows);
-        return DEFT_EUNSUPPORTED;
-    }
     dim3 grid((unsigned)nq, (unsigned)((Hq + 3) / 4));
     if (D == 128)
         hipLaunchKernelGGL((merge_kernel<128>), grid, dim3(256), lds, stream, ws.partial_o, ws.partial_lse, row_q, rows,
