@@ -597,13 +597,26 @@ static int np_union_env() {  // tiles per union group of leaf tiles (1 = off, 0 
 // Flatten plan: unit list (one workgroup) then one record per unit.
 static int launch_plan(const Stage1Params& p, int NB, const PlanView& pv, const AppendArgs& ap, hipStream_t stream) {
     if (NB <= 0) return DEFT_OK;
-    if (sizeof(int) * 4 * (size_t)NB > 48 * 1024) {
+    // The unit kernel is one workgroup and may use the CU's whole LDS: 9216 blocks = 1.18 M KV tokens per call,
+    // more than a 7B model's KV cache fits in 288 GB.
+    constexpr size_t UNIT_LDS = 156 * 1024;
+    if (sizeof(int) * 4 * (size_t)NB > 144 * 1024) {
         set_error("plan: %d blocks exceed the unit kernel's LDS", NB);
         return DEFT_EUNSUPPORTED;
     }
+    static bool attr_set = false;
+    if (!attr_set) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&flatten_units_kernel),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)UNIT_LDS);
+        if (e != hipSuccess) {
+            set_error("hipFuncSetAttribute(flatten_units): %s", hipGetErrorString(e));
+            return DEFT_EHIP;
+        }
+        attr_set = true;
+    }
     // block tables + a run table for the tile-parallel record order (as many runs as fit; beyond that the kernel scans)
     int64_t run_cap = pv.cap;
-    while (sizeof(int) * (4 * (size_t)NB + 3 * (size_t)run_cap) > 60 * 1024 && run_cap > 0) run_cap /= 2;
+    while (sizeof(int) * (4 * (size_t)NB + 3 * (size_t)run_cap) > (NB > 2048 ? UNIT_LDS : 60 * 1024) && run_cap > 0) run_cap /= 2;
     const size_t lds = sizeof(int) * (4 * (size_t)NB + 3 * (size_t)run_cap);
     const UnitList ul = unit_list(pv);
     const int np = stage1_kind();

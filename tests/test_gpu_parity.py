@@ -527,13 +527,16 @@ def test_sequential_module_path_with_fused_append():
 
 
 @pytest.mark.parametrize("mode", ["flatten", "node"])
-def test_many_partial_rows_take_several_merge_passes(mode):
+@pytest.mark.parametrize("shape", [(4, 2, 100_000, 48), (2, 1, 450_000, 3)])
+def test_many_partial_rows_take_several_merge_passes(mode, shape):
     """A 100k-token prefix under 48 branches leaves ~37k (Flatten) / ~25k (Node) partial rows: more than one pass
-    of the merge kernel's LDS row list (15872 rows per pass).  Checked against fp64 attention per leaf."""
+    of the merge kernel's LDS row list (15872 rows per pass); a 450k-token prefix is 3516 Flatten blocks, past the
+    unit kernel's 64 KB LDS tables (it takes the CU's whole LDS then).  Checked against fp64 attention per leaf."""
     from deft_amd.memory_pool import ReqToTokenPool, TokenToKVPool
     from deft_amd.tree_cache import TreeCache
 
-    Hq, Hkv, D, prefix, width = 4, 2, 128, 100_000, 48
+    Hq, Hkv, prefix, width = shape
+    D = 128
     size = prefix + 4 * width + 256
     req = ReqToTokenPool(width + 8, size + 8, device="cuda")
     pool = TokenToKVPool(size, torch.float16, Hkv, D, 1, device="cuda")
@@ -557,7 +560,7 @@ def test_many_partial_rows_take_several_merge_passes(mode):
                                     md.node_q_offset, md.node_q_len)
     torch.cuda.synchronize()
     leaves = sorted(tree.leaves.values(), key=lambda n: n.id)
-    for r in (0, 17, 31, 32, 47):
+    for r in sorted({0, width // 3, width - 1}):
         slots = torch.tensor(tree.leaf_path_slots(leaves[r]), device="cuda")
         k = kb[slots].double().repeat_interleave(Hq // Hkv, dim=1).transpose(0, 1)
         v = vb[slots].double().repeat_interleave(Hq // Hkv, dim=1).transpose(0, 1)

@@ -14,7 +14,7 @@ runs = steps = 0
 worst = 0.0
 while time.time() < t_end:
     Hq, Hkv = rng.choice([(32, 32), (32, 8), (8, 2), (4, 4), (16, 1)])
-    D = 128
+    D = 64 if Hq <= 8 and rng.random() < 0.3 else 128
     mode = rng.choice(["flatten", "flatten", "node", "seq"])
     task = rng.choice(["reasoning", "reasoning", "few_shot", "speculative_decoding"])
     if task == "reasoning":
@@ -28,7 +28,7 @@ while time.time() < t_end:
     else:
         tpl = rp.synthetic_speculative_template(rng.choice([4, 16, 64]), rng.randint(3, 8), (1, rng.randint(1, 4)), rng.randint(0, 999))
         gen = 100
-    prompt = rng.choice([1, 5, 127, 128, 129, 300, 1000, 4096])
+    prompt = rng.choice([1, 5, 127, 128, 129, 300, 1000, 4096, 4096, 20000, 70000] if Hq <= 8 else [1, 5, 127, 128, 129, 300, 1000, 4096])
     r = rp.TemplateReplay(Hq, Hkv, D, layers=1, mode=mode, device="cuda", attention=True, seed=rng.randint(0, 10 ** 6))
     holder = {}
     real = rp.TreeCache
