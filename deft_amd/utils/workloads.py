@@ -49,6 +49,8 @@ WORKLOADS: Dict[str, Workload] = {
     "fewshot_1kx32_seq": Workload("fewshot_1kx32_seq", "llama2-7b", "seq", "few_shot", 1024, 32, 200),
     # configs[2]: Medusa depth-4 width-10 template as the reference mocks it (tree_size64), DeFT-Node
     "medusa64_node": Workload("medusa64_node", "llama2-7b", "node", "medusa", 1016, 64, 1),
+    # the north-star tree on a GQA model (Llama-3-8B: 32 branches x 4 query heads per KV head = 128 rows per tile)
+    "gqa_4kx32": Workload("gqa_4kx32", "llama3-8b", "flatten", "few_shot", 4096, 32, 200),
     # configs[3]: Llama-3-8B ToT tree, 4k prefix, 50 nodes, DeFT-Flatten
     "tot50_4k": Workload("tot50_4k", "llama3-8b", "flatten", "tot", 4096),
     # configs[4]: 64 independent 8k-prefix trees (8 branches x 64 tokens) over 8 GPUs, Llama-3-8B:
