@@ -289,7 +289,7 @@ def main():
         if w.kind == "few_shot" and args.branch_len is None:
             variants += [(f"{w.name}_len1", Workload(**{**w.__dict__, "branch_len": 1})),
                          (f"{w.name}_len400", Workload(**{**w.__dict__, "branch_len": 400}))]
-        for name in ("fewshot_1kx32", "medusa64_node", "tot50_4k", "forest_8kx8_single", "forest_8kx8",
+        for name in ("fewshot_1kx32", "medusa64_node", "tot50_4k", "gqa_4kx32", "forest_8kx8_single", "forest_8kx8",
                      "northstar_4kx32_seq", "fewshot_1kx32_seq"):
             if name != w.name:
                 variants.append((name, WORKLOADS[name]))

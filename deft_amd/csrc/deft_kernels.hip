@@ -708,7 +708,10 @@ static int launch_stage1_np(const Stage1Params& p, int64_t unit_cap, const PlanV
     // 56.8 -> 54.2); GQA, where every workgroup's tiles come from L2 after the first pass, prefers resident
     // workgroups only (ToT-50 28.1 -> 24.0 us, 8-tree forest 65.5 -> 60.9).
     {
-        const int capx = getenv("DEFT_NP_GRIDCAP") ? atoi(getenv("DEFT_NP_GRIDCAP")) : (p.G > 1 ? 1 : 3);
+        // GQA launches whose whole record capacity is within 8 x the resident slots (a single tree: the Llama-3
+        // north-star tree, ToT-50) have about one item per workgroup anyway and gain 2 us from 2 x slots.
+        const bool small_gqa = unit_cap * p.Hkv <= 16LL * num_cus();
+        const int capx = getenv("DEFT_NP_GRIDCAP") ? atoi(getenv("DEFT_NP_GRIDCAP")) : (p.G > 1 ? (small_gqa ? 2 : 1) : 3);
         const int64_t cap_wgs = (int64_t)capx * 2LL * num_cus();
         if (cap_wgs > 0 && grid > cap_wgs) grid = cap_wgs;
     }

@@ -614,7 +614,8 @@ __device__ inline void run_push(RunTable& rt, int r0, int nt, int uni) {
     ++rt.n;
 }
 
-__device__ inline void np_record_order(const UnitList& ul, int R, int Hkv, int slots, int chunk_c, int32_t* hdr, RunTable rt) {
+__device__ inline void np_record_order(const UnitList& ul, int R, int Hkv, int G, int slots, int chunk_c, int32_t* hdr,
+                                       RunTable rt) {
     if (rt.n > rt.cap) {  // rebuild the table is impossible: scan (slow path, huge trees only)
         rt.n = 0;
         rt.cap = 0;
@@ -644,6 +645,18 @@ __device__ inline void np_record_order(const UnitList& ul, int R, int Hkv, int s
             if (!uni && nt > lmax) lmax = nt;
         });
         C = lmax >= 32 ? 8 : (lmax >= 8 ? 4 : (lmax >= 4 ? 2 : 1));
+        // ... and with GQA a chunk should not outlast the launch: the passes of a shared tile are separate chunks that
+        // hit L2, so with T tiles per resident slot in all, chunks longer than ~T leave a few workgroups running
+        // alone at the end (Llama-3 north-star tree: 2.8 tiles per slot, 8-tile chunks ran 18 us of a 25 us launch
+        // with a quarter of the slots occupied; 4-tile chunks: 19.9 us).  MHA, every tile from HBM, measured the
+        // other way (1-token branches, 2 tiles per slot: 8-tile chunks 19.1 us, 4-tile chunks 21.0).
+        if (G > 1) {
+            int64_t tiles_all = 0;
+            for_runs([&](int, int nt, int) { tiles_all += nt; });
+            int cmax = 1;
+            while (cmax < 8 && (int64_t)cmax * slots < tiles_all * Hkv) cmax <<= 1;
+            if (C > cmax) C = cmax;
+        }
         for (; C > 1; C >>= 1) {
             int64_t n = 0;
             for_runs([&](int, int nt, int uni) { n += uni ? 1 : (nt + C - 1) / C; });
@@ -697,7 +710,15 @@ __global__ __launch_bounds__(256) void flatten_units_kernel(const int64_t* block
             const int64_t a = block_q_offset[t], b = block_q_offset[t - 1];
             for (int i = 0; !open && i < cnt; ++i) open = block_q[a + i] != block_q[b + i];
         }
-        sOpen[t] = open ? 1 : 0;
+        // bit 1: the list also differs from the one TWO blocks back (a node with more than 32 queries is emitted by
+        // the reference as alternating blocks, queries 0..31 / 32.. of the same 128 slots, tree_cache.py:763-799)
+        bool open2 = (t < 2);
+        if (t >= 2) {
+            open2 = cnt != (int)block_q_cnts[t - 2];
+            const int64_t a = block_q_offset[t], b = block_q_offset[t - 2];
+            for (int i = 0; !open2 && i < cnt; ++i) open2 = block_q[a + i] != block_q[b + i];
+        }
+        sOpen[t] = (open ? 1 : 0) | (open2 ? 2 : 0);
         sPass[t] = (cnt * G + MQ - 1) / MQ;
     }
     __syncthreads();
@@ -706,9 +727,30 @@ __global__ __launch_bounds__(256) void flatten_units_kernel(const int64_t* block
         const int ucap = (UNION_CAP * G <= MQ) ? UNION_CAP : MQ / G;  // union queries whose virtual rows fit one pass
         for (int ta = 0; ta < NB;) {
             int tb = ta + 1;
-            while (tb < NB && !sOpen[tb]) ++tb;
+            while (tb < NB && !(sOpen[tb] & 1)) ++tb;
             const int passes = sPass[ta];
             const int cnt_a = sCnt[ta];
+            // ---- two query chunks of one node, alternating block by block: two interleaved runs -------------
+            if (tb - ta == 1 && ta + 3 < NB && !(sOpen[ta + 2] & 2) && !(sOpen[ta + 3] & 2)) {
+                int te = ta + 2;
+                while (te < NB && !(sOpen[te] & 2)) ++te;
+                for (int par = 0; par < 2; ++par) {
+                    const int pp = sPass[ta + par];
+                    for (int ps = 0; ps < pp; ++ps) {
+                        const int first = r;
+                        for (int t = ta + par; t < te && r < cap; t += 2, ++r) {
+                            ul.src[r] = t;
+                            ul.aux[r] = 0;
+                            ul.pass[r] = ps;
+                            ul.flags[r] = (first << 1) | ((t == ta + par) ? 1 : 0);
+                            ul.prow[r] = sOff[t];
+                        }
+                        if (r > first) run_push(rt, first, r - first, 0);
+                    }
+                }
+                ta = te;
+                continue;
+            }
             // taper: the workgroups dispatched last should be short, so that the launch ends together -- the last
             // `slots` leaf tiles (per head) stay single, the `2 slots` before them go in pairs
             int ulen = union_len;
@@ -783,7 +825,7 @@ __global__ __launch_bounds__(256) void flatten_units_kernel(const int64_t* block
         hdr[1] = 0;
         sched[0] = 0;
         for (int k = 0; k < NTICKET; ++k) sched[ticket_word(k)] = 0;
-        if (np) np_record_order(ul, r, Hkv, slots, chunk_c, hdr, rt);
+        if (np) np_record_order(ul, r, Hkv, G, slots, chunk_c, hdr, rt);
     }
 }
 
@@ -959,7 +1001,7 @@ __global__ __launch_bounds__(256) void node_units_kernel(const int64_t* node_kv_
         hdr[1] = 0;
         sched[0] = 0;
         for (int k = 0; k < NTICKET; ++k) sched[ticket_word(k)] = 0;
-        if (np) np_record_order(ul, r, Hkv, slots, chunk_c, hdr, rt);
+        if (np) np_record_order(ul, r, Hkv, G, slots, chunk_c, hdr, rt);
     }
 }
 
