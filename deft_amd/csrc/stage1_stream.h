@@ -710,15 +710,20 @@ __global__ __launch_bounds__(256) void flatten_units_kernel(const int64_t* block
             const int64_t a = block_q_offset[t], b = block_q_offset[t - 1];
             for (int i = 0; !open && i < cnt; ++i) open = block_q[a + i] != block_q[b + i];
         }
-        // bit 1: the list also differs from the one TWO blocks back (a node with more than 32 queries is emitted by
-        // the reference as alternating blocks, queries 0..31 / 32.. of the same 128 slots, tree_cache.py:763-799)
-        bool open2 = (t < 2);
-        if (t >= 2) {
-            open2 = cnt != (int)block_q_cnts[t - 2];
-            const int64_t a = block_q_offset[t], b = block_q_offset[t - 2];
-            for (int i = 0; !open2 && i < cnt; ++i) open2 = block_q[a + i] != block_q[b + i];
+        // bits 1..3: the list also differs from the one 2 / 3 / 4 blocks back (a node with more than 32 queries is
+        // emitted by the reference as alternating blocks -- queries 0..31 / 32..63 / ... of the same 128 slots,
+        // tree_cache.py:763-799 -- so its blocks repeat with period ceil(queries / 32))
+        int bits = open ? 1 : 0;
+        for (int pd = 2; pd <= 4; ++pd) {
+            bool od = (t < pd);
+            if (t >= pd) {
+                od = cnt != (int)block_q_cnts[t - pd];
+                const int64_t a = block_q_offset[t], b = block_q_offset[t - pd];
+                for (int i = 0; !od && i < cnt; ++i) od = block_q[a + i] != block_q[b + i];
+            }
+            bits |= od ? (1 << (pd - 1)) : 0;
         }
-        sOpen[t] = (open ? 1 : 0) | (open2 ? 2 : 0);
+        sOpen[t] = bits;
         sPass[t] = (cnt * G + MQ - 1) / MQ;
     }
     __syncthreads();
@@ -730,26 +735,34 @@ __global__ __launch_bounds__(256) void flatten_units_kernel(const int64_t* block
             while (tb < NB && !(sOpen[tb] & 1)) ++tb;
             const int passes = sPass[ta];
             const int cnt_a = sCnt[ta];
-            // ---- two query chunks of one node, alternating block by block: two interleaved runs -------------
-            if (tb - ta == 1 && ta + 3 < NB && !(sOpen[ta + 2] & 2) && !(sOpen[ta + 3] & 2)) {
-                int te = ta + 2;
-                while (te < NB && !(sOpen[te] & 2)) ++te;
-                for (int par = 0; par < 2; ++par) {
-                    const int pp = sPass[ta + par];
-                    for (int ps = 0; ps < pp; ++ps) {
-                        const int first = r;
-                        for (int t = ta + par; t < te && r < cap; t += 2, ++r) {
-                            ul.src[r] = t;
-                            ul.aux[r] = 0;
-                            ul.pass[r] = ps;
-                            ul.flags[r] = (first << 1) | ((t == ta + par) ? 1 : 0);
-                            ul.prow[r] = sOff[t];
-                        }
-                        if (r > first) run_push(rt, first, r - first, 0);
-                    }
+            // ---- P query chunks of one node, alternating block by block: P interleaved runs ------------------
+            if (tb - ta == 1) {
+                int P = 0;
+                for (int pd = 2; pd <= 4 && !P; ++pd) {
+                    bool rep = ta + 2 * pd <= NB;
+                    for (int t = ta + pd; rep && t < ta + 2 * pd; ++t) rep = !(sOpen[t] & (1 << (pd - 1)));
+                    if (rep) P = pd;
                 }
-                ta = te;
-                continue;
+                if (P) {
+                    int te = ta + P;
+                    while (te < NB && !(sOpen[te] & (1 << (P - 1)))) ++te;
+                    for (int par = 0; par < P; ++par) {
+                        const int pp = sPass[ta + par];
+                        for (int ps = 0; ps < pp; ++ps) {
+                            const int first = r;
+                            for (int t = ta + par; t < te && r < cap; t += P, ++r) {
+                                ul.src[r] = t;
+                                ul.aux[r] = 0;
+                                ul.pass[r] = ps;
+                                ul.flags[r] = (first << 1) | ((t == ta + par) ? 1 : 0);
+                                ul.prow[r] = sOff[t];
+                            }
+                            if (r > first) run_push(rt, first, r - first, 0);
+                        }
+                    }
+                    ta = te;
+                    continue;
+                }
             }
             // taper: the workgroups dispatched last should be short, so that the launch ends together -- the last
             // `slots` leaf tiles (per head) stay single, the `2 slots` before them go in pairs

@@ -567,3 +567,45 @@ def test_many_partial_rows_take_several_merge_passes(mode, shape):
         s = torch.einsum("hd,hsd->hs", q[r].double(), k) / D ** 0.5
         ref = torch.einsum("hs,hsd->hd", torch.softmax(s, dim=-1), v)
         assert (o[r].double() - ref).abs().max().item() < TOL_EXACT
+
+
+@pytest.mark.parametrize("mode", ["flatten", "node"])
+@pytest.mark.parametrize("shape", [(4, 4, 70), (8, 2, 100), (4, 4, 33)])
+def test_nodes_with_more_than_32_queries_fold_as_interleaved_runs(mode, shape):
+    """A node shared by 33 / 70 / 100 leaves is cut by the reference's builder into alternating blocks of at most 32
+    queries (period 2, 3, 4): the plan folds each query chunk's blocks as one run.  Against fp64 attention per leaf."""
+    from deft_amd.memory_pool import ReqToTokenPool, TokenToKVPool
+    from deft_amd.tree_cache import TreeCache
+
+    Hq, Hkv, width = shape
+    D, prefix = 128, 1500
+    size = prefix + 4 * width + 256
+    req = ReqToTokenPool(width + 8, size + 8, device="cuda")
+    pool = TokenToKVPool(size, torch.float16, Hkv, D, 1, device="cuda")
+    tree = TreeCache(torch.float16, Hkv, D, 1, req, pool, None, True, False)
+    tree.init_prompt(torch.arange(1, prefix + 1, dtype=torch.int32))
+    tree.branch(tree.root, width)
+    for _ in range(3):
+        for leaf in list(tree.leaves.values()):
+            leaf.append_token(7)
+        tree.alloc()
+    md = deft_amd.TreeMetadata.from_tree_cache(tree)
+    g = torch.Generator(device="cuda").manual_seed(9)
+    pool._storage.normal_(generator=g)
+    q = torch.randn((width, Hq, D), dtype=torch.float16, device="cuda", generator=g)
+    kb, vb = pool.get_key_buffer(0), pool.get_value_buffer(0)
+    o = torch.full_like(q, float("nan"))
+    if mode == "flatten":
+        deft_amd.tree_attention_subtree_fwd(q, kb, vb, o, *_flatten_args(md))
+    else:
+        deft_amd.tree_attention_fwd(q, kb, vb, o, md.node_kv, md.node_kv_offset, md.node_kv_len, md.node_q,
+                                    md.node_q_offset, md.node_q_len)
+    torch.cuda.synchronize()
+    leaves = sorted(tree.leaves.values(), key=lambda n: n.id)
+    for r in range(width):
+        slots = torch.tensor(tree.leaf_path_slots(leaves[r]), device="cuda")
+        k = kb[slots].double().repeat_interleave(Hq // Hkv, dim=1).transpose(0, 1)
+        v = vb[slots].double().repeat_interleave(Hq // Hkv, dim=1).transpose(0, 1)
+        s = torch.einsum("hd,hsd->hs", q[r].double(), k) / D ** 0.5
+        ref = torch.einsum("hs,hsd->hd", torch.softmax(s, dim=-1), v)
+        assert (o[r].double() - ref).abs().max().item() < TOL_EXACT, r

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised replays: random tree templates (widths, node lengths, prompt length), geometries and modes; at every
 step the attention output of layer 0 is compared with fp64 per-leaf attention over the leaf's page-table row,
-computed with torch on the GPU.  tools/fuzz_replay.py [seconds] [seed]"""
+computed with torch on the GPU.  tools/fuzz_replay.py [seconds] [seed] [max replays]"""
 import os, sys, time, random
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
@@ -10,9 +10,10 @@ from deft_amd import replay as rp
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 t_end = time.time() + budget
+max_runs = int(sys.argv[3]) if len(sys.argv) > 3 else 10 ** 9
 runs = steps = 0
 worst = 0.0
-while time.time() < t_end:
+while time.time() < t_end and runs < max_runs:
     Hq, Hkv = rng.choice([(32, 32), (32, 8), (8, 2), (4, 4), (16, 1)])
     D = 64 if Hq <= 8 and rng.random() < 0.3 else 128
     mode = rng.choice(["flatten", "flatten", "node", "seq"])
@@ -29,6 +30,10 @@ while time.time() < t_end:
         tpl = rp.synthetic_speculative_template(rng.choice([4, 16, 64]), rng.randint(3, 8), (1, rng.randint(1, 4)), rng.randint(0, 999))
         gen = 100
     prompt = rng.choice([1, 5, 127, 128, 129, 300, 1000, 4096, 4096, 20000, 70000] if Hq <= 8 else [1, 5, 127, 128, 129, 300, 1000, 4096])
+    if prompt >= 20000:
+        gen = min(gen, 30)  # the fp64 check walks every leaf's whole path at every step
+    if os.environ.get("FUZZ_VERBOSE"):
+        print(runs, Hq, Hkv, D, mode, task, prompt, gen, flush=True)
     r = rp.TemplateReplay(Hq, Hkv, D, layers=1, mode=mode, device="cuda", attention=True, seed=rng.randint(0, 10 ** 6))
     holder = {}
     real = rp.TreeCache
