@@ -715,8 +715,8 @@ __global__ __launch_bounds__(256) void flatten_units_kernel(const int64_t* block
         // tree_cache.py:763-799 -- so its blocks repeat with period ceil(queries / 32))
         int bits = open ? 1 : 0;
         for (int pd = 2; pd <= 4; ++pd) {
-            bool od = (t < pd);
-            if (t >= pd) {
+            bool od = (t < pd) || !open;  // inside an ordinary run the longer periods are never looked at
+            if (!od) {
                 od = cnt != (int)block_q_cnts[t - pd];
                 const int64_t a = block_q_offset[t], b = block_q_offset[t - pd];
                 for (int i = 0; !od && i < cnt; ++i) od = block_q[a + i] != block_q[b + i];
@@ -736,7 +736,7 @@ __global__ __launch_bounds__(256) void flatten_units_kernel(const int64_t* block
             const int passes = sPass[ta];
             const int cnt_a = sCnt[ta];
             // ---- P query chunks of one node, alternating block by block: P interleaved runs ------------------
-            if (tb - ta == 1) {
+            if (tb - ta == 1 && cnt_a == MQ) {  // (the first chunk of such a node is always full: cheap filter)
                 int P = 0;
                 for (int pd = 2; pd <= 4 && !P; ++pd) {
                     bool rep = ta + 2 * pd <= NB;
