@@ -24,7 +24,7 @@ while time.time() < t_end and runs < max_runs:
                                               lens=[rng.choice([1, 2, 3, 7, 40, 130, 200]) for _ in range(depth)])
         gen = 600
     elif task == "few_shot":
-        tpl = rp.synthetic_few_shot_template(rng.choice([1, 2, 5, 33, 40, 64]))
+        tpl = rp.synthetic_few_shot_template(rng.choice([1, 2, 5, 33, 40, 64, 70, 100]))
         gen = rng.choice([3, 10, 140])
     else:
         tpl = rp.synthetic_speculative_template(rng.choice([4, 16, 64]), rng.randint(3, 8), (1, rng.randint(1, 4)), rng.randint(0, 999))
