@@ -648,15 +648,26 @@ static int launch_plan(const Stage1Params& p, int NB, const PlanView& pv, const 
         }
         attr_set = true;
     }
-    // block tables + a run table for the tile-parallel record order (as many runs as fit; beyond that the kernel scans)
-    int64_t run_cap = pv.cap;
-    while (sizeof(int) * (4 * (size_t)NB + 3 * (size_t)run_cap) > (NB > 2048 ? UNIT_LDS : 60 * 1024) && run_cap > 0) run_cap /= 2;
-    const size_t lds = sizeof(int) * (4 * (size_t)NB + 3 * (size_t)run_cap);
-    const UnitList ul = unit_list(pv);
+    // block tables (+ the small blocks' query lists for the union groups of the tile-parallel order, when they fit) and
+    // a run table.  With an entry for every possible run (5 words each) the kernel writes units and record order with
+    // all its waves; otherwise one lane emits them and the table holds as many runs as fit (beyond that it scans).
     const int np = stage1_kind();
-    hipLaunchKernelGGL(flatten_units_kernel, dim3(1), dim3(256), lds, stream, p.block_q, p.block_q_cnts, p.block_q_offset, NB,
+    const int qtab = np && sizeof(int) * 8 * (size_t)NB <= 100 * 1024;
+    const size_t blk = (qtab ? 8 : 4) * (size_t)NB;
+    int64_t run_cap = pv.cap;
+    int par = !getenv("DEFT_PLAN_SERIAL");
+    if (par && sizeof(int) * (blk + 5 * (size_t)run_cap + 8) > UNIT_LDS) {  // as many runs as fit (the kernel falls back if more turn up)
+        run_cap = ((int64_t)(UNIT_LDS / sizeof(int)) - (int64_t)blk - 8) / 5;
+        if (run_cap < 256) par = 0, run_cap = pv.cap;
+    }
+    if (par && getenv("DEFT_PLAN_RUNCAP")) run_cap = std::max(1, std::min((int)run_cap, atoi(getenv("DEFT_PLAN_RUNCAP"))));  // tests: force the fallback
+    if (!par)
+        while (sizeof(int) * (blk + 3 * (size_t)run_cap + 8) > UNIT_LDS && run_cap > 0) run_cap /= 2;
+    const size_t lds = sizeof(int) * (blk + (par ? 5 : 3) * (size_t)run_cap + 8);
+    const UnitList ul = unit_list(pv);
+    hipLaunchKernelGGL(flatten_units_kernel, dim3(1), dim3(1024), lds, stream, p.block_q, p.block_q_cnts, p.block_q_offset, NB,
                        p.G, (int)pv.cap, ul, pv.hdr, pv.sched, np, p.Hkv, 2 * num_cus(), np_chunk_env(), np ? np_union_env() : 1,
-                       getenv("DEFT_NP_TAPER") ? atoi(getenv("DEFT_NP_TAPER")) : 0, (int)run_cap);
+                       getenv("DEFT_NP_TAPER") ? atoi(getenv("DEFT_NP_TAPER")) : 0, (int)run_cap, qtab, par);
     int rc = check_launch("flatten units launch");
     if (rc) return rc;
     hipLaunchKernelGGL(flatten_records_kernel, dim3((unsigned)(pv.cap + 1)), dim3(128), 0, stream, p.block_q, p.block_q_cnts,
@@ -847,7 +858,9 @@ int deft_stage1_kind(void) { return stage1_kind(); }
 // Python's os.environ.get several us per lookup).
 int deft_plan_variant(void) {
     const char* t = getenv("DEFT_NP_TAPER");
-    return stage1_kind() | ((np_chunk_env() & 0xff) << 4) | ((np_union_env() & 0xff) << 12) | ((t ? atoi(t) & 0xf : 0) << 20);
+    const char* rc = getenv("DEFT_PLAN_RUNCAP");  // (the two below change how the plan is built, not the plan: tests compare them)
+    return stage1_kind() | ((np_chunk_env() & 0xff) << 4) | ((np_union_env() & 0xff) << 12) | ((t ? atoi(t) & 0xf : 0) << 20) |
+           ((getenv("DEFT_PLAN_SERIAL") ? 1 : 0) << 24) | ((rc ? atoi(rc) & 0x3f : 0) << 25);
 }
 
 // Internal profiling hook (not part of the public header): device buffer of

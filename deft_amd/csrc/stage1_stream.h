@@ -690,49 +690,127 @@ __device__ inline void np_record_order(const UnitList& ul, int R, int Hkv, int G
 // tail shares a block with the next branch's head, so their lists go {a}, {a,b}, {b}, {b,c} ... -- are grouped, up
 // to union_len tiles and UNION_CAP queries, into ONE run over the union of their queries (per-slot masks keep a
 // query away from keys that are not on its path), so that one workgroup folds them and writes one partial per query.
-__global__ __launch_bounds__(256) void flatten_units_kernel(const int64_t* block_q, const int64_t* block_q_cnts,
+__global__ __launch_bounds__(1024) void flatten_units_kernel(const int64_t* block_q, const int64_t* block_q_cnts,
                                                             const int64_t* block_q_offset, int NB, int G, int cap,
                                                             UnitList ul, int32_t* hdr, int32_t* sched, int np, int Hkv,
-                                                            int slots, int chunk_c, int union_len, int taper, int run_cap) {
+                                                            int slots, int chunk_c, int union_len, int taper, int run_cap,
+                                                            int qtab, int par) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int* sOpen = reinterpret_cast<int*>(smem);  // [NB]
     int* sPass = sOpen + NB;                    // [NB]
     int* sCnt = sPass + NB;                     // [NB] block_q_cnts
     int* sOff = sCnt + NB;                      // [NB] block_q_offset
-    RunTable rt{sOff + NB, sOff + NB + run_cap, sOff + NB + 2 * run_cap, 0, run_cap};
+    // [NB][UNION_CAP] query lists of the blocks small enough to join a union group (qtab: the table fits in LDS):
+    // the one-thread phase below otherwise waits for a global load per leaf tile
+    int* sQ = sOff + NB;
+    int* sRun = sQ + (qtab ? UNION_CAP * NB : 0);
+    RunTable rt{sRun, sRun + run_cap, sRun + 2 * run_cap, 0, run_cap};
     for (int t = threadIdx.x; t < NB; t += blockDim.x) {
         const int cnt = (int)block_q_cnts[t];
         sCnt[t] = cnt;
         sOff[t] = (int)block_q_offset[t];
-        bool open = (t == 0);
-        if (t > 0) {
-            open = cnt != (int)block_q_cnts[t - 1];
-            const int64_t a = block_q_offset[t], b = block_q_offset[t - 1];
-            for (int i = 0; !open && i < cnt; ++i) open = block_q[a + i] != block_q[b + i];
-        }
-        // bits 1..3: the list also differs from the one 2 / 3 / 4 blocks back (a node with more than 32 queries is
-        // emitted by the reference as alternating blocks -- queries 0..31 / 32..63 / ... of the same 128 slots,
-        // tree_cache.py:763-799 -- so its blocks repeat with period ceil(queries / 32))
-        int bits = open ? 1 : 0;
-        for (int pd = 2; pd <= 4; ++pd) {
-            bool od = (t < pd) || !open;  // inside an ordinary run the longer periods are never looked at
-            if (!od) {
-                od = cnt != (int)block_q_cnts[t - pd];
-                const int64_t a = block_q_offset[t], b = block_q_offset[t - pd];
-                for (int i = 0; !od && i < cnt; ++i) od = block_q[a + i] != block_q[b + i];
-            }
-            bits |= od ? (1 << (pd - 1)) : 0;
-        }
-        sOpen[t] = bits;
         sPass[t] = (cnt * G + MQ - 1) / MQ;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    // Does block t's query list differ from the one 1 / 2 / 3 / 4 blocks back?  Half a wave per block, lane i on
+    // list entry i (and i + 32, ... for longer lists), the five loads of an entry independent of each other: one
+    // round trip per block instead of one per list entry (a shared-prefix block has 32 entries, and a thread walking
+    // them with early exit waited ~1 us for each).
+    //   bit 0: opens a run;  bits 1..3: the list also differs from the one 2 / 3 / 4 blocks back (a node with more
+    //   than 32 queries is emitted by the reference as alternating blocks -- queries 0..31 / 32..63 / ... of the same
+    //   128 slots, tree_cache.py:763-799 -- so its blocks repeat with period ceil(queries / 32)); inside an ordinary
+    //   run the longer periods are never looked at and read as "differs".
+    {
+        const int lane = threadIdx.x & 63, half = lane >> 5, li = lane & 31;
+        const int nhw = (blockDim.x >> 6) * 2;
+        for (int t0 = (threadIdx.x >> 6) * 2; t0 < NB; t0 += nhw) {
+            const int t = t0 + half;
+            const bool live = t < NB;
+            const int cnt = live ? sCnt[t] : 0;
+            const int a = live ? sOff[t] : 0;
+            int diff = 0;  // bit pd-1: some entry of this lane differs from the block pd back
+            bool same_cnt[4];
+            for (int pd = 1; pd <= 4; ++pd) same_cnt[pd - 1] = live && t >= pd && sCnt[t - pd] == cnt;
+            for (int i = li; i < cnt; i += 32) {
+                const int64_t mine = block_q[a + i];
+                int64_t other[4];
+                for (int pd = 1; pd <= 4; ++pd) other[pd - 1] = same_cnt[pd - 1] ? block_q[sOff[t - pd] + i] : mine;
+                for (int pd = 1; pd <= 4; ++pd) diff |= (other[pd - 1] != mine) ? (1 << (pd - 1)) : 0;
+                if (qtab && cnt <= UNION_CAP) sQ[t * UNION_CAP + i] = (int)mine;
+            }
+            int bits = 0;
+            for (int pd = 1; pd <= 4; ++pd) {
+                const unsigned long long b = __ballot((diff >> (pd - 1)) & 1);
+                const bool any = ((half ? (b >> 32) : b) & 0xffffffffull) != 0;
+                bits |= (!same_cnt[pd - 1] || any) ? (1 << (pd - 1)) : 0;
+            }
+            if (!(bits & 1)) bits = 0xe;  // not opening a run: longer periods read as "differs"
+            if (live && li == 0) sOpen[t] = bits;
+        }
+    }
+    __syncthreads();
+    // Phase 2: wave 0 walks the blocks and decides the runs (every lane takes the same decisions; the lanes only split
+    // the searches for the next run boundary).  `par`: every run gets an entry of the LDS table, and the units and the
+    // record order are then written by all waves (phases 3 and 4) -- one thread emitting them costs ~0.4 us per unit
+    // and pass, 75 us per decode step for the north-star tree and 2 ms for a 100k-token prefix under 48 branches.
+    // Otherwise (tables beyond the LDS) lane 0 emits as it walks.
+    int* sMeta = sRun + (par ? 5 : 3) * run_cap;  // [8]: units, runs, chunk length, leaders, "written by all waves"
+    int* rT0 = sRun + 3 * run_cap;    // par: first block of the run;      later: the run's first leader record
+    int* rSp = sRun + 4 * run_cap;    // par: block stride | pass << 8;   later: the run's first follower record - leaders
+    const int lane = threadIdx.x & 63;
+    const int par_req = par;
+    if (threadIdx.x < 64) {
+      // (a second walk, lane 0 emitting, if the runs did not fit the table: trees with very many small runs)
+      for (int attempt = 0; attempt < 2; ++attempt) {
+        par = par_req && attempt == 0;
+        rt.n = 0;
         int r = 0, ng = 0;
         const int ucap = (UNION_CAP * G <= MQ) ? UNION_CAP : MQ / G;  // union queries whose virtual rows fit one pass
+        // first block >= from whose sOpen has a bit of `mask` set (NB if none)
+        auto find = [&](int from, int mask) {
+            for (int base = from; base < NB; base += 64) {
+                const int t = base + lane;
+                const unsigned long long b = __ballot(t < NB && (sOpen[t] & mask));
+                if (b) return base + __ffsll((long long)b) - 1;
+            }
+            return NB;
+        };
+        // units of one run: blocks t0, t0 + st, ... < te, pass ps, aux (0, or union group + 1)
+        auto emit_run = [&](int t0, int te, int st, int aux, int ps) {
+            int n = (te - t0 + st - 1) / st;
+            if (n > cap - r) n = cap - r;
+            if (n <= 0) return;
+            const int first = r;
+            if (par) {
+                if (lane == 0 && rt.n < rt.cap) {
+                    rt.r0[rt.n] = first;
+                    rt.nt[rt.n] = n;
+                    rt.uni[rt.n] = aux;
+                    rT0[rt.n] = t0;
+                    rSp[rt.n] = st | (ps << 8);
+                }
+                ++rt.n;
+            } else {
+                if (lane == 0)
+                    for (int j = 0; j < n; ++j) {
+                        const int t = t0 + j * st;
+                        ul.src[first + j] = t;
+                        ul.aux[first + j] = aux;
+                        ul.pass[first + j] = ps;
+                        ul.flags[first + j] = (first << 1) | (j == 0 ? 1 : 0);
+                        ul.prow[first + j] = sOff[t];
+                    }
+                if (rt.n < rt.cap && lane == 0) {
+                    rt.r0[rt.n] = first;
+                    rt.nt[rt.n] = n;
+                    rt.uni[rt.n] = aux;
+                }
+                ++rt.n;
+            }
+            r += n;
+        };
         for (int ta = 0; ta < NB;) {
-            int tb = ta + 1;
-            while (tb < NB && !(sOpen[tb] & 1)) ++tb;
+            const int tb = find(ta + 1, 1);
             const int passes = sPass[ta];
             const int cnt_a = sCnt[ta];
             // ---- P query chunks of one node, alternating block by block: P interleaved runs ------------------
@@ -744,21 +822,10 @@ __global__ __launch_bounds__(256) void flatten_units_kernel(const int64_t* block
                     if (rep) P = pd;
                 }
                 if (P) {
-                    int te = ta + P;
-                    while (te < NB && !(sOpen[te] & (1 << (P - 1)))) ++te;
-                    for (int par = 0; par < P; ++par) {
-                        const int pp = sPass[ta + par];
-                        for (int ps = 0; ps < pp; ++ps) {
-                            const int first = r;
-                            for (int t = ta + par; t < te && r < cap; t += P, ++r) {
-                                ul.src[r] = t;
-                                ul.aux[r] = 0;
-                                ul.pass[r] = ps;
-                                ul.flags[r] = (first << 1) | ((t == ta + par) ? 1 : 0);
-                                ul.prow[r] = sOff[t];
-                            }
-                            if (r > first) run_push(rt, first, r - first, 0);
-                        }
+                    const int te = find(ta + P, 1 << (P - 1));
+                    for (int par_ = 0; par_ < P; ++par_) {
+                        const int pp = sPass[ta + par_];
+                        for (int ps = 0; ps < pp; ++ps) emit_run(ta + par_, te, P, 0, ps);
                     }
                     ta = te;
                     continue;
@@ -775,70 +842,177 @@ __global__ __launch_bounds__(256) void flatten_units_kernel(const int64_t* block
             }
             if (np && ulen > 1 && ucap >= 2 && cnt_a <= ucap && tb - ta < ulen && r < cap) {  // (np: tile-parallel order)
                 // ---- union group starting at ta ----------------------------------------------------
-                int uq[UNION_CAP], urow[UNION_CAP], un = 0;
+                // (the union and a block's list live in registers, every loop below is unrolled over UNION_CAP: a list
+                //  read entry by entry from LDS cost ~0.6 us per leaf tile)
+                static_assert(UNION_CAP == 4, "the query table is read as int4");
+                int uq[UNION_CAP] = {0, 0, 0, 0}, urow[UNION_CAP] = {0, 0, 0, 0}, un = 0;
                 int te = ta;
                 while (te < NB && te - ta < ulen && r + (te - ta) < cap) {
                     const int cnt = sCnt[te];
                     if (cnt > ucap) break;
-                    const int64_t off = sOff[te];
+                    const int off = sOff[te];
+                    int qv[UNION_CAP];
+                    if (qtab) {
+                        const int4 v = *reinterpret_cast<const int4*>(sQ + te * UNION_CAP);
+                        qv[0] = v.x, qv[1] = v.y, qv[2] = v.z, qv[3] = v.w;
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < UNION_CAP; ++i) qv[i] = i < cnt ? (int)block_q[off + i] : 0;
+                    }
                     int add = 0;  // queries of block te that are new to the union
-                    for (int i = 0; i < cnt; ++i) {
-                        const int qv = (int)block_q[off + i];
+#pragma unroll
+                    for (int i = 0; i < UNION_CAP; ++i) {
                         bool found = false;
-                        for (int j = 0; j < un; ++j) found |= (uq[j] == qv);
-                        add += found ? 0 : 1;
+#pragma unroll
+                        for (int j = 0; j < UNION_CAP; ++j) found |= (j < un) & (uq[j] == qv[i]);
+                        add += (i < cnt && !found) ? 1 : 0;
                     }
                     if (un + add > ucap) break;
-                    for (int i = 0; i < cnt; ++i) {
-                        const int qv = (int)block_q[off + i];
-                        bool found = false;
-                        for (int j = 0; j < un; ++j) found |= (uq[j] == qv);
+#pragma unroll
+                    for (int i = 0; i < UNION_CAP; ++i) {
+                        bool found = i >= cnt;
+#pragma unroll
+                        for (int j = 0; j < UNION_CAP; ++j) found |= (j < un) & (uq[j] == qv[i]);
                         if (!found) {  // first occurrence: this tile's row carries the query's partial
-                            uq[un] = qv;
-                            urow[un] = (int)off + i;
+#pragma unroll
+                            for (int j = 0; j < UNION_CAP; ++j)
+                                if (j == un) {
+                                    uq[j] = qv[i];
+                                    urow[j] = off + i;
+                                }
                             ++un;
                         }
                     }
                     ++te;
                 }
                 if (te - ta >= 2) {
-                    ul.gn[ng] = un;
-                    for (int j = 0; j < UNION_CAP; ++j) {
-                        ul.gq[j * cap + ng] = j < un ? uq[j] : 0;
-                        ul.grow[j * cap + ng] = j < un ? urow[j] : 0;
+                    if (lane == 0) {
+                        ul.gn[ng] = un;
+                        for (int j = 0; j < UNION_CAP; ++j) {
+                            ul.gq[j * cap + ng] = j < un ? uq[j] : 0;
+                            ul.grow[j * cap + ng] = j < un ? urow[j] : 0;
+                        }
                     }
-                    const int first = r;
-                    for (int t = ta; t < te; ++t, ++r) {
-                        ul.src[r] = t;
-                        ul.aux[r] = ng + 1;
-                        ul.pass[r] = 0;
-                        ul.flags[r] = (first << 1) | ((t == ta) ? 1 : 0);
-                        ul.prow[r] = sOff[t];
-                    }
-                    run_push(rt, first, te - ta, 1);
+                    emit_run(ta, te, 1, ng + 1, 0);
                     ++ng;
                     ta = te;
                     continue;
                 }
             }
-            for (int ps = 0; ps < passes; ++ps) {
-                const int first = r;
-                for (int t = ta; t < tb && r < cap; ++t, ++r) {
-                    ul.src[r] = t;
-                    ul.aux[r] = 0;
-                    ul.pass[r] = ps;
-                    ul.flags[r] = (first << 1) | ((t == ta) ? 1 : 0);
-                    ul.prow[r] = sOff[t];
-                }
-                if (r > first) run_push(rt, first, r - first, 0);
-            }
+            for (int ps = 0; ps < passes; ++ps) emit_run(ta, tb, 1, 0, ps);
             ta = tb;
         }
-        hdr[0] = r;
-        hdr[1] = 0;
-        sched[0] = 0;
-        for (int k = 0; k < NTICKET; ++k) sched[ticket_word(k)] = 0;
-        if (np) np_record_order(ul, r, Hkv, G, slots, chunk_c, hdr, rt);
+        if (lane == 0) {
+            hdr[0] = r;
+            hdr[1] = 0;
+            sched[0] = 0;
+            for (int k = 0; k < NTICKET; ++k) sched[ticket_word(k)] = 0;
+            if (par && rt.n <= rt.cap) {
+                sMeta[0] = r;
+                sMeta[1] = rt.n;
+                sMeta[4] = 1;
+            } else if (!par) {
+                sMeta[4] = 0;
+                if (np) np_record_order(ul, r, Hkv, G, slots, chunk_c, hdr, rt);
+            }
+        }
+        if (!par || rt.n <= rt.cap) break;
+      }
+    }
+    __syncthreads();
+    if (!sMeta[4]) return;
+    // Phase 3: the units of run k, one wave per run, one lane per unit.
+    const int NR = sMeta[1];
+    const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    for (int k = wave; k < NR; k += nwaves) {
+        const int first = rt.r0[k], n = rt.nt[k], aux = rt.uni[k], t0 = rT0[k], st = rSp[k] & 0xff, ps = rSp[k] >> 8;
+        for (int j = lane; j < n; j += 64) {
+            const int t = t0 + j * st;
+            ul.src[first + j] = t;
+            ul.aux[first + j] = aux;
+            ul.pass[first + j] = ps;
+            ul.flags[first + j] = (first << 1) | (j == 0 ? 1 : 0);
+            ul.prow[first + j] = sOff[t];
+        }
+    }
+    if (!np) return;
+    __syncthreads();  // (rT0 / rSp are reused below)
+    // Phase 4: record order of the tile-parallel stage 1 (the rules of np_record_order above, same result).
+    // Wave 0: chunk length C from sums / maxima over the runs, then each run's first leader and first follower record
+    // by prefix sums over the runs' chunk counts.
+    if (threadIdx.x < 64) {
+        auto wave_sum = [&](auto&& f) {
+            int acc = 0;
+            for (int k = lane; k < NR; k += 64) acc += f(rt.nt[k], rt.uni[k]);
+            for (int m = 32; m > 0; m >>= 1) acc += __shfl_xor(acc, m, 64);
+            return acc;
+        };
+        int C = chunk_c;
+        if (C <= 0) {
+            int lmax = 0;
+            for (int k = lane; k < NR; k += 64)
+                if (!rt.uni[k] && rt.nt[k] > lmax) lmax = rt.nt[k];
+            for (int m = 32; m > 0; m >>= 1) lmax = max(lmax, __shfl_xor(lmax, m, 64));
+            C = lmax >= 32 ? 8 : (lmax >= 8 ? 4 : (lmax >= 4 ? 2 : 1));
+            if (G > 1) {
+                const int64_t tiles_all = wave_sum([](int nt, int) { return nt; });
+                int cmax = 1;
+                while (cmax < 8 && (int64_t)cmax * slots < tiles_all * Hkv) cmax <<= 1;
+                if (C > cmax) C = cmax;
+            }
+            for (; C > 1; C >>= 1) {
+                const int64_t n = wave_sum([C](int nt, int uni) { return uni ? 1 : (nt + C - 1) / C; });
+                if (10 * n * Hkv >= 3LL * slots) break;
+            }
+        }
+        int lead = 0, foll = 0;
+        for (int base = 0; base < NR; base += 64) {
+            const int k = base + lane;
+            const int nt = k < NR ? rt.nt[k] : 0;
+            const int S = k < NR ? (rt.uni[k] ? 1 : (nt + C - 1) / C) : 0;
+            int a = S, b = nt - S;  // inclusive scans over the lanes
+            for (int d = 1; d < 64; d <<= 1) {
+                const int ua = __shfl_up(a, d, 64), ub = __shfl_up(b, d, 64);
+                if (lane >= d) {
+                    a += ua;
+                    b += ub;
+                }
+            }
+            if (k < NR) {
+                rT0[k] = lead + a - S;
+                rSp[k] = foll + b - (nt - S);
+            }
+            lead += __shfl(a, 63, 64);
+            foll += __shfl(b, 63, 64);
+        }
+        if (lane == 0) {
+            sMeta[2] = C;
+            sMeta[3] = lead;
+            hdr[1] = lead;
+        }
+    }
+    __syncthreads();
+    {
+        const int C = sMeta[2], NL = sMeta[3];
+        for (int k = wave; k < NR; k += nwaves) {
+            const int first = rt.r0[k], nt = rt.nt[k];
+            const int S = rt.uni[k] ? 1 : (nt + C - 1) / C;  // a union group is one chunk
+            const int li = rT0[k], fi = NL + rSp[k];
+            const int q = nt / S, rem = nt - q * S;  // chunk p folds units p, p + S, ...: q + 1 of them for p < rem, else q
+            for (int u = lane; u < nt; u += 64) {
+                const int j = u / S, pc = u - j * S;
+                const int fb = fi + pc * (q - 1) + min(pc, rem);  // followers of the chunks before pc
+                if (j == 0) {
+                    ul.perm[li + pc] = first + pc;
+                    ul.ch_n[li + pc] = q + (pc < rem ? 1 : 0);
+                    ul.ch_fb[li + pc] = fb;
+                } else {
+                    ul.perm[fb + j - 1] = first + u;
+                    ul.ch_n[fb + j - 1] = 0;
+                    ul.ch_fb[fb + j - 1] = 0;
+                }
+            }
+        }
     }
 }
 
