@@ -684,6 +684,59 @@ __device__ inline void np_record_order(const UnitList& ul, int R, int Hkv, int G
     hdr[1] = NL;
 }
 
+// Union group of leaf tiles starting at block t (Flatten, tile-parallel order): up to `ulen` consecutive blocks whose
+// query lists hold at most `ucap` queries each and at most `ucap` distinct queries together.  Returns the number of
+// blocks taken; uq / urow / un = the union's queries in order of first occurrence and the partial row (block_q
+// position) of each first occurrence.  sQ: the [NB][UNION_CAP] LDS table of the small blocks' lists, or nullptr
+// (lists read from block_q).  Everything lives in registers, every loop is unrolled over UNION_CAP.
+__device__ inline int union_group(int t, int NB, int ulen, int ucap, const int* sCnt, const int* sOff, const int* sQ,
+                                  const int64_t* block_q, int (&uq)[UNION_CAP], int (&urow)[UNION_CAP], int& un) {
+    static_assert(UNION_CAP == 4, "the query table is read as int4");
+    un = 0;
+#pragma unroll
+    for (int j = 0; j < UNION_CAP; ++j) uq[j] = 0, urow[j] = 0;
+    int te = t;
+    while (te < NB && te - t < ulen) {
+        const int cnt = sCnt[te];
+        if (cnt > ucap) break;
+        const int off = sOff[te];
+        int qv[UNION_CAP];
+        if (sQ) {
+            const int4 v = *reinterpret_cast<const int4*>(sQ + te * UNION_CAP);
+            qv[0] = v.x, qv[1] = v.y, qv[2] = v.z, qv[3] = v.w;
+        } else {
+#pragma unroll
+            for (int i = 0; i < UNION_CAP; ++i) qv[i] = i < cnt ? (int)block_q[off + i] : 0;
+        }
+        int add = 0;  // queries of block te that are new to the union
+#pragma unroll
+        for (int i = 0; i < UNION_CAP; ++i) {
+            bool found = false;
+#pragma unroll
+            for (int j = 0; j < UNION_CAP; ++j) found |= (j < un) & (uq[j] == qv[i]);
+            add += (i < cnt && !found) ? 1 : 0;
+        }
+        if (un + add > ucap) break;
+#pragma unroll
+        for (int i = 0; i < UNION_CAP; ++i) {
+            bool found = i >= cnt;
+#pragma unroll
+            for (int j = 0; j < UNION_CAP; ++j) found |= (j < un) & (uq[j] == qv[i]);
+            if (!found) {  // first occurrence: this tile's row carries the query's partial
+#pragma unroll
+                for (int j = 0; j < UNION_CAP; ++j)
+                    if (j == un) {
+                        uq[j] = qv[i];
+                        urow[j] = off + i;
+                    }
+                ++un;
+            }
+        }
+        ++te;
+    }
+    return te - t;
+}
+
 // Flatten: one workgroup.  Phase 1 (parallel over blocks): does block t open a run, how many passes.
 // Phase 2 (one thread): emit units run by run, pass-major inside a run so that consecutive units fold.
 // Tile-parallel order only (union_len > 1): short runs of leaf tiles with small, different query lists -- a branch's
@@ -749,6 +802,37 @@ __global__ __launch_bounds__(1024) void flatten_units_kernel(const int64_t* bloc
         }
     }
     __syncthreads();
+    // Phase 1b (tile-parallel order): for every block, how many blocks a union group starting there would take
+    // (0 = none), one thread per block, into bits 8.. of sOpen -- the walk below then only looks the answer up.
+    const int ucap = (UNION_CAP * G <= MQ) ? UNION_CAP : MQ / G;  // union queries whose virtual rows fit one pass
+    auto union_len_at = [&](int t) {
+        // taper: the workgroups dispatched last should be short, so that the launch ends together -- the last
+        // `slots` leaf tiles (per head) stay single, the `2 slots` before them go in pairs
+        int ulen = union_len;
+        if (ulen <= 0) ulen = G > 1 ? 1 : ((int64_t)NB * Hkv < 2048 ? 4 : 3);  // measured, tools/np_sweep.sh / tools/ab.py
+        if (taper) {
+            const int64_t rest = (int64_t)(NB - t) * Hkv;
+            if (rest <= (int64_t)slots) ulen = 1;
+            else if (rest <= 3LL * slots) ulen = min(ulen, 2);
+        }
+        return ulen;
+    };
+    if (np && ucap >= 2)
+        for (int t = threadIdx.x; t < NB; t += blockDim.x) {
+            const int ulen = union_len_at(t);
+            int g = 0;
+            if (ulen > 1 && sCnt[t] <= ucap) {
+                bool short_run = NB - t < ulen;  // the run that opens at t is shorter than a group
+                for (int u = t + 1; u < t + ulen && u < NB; ++u) short_run |= (sOpen[u] & 1) != 0;
+                if (short_run) {
+                    int uq[UNION_CAP], urow[UNION_CAP], un;
+                    g = union_group(t, NB, ulen, ucap, sCnt, sOff, qtab ? sQ : nullptr, block_q, uq, urow, un);
+                    if (g < 2) g = 0;
+                }
+            }
+            sOpen[t] = (sOpen[t] & 0xf) | (g << 8);
+        }
+    __syncthreads();
     // Phase 2: wave 0 walks the blocks and decides the runs (every lane takes the same decisions; the lanes only split
     // the searches for the next run boundary).  `par`: every run gets an entry of the LDS table, and the units and the
     // record order are then written by all waves (phases 3 and 4) -- one thread emitting them costs ~0.4 us per unit
@@ -765,7 +849,6 @@ __global__ __launch_bounds__(1024) void flatten_units_kernel(const int64_t* bloc
         par = par_req && attempt == 0;
         rt.n = 0;
         int r = 0, ng = 0;
-        const int ucap = (UNION_CAP * G <= MQ) ? UNION_CAP : MQ / G;  // union queries whose virtual rows fit one pass
         // first block >= from whose sOpen has a bit of `mask` set (NB if none)
         auto find = [&](int from, int mask) {
             for (int base = from; base < NB; base += 64) {
@@ -777,7 +860,7 @@ __global__ __launch_bounds__(1024) void flatten_units_kernel(const int64_t* bloc
         };
         // units of one run: blocks t0, t0 + st, ... < te, pass ps, aux (0, or union group + 1)
         auto emit_run = [&](int t0, int te, int st, int aux, int ps) {
-            int n = (te - t0 + st - 1) / st;
+            int n = st == 1 ? te - t0 : (te - t0 + st - 1) / st;
             if (n > cap - r) n = cap - r;
             if (n <= 0) return;
             const int first = r;
@@ -810,6 +893,23 @@ __global__ __launch_bounds__(1024) void flatten_units_kernel(const int64_t* bloc
             r += n;
         };
         for (int ta = 0; ta < NB;) {
+            // ---- union group starting at ta (phase 1b) ------------------------------------------------------
+            const int glen = sOpen[ta] >> 8;
+            if (glen >= 2 && r < cap) {
+                if (!par && lane == 0) {  // (the parallel form writes the group in phase 3)
+                    int uq[UNION_CAP], urow[UNION_CAP], un;
+                    union_group(ta, NB, glen, ucap, sCnt, sOff, qtab ? sQ : nullptr, block_q, uq, urow, un);
+                    ul.gn[ng] = un;
+                    for (int j = 0; j < UNION_CAP; ++j) {
+                        ul.gq[j * cap + ng] = j < un ? uq[j] : 0;
+                        ul.grow[j * cap + ng] = j < un ? urow[j] : 0;
+                    }
+                }
+                emit_run(ta, ta + glen, 1, ng + 1, 0);
+                ++ng;
+                ta += glen;
+                continue;
+            }
             const int tb = find(ta + 1, 1);
             const int passes = sPass[ta];
             const int cnt_a = sCnt[ta];
@@ -827,74 +927,6 @@ __global__ __launch_bounds__(1024) void flatten_units_kernel(const int64_t* bloc
                         const int pp = sPass[ta + par_];
                         for (int ps = 0; ps < pp; ++ps) emit_run(ta + par_, te, P, 0, ps);
                     }
-                    ta = te;
-                    continue;
-                }
-            }
-            // taper: the workgroups dispatched last should be short, so that the launch ends together -- the last
-            // `slots` leaf tiles (per head) stay single, the `2 slots` before them go in pairs
-            int ulen = union_len;
-            if (ulen <= 0) ulen = G > 1 ? 1 : ((int64_t)NB * Hkv < 2048 ? 4 : 3);  // measured, tools/np_sweep.sh / tools/ab.py
-            if (taper) {
-                const int64_t rest = (int64_t)(NB - ta) * Hkv;
-                if (rest <= (int64_t)slots) ulen = 1;
-                else if (rest <= 3LL * slots) ulen = min(ulen, 2);
-            }
-            if (np && ulen > 1 && ucap >= 2 && cnt_a <= ucap && tb - ta < ulen && r < cap) {  // (np: tile-parallel order)
-                // ---- union group starting at ta ----------------------------------------------------
-                // (the union and a block's list live in registers, every loop below is unrolled over UNION_CAP: a list
-                //  read entry by entry from LDS cost ~0.6 us per leaf tile)
-                static_assert(UNION_CAP == 4, "the query table is read as int4");
-                int uq[UNION_CAP] = {0, 0, 0, 0}, urow[UNION_CAP] = {0, 0, 0, 0}, un = 0;
-                int te = ta;
-                while (te < NB && te - ta < ulen && r + (te - ta) < cap) {
-                    const int cnt = sCnt[te];
-                    if (cnt > ucap) break;
-                    const int off = sOff[te];
-                    int qv[UNION_CAP];
-                    if (qtab) {
-                        const int4 v = *reinterpret_cast<const int4*>(sQ + te * UNION_CAP);
-                        qv[0] = v.x, qv[1] = v.y, qv[2] = v.z, qv[3] = v.w;
-                    } else {
-#pragma unroll
-                        for (int i = 0; i < UNION_CAP; ++i) qv[i] = i < cnt ? (int)block_q[off + i] : 0;
-                    }
-                    int add = 0;  // queries of block te that are new to the union
-#pragma unroll
-                    for (int i = 0; i < UNION_CAP; ++i) {
-                        bool found = false;
-#pragma unroll
-                        for (int j = 0; j < UNION_CAP; ++j) found |= (j < un) & (uq[j] == qv[i]);
-                        add += (i < cnt && !found) ? 1 : 0;
-                    }
-                    if (un + add > ucap) break;
-#pragma unroll
-                    for (int i = 0; i < UNION_CAP; ++i) {
-                        bool found = i >= cnt;
-#pragma unroll
-                        for (int j = 0; j < UNION_CAP; ++j) found |= (j < un) & (uq[j] == qv[i]);
-                        if (!found) {  // first occurrence: this tile's row carries the query's partial
-#pragma unroll
-                            for (int j = 0; j < UNION_CAP; ++j)
-                                if (j == un) {
-                                    uq[j] = qv[i];
-                                    urow[j] = off + i;
-                                }
-                            ++un;
-                        }
-                    }
-                    ++te;
-                }
-                if (te - ta >= 2) {
-                    if (lane == 0) {
-                        ul.gn[ng] = un;
-                        for (int j = 0; j < UNION_CAP; ++j) {
-                            ul.gq[j * cap + ng] = j < un ? uq[j] : 0;
-                            ul.grow[j * cap + ng] = j < un ? urow[j] : 0;
-                        }
-                    }
-                    emit_run(ta, te, 1, ng + 1, 0);
-                    ++ng;
                     ta = te;
                     continue;
                 }
@@ -926,6 +958,15 @@ __global__ __launch_bounds__(1024) void flatten_units_kernel(const int64_t* bloc
     const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     for (int k = wave; k < NR; k += nwaves) {
         const int first = rt.r0[k], n = rt.nt[k], aux = rt.uni[k], t0 = rT0[k], st = rSp[k] & 0xff, ps = rSp[k] >> 8;
+        if (aux > 0 && lane == 0) {  // a union group: its queries and the rows that carry their partials
+            int uq[UNION_CAP], urow[UNION_CAP], un;
+            union_group(t0, NB, sOpen[t0] >> 8, ucap, sCnt, sOff, qtab ? sQ : nullptr, block_q, uq, urow, un);
+            ul.gn[aux - 1] = un;
+            for (int j = 0; j < UNION_CAP; ++j) {
+                ul.gq[j * cap + aux - 1] = j < un ? uq[j] : 0;
+                ul.grow[j * cap + aux - 1] = j < un ? urow[j] : 0;
+            }
+        }
         for (int j = lane; j < n; j += 64) {
             const int t = t0 + j * st;
             ul.src[first + j] = t;
