@@ -1083,11 +1083,36 @@ static int launch_node_plan(const Stage1Params& p, int NE, int64_t rows_cap, con
                             hipStream_t stream) {
     const UnitList ul = unit_list(pv);
     const int np = stage1_kind();
-    int64_t run_cap = pv.cap;
-    while (sizeof(int) * 3 * (size_t)run_cap > 60 * 1024 && run_cap > 0) run_cap /= 2;
-    hipLaunchKernelGGL(node_units_kernel, dim3(1), dim3(256), sizeof(int) * 3 * (size_t)(run_cap > 0 ? run_cap : 1), stream,
+    // entry lengths + a run table in LDS: 8 words per run and every possible run (the kernel then writes units and
+    // record order with all its waves), or as many runs as fit (it falls back to one lane if more turn up)
+    constexpr size_t UNIT_LDS = 156 * 1024;
+    const size_t blk = 2 * (size_t)NE;
+    if (sizeof(int) * (blk + 8 + 3 * 64) > UNIT_LDS) {
+        set_error("plan: %d entries exceed the unit kernel's LDS", NE);
+        return DEFT_EUNSUPPORTED;
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&node_units_kernel),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)UNIT_LDS);
+        if (e != hipSuccess) {
+            set_error("hipFuncSetAttribute(node_units): %s", hipGetErrorString(e));
+            return DEFT_EHIP;
+        }
+        attr_set = true;
+    }
+    int64_t run_cap = pv.cap > 0 ? pv.cap : 1;
+    int par = !getenv("DEFT_PLAN_SERIAL");
+    if (par && sizeof(int) * (blk + 8 * (size_t)run_cap + 8) > UNIT_LDS) {
+        run_cap = ((int64_t)(UNIT_LDS / sizeof(int)) - (int64_t)blk - 8) / 8;
+        if (run_cap < 256) par = 0, run_cap = pv.cap > 0 ? pv.cap : 1;
+    }
+    if (par && getenv("DEFT_PLAN_RUNCAP")) run_cap = std::max(1, std::min((int)run_cap, atoi(getenv("DEFT_PLAN_RUNCAP"))));  // tests: force the fallback
+    if (!par)
+        while (sizeof(int) * (blk + 3 * (size_t)run_cap + 8) > UNIT_LDS && run_cap > 1) run_cap /= 2;
+    hipLaunchKernelGGL(node_units_kernel, dim3(1), dim3(1024), sizeof(int) * (blk + (par ? 8 : 3) * (size_t)run_cap + 8), stream,
                        p.node_kv_len, p.node_q_len, NE, p.G, (int)pv.cap, rows_cap, ul, pv.hdr, pv.sched, pv.row_q, np, p.Hkv,
-                       2 * num_cus(), np_chunk_env(), (int)run_cap);
+                       2 * num_cus(), np_chunk_env(), (int)run_cap, par);
     int rc = check_launch("node units launch");
     if (rc) return rc;
     hipLaunchKernelGGL(node_records_kernel, dim3((unsigned)(pv.cap + 1)), dim3(128), 0, stream, p.node_kv, p.node_kv_offset,

@@ -684,6 +684,91 @@ __device__ inline void np_record_order(const UnitList& ul, int R, int Hkv, int G
     hdr[1] = NL;
 }
 
+// Record order of the tile-parallel stage 1, written by all waves of the unit kernel from its LDS run table (the
+// rules of np_record_order above, same result).  Called by every thread after the units are written; rT0 / rSp are
+// scratch arrays of run_cap words (the callers' run fields are dead by then), sMeta[2..3] two shared words.
+__device__ inline void record_order_parallel(const UnitList& ul, const RunTable& rt, int NR, int* rT0, int* rSp, int* sMeta,
+                                             int32_t* hdr, int Hkv, int G, int slots, int chunk_c) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    __syncthreads();  // (rT0 / rSp are reused below)
+    // Wave 0: chunk length C from sums / maxima over the runs, then each run's first leader and first follower record
+    // by prefix sums over the runs' chunk counts.
+    if (threadIdx.x < 64) {
+        auto wave_sum = [&](auto&& f) {
+            int acc = 0;
+            for (int k = lane; k < NR; k += 64) acc += f(rt.nt[k], rt.uni[k]);
+            for (int m = 32; m > 0; m >>= 1) acc += __shfl_xor(acc, m, 64);
+            return acc;
+        };
+        int C = chunk_c;
+        if (C <= 0) {
+            int lmax = 0;
+            for (int k = lane; k < NR; k += 64)
+                if (!rt.uni[k] && rt.nt[k] > lmax) lmax = rt.nt[k];
+            for (int m = 32; m > 0; m >>= 1) lmax = max(lmax, __shfl_xor(lmax, m, 64));
+            C = lmax >= 32 ? 8 : (lmax >= 8 ? 4 : (lmax >= 4 ? 2 : 1));
+            if (G > 1) {
+                const int64_t tiles_all = wave_sum([](int nt, int) { return nt; });
+                int cmax = 1;
+                while (cmax < 8 && (int64_t)cmax * slots < tiles_all * Hkv) cmax <<= 1;
+                if (C > cmax) C = cmax;
+            }
+            for (; C > 1; C >>= 1) {
+                const int64_t n = wave_sum([C](int nt, int uni) { return uni ? 1 : (nt + C - 1) / C; });
+                if (10 * n * Hkv >= 3LL * slots) break;
+            }
+        }
+        int lead = 0, foll = 0;
+        for (int base = 0; base < NR; base += 64) {
+            const int k = base + lane;
+            const int nt = k < NR ? rt.nt[k] : 0;
+            const int S = k < NR ? (rt.uni[k] ? 1 : (nt + C - 1) / C) : 0;
+            int a = S, b = nt - S;  // inclusive scans over the lanes
+            for (int d = 1; d < 64; d <<= 1) {
+                const int ua = __shfl_up(a, d, 64), ub = __shfl_up(b, d, 64);
+                if (lane >= d) {
+                    a += ua;
+                    b += ub;
+                }
+            }
+            if (k < NR) {
+                rT0[k] = lead + a - S;
+                rSp[k] = foll + b - (nt - S);
+            }
+            lead += __shfl(a, 63, 64);
+            foll += __shfl(b, 63, 64);
+        }
+        if (lane == 0) {
+            sMeta[2] = C;
+            sMeta[3] = lead;
+            hdr[1] = lead;
+        }
+    }
+    __syncthreads();
+    {
+        const int C = sMeta[2], NL = sMeta[3];
+        for (int k = wave; k < NR; k += nwaves) {
+            const int first = rt.r0[k], nt = rt.nt[k];
+            const int S = rt.uni[k] ? 1 : (nt + C - 1) / C;  // a union group is one chunk
+            const int li = rT0[k], fi = NL + rSp[k];
+            const int q = nt / S, rem = nt - q * S;  // chunk p folds units p, p + S, ...: q + 1 of them for p < rem, else q
+            for (int u = lane; u < nt; u += 64) {
+                const int j = u / S, pc = u - j * S;
+                const int fb = fi + pc * (q - 1) + min(pc, rem);  // followers of the chunks before pc
+                if (j == 0) {
+                    ul.perm[li + pc] = first + pc;
+                    ul.ch_n[li + pc] = q + (pc < rem ? 1 : 0);
+                    ul.ch_fb[li + pc] = fb;
+                } else {
+                    ul.perm[fb + j - 1] = first + u;
+                    ul.ch_n[fb + j - 1] = 0;
+                    ul.ch_fb[fb + j - 1] = 0;
+                }
+            }
+        }
+    }
+}
+
 // Union group of leaf tiles starting at block t (Flatten, tile-parallel order): up to `ulen` consecutive blocks whose
 // query lists hold at most `ucap` queries each and at most `ucap` distinct queries together.  Returns the number of
 // blocks taken; uq / urow / un = the union's queries in order of first occurrence and the partial row (block_q
@@ -977,84 +1062,8 @@ __global__ __launch_bounds__(1024) void flatten_units_kernel(const int64_t* bloc
         }
     }
     if (!np) return;
-    __syncthreads();  // (rT0 / rSp are reused below)
-    // Phase 4: record order of the tile-parallel stage 1 (the rules of np_record_order above, same result).
-    // Wave 0: chunk length C from sums / maxima over the runs, then each run's first leader and first follower record
-    // by prefix sums over the runs' chunk counts.
-    if (threadIdx.x < 64) {
-        auto wave_sum = [&](auto&& f) {
-            int acc = 0;
-            for (int k = lane; k < NR; k += 64) acc += f(rt.nt[k], rt.uni[k]);
-            for (int m = 32; m > 0; m >>= 1) acc += __shfl_xor(acc, m, 64);
-            return acc;
-        };
-        int C = chunk_c;
-        if (C <= 0) {
-            int lmax = 0;
-            for (int k = lane; k < NR; k += 64)
-                if (!rt.uni[k] && rt.nt[k] > lmax) lmax = rt.nt[k];
-            for (int m = 32; m > 0; m >>= 1) lmax = max(lmax, __shfl_xor(lmax, m, 64));
-            C = lmax >= 32 ? 8 : (lmax >= 8 ? 4 : (lmax >= 4 ? 2 : 1));
-            if (G > 1) {
-                const int64_t tiles_all = wave_sum([](int nt, int) { return nt; });
-                int cmax = 1;
-                while (cmax < 8 && (int64_t)cmax * slots < tiles_all * Hkv) cmax <<= 1;
-                if (C > cmax) C = cmax;
-            }
-            for (; C > 1; C >>= 1) {
-                const int64_t n = wave_sum([C](int nt, int uni) { return uni ? 1 : (nt + C - 1) / C; });
-                if (10 * n * Hkv >= 3LL * slots) break;
-            }
-        }
-        int lead = 0, foll = 0;
-        for (int base = 0; base < NR; base += 64) {
-            const int k = base + lane;
-            const int nt = k < NR ? rt.nt[k] : 0;
-            const int S = k < NR ? (rt.uni[k] ? 1 : (nt + C - 1) / C) : 0;
-            int a = S, b = nt - S;  // inclusive scans over the lanes
-            for (int d = 1; d < 64; d <<= 1) {
-                const int ua = __shfl_up(a, d, 64), ub = __shfl_up(b, d, 64);
-                if (lane >= d) {
-                    a += ua;
-                    b += ub;
-                }
-            }
-            if (k < NR) {
-                rT0[k] = lead + a - S;
-                rSp[k] = foll + b - (nt - S);
-            }
-            lead += __shfl(a, 63, 64);
-            foll += __shfl(b, 63, 64);
-        }
-        if (lane == 0) {
-            sMeta[2] = C;
-            sMeta[3] = lead;
-            hdr[1] = lead;
-        }
-    }
-    __syncthreads();
-    {
-        const int C = sMeta[2], NL = sMeta[3];
-        for (int k = wave; k < NR; k += nwaves) {
-            const int first = rt.r0[k], nt = rt.nt[k];
-            const int S = rt.uni[k] ? 1 : (nt + C - 1) / C;  // a union group is one chunk
-            const int li = rT0[k], fi = NL + rSp[k];
-            const int q = nt / S, rem = nt - q * S;  // chunk p folds units p, p + S, ...: q + 1 of them for p < rem, else q
-            for (int u = lane; u < nt; u += 64) {
-                const int j = u / S, pc = u - j * S;
-                const int fb = fi + pc * (q - 1) + min(pc, rem);  // followers of the chunks before pc
-                if (j == 0) {
-                    ul.perm[li + pc] = first + pc;
-                    ul.ch_n[li + pc] = q + (pc < rem ? 1 : 0);
-                    ul.ch_fb[li + pc] = fb;
-                } else {
-                    ul.perm[fb + j - 1] = first + u;
-                    ul.ch_n[fb + j - 1] = 0;
-                    ul.ch_fb[fb + j - 1] = 0;
-                }
-            }
-        }
-    }
+    // Phase 4: record order of the tile-parallel stage 1
+    record_order_parallel(ul, rt, NR, rT0, rSp, sMeta, hdr, Hkv, G, slots, chunk_c);
 }
 
 // One workgroup of 128 threads per unit (+ the sentinel): pack its record.
@@ -1174,63 +1183,131 @@ __global__ __launch_bounds__(128) void flatten_records_kernel(const int64_t* blo
 // Small entries (one tile, one pass) that follow each other are PACKED into one tile as long as their slots fit
 // in 128 and their virtual query rows in 32 -- per-slot row masks make that the same arithmetic (a Medusa step
 // has 64 one-token nodes: 2 tiles instead of 64).  A packed unit has aux = -(entries in it).
-__global__ __launch_bounds__(256) void node_units_kernel(const int64_t* node_kv_len, const int64_t* node_q_len, int NE, int G,
-                                                         int cap, int64_t rows_cap, UnitList ul, int32_t* hdr,
-                                                         int32_t* sched, int32_t* row_q, int np, int Hkv, int slots,
-                                                         int chunk_c, int run_cap) {
+// One workgroup.  The entries' lengths go to LDS (one round trip), wave 0 walks the entries and decides the runs (packs
+// are sequential by nature), all waves then write the units and the record order from the LDS run table -- as in
+// flatten_units_kernel; `par` = 0 (tables beyond the LDS) or an overflowing table: lane 0 emits as it walks.
+__global__ __launch_bounds__(1024) void node_units_kernel(const int64_t* node_kv_len, const int64_t* node_q_len, int NE, int G,
+                                                          int cap, int64_t rows_cap, UnitList ul, int32_t* hdr,
+                                                          int32_t* sched, int32_t* row_q, int np, int Hkv, int slots,
+                                                          int chunk_c, int run_cap, int par) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    int* sRun = reinterpret_cast<int*>(smem);
+    int* sLen = reinterpret_cast<int*>(smem);  // [NE] node_kv_len
+    int* sQl = sLen + NE;                      // [NE] node_q_len
+    int* sRun = sQl + NE;
+    RunTable rt{sRun, sRun + run_cap, sRun + 2 * run_cap, 0, run_cap};
+    int* rT0 = sRun + 3 * run_cap;    // par: the run's entry;               later: its first leader record
+    int* rSp = sRun + 4 * run_cap;    // par: the run's pass;                later: its first follower record - leaders
+    int* rProw = sRun + 5 * run_cap;  // par: partial row of the run's first tile
+    int* rQl = sRun + 6 * run_cap;    // par: partial rows per tile
+    int* rAux = sRun + 7 * run_cap;   // par: 1 = tiles of one entry (aux = tile index), <= 0 = a pack (aux = -entries)
+    int* sMeta = sRun + (par ? 8 : 3) * run_cap;  // [8]
     for (int64_t i = threadIdx.x; i < rows_cap; i += blockDim.x) row_q[i] = -1;
-    if (threadIdx.x == 0) {
-        RunTable rt{sRun, sRun + run_cap, sRun + 2 * run_cap, 0, run_cap};
-        int r = 0, rowbase = 0;
-        int pack_r = -1, pack_n = 0, pack_keys = 0, pack_rows = 0;  // open pack: its unit, entries, slots, virtual rows
-        for (int e = 0; e < NE; ++e) {
-            const int len = (int)node_kv_len[e];
-            const int nt = (len + TILE - 1) / TILE;
-            const int ql = (int)node_q_len[e];
-            const int np = (ql * G + MQ - 1) / MQ;
-            if (nt == 1 && np == 1 && r < cap) {
-                if (pack_r >= 0 && pack_n < MQ && pack_keys + len <= TILE && pack_rows + ql * G <= MQ) {
-                    ++pack_n;
-                    pack_keys += len;
-                    pack_rows += ql * G;
-                    ul.aux[pack_r] = -pack_n;
-                } else {
-                    pack_r = r;
-                    pack_n = 1;
-                    pack_keys = len;
-                    pack_rows = ql * G;
-                    ul.src[r] = e;
-                    ul.aux[r] = 0;  // a pack of one is an ordinary unit
-                    ul.pass[r] = 0;
-                    ul.flags[r] = (r << 1) | 1;
-                    ul.prow[r] = rowbase;
-                    run_push(rt, r, 1, 0);
-                    ++r;
-                }
-            } else {
-                pack_r = -1;
-                for (int ps = 0; ps < np; ++ps) {
-                    const int first = r;
-                    for (int tt = 0; tt < nt && r < cap; ++tt, ++r) {
-                        ul.src[r] = e;
-                        ul.aux[r] = tt;
-                        ul.pass[r] = ps;
-                        ul.flags[r] = (first << 1) | ((tt == 0) ? 1 : 0);
-                        ul.prow[r] = rowbase + tt * ql;
+    for (int e = threadIdx.x; e < NE; e += blockDim.x) {
+        sLen[e] = (int)node_kv_len[e];
+        sQl[e] = (int)node_q_len[e];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int par_req = par;
+    if (threadIdx.x < 64) {
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            par = par_req && attempt == 0;
+            rt.n = 0;
+            int r = 0, rowbase = 0;
+            int pack_r = -1, pack_k = -1, pack_n = 0, pack_keys = 0, pack_rows = 0;  // open pack: unit, run, entries, slots, virtual rows
+            auto emit_run = [&](int e, int n, int ps, int prow0, int ql, int aux) {
+                if (n > cap - r) n = cap - r;
+                if (n <= 0) return;
+                const int first = r;
+                if (par) {
+                    if (lane == 0 && rt.n < rt.cap) {
+                        rt.r0[rt.n] = first;
+                        rt.nt[rt.n] = n;
+                        rt.uni[rt.n] = 0;
+                        rT0[rt.n] = e;
+                        rSp[rt.n] = ps;
+                        rProw[rt.n] = prow0;
+                        rQl[rt.n] = ql;
+                        rAux[rt.n] = aux;
                     }
-                    if (r > first) run_push(rt, first, r - first, 0);
+                } else if (lane == 0) {
+                    for (int j = 0; j < n; ++j) {
+                        ul.src[first + j] = e;
+                        ul.aux[first + j] = aux > 0 ? j : aux;
+                        ul.pass[first + j] = ps;
+                        ul.flags[first + j] = (first << 1) | (j == 0 ? 1 : 0);
+                        ul.prow[first + j] = prow0 + j * ql;
+                    }
+                    if (rt.n < rt.cap) {
+                        rt.r0[rt.n] = first;
+                        rt.nt[rt.n] = n;
+                        rt.uni[rt.n] = 0;
+                    }
+                }
+                ++rt.n;
+                r += n;
+            };
+            for (int e = 0; e < NE; ++e) {
+                const int len = sLen[e];
+                const int nt = (len + TILE - 1) / TILE;
+                const int ql = sQl[e];
+                const int npass = (ql * G + MQ - 1) / MQ;
+                if (nt == 1 && npass == 1 && r < cap) {
+                    if (pack_r >= 0 && pack_n < MQ && pack_keys + len <= TILE && pack_rows + ql * G <= MQ) {
+                        ++pack_n;
+                        pack_keys += len;
+                        pack_rows += ql * G;
+                        if (lane == 0) {
+                            if (!par) ul.aux[pack_r] = -pack_n;
+                            else if (pack_k < rt.cap) rAux[pack_k] = -pack_n;
+                        }
+                    } else {
+                        pack_r = r;
+                        pack_k = rt.n;
+                        pack_n = 1;
+                        pack_keys = len;
+                        pack_rows = ql * G;
+                        emit_run(e, 1, 0, rowbase, 0, 0);  // a pack of one is an ordinary unit
+                    }
+                } else {
+                    pack_r = -1;
+                    for (int ps = 0; ps < npass; ++ps) emit_run(e, nt, ps, rowbase, ql, 1);
+                }
+                rowbase += nt * ql;
+            }
+            if (lane == 0) {
+                hdr[0] = r;
+                hdr[1] = 0;
+                sched[0] = 0;
+                for (int k = 0; k < NTICKET; ++k) sched[ticket_word(k)] = 0;
+                if (par && rt.n <= rt.cap) {
+                    sMeta[0] = r;
+                    sMeta[1] = rt.n;
+                    sMeta[4] = 1;
+                } else if (!par) {
+                    sMeta[4] = 0;
+                    if (np) np_record_order(ul, r, Hkv, G, slots, chunk_c, hdr, rt);
                 }
             }
-            rowbase += nt * ql;
+            if (!par || rt.n <= rt.cap) break;
         }
-        hdr[0] = r;
-        hdr[1] = 0;
-        sched[0] = 0;
-        for (int k = 0; k < NTICKET; ++k) sched[ticket_word(k)] = 0;
-        if (np) np_record_order(ul, r, Hkv, G, slots, chunk_c, hdr, rt);
     }
+    __syncthreads();
+    if (!sMeta[4]) return;
+    const int NR = sMeta[1];
+    const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    for (int k = wave; k < NR; k += nwaves) {
+        const int first = rt.r0[k], n = rt.nt[k], e = rT0[k], ps = rSp[k], prow0 = rProw[k], ql = rQl[k], aux = rAux[k];
+        for (int j = lane; j < n; j += 64) {
+            ul.src[first + j] = e;
+            ul.aux[first + j] = aux > 0 ? j : aux;
+            ul.pass[first + j] = ps;
+            ul.flags[first + j] = (first << 1) | (j == 0 ? 1 : 0);
+            ul.prow[first + j] = prow0 + j * ql;
+        }
+    }
+    if (!np) return;
+    record_order_parallel(ul, rt, NR, rT0, rSp, sMeta, hdr, Hkv, G, slots, chunk_c);
 }
 
 __global__ __launch_bounds__(128) void node_records_kernel(const int64_t* node_kv, const int64_t* node_kv_offset,

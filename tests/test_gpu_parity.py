@@ -611,7 +611,7 @@ def test_nodes_with_more_than_32_queries_fold_as_interleaved_runs(mode, shape):
         assert (o[r].double() - ref).abs().max().item() < TOL_EXACT, r
 
 
-@pytest.mark.parametrize("shape", [(32, 32, 1024, 32, 200), (8, 2, 1500, 70, 3), (4, 4, 300, 5, 40)])
+@pytest.mark.parametrize("shape", [(32, 32, 1024, 32, 200), (8, 2, 1500, 70, 3), (4, 4, 300, 5, 40), (4, 4, 5, 40, 1)])
 def test_plan_build_forms_give_identical_plans(shape, monkeypatch):
     """The Flatten plan is written either by all waves of the unit kernel from a table of runs (default), or by one
     lane as it walks the blocks (tables beyond the LDS; `DEFT_PLAN_SERIAL=1`), or by one lane after the run table
@@ -658,6 +658,31 @@ def test_plan_build_forms_give_identical_plans(shape, monkeypatch):
             n_units = int(plan[:4].view(torch.int32).item())
             assert 0 < n_units <= cap
             # header words 0..1 (units, chunk leaders) and every record the kernels may read (unit slots + sentinel)
+            plans.append((plan[:8].clone(), plan[4096:4096 + 2048 * (n_units + 1)].clone()))
+    assert torch.isfinite(outs[0].float()).all()
+    for o, (hd, rec) in zip(outs[1:], plans[1:]):
+        assert torch.equal(o, outs[0])
+        assert torch.equal(hd, plans[0][0])
+        assert torch.equal(rec, plans[0][1])
+    # the Node plan (entries cut into tiles, small entries packed) has the same three forms
+    nd = [md.node_kv, md.node_kv_offset, md.node_kv_len, md.node_q, md.node_q_offset, md.node_q_len]
+    NE, Pn, total_kv = md.node_kv_offset.shape[0], md.node_q.shape[0], md.node_kv.shape[0]
+    nbytes = lib.deft_node_plan_bytes(NE, Pn, total_kv, Hq, Hkv)
+    outs, plans = [], []
+    for env in ({}, {"DEFT_PLAN_SERIAL": "1"}, {"DEFT_PLAN_RUNCAP": "2"}):
+        with monkeypatch.context() as m:
+            for k_, v_ in env.items():
+                m.setenv(k_, v_)
+            o = torch.full_like(q, float("nan"))
+            deft_amd.tree_attention_fwd(q, kb, vb, o, *nd)
+            plan = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
+            check(lib.deft_node_build_plan(*[t.data_ptr() for t in nd], NE, Pn, total_kv, Hq, Hkv, q.stride(0), q.stride(1),
+                                           kb.stride(0), None, 0, 0, plan.data_ptr(), nbytes,
+                                           torch.cuda.current_stream().cuda_stream), "deft_node_build_plan")
+            torch.cuda.synchronize()
+            outs.append(o)
+            n_units = int(plan[:4].view(torch.int32).item())
+            assert n_units > 0 and 4096 + 2048 * (n_units + 1) <= nbytes
             plans.append((plan[:8].clone(), plan[4096:4096 + 2048 * (n_units + 1)].clone()))
     assert torch.isfinite(outs[0].float()).all()
     for o, (hd, rec) in zip(outs[1:], plans[1:]):

@@ -16,7 +16,10 @@ from deft_amd.utils.workloads import GEOMETRY, WORKLOADS, build_forest, build_tr
 dev = torch.device("cuda", 0)
 names = sys.argv[1:] or ["northstar_4kx32", "fewshot_1kx32", "tot50_4k", "gqa_4kx32", "forest_8kx8", "medusa64_node"]
 for name in names:
-    w = WORKLOADS[name]
+    w = WORKLOADS[name.split(":")[0]]
+    if name.endswith(":node"):  # a Flatten workload's tree through the Node operator
+        from deft_amd.utils.workloads import Workload
+        w = Workload(**{**w.__dict__, "mode": "node"})
     Hq, Hkv, D, _ = GEOMETRY[w.model]
     if w.trees > 1:
         forest, pool = build_forest(w, w.trees, 1, str(dev))
@@ -52,6 +55,19 @@ for name in names:
             e0.record()
             check(lib.deft_flatten_build_plan(*[t.data_ptr() for t in mdl], NB, P, Hq, Hkv, q.stride(0), q.stride(1), kb.stride(0),
                                               None, 0, 0, plan.data_ptr(), nbytes, s), "deft_flatten_build_plan")
+            e1.record(); torch.cuda.synchronize(); t_plan.append(e0.elapsed_time(e1) * 1e3)
+    else:
+        nd = [md.node_kv, md.node_kv_offset, md.node_kv_len, md.node_q, md.node_q_offset, md.node_q_len]
+        NE, Pn, total_kv = md.node_kv_offset.shape[0], md.node_q.shape[0], md.node_kv.shape[0]
+        nbytes = lib.deft_node_plan_bytes(NE, Pn, total_kv, Hq, Hkv)
+        plan = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
+        s = torch.cuda.current_stream().cuda_stream
+        for _ in range(8):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            for _ in range(4): call(md)
+            e0.record()
+            check(lib.deft_node_build_plan(*[t.data_ptr() for t in nd], NE, Pn, total_kv, Hq, Hkv, q.stride(0), q.stride(1), kb.stride(0),
+                                           None, 0, 0, plan.data_ptr(), nbytes, s), "deft_node_build_plan")
             e1.record(); torch.cuda.synchronize(); t_plan.append(e0.elapsed_time(e1) * 1e3)
     print(json.dumps({"workload": name, "mode": w.mode, "out_sha": hashlib.sha256(o.cpu().numpy().tobytes()).hexdigest()[:16],
                       "plan_us": round(sorted(t_plan)[len(t_plan) // 2], 1) if t_plan else None,
