@@ -1083,14 +1083,10 @@ static int launch_node_plan(const Stage1Params& p, int NE, int64_t rows_cap, con
                             hipStream_t stream) {
     const UnitList ul = unit_list(pv);
     const int np = stage1_kind();
-    // entry lengths + a run table in LDS: 8 words per run and every possible run (the kernel then writes units and
+    // a run table in LDS: 8 words per run and every possible run (the kernel then writes units and
     // record order with all its waves), or as many runs as fit (it falls back to one lane if more turn up)
     constexpr size_t UNIT_LDS = 156 * 1024;
-    const size_t blk = 2 * (size_t)NE;
-    if (sizeof(int) * (blk + 8 + 3 * 64) > UNIT_LDS) {
-        set_error("plan: %d entries exceed the unit kernel's LDS", NE);
-        return DEFT_EUNSUPPORTED;
-    }
+    const size_t blk = 0;
     static bool attr_set = false;
     if (!attr_set) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&node_units_kernel),

@@ -1183,17 +1183,14 @@ __global__ __launch_bounds__(128) void flatten_records_kernel(const int64_t* blo
 // Small entries (one tile, one pass) that follow each other are PACKED into one tile as long as their slots fit
 // in 128 and their virtual query rows in 32 -- per-slot row masks make that the same arithmetic (a Medusa step
 // has 64 one-token nodes: 2 tiles instead of 64).  A packed unit has aux = -(entries in it).
-// One workgroup.  The entries' lengths go to LDS (one round trip), wave 0 walks the entries and decides the runs (packs
-// are sequential by nature), all waves then write the units and the record order from the LDS run table -- as in
+// One workgroup.  Wave 0 walks the entries and decides the runs (packs are sequential by nature), all waves then write the units and the record order from the LDS run table -- as in
 // flatten_units_kernel; `par` = 0 (tables beyond the LDS) or an overflowing table: lane 0 emits as it walks.
 __global__ __launch_bounds__(1024) void node_units_kernel(const int64_t* node_kv_len, const int64_t* node_q_len, int NE, int G,
                                                           int cap, int64_t rows_cap, UnitList ul, int32_t* hdr,
                                                           int32_t* sched, int32_t* row_q, int np, int Hkv, int slots,
                                                           int chunk_c, int run_cap, int par) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    int* sLen = reinterpret_cast<int*>(smem);  // [NE] node_kv_len
-    int* sQl = sLen + NE;                      // [NE] node_q_len
-    int* sRun = sQl + NE;
+    int* sRun = reinterpret_cast<int*>(smem);
     RunTable rt{sRun, sRun + run_cap, sRun + 2 * run_cap, 0, run_cap};
     int* rT0 = sRun + 3 * run_cap;    // par: the run's entry;               later: its first leader record
     int* rSp = sRun + 4 * run_cap;    // par: the run's pass;                later: its first follower record - leaders
@@ -1202,11 +1199,6 @@ __global__ __launch_bounds__(1024) void node_units_kernel(const int64_t* node_kv
     int* rAux = sRun + 7 * run_cap;   // par: 1 = tiles of one entry (aux = tile index), <= 0 = a pack (aux = -entries)
     int* sMeta = sRun + (par ? 8 : 3) * run_cap;  // [8]
     for (int64_t i = threadIdx.x; i < rows_cap; i += blockDim.x) row_q[i] = -1;
-    for (int e = threadIdx.x; e < NE; e += blockDim.x) {
-        sLen[e] = (int)node_kv_len[e];
-        sQl[e] = (int)node_q_len[e];
-    }
-    __syncthreads();
     const int lane = threadIdx.x & 63;
     const int par_req = par;
     if (threadIdx.x < 64) {
@@ -1247,10 +1239,18 @@ __global__ __launch_bounds__(1024) void node_units_kernel(const int64_t* node_kv
                 ++rt.n;
                 r += n;
             };
-            for (int e = 0; e < NE; ++e) {
-                const int len = sLen[e];
+            // 64 entries at a time: lane i loads the lengths of entry base + i (one round trip per batch), the walk
+            // reads them with v_readlane -- scalar code, no memory access per entry (a Medusa step has 65 entries)
+            for (int base = 0; base < NE; base += 64) {
+              const int mine = base + lane;
+              const int vlen = mine < NE ? (int)node_kv_len[mine] : 0;
+              const int vql = mine < NE ? (int)node_q_len[mine] : 0;
+              const int lim = min(64, NE - base);
+              for (int i = 0; i < lim; ++i) {
+                const int e = base + i;
+                const int len = __builtin_amdgcn_readlane(vlen, i);
                 const int nt = (len + TILE - 1) / TILE;
-                const int ql = sQl[e];
+                const int ql = __builtin_amdgcn_readlane(vql, i);
                 const int npass = (ql * G + MQ - 1) / MQ;
                 if (nt == 1 && npass == 1 && r < cap) {
                     if (pack_r >= 0 && pack_n < MQ && pack_keys + len <= TILE && pack_rows + ql * G <= MQ) {
@@ -1274,6 +1274,7 @@ __global__ __launch_bounds__(1024) void node_units_kernel(const int64_t* node_kv
                     for (int ps = 0; ps < npass; ++ps) emit_run(e, nt, ps, rowbase, ql, 1);
                 }
                 rowbase += nt * ql;
+              }
             }
             if (lane == 0) {
                 hdr[0] = r;
