@@ -6,7 +6,8 @@ for each of the 32 layers, the paged KV append of the new token rows followed by
 the DeFT-Flatten (or DeFT-Node) attention operator, each layer on its own KV pool
 (working set = layers x tree KV, far beyond the 256 MB Infinity Cache).  Inputs are
 resident in HBM when the timed region starts; the host-side metadata build is a
-caller of the path, reported separately (`metadata_build_ms`), not timed.
+caller of the path, reported separately (`metadata_build_ms`), not timed, and so is its
+device-side repack, once per step for all layers (`plan_build_us_per_step`).
 
 Contract: `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on
 rank 0.  For N > 1 launch with torch.distributed.run (one rank per GPU); every rank
@@ -183,6 +184,41 @@ class Bench:
         return {"mean_us": sum(sweeps) / len(sweeps), "median_us": sweeps[len(sweeps) // 2],
                 "launches": len(sweeps) * 4 * self.layers, "launch": "hipgraph" if graph is not None else "eager"}
 
+    def time_plan(self, reps: int = 7):
+        """Median duration (us) of the per-step plan kernels -- the device-side repack of the metadata every layer of
+        a decode step shares -- built once per step by the operators (cached on the metadata tensors, so the hipGraph
+        step above does not contain it): HIP events on the launching stream, right behind attention launches."""
+        md, pool = self.md, self.pool
+        q0 = self.q[0].view(self.nq, self.Hq, self.D)
+        kss = pool.get_key_buffer(0).stride(0)
+        s = torch.cuda.current_stream(self.device).cuda_stream
+        if self.w.mode == "flatten":
+            mdl = [md.block_q, md.block_q_cnts, md.block_q_offset, md.block_bitmasks, md.block_kv, md.block_lens]
+            NB, P = md.block_q_cnts.shape[0], md.block_q.shape[0]
+            nbytes = lib.deft_flatten_plan_bytes(NB, P, self.Hq, self.Hkv)
+            plan = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=self.device)
+            build = lambda: check(lib.deft_flatten_build_plan(*[t.data_ptr() for t in mdl], NB, P, self.Hq, self.Hkv, q0.stride(0),
+                                                              q0.stride(1), kss, None, 0, 0, plan.data_ptr(), nbytes, s), "plan")
+        elif self.w.mode == "node":
+            mdl = [md.node_kv, md.node_kv_offset, md.node_kv_len, md.node_q, md.node_q_offset, md.node_q_len]
+            NE, P, total = md.node_kv_offset.shape[0], md.node_q.shape[0], md.node_kv.shape[0]
+            nbytes = lib.deft_node_plan_bytes(NE, P, total, self.Hq, self.Hkv)
+            plan = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=self.device)
+            build = lambda: check(lib.deft_node_build_plan(*[t.data_ptr() for t in mdl], NE, P, total, self.Hq, self.Hkv, q0.stride(0),
+                                                           q0.stride(1), kss, None, 0, 0, plan.data_ptr(), nbytes, s), "plan")
+        else:
+            return None
+        ts = []
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.step()
+            e0.record()
+            build()
+            e1.record()
+            torch.cuda.synchronize(self.device)
+            ts.append(e0.elapsed_time(e1) * 1e3)
+        return sorted(ts)[len(ts) // 2]
+
     def cpu_baseline(self, budget_s: float):
         from oracle.cpu_baseline import time_cpu_baseline  # the checker/baseline, never the product path
 
@@ -257,6 +293,7 @@ def main():
     tokens_per_s = n_gpus * b.nq / (dt / args.steps)
 
     s1 = b.time_stage1(reps=3)
+    plan_us = b.time_plan()
     algo = b.algorithmic_bytes_per_layer()
     roofline = None
     if s1 is not None:
@@ -312,6 +349,7 @@ def main():
                     "stage1_us": round(s1v["mean_us"], 2) if s1v else None,
                     "stage1_hbm_frac": round(av / (s1v["mean_us"] * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4) if s1v else None,
                     "metadata_build_ms": round(bv.metadata_build_ms, 3), "launch": bv.launch,
+                    "plan_build_us_per_step": round(pv, 1) if (pv := bv.time_plan(5)) is not None else None,
                 }
                 del bv
             except Exception as e:  # an extra must never take the headline down
@@ -344,6 +382,7 @@ def main():
             "step_algorithmic_GBps": round(step_achieved, 1),
             "step_hbm_frac": round(step_achieved / HBM_PEAK_GBPS, 4),
             "metadata_build_ms": round(b.metadata_build_ms, 3),
+            "plan_build_us_per_step": round(plan_us, 1) if plan_us is not None else None,
             "roofline": roofline, "cpu_baseline": cpu, "other_workloads": extras,
         }
         print(json.dumps(line), flush=True)
