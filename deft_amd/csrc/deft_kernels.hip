@@ -292,6 +292,7 @@ __global__ __launch_bounds__(256, 2) void stage1_kernel(Stage1Params p) {
 
 }  // namespace deft
 #include "stage1_stream.h"
+#include "plan_kernels.h"
 #include "stage1_np.h"
 #include "prefill.h"
 namespace deft {

@@ -2,7 +2,7 @@
 //
 // Included by deft_kernels.hip (needs its typedefs and Stage1Params).
 //
-//   * plan kernels (once per decode step) pack each 128-slot KV tile's metadata into one 2 KB record:
+//   * plan kernels (plan_kernels.h, once per decode step) pack each 128-slot KV tile's metadata into one 2 KB record:
 //     the byte offset of every KV row in the pool, a 32-bit virtual-query mask per slot and the
 //     query / partial-row maps (PLAN_* below);
 //   * ONE workgroup per CU = 4 compute waves + 4 LOADER waves.  Only the loaders issue DMA, so the
@@ -558,881 +558,6 @@ __global__ __launch_bounds__(512, 2) void stage1_stream_kernel(StreamParams sp) 
         unext = u2;
     }
     finish();
-}
-
-// ---------------------------------------------------------------------------
-// Plan kernels (once per decode step): metadata -> unit list -> records
-// ---------------------------------------------------------------------------
-// Byte offset of a pool slot's row, or (bit 63 | offset into k_new / v_new) when the slot is one of
-// this step's new tokens and the caller uses the fused append.
-__device__ __forceinline__ int64_t plan_rowoff(int64_t slot, int64_t kv_stride_slot, const int32_t* cache_loc, int n_new,
-                                               int64_t new_row_bytes) {
-    for (int i = 0; i < n_new; ++i)
-        if ((int64_t)cache_loc[i] == slot) return ((int64_t)1 << 63) | ((int64_t)i * new_row_bytes);
-    return slot * kv_stride_slot * 2;  // fp16 bytes
-}
-
-struct UnitList {   // all int32, capacity `cap` each
-    int32_t* src;   // Flatten: block index; Node: entry index
-    int32_t* aux;   // Flatten: 0;           Node: 128-slot tile index within the entry
-    int32_t* pass;  // 32-row pass of the unit's virtual query rows
-    int32_t* flags; // bit 0: opens a run (query list differs from the previous unit's); bits 1..: unit index of the run's first unit
-    int32_t* prow;  // first partial row of the unit's tile
-    // tile-parallel record order (stage1_np.h), indexed by RECORD: which unit the record packs, and its chunk
-    int32_t* perm;   // record -> unit
-    int32_t* ch_n;   // tiles of the chunk this record leads (itself included); 0 = follower
-    int32_t* ch_fb;  // record index of the chunk's first follower (followers are consecutive records)
-    // union groups (Flatten, tile-parallel order), indexed by GROUP id = aux - 1: consecutive leaf tiles whose query
-    // lists differ but are small are folded by ONE workgroup over the union of their queries
-    int32_t* gn;    // queries in the union (<= UNION_CAP)
-    int32_t* gq;    // [UNION_CAP][cap] query rows of the union, ascending
-    int32_t* grow;  // [UNION_CAP][cap] the partial row that carries each union query (its first occurrence in the group)
-};
-constexpr int UNION_CAP = 4;
-
-// Record order for the tile-parallel stage 1 (one workgroup per chunk, stage1_np.h).  A run of `nt` units with
-// one query list is cut into S = ceil(nt / C) chunks; chunk p folds units p, p + S, p + 2S, ... of the run
-// (interleaved: the chunks of a run advance through the pool side by side, one contiguous front).  Records are
-// renumbered: the leaders of all chunks first (run by run, so the long shared-prefix chunks are dispatched first),
-// then the followers, those of one chunk consecutive.  hdr[1] = number of leaders.  One thread.
-// The runs come from a table the emitting thread kept in LDS (run k = units r0[k] .. r0[k] + nt[k] - 1, uni[k] = it is
-// a union group): walking the unit arrays in global memory instead costs one dependent load per unit (~100 us for the
-// north-star tree, once per decode step).
-struct RunTable {
-    int* r0;
-    int* nt;
-    int* uni;
-    int n;    // runs recorded
-    int cap;  // capacity; n > cap = overflow, fall back to scanning the unit arrays
-};
-__device__ inline void run_push(RunTable& rt, int r0, int nt, int uni) {
-    if (rt.n < rt.cap) {
-        rt.r0[rt.n] = r0;
-        rt.nt[rt.n] = nt;
-        rt.uni[rt.n] = uni;
-    }
-    ++rt.n;
-}
-
-__device__ inline void np_record_order(const UnitList& ul, int R, int Hkv, int G, int slots, int chunk_c, int32_t* hdr,
-                                       RunTable rt) {
-    if (rt.n > rt.cap) {  // rebuild the table is impossible: scan (slow path, huge trees only)
-        rt.n = 0;
-        rt.cap = 0;
-    }
-    const bool have = rt.cap > 0;
-    // run iteration: either the LDS table or a scan over flags / aux
-    auto for_runs = [&](auto&& fn) {
-        if (have) {
-            for (int k = 0; k < rt.n; ++k) fn(rt.r0[k], rt.nt[k], rt.uni[k]);
-        } else {
-            for (int r = 0; r < R;) {
-                const int id = ul.flags[r] >> 1;
-                int e = r + 1;
-                while (e < R && (ul.flags[e] >> 1) == id) ++e;
-                fn(r, e - r, ul.aux[r] > 0 ? 1 : 0);
-                r = e;
-            }
-        }
-    };
-    int C = chunk_c;
-    if (C <= 0) {
-        // Measured on MI355X (tools/np_sweep.sh): per-workgroup cost (descriptor round trip, 32-row epilogue) favours
-        // long chunks, the critical path and the number of resident slots bound them.  8 tiles for long shared
-        // prefixes, 4 from 8 tiles on, halved while fewer than ~0.3 workgroups per slot would be left.
-        int lmax = 0;
-        for_runs([&](int, int nt, int uni) {
-            if (!uni && nt > lmax) lmax = nt;
-        });
-        C = lmax >= 32 ? 8 : (lmax >= 8 ? 4 : (lmax >= 4 ? 2 : 1));
-        // ... and with GQA a chunk should not outlast the launch: the passes of a shared tile are separate chunks that
-        // hit L2, so with T tiles per resident slot in all, chunks longer than ~T leave a few workgroups running
-        // alone at the end (Llama-3 north-star tree: 2.8 tiles per slot, 8-tile chunks ran 18 us of a 25 us launch
-        // with a quarter of the slots occupied; 4-tile chunks: 19.9 us).  MHA, every tile from HBM, measured the
-        // other way (1-token branches, 2 tiles per slot: 8-tile chunks 19.1 us, 4-tile chunks 21.0).
-        if (G > 1) {
-            int64_t tiles_all = 0;
-            for_runs([&](int, int nt, int) { tiles_all += nt; });
-            int cmax = 1;
-            while (cmax < 8 && (int64_t)cmax * slots < tiles_all * Hkv) cmax <<= 1;
-            if (C > cmax) C = cmax;
-        }
-        for (; C > 1; C >>= 1) {
-            int64_t n = 0;
-            for_runs([&](int, int nt, int uni) { n += uni ? 1 : (nt + C - 1) / C; });
-            if (10 * n * Hkv >= 3LL * slots) break;
-        }
-    }
-    int NL = 0;
-    for_runs([&](int, int nt, int uni) { NL += uni ? 1 : (nt + C - 1) / C; });
-    int li = 0, fi = NL;
-    for_runs([&](int r, int nt, int uni) {
-        const int S = uni ? 1 : (nt + C - 1) / C;  // a union group is one chunk
-        for (int p = 0; p < S; ++p) {
-            const int cnt = (nt - p + S - 1) / S;
-            ul.perm[li] = r + p;
-            ul.ch_n[li] = cnt;
-            ul.ch_fb[li] = fi;
-            ++li;
-            for (int j = 1; j < cnt; ++j, ++fi) {
-                ul.perm[fi] = r + p + j * S;
-                ul.ch_n[fi] = 0;
-                ul.ch_fb[fi] = 0;
-            }
-        }
-    });
-    hdr[1] = NL;
-}
-
-// Record order of the tile-parallel stage 1, written by all waves of the unit kernel from its LDS run table (the
-// rules of np_record_order above, same result).  Called by every thread after the units are written; rT0 / rSp are
-// scratch arrays of run_cap words (the callers' run fields are dead by then), sMeta[2..3] two shared words.
-__device__ inline void record_order_parallel(const UnitList& ul, const RunTable& rt, int NR, int* rT0, int* rSp, int* sMeta,
-                                             int32_t* hdr, int Hkv, int G, int slots, int chunk_c) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-    __syncthreads();  // (rT0 / rSp are reused below)
-    // Wave 0: chunk length C from sums / maxima over the runs, then each run's first leader and first follower record
-    // by prefix sums over the runs' chunk counts.
-    if (threadIdx.x < 64) {
-        auto wave_sum = [&](auto&& f) {
-            int acc = 0;
-            for (int k = lane; k < NR; k += 64) acc += f(rt.nt[k], rt.uni[k]);
-            for (int m = 32; m > 0; m >>= 1) acc += __shfl_xor(acc, m, 64);
-            return acc;
-        };
-        int C = chunk_c;
-        if (C <= 0) {
-            int lmax = 0;
-            for (int k = lane; k < NR; k += 64)
-                if (!rt.uni[k] && rt.nt[k] > lmax) lmax = rt.nt[k];
-            for (int m = 32; m > 0; m >>= 1) lmax = max(lmax, __shfl_xor(lmax, m, 64));
-            C = lmax >= 32 ? 8 : (lmax >= 8 ? 4 : (lmax >= 4 ? 2 : 1));
-            if (G > 1) {
-                const int64_t tiles_all = wave_sum([](int nt, int) { return nt; });
-                int cmax = 1;
-                while (cmax < 8 && (int64_t)cmax * slots < tiles_all * Hkv) cmax <<= 1;
-                if (C > cmax) C = cmax;
-            }
-            for (; C > 1; C >>= 1) {
-                const int64_t n = wave_sum([C](int nt, int uni) { return uni ? 1 : (nt + C - 1) / C; });
-                if (10 * n * Hkv >= 3LL * slots) break;
-            }
-        }
-        int lead = 0, foll = 0;
-        for (int base = 0; base < NR; base += 64) {
-            const int k = base + lane;
-            const int nt = k < NR ? rt.nt[k] : 0;
-            const int S = k < NR ? (rt.uni[k] ? 1 : (nt + C - 1) / C) : 0;
-            int a = S, b = nt - S;  // inclusive scans over the lanes
-            for (int d = 1; d < 64; d <<= 1) {
-                const int ua = __shfl_up(a, d, 64), ub = __shfl_up(b, d, 64);
-                if (lane >= d) {
-                    a += ua;
-                    b += ub;
-                }
-            }
-            if (k < NR) {
-                rT0[k] = lead + a - S;
-                rSp[k] = foll + b - (nt - S);
-            }
-            lead += __shfl(a, 63, 64);
-            foll += __shfl(b, 63, 64);
-        }
-        if (lane == 0) {
-            sMeta[2] = C;
-            sMeta[3] = lead;
-            hdr[1] = lead;
-        }
-    }
-    __syncthreads();
-    {
-        const int C = sMeta[2], NL = sMeta[3];
-        for (int k = wave; k < NR; k += nwaves) {
-            const int first = rt.r0[k], nt = rt.nt[k];
-            const int S = rt.uni[k] ? 1 : (nt + C - 1) / C;  // a union group is one chunk
-            const int li = rT0[k], fi = NL + rSp[k];
-            const int q = nt / S, rem = nt - q * S;  // chunk p folds units p, p + S, ...: q + 1 of them for p < rem, else q
-            for (int u = lane; u < nt; u += 64) {
-                const int j = u / S, pc = u - j * S;
-                const int fb = fi + pc * (q - 1) + min(pc, rem);  // followers of the chunks before pc
-                if (j == 0) {
-                    ul.perm[li + pc] = first + pc;
-                    ul.ch_n[li + pc] = q + (pc < rem ? 1 : 0);
-                    ul.ch_fb[li + pc] = fb;
-                } else {
-                    ul.perm[fb + j - 1] = first + u;
-                    ul.ch_n[fb + j - 1] = 0;
-                    ul.ch_fb[fb + j - 1] = 0;
-                }
-            }
-        }
-    }
-}
-
-// Union group of leaf tiles starting at block t (Flatten, tile-parallel order): up to `ulen` consecutive blocks whose
-// query lists hold at most `ucap` queries each and at most `ucap` distinct queries together.  Returns the number of
-// blocks taken; uq / urow / un = the union's queries in order of first occurrence and the partial row (block_q
-// position) of each first occurrence.  sQ: the [NB][UNION_CAP] LDS table of the small blocks' lists, or nullptr
-// (lists read from block_q).  Everything lives in registers, every loop is unrolled over UNION_CAP.
-__device__ inline int union_group(int t, int NB, int ulen, int ucap, const int* sCnt, const int* sOff, const int* sQ,
-                                  const int64_t* block_q, int (&uq)[UNION_CAP], int (&urow)[UNION_CAP], int& un) {
-    static_assert(UNION_CAP == 4, "the query table is read as int4");
-    un = 0;
-#pragma unroll
-    for (int j = 0; j < UNION_CAP; ++j) uq[j] = 0, urow[j] = 0;
-    int te = t;
-    while (te < NB && te - t < ulen) {
-        const int cnt = sCnt[te];
-        if (cnt > ucap) break;
-        const int off = sOff[te];
-        int qv[UNION_CAP];
-        if (sQ) {
-            const int4 v = *reinterpret_cast<const int4*>(sQ + te * UNION_CAP);
-            qv[0] = v.x, qv[1] = v.y, qv[2] = v.z, qv[3] = v.w;
-        } else {
-#pragma unroll
-            for (int i = 0; i < UNION_CAP; ++i) qv[i] = i < cnt ? (int)block_q[off + i] : 0;
-        }
-        int add = 0;  // queries of block te that are new to the union
-#pragma unroll
-        for (int i = 0; i < UNION_CAP; ++i) {
-            bool found = false;
-#pragma unroll
-            for (int j = 0; j < UNION_CAP; ++j) found |= (j < un) & (uq[j] == qv[i]);
-            add += (i < cnt && !found) ? 1 : 0;
-        }
-        if (un + add > ucap) break;
-#pragma unroll
-        for (int i = 0; i < UNION_CAP; ++i) {
-            bool found = i >= cnt;
-#pragma unroll
-            for (int j = 0; j < UNION_CAP; ++j) found |= (j < un) & (uq[j] == qv[i]);
-            if (!found) {  // first occurrence: this tile's row carries the query's partial
-#pragma unroll
-                for (int j = 0; j < UNION_CAP; ++j)
-                    if (j == un) {
-                        uq[j] = qv[i];
-                        urow[j] = off + i;
-                    }
-                ++un;
-            }
-        }
-        ++te;
-    }
-    return te - t;
-}
-
-// Flatten: one workgroup.  Phase 1 (parallel over blocks): does block t open a run, how many passes.
-// Phase 2 (one thread): emit units run by run, pass-major inside a run so that consecutive units fold.
-// Tile-parallel order only (union_len > 1): short runs of leaf tiles with small, different query lists -- a branch's
-// tail shares a block with the next branch's head, so their lists go {a}, {a,b}, {b}, {b,c} ... -- are grouped, up
-// to union_len tiles and UNION_CAP queries, into ONE run over the union of their queries (per-slot masks keep a
-// query away from keys that are not on its path), so that one workgroup folds them and writes one partial per query.
-__global__ __launch_bounds__(1024) void flatten_units_kernel(const int64_t* block_q, const int64_t* block_q_cnts,
-                                                            const int64_t* block_q_offset, int NB, int G, int cap,
-                                                            UnitList ul, int32_t* hdr, int32_t* sched, int np, int Hkv,
-                                                            int slots, int chunk_c, int union_len, int taper, int run_cap,
-                                                            int qtab, int par) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    int* sOpen = reinterpret_cast<int*>(smem);  // [NB]
-    int* sPass = sOpen + NB;                    // [NB]
-    int* sCnt = sPass + NB;                     // [NB] block_q_cnts
-    int* sOff = sCnt + NB;                      // [NB] block_q_offset
-    // [NB][UNION_CAP] query lists of the blocks small enough to join a union group (qtab: the table fits in LDS):
-    // the one-thread phase below otherwise waits for a global load per leaf tile
-    int* sQ = sOff + NB;
-    int* sRun = sQ + (qtab ? UNION_CAP * NB : 0);
-    RunTable rt{sRun, sRun + run_cap, sRun + 2 * run_cap, 0, run_cap};
-    for (int t = threadIdx.x; t < NB; t += blockDim.x) {
-        const int cnt = (int)block_q_cnts[t];
-        sCnt[t] = cnt;
-        sOff[t] = (int)block_q_offset[t];
-        sPass[t] = (cnt * G + MQ - 1) / MQ;
-    }
-    __syncthreads();
-    // Does block t's query list differ from the one 1 / 2 / 3 / 4 blocks back?  Half a wave per block, lane i on
-    // list entry i (and i + 32, ... for longer lists), the five loads of an entry independent of each other: one
-    // round trip per block instead of one per list entry (a shared-prefix block has 32 entries, and a thread walking
-    // them with early exit waited ~1 us for each).
-    //   bit 0: opens a run;  bits 1..3: the list also differs from the one 2 / 3 / 4 blocks back (a node with more
-    //   than 32 queries is emitted by the reference as alternating blocks -- queries 0..31 / 32..63 / ... of the same
-    //   128 slots, tree_cache.py:763-799 -- so its blocks repeat with period ceil(queries / 32)); inside an ordinary
-    //   run the longer periods are never looked at and read as "differs".
-    {
-        const int lane = threadIdx.x & 63, half = lane >> 5, li = lane & 31;
-        const int nhw = (blockDim.x >> 6) * 2;
-        for (int t0 = (threadIdx.x >> 6) * 2; t0 < NB; t0 += nhw) {
-            const int t = t0 + half;
-            const bool live = t < NB;
-            const int cnt = live ? sCnt[t] : 0;
-            const int a = live ? sOff[t] : 0;
-            int diff = 0;  // bit pd-1: some entry of this lane differs from the block pd back
-            bool same_cnt[4];
-            for (int pd = 1; pd <= 4; ++pd) same_cnt[pd - 1] = live && t >= pd && sCnt[t - pd] == cnt;
-            for (int i = li; i < cnt; i += 32) {
-                const int64_t mine = block_q[a + i];
-                int64_t other[4];
-                for (int pd = 1; pd <= 4; ++pd) other[pd - 1] = same_cnt[pd - 1] ? block_q[sOff[t - pd] + i] : mine;
-                for (int pd = 1; pd <= 4; ++pd) diff |= (other[pd - 1] != mine) ? (1 << (pd - 1)) : 0;
-                if (qtab && cnt <= UNION_CAP) sQ[t * UNION_CAP + i] = (int)mine;
-            }
-            int bits = 0;
-            for (int pd = 1; pd <= 4; ++pd) {
-                const unsigned long long b = __ballot((diff >> (pd - 1)) & 1);
-                const bool any = ((half ? (b >> 32) : b) & 0xffffffffull) != 0;
-                bits |= (!same_cnt[pd - 1] || any) ? (1 << (pd - 1)) : 0;
-            }
-            if (!(bits & 1)) bits = 0xe;  // not opening a run: longer periods read as "differs"
-            if (live && li == 0) sOpen[t] = bits;
-        }
-    }
-    __syncthreads();
-    // Phase 1b (tile-parallel order): for every block, how many blocks a union group starting there would take
-    // (0 = none), one thread per block, into bits 8.. of sOpen -- the walk below then only looks the answer up.
-    const int ucap = (UNION_CAP * G <= MQ) ? UNION_CAP : MQ / G;  // union queries whose virtual rows fit one pass
-    auto union_len_at = [&](int t) {
-        // taper: the workgroups dispatched last should be short, so that the launch ends together -- the last
-        // `slots` leaf tiles (per head) stay single, the `2 slots` before them go in pairs
-        int ulen = union_len;
-        if (ulen <= 0) ulen = G > 1 ? 1 : ((int64_t)NB * Hkv < 2048 ? 4 : 3);  // measured, tools/np_sweep.sh / tools/ab.py
-        if (taper) {
-            const int64_t rest = (int64_t)(NB - t) * Hkv;
-            if (rest <= (int64_t)slots) ulen = 1;
-            else if (rest <= 3LL * slots) ulen = min(ulen, 2);
-        }
-        return ulen;
-    };
-    if (np && ucap >= 2)
-        for (int t = threadIdx.x; t < NB; t += blockDim.x) {
-            const int ulen = union_len_at(t);
-            int g = 0;
-            if (ulen > 1 && sCnt[t] <= ucap) {
-                bool short_run = NB - t < ulen;  // the run that opens at t is shorter than a group
-                for (int u = t + 1; u < t + ulen && u < NB; ++u) short_run |= (sOpen[u] & 1) != 0;
-                if (short_run) {
-                    int uq[UNION_CAP], urow[UNION_CAP], un;
-                    g = union_group(t, NB, ulen, ucap, sCnt, sOff, qtab ? sQ : nullptr, block_q, uq, urow, un);
-                    if (g < 2) g = 0;
-                }
-            }
-            sOpen[t] = (sOpen[t] & 0xf) | (g << 8);
-        }
-    __syncthreads();
-    // Phase 2: wave 0 walks the blocks and decides the runs (every lane takes the same decisions; the lanes only split
-    // the searches for the next run boundary).  `par`: every run gets an entry of the LDS table, and the units and the
-    // record order are then written by all waves (phases 3 and 4) -- one thread emitting them costs ~0.4 us per unit
-    // and pass, 75 us per decode step for the north-star tree and 2 ms for a 100k-token prefix under 48 branches.
-    // Otherwise (tables beyond the LDS) lane 0 emits as it walks.
-    int* sMeta = sRun + (par ? 5 : 3) * run_cap;  // [8]: units, runs, chunk length, leaders, "written by all waves"
-    int* rT0 = sRun + 3 * run_cap;    // par: first block of the run;      later: the run's first leader record
-    int* rSp = sRun + 4 * run_cap;    // par: block stride | pass << 8;   later: the run's first follower record - leaders
-    const int lane = threadIdx.x & 63;
-    const int par_req = par;
-    if (threadIdx.x < 64) {
-      // (a second walk, lane 0 emitting, if the runs did not fit the table: trees with very many small runs)
-      for (int attempt = 0; attempt < 2; ++attempt) {
-        par = par_req && attempt == 0;
-        rt.n = 0;
-        int r = 0, ng = 0;
-        // first block >= from whose sOpen has a bit of `mask` set (NB if none)
-        auto find = [&](int from, int mask) {
-            for (int base = from; base < NB; base += 64) {
-                const int t = base + lane;
-                const unsigned long long b = __ballot(t < NB && (sOpen[t] & mask));
-                if (b) return base + __ffsll((long long)b) - 1;
-            }
-            return NB;
-        };
-        // units of one run: blocks t0, t0 + st, ... < te, pass ps, aux (0, or union group + 1)
-        auto emit_run = [&](int t0, int te, int st, int aux, int ps) {
-            int n = st == 1 ? te - t0 : (te - t0 + st - 1) / st;
-            if (n > cap - r) n = cap - r;
-            if (n <= 0) return;
-            const int first = r;
-            if (par) {
-                if (lane == 0 && rt.n < rt.cap) {
-                    rt.r0[rt.n] = first;
-                    rt.nt[rt.n] = n;
-                    rt.uni[rt.n] = aux;
-                    rT0[rt.n] = t0;
-                    rSp[rt.n] = st | (ps << 8);
-                }
-                ++rt.n;
-            } else {
-                if (lane == 0)
-                    for (int j = 0; j < n; ++j) {
-                        const int t = t0 + j * st;
-                        ul.src[first + j] = t;
-                        ul.aux[first + j] = aux;
-                        ul.pass[first + j] = ps;
-                        ul.flags[first + j] = (first << 1) | (j == 0 ? 1 : 0);
-                        ul.prow[first + j] = sOff[t];
-                    }
-                if (rt.n < rt.cap && lane == 0) {
-                    rt.r0[rt.n] = first;
-                    rt.nt[rt.n] = n;
-                    rt.uni[rt.n] = aux;
-                }
-                ++rt.n;
-            }
-            r += n;
-        };
-        for (int ta = 0; ta < NB;) {
-            // ---- union group starting at ta (phase 1b) ------------------------------------------------------
-            const int glen = sOpen[ta] >> 8;
-            if (glen >= 2 && r < cap) {
-                if (!par && lane == 0) {  // (the parallel form writes the group in phase 3)
-                    int uq[UNION_CAP], urow[UNION_CAP], un;
-                    union_group(ta, NB, glen, ucap, sCnt, sOff, qtab ? sQ : nullptr, block_q, uq, urow, un);
-                    ul.gn[ng] = un;
-                    for (int j = 0; j < UNION_CAP; ++j) {
-                        ul.gq[j * cap + ng] = j < un ? uq[j] : 0;
-                        ul.grow[j * cap + ng] = j < un ? urow[j] : 0;
-                    }
-                }
-                emit_run(ta, ta + glen, 1, ng + 1, 0);
-                ++ng;
-                ta += glen;
-                continue;
-            }
-            const int tb = find(ta + 1, 1);
-            const int passes = sPass[ta];
-            const int cnt_a = sCnt[ta];
-            // ---- P query chunks of one node, alternating block by block: P interleaved runs ------------------
-            if (tb - ta == 1 && cnt_a == MQ) {  // (the first chunk of such a node is always full: cheap filter)
-                int P = 0;
-                for (int pd = 2; pd <= 4 && !P; ++pd) {
-                    bool rep = ta + 2 * pd <= NB;
-                    for (int t = ta + pd; rep && t < ta + 2 * pd; ++t) rep = !(sOpen[t] & (1 << (pd - 1)));
-                    if (rep) P = pd;
-                }
-                if (P) {
-                    const int te = find(ta + P, 1 << (P - 1));
-                    for (int par_ = 0; par_ < P; ++par_) {
-                        const int pp = sPass[ta + par_];
-                        for (int ps = 0; ps < pp; ++ps) emit_run(ta + par_, te, P, 0, ps);
-                    }
-                    ta = te;
-                    continue;
-                }
-            }
-            for (int ps = 0; ps < passes; ++ps) emit_run(ta, tb, 1, 0, ps);
-            ta = tb;
-        }
-        if (lane == 0) {
-            hdr[0] = r;
-            hdr[1] = 0;
-            sched[0] = 0;
-            for (int k = 0; k < NTICKET; ++k) sched[ticket_word(k)] = 0;
-            if (par && rt.n <= rt.cap) {
-                sMeta[0] = r;
-                sMeta[1] = rt.n;
-                sMeta[4] = 1;
-            } else if (!par) {
-                sMeta[4] = 0;
-                if (np) np_record_order(ul, r, Hkv, G, slots, chunk_c, hdr, rt);
-            }
-        }
-        if (!par || rt.n <= rt.cap) break;
-      }
-    }
-    __syncthreads();
-    if (!sMeta[4]) return;
-    // Phase 3: the units of run k, one wave per run, one lane per unit.
-    const int NR = sMeta[1];
-    const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-    for (int k = wave; k < NR; k += nwaves) {
-        const int first = rt.r0[k], n = rt.nt[k], aux = rt.uni[k], t0 = rT0[k], st = rSp[k] & 0xff, ps = rSp[k] >> 8;
-        if (aux > 0 && lane == 0) {  // a union group: its queries and the rows that carry their partials
-            int uq[UNION_CAP], urow[UNION_CAP], un;
-            union_group(t0, NB, sOpen[t0] >> 8, ucap, sCnt, sOff, qtab ? sQ : nullptr, block_q, uq, urow, un);
-            ul.gn[aux - 1] = un;
-            for (int j = 0; j < UNION_CAP; ++j) {
-                ul.gq[j * cap + aux - 1] = j < un ? uq[j] : 0;
-                ul.grow[j * cap + aux - 1] = j < un ? urow[j] : 0;
-            }
-        }
-        for (int j = lane; j < n; j += 64) {
-            const int t = t0 + j * st;
-            ul.src[first + j] = t;
-            ul.aux[first + j] = aux;
-            ul.pass[first + j] = ps;
-            ul.flags[first + j] = (first << 1) | (j == 0 ? 1 : 0);
-            ul.prow[first + j] = sOff[t];
-        }
-    }
-    if (!np) return;
-    // Phase 4: record order of the tile-parallel stage 1
-    record_order_parallel(ul, rt, NR, rT0, rSp, sMeta, hdr, Hkv, G, slots, chunk_c);
-}
-
-// One workgroup of 128 threads per unit (+ the sentinel): pack its record.
-__global__ __launch_bounds__(128) void flatten_records_kernel(const int64_t* block_q, const int64_t* block_q_cnts,
-                                                              const int64_t* block_bitmasks, const int64_t* block_kv,
-                                                              const int64_t* block_lens, int G, int rows, int64_t q_st,
-                                                              int64_t q_sh, int64_t kv_stride_slot, UnitList ul,
-                                                              const int32_t* hdr, char* plan, int32_t* row_q,
-                                                              const int32_t* cache_loc, int n_new, int64_t new_row_bytes,
-                                                              int np) {
-    const int r = blockIdx.x;
-    const int k = threadIdx.x;
-    const int R = hdr[0];
-    char* rec = plan + (int64_t)r * PLAN_BYTES;
-    int64_t* ro = reinterpret_cast<int64_t*>(rec + PLAN_ROWOFF);
-    uint32_t* mk = reinterpret_cast<uint32_t*>(rec + PLAN_MASK);
-    int32_t* desc = reinterpret_cast<int32_t*>(rec + PLAN_DESC);
-    if (r > R) {  // unused capacity: a tile-parallel workgroup that lands here must see "not a chunk leader"
-        if (k == 0) desc[4] = 0;
-        return;
-    }
-    if (r == R) {  // sentinel
-        ro[k] = 0;
-        mk[k] = 0u;
-        if (k == 0) {
-            desc[0] = 0;
-            desc[1] = 0;
-            desc[2] = 1;
-            desc[3] = -1;
-            desc[4] = 0;
-        }
-        return;
-    }
-    const int u = np ? ul.perm[r] : r;  // unit packed into this record
-    const int t = ul.src[u];
-    const int ps = ul.pass[u];
-    const int prow = ul.prow[u];
-    const int len = (int)block_lens[t];
-    const int cnt = (int)block_q_cnts[t];
-    const bool live = k < len;
-    ro[k] = plan_rowoff(block_kv[(int64_t)t * TILE + (live ? k : 0)], kv_stride_slot, cache_loc, n_new, new_row_bytes);
-    const uint32_t qmask = live ? (uint32_t)block_bitmasks[(int64_t)t * TILE + k] : 0u;
-    if (ul.aux[u] > 0) {
-        // ---- member of a union group: virtual row v = (union query v / G, head v % G); a query that is not in
-        //      this block's own list sees none of its slots ------------------------------------------------
-        const int gid = ul.aux[u] - 1;
-        const int cap = (int)(ul.gq - ul.gn);  // arrays are `cap` apart
-        const int un = ul.gn[gid];
-        const int nvu = un * G;
-        uint32_t vmu = 0u;
-        for (int j = 0; j < un; ++j) {
-            const int qv = ul.gq[j * cap + gid];
-            int idx = -1;
-            for (int i = 0; i < cnt; ++i)
-                if ((int)block_q[prow + i] == qv) idx = i;
-            if (idx >= 0 && ((qmask >> idx) & 1u)) vmu |= ((G >= 32 ? 0xffffffffu : ((1u << G) - 1u)) << (j * G));
-        }
-        mk[k] = vmu;
-        if (k < MQ) {
-            const int kk = k < nvu ? k : 0;  // rows beyond the union alias its first row (their mask bits are 0)
-            const int j = kk / G, g = kk % G;
-            reinterpret_cast<int32_t*>(rec + PLAN_QSRC)[k] = (int)(ul.gq[j * cap + gid] * q_st + g * q_sh);
-            reinterpret_cast<int32_t*>(rec + PLAN_OROW)[k] = k < nvu ? g * rows + ul.grow[j * cap + gid] : 0;
-            if (k < cnt) {  // this tile's own partial rows: live iff the group parks a query's partial there
-                int qlive = -1;
-                for (int j2 = 0; j2 < un; ++j2)
-                    if (ul.grow[j2 * cap + gid] == prow + k) qlive = ul.gq[j2 * cap + gid];
-                row_q[prow + k] = qlive;
-            }
-        }
-        if (k == 0) {
-            desc[0] = nvu;
-            desc[1] = prow;
-            desc[2] = ul.flags[u] & 1;
-            desc[3] = ul.flags[u] >> 1;
-            desc[4] = ul.ch_n[r];
-            desc[5] = ul.ch_fb[r];
-        }
-        return;
-    }
-    const int nv = min(MQ, cnt * G - MQ * ps);  // virtual rows of this pass
-    uint32_t vm = 0u;
-    for (int v = 0; v < nv; ++v) vm |= ((qmask >> ((MQ * ps + v) / G)) & 1u) << v;
-    mk[k] = vm;
-    if (k < MQ) {
-        int qs = 0, orow = 0;
-        if (k < nv) {
-            const int qi = (MQ * ps + k) / G, g = (MQ * ps + k) % G;
-            qs = (int)(block_q[prow + qi] * q_st + g * q_sh);
-            orow = g * rows + prow + qi;
-        } else if (nv > 0) {
-            qs = (int)(block_q[prow + (MQ * ps) / G] * q_st + ((MQ * ps) % G) * q_sh);  // alias a real row
-        }
-        reinterpret_cast<int32_t*>(rec + PLAN_QSRC)[k] = qs;
-        reinterpret_cast<int32_t*>(rec + PLAN_OROW)[k] = orow;
-        if (!np) {
-            if (ps == 0 && k < cnt) row_q[prow + k] = (int32_t)block_q[prow + k];
-        } else if (k < nv && (MQ * ps + k) % G == 0) {
-            // tile-parallel order: folding is decided here, so only a chunk leader's rows are live
-            const int qi = (MQ * ps + k) / G;
-            row_q[prow + qi] = ul.ch_n[r] > 0 ? (int32_t)block_q[prow + qi] : -1;
-        }
-    }
-    if (k == 0) {
-        desc[0] = nv;
-        desc[1] = prow;
-        desc[2] = ul.flags[u] & 1;
-        desc[3] = ul.flags[u] >> 1;  // run id: tiles with equal ids share one query list and may fold
-        desc[4] = np ? ul.ch_n[r] : 0;
-        desc[5] = np ? ul.ch_fb[r] : 0;
-    }
-}
-
-// Node mode (tree_attention.py:14-293): every entry (a node's KV x up to 32 of its queries) is cut into
-// 128-slot tiles; all live slots are visible to all of the entry's queries.  Consecutive tiles of one
-// entry fold, which is the reference's serial online-softmax walk (:230-276) without the serialisation.
-// Small entries (one tile, one pass) that follow each other are PACKED into one tile as long as their slots fit
-// in 128 and their virtual query rows in 32 -- per-slot row masks make that the same arithmetic (a Medusa step
-// has 64 one-token nodes: 2 tiles instead of 64).  A packed unit has aux = -(entries in it).
-// One workgroup.  Wave 0 walks the entries and decides the runs (packs are sequential by nature), all waves then write the units and the record order from the LDS run table -- as in
-// flatten_units_kernel; `par` = 0 (tables beyond the LDS) or an overflowing table: lane 0 emits as it walks.
-__global__ __launch_bounds__(1024) void node_units_kernel(const int64_t* node_kv_len, const int64_t* node_q_len, int NE, int G,
-                                                          int cap, int64_t rows_cap, UnitList ul, int32_t* hdr,
-                                                          int32_t* sched, int32_t* row_q, int np, int Hkv, int slots,
-                                                          int chunk_c, int run_cap, int par) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    int* sRun = reinterpret_cast<int*>(smem);
-    RunTable rt{sRun, sRun + run_cap, sRun + 2 * run_cap, 0, run_cap};
-    int* rT0 = sRun + 3 * run_cap;    // par: the run's entry;               later: its first leader record
-    int* rSp = sRun + 4 * run_cap;    // par: the run's pass;                later: its first follower record - leaders
-    int* rProw = sRun + 5 * run_cap;  // par: partial row of the run's first tile
-    int* rQl = sRun + 6 * run_cap;    // par: partial rows per tile
-    int* rAux = sRun + 7 * run_cap;   // par: 1 = tiles of one entry (aux = tile index), <= 0 = a pack (aux = -entries)
-    int* sMeta = sRun + (par ? 8 : 3) * run_cap;  // [8]
-    for (int64_t i = threadIdx.x; i < rows_cap; i += blockDim.x) row_q[i] = -1;
-    const int lane = threadIdx.x & 63;
-    const int par_req = par;
-    if (threadIdx.x < 64) {
-        for (int attempt = 0; attempt < 2; ++attempt) {
-            par = par_req && attempt == 0;
-            rt.n = 0;
-            int r = 0, rowbase = 0;
-            int pack_r = -1, pack_k = -1, pack_n = 0, pack_keys = 0, pack_rows = 0;  // open pack: unit, run, entries, slots, virtual rows
-            auto emit_run = [&](int e, int n, int ps, int prow0, int ql, int aux) {
-                if (n > cap - r) n = cap - r;
-                if (n <= 0) return;
-                const int first = r;
-                if (par) {
-                    if (lane == 0 && rt.n < rt.cap) {
-                        rt.r0[rt.n] = first;
-                        rt.nt[rt.n] = n;
-                        rt.uni[rt.n] = 0;
-                        rT0[rt.n] = e;
-                        rSp[rt.n] = ps;
-                        rProw[rt.n] = prow0;
-                        rQl[rt.n] = ql;
-                        rAux[rt.n] = aux;
-                    }
-                } else if (lane == 0) {
-                    for (int j = 0; j < n; ++j) {
-                        ul.src[first + j] = e;
-                        ul.aux[first + j] = aux > 0 ? j : aux;
-                        ul.pass[first + j] = ps;
-                        ul.flags[first + j] = (first << 1) | (j == 0 ? 1 : 0);
-                        ul.prow[first + j] = prow0 + j * ql;
-                    }
-                    if (rt.n < rt.cap) {
-                        rt.r0[rt.n] = first;
-                        rt.nt[rt.n] = n;
-                        rt.uni[rt.n] = 0;
-                    }
-                }
-                ++rt.n;
-                r += n;
-            };
-            // 64 entries at a time: lane i loads the lengths of entry base + i (one round trip per batch), the walk
-            // reads them with v_readlane -- scalar code, no memory access per entry (a Medusa step has 65 entries)
-            for (int base = 0; base < NE; base += 64) {
-              const int mine = base + lane;
-              const int vlen = mine < NE ? (int)node_kv_len[mine] : 0;
-              const int vql = mine < NE ? (int)node_q_len[mine] : 0;
-              const int lim = min(64, NE - base);
-              for (int i = 0; i < lim; ++i) {
-                const int e = base + i;
-                const int len = __builtin_amdgcn_readlane(vlen, i);
-                const int nt = (len + TILE - 1) / TILE;
-                const int ql = __builtin_amdgcn_readlane(vql, i);
-                const int npass = (ql * G + MQ - 1) / MQ;
-                if (nt == 1 && npass == 1 && r < cap) {
-                    if (pack_r >= 0 && pack_n < MQ && pack_keys + len <= TILE && pack_rows + ql * G <= MQ) {
-                        ++pack_n;
-                        pack_keys += len;
-                        pack_rows += ql * G;
-                        if (lane == 0) {
-                            if (!par) ul.aux[pack_r] = -pack_n;
-                            else if (pack_k < rt.cap) rAux[pack_k] = -pack_n;
-                        }
-                    } else {
-                        pack_r = r;
-                        pack_k = rt.n;
-                        pack_n = 1;
-                        pack_keys = len;
-                        pack_rows = ql * G;
-                        emit_run(e, 1, 0, rowbase, 0, 0);  // a pack of one is an ordinary unit
-                    }
-                } else {
-                    pack_r = -1;
-                    for (int ps = 0; ps < npass; ++ps) emit_run(e, nt, ps, rowbase, ql, 1);
-                }
-                rowbase += nt * ql;
-              }
-            }
-            if (lane == 0) {
-                hdr[0] = r;
-                hdr[1] = 0;
-                sched[0] = 0;
-                for (int k = 0; k < NTICKET; ++k) sched[ticket_word(k)] = 0;
-                if (par && rt.n <= rt.cap) {
-                    sMeta[0] = r;
-                    sMeta[1] = rt.n;
-                    sMeta[4] = 1;
-                } else if (!par) {
-                    sMeta[4] = 0;
-                    if (np) np_record_order(ul, r, Hkv, G, slots, chunk_c, hdr, rt);
-                }
-            }
-            if (!par || rt.n <= rt.cap) break;
-        }
-    }
-    __syncthreads();
-    if (!sMeta[4]) return;
-    const int NR = sMeta[1];
-    const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-    for (int k = wave; k < NR; k += nwaves) {
-        const int first = rt.r0[k], n = rt.nt[k], e = rT0[k], ps = rSp[k], prow0 = rProw[k], ql = rQl[k], aux = rAux[k];
-        for (int j = lane; j < n; j += 64) {
-            ul.src[first + j] = e;
-            ul.aux[first + j] = aux > 0 ? j : aux;
-            ul.pass[first + j] = ps;
-            ul.flags[first + j] = (first << 1) | (j == 0 ? 1 : 0);
-            ul.prow[first + j] = prow0 + j * ql;
-        }
-    }
-    if (!np) return;
-    record_order_parallel(ul, rt, NR, rT0, rSp, sMeta, hdr, Hkv, G, slots, chunk_c);
-}
-
-__global__ __launch_bounds__(128) void node_records_kernel(const int64_t* node_kv, const int64_t* node_kv_offset,
-                                                           const int64_t* node_kv_len, const int64_t* node_q,
-                                                           const int64_t* node_q_offset, const int64_t* node_q_len, int G,
-                                                           int rows, int64_t q_st, int64_t q_sh, int64_t kv_stride_slot,
-                                                           UnitList ul, const int32_t* hdr, char* plan, int32_t* row_q,
-                                                           const int32_t* cache_loc, int n_new, int64_t new_row_bytes,
-                                                           int np) {
-    const int r = blockIdx.x;
-    const int k = threadIdx.x;
-    const int R = hdr[0];
-    char* rec = plan + (int64_t)r * PLAN_BYTES;
-    int64_t* ro = reinterpret_cast<int64_t*>(rec + PLAN_ROWOFF);
-    uint32_t* mk = reinterpret_cast<uint32_t*>(rec + PLAN_MASK);
-    int32_t* desc = reinterpret_cast<int32_t*>(rec + PLAN_DESC);
-    if (r > R) {  // unused capacity (see flatten_records_kernel)
-        if (k == 0) desc[4] = 0;
-        return;
-    }
-    if (r == R) {  // sentinel
-        ro[k] = 0;
-        mk[k] = 0u;
-        if (k == 0) {
-            desc[0] = 0;
-            desc[1] = 0;
-            desc[2] = 1;
-            desc[3] = -1;
-            desc[4] = 0;
-        }
-        return;
-    }
-    const int u = np ? ul.perm[r] : r;  // unit packed into this record
-    if (k == 0) {
-        desc[4] = np ? ul.ch_n[r] : 0;
-        desc[5] = np ? ul.ch_fb[r] : 0;
-    }
-    const int e0 = ul.src[u], aux = ul.aux[u], ps = ul.pass[u], prow = ul.prow[u];
-    if (aux < 0) {
-        // ---- packed unit: entries e0 .. e0 - aux - 1, each one tile and one pass -------------------------
-        const int cnt = -aux;
-        // slot k -> (entry j, position inside it); virtual row k -> (entry j, query, head of the group)
-        int kj = -1, kpos = 0, kvb = 0, knv = 0;  // for the slot role
-        int vj = -1, vloc = 0, vrowbase = 0;      // for the row role (k < MQ)
-        int keys = 0, vrows = 0, rowsum = 0;
-        int first_slot_e = e0;
-        for (int j = 0; j < cnt; ++j) {
-            const int e = e0 + j;
-            const int len = (int)node_kv_len[e];
-            const int nv = (int)node_q_len[e] * G;
-            if (kj < 0 && k < keys + len) {
-                kj = e;
-                kpos = k - keys;
-                kvb = vrows;
-                knv = nv;
-            }
-            if (vj < 0 && k < vrows + nv) {
-                vj = e;
-                vloc = k - vrows;
-                vrowbase = rowsum;
-            }
-            keys += len;
-            vrows += nv;
-            rowsum += (int)node_q_len[e];
-        }
-        const bool live = kj >= 0;
-        const int64_t slot = live ? node_kv[node_kv_offset[kj] + kpos] : node_kv[node_kv_offset[first_slot_e]];
-        ro[k] = plan_rowoff(slot, kv_stride_slot, cache_loc, n_new, new_row_bytes);
-        mk[k] = live ? ((knv >= 32 ? 0xffffffffu : ((1u << knv) - 1u)) << kvb) : 0u;
-        if (k < MQ) {
-            int qs, orow = 0;
-            if (vj >= 0) {
-                const int qi = vloc / G, g = vloc % G;
-                const int64_t qrow = node_q[node_q_offset[vj] + qi];
-                qs = (int)(qrow * q_st + g * q_sh);
-                orow = g * rows + prow + vrowbase + qi;
-                if (g == 0) row_q[prow + vrowbase + qi] = (int32_t)qrow;
-            } else {
-                qs = (int)(node_q[node_q_offset[e0]] * q_st);  // alias a real row
-            }
-            reinterpret_cast<int32_t*>(rec + PLAN_QSRC)[k] = qs;
-            reinterpret_cast<int32_t*>(rec + PLAN_OROW)[k] = orow;
-        }
-        if (k == 0) {
-            desc[0] = vrows;
-            desc[1] = prow;
-            desc[2] = 1;
-            desc[3] = ul.flags[u] >> 1;
-        }
-        return;
-    }
-    const int e = e0, tt = aux;
-    const int64_t kv0 = node_kv_offset[e] + (int64_t)tt * TILE;
-    const int len = (int)min((int64_t)TILE, node_kv_len[e] - (int64_t)tt * TILE);
-    const int64_t q0 = node_q_offset[e];
-    const int ql = (int)node_q_len[e];
-    const int nv = min(MQ, ql * G - MQ * ps);
-    const bool live = k < len;
-    ro[k] = plan_rowoff(node_kv[kv0 + (live ? k : 0)], kv_stride_slot, cache_loc, n_new, new_row_bytes);
-    mk[k] = live ? (nv >= 32 ? 0xffffffffu : ((1u << nv) - 1u)) : 0u;
-    if (k < MQ) {
-        int qs = 0, orow = 0;
-        if (k < nv) {
-            const int qi = (MQ * ps + k) / G, g = (MQ * ps + k) % G;
-            qs = (int)(node_q[q0 + qi] * q_st + g * q_sh);
-            orow = g * rows + prow + qi;
-        } else if (nv > 0) {
-            qs = (int)(node_q[q0 + (MQ * ps) / G] * q_st + ((MQ * ps) % G) * q_sh);
-        }
-        reinterpret_cast<int32_t*>(rec + PLAN_QSRC)[k] = qs;
-        reinterpret_cast<int32_t*>(rec + PLAN_OROW)[k] = orow;
-        if (!np) {
-            if (ps == 0 && k < ql) row_q[prow + k] = (int32_t)node_q[q0 + k];
-        } else if (k < nv && (MQ * ps + k) % G == 0) {
-            const int qi = (MQ * ps + k) / G;
-            row_q[prow + qi] = ul.ch_n[r] > 0 ? (int32_t)node_q[q0 + qi] : -1;
-        }
-    }
-    if (k == 0) {
-        desc[0] = nv;
-        desc[1] = prow;
-        desc[2] = ul.flags[u] & 1;
-        desc[3] = ul.flags[u] >> 1;
-    }
 }
 
 }  // namespace deft
