@@ -16,7 +16,10 @@ for (Hq, Hkv, prefix, width) in [(4, 2, 100_000, 48), (2, 1, 450_000, 3), (32, 3
     for _ in range(3):
         for leaf in list(tree.leaves.values()): leaf.append_token(7)
         tree.alloc()
-    t = time.perf_counter(); md = deft_amd.TreeMetadata.from_tree_cache(tree); torch.cuda.synchronize(); t_md = time.perf_counter() - t
+    tms = []
+    for _ in range(6):  # host builder + one H2D copy; the first calls pay the pinned staging buffers
+        t = time.perf_counter(); md = deft_amd.TreeMetadata.from_tree_cache(tree); torch.cuda.synchronize(); tms.append(time.perf_counter() - t)
+    t_md = sorted(tms[2:])[2]
     q = torch.randn((width, Hq, D), dtype=torch.float16, device="cuda")
     kb, vb = pool.get_key_buffer(0), pool.get_value_buffer(0)
     o = torch.empty_like(q)
