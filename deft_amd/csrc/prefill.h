@@ -136,6 +136,8 @@ __global__ __launch_bounds__(512, 1) void prefill_kernel(PrefillParams p) {
             }
         }
         // ---- one online-softmax step per tile (one rescale of O per 128 keys) ----------------------------------
+        // (VALU-bound: per score one max, one fma feeding exp2, one conversion and half a dot2 -- the scale rides in the
+        //  fma, the row sum over the ROUNDED probabilities is a packed fp16 dot with ones)
         float mx = -INFINITY;
         if (diag) {
 #pragma unroll
@@ -143,31 +145,33 @@ __global__ __launch_bounds__(512, 1) void prefill_kernel(PrefillParams p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int key = key0 + 32 * kb + 8 * (r >> 2) + 4 * h + (r & 3);
-                    acc[kb][r] = key <= qi ? acc[kb][r] * p.scale_log2e : -INFINITY;  // causal; keys >= len are > every valid query
+                    acc[kb][r] = key <= qi ? acc[kb][r] : -INFINITY;  // causal; keys >= len are > every valid query
                     mx = fmaxf(mx, acc[kb][r]);
                 }
         } else {
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    acc[kb][r] *= p.scale_log2e;
-                    mx = fmaxf(mx, acc[kb][r]);
-                }
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, acc[kb][r]);
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        mx = fmaxf(mx, __shfl_xor(mx, 32)) * p.scale_log2e;  // (scaling is monotonic: the max of the scaled scores)
         const float m_new = fmaxf(m_run, mx);
         const float msafe = (m_new == -INFINITY) ? 0.f : m_new;
         const float alpha = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run - msafe);
         half8 pb[4][2];
         float sum = 0.f;
+        typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+        const half2v ones = {(_Float16)1.f, (_Float16)1.f};
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const _Float16 ph = (_Float16)__builtin_amdgcn_exp2f(acc[kb][r] - msafe);
-                pb[kb][r >> 3][r & 7] = ph;
-                sum += (float)ph;
+            for (int r = 0; r < 16; r += 2) {
+                const _Float16 p0 = (_Float16)__builtin_amdgcn_exp2f(__builtin_fmaf(acc[kb][r], p.scale_log2e, -msafe));
+                const _Float16 p1 = (_Float16)__builtin_amdgcn_exp2f(__builtin_fmaf(acc[kb][r + 1], p.scale_log2e, -msafe));
+                pb[kb][r >> 3][r & 7] = p0;
+                pb[kb][r >> 3][(r & 7) + 1] = p1;
+                const half2v pp = {p0, p1};
+                sum = __builtin_amdgcn_fdot2(pp, ones, sum, false);
             }
         sum += __shfl_xor(sum, 32);
         l_run = l_run * alpha + sum;
