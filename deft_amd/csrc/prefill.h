@@ -74,6 +74,11 @@ __global__ __launch_bounds__(512, 1) void prefill_kernel(PrefillParams p) {
     const int vtr_row_b = (4 * (tg >> 1) + (tx >> 2)) * D * 2 + (tx & 1) * 8;
     const int krow_b = c * D * 2;
     const int kcol_b = ((h ^ c) & 15) * 16;
+    int kfrag_b[KS], vfrag_b[4];  // per-lane fragment bases inside a stage
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) kfrag_b[ks] = krow_b + (kcol_b ^ (32 * ks));
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk) vfrag_b[blk] = vtr_row_b + vtr_col_b[blk];
 
     const char* kbase = reinterpret_cast<const char*>(p.k + start * p.k_st + (int64_t)kvh * p.k_sh);
     const char* vbase = reinterpret_cast<const char*>(p.v + start * p.v_st + (int64_t)kvh * p.v_sh);
@@ -126,12 +131,14 @@ __global__ __launch_bounds__(512, 1) void prefill_kernel(PrefillParams p) {
         for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[kb][r] = 0.f;
-        const int kblk = SM::K_OFF + stg * SM::STAGE + krow_b;
+        // (fragment addresses = a per-lane base kept in a register + the stage + an immediate: one add per k-step)
+        const int kstage = SM::K_OFF + stg * SM::STAGE;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
+            const char* kp = smem + (kfrag_b[ks] + kstage);
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb) {
-                const half8 a = *reinterpret_cast<const half8*>(smem + kblk + 32 * kb * D * 2 + (kcol_b ^ (32 * ks)));
+                const half8 a = *reinterpret_cast<const half8*>(kp + 32 * kb * D * 2);
                 acc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qf[ks], acc[kb], 0, 0, 0);
             }
         }
@@ -183,7 +190,10 @@ __global__ __launch_bounds__(512, 1) void prefill_kernel(PrefillParams p) {
                 for (int r = 0; r < 16; ++r) o[bk][r] *= alpha;
         }
         // ---- O^T += V^T P^T: 32 MFMAs on four independent accumulators -------------------------------------------
-        const int vblk = SM::V_OFF + stg * SM::STAGE + vtr_row_b;
+        const int vstage = SM::V_OFF + stg * SM::STAGE;
+        int vfrag[4];
+#pragma unroll
+        for (int bk = 0; bk < 4; ++bk) vfrag[bk] = vfrag_b[bk] + vstage;
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
 #pragma unroll
@@ -191,7 +201,7 @@ __global__ __launch_bounds__(512, 1) void prefill_kernel(PrefillParams p) {
 #pragma unroll
                 for (int bk = 0; bk < 4; ++bk) {
                     typedef __attribute__((address_space(3))) short4v* lds_s4;
-                    const int vb = vblk + 32 * kb * D * 2 + vtr_col_b[bk] + (16 * tt) * D * 2;
+                    const int vb = vfrag[bk] + (32 * kb * D * 2 + (16 * tt) * D * 2);
                     union {
                         short4v s4[2];
                         half8 h8;
