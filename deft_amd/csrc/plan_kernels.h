@@ -48,20 +48,12 @@ constexpr int UNION_CAP = 4;
 // a union group): walking the unit arrays in global memory instead costs one dependent load per unit (~100 us for the
 // north-star tree, once per decode step).
 struct RunTable {
-    int* r0;
-    int* nt;
-    int* uni;
+    int* r0;   // first unit of the run
+    int* nt;   // units (tiles) in the run
+    int* uni;  // non-zero: a union group = one chunk whatever its length (the Flatten kernel keeps the group id + 1 here)
     int n;    // runs recorded
     int cap;  // capacity; n > cap = overflow, fall back to scanning the unit arrays
 };
-__device__ inline void run_push(RunTable& rt, int r0, int nt, int uni) {
-    if (rt.n < rt.cap) {
-        rt.r0[rt.n] = r0;
-        rt.nt[rt.n] = nt;
-        rt.uni[rt.n] = uni;
-    }
-    ++rt.n;
-}
 
 __device__ inline void np_record_order(const UnitList& ul, int R, int Hkv, int G, int slots, int chunk_c, int32_t* hdr,
                                        RunTable rt) {
