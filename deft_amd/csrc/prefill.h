@@ -107,7 +107,13 @@ __global__ __launch_bounds__(512, 1) void prefill_kernel(PrefillParams p) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const half8*>(qp + 16 * ks);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // Q fragments and tile 0 (the compiler's own wait would do the same)
+    // Q fragments and tile 0.  The empty asm statements make the compiler itself wait for the Q loads HERE: otherwise its
+    // counter model carries "8 loads outstanding" into the tile loop and puts s_waitcnt vmcnt(7) .. vmcnt(0) in front of
+    // the first use of qf[0] .. qf[7] in EVERY iteration, where the only loads in flight are the next tile's DMA
+    // (inline asm, invisible to it).  Measured neutral (a tile lasts far longer than the DMA), kept for the cleaner loop.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]));
 
     float m_run = -INFINITY, l_run = 0.f;
     floatx16 o[4];
