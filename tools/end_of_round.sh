@@ -1,3 +1,7 @@
+#!/bin/bash
+# End-of-round evidence on ONE MI355X box (run as `gpurun -- bash tools/end_of_round.sh`): replay tables, the default
+# bench line, the rocprofv3 kernel-trace summary of the same command and the two PMC passes (own runs, --kernel-trace
+# only).  Writes gpurun_out/r1e/r1e_*; the files judged are copied from there into profiles/ (see profiles/README.md).
 R=$GRAFT_REPO_ROOT; export PYTHONPATH=$R; O=$R/gpurun_out/r1e; mkdir -p $O
 cd $R
 timeout 300 python tools/replay.py --task few_shot --width 32 --prompt-len 4096 --max-gen-len 200 --out $O/r1e_replay_few_shot_4kx32.json > $O/replay_fs.log 2>&1
