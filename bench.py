@@ -300,8 +300,8 @@ def main():
         achieved = algo / (s1["mean_us"] * 1e-6) / 1e9
         # HBM bytes per launch from the committed PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE, own pass,
         # x2 gfx950 correction, /opt/skills/guides/MI355X_MICROARCH.md "HBM"); null for workloads that were not profiled
-        kind = "stage1_np_kernel" if lib.deft_stage1_kind() == 1 else "stage1_stream_kernel"
-        pmc_file = "r1e_pmc_fetch_size_np.json" if kind == "stage1_np_kernel" else "r1_pmc_fetch_size.json"
+        kind = "stage1_np_kernel"
+        pmc_file = "r1e_pmc_fetch_size_np.json"
         traffic = None
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))

@@ -37,8 +37,11 @@ lib = _load()
 _vp, _i64, _i32, _f32, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_size_t
 
 lib.deft_abi_version.restype = C.c_int
-lib.deft_stage1_kind.restype = C.c_int
 lib.deft_plan_variant.restype = C.c_int
+lib.deft_debug_plan_form.argtypes = [C.c_int, C.c_int]  # test hooks, not part of include/deft_amd.h
+lib.deft_debug_plan_form.restype = None
+lib.deft_debug_two_launch.argtypes = [C.c_int]
+lib.deft_debug_two_launch.restype = None
 lib.deft_last_error.restype = C.c_char_p
 lib.deft_supported.argtypes = [_i32, _i32, _i32]
 lib.deft_supported.restype = C.c_int
@@ -117,7 +120,7 @@ for _f in ("deft_tree_free", "deft_tree_add_node", "deft_tree_remove_node", "def
     getattr(lib, _f).restype = C.c_int
 
 EXPORTED = (
-    "deft_abi_version", "deft_last_error", "deft_supported", "deft_stage1_kind", "deft_plan_variant",
+    "deft_abi_version", "deft_last_error", "deft_supported", "deft_plan_variant",
     "deft_flatten_workspace_bytes", "deft_flatten_plan_bytes", "deft_flatten_build_plan",
     "deft_flatten_decode_f16", "deft_flatten_decode_append_f16", "deft_flatten_stage1_f16",
     "deft_flatten_read_partials", "deft_node_workspace_bytes", "deft_node_plan_bytes", "deft_node_build_plan",

@@ -28,6 +28,7 @@
 //     one fp16 rounding.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 
@@ -76,7 +77,7 @@ struct Stage1Params {
     int64_t rows;  // partial rows per head (stride of partial_o / partial_lse)
     int Hkv, G;
     float scale_log2e;
-    int ablate;  // internal profiling knob (env DEFT_STAGE1_ABLATE): 1 no K/V loads, 2 no compute, 4 no PV
+    int ablate;  // experiments build only: profiling bits of the head_dim-128 kernel (stage1_np.h)
 };
 
 template <int D>
@@ -154,7 +155,7 @@ __global__ __launch_bounds__(256, 2) void stage1_kernel(Stage1Params p) {
 
     // ---- gather K and V rows of this KV head into LDS ---------------------------
     // wave w stages keys [32w, 32w+32): 16-byte pieces, CH lanes per row.
-    if (!(p.ablate & 1)) {
+    {
         constexpr int ITER = 32 * CH / 64;
         uintx4 kreg[ITER], vreg[ITER];
 #pragma unroll
@@ -179,12 +180,6 @@ __global__ __launch_bounds__(256, 2) void stage1_kernel(Stage1Params p) {
 
     const bool qvalid = c < cnt;
     const int64_t qrow = qvalid ? qrows[c] : 0;
-    if (p.ablate & 2) {
-        __syncthreads();
-        if (sK[tid] == (_Float16)12345.f) p.partial_lse[0] = 1.f;  // keeps the staging alive
-        return;
-    }
-
     for (int g = 0; g < p.G; ++g) {
         const int hq = kvh * p.G + g;
 
@@ -256,7 +251,7 @@ __global__ __launch_bounds__(256, 2) void stage1_kernel(Stage1Params p) {
         __syncthreads();
 
         // ---- O^T[d][query] = sum_key V[key][d] * P[query][key], 32 d-columns per wave ----
-        if (w < MB && !(p.ablate & 4)) {
+        if (w < MB) {
             floatx16 o;
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[r] = 0.f;
@@ -291,8 +286,9 @@ __global__ __launch_bounds__(256, 2) void stage1_kernel(Stage1Params p) {
 }
 
 }  // namespace deft
-#include "stage1_stream.h"
+#include "plan_records.h"
 #include "plan_kernels.h"
+#include "merge.h"
 #include "stage1_np.h"
 #include "prefill.h"
 namespace deft {
@@ -346,169 +342,23 @@ __global__ __launch_bounds__(256) void node_prep_kernel(const int64_t* node_kv_o
 }
 
 // ---------------------------------------------------------------------------
-// stage 2: merge the partial rows of one query, four heads per workgroup
+// stage 2 as its own launch (merge.h): one workgroup per (query, four heads), a wave per head.  Serves head_dim 64
+// and the stage-1-only entry points; head_dim 128 decodes merge inside the stage-1 launch (stage1_np.h).
 // ---------------------------------------------------------------------------
-// Deterministic gather (the reference scatters with fp32/fp16 atomics,
-// tree_attention.py:419-546): the four waves first list the partial rows of this query
-// in ascending row order (each wave scans a quarter of row_q), then every wave merges
-// one head: 64 candidate rows at a time it loads their log-sum-exps in parallel, keeps a
-// running true maximum (online rescale), and accumulates only the rows that carry a
-// partial (lse > -inf; rows folded into a group by the streaming stage 1 are skipped),
-// eight independent 512-byte row loads in flight per step.  fp32 accumulate, one fp16 rounding.
-constexpr int64_t MERGE_SEG = 15872;  // rows of row_q listed per pass: 4 x 3968 ints + 4 counters stay under 64 KB of LDS
+constexpr int MERGE_LIST_CAP = 4096;  // row ids per wave in LDS; longer lists are merged window by window
 template <int D>
 __global__ __launch_bounds__(256) void merge_kernel(const float* partial_o, const float* partial_lse, const int32_t* row_q,
-                                                     int64_t rows, _Float16* out, int64_t o_st, int64_t o_sh, int Hq,
-                                                     unsigned long long* dbg, int merge_flags) {
-    if (dbg && threadIdx.x == 0) atomicMin(dbg + 65538, wall_clock64());
-    constexpr int VEC = D / 64;  // output columns per lane
+                                                     int64_t rows, _Float16* out, int64_t o_st, int64_t o_sh, int Hq, int cap) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    int* sCnt = reinterpret_cast<int*>(smem);  // [4] matches found by each wave
-    int* sRows = sCnt + 4;                      // [4][quarter] matching rows, ascending within a quarter
-    const int tid = threadIdx.x;
-    const int w = tid >> 6;
-    const int lane = tid & 63;
-    const int qi = blockIdx.x;
-    const int hq = blockIdx.y * 4 + w;
-    const float* lse_h = partial_lse + (int64_t)(hq < Hq ? hq : 0) * rows;
-    const float* po_h = partial_o + (int64_t)(hq < Hq ? hq : 0) * rows * D + VEC * lane;
-    float acc[VEC];
-#pragma unroll
-    for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
-    float m_run = -INFINITY, L = 0.f;
-
-    // The row list is built MERGE_SEG rows of row_q at a time (one pass for every tree up to 16k partial rows;
-    // longer workspaces take further passes that carry the running maximum / sum / accumulator across).
-    for (int64_t seg0 = 0; seg0 < rows; seg0 += MERGE_SEG) {
-    const int64_t seg_rows = rows - seg0 < MERGE_SEG ? rows - seg0 : MERGE_SEG;
-    const int quarter = (int)(((seg_rows + 3) / 4 + 63) / 64 * 64);
-    if (seg0) __syncthreads();  // the previous pass's list is still being read
-
-    // 1. rows of this query inside this wave's quarter of the segment (eight independent loads per lane in
-    //    flight, then ordered ballots: one L2 round trip per 512 rows instead of one per 64)
-    {
-        int n = 0;
-        const int64_t lo = seg0 + (int64_t)w * quarter;
-        const int64_t hi = lo + quarter < seg0 + seg_rows ? lo + quarter : seg0 + seg_rows;
-        for (int64_t base = lo; base < hi; base += 512) {
-            int val[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int64_t i = base + 64 * u + lane;
-                val[u] = (i < hi) ? row_q[i] : -1;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const bool hit = val[u] == qi;
-                const unsigned long long mask = __ballot(hit);
-                if (hit) sRows[w * quarter + n + __popcll(mask & ((1ull << lane) - 1ull))] = (int)(base + 64 * u + lane);
-                n += __popcll(mask);
-            }
-        }
-        if (lane == 0) sCnt[w] = n;
-    }
-    __syncthreads();
-
-    // 2. merge this head's partials
-    // the four per-wave lists, read as one list in ascending row order
-    const int c0 = sCnt[0], c1 = sCnt[1], c2 = sCnt[2], c3 = sCnt[3];
-    const int n = hq < Hq ? c0 + c1 + c2 + c3 : 0;
-    // Few rows in a single pass (the usual case: one partial per chunk of the path): their log-sum-exps AND the rows
-    // themselves are requested together -- one memory round trip instead of two dependent ones (0.4-0.8 us per
-    // layer on every workload; DEFT_MERGE_FLAGS=1 switches it off for A/B).
-    constexpr int NF = 16;
-    if (rows <= MERGE_SEG && n > 0 && n <= NF && !(merge_flags & 1)) {
-        float lk[NF];
-        float vk[NF][VEC];
-#pragma unroll
-        for (int k = 0; k < NF; ++k) {
-            lk[k] = -INFINITY;
-#pragma unroll
-            for (int j = 0; j < VEC; ++j) vk[k][j] = 0.f;
-            if (k < n) {
-                int idx = k, sg = 0;
-                if (idx >= c0) { idx -= c0; sg = 1; if (idx >= c1) { idx -= c1; sg = 2; if (idx >= c2) { idx -= c2; sg = 3; } } }
-                const int r = sRows[sg * quarter + idx];
-                lk[k] = lse_h[r];
-#pragma unroll
-                for (int j = 0; j < VEC; ++j) vk[k][j] = po_h[(int64_t)r * D + j];
-            }
-        }
-        float mm = -INFINITY;
-#pragma unroll
-        for (int k = 0; k < NF; ++k) mm = fmaxf(mm, lk[k]);
-        if (mm > -INFINITY) {
-#pragma unroll
-            for (int k = 0; k < NF; ++k) {
-                const float wk = (lk[k] == -INFINITY) ? 0.f : __expf(lk[k] - mm);  // a row without a partial may hold anything
-                L += wk;
-#pragma unroll
-                for (int j = 0; j < VEC; ++j) acc[j] += (wk > 0.f) ? wk * vk[k][j] : 0.f;
-            }
-        }
-    } else
-    for (int base = 0; base < n; base += 64) {
-        const int g = base + lane;
-        const bool in = g < n;
-        int idx = g, seg = 0;
-        if (idx >= c0) { idx -= c0; seg = 1; if (idx >= c1) { idx -= c1; seg = 2; if (idx >= c2) { idx -= c2; seg = 3; } } }
-        const int r = in ? sRows[seg * quarter + idx] : 0;
-        const float lse = in ? lse_h[r] : -INFINITY;
-        float cm = lse;
-#pragma unroll
-        for (int sft = 32; sft > 0; sft >>= 1) cm = fmaxf(cm, __shfl_xor(cm, sft));
-        if (cm == -INFINITY) continue;  // wave-uniform
-        const float m_new = fmaxf(m_run, cm);
-        const float scale = (m_run == -INFINITY) ? 0.f : __expf(m_run - m_new);
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) acc[j] *= scale;
-        L *= scale;
-        m_run = m_new;
-        const float wgt = (lse == -INFINITY) ? 0.f : __expf(lse - m_new);
-        float ws = wgt;
-#pragma unroll
-        for (int sft = 32; sft > 0; sft >>= 1) ws += __shfl_xor(ws, sft);
-        L += ws;
-        unsigned long long live = __ballot(wgt > 0.f);
-        while (live) {  // wave-uniform loop, up to eight independent row loads per trip
-            constexpr int NU = 8;
-            int kk[NU];
-            float wk[NU];
-            int cnt = 0;
-#pragma unroll
-            for (int u = 0; u < NU; ++u) {
-                kk[u] = 0;
-                wk[u] = 0.f;
-                if (live) {
-                    const int bit = __builtin_ctzll(live);
-                    live &= live - 1;
-                    kk[u] = __shfl(r, bit);
-                    wk[u] = __shfl(wgt, bit);
-                    cnt = u + 1;
-                }
-            }
-            float v[NU][VEC];
-#pragma unroll
-            for (int u = 0; u < NU; ++u)
-                if (u < cnt) {
-#pragma unroll
-                    for (int j = 0; j < VEC; ++j) v[u][j] = po_h[(int64_t)kk[u] * D + j];
-                }
-#pragma unroll
-            for (int u = 0; u < NU; ++u)
-                if (u < cnt) {
-#pragma unroll
-                    for (int j = 0; j < VEC; ++j) acc[j] += wk[u] * v[u][j];
-                }
-        }
-    }
-    }  // segments
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;  // (uniform: buffer descriptors stay in SGPRs)
+    const int q = blockIdx.x, hq = blockIdx.y * 4 + w;
     if (hq >= Hq) return;
-    const float inv = L > 0.f ? 1.f / L : 0.f;
-    _Float16* dst = out + (int64_t)qi * o_st + (int64_t)hq * o_sh + VEC * lane;
-#pragma unroll
-    for (int j = 0; j < VEC; ++j) dst[j] = (_Float16)(acc[j] * inv);
-    if (dbg && lane == 0) atomicMax(dbg + 65539, wall_clock64());
+    int* list = reinterpret_cast<int*>(smem) + w * cap;
+    int have = scan_rows_wave(row_q, 0, rows < cap ? rows : cap, q, list, cap, lane);
+    if (rows > cap) have = -1;
+    __builtin_amdgcn_wave_barrier();
+    merge_pair_wave<D, 0>(partial_o, partial_lse, row_q, rows, q, hq, list, cap, have, out + (int64_t)q * o_st + (int64_t)hq * o_sh,
+                          lane);
 }
 
 // ---------------------------------------------------------------------------
@@ -535,7 +385,24 @@ __global__ __launch_bounds__(256) void kv_append_kernel(_Float16* k_base, _Float
 // ---------------------------------------------------------------------------
 // host-side launch helpers
 // ---------------------------------------------------------------------------
-static unsigned long long* g_stream_dbg = nullptr;  // internal profiling hook, see deft_debug_set_buffer
+// Experiment knobs exist in the experiments build only (`make exp`, -DDEFT_EXPERIMENTS -> libdeft_amd_exp.so): there a
+// knob reads its environment variable at every call, so that one process can A/B settings on the same pools
+// (tools/ab.py).  The shipped library reads no environment: every knob is its default.
+#ifdef DEFT_EXPERIMENTS
+static int knob(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+static unsigned long long* g_dbg = nullptr;  // per-workgroup time stamps, see deft_debug_set_buffer
+#else
+static inline int knob(const char*, int dflt) { return dflt; }
+static constexpr unsigned long long* g_dbg = nullptr;
+#endif
+// Test hook (deft_debug_plan_form, not in the public header): force the plan kernels' fallback forms, which are
+// otherwise reached only by trees whose run tables exceed the LDS.
+static int g_plan_serial = 0, g_plan_runcap = 0;
+// Test hook (deft_debug_two_launch): decode as stage 1 + merge_kernel instead of the single launch, for bit-for-bit A/B.
+static int g_two_launch = 0;
 
 static int check_launch(const char* what) {
     const hipError_t e = hipGetLastError();
@@ -546,45 +413,58 @@ static int check_launch(const char* what) {
     return DEFT_OK;
 }
 
-template <int D, int MODE>
-static int launch_stage1(const Stage1Params& p, int64_t tiles, hipStream_t stream) {
-    using SM = Stage1Smem<D>;
-    static bool attr_set = false;  // raising the dynamic-LDS cap is idempotent; races are harmless
-    if (!attr_set) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&stage1_kernel<D, MODE>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, SM::BYTES);
-        if (e != hipSuccess) {
-            set_error("hipFuncSetAttribute(stage1): %s", hipGetErrorString(e));
-            return DEFT_EHIP;
-        }
-        attr_set = true;
+// Per-device facts: the CU count, and which kernels already had their dynamic-LDS cap raised (a function attribute
+// is per device in HIP).
+struct DeviceState {
+    int cus = 0;
+    unsigned attrs = 0;
+};
+static DeviceState& dev_state() {
+    static DeviceState st[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    return st[dev];
+}
+static int num_cus() {
+    DeviceState& d = dev_state();
+    if (d.cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            d.cus = prop.multiProcessorCount;
+        if (d.cus <= 0) d.cus = 256;
     }
+    return d.cus;
+}
+enum : unsigned { ATTR_V1_64_0 = 1, ATTR_V1_64_1 = 2, ATTR_NP = 4, ATTR_UNITS = 8, ATTR_NODE_UNITS = 16, ATTR_PREFILL = 32, ATTR_TREE = 64 };
+static int raise_lds(const void* fn, int bytes, unsigned bit, const char* what) {  // idempotent; races are harmless
+    DeviceState& d = dev_state();
+    if (d.attrs & bit) return DEFT_OK;
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) {
+        set_error("hipFuncSetAttribute(%s): %s", what, hipGetErrorString(e));
+        return DEFT_EHIP;
+    }
+    d.attrs |= bit;
+    return DEFT_OK;
+}
+
+// head_dim 64: one workgroup per (tile, KV head)
+template <int MODE>
+static int launch_stage1_d64(const Stage1Params& p, int64_t tiles, hipStream_t stream) {
+    using SM = Stage1Smem<64>;
+    int rc = raise_lds(reinterpret_cast<const void*>(&stage1_kernel<64, MODE>), SM::BYTES, MODE ? ATTR_V1_64_1 : ATTR_V1_64_0, "stage1");
+    if (rc) return rc;
     const int64_t grid = tiles * p.Hkv;
     if (grid <= 0) return DEFT_OK;
-    static const int ablate = getenv("DEFT_STAGE1_ABLATE") ? atoi(getenv("DEFT_STAGE1_ABLATE")) : 0;
-    Stage1Params pp = p;
-    pp.ablate = ablate;
     if (grid > 0x7fffffffLL) {
         set_error("stage1 grid too large: %lld", (long long)grid);
         return DEFT_EINVAL;
     }
-    hipLaunchKernelGGL((stage1_kernel<D, MODE>), dim3((unsigned)grid), dim3(256), SM::BYTES, stream, pp);
+    hipLaunchKernelGGL((stage1_kernel<64, MODE>), dim3((unsigned)grid), dim3(256), SM::BYTES, stream, p);
     return check_launch("stage1 launch");
 }
 
-static int num_cus() {
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-            cus = prop.multiProcessorCount;
-        if (cus <= 0) cus = 256;
-    }
-    return cus;
-}
-
-// Flatten stage 1, streaming form (MHA, head_dim 128).  `plan` is workspace memory.
 // Optional fused paged append (deft_*_decode_append_f16): this step's new K/V rows and their pool slots.
 struct AppendArgs {
     const _Float16* k_new = nullptr;
@@ -592,6 +472,13 @@ struct AppendArgs {
     const int32_t* cache_loc = nullptr;
     int64_t new_st = 0;
     int n_new = 0;
+};
+
+// Where the merged output goes (single-launch decode)
+struct MergeArgs {
+    _Float16* out = nullptr;
+    int64_t o_st = 0, o_sh = 0;
+    int nq = 0, Hq = 0;
 };
 
 static UnitList unit_list(const PlanView& pv) {
@@ -610,24 +497,8 @@ static UnitList unit_list(const PlanView& pv) {
     return ul;
 }
 
-// Which stage-1 form serves head_dim 128: 1 = tile-parallel (stage1_np.h), 0 = streaming (stage1_stream.h).
-// The plan's record order depends on it, so the answer must be the same when a plan is built and when it is used:
-// it is a function of the environment only (read at every call so that one process can A/B both forms; callers
-// that cache plans key them by deft_stage1_kind()).
-static int stage1_kind() {
-    const char* e = getenv("DEFT_STAGE1_KERNEL");
-    if (e && !strcmp(e, "stream")) return 0;
-    if (e && !strcmp(e, "np")) return 1;
-    return 1;
-}
-static int np_chunk_env() {
-    const char* e = getenv("DEFT_NP_CHUNK");
-    return e ? atoi(e) : 0;
-}
-static int np_union_env() {  // tiles per union group of leaf tiles (1 = off, 0 = chosen by the plan kernel)
-    const char* e = getenv("DEFT_NP_UNION");
-    return e ? atoi(e) : 0;
-}
+static int np_chunk_knob() { return knob("DEFT_NP_CHUNK", 0); }  // tiles per chunk (0 = the plan kernel's rule)
+static int np_union_knob() { return knob("DEFT_NP_UNION", 0); }  // leaf tiles per union group (1 = off, 0 = rule)
 
 // Flatten plan: unit list (one workgroup) then one record per unit.
 static int launch_plan(const Stage1Params& p, int NB, const PlanView& pv, const AppendArgs& ap, hipStream_t stream) {
@@ -639,181 +510,108 @@ static int launch_plan(const Stage1Params& p, int NB, const PlanView& pv, const 
         set_error("plan: %d blocks exceed the unit kernel's LDS", NB);
         return DEFT_EUNSUPPORTED;
     }
-    static bool attr_set = false;
-    if (!attr_set) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&flatten_units_kernel),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)UNIT_LDS);
-        if (e != hipSuccess) {
-            set_error("hipFuncSetAttribute(flatten_units): %s", hipGetErrorString(e));
-            return DEFT_EHIP;
-        }
-        attr_set = true;
-    }
-    // block tables (+ the small blocks' query lists for the union groups of the tile-parallel order, when they fit) and
-    // a run table.  With an entry for every possible run (5 words each) the kernel writes units and record order with
-    // all its waves; otherwise one lane emits them and the table holds as many runs as fit (beyond that it scans).
-    const int np = stage1_kind();
-    const int qtab = np && sizeof(int) * 8 * (size_t)NB <= 100 * 1024;
+    int rc = raise_lds(reinterpret_cast<const void*>(&flatten_units_kernel), (int)UNIT_LDS, ATTR_UNITS, "flatten_units");
+    if (rc) return rc;
+    // block tables (+ the small blocks' query lists for the union groups, when they fit) and a run table.  With an
+    // entry for every possible run (5 words each) the kernel writes units and record order with all its waves;
+    // otherwise one lane emits them and the table holds as many runs as fit (beyond that it scans).
+    const int qtab = sizeof(int) * 8 * (size_t)NB <= 100 * 1024;
     const size_t blk = (qtab ? 8 : 4) * (size_t)NB;
     int64_t run_cap = pv.cap;
-    int par = !getenv("DEFT_PLAN_SERIAL");
+    int par = !g_plan_serial;
     if (par && sizeof(int) * (blk + 5 * (size_t)run_cap + 8) > UNIT_LDS) {  // as many runs as fit (the kernel falls back if more turn up)
         run_cap = ((int64_t)(UNIT_LDS / sizeof(int)) - (int64_t)blk - 8) / 5;
         if (run_cap < 256) par = 0, run_cap = pv.cap;
     }
-    if (par && getenv("DEFT_PLAN_RUNCAP")) run_cap = std::max(1, std::min((int)run_cap, atoi(getenv("DEFT_PLAN_RUNCAP"))));  // tests: force the fallback
+    if (par && g_plan_runcap > 0) run_cap = std::max(1, std::min((int)run_cap, g_plan_runcap));  // tests: force the fallback
     if (!par)
         while (sizeof(int) * (blk + 3 * (size_t)run_cap + 8) > UNIT_LDS && run_cap > 0) run_cap /= 2;
     const size_t lds = sizeof(int) * (blk + (par ? 5 : 3) * (size_t)run_cap + 8);
     const UnitList ul = unit_list(pv);
     hipLaunchKernelGGL(flatten_units_kernel, dim3(1), dim3(1024), lds, stream, p.block_q, p.block_q_cnts, p.block_q_offset, NB,
-                       p.G, (int)pv.cap, ul, pv.hdr, pv.sched, np, p.Hkv, 2 * num_cus(), np_chunk_env(), np ? np_union_env() : 1,
-                       getenv("DEFT_NP_TAPER") ? atoi(getenv("DEFT_NP_TAPER")) : 0, (int)run_cap, qtab, par);
-    int rc = check_launch("flatten units launch");
+                       p.G, (int)pv.cap, ul, pv.hdr, p.Hkv, 2 * num_cus(), np_chunk_knob(), np_union_knob(), (int)run_cap, qtab,
+                       par);
+    rc = check_launch("flatten units launch");
     if (rc) return rc;
     hipLaunchKernelGGL(flatten_records_kernel, dim3((unsigned)(pv.cap + 1)), dim3(128), 0, stream, p.block_q, p.block_q_cnts,
                        p.block_bitmasks, p.block_kv, p.block_lens, p.G, (int)p.rows, p.q_st, p.q_sh, p.kv_ss, ul, pv.hdr,
-                       pv.records, pv.row_q, ap.cache_loc, ap.n_new, ap.new_st * 2, np);
+                       pv.records, pv.row_q, ap.cache_loc, ap.n_new, ap.new_st * 2);
     return check_launch("flatten records launch");
 }
 
-// Stage 1, streaming form (head_dim 128; MHA and GQA).  Units per head are only known on the device
-// (plan header), so the grid is sized from the host-side upper bound.
-static int launch_stage1_stream(const Stage1Params& p, int64_t unit_cap, const PlanView& pv, const AppendArgs& ap,
-                                hipStream_t stream) {
-    using SM = StreamSmem<128>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&stage1_stream_kernel<128>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, SM::BYTES);
-        if (e != hipSuccess) {
-            set_error("hipFuncSetAttribute(stage1_stream): %s", hipGetErrorString(e));
-            return DEFT_EHIP;
-        }
-        attr_set = true;
-    }
-    if (unit_cap <= 0) return DEFT_OK;
-    const int64_t U_max = unit_cap * p.Hkv;
-    int64_t workers = (int64_t)num_cus();  // one workgroup per CU
-    static const int workers_env = getenv("DEFT_STREAM_WORKERS") ? atoi(getenv("DEFT_STREAM_WORKERS")) : 0;  // experiments
-    if (workers_env > 0) workers = workers_env;
-    if (workers > U_max) workers = U_max;
-    StreamParams sp{};
-    sp.s = p;
-    // profiling knobs, read at every launch so that one process can A/B them on the same pools
-    sp.s.ablate = getenv("DEFT_STAGE1_ABLATE") ? atoi(getenv("DEFT_STAGE1_ABLATE")) : 0;
-    sp.dyn_pct = getenv("DEFT_STREAM_DYN") ? atoi(getenv("DEFT_STREAM_DYN")) : 30;
-    sp.hdr = pv.hdr;
-    sp.cap = (int)pv.cap + 1;
-    sp.plan = pv.records;
-    sp.sched = pv.sched;
-    sp.dbg = g_stream_dbg;
-    sp.k_new = ap.k_new;
-    sp.v_new = ap.v_new;
-    sp.cache_loc = ap.cache_loc;
-    sp.new_st = ap.new_st;
-    sp.n_new = ap.k_new ? ap.n_new : 0;
-    hipLaunchKernelGGL((stage1_stream_kernel<128>), dim3((unsigned)workers), dim3(512), SM::BYTES, stream, sp);
-    return check_launch("stage1 stream launch");
-}
-
-// Stage 1, tile-parallel form (head_dim 128): one workgroup per record slot and KV head; slots that are not
-// chunk leaders exit at once (they are at the end of the grid).
+// Stage 1 (head_dim 128): one workgroup per record slot and KV head; slots that are not chunk leaders exit at once
+// (they are at the end of the stage-1 part of the grid).  With `mg`, merge workgroups follow them in the same grid
+// and the call is the whole decode (stage1_np.h); without, the caller launches merge_kernel.
+static bool can_fuse(int Hkv) { return Hkv <= FUSED_MAX_HKV && !g_two_launch; }
 static int launch_stage1_np(const Stage1Params& p, int64_t unit_cap, const PlanView& pv, const AppendArgs& ap,
-                            hipStream_t stream) {
+                            const MergeArgs* mg, hipStream_t stream) {
     using SM = NpSmem<128>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&stage1_np_kernel<128, false>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, SM::BYTES);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&stage1_np_kernel<128, true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, SM::BYTES);
-        if (e != hipSuccess) {
-            set_error("hipFuncSetAttribute(stage1_np): %s", hipGetErrorString(e));
-            return DEFT_EHIP;
-        }
-        attr_set = true;
-    }
+    int rc = raise_lds(reinterpret_cast<const void*>(&stage1_np_kernel<128>), SM::BYTES, ATTR_NP, "stage1_np");
+    if (rc) return rc;
     if (unit_cap <= 0) return DEFT_OK;
     int64_t grid = unit_cap * p.Hkv;
     if (grid > 0x7fffffffLL) {
         set_error("stage1 grid too large: %lld", (long long)grid);
         return DEFT_EINVAL;
     }
-    // Default: one workgroup per record slot, placed by the hardware dispatcher.  DEFT_NP_PERSIST=1 (experiment) keeps
-    // two resident workgroups per CU that draw chunks from a chip-wide ticket queue instead: it evens out the
-    // XCDs (the odd ones stream ~20 % slower and the dispatcher deals workgroups round-robin) but measured equal or
-    // slower on every workload (profiles/r1_np_*.txt): with ~2 chunks per workgroup there is little left to balance.
-    const int persist = getenv("DEFT_NP_PERSIST") ? atoi(getenv("DEFT_NP_PERSIST")) : 0;
     // The grid is sized by record CAPACITY (the leader count lives on the device); slots beyond the leaders exit at
     // once but still cost a dispatch each -- tens of thousands for the sequential comparator's one-query entries --
     // so the grid is capped at a few times the resident slots and a workgroup whose index has more than one item takes
-    // them in a loop (item, item + grid, ...).  Measured (same box, tools: DEFT_NP_GRIDCAP=0,1,2,3,8): 3 x slots is
-    // never worse and up to 22 % better for MHA (sequential north-star tree 261 -> 204 us, 400-token branches
-    // 56.8 -> 54.2); GQA, where every workgroup's tiles come from L2 after the first pass, prefers resident
-    // workgroups only (ToT-50 28.1 -> 24.0 us, 8-tree forest 65.5 -> 60.9).
+    // them in a loop (item, item + grid, ...).  Measured (same box, DEFT_NP_GRIDCAP=0,1,2,3,8 in the experiments
+    // build): 3 x slots is never worse and up to 22 % better for MHA (sequential north-star tree 261 -> 204 us,
+    // 400-token branches 56.8 -> 54.2); GQA, where every workgroup's tiles come from L2 after the first pass, prefers
+    // resident workgroups only (ToT-50 28.1 -> 24.0 us, 8-tree forest 65.5 -> 60.9).
     {
         // GQA launches whose whole record capacity is within 8 x the resident slots (a single tree: the Llama-3
         // north-star tree, ToT-50) have about one item per workgroup anyway and gain 2 us from 2 x slots.
         const bool small_gqa = unit_cap * p.Hkv <= 16LL * num_cus();
-        const int capx = getenv("DEFT_NP_GRIDCAP") ? atoi(getenv("DEFT_NP_GRIDCAP")) : (p.G > 1 ? (small_gqa ? 2 : 1) : 3);
+        const int capx = knob("DEFT_NP_GRIDCAP", p.G > 1 ? (small_gqa ? 2 : 1) : 3);
         const int64_t cap_wgs = (int64_t)capx * 2LL * num_cus();
         if (cap_wgs > 0 && grid > cap_wgs) grid = cap_wgs;
-    }
-    if (persist) {
-        int64_t resident = 2LL * num_cus();
-        if (getenv("DEFT_NP_WORKERS")) resident = atoi(getenv("DEFT_NP_WORKERS"));
-        if (grid > resident) grid = resident;
     }
     NpParams npp{};
     npp.s = p;
     npp.hdr = pv.hdr;
-    npp.sched = pv.sched;
-    npp.persist = persist;
-    npp.fast_n = getenv("DEFT_NP_FAST") ? atoi(getenv("DEFT_NP_FAST")) : 2 * num_cus();
-    npp.s.ablate = getenv("DEFT_STAGE1_ABLATE") ? atoi(getenv("DEFT_STAGE1_ABLATE")) : 0;
+    npp.fast_n = knob("DEFT_NP_FAST", 2 * num_cus());
+    npp.s.ablate = knob("DEFT_STAGE1_ABLATE", 0);
     npp.plan = pv.records;
     npp.k_new = ap.k_new;
     npp.v_new = ap.v_new;
     npp.cache_loc = ap.cache_loc;
     npp.new_st = ap.new_st;
     npp.n_new = ap.k_new ? ap.n_new : 0;
-    npp.dbg = g_stream_dbg;
-    if (persist)
-        hipLaunchKernelGGL((stage1_np_kernel<128, true>), dim3((unsigned)grid), dim3(256), SM::BYTES, stream, npp);
-    else
-        hipLaunchKernelGGL((stage1_np_kernel<128, false>), dim3((unsigned)grid), dim3(256), SM::BYTES, stream, npp);
+    npp.dbg = g_dbg;
+    npp.n_stage1 = (int)grid;
+    int64_t merge_wgs = 0;
+    if (mg && mg->nq > 0) {
+        // a wave per (query, head) pair, at most one merge workgroup per CU: half of the resident slots always stay
+        // with stage 1, so the merge waves' wait cannot starve the workgroups they wait for
+        const int64_t pairs = (int64_t)mg->nq * mg->Hq;
+        merge_wgs = std::min<int64_t>((pairs + 3) / 4, knob("DEFT_MERGE_WGS", num_cus()));
+        npp.fused = 1;
+        npp.row_q = pv.row_q;
+        npp.out = mg->out;
+        npp.o_st = mg->o_st;
+        npp.o_sh = mg->o_sh;
+        npp.nq = mg->nq;
+        npp.Hq = mg->Hq;
+    }
+    hipLaunchKernelGGL((stage1_np_kernel<128>), dim3((unsigned)(grid + merge_wgs)), dim3(256), SM::BYTES, stream, npp);
     return check_launch("stage1 np launch");
-}
-
-static int launch_stage1_d128(const Stage1Params& p, int64_t unit_cap, const PlanView& pv, const AppendArgs& ap,
-                              hipStream_t stream) {
-    return stage1_kind() ? launch_stage1_np(p, unit_cap, pv, ap, stream) : launch_stage1_stream(p, unit_cap, pv, ap, stream);
-}
-
-template <int MODE>
-static int dispatch_stage1(int D, const Stage1Params& p, int64_t tiles, hipStream_t stream) {
-    if (D == 128) return launch_stage1<128, MODE>(p, tiles, stream);
-    if (D == 64) return launch_stage1<64, MODE>(p, tiles, stream);
-    set_error("unsupported head_dim %d (supported: 64, 128)", D);
-    return DEFT_EUNSUPPORTED;
 }
 
 static int launch_merge(int D, const Workspace& ws, const int32_t* row_q, int64_t rows, void* out, int64_t o_st, int64_t o_sh,
                         int nq, int Hq, hipStream_t stream) {
     if (nq <= 0) return DEFT_OK;
-    const int64_t seg = rows < MERGE_SEG ? rows : MERGE_SEG;
-    const int64_t quarter = ((seg + 3) / 4 + 63) / 64 * 64;
-    const size_t lds = sizeof(int) * (size_t)(4 + 4 * quarter);
+    const int cap = (int)std::min<int64_t>(std::max<int64_t>(rows, 64), MERGE_LIST_CAP);
+    const size_t lds = sizeof(int) * 4 * (size_t)cap;
     dim3 grid((unsigned)nq, (unsigned)((Hq + 3) / 4));
-    const int mflags = getenv("DEFT_MERGE_FLAGS") ? atoi(getenv("DEFT_MERGE_FLAGS")) : 0;  // 1: no few-rows fast path (A/B)
     if (D == 128)
         hipLaunchKernelGGL((merge_kernel<128>), grid, dim3(256), lds, stream, ws.partial_o, ws.partial_lse, row_q, rows,
-                           static_cast<_Float16*>(out), o_st, o_sh, Hq, g_stream_dbg, mflags);
+                           static_cast<_Float16*>(out), o_st, o_sh, Hq, cap);
     else
         hipLaunchKernelGGL((merge_kernel<64>), grid, dim3(256), lds, stream, ws.partial_o, ws.partial_lse, row_q, rows,
-                           static_cast<_Float16*>(out), o_st, o_sh, Hq, g_stream_dbg, mflags);
+                           static_cast<_Float16*>(out), o_st, o_sh, Hq, cap);
     return check_launch("merge launch");
 }
 
@@ -852,21 +650,25 @@ extern "C" {
 
 int deft_abi_version(void) { return 1; }
 
-int deft_stage1_kind(void) { return stage1_kind(); }
-
-// Everything a plan's layout depends on besides the caller's arguments: the stage-1 form and the experiment knobs
-// of the plan kernels, folded into one integer (callers that cache plans key them by it; a C getenv costs ~0.1 us,
-// Python's os.environ.get several us per lookup).
+// Everything a plan's layout depends on besides the caller's arguments.  The shipped library has no such thing (0);
+// the experiments build folds its plan knobs into the value, so that callers which cache plans key them by it.
 int deft_plan_variant(void) {
-    const char* t = getenv("DEFT_NP_TAPER");
-    const char* rc = getenv("DEFT_PLAN_RUNCAP");  // (the two below change how the plan is built, not the plan: tests compare them)
-    return stage1_kind() | ((np_chunk_env() & 0xff) << 4) | ((np_union_env() & 0xff) << 12) | ((t ? atoi(t) & 0xf : 0) << 20) |
-           ((getenv("DEFT_PLAN_SERIAL") ? 1 : 0) << 24) | ((rc ? atoi(rc) & 0x3f : 0) << 25);
+    return ((np_chunk_knob() & 0xff) << 4) | ((np_union_knob() & 0xff) << 12) | ((g_plan_serial ? 1 : 0) << 24) |
+           ((g_plan_runcap & 0x3f) << 25);
 }
 
-// Internal profiling hook (not part of the public header): device buffer of
-// workers*16*8 u64 receiving s_memtime stamps of the streaming kernel's phases.
-void deft_debug_set_buffer(void* dev_ptr) { g_stream_dbg = static_cast<unsigned long long*>(dev_ptr); }
+// Internal hooks (not part of the public header).  deft_debug_plan_form: tests force the plan kernels' fallback
+// forms (serial: one lane emits the plan; runcap > 0: a run table of that many entries).  deft_debug_two_launch:
+// stage 1 and merge as two launches (the single-launch decode is checked against it bit for bit).  deft_debug_set_buffer
+// (experiments build only): device buffer of 8192 x 8 u64 receiving per-workgroup time stamps of stage 1.
+void deft_debug_plan_form(int serial, int runcap) {
+    g_plan_serial = serial;
+    g_plan_runcap = runcap;
+}
+void deft_debug_two_launch(int on) { g_two_launch = on; }
+#ifdef DEFT_EXPERIMENTS
+void deft_debug_set_buffer(void* dev_ptr) { g_dbg = static_cast<unsigned long long*>(dev_ptr); }
+#endif
 
 int deft_supported(int Hq, int Hkv, int D) { return (Hq > 0 && Hkv > 0 && Hq % Hkv == 0 && (D == 64 || D == 128)) ? 1 : 0; }
 
@@ -903,8 +705,10 @@ static int flatten_stage1_impl(const void* q, int64_t q_stride_tok, int64_t q_st
                                const int64_t* block_q_cnts, const int64_t* block_q_offset, const int64_t* block_bitmasks,
                                const int64_t* block_kv, const int64_t* block_lens, int NB, int P, int nq, int Hq, int Hkv,
                                int D, float scale, const void* plan, void* workspace, size_t workspace_bytes, void* stream,
-                               const AppendArgs& ap, Workspace* ws_out, const int32_t** row_q_out) {
+                               const AppendArgs& ap, const MergeArgs* mg, Workspace* ws_out, const int32_t** row_q_out,
+                               bool* merged) {
     // `workspace` doubles as the (unused) output pointer for the shared argument check
+    *merged = false;
     int rc = check_common(q, q_stride_tok, q_stride_head, k_base, v_base, kv_stride_slot, kv_stride_head, workspace, 2, 2,
                           nq, Hq, Hkv, D);
     if (rc) return rc;
@@ -942,9 +746,7 @@ static int flatten_stage1_impl(const void* q, int64_t q_stride_tok, int64_t q_st
     p.scale_log2e = scale * LOG2E;
     *ws_out = ws;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    // streaming form for MHA / head_dim 128 (env DEFT_STAGE1_VARIANT=tile forces the tile-per-workgroup form)
-    static const bool force_tile = getenv("DEFT_STAGE1_VARIANT") && !strcmp(getenv("DEFT_STAGE1_VARIANT"), "tile");
-    if (D == 128 && !force_tile) {
+    if (D == 128) {
         PlanView pv;
         if (plan) {
             pv = plan_view(const_cast<void*>(plan), cap, P);
@@ -954,15 +756,19 @@ static int flatten_stage1_impl(const void* q, int64_t q_stride_tok, int64_t q_st
             if (rc) return rc;
         }
         *row_q_out = pv.row_q;
-        return launch_stage1_d128(p, cap, pv, ap, st);
+        if (mg && can_fuse(Hkv)) {  // single-launch decode: stage 1 and merge in one grid
+            *merged = true;
+            return launch_stage1_np(p, cap, pv, ap, mg, st);
+        }
+        return launch_stage1_np(p, cap, pv, ap, nullptr, st);
     }
-    if (ap.k_new) {  // tile-per-workgroup form: separate append launch first
+    if (ap.k_new) {  // head_dim 64 (tile-per-workgroup form): separate append launch first
         rc = deft_kv_append_f16(const_cast<void*>(k_base), const_cast<void*>(v_base), kv_stride_slot, kv_stride_head,
                                 ap.cache_loc, ap.k_new, ap.v_new, ap.new_st, ap.n_new, Hkv, D, stream);
         if (rc) return rc;
     }
     *row_q_out = ws.row_q;
-    return dispatch_stage1<0>(D, p, NB, st);
+    return launch_stage1_d64<0>(p, NB, st);
 }
 
 size_t deft_flatten_plan_bytes(int NB, int P, int Hq, int Hkv) {
@@ -1016,9 +822,10 @@ int deft_flatten_stage1_f16(const void* q, int64_t q_stride_tok, int64_t q_strid
     }
     Workspace ws;
     const int32_t* row_q = nullptr;
+    bool merged = false;
     return flatten_stage1_impl(q, q_stride_tok, q_stride_head, k_base, v_base, kv_stride_slot, kv_stride_head, block_q,
                                block_q_cnts, block_q_offset, block_bitmasks, block_kv, block_lens, NB, P, nq, Hq, Hkv, D,
-                               scale, plan, workspace, workspace_bytes, stream, AppendArgs(), &ws, &row_q);
+                               scale, plan, workspace, workspace_bytes, stream, AppendArgs(), nullptr, &ws, &row_q, &merged);
 }
 
 static int flatten_decode_impl(const void* q, int64_t q_stride_tok, int64_t q_stride_head, const void* k_base,
@@ -1039,10 +846,17 @@ static int flatten_decode_impl(const void* q, int64_t q_stride_tok, int64_t q_st
     }
     Workspace ws;
     const int32_t* row_q = nullptr;
+    MergeArgs mg;
+    mg.out = static_cast<_Float16*>(out);
+    mg.o_st = o_stride_tok;
+    mg.o_sh = o_stride_head;
+    mg.nq = nq;
+    mg.Hq = Hq;
+    bool merged = false;
     rc = flatten_stage1_impl(q, q_stride_tok, q_stride_head, k_base, v_base, kv_stride_slot, kv_stride_head, block_q,
                              block_q_cnts, block_q_offset, block_bitmasks, block_kv, block_lens, NB, P, nq, Hq, Hkv, D, scale,
-                             plan, workspace, workspace_bytes, stream, ap, &ws, &row_q);
-    if (rc) return rc;
+                             plan, workspace, workspace_bytes, stream, ap, &mg, &ws, &row_q, &merged);
+    if (rc || merged) return rc;
     return launch_merge(D, ws, row_q, P, out, o_stride_tok, o_stride_head, nq, Hq, static_cast<hipStream_t>(stream));
 }
 
@@ -1083,38 +897,28 @@ int deft_flatten_decode_append_f16(const void* q, int64_t q_stride_tok, int64_t 
 static int launch_node_plan(const Stage1Params& p, int NE, int64_t rows_cap, const PlanView& pv, const AppendArgs& ap,
                             hipStream_t stream) {
     const UnitList ul = unit_list(pv);
-    const int np = stage1_kind();
     // a run table in LDS: 8 words per run and every possible run (the kernel then writes units and
     // record order with all its waves), or as many runs as fit (it falls back to one lane if more turn up)
     constexpr size_t UNIT_LDS = 156 * 1024;
-    const size_t blk = 0;
-    static bool attr_set = false;
-    if (!attr_set) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&node_units_kernel),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)UNIT_LDS);
-        if (e != hipSuccess) {
-            set_error("hipFuncSetAttribute(node_units): %s", hipGetErrorString(e));
-            return DEFT_EHIP;
-        }
-        attr_set = true;
-    }
+    int rc = raise_lds(reinterpret_cast<const void*>(&node_units_kernel), (int)UNIT_LDS, ATTR_NODE_UNITS, "node_units");
+    if (rc) return rc;
     int64_t run_cap = pv.cap > 0 ? pv.cap : 1;
-    int par = !getenv("DEFT_PLAN_SERIAL");
-    if (par && sizeof(int) * (blk + 8 * (size_t)run_cap + 8) > UNIT_LDS) {
-        run_cap = ((int64_t)(UNIT_LDS / sizeof(int)) - (int64_t)blk - 8) / 8;
+    int par = !g_plan_serial;
+    if (par && sizeof(int) * (8 * (size_t)run_cap + 8) > UNIT_LDS) {
+        run_cap = ((int64_t)(UNIT_LDS / sizeof(int)) - 8) / 8;
         if (run_cap < 256) par = 0, run_cap = pv.cap > 0 ? pv.cap : 1;
     }
-    if (par && getenv("DEFT_PLAN_RUNCAP")) run_cap = std::max(1, std::min((int)run_cap, atoi(getenv("DEFT_PLAN_RUNCAP"))));  // tests: force the fallback
+    if (par && g_plan_runcap > 0) run_cap = std::max(1, std::min((int)run_cap, g_plan_runcap));  // tests: force the fallback
     if (!par)
-        while (sizeof(int) * (blk + 3 * (size_t)run_cap + 8) > UNIT_LDS && run_cap > 1) run_cap /= 2;
-    hipLaunchKernelGGL(node_units_kernel, dim3(1), dim3(1024), sizeof(int) * (blk + (par ? 8 : 3) * (size_t)run_cap + 8), stream,
-                       p.node_kv_len, p.node_q_len, NE, p.G, (int)pv.cap, rows_cap, ul, pv.hdr, pv.sched, pv.row_q, np, p.Hkv,
-                       2 * num_cus(), np_chunk_env(), (int)run_cap, par);
-    int rc = check_launch("node units launch");
+        while (sizeof(int) * (3 * (size_t)run_cap + 8) > UNIT_LDS && run_cap > 1) run_cap /= 2;
+    hipLaunchKernelGGL(node_units_kernel, dim3(1), dim3(1024), sizeof(int) * ((par ? 8 : 3) * (size_t)run_cap + 8), stream,
+                       p.node_kv_len, p.node_q_len, NE, p.G, (int)pv.cap, rows_cap, ul, pv.hdr, pv.row_q, p.Hkv,
+                       2 * num_cus(), np_chunk_knob(), (int)run_cap, par);
+    rc = check_launch("node units launch");
     if (rc) return rc;
     hipLaunchKernelGGL(node_records_kernel, dim3((unsigned)(pv.cap + 1)), dim3(128), 0, stream, p.node_kv, p.node_kv_offset,
                        p.node_kv_len, p.node_q, p.node_q_offset, p.node_q_len, p.G, (int)p.rows, p.q_st, p.q_sh, p.kv_ss, ul,
-                       pv.hdr, pv.records, pv.row_q, ap.cache_loc, ap.n_new, ap.new_st * 2, np);
+                       pv.hdr, pv.records, pv.row_q, ap.cache_loc, ap.n_new, ap.new_st * 2);
     return check_launch("node records launch");
 }
 
@@ -1221,8 +1025,7 @@ static int node_decode_impl(const void* q, int64_t q_stride_tok, int64_t q_strid
     p.Hkv = Hkv;
     p.G = G;
     p.scale_log2e = scale * LOG2E;
-    static const bool force_tile = getenv("DEFT_STAGE1_VARIANT") && !strcmp(getenv("DEFT_STAGE1_VARIANT"), "tile");
-    if (D == 128 && !force_tile) {  // streaming stage 1 on node tiles
+    if (D == 128) {
         PlanView pv;
         if (plan) {
             pv = plan_view(const_cast<void*>(plan), tiles * G, rows);
@@ -1231,7 +1034,16 @@ static int node_decode_impl(const void* q, int64_t q_stride_tok, int64_t q_strid
             rc = launch_node_plan(p, NE, rows, pv, ap, st);
             if (rc) return rc;
         }
-        rc = launch_stage1_d128(p, tiles * G, pv, ap, st);
+        if (can_fuse(Hkv)) {  // single-launch decode
+            MergeArgs mg;
+            mg.out = static_cast<_Float16*>(out);
+            mg.o_st = o_stride_tok;
+            mg.o_sh = o_stride_head;
+            mg.nq = nq;
+            mg.Hq = Hq;
+            return launch_stage1_np(p, tiles * G, pv, ap, &mg, st);
+        }
+        rc = launch_stage1_np(p, tiles * G, pv, ap, nullptr, st);
         if (rc) return rc;
         return launch_merge(D, ws, pv.row_q, rows, out, o_stride_tok, o_stride_head, nq, Hq, st);
     }
@@ -1251,7 +1063,7 @@ static int node_decode_impl(const void* q, int64_t q_stride_tok, int64_t q_strid
     rc = check_launch("node prep launch");
     if (rc) return rc;
     p.desc = ws.desc;
-    rc = dispatch_stage1<1>(D, p, tiles, st);
+    rc = launch_stage1_d64<1>(p, tiles, st);
     if (rc) return rc;
     return launch_merge(D, ws, ws.row_q, rows, out, o_stride_tok, o_stride_head, nq, Hq, st);
 }
@@ -1597,15 +1409,9 @@ extern "C" int deft_prefill_f16(const void* q, int64_t q_stride_tok, int64_t q_s
         return DEFT_EINVAL;
     }
     using SM = PrefillSmem<128>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&prefill_kernel<128>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, SM::BYTES);
-        if (e != hipSuccess) {
-            set_error("hipFuncSetAttribute(prefill): %s", hipGetErrorString(e));
-            return DEFT_EHIP;
-        }
-        attr_set = true;
+    {
+        const int rc = raise_lds(reinterpret_cast<const void*>(&prefill_kernel<128>), SM::BYTES, ATTR_PREFILL, "prefill");
+        if (rc) return rc;
     }
     PrefillParams p{};
     p.q = static_cast<const _Float16*>(q);

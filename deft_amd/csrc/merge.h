@@ -1,0 +1,136 @@
+// Stage 2: log-sum-exp merge of the partial rows of one (query, head) pair by ONE wave
+// (the reference: tree_attention.py:296-546, two kernels with fp32 / fp16 atomics and a host-side div_).
+//
+// Deterministic gather: the wave lists the partial rows of its query in ascending row order (scan of row_q, ordered
+// ballots), takes the TRUE maximum of their log-sum-exps, accumulates in fp32 in list order and rounds to fp16 once.
+// Used by the stand-alone merge kernel (merge_kernel, deft_kernels.hip) and by the merge waves at the end of the
+// single-launch decode kernel (stage1_np.h) -- same code, same bits.
+//
+// Included by deft_kernels.hip after plan_records.h.
+#pragma once
+
+namespace deft {
+
+// Running state of one pair's merge; lists longer than the wave's LDS area are merged piecewise (online rescale).
+struct MergeState {
+    float m = -INFINITY;  // running maximum of the log-sum-exps seen
+    float L = 0.f;        // sum of exp(lse - m)
+    floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+};
+
+// Rows [from, to) of row_q that belong to query q, ascending, appended to list[0 .. cap); returns how many were found
+// (only the first `cap` are stored).  Eight independent loads per lane in flight: one L2 round trip per 512 rows.
+__device__ inline int scan_rows_wave(const int32_t* row_q, int64_t from, int64_t to, int q, int* list, int cap, int lane) {
+    int n = 0;
+    for (int64_t base = from; base < to; base += 512) {
+        int val[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int64_t i = base + 64 * u + lane;
+            val[u] = (i < to) ? row_q[i] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const bool hit = val[u] == q;
+            const unsigned long long mask = __ballot(hit);
+            const int pos = n + __popcll(mask & ((1ull << lane) - 1ull));
+            if (hit && pos < cap) list[pos] = (int)(base + 64 * u + lane);
+            n += __popcll(mask);
+        }
+    }
+    return n;
+}
+
+// Fold rows list[0 .. n) of one head into the state.  CP = cache policy of the loads (0: ordinary; CP_SYS: the rows
+// were written by other workgroups of this launch).  po / lse: buffer resources over the head's partial rows.
+template <int D, int CP>
+__device__ inline void merge_accumulate(MergeState& st, __amdgpu_buffer_rsrc_t po, __amdgpu_buffer_rsrc_t lse, const int* list,
+                                        int n, int lane) {
+    constexpr int LPR = D / 4;     // lanes per row (16 bytes each)
+    constexpr int RPS = 64 / LPR;  // rows per wave-wide load
+    constexpr int NU = 8;          // loads in flight per lane
+    const int sub = lane / LPR, col = lane % LPR;
+    for (int cbase = 0; cbase < n; cbase += 64) {
+        const int cn = n - cbase < 64 ? n - cbase : 64;
+        float x = -INFINITY;
+        if (lane < cn) x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(lse, list[cbase + lane] * 4, 0, CP));
+        uintx4 v[NU];
+        auto load_batch = [&](int b) {
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const int j = b * NU * RPS + u * RPS + sub;
+                v[u] = uintx4{0u, 0u, 0u, 0u};
+                if (j < cn) v[u] = __builtin_amdgcn_raw_buffer_load_b128(po, list[cbase + j] * (D * 4) + col * 16, 0, CP);
+            }
+        };
+        load_batch(0);  // requested together with the log-sum-exps: one memory round trip for up to NU * RPS rows
+        float cm = x;
+#pragma unroll
+        for (int sft = 32; sft > 0; sft >>= 1) cm = fmaxf(cm, __shfl_xor(cm, sft));
+        if (cm == -INFINITY) continue;  // wave-uniform: nothing live in this chunk
+        const float m_new = fmaxf(st.m, cm);
+        const float scale = (st.m == -INFINITY) ? 0.f : __expf(st.m - m_new);
+        const float wl = (x == -INFINITY) ? 0.f : __expf(x - m_new);
+        float ws = wl;
+#pragma unroll
+        for (int sft = 32; sft > 0; sft >>= 1) ws += __shfl_xor(ws, sft);
+        st.L = st.L * scale + ws;
+        st.acc *= scale;
+        st.m = m_new;
+        for (int b = 0; b * NU * RPS < cn; ++b) {
+            if (b > 0) load_batch(b);
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const int j = b * NU * RPS + u * RPS + sub;
+                const float wj = __shfl(wl, j & 63);
+                if (j < cn && wj > 0.f) {
+                    const floatx4 f = __builtin_bit_cast(floatx4, v[u]);
+                    st.acc += f * wj;
+                }
+            }
+        }
+    }
+}
+
+// Sum the row groups of the wave and write the pair's output row (fp16, one rounding).
+template <int D>
+__device__ inline void merge_finish(const MergeState& st, _Float16* dst, int lane) {
+    constexpr int LPR = D / 4;
+    floatx4 a = st.acc;
+#pragma unroll
+    for (int off = LPR; off < 64; off <<= 1)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[e] += __shfl_xor(a[e], off);
+    if (lane < LPR) {
+        const float inv = st.L > 0.f ? 1.f / st.L : 0.f;
+        half2v lo = {(_Float16)(a[0] * inv), (_Float16)(a[1] * inv)};
+        half2v hi = {(_Float16)(a[2] * inv), (_Float16)(a[3] * inv)};
+        *reinterpret_cast<half2v*>(dst + 4 * lane) = lo;  // output rows are only 4-byte aligned by contract
+        *reinterpret_cast<half2v*>(dst + 4 * lane + 2) = hi;
+    }
+}
+
+// One (query, head) pair, start to finish: rows of the query from row_q (list area of `cap` ints in LDS, longer
+// lists in further passes), merge, store.  `have` >= 0: list[0 .. min(have, cap)) already holds the first scan.
+template <int D, int CP>
+__device__ inline void merge_pair_wave(const float* partial_o, const float* partial_lse, const int32_t* row_q, int64_t rows,
+                                       int q, int hq, int* list, int cap, int have, _Float16* dst, int lane) {
+    const __amdgpu_buffer_rsrc_t po = make_rsrc(partial_o + (int64_t)hq * rows * D);
+    const __amdgpu_buffer_rsrc_t ls = make_rsrc(partial_lse + (int64_t)hq * rows);
+    MergeState st;
+    if (have >= 0 && have <= cap) {  // the usual case: the whole list was scanned ahead of time
+        merge_accumulate<D, CP>(st, po, ls, list, have, lane);
+    } else {
+        // a query with more rows than the list area: window by window over row_q (each window holds at most cap rows)
+        for (int64_t from = 0; from < rows; from += cap) {
+            const int64_t to = from + cap < rows ? from + cap : rows;
+            const int n = scan_rows_wave(row_q, from, to, q, list, cap, lane);
+            __builtin_amdgcn_wave_barrier();
+            merge_accumulate<D, CP>(st, po, ls, list, n, lane);
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    merge_finish<D>(st, dst, lane);
+}
+
+}  // namespace deft

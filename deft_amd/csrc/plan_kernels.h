@@ -1,8 +1,7 @@
 // Plan kernels (once per decode step, shared by all layers): TreeMetadata arrays -> unit list -> one 2 KiB record per
 // 128-slot tile, in the order the stage-1 kernels consume them.
 //
-// Included by deft_kernels.hip after stage1_stream.h (record layout PLAN_*, TILE, MQ, the scheduler words) and before
-// stage1_np.h.  Flatten (tree_cache.py:618-881 blocks): flatten_units_kernel + flatten_records_kernel; Node
+// Included by deft_kernels.hip after plan_records.h (record layout PLAN_*, header words) and before stage1_np.h.  Flatten (tree_cache.py:618-881 blocks): flatten_units_kernel + flatten_records_kernel; Node
 // (tree_attention.py:14-293 entries): node_units_kernel + node_records_kernel.  The unit kernels are one workgroup:
 // wave 0 decides the runs, all waves write units and the tile-parallel record order ("Plan kernels").
 #pragma once
@@ -271,9 +270,9 @@ __device__ inline int union_group(int t, int NB, int ulen, int ucap, const int* 
 // query away from keys that are not on its path), so that one workgroup folds them and writes one partial per query.
 __global__ __launch_bounds__(1024) void flatten_units_kernel(const int64_t* block_q, const int64_t* block_q_cnts,
                                                             const int64_t* block_q_offset, int NB, int G, int cap,
-                                                            UnitList ul, int32_t* hdr, int32_t* sched, int np, int Hkv,
-                                                            int slots, int chunk_c, int union_len, int taper, int run_cap,
-                                                            int qtab, int par) {
+                                                            UnitList ul, int32_t* hdr, int Hkv, int slots, int chunk_c,
+                                                            int union_len, int run_cap, int qtab, int par) {
+    constexpr int np = 1;  // records in the tile-parallel order (leaders first); the only stage-1 form
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int* sOpen = reinterpret_cast<int*>(smem);  // [NB]
     int* sPass = sOpen + NB;                    // [NB]
@@ -332,15 +331,9 @@ __global__ __launch_bounds__(1024) void flatten_units_kernel(const int64_t* bloc
     // (0 = none), one thread per block, into bits 8.. of sOpen -- the walk below then only looks the answer up.
     const int ucap = (UNION_CAP * G <= MQ) ? UNION_CAP : MQ / G;  // union queries whose virtual rows fit one pass
     auto union_len_at = [&](int t) {
-        // taper: the workgroups dispatched last should be short, so that the launch ends together -- the last
-        // `slots` leaf tiles (per head) stay single, the `2 slots` before them go in pairs
+        (void)t;
         int ulen = union_len;
         if (ulen <= 0) ulen = G > 1 ? 1 : ((int64_t)NB * Hkv < 2048 ? 4 : 3);  // measured, tools/np_sweep.sh / tools/ab.py
-        if (taper) {
-            const int64_t rest = (int64_t)(NB - t) * Hkv;
-            if (rest <= (int64_t)slots) ulen = 1;
-            else if (rest <= 3LL * slots) ulen = min(ulen, 2);
-        }
         return ulen;
     };
     if (np && ucap >= 2)
@@ -463,8 +456,9 @@ __global__ __launch_bounds__(1024) void flatten_units_kernel(const int64_t* bloc
         if (lane == 0) {
             hdr[0] = r;
             hdr[1] = 0;
-            sched[0] = 0;
-            for (int k = 0; k < NTICKET; ++k) sched[ticket_word(k)] = 0;
+            hdr[HDR_ERR] = 0;
+            hdr[HDR_MDONE] = 0;  // arrival counters of the single-launch decode: 0 between launches
+            for (int k = 0; k < FUSED_MAX_HKV; ++k) hdr[HDR_DONE + HDR_DONE_STRIDE * k] = 0;
             if (par && rt.n <= rt.cap) {
                 sMeta[0] = r;
                 sMeta[1] = rt.n;
@@ -513,8 +507,8 @@ __global__ __launch_bounds__(128) void flatten_records_kernel(const int64_t* blo
                                                               const int64_t* block_lens, int G, int rows, int64_t q_st,
                                                               int64_t q_sh, int64_t kv_stride_slot, UnitList ul,
                                                               const int32_t* hdr, char* plan, int32_t* row_q,
-                                                              const int32_t* cache_loc, int n_new, int64_t new_row_bytes,
-                                                              int np) {
+                                                              const int32_t* cache_loc, int n_new, int64_t new_row_bytes) {
+    constexpr int np = 1;
     const int r = blockIdx.x;
     const int k = threadIdx.x;
     const int R = hdr[0];
@@ -628,8 +622,9 @@ __global__ __launch_bounds__(128) void flatten_records_kernel(const int64_t* blo
 // flatten_units_kernel; `par` = 0 (tables beyond the LDS) or an overflowing table: lane 0 emits as it walks.
 __global__ __launch_bounds__(1024) void node_units_kernel(const int64_t* node_kv_len, const int64_t* node_q_len, int NE, int G,
                                                           int cap, int64_t rows_cap, UnitList ul, int32_t* hdr,
-                                                          int32_t* sched, int32_t* row_q, int np, int Hkv, int slots,
-                                                          int chunk_c, int run_cap, int par) {
+                                                          int32_t* row_q, int Hkv, int slots, int chunk_c, int run_cap,
+                                                          int par) {
+    constexpr int np = 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int* sRun = reinterpret_cast<int*>(smem);
     RunTable rt{sRun, sRun + run_cap, sRun + 2 * run_cap, 0, run_cap};
@@ -720,8 +715,9 @@ __global__ __launch_bounds__(1024) void node_units_kernel(const int64_t* node_kv
             if (lane == 0) {
                 hdr[0] = r;
                 hdr[1] = 0;
-                sched[0] = 0;
-                for (int k = 0; k < NTICKET; ++k) sched[ticket_word(k)] = 0;
+                hdr[HDR_ERR] = 0;
+                hdr[HDR_MDONE] = 0;  // arrival counters of the single-launch decode: 0 between launches
+                for (int k = 0; k < FUSED_MAX_HKV; ++k) hdr[HDR_DONE + HDR_DONE_STRIDE * k] = 0;
                 if (par && rt.n <= rt.cap) {
                     sMeta[0] = r;
                     sMeta[1] = rt.n;
@@ -757,8 +753,8 @@ __global__ __launch_bounds__(128) void node_records_kernel(const int64_t* node_k
                                                            const int64_t* node_q_offset, const int64_t* node_q_len, int G,
                                                            int rows, int64_t q_st, int64_t q_sh, int64_t kv_stride_slot,
                                                            UnitList ul, const int32_t* hdr, char* plan, int32_t* row_q,
-                                                           const int32_t* cache_loc, int n_new, int64_t new_row_bytes,
-                                                           int np) {
+                                                           const int32_t* cache_loc, int n_new, int64_t new_row_bytes) {
+    constexpr int np = 1;
     const int r = blockIdx.x;
     const int k = threadIdx.x;
     const int R = hdr[0];

@@ -1,0 +1,77 @@
+// Per-step plan: record layout, header words and the LDS-DMA / wait helpers shared by the plan kernels
+// (plan_kernels.h, tree_plan.h) and the stage-1 kernel (stage1_np.h).
+//
+// Included by deft_kernels.hip (needs its typedefs and Stage1Params).
+#pragma once
+
+namespace deft {
+
+typedef int32_t intx4 __attribute__((ext_vector_type(4)));
+typedef short short4v __attribute__((ext_vector_type(4)));
+
+// One plan record per work unit of ONE KV head (+ a sentinel record after the last one).  A unit is a
+// 128-slot KV tile together with up to 32 "virtual query rows": row v = (query qi, head g of the GQA
+// group), g fastest.  A tile whose cnt * G rows exceed 32 appears once per 32-row pass; passes of a run
+// of tiles with one query list are ordered pass-major so that consecutive records fold.
+constexpr int PLAN_BYTES = 2048;
+constexpr int PLAN_ROWOFF = 0;   // int64[128]  byte offset of each slot's row in the pool (pads alias slot 0)
+constexpr int PLAN_MASK = 1024;  // uint32[128] bit v set <=> virtual row v sees the slot (0 for pads)
+constexpr int PLAN_DESC = 1536;  // int32[8]    n_vrows, prow, opens_run, run_id, chunk tiles (0 = follower), first follower record, -, -
+constexpr int PLAN_QSRC = 1600;  // int32[32]   element offset of row v's Q vector from q + kvh*G*q_stride_head
+constexpr int PLAN_OROW = 1728;  // int32[32]   partial row of row v, relative to kvh*G*rows: g*rows + prow + qi
+
+// Plan header (4 KB in front of the records), int32 words:
+//   hdr[0]  R   records (units) per KV head          hdr[1]  NL  chunk leaders (work items per KV head)
+//   hdr[2]  error flags raised by the kernels (bit 0: a merge wave gave up waiting; bit 1: sequential plan overflow)
+//   hdr[HDR_MDONE]           merge waves that have finished (single-launch decode; the last one re-arms the words)
+//   hdr[HDR_DONE + 16 kvh]   chunks of KV head kvh whose partial rows are in memory; one cache line per head
+// All counters are 0 between launches: a plan serves ONE launch at a time (the layers of a decode step run in
+// stream order).
+constexpr int PLAN_HDR = 4096;
+constexpr int HDR_ERR = 2;
+constexpr int HDR_MDONE = 16;
+constexpr int HDR_DONE = 128;
+constexpr int HDR_DONE_STRIDE = 16;
+constexpr int FUSED_MAX_HKV = (PLAN_HDR / 4 - HDR_DONE) / HDR_DONE_STRIDE;  // 56 KV heads fit the header
+
+// 64 lanes x 16 bytes, global (per-lane address) -> LDS (lds_dst + 16*lane).  M0 is not
+// otherwise used by the kernels (checked in the .s), so it is written, not saved.
+__device__ __forceinline__ void dma16(const void* gsrc, uint32_t lds_dst) {
+    asm volatile(
+        "s_mov_b32 m0, %1\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %0, off"
+        :
+        : "v"(gsrc), "s"(lds_dst)
+        : "memory");
+}
+
+// 64 lanes x 4 bytes, global (per-lane address) -> LDS (lds_dst + 4*lane)
+__device__ __forceinline__ void dma4(const void* gsrc, uint32_t lds_dst) {
+    asm volatile(
+        "s_mov_b32 m0, %1\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dword %0, off"
+        :
+        : "v"(gsrc), "s"(lds_dst)
+        : "memory");
+}
+
+// All DMA issue and all waits on it are inline asm: hipcc neither counts asm VMEM operations nor drains them at a
+// raw s_barrier, which is what lets loads stay in flight across barriers (cdna_hip_programming.md section 5.7).
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Buffer resource over a float array for loads / stores with an explicit cache policy (the hand-off of partial rows
+// from the stage-1 workgroups to the merge waves of the same launch: write-through `sc0 sc1` stores and `sc0 sc1` loads on
+// both sides, MI355X_MICROARCH.md "Workgroup dispatch, XCD placement & inter-workgroup visibility").
+constexpr int CP_SYS = 17;  // cache policy bits: sc0 (1) | sc1 (16)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
+}
+
+}  // namespace deft

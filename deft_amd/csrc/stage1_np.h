@@ -1,12 +1,12 @@
 // Stage 1 (Flatten and Node), tile-parallel form: one workgroup per CHUNK of KV tiles, two workgroups per CU,
 // placed by the hardware dispatcher.
 //
-// Included by deft_kernels.hip after stage1_stream.h (shares its plan records, dma16, wait_vm, lds_barrier).
+// Included by deft_kernels.hip after plan_records.h, plan_kernels.h and merge.h.
 //
-// The streaming form (stage1_stream.h) reaches the practical HBM rate in its steady state but pays ~8 us per launch
-// around it: a dependent ramp, and a tail in which persistent workgroups that prefetch five tiles ahead cannot
-// rebalance.  A plain gather dispatched by the hardware (tools/probes/gather_dma.hip) has neither.  This kernel keeps
-// that shape and still folds the shared prefix:
+// A persistent streaming form (round 1) reached the practical HBM rate in its steady state but
+// paid ~8 us per launch around it: a dependent ramp, and a tail in which persistent workgroups that prefetch five
+// tiles ahead cannot rebalance.  A plain gather dispatched by the hardware (tools/probes/gather_dma.hip) has neither.
+// This kernel keeps that shape and still folds the shared prefix:
 //
 //   * a workgroup = 4 waves = one chunk: a leader record and its followers (np_record_order), all tiles of ONE run,
 //     i.e. with one query list, taken at a stride through the run;
@@ -23,17 +23,30 @@
 //   * no record staging: a workgroup's record index is its block index, so the descriptor (scalar load), the row
 //     offsets and masks (4-byte LDS-DMA into a per-wave area) and nothing else stand between launch and the first
 //     K/V request.  Records beyond the leaders exit at once; they sit at the end of the grid.
+//
+// Single-launch decode (`fused`): the LAST workgroups of the grid are merge workgroups.  Each of their waves owns
+// (query, head) pairs: it lists the query's partial rows from row_q while stage 1 is still running, waits until every
+// chunk of its KV head has delivered (one arrival counter per KV head in the plan header, bumped by a stage-1
+// workgroup once its write-through partial stores have completed), then merges and writes the output row -- the
+// stage-2 launch, its ramp and the kernel boundary in front of it are gone, and heads that finish early are merged
+// under the tail of the others.  Merge workgroups never outnumber half of the resident slots, so stage-1 workgroups
+// can always be placed whatever order the dispatcher picks.
 #pragma once
 
 namespace deft {
 
 struct NpParams {
     Stage1Params s;
-    const char* plan;    // [cap+1][PLAN_BYTES], leaders first (np_record_order)
-    const int32_t* hdr;  // plan header: hdr[1] = number of chunk leaders
-    int* sched;          // sched[0] = workgroups done, sched[ticket_word(0)] = chunk ticket; all 0 between launches
-    int persist;         // 1: resident workgroups draw further chunks from the ticket counter; 0: one chunk per workgroup
-    int fast_n;          // workgroups < fast_n (the ones resident at launch) request tile 0's offsets before anything else
+    const char* plan;  // [cap+1][PLAN_BYTES], leaders first (np_record_order)
+    int32_t* hdr;      // plan header (plan_records.h): hdr[1] = number of chunk leaders; arrival counters
+    int fast_n;        // workgroups < fast_n (the ones resident at launch) request tile 0's offsets before anything else
+    int n_stage1;      // workgroups [0, n_stage1) run stage 1; the rest of the grid are merge workgroups
+    // single-launch decode: merge in the same launch (0: stage 1 only, the caller launches merge_kernel)
+    int fused;
+    const int32_t* row_q;  // partial row -> query (-1 = dead row)
+    _Float16* out;
+    int64_t o_st, o_sh;
+    int nq, Hq;
     // fused paged append (optional), as in StreamParams
     const _Float16* k_new;
     const _Float16* v_new;
@@ -58,18 +71,17 @@ struct NpSmem {
     static_assert(2 * BYTES <= 160 * 1024, "two workgroups per CU");
 };
 
-// 64 lanes x 4 bytes, global (per-lane address) -> LDS (lds_dst + 4*lane)
-__device__ __forceinline__ void dma4(const void* gsrc, uint32_t lds_dst) {
-    asm volatile(
-        "s_mov_b32 m0, %1\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dword %0, off"
-        :
-        : "v"(gsrc), "s"(lds_dst)
-        : "memory");
-}
+// Profiling hooks exist in the experiments build only (make exp: -DDEFT_EXPERIMENTS); the shipped kernel has neither
+// the ablation branches nor the per-workgroup time stamps.
+#ifdef DEFT_EXPERIMENTS
+#define ABL(bit) (p.ablate & (bit))
+#define DBG np.dbg
+#else
+#define ABL(bit) false
+#define DBG ((unsigned long long*)nullptr)
+#endif
 
-template <int D, bool PERSIST>
+template <int D>
 __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
     constexpr int KS = D / 16;
     constexpr int LPT = 32 * (D / 8) / 64;  // DMA instructions per wave per K (or V) slice
@@ -84,8 +96,51 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
     const int c = l & 31;
     const int h = l >> 5;
     const int bid = blockIdx.x;
-    const int W = (int)gridDim.x;
+    const int W = np.n_stage1;  // stage-1 workgroups (stride of the item loop)
     unsigned long long t_start = 0, t_k0 = 0, t_epi = 0;
+
+    // ---- merge workgroups (single-launch decode): the tail of the grid ------------------------------------
+    if (bid >= W) {
+        // Wave gw of the 4 M merge waves takes pairs gw, gw + 4 M, ...; pair = (query p % nq, head p / nq).
+        const int M = (int)gridDim.x - W;
+        const int gw = (bid - W) * 4 + w;
+        const int pairs = np.nq * np.Hq;
+        constexpr int LIST_CAP = 4096;  // row ids per wave (16 KB of the workgroup's LDS each)
+        static_assert(4 * LIST_CAP * 4 <= SM::BYTES, "merge lists fit the stage-1 LDS allocation");
+        int* list = reinterpret_cast<int*>(smem) + w * LIST_CAP;
+        int have_q = -1, have = -1;
+        int NL = 0;
+        for (int pr = gw; pr < pairs; pr += 4 * M) {
+            const int q = pr % np.nq, hq = pr / np.nq;
+            if (q != have_q) {  // list the query's partial rows while stage 1 is still running
+                have = scan_rows_wave(np.row_q, 0, p.rows < LIST_CAP ? p.rows : LIST_CAP, q, list, LIST_CAP, l);
+                if (p.rows > LIST_CAP) have = -1;  // longer workspaces: merge_pair_wave scans window by window
+                have_q = q;
+                __builtin_amdgcn_wave_barrier();
+            }
+            // wait for every chunk of this KV head (bounded: a lost arrival must not hang the GPU)
+            const int32_t* cnt = np.hdr + HDR_DONE + HDR_DONE_STRIDE * (hq / p.G);
+            if (NL == 0) NL = __builtin_amdgcn_readfirstlane(__hip_atomic_load(np.hdr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            bool ok = false;
+            for (int spin = 0; spin < (1 << 22); ++spin) {
+                const int got = __builtin_amdgcn_readfirstlane(__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                if (got >= NL) {
+                    ok = true;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(16);
+            }
+            if (!ok && l == 0) atomicOr(np.hdr + HDR_ERR, 1);
+            merge_pair_wave<D, CP_SYS>(p.partial_o, p.partial_lse, np.row_q, p.rows, q, hq, list, LIST_CAP, have,
+                                       np.out + (int64_t)q * np.o_st + (int64_t)hq * np.o_sh, l);
+        }
+        // the last merge wave to leave re-arms the arrival counters for the next launch (graph-safe: no memset)
+        if (l == 0 && atomicAdd(np.hdr + HDR_MDONE, 1) == 4 * M - 1) {
+            np.hdr[HDR_MDONE] = 0;
+            for (int k = 0; k < p.Hkv; ++k) np.hdr[HDR_DONE + HDR_DONE_STRIDE * k] = 0;
+        }
+        return;
+    }
 
     // ---- fused paged append: new-token row j is copied into the pool by workgroup (grid-1-j) % grid (nobody reads
     //      those pool rows in this launch: rows flagged NEW in the plan are taken from k_new / v_new) ------------
@@ -104,26 +159,14 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
     }
 
     // Work items = (chunk leader record, KV head), head fastest: neighbours share a record and a stretch of the pool,
-    // long shared-prefix chunks come first.  Item `bid` is this workgroup's first; resident workgroups then draw
-    // items W, W+1, ... from chip-wide ticket counters -- the XCDs of an MI355X do not stream at the same rate (the odd
-    // ones ~20 % slower, tools/np_timeline.py) and the hardware dispatcher deals workgroups to XCDs round-robin,
-    // so only a chip-wide queue lets them finish together.
+    // long shared-prefix chunks come first.  Item `bid` is this workgroup's first; a workgroup whose index has
+    // further items (capped grids) takes item + W, item + 2 W, ... in a loop.
     int NI = 0x7fffffff;  // leaders x heads, read with the first item's descriptor
     int item = bid;
     int rec0 = 0, kvh = 0, fb = 0, sd4 = 0, sd0 = 0, sd5 = 0;
     auto rec_of = [&](int i) { return np.plan + (int64_t)(i == 0 ? rec0 : fb + i - 1) * PLAN_BYTES; };
-    // NTICKET counters, one cache line each (one counter serialises at ~80 atomics/us: 512 requests at launch would
-    // take 6 us).  Workgroup b uses counter (b >> 3) % NTICKET and that counter's stripe of the items, so every
-    // stripe is served by workgroups of ALL eight XCDs (b % 8 is the XCD under round-robin dispatch).
-    const int tk_lane = (p.ablate & 256) ? 0 : (bid >> 3) % NTICKET;
-    auto finish = [&]() {  // the last workgroup to leave re-arms the scheduler words for the next launch
-        if (PERSIST && !(p.ablate & 512) && tid == 0 && atomicAdd(np.sched, 1) == W - 1) {
-            np.sched[0] = 0;
-            for (int k = 0; k < NTICKET; ++k) np.sched[ticket_word(k)] = 0;
-        }
-    };
 
-    // ---- loop-invariant lane constants (same LDS layouts as stage1_stream.h) ----------------
+    // ---- loop-invariant lane constants ------------------------------------------------------------------
     const int dpos = l & 15, dkey = l >> 4;
     int kchunk_b[4];
 #pragma unroll
@@ -186,7 +229,7 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
     };
 
     for (bool first = true;; first = false) {
-    if (np.dbg) t_start = wall_clock64();
+    if (DBG) t_start = wall_clock64();
     rec0 = item / p.Hkv;
     kvh = item - rec0 * p.Hkv;
     const char* rec_lead = np.plan + (int64_t)rec0 * PLAN_BYTES;
@@ -252,17 +295,8 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
         // ---- K(i) (and Q) landed: younger than it are aux(i+1) [2] and V(i) [8] -------------------------
         if (has1) wait_vm<LPT + 2>();
         else wait_vm<LPT>();
-        // Next item's ticket: requested by wave 0 at the start of the chunk's LAST tile (claiming earlier would hand
-        // the whole queue out at launch: a workgroup only sees ~2 chunks) and retired by this tile's final vmcnt(0).
-        // It lands in the FIXED register v255 named in the asm text (never a C++ variable the compiler could copy
-        // while the atomic is in flight); the kernel's own allocation -- including register TUPLES, which a textual
-        // grep for the name misses -- stays below it (tools/check_asm.sh).
-        if (PERSIST && !has1 && w == 0 && l == 0) {
-            int* tk = np.sched + ticket_word(tk_lane);
-            asm volatile("global_atomic_add v255, %0, %1, off sc0" ::"v"(tk), "v"(1) : "memory", "v255");
-        }
         if (i == 0) {
-            if (np.dbg) t_k0 = wall_clock64();
+            if (DBG) t_k0 = wall_clock64();
             lds_barrier();  // Q rows of all four waves visible
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
@@ -279,7 +313,7 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
         floatx16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        if (!(p.ablate & 1)) {  // profiling knob (env DEFT_STAGE1_ABLATE): 1 skip QK^T, 4 skip PV, 16 skip the epilogue
+        if (!ABL(1)) {  // experiments build: 1 skip QK^T, 4 skip PV, 16 skip the epilogue, 32 skip the stores
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const half8 a = *reinterpret_cast<const half8*>(smem + krow_b + (kcol_b ^ (32 * ks)));
@@ -330,7 +364,7 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
         else if (has1) wait_vm<LPT>();
         else wait_vm<0>();
         // ---- O^T += V^T P^T: four 32-column blocks x two 16-key steps ------------------------------------
-        if (!(p.ablate & 4))
+        if (!ABL(4))
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
 #pragma unroll
@@ -349,17 +383,12 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
         if (has1) issue_v();  // V(i+1); rowoff still holds tile i+1's offsets
     }
 
-    if (PERSIST && w == 0) {
-        int t;
-        asm volatile("v_readfirstlane_b32 %0, v255" : "=s"(t)::"memory");
-        if (l == 0) *reinterpret_cast<int*>(smem + SM::NEXT_OFF) = W + t * NTICKET + tk_lane;
-    }
-    if (p.ablate & 16) {
+    if (ABL(16)) {
         lds_barrier();
-        item = PERSIST ? __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int*>(smem + SM::NEXT_OFF)) : item + W;
+        item += W;
         continue;
     }
-    if (np.dbg) t_epi = wall_clock64();
+    if (DBG) t_epi = wall_clock64();
     // ---- epilogue: merge the four waves' (m, l, O) and write one partial row per virtual query row.  ONE barrier:
     //      every wave parks its unscaled O (and m, l) in its own slices -- nobody else ever touched them -- and
     //      the readers rescale while they sum.  Rows of follower tiles are dead by construction: the plan gave
@@ -371,7 +400,7 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
         xl[w * MQ + c] = l_run;
     }
     // query row c < 16 in the K slice, c >= 16 in the V slice; [row][128] floats, 16-byte chunk index XOR-ed by the row
-    if (c < nv && !(p.ablate & 64)) {
+    if (c < nv && !(ABL(64))) {
         char* dst = smem + (c < 16 ? SM::K_OFF : SM::V_OFF) + w * SM::SLICE + (c & 15) * (D * 4);
 #pragma unroll
         for (int blk = 0; blk < 4; ++blk)
@@ -382,9 +411,10 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
                 *reinterpret_cast<floatx4*>(dst + ((k4 ^ c) & 31) * 16) = v4;
             }
     }
-    if (!(p.ablate & 64)) lds_barrier();
+    if (!(ABL(64))) lds_barrier();
     const int64_t head_rows = (int64_t)kvh * p.G * p.rows;
     const int32_t* orow = reinterpret_cast<const int32_t*>(smem + SM::OROW_OFF);
+    const __amdgpu_buffer_rsrc_t rs_o = make_rsrc(p.partial_o + head_rows * D), rs_l = make_rsrc(p.partial_lse + head_rows);
     // wave w sums the 16-byte chunks 8w .. 8w+7 of every row: lane = (row within a group of 8, chunk)
     const int k4 = 8 * w + (l & 7);
     for (int q0 = 0; q0 < nv; q0 += 8) {
@@ -405,33 +435,52 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
                 a += b * f;
             }
             const float inv = L > 0.f ? 1.f / L : 0.f;
-            const int64_t row = head_rows + orow[qr];
-            if (p.ablate & 32) continue;
-            *reinterpret_cast<floatx4*>(p.partial_o + row * D + 4 * k4) = a * inv;
-            if (k4 == 0) p.partial_lse[row] = (L > 0.f) ? (M + __builtin_amdgcn_logf(L)) * LN2 : -INFINITY;
+            const int orow_q = orow[qr];
+            if (ABL(32)) continue;
+            const floatx4 res = a * inv;
+            const float lse = (L > 0.f) ? (M + __builtin_amdgcn_logf(L)) * LN2 : -INFINITY;
+            if (np.fused) {
+                // read by a merge wave of this launch, possibly on another XCD: write-through stores (one descriptor
+                // per KV head -- wave-uniform -- and the row in the per-lane offset)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uintx4, res), rs_o, orow_q * (D * 4) + 16 * k4, 0, CP_SYS);
+                if (k4 == 0) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, lse), rs_l, orow_q * 4, 0, CP_SYS);
+            } else {
+                const int64_t row = head_rows + orow_q;
+                *reinterpret_cast<floatx4*>(p.partial_o + row * D + 4 * k4) = res;
+                if (k4 == 0) p.partial_lse[row] = lse;
+            }
         }
     }
-    if (np.dbg && tid == 0 && item < 8192) {
+    if (DBG && tid == 0 && item < 8192) {
         unsigned hw, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        unsigned long long* d = np.dbg + (int64_t)item * 8;
+        unsigned long long* d = DBG + (int64_t)item * 8;
         d[0] = t_start;
         d[1] = t_k0;
         d[2] = t_epi;
         d[3] = wall_clock64();
         d[4] = (unsigned long long)n;
         d[5] = ((unsigned long long)xcc << 32) | hw;
-        d[6] = (unsigned long long)(long long)*reinterpret_cast<const int*>(smem + SM::NEXT_OFF);
     }
-    // Next item: from the ticket queue (resident mode), or -- hardware dispatch with a capped grid -- simply item + W:
-    // record capacity beyond the chunk leaders would otherwise be launched as workgroups that only find out that
-    // they have nothing to do (tens of thousands of them for the sequential comparator's one-query entries).
-    if (item + W >= NI && !PERSIST) break;
-    lds_barrier();  // every wave is done reading the others' slices; the next item is visible
-    item = PERSIST ? __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int*>(smem + SM::NEXT_OFF)) : item + W;
+    // Arrival (single-launch decode): this wave's partial stores have completed -- write-through, so they are in
+    // memory -- then, behind the barrier, ONE bump of the KV head's counter; the merge waves poll it.
+    if (np.fused) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lds_barrier();
+        if (tid == 0) __hip_atomic_fetch_add(np.hdr + HDR_DONE + HDR_DONE_STRIDE * kvh, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (item + W >= NI) break;
+    } else {
+        // Next item of a capped grid: record capacity beyond the chunk leaders would otherwise be launched as workgroups
+        // that only find out that they have nothing to do (tens of thousands for the sequential comparator's entries).
+        if (item + W >= NI) break;
+        lds_barrier();  // every wave is done reading the others' slices
+    }
+    item += W;
     }  // work items
-    finish();
 }
+
+#undef ABL
+#undef DBG
 
 }  // namespace deft

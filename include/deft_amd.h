@@ -56,13 +56,9 @@ extern "C" {
 int deft_abi_version(void);
 const char* deft_last_error(void);
 
-/* Which stage-1 form serves head_dim 128 in this process: 0 = streaming (persistent workgroups), 1 = tile-parallel
- * (one workgroup per chunk of tiles).  A plan (deft_*_build_plan) is laid out for the form that was current when it
- * was built; callers that cache plans across calls key them by this value.  It only changes with the environment
- * variable DEFT_STAGE1_KERNEL (stream | np), which exists for A/B measurements. */
-int deft_stage1_kind(void);
-/* deft_stage1_kind() plus the experiment knobs of the plan kernels (DEFT_NP_CHUNK / _UNION / _TAPER) in one integer:
- * the key for cached plans. */
+/* Key for callers that cache plans (deft_*_build_plan) across calls: everything a plan's layout depends on
+ * besides the arguments it was built from.  Always 0 in the shipped library, which reads no environment; the
+ * experiments build (`make -C deft_amd/csrc exp`, A/B measurements only) folds its plan knobs into it. */
 int deft_plan_variant(void);
 
 /* 1 if (Hq, Hkv, D) is covered: Hq % Hkv == 0, D in {64, 128}
@@ -82,7 +78,8 @@ size_t deft_flatten_workspace_bytes(int NB, int P, int nq, int Hq, int Hkv, int 
  * map) can be built once per step and handed to every layer's call.  `plan` is caller-
  * owned device memory of deft_flatten_plan_bytes(NB, P, Hq, Hkv) bytes; it depends on the
  * six metadata arrays, the head counts and the q / pool strides only (not on the layer).
- * Two words of it are scheduler state that every launch leaves zeroed again.  Passing plan = NULL to the decode call
+ * Its header holds the arrival counters of the single-launch decode, which every launch leaves zeroed again, so a
+ * plan serves one launch at a time (the layers of a step run in stream order).  Passing plan = NULL to the decode call
  * makes it build the plan itself into the workspace (one more small kernel per call).
  */
 size_t deft_flatten_plan_bytes(int NB, int P, int Hq, int Hkv);

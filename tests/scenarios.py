@@ -137,6 +137,18 @@ def s_fewshot_4k(tree, ids):  # north-star tree at branch length 1
     _step(tree, 1)
 
 
+def s_fewshot_4k_len200(tree, ids):  # north-star tree at the benchmarked branch length (BASELINE north_star)
+    tree.init_prompt(ids(4096))
+    tree.branch(tree.root, 32)
+    _step(tree, 200)
+
+
+def s_forest_tree_8kx8(tree, ids):  # BASELINE config 5: ONE of the 64 trees (8192-token prefix, 8 branches x 64 tokens)
+    tree.init_prompt(ids(8192))
+    tree.branch(tree.root, 8)
+    _step(tree, 64)
+
+
 class Scenario(NamedTuple):
     script: Callable
     max_q_len: int = 32
@@ -161,14 +173,28 @@ SCENARIOS: Dict[str, Scenario] = {
     "tot50": Scenario(s_tot50, pool_size=8192, kernels=False),
     "fewshot_1k": Scenario(s_fewshot_1k, pool_size=2048, kernels=False),
     "fewshot_4k": Scenario(s_fewshot_4k, pool_size=8192, kernels=False),
+    "fewshot_4k_len200": Scenario(s_fewshot_4k_len200, pool_size=10752, kernels=False),
+    "forest_tree_8kx8": Scenario(s_forest_tree_8kx8, pool_size=8832, kernels=False),
 }
 
 # (Hq, Hkv, D) used for the small kernel goldens
 SMALL_GEOMETRIES = ((4, 4, 128), (8, 2, 128), (4, 4, 64))
-# full Llama-2-7B geometry goldens (F3): scenario -> (Hq, Hkv, D)
-FULL_GEOMETRY = {"fewshot_1k": (32, 32, 128), "fewshot_4k": (32, 32, 128)}
-# Llama-3-8B GQA geometry on the medusa tree (node mode headline) and ToT tree
-GQA_GEOMETRY = {"medusa64": (32, 8, 128)}
+# full Llama-2-7B geometry goldens (F3): scenario -> (Hq, Hkv, D).  BASELINE configs[1] (1k x 32), the north-star tree
+# at branch length 1 and at the benchmarked length 200, configs[2] (Medusa-64) at the model BASELINE names for it
+FULL_GEOMETRY = {"fewshot_1k": (32, 32, 128), "fewshot_4k": (32, 32, 128), "fewshot_4k_len200": (32, 32, 128),
+                 "medusa64": (32, 32, 128)}
+# Llama-3-8B GQA geometry: the Medusa tree, configs[3] (ToT-50) and one tree of configs[4] (8k x 8 x 64)
+GQA_GEOMETRY = {"medusa64": (32, 8, 128), "tot50": (32, 8, 128), "forest_tree_8kx8": (32, 8, 128)}
+
+
+def big_cases():
+    """(scenario, geometry) pairs of the full-size goldens, each once."""
+    seen = []
+    for d in (FULL_GEOMETRY, GQA_GEOMETRY):
+        for name, geom in d.items():
+            if (name, geom) not in seen:
+                seen.append((name, geom))
+    return seen
 
 
 def input_seeds(name: str, geom) -> Dict[str, int]:

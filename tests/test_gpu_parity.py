@@ -14,7 +14,7 @@ from deft_amd.tree_attention import flatten_stage1_partials
 from helpers import leaf_paths, max_abs, oracle_metadata, oracle_tree, seeded_inputs
 from oracle import attention as oa
 from product_helpers import md_numpy, product_metadata, product_tree
-from scenarios import FULL_GEOMETRY, GQA_GEOMETRY, SCENARIOS, SMALL_GEOMETRIES
+from scenarios import SCENARIOS, SMALL_GEOMETRIES, big_cases
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-3
@@ -46,8 +46,7 @@ def _cases():
         if sc.kernels:
             for geom in SMALL_GEOMETRIES:
                 yield name, geom
-    for name, geom in {**FULL_GEOMETRY, **GQA_GEOMETRY}.items():
-        yield name, geom
+    yield from big_cases()  # BASELINE's own configurations at full geometry
 
 
 @pytest.mark.parametrize("mode", ["flatten", "node"])
@@ -322,54 +321,13 @@ def test_full_size_properties_northstar_tree():
         assert (o1[r].float() - ref).abs().max().item() < TOL
 
 
-@pytest.mark.parametrize("dyn", ["0", "30", "100"])
-def test_ticket_tail_matches_static_walk(dyn, monkeypatch):
-    """The streaming kernel hands the last DEFT_STREAM_DYN % of every workgroup's tiles out by atomic ticket.  The
-    Which workgroup computes a ticket tile depends on arrival order, the attention output must not: 4k x 32 tree with 200-token branches (82 tiles per head = 10.25 per workgroup), every share
-    against the static walk and three leaves against torch fp32 sequential attention."""
-    from deft_amd.utils.workloads import Workload, build_tree
-
-    w = Workload("t", "llama2-7b", "flatten", "few_shot", 4096, 32, 200)
-    tree, pool = build_tree(w, 1, "cuda")
-    md = deft_amd.TreeMetadata.from_tree_cache(tree)
-    g = torch.Generator(device="cuda").manual_seed(5)
-    pool._storage.normal_(generator=g)
-    q = torch.randn((32, 32, 128), dtype=torch.float16, device="cuda", generator=g)
-    kb, vb = pool.get_key_buffer(0), pool.get_value_buffer(0)
-    monkeypatch.setenv("DEFT_STAGE1_KERNEL", "stream")  # the streaming form (the default is the tile-parallel one)
-    monkeypatch.setenv("DEFT_STREAM_DYN", "0")
-    o_static = torch.zeros_like(q)
-    deft_amd.tree_attention_subtree_fwd(q, kb, vb, o_static, *_flatten_args(md))
-    torch.cuda.synchronize()
-    monkeypatch.setenv("DEFT_STREAM_DYN", dyn)
-    outs = []
-    for _ in range(3):
-        o = torch.zeros_like(q)
-        deft_amd.tree_attention_subtree_fwd(q, kb, vb, o, *_flatten_args(md))
-        outs.append(o)
-    torch.cuda.synchronize()
-    for o in outs:
-        assert (o.float() - o_static.float()).abs().max().item() < TOL_EXACT
-        assert torch.equal(o, outs[0])  # ticket-assigned tiles never fold: bit-identical run to run
-    leaves = sorted(tree.leaves.values(), key=lambda n: n.id)
-    for r in (0, 17, 31):
-        slots = torch.tensor(tree.leaf_path_slots(leaves[r]), device="cuda")
-        k = kb[slots].float().transpose(0, 1)
-        v = vb[slots].float().transpose(0, 1)
-        s = torch.einsum("hd,hsd->hs", q[r].float(), k) / 128 ** 0.5
-        ref = torch.einsum("hs,hsd->hd", torch.softmax(s, dim=-1), v)
-        assert (outs[-1][r].float() - ref).abs().max().item() < TOL
-
-
-@pytest.mark.parametrize("env", [{}, {"DEFT_NP_CHUNK": "1", "DEFT_NP_UNION": "1"}, {"DEFT_NP_CHUNK": "8", "DEFT_NP_UNION": "4"},
-                                 {"DEFT_NP_CHUNK": "2", "DEFT_NP_UNION": "8"}, {"DEFT_NP_PERSIST": "1"},
-                                 {"DEFT_STAGE1_KERNEL": "stream"}])
-def test_full_size_fold_structure_does_not_change_the_result(env, monkeypatch):
-    """BASELINE's north-star tree (Llama-2-7B, 4096 x 32 x 200 tokens) through every way of cutting it into
-    workgroups: no folding at all, the default chunks and union groups, long chunks with large unions, resident
-    workgroups with the ticket queue, and the streaming form.  Folding changes the order of fp32 additions, nothing
-    else: all agree within the exact-merge tolerance, each is bit-deterministic, and the sequential comparator over
-    the page table (every leaf its own full path) agrees with them; three leaves against torch fp32 attention."""
+@pytest.mark.parametrize("two_launch", [0, 1])
+def test_full_size_fold_structure_does_not_change_the_result(two_launch):
+    """BASELINE's north-star tree (Llama-2-7B, 4096 x 32 x 200 tokens) through every decomposition the library has:
+    Flatten blocks (chunks + union groups), Node entries cut into tiles, and the sequential comparator over the page
+    table (every leaf its own full path); as the single-launch decode and as stage 1 + merge_kernel.  Folding changes
+    the order of fp32 additions, nothing else: all agree within the exact-merge tolerance, each is bit-deterministic;
+    three leaves against torch fp32 attention."""
     from deft_amd.utils.workloads import Workload, build_tree
 
     w = Workload("t", "llama2-7b", "flatten", "few_shot", 4096, 32, 200)
@@ -380,23 +338,26 @@ def test_full_size_fold_structure_does_not_change_the_result(env, monkeypatch):
     q = torch.randn((32, 32, 128), dtype=torch.float16, device="cuda", generator=g)
     kb, vb = pool.get_key_buffer(0), pool.get_value_buffer(0)
     o_ref = torch.zeros_like(q)
-    deft_amd.tree_attention_subtree_fwd(q, kb, vb, o_ref, *_flatten_args(md))  # default settings
+    deft_amd.tree_attention_subtree_fwd(q, kb, vb, o_ref, *_flatten_args(md))  # default: single launch
     torch.cuda.synchronize()
-    for k_, v_ in env.items():
-        monkeypatch.setenv(k_, v_)
-    outs = []
-    for _ in range(2):
-        o = torch.full_like(q, float("nan"))
-        deft_amd.tree_attention_subtree_fwd(q, kb, vb, o, *_flatten_args(md))
-        outs.append(o)
-    o_node = torch.full_like(q, float("nan"))
-    deft_amd.tree_attention_fwd(q, kb, vb, o_node, md.node_kv, md.node_kv_offset, md.node_kv_len, md.node_q,
-                                md.node_q_offset, md.node_q_len)
-    meta, lens = _seq_metadata(tree)
-    o_seq = torch.full_like(q, float("nan"))
-    deft_amd.token_attention_fwd(q, kb, vb, o_seq, tree.req_to_token_pool.req_to_token, meta.req_pool_indices,
-                                 meta.start_loc, meta.seq_lens, meta.max_seq_len, None, meta.total_num_tokens)
-    torch.cuda.synchronize()
+    deft_amd.lib.deft_debug_two_launch(two_launch)
+    try:
+        outs = []
+        for _ in range(2):
+            o = torch.full_like(q, float("nan"))
+            deft_amd.tree_attention_subtree_fwd(q, kb, vb, o, *_flatten_args(md))
+            outs.append(o)
+        o_node = torch.full_like(q, float("nan"))
+        deft_amd.tree_attention_fwd(q, kb, vb, o_node, md.node_kv, md.node_kv_offset, md.node_kv_len, md.node_q,
+                                    md.node_q_offset, md.node_q_len)
+        meta, lens = _seq_metadata(tree)
+        o_seq = torch.full_like(q, float("nan"))
+        deft_amd.token_attention_fwd(q, kb, vb, o_seq, tree.req_to_token_pool.req_to_token, meta.req_pool_indices,
+                                     meta.start_loc, meta.seq_lens, meta.max_seq_len, None, meta.total_num_tokens)
+        torch.cuda.synchronize()
+    finally:
+        deft_amd.lib.deft_debug_two_launch(0)
+    assert torch.equal(outs[0], o_ref)  # the merge waves of the single launch and merge_kernel run the same code
     assert torch.equal(outs[0], outs[1])
     for o in (outs[0], o_node, o_seq):
         assert torch.isfinite(o.float()).all()
@@ -612,10 +573,10 @@ def test_nodes_with_more_than_32_queries_fold_as_interleaved_runs(mode, shape):
 
 
 @pytest.mark.parametrize("shape", [(32, 32, 1024, 32, 200), (8, 2, 1500, 70, 3), (4, 4, 300, 5, 40), (4, 4, 5, 40, 1)])
-def test_plan_build_forms_give_identical_plans(shape, monkeypatch):
+def test_plan_build_forms_give_identical_plans(shape):
     """The Flatten plan is written either by all waves of the unit kernel from a table of runs (default), or by one
-    lane as it walks the blocks (tables beyond the LDS; `DEFT_PLAN_SERIAL=1`), or by one lane after the run table
-    overflowed (`DEFT_PLAN_RUNCAP=2` forces it): the three must produce the same plan, so the outputs are
+    lane as it walks the blocks (tables beyond the LDS), or by one lane after the run table overflowed
+    (`deft_debug_plan_form(serial, runcap)` forces either): the three must produce the same plan, so the outputs are
     bit-identical (the partial rows are a function of the plan) and the plan bytes the kernels read are equal."""
     from deft_amd._lib import check, lib
     from deft_amd.memory_pool import ReqToTokenPool, TokenToKVPool
@@ -643,10 +604,9 @@ def test_plan_build_forms_give_identical_plans(shape, monkeypatch):
     nbytes = lib.deft_flatten_plan_bytes(NB, P, Hq, Hkv)
     cap = NB * (Hq // Hkv)
     outs, plans = [], []
-    for env in ({}, {"DEFT_PLAN_SERIAL": "1"}, {"DEFT_PLAN_RUNCAP": "2"}):
-        with monkeypatch.context() as m:
-            for k_, v_ in env.items():
-                m.setenv(k_, v_)
+    for form in ((0, 0), (1, 0), (0, 2)):
+        try:
+            lib.deft_debug_plan_form(*form)
             o = torch.full_like(q, float("nan"))
             deft_amd.tree_attention_subtree_fwd(q, kb, vb, o, *_flatten_args(md))  # (the plan cache is keyed by these knobs)
             plan = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
@@ -659,6 +619,8 @@ def test_plan_build_forms_give_identical_plans(shape, monkeypatch):
             assert 0 < n_units <= cap
             # header words 0..1 (units, chunk leaders) and every record the kernels may read (unit slots + sentinel)
             plans.append((plan[:8].clone(), plan[4096:4096 + 2048 * (n_units + 1)].clone()))
+        finally:
+            lib.deft_debug_plan_form(0, 0)
     assert torch.isfinite(outs[0].float()).all()
     for o, (hd, rec) in zip(outs[1:], plans[1:]):
         assert torch.equal(o, outs[0])
@@ -669,10 +631,9 @@ def test_plan_build_forms_give_identical_plans(shape, monkeypatch):
     NE, Pn, total_kv = md.node_kv_offset.shape[0], md.node_q.shape[0], md.node_kv.shape[0]
     nbytes = lib.deft_node_plan_bytes(NE, Pn, total_kv, Hq, Hkv)
     outs, plans = [], []
-    for env in ({}, {"DEFT_PLAN_SERIAL": "1"}, {"DEFT_PLAN_RUNCAP": "2"}):
-        with monkeypatch.context() as m:
-            for k_, v_ in env.items():
-                m.setenv(k_, v_)
+    for form in ((0, 0), (1, 0), (0, 2)):
+        try:
+            lib.deft_debug_plan_form(*form)
             o = torch.full_like(q, float("nan"))
             deft_amd.tree_attention_fwd(q, kb, vb, o, *nd)
             plan = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
@@ -684,6 +645,8 @@ def test_plan_build_forms_give_identical_plans(shape, monkeypatch):
             n_units = int(plan[:4].view(torch.int32).item())
             assert n_units > 0 and 4096 + 2048 * (n_units + 1) <= nbytes
             plans.append((plan[:8].clone(), plan[4096:4096 + 2048 * (n_units + 1)].clone()))
+        finally:
+            lib.deft_debug_plan_form(0, 0)
     assert torch.isfinite(outs[0].float()).all()
     for o, (hd, rec) in zip(outs[1:], plans[1:]):
         assert torch.equal(o, outs[0])

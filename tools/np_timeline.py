@@ -7,8 +7,9 @@ os.environ.setdefault("DEFT_STAGE1_KERNEL", "np")
 from bench import Bench
 from deft_amd._lib import lib
 from deft_amd.utils.workloads import WORKLOADS, Workload
-bl = int(sys.argv[1]) if len(sys.argv) > 1 else 200
-w = Workload(**{**WORKLOADS[os.environ.get("WL","northstar_4kx32")].__dict__, "branch_len": bl})
+w0 = WORKLOADS[os.environ.get("WL", "northstar_4kx32")]
+bl = int(sys.argv[1]) if len(sys.argv) > 1 else w0.branch_len
+w = Workload(**{**w0.__dict__, "branch_len": bl})
 b = Bench(w, 8, torch.device("cuda", 0)); b.prepare(use_graph=False)
 lib.deft_debug_set_buffer.argtypes = [ctypes.c_void_p]
 NW = 8192
