@@ -40,8 +40,6 @@ lib.deft_abi_version.restype = C.c_int
 lib.deft_plan_variant.restype = C.c_int
 lib.deft_debug_plan_form.argtypes = [C.c_int, C.c_int]  # test hooks, not part of include/deft_amd.h
 lib.deft_debug_plan_form.restype = None
-lib.deft_debug_two_launch.argtypes = [C.c_int]
-lib.deft_debug_two_launch.restype = None
 lib.deft_last_error.restype = C.c_char_p
 lib.deft_supported.argtypes = [_i32, _i32, _i32]
 lib.deft_supported.restype = C.c_int

@@ -22,13 +22,13 @@ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 //   row_q       [rows]        i32   query row of each partial row, -1 = unused
 //   desc        [tiles][8]    i32   tile descriptors (Node mode only)
 //   plan        [NB+1][2048]  bytes Flatten plan records: row byte offsets, 32-bit masks, {cnt, prow,
-//                                   run_start, len} per block (stage1_stream.h)
+//                                   run_start, len} per block (plan_records.h)
 struct Workspace {
     float* partial_o;
     float* partial_lse;
     int32_t* row_q;
     int32_t* desc;
-    char* plan;          // [NB+1][2048] Flatten streaming plan records (stage1_stream.h)
+    char* plan;          // a whole plan buffer when the caller passes no plan
     size_t bytes;
 };
 
@@ -53,32 +53,39 @@ inline Workspace carve(void* base, int Hq, int D, int64_t rows, int64_t tiles, s
 inline int64_t node_max_tiles(int NE, int64_t total_kv) { return (int64_t)NE + total_kv / DEFT_BLOCK_LEN; }
 
 // Plan buffer (built once per decode step, read by every layer's call):
-//   header      4 KB  : int32 hdr[0] = records per KV head; sched[0] = workgroups-done counter at +64;
-//                       8 ticket counters at +512 + 256 k (one cache line each; workgroup b uses k = b % 8)
-//   records     (cap+1) x 2048 B (stage1_stream.h PLAN_*), cap = units-per-head capacity
+//   header      4 KB  : int32 hdr[0] = records per KV head, hdr[1] = chunk leaders, hdr[2] = error flags,
+//                       hdr[3] = 1 when the per-query row lists below are valid (plan_records.h)
+//   records     (cap+1) x 2048 B (plan_records.h PLAN_*), cap = units-per-head capacity
 //   unit list   17 x cap int32 (src, aux, pass, flags, prow; tile-parallel order: perm, chunk tiles, first follower; union groups: n, 4 queries, 4 rows)
-//   row_q       rows int32 : partial row -> query row
+//   row_q       rows int32 : partial row -> query row (-1 = dead row)
+//   qoff, qlist rows + 1, rows int32 : per query, its live partial rows in ascending order (what the merge reads)
 struct PlanView {
     int32_t* hdr;
-    int32_t* sched;
     char* records;
     int32_t* units;  // 17 arrays of `cap`
     int32_t* row_q;
+    int32_t* qoff;   // [rows + 1] first entry of every query's row list (queries are < rows: each has a partial row)
+    int32_t* qlist;  // [rows] live partial rows grouped by query, ascending within a query
     int64_t cap;
+    int64_t rows;
     size_t bytes;
 };
 inline PlanView plan_view(void* base, int64_t cap, int64_t rows) {
     PlanView v;
     char* p = static_cast<char*>(base);
     v.cap = cap;
+    v.rows = rows;
     v.hdr = reinterpret_cast<int32_t*>(p);
-    v.sched = reinterpret_cast<int32_t*>(p + 64);
     size_t off = 4096;
     v.records = p + off;
     off = align_up(off + 2048 * (size_t)(cap + 1), 256);
     v.units = reinterpret_cast<int32_t*>(p + off);
     off = align_up(off + sizeof(int32_t) * 17 * (size_t)(cap > 0 ? cap : 1), 256);
     v.row_q = reinterpret_cast<int32_t*>(p + off);
+    off = align_up(off + sizeof(int32_t) * (size_t)(rows > 0 ? rows : 1), 256);
+    v.qoff = reinterpret_cast<int32_t*>(p + off);
+    off = align_up(off + sizeof(int32_t) * (size_t)((rows > 0 ? rows : 1) + 1), 256);
+    v.qlist = reinterpret_cast<int32_t*>(p + off);
     off = align_up(off + sizeof(int32_t) * (size_t)(rows > 0 ? rows : 1), 256);
     v.bytes = off;
     return v;

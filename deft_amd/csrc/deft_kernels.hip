@@ -348,17 +348,23 @@ __global__ __launch_bounds__(256) void node_prep_kernel(const int64_t* node_kv_o
 constexpr int MERGE_LIST_CAP = 4096;  // row ids per wave in LDS; longer lists are merged window by window
 template <int D>
 __global__ __launch_bounds__(256) void merge_kernel(const float* partial_o, const float* partial_lse, const int32_t* row_q,
-                                                     int64_t rows, _Float16* out, int64_t o_st, int64_t o_sh, int Hq, int cap) {
+                                                     int64_t rows, _Float16* out, int64_t o_st, int64_t o_sh, int Hq, int cap,
+                                                     const int32_t* hdr, const int32_t* qoff, const int32_t* qlist) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;  // (uniform: buffer descriptors stay in SGPRs)
     const int q = blockIdx.x, hq = blockIdx.y * 4 + w;
     if (hq >= Hq) return;
+    _Float16* out_q = out + (int64_t)q * o_st;
+    if (hdr && hdr[HDR_QLISTS]) {  // the plan lists every query's rows: one round trip for the list, one for the rows
+        const int o = qoff[q], n = qoff[q + 1] - o;
+        merge_heads_wave<D, 0, 1>(partial_o, partial_lse, row_q, rows, q, hq, 1, Hq, const_cast<int*>(qlist) + o, n, n, out_q, o_sh, lane);
+        return;
+    }
     int* list = reinterpret_cast<int*>(smem) + w * cap;
     int have = scan_rows_wave(row_q, 0, rows < cap ? rows : cap, q, list, cap, lane);
     if (rows > cap) have = -1;
     __builtin_amdgcn_wave_barrier();
-    merge_pair_wave<D, 0>(partial_o, partial_lse, row_q, rows, q, hq, list, cap, have, out + (int64_t)q * o_st + (int64_t)hq * o_sh,
-                          lane);
+    merge_heads_wave<D, 0, 1>(partial_o, partial_lse, row_q, rows, q, hq, 1, Hq, list, cap, have, out_q, o_sh, lane);
 }
 
 // ---------------------------------------------------------------------------
@@ -401,8 +407,6 @@ static constexpr unsigned long long* g_dbg = nullptr;
 // Test hook (deft_debug_plan_form, not in the public header): force the plan kernels' fallback forms, which are
 // otherwise reached only by trees whose run tables exceed the LDS.
 static int g_plan_serial = 0, g_plan_runcap = 0;
-// Test hook (deft_debug_two_launch): decode as stage 1 + merge_kernel instead of the single launch, for bit-for-bit A/B.
-static int g_two_launch = 0;
 
 static int check_launch(const char* what) {
     const hipError_t e = hipGetLastError();
@@ -474,13 +478,6 @@ struct AppendArgs {
     int n_new = 0;
 };
 
-// Where the merged output goes (single-launch decode)
-struct MergeArgs {
-    _Float16* out = nullptr;
-    int64_t o_st = 0, o_sh = 0;
-    int nq = 0, Hq = 0;
-};
-
 static UnitList unit_list(const PlanView& pv) {
     UnitList ul;
     ul.src = pv.units;
@@ -495,6 +492,17 @@ static UnitList unit_list(const PlanView& pv) {
     ul.gq = pv.units + 9 * pv.cap;
     ul.grow = pv.units + 13 * pv.cap;
     return ul;
+}
+
+// Per-query row lists of a plan (plan_kernels.h): after the records kernel has written row_q.
+static int launch_qrows(const PlanView& pv, hipStream_t stream) {
+    const int64_t rows = pv.rows;
+    if (rows <= 0 || rows > QROWS_MAX) return DEFT_OK;  // hdr[HDR_QLISTS] stays 0: the merge scans row_q itself
+    hipLaunchKernelGGL(qrows_hist_kernel, dim3(1), dim3(1024), sizeof(int) * (size_t)rows, stream, pv.row_q, (int)rows, pv.qoff, pv.hdr);
+    int rc = check_launch("qrows hist launch");
+    if (rc) return rc;
+    hipLaunchKernelGGL(qrows_fill_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, pv.row_q, (int)rows, pv.qoff, pv.qlist);
+    return check_launch("qrows fill launch");
 }
 
 static int np_chunk_knob() { return knob("DEFT_NP_CHUNK", 0); }  // tiles per chunk (0 = the plan kernel's rule)
@@ -536,15 +544,15 @@ static int launch_plan(const Stage1Params& p, int NB, const PlanView& pv, const 
     hipLaunchKernelGGL(flatten_records_kernel, dim3((unsigned)(pv.cap + 1)), dim3(128), 0, stream, p.block_q, p.block_q_cnts,
                        p.block_bitmasks, p.block_kv, p.block_lens, p.G, (int)p.rows, p.q_st, p.q_sh, p.kv_ss, ul, pv.hdr,
                        pv.records, pv.row_q, ap.cache_loc, ap.n_new, ap.new_st * 2);
-    return check_launch("flatten records launch");
+    rc = check_launch("flatten records launch");
+    if (rc) return rc;
+    return launch_qrows(pv, stream);
 }
 
 // Stage 1 (head_dim 128): one workgroup per record slot and KV head; slots that are not chunk leaders exit at once
-// (they are at the end of the stage-1 part of the grid).  With `mg`, merge workgroups follow them in the same grid
-// and the call is the whole decode (stage1_np.h); without, the caller launches merge_kernel.
-static bool can_fuse(int Hkv) { return Hkv <= FUSED_MAX_HKV && !g_two_launch; }
+// (they are at the end of the grid).
 static int launch_stage1_np(const Stage1Params& p, int64_t unit_cap, const PlanView& pv, const AppendArgs& ap,
-                            const MergeArgs* mg, hipStream_t stream) {
+                            hipStream_t stream) {
     using SM = NpSmem<128>;
     int rc = raise_lds(reinterpret_cast<const void*>(&stage1_np_kernel<128>), SM::BYTES, ATTR_NP, "stage1_np");
     if (rc) return rc;
@@ -581,37 +589,25 @@ static int launch_stage1_np(const Stage1Params& p, int64_t unit_cap, const PlanV
     npp.new_st = ap.new_st;
     npp.n_new = ap.k_new ? ap.n_new : 0;
     npp.dbg = g_dbg;
-    npp.n_stage1 = (int)grid;
-    int64_t merge_wgs = 0;
-    if (mg && mg->nq > 0) {
-        // a wave per (query, head) pair, at most one merge workgroup per CU: half of the resident slots always stay
-        // with stage 1, so the merge waves' wait cannot starve the workgroups they wait for
-        const int64_t pairs = (int64_t)mg->nq * mg->Hq;
-        merge_wgs = std::min<int64_t>((pairs + 3) / 4, knob("DEFT_MERGE_WGS", num_cus()));
-        npp.fused = 1;
-        npp.row_q = pv.row_q;
-        npp.out = mg->out;
-        npp.o_st = mg->o_st;
-        npp.o_sh = mg->o_sh;
-        npp.nq = mg->nq;
-        npp.Hq = mg->Hq;
-    }
-    hipLaunchKernelGGL((stage1_np_kernel<128>), dim3((unsigned)(grid + merge_wgs)), dim3(256), SM::BYTES, stream, npp);
+    hipLaunchKernelGGL((stage1_np_kernel<128>), dim3((unsigned)grid), dim3(256), SM::BYTES, stream, npp);
     return check_launch("stage1 np launch");
 }
 
-static int launch_merge(int D, const Workspace& ws, const int32_t* row_q, int64_t rows, void* out, int64_t o_st, int64_t o_sh,
-                        int nq, int Hq, hipStream_t stream) {
+static int launch_merge(int D, const Workspace& ws, const PlanView* pv, const int32_t* row_q, int64_t rows, void* out,
+                        int64_t o_st, int64_t o_sh, int nq, int Hq, hipStream_t stream) {
     if (nq <= 0) return DEFT_OK;
     const int cap = (int)std::min<int64_t>(std::max<int64_t>(rows, 64), MERGE_LIST_CAP);
     const size_t lds = sizeof(int) * 4 * (size_t)cap;
     dim3 grid((unsigned)nq, (unsigned)((Hq + 3) / 4));
+    const int32_t* hdr = pv ? pv->hdr : nullptr;
+    const int32_t* qoff = pv ? pv->qoff : nullptr;
+    const int32_t* qlist = pv ? pv->qlist : nullptr;
     if (D == 128)
         hipLaunchKernelGGL((merge_kernel<128>), grid, dim3(256), lds, stream, ws.partial_o, ws.partial_lse, row_q, rows,
-                           static_cast<_Float16*>(out), o_st, o_sh, Hq, cap);
+                           static_cast<_Float16*>(out), o_st, o_sh, Hq, cap, hdr, qoff, qlist);
     else
         hipLaunchKernelGGL((merge_kernel<64>), grid, dim3(256), lds, stream, ws.partial_o, ws.partial_lse, row_q, rows,
-                           static_cast<_Float16*>(out), o_st, o_sh, Hq, cap);
+                           static_cast<_Float16*>(out), o_st, o_sh, Hq, cap, hdr, qoff, qlist);
     return check_launch("merge launch");
 }
 
@@ -658,14 +654,12 @@ int deft_plan_variant(void) {
 }
 
 // Internal hooks (not part of the public header).  deft_debug_plan_form: tests force the plan kernels' fallback
-// forms (serial: one lane emits the plan; runcap > 0: a run table of that many entries).  deft_debug_two_launch:
-// stage 1 and merge as two launches (the single-launch decode is checked against it bit for bit).  deft_debug_set_buffer
+// forms (serial: one lane emits the plan; runcap > 0: a run table of that many entries).  deft_debug_set_buffer
 // (experiments build only): device buffer of 8192 x 8 u64 receiving per-workgroup time stamps of stage 1.
 void deft_debug_plan_form(int serial, int runcap) {
     g_plan_serial = serial;
     g_plan_runcap = runcap;
 }
-void deft_debug_two_launch(int on) { g_two_launch = on; }
 #ifdef DEFT_EXPERIMENTS
 void deft_debug_set_buffer(void* dev_ptr) { g_dbg = static_cast<unsigned long long*>(dev_ptr); }
 #endif
@@ -705,10 +699,10 @@ static int flatten_stage1_impl(const void* q, int64_t q_stride_tok, int64_t q_st
                                const int64_t* block_q_cnts, const int64_t* block_q_offset, const int64_t* block_bitmasks,
                                const int64_t* block_kv, const int64_t* block_lens, int NB, int P, int nq, int Hq, int Hkv,
                                int D, float scale, const void* plan, void* workspace, size_t workspace_bytes, void* stream,
-                               const AppendArgs& ap, const MergeArgs* mg, Workspace* ws_out, const int32_t** row_q_out,
-                               bool* merged) {
+                               const AppendArgs& ap, Workspace* ws_out, const int32_t** row_q_out,
+                               PlanView* pv_out) {
+    pv_out->hdr = nullptr;  // (no plan: head_dim 64)
     // `workspace` doubles as the (unused) output pointer for the shared argument check
-    *merged = false;
     int rc = check_common(q, q_stride_tok, q_stride_head, k_base, v_base, kv_stride_slot, kv_stride_head, workspace, 2, 2,
                           nq, Hq, Hkv, D);
     if (rc) return rc;
@@ -756,11 +750,8 @@ static int flatten_stage1_impl(const void* q, int64_t q_stride_tok, int64_t q_st
             if (rc) return rc;
         }
         *row_q_out = pv.row_q;
-        if (mg && can_fuse(Hkv)) {  // single-launch decode: stage 1 and merge in one grid
-            *merged = true;
-            return launch_stage1_np(p, cap, pv, ap, mg, st);
-        }
-        return launch_stage1_np(p, cap, pv, ap, nullptr, st);
+        *pv_out = pv;
+        return launch_stage1_np(p, cap, pv, ap, st);
     }
     if (ap.k_new) {  // head_dim 64 (tile-per-workgroup form): separate append launch first
         rc = deft_kv_append_f16(const_cast<void*>(k_base), const_cast<void*>(v_base), kv_stride_slot, kv_stride_head,
@@ -822,10 +813,10 @@ int deft_flatten_stage1_f16(const void* q, int64_t q_stride_tok, int64_t q_strid
     }
     Workspace ws;
     const int32_t* row_q = nullptr;
-    bool merged = false;
+    PlanView pv;
     return flatten_stage1_impl(q, q_stride_tok, q_stride_head, k_base, v_base, kv_stride_slot, kv_stride_head, block_q,
                                block_q_cnts, block_q_offset, block_bitmasks, block_kv, block_lens, NB, P, nq, Hq, Hkv, D,
-                               scale, plan, workspace, workspace_bytes, stream, AppendArgs(), nullptr, &ws, &row_q, &merged);
+                               scale, plan, workspace, workspace_bytes, stream, AppendArgs(), &ws, &row_q, &pv);
 }
 
 static int flatten_decode_impl(const void* q, int64_t q_stride_tok, int64_t q_stride_head, const void* k_base,
@@ -846,18 +837,12 @@ static int flatten_decode_impl(const void* q, int64_t q_stride_tok, int64_t q_st
     }
     Workspace ws;
     const int32_t* row_q = nullptr;
-    MergeArgs mg;
-    mg.out = static_cast<_Float16*>(out);
-    mg.o_st = o_stride_tok;
-    mg.o_sh = o_stride_head;
-    mg.nq = nq;
-    mg.Hq = Hq;
-    bool merged = false;
+    PlanView pv;
     rc = flatten_stage1_impl(q, q_stride_tok, q_stride_head, k_base, v_base, kv_stride_slot, kv_stride_head, block_q,
                              block_q_cnts, block_q_offset, block_bitmasks, block_kv, block_lens, NB, P, nq, Hq, Hkv, D, scale,
-                             plan, workspace, workspace_bytes, stream, ap, &mg, &ws, &row_q, &merged);
-    if (rc || merged) return rc;
-    return launch_merge(D, ws, row_q, P, out, o_stride_tok, o_stride_head, nq, Hq, static_cast<hipStream_t>(stream));
+                             plan, workspace, workspace_bytes, stream, ap, &ws, &row_q, &pv);
+    if (rc) return rc;
+    return launch_merge(D, ws, pv.hdr ? &pv : nullptr, row_q, P, out, o_stride_tok, o_stride_head, nq, Hq, static_cast<hipStream_t>(stream));
 }
 
 int deft_flatten_decode_f16(const void* q, int64_t q_stride_tok, int64_t q_stride_head, const void* k_base,
@@ -919,7 +904,9 @@ static int launch_node_plan(const Stage1Params& p, int NE, int64_t rows_cap, con
     hipLaunchKernelGGL(node_records_kernel, dim3((unsigned)(pv.cap + 1)), dim3(128), 0, stream, p.node_kv, p.node_kv_offset,
                        p.node_kv_len, p.node_q, p.node_q_offset, p.node_q_len, p.G, (int)p.rows, p.q_st, p.q_sh, p.kv_ss, ul,
                        pv.hdr, pv.records, pv.row_q, ap.cache_loc, ap.n_new, ap.new_st * 2);
-    return check_launch("node records launch");
+    rc = check_launch("node records launch");
+    if (rc) return rc;
+    return launch_qrows(pv, stream);
 }
 
 size_t deft_node_plan_bytes(int NE, int P, int64_t total_kv, int Hq, int Hkv) {
@@ -1034,18 +1021,9 @@ static int node_decode_impl(const void* q, int64_t q_stride_tok, int64_t q_strid
             rc = launch_node_plan(p, NE, rows, pv, ap, st);
             if (rc) return rc;
         }
-        if (can_fuse(Hkv)) {  // single-launch decode
-            MergeArgs mg;
-            mg.out = static_cast<_Float16*>(out);
-            mg.o_st = o_stride_tok;
-            mg.o_sh = o_stride_head;
-            mg.nq = nq;
-            mg.Hq = Hq;
-            return launch_stage1_np(p, tiles * G, pv, ap, &mg, st);
-        }
-        rc = launch_stage1_np(p, tiles * G, pv, ap, nullptr, st);
+        rc = launch_stage1_np(p, tiles * G, pv, ap, st);
         if (rc) return rc;
-        return launch_merge(D, ws, pv.row_q, rows, out, o_stride_tok, o_stride_head, nq, Hq, st);
+        return launch_merge(D, ws, &pv, pv.row_q, rows, out, o_stride_tok, o_stride_head, nq, Hq, st);
     }
     // tile-per-workgroup form (head_dim 64)
     if (ap.k_new) {  // separate append launch first
@@ -1065,7 +1043,7 @@ static int node_decode_impl(const void* q, int64_t q_stride_tok, int64_t q_strid
     p.desc = ws.desc;
     rc = launch_stage1_d64<1>(p, tiles, st);
     if (rc) return rc;
-    return launch_merge(D, ws, ws.row_q, rows, out, o_stride_tok, o_stride_head, nq, Hq, st);
+    return launch_merge(D, ws, nullptr, ws.row_q, rows, out, o_stride_tok, o_stride_head, nq, Hq, st);
 }
 
 extern "C" {

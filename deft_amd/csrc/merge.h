@@ -41,51 +41,70 @@ __device__ inline int scan_rows_wave(const int32_t* row_q, int64_t from, int64_t
     return n;
 }
 
-// Fold rows list[0 .. n) of one head into the state.  CP = cache policy of the loads (0: ordinary; CP_SYS: the rows
-// were written by other workgroups of this launch).  po / lse: buffer resources over the head's partial rows.
-template <int D, int CP>
-__device__ inline void merge_accumulate(MergeState& st, __amdgpu_buffer_rsrc_t po, __amdgpu_buffer_rsrc_t lse, const int* list,
-                                        int n, int lane) {
+// Fold rows list[0 .. n) of NH heads into their states -- one query, so ONE row list; the heads only differ in the
+// base of their partial rows, and the loads of all NH heads are requested together (one memory round trip for up to
+// NH * NU * RPS rows).  CP = cache policy of the loads (0: ordinary; CP_SYS: the rows were written by other workgroups
+// of this launch).  po / lse: buffer resources over each head's partial rows.
+template <int D, int CP, int NH>
+__device__ inline void merge_accumulate(MergeState (&st)[NH], const __amdgpu_buffer_rsrc_t (&po)[NH],
+                                        const __amdgpu_buffer_rsrc_t (&lse)[NH], const int* list, int n, int lane) {
     constexpr int LPR = D / 4;     // lanes per row (16 bytes each)
     constexpr int RPS = 64 / LPR;  // rows per wave-wide load
-    constexpr int NU = 8;          // loads in flight per lane
+    constexpr int NU = NH >= 4 ? 4 : 8;  // loads in flight per lane and head
     const int sub = lane / LPR, col = lane % LPR;
     for (int cbase = 0; cbase < n; cbase += 64) {
         const int cn = n - cbase < 64 ? n - cbase : 64;
-        float x = -INFINITY;
-        if (lane < cn) x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(lse, list[cbase + lane] * 4, 0, CP));
-        uintx4 v[NU];
+        float x[NH];
+        const int my_row = lane < cn ? list[cbase + lane] : 0;
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            x[h] = -INFINITY;
+            if (lane < cn) x[h] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(lse[h], my_row * 4, 0, CP));
+        }
+        uintx4 v[NH][NU];
         auto load_batch = [&](int b) {
 #pragma unroll
             for (int u = 0; u < NU; ++u) {
                 const int j = b * NU * RPS + u * RPS + sub;
-                v[u] = uintx4{0u, 0u, 0u, 0u};
-                if (j < cn) v[u] = __builtin_amdgcn_raw_buffer_load_b128(po, list[cbase + j] * (D * 4) + col * 16, 0, CP);
+                const int off = j < cn ? list[cbase + j] * (D * 4) + col * 16 : 0;
+#pragma unroll
+                for (int h = 0; h < NH; ++h) {
+                    v[h][u] = uintx4{0u, 0u, 0u, 0u};
+                    if (j < cn) v[h][u] = __builtin_amdgcn_raw_buffer_load_b128(po[h], off, 0, CP);
+                }
             }
         };
-        load_batch(0);  // requested together with the log-sum-exps: one memory round trip for up to NU * RPS rows
-        float cm = x;
+        load_batch(0);  // requested together with the log-sum-exps
+        float wl[NH];
+        bool any = false;
 #pragma unroll
-        for (int sft = 32; sft > 0; sft >>= 1) cm = fmaxf(cm, __shfl_xor(cm, sft));
-        if (cm == -INFINITY) continue;  // wave-uniform: nothing live in this chunk
-        const float m_new = fmaxf(st.m, cm);
-        const float scale = (st.m == -INFINITY) ? 0.f : __expf(st.m - m_new);
-        const float wl = (x == -INFINITY) ? 0.f : __expf(x - m_new);
-        float ws = wl;
+        for (int h = 0; h < NH; ++h) {
+            float cm = x[h];
 #pragma unroll
-        for (int sft = 32; sft > 0; sft >>= 1) ws += __shfl_xor(ws, sft);
-        st.L = st.L * scale + ws;
-        st.acc *= scale;
-        st.m = m_new;
+            for (int sft = 32; sft > 0; sft >>= 1) cm = fmaxf(cm, __shfl_xor(cm, sft));
+            wl[h] = 0.f;
+            if (cm == -INFINITY) continue;  // wave-uniform: nothing live for this head in this chunk
+            any = true;
+            const float m_new = fmaxf(st[h].m, cm);
+            const float scale = (st[h].m == -INFINITY) ? 0.f : __expf(st[h].m - m_new);
+            wl[h] = (x[h] == -INFINITY) ? 0.f : __expf(x[h] - m_new);
+            float ws = wl[h];
+#pragma unroll
+            for (int sft = 32; sft > 0; sft >>= 1) ws += __shfl_xor(ws, sft);
+            st[h].L = st[h].L * scale + ws;
+            st[h].acc *= scale;
+            st[h].m = m_new;
+        }
+        if (!any) continue;
         for (int b = 0; b * NU * RPS < cn; ++b) {
             if (b > 0) load_batch(b);
 #pragma unroll
             for (int u = 0; u < NU; ++u) {
                 const int j = b * NU * RPS + u * RPS + sub;
-                const float wj = __shfl(wl, j & 63);
-                if (j < cn && wj > 0.f) {
-                    const floatx4 f = __builtin_bit_cast(floatx4, v[u]);
-                    st.acc += f * wj;
+#pragma unroll
+                for (int h = 0; h < NH; ++h) {
+                    const float wj = __shfl(wl[h], j & 63);
+                    if (j < cn && wj > 0.f) st[h].acc += __builtin_bit_cast(floatx4, v[h][u]) * wj;
                 }
             }
         }
@@ -110,27 +129,36 @@ __device__ inline void merge_finish(const MergeState& st, _Float16* dst, int lan
     }
 }
 
-// One (query, head) pair, start to finish: rows of the query from row_q (list area of `cap` ints in LDS, longer
-// lists in further passes), merge, store.  `have` >= 0: list[0 .. min(have, cap)) already holds the first scan.
-template <int D, int CP>
-__device__ inline void merge_pair_wave(const float* partial_o, const float* partial_lse, const int32_t* row_q, int64_t rows,
-                                       int q, int hq, int* list, int cap, int have, _Float16* dst, int lane) {
-    const __amdgpu_buffer_rsrc_t po = make_rsrc(partial_o + (int64_t)hq * rows * D);
-    const __amdgpu_buffer_rsrc_t ls = make_rsrc(partial_lse + (int64_t)hq * rows);
-    MergeState st;
+// One query, NH heads (hq0, hq0 + hq_step, ...; those >= Hq are skipped), start to finish: rows of the query from
+// row_q (list area of `cap` ints in LDS, longer lists in further passes), merge, store.  `have` >= 0:
+// list[0 .. min(have, cap)) already holds the scan.
+template <int D, int CP, int NH>
+__device__ inline void merge_heads_wave(const float* partial_o, const float* partial_lse, const int32_t* row_q, int64_t rows,
+                                        int q, int hq0, int hq_step, int Hq, int* list, int cap, int have, _Float16* out_q,
+                                        int64_t o_sh, int lane) {
+    __amdgpu_buffer_rsrc_t po[NH], ls[NH];
+    MergeState st[NH];
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+        const int hq = hq0 + h * hq_step < Hq ? hq0 + h * hq_step : hq0;  // (a skipped head re-reads the first one)
+        po[h] = make_rsrc(partial_o + (int64_t)hq * rows * D);
+        ls[h] = make_rsrc(partial_lse + (int64_t)hq * rows);
+    }
     if (have >= 0 && have <= cap) {  // the usual case: the whole list was scanned ahead of time
-        merge_accumulate<D, CP>(st, po, ls, list, have, lane);
+        merge_accumulate<D, CP, NH>(st, po, ls, list, have, lane);
     } else {
         // a query with more rows than the list area: window by window over row_q (each window holds at most cap rows)
         for (int64_t from = 0; from < rows; from += cap) {
             const int64_t to = from + cap < rows ? from + cap : rows;
             const int n = scan_rows_wave(row_q, from, to, q, list, cap, lane);
             __builtin_amdgcn_wave_barrier();
-            merge_accumulate<D, CP>(st, po, ls, list, n, lane);
+            merge_accumulate<D, CP, NH>(st, po, ls, list, n, lane);
             __builtin_amdgcn_wave_barrier();
         }
     }
-    merge_finish<D>(st, dst, lane);
+#pragma unroll
+    for (int h = 0; h < NH; ++h)
+        if (hq0 + h * hq_step < Hq) merge_finish<D>(st[h], out_q + (int64_t)(hq0 + h * hq_step) * o_sh, lane);
 }
 
 }  // namespace deft

@@ -457,8 +457,7 @@ __global__ __launch_bounds__(1024) void flatten_units_kernel(const int64_t* bloc
             hdr[0] = r;
             hdr[1] = 0;
             hdr[HDR_ERR] = 0;
-            hdr[HDR_MDONE] = 0;  // arrival counters of the single-launch decode: 0 between launches
-            for (int k = 0; k < FUSED_MAX_HKV; ++k) hdr[HDR_DONE + HDR_DONE_STRIDE * k] = 0;
+            hdr[HDR_QLISTS] = 0;
             if (par && rt.n <= rt.cap) {
                 sMeta[0] = r;
                 sMeta[1] = rt.n;
@@ -716,8 +715,7 @@ __global__ __launch_bounds__(1024) void node_units_kernel(const int64_t* node_kv
                 hdr[0] = r;
                 hdr[1] = 0;
                 hdr[HDR_ERR] = 0;
-                hdr[HDR_MDONE] = 0;  // arrival counters of the single-launch decode: 0 between launches
-                for (int k = 0; k < FUSED_MAX_HKV; ++k) hdr[HDR_DONE + HDR_DONE_STRIDE * k] = 0;
+                hdr[HDR_QLISTS] = 0;
                 if (par && rt.n <= rt.cap) {
                     sMeta[0] = r;
                     sMeta[1] = rt.n;
@@ -869,6 +867,82 @@ __global__ __launch_bounds__(128) void node_records_kernel(const int64_t* node_k
         desc[1] = prow;
         desc[2] = ul.flags[u] & 1;
         desc[3] = ul.flags[u] >> 1;
+    }
+}
+
+}  // namespace deft
+
+namespace deft {
+
+// ---------------------------------------------------------------------------
+// Per-query row lists: which partial rows the merge of query q reads, ascending.  row_q (partial row -> query, -1 =
+// dead) is written record by record; every layer's merge would otherwise scan it again (two to six dependent round
+// trips per launch, 32 times per step).  Two small kernels once per step: a histogram + exclusive scan (one workgroup),
+// then one wave per query collecting its rows in order (ordered ballots, no atomics: the lists -- and the order of
+// the merge's fp32 additions -- are a function of the plan alone).
+// ---------------------------------------------------------------------------
+constexpr int QROWS_MAX = 15 * 1024;  // rows whose histogram fits the LDS; larger workspaces keep the scanning merge
+
+__global__ __launch_bounds__(1024) void qrows_hist_kernel(const int32_t* row_q, int rows, int32_t* qoff, int32_t* hdr) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int* sCnt = reinterpret_cast<int*>(smem);  // [rows] then scanned in place
+    __shared__ int sWave[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < rows; i += 1024) sCnt[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < rows; i += 1024) {
+        const int q = row_q[i];
+        if (q >= 0 && q < rows) atomicAdd(&sCnt[q], 1);  // LDS integer adds: the counts do not depend on the order
+    }
+    __syncthreads();
+    // exclusive scan of sCnt[0 .. rows): thread t owns the consecutive span [t * per, (t + 1) * per)
+    const int per = (rows + 1023) / 1024;
+    const int lo = tid * per, hi = min(rows, lo + per);
+    int sum = 0;
+    for (int i = lo; i < hi; ++i) sum += sCnt[i];
+    int inc = sum;
+    for (int d = 1; d < 64; d <<= 1) {
+        const int u = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += u;
+    }
+    if (lane == 63) sWave[wave] = inc;
+    __syncthreads();
+    int base = 0;
+    for (int k = 0; k < wave; ++k) base += sWave[k];
+    int run = base + inc - sum;
+    for (int i = lo; i < hi; ++i) {
+        const int c = sCnt[i];
+        qoff[i] = run;
+        run += c;
+    }
+    if (tid == 1023) {
+        qoff[rows] = run;
+        hdr[HDR_QLISTS] = 1;
+    }
+}
+
+// one wave per query (four per workgroup): the query's rows, ascending, into qlist[qoff[q] ..)
+__global__ __launch_bounds__(256) void qrows_fill_kernel(const int32_t* row_q, int rows, const int32_t* qoff, int32_t* qlist) {
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= rows) return;
+    const int o = qoff[q], n = qoff[q + 1] - o;
+    if (n <= 0) return;  // (not a query of this step)
+    int found = 0;
+    for (int base = 0; base < rows && found < n; base += 512) {
+        int val[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = base + 64 * u + lane;
+            val[u] = (i < rows) ? row_q[i] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const bool hit = val[u] == q;
+            const unsigned long long mask = __ballot(hit);
+            if (hit) qlist[o + found + __popcll(mask & ((1ull << lane) - 1ull))] = base + 64 * u + lane;
+            found += __popcll(mask);
+        }
     }
 }
 

@@ -22,17 +22,11 @@ constexpr int PLAN_OROW = 1728;  // int32[32]   partial row of row v, relative t
 
 // Plan header (4 KB in front of the records), int32 words:
 //   hdr[0]  R   records (units) per KV head          hdr[1]  NL  chunk leaders (work items per KV head)
-//   hdr[2]  error flags raised by the kernels (bit 0: a merge wave gave up waiting; bit 1: sequential plan overflow)
-//   hdr[HDR_MDONE]           merge waves that have finished (single-launch decode; the last one re-arms the words)
-//   hdr[HDR_DONE + 16 kvh]   chunks of KV head kvh whose partial rows are in memory; one cache line per head
-// All counters are 0 between launches: a plan serves ONE launch at a time (the layers of a decode step run in
-// stream order).
+//   hdr[2]  error flags raised by the plan kernels (bit 1: sequential plan overflow)
+//   hdr[3]  1 = the per-query row lists (qoff / qlist) are valid; 0 = the merge scans row_q itself
 constexpr int PLAN_HDR = 4096;
 constexpr int HDR_ERR = 2;
-constexpr int HDR_MDONE = 16;
-constexpr int HDR_DONE = 128;
-constexpr int HDR_DONE_STRIDE = 16;
-constexpr int FUSED_MAX_HKV = (PLAN_HDR / 4 - HDR_DONE) / HDR_DONE_STRIDE;  // 56 KV heads fit the header
+constexpr int HDR_QLISTS = 3;
 
 // 64 lanes x 16 bytes, global (per-lane address) -> LDS (lds_dst + 16*lane).  M0 is not
 // otherwise used by the kernels (checked in the .s), so it is written, not saved.
@@ -66,10 +60,7 @@ __device__ __forceinline__ void wait_vm() {
 
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// Buffer resource over a float array for loads / stores with an explicit cache policy (the hand-off of partial rows
-// from the stage-1 workgroups to the merge waves of the same launch: write-through `sc0 sc1` stores and `sc0 sc1` loads on
-// both sides, MI355X_MICROARCH.md "Workgroup dispatch, XCD placement & inter-workgroup visibility").
-constexpr int CP_SYS = 17;  // cache policy bits: sc0 (1) | sc1 (16)
+// Buffer resource over a float array: the merge addresses partial rows as descriptor (per head, in SGPRs) + 32-bit offset.
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
 }

@@ -24,13 +24,11 @@
 //     offsets and masks (4-byte LDS-DMA into a per-wave area) and nothing else stand between launch and the first
 //     K/V request.  Records beyond the leaders exit at once; they sit at the end of the grid.
 //
-// Single-launch decode (`fused`): the LAST workgroups of the grid are merge workgroups.  Each of their waves owns
-// (query, head) pairs: it lists the query's partial rows from row_q while stage 1 is still running, waits until every
-// chunk of its KV head has delivered (one arrival counter per KV head in the plan header, bumped by a stage-1
-// workgroup once its write-through partial stores have completed), then merges and writes the output row -- the
-// stage-2 launch, its ramp and the kernel boundary in front of it are gone, and heads that finish early are merged
-// under the tail of the others.  Merge workgroups never outnumber half of the resident slots, so stage-1 workgroups
-// can always be placed whatever order the dispatcher picks.
+// The merge stays a launch of its own (merge_kernel).  Round 2 built and measured the alternative -- merge workgroups
+// inside this launch, waiting on per-KV-head arrival counters for the write-through partial rows -- in four forms
+// (profiles/r2_fused_merge_negative.txt): correct, bit-identical, and 3-30 us per layer SLOWER
+// than two launches on every workload: a waiting workgroup holds a slot stage 1 wants, a thousand pollers delay
+// every arrival, and a cross-workgroup read of fresh rows moves a few GB/s per wave.
 #pragma once
 
 namespace deft {
@@ -38,16 +36,9 @@ namespace deft {
 struct NpParams {
     Stage1Params s;
     const char* plan;  // [cap+1][PLAN_BYTES], leaders first (np_record_order)
-    int32_t* hdr;      // plan header (plan_records.h): hdr[1] = number of chunk leaders; arrival counters
+    const int32_t* hdr;  // plan header (plan_records.h): hdr[1] = number of chunk leaders
     int fast_n;        // workgroups < fast_n (the ones resident at launch) request tile 0's offsets before anything else
-    int n_stage1;      // workgroups [0, n_stage1) run stage 1; the rest of the grid are merge workgroups
-    // single-launch decode: merge in the same launch (0: stage 1 only, the caller launches merge_kernel)
-    int fused;
-    const int32_t* row_q;  // partial row -> query (-1 = dead row)
-    _Float16* out;
-    int64_t o_st, o_sh;
-    int nq, Hq;
-    // fused paged append (optional), as in StreamParams
+    // fused paged append (optional): rows whose plan offset has bit 63 set are read from k_new / v_new
     const _Float16* k_new;
     const _Float16* v_new;
     const int32_t* cache_loc;
@@ -96,51 +87,8 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
     const int c = l & 31;
     const int h = l >> 5;
     const int bid = blockIdx.x;
-    const int W = np.n_stage1;  // stage-1 workgroups (stride of the item loop)
+    const int W = (int)gridDim.x;
     unsigned long long t_start = 0, t_k0 = 0, t_epi = 0;
-
-    // ---- merge workgroups (single-launch decode): the tail of the grid ------------------------------------
-    if (bid >= W) {
-        // Wave gw of the 4 M merge waves takes pairs gw, gw + 4 M, ...; pair = (query p % nq, head p / nq).
-        const int M = (int)gridDim.x - W;
-        const int gw = (bid - W) * 4 + w;
-        const int pairs = np.nq * np.Hq;
-        constexpr int LIST_CAP = 4096;  // row ids per wave (16 KB of the workgroup's LDS each)
-        static_assert(4 * LIST_CAP * 4 <= SM::BYTES, "merge lists fit the stage-1 LDS allocation");
-        int* list = reinterpret_cast<int*>(smem) + w * LIST_CAP;
-        int have_q = -1, have = -1;
-        int NL = 0;
-        for (int pr = gw; pr < pairs; pr += 4 * M) {
-            const int q = pr % np.nq, hq = pr / np.nq;
-            if (q != have_q) {  // list the query's partial rows while stage 1 is still running
-                have = scan_rows_wave(np.row_q, 0, p.rows < LIST_CAP ? p.rows : LIST_CAP, q, list, LIST_CAP, l);
-                if (p.rows > LIST_CAP) have = -1;  // longer workspaces: merge_pair_wave scans window by window
-                have_q = q;
-                __builtin_amdgcn_wave_barrier();
-            }
-            // wait for every chunk of this KV head (bounded: a lost arrival must not hang the GPU)
-            const int32_t* cnt = np.hdr + HDR_DONE + HDR_DONE_STRIDE * (hq / p.G);
-            if (NL == 0) NL = __builtin_amdgcn_readfirstlane(__hip_atomic_load(np.hdr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            bool ok = false;
-            for (int spin = 0; spin < (1 << 22); ++spin) {
-                const int got = __builtin_amdgcn_readfirstlane(__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                if (got >= NL) {
-                    ok = true;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(16);
-            }
-            if (!ok && l == 0) atomicOr(np.hdr + HDR_ERR, 1);
-            merge_pair_wave<D, CP_SYS>(p.partial_o, p.partial_lse, np.row_q, p.rows, q, hq, list, LIST_CAP, have,
-                                       np.out + (int64_t)q * np.o_st + (int64_t)hq * np.o_sh, l);
-        }
-        // the last merge wave to leave re-arms the arrival counters for the next launch (graph-safe: no memset)
-        if (l == 0 && atomicAdd(np.hdr + HDR_MDONE, 1) == 4 * M - 1) {
-            np.hdr[HDR_MDONE] = 0;
-            for (int k = 0; k < p.Hkv; ++k) np.hdr[HDR_DONE + HDR_DONE_STRIDE * k] = 0;
-        }
-        return;
-    }
 
     // ---- fused paged append: new-token row j is copied into the pool by workgroup (grid-1-j) % grid (nobody reads
     //      those pool rows in this launch: rows flagged NEW in the plan are taken from k_new / v_new) ------------
@@ -248,7 +196,7 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
         const int nl = np.hdr[1];
         const int d4 = desc0[4], d0 = desc0[0], d5 = desc0[5];  // speculative for slots beyond the leaders: valid memory
         NI = __builtin_amdgcn_readfirstlane(nl) * p.Hkv;
-        if (item >= NI) {
+        if (item >= NI) {  // this record slot leads no chunk: merge duty (single-launch decode) or nothing
             if (spec) wait_vm<0>();
             break;
         }
@@ -256,7 +204,6 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
         sd0 = __builtin_amdgcn_readfirstlane(d0);
         sd5 = __builtin_amdgcn_readfirstlane(d5);
     } else {
-        if ((unsigned)item >= (unsigned)NI) break;  // resident mode: a ticket beyond the last item
         sd4 = __builtin_amdgcn_readfirstlane(desc0[4]);
         sd0 = __builtin_amdgcn_readfirstlane(desc0[0]);
         sd5 = __builtin_amdgcn_readfirstlane(desc0[5]);
@@ -414,7 +361,6 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
     if (!(ABL(64))) lds_barrier();
     const int64_t head_rows = (int64_t)kvh * p.G * p.rows;
     const int32_t* orow = reinterpret_cast<const int32_t*>(smem + SM::OROW_OFF);
-    const __amdgpu_buffer_rsrc_t rs_o = make_rsrc(p.partial_o + head_rows * D), rs_l = make_rsrc(p.partial_lse + head_rows);
     // wave w sums the 16-byte chunks 8w .. 8w+7 of every row: lane = (row within a group of 8, chunk)
     const int k4 = 8 * w + (l & 7);
     for (int q0 = 0; q0 < nv; q0 += 8) {
@@ -439,16 +385,9 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
             if (ABL(32)) continue;
             const floatx4 res = a * inv;
             const float lse = (L > 0.f) ? (M + __builtin_amdgcn_logf(L)) * LN2 : -INFINITY;
-            if (np.fused) {
-                // read by a merge wave of this launch, possibly on another XCD: write-through stores (one descriptor
-                // per KV head -- wave-uniform -- and the row in the per-lane offset)
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uintx4, res), rs_o, orow_q * (D * 4) + 16 * k4, 0, CP_SYS);
-                if (k4 == 0) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, lse), rs_l, orow_q * 4, 0, CP_SYS);
-            } else {
-                const int64_t row = head_rows + orow_q;
-                *reinterpret_cast<floatx4*>(p.partial_o + row * D + 4 * k4) = res;
-                if (k4 == 0) p.partial_lse[row] = lse;
-            }
+            const int64_t row = head_rows + orow_q;
+            *reinterpret_cast<floatx4*>(p.partial_o + row * D + 4 * k4) = res;
+            if (k4 == 0) p.partial_lse[row] = lse;
         }
     }
     if (DBG && tid == 0 && item < 8192) {
@@ -462,20 +401,12 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
         d[3] = wall_clock64();
         d[4] = (unsigned long long)n;
         d[5] = ((unsigned long long)xcc << 32) | hw;
+        d[6] = (unsigned long long)kvh;
     }
-    // Arrival (single-launch decode): this wave's partial stores have completed -- write-through, so they are in
-    // memory -- then, behind the barrier, ONE bump of the KV head's counter; the merge waves poll it.
-    if (np.fused) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        lds_barrier();
-        if (tid == 0) __hip_atomic_fetch_add(np.hdr + HDR_DONE + HDR_DONE_STRIDE * kvh, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (item + W >= NI) break;
-    } else {
-        // Next item of a capped grid: record capacity beyond the chunk leaders would otherwise be launched as workgroups
-        // that only find out that they have nothing to do (tens of thousands for the sequential comparator's entries).
-        if (item + W >= NI) break;
-        lds_barrier();  // every wave is done reading the others' slices
-    }
+    // Next item of a capped grid: record capacity beyond the chunk leaders would otherwise be launched as workgroups
+    // that only find out that they have nothing to do (tens of thousands for the sequential comparator's entries).
+    if (item + W >= NI) break;
+    lds_barrier();  // every wave is done reading the others' slices
     item += W;
     }  // work items
 }

@@ -321,13 +321,11 @@ def test_full_size_properties_northstar_tree():
         assert (o1[r].float() - ref).abs().max().item() < TOL
 
 
-@pytest.mark.parametrize("two_launch", [0, 1])
-def test_full_size_fold_structure_does_not_change_the_result(two_launch):
+def test_full_size_fold_structure_does_not_change_the_result():
     """BASELINE's north-star tree (Llama-2-7B, 4096 x 32 x 200 tokens) through every decomposition the library has:
     Flatten blocks (chunks + union groups), Node entries cut into tiles, and the sequential comparator over the page
-    table (every leaf its own full path); as the single-launch decode and as stage 1 + merge_kernel.  Folding changes
-    the order of fp32 additions, nothing else: all agree within the exact-merge tolerance, each is bit-deterministic;
-    three leaves against torch fp32 attention."""
+    table (every leaf its own full path).  Folding changes the order of fp32 additions, nothing else: all agree within
+    the exact-merge tolerance, each is bit-deterministic; three leaves against torch fp32 attention."""
     from deft_amd.utils.workloads import Workload, build_tree
 
     w = Workload("t", "llama2-7b", "flatten", "few_shot", 4096, 32, 200)
@@ -340,24 +338,20 @@ def test_full_size_fold_structure_does_not_change_the_result(two_launch):
     o_ref = torch.zeros_like(q)
     deft_amd.tree_attention_subtree_fwd(q, kb, vb, o_ref, *_flatten_args(md))  # default: single launch
     torch.cuda.synchronize()
-    deft_amd.lib.deft_debug_two_launch(two_launch)
-    try:
-        outs = []
-        for _ in range(2):
-            o = torch.full_like(q, float("nan"))
-            deft_amd.tree_attention_subtree_fwd(q, kb, vb, o, *_flatten_args(md))
-            outs.append(o)
-        o_node = torch.full_like(q, float("nan"))
-        deft_amd.tree_attention_fwd(q, kb, vb, o_node, md.node_kv, md.node_kv_offset, md.node_kv_len, md.node_q,
-                                    md.node_q_offset, md.node_q_len)
-        meta, lens = _seq_metadata(tree)
-        o_seq = torch.full_like(q, float("nan"))
-        deft_amd.token_attention_fwd(q, kb, vb, o_seq, tree.req_to_token_pool.req_to_token, meta.req_pool_indices,
-                                     meta.start_loc, meta.seq_lens, meta.max_seq_len, None, meta.total_num_tokens)
-        torch.cuda.synchronize()
-    finally:
-        deft_amd.lib.deft_debug_two_launch(0)
-    assert torch.equal(outs[0], o_ref)  # the merge waves of the single launch and merge_kernel run the same code
+    outs = []
+    for _ in range(2):
+        o = torch.full_like(q, float("nan"))
+        deft_amd.tree_attention_subtree_fwd(q, kb, vb, o, *_flatten_args(md))
+        outs.append(o)
+    o_node = torch.full_like(q, float("nan"))
+    deft_amd.tree_attention_fwd(q, kb, vb, o_node, md.node_kv, md.node_kv_offset, md.node_kv_len, md.node_q,
+                                md.node_q_offset, md.node_q_len)
+    meta, lens = _seq_metadata(tree)
+    o_seq = torch.full_like(q, float("nan"))
+    deft_amd.token_attention_fwd(q, kb, vb, o_seq, tree.req_to_token_pool.req_to_token, meta.req_pool_indices,
+                                 meta.start_loc, meta.seq_lens, meta.max_seq_len, None, meta.total_num_tokens)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], o_ref)
     assert torch.equal(outs[0], outs[1])
     for o in (outs[0], o_node, o_seq):
         assert torch.isfinite(o.float()).all()

@@ -33,6 +33,14 @@ for rep in range(3):
         m = n == nn
         print(f"  n={int(nn)}: {int(m.sum()):4d} WGs  start {pct(st[m])}  ramp(start->K0) {pct((k0 - st)[m])}  body {pct((ep - k0)[m])}  "
               f"epilogue {pct((en - ep)[m])}  total {pct((en - st)[m])}  end {pct(en[m])}")
+    # single-launch decode: how long after its KV head's last stage-1 workgroup ended did a merge workgroup see the
+    # counter complete, and how long did its merges take
+    mg = n == 1000
+    if mg.any():
+        kvh = d[:, 6]
+        head_done = {int(k): float(en[(~mg) & (kvh == k)].max()) for k in set(kvh[~mg].tolist())}
+        lag = np.array([wt - head_done.get(int(k), 0.0) for wt, k in zip(ep[mg], kvh[mg])])
+        print(f"  merge WGs: saw-complete minus head-done {pct(lag)}  merge duration {pct((en - ep)[mg])}  stage-1 last end {en[~mg].max():.2f}  head-done {pct(np.array(list(head_done.values())))}")
     # occupancy over time: workgroups alive per microsecond
     edges = np.arange(0, en.max() + 1, 2.0)
     alive = [(int(((st <= t) & (en > t)).sum())) for t in edges]
