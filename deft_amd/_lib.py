@@ -103,19 +103,35 @@ lib.deft_md_free.argtypes = [_i64]
 lib.deft_md_free.restype = C.c_int
 lib.deft_tree_create.argtypes = []
 lib.deft_tree_create.restype = _i64
-lib.deft_tree_free.argtypes = [_i64]
-lib.deft_tree_add_node.argtypes = [_i64, _i64, _i64]
-lib.deft_tree_remove_node.argtypes = [_i64, _i64]
-lib.deft_tree_set_leaf.argtypes = [_i64, _i64, C.c_int]
-lib.deft_tree_append_slots.argtypes = [_i64, C.c_int, _vp, _vp]
-lib.deft_tree_extend_node.argtypes = [_i64, _i64, C.c_int, _vp]
-lib.deft_tree_clear_node_kv.argtypes = [_i64, _i64]
-lib.deft_tree_stats.argtypes = [_i64, _vp]
-lib.deft_tree_build_md.argtypes = [_i64, C.c_int, C.c_int, C.c_int]
-lib.deft_tree_build_md.restype = _i64
-for _f in ("deft_tree_free", "deft_tree_add_node", "deft_tree_remove_node", "deft_tree_set_leaf", "deft_tree_append_slots",
-           "deft_tree_extend_node", "deft_tree_clear_node_kv", "deft_tree_stats"):
-    getattr(lib, _f).restype = C.c_int
+_TREE_FUNCS = {
+    "deft_tree_free": ([_i64], C.c_int),
+    "deft_tree_add_node": ([_i64, _i64, _i64], C.c_int),
+    "deft_tree_remove_node": ([_i64, _i64], C.c_int),
+    "deft_tree_set_leaf": ([_i64, _i64, C.c_int], C.c_int),
+    "deft_tree_branch": ([_i64, _i64, C.c_int, _i64], C.c_int),
+    "deft_tree_cut": ([_i64, _i64, _vp, C.c_int, _vp, _vp, _i64, _vp], C.c_int),
+    "deft_tree_alloc_step": ([_i64, C.c_int, _vp], C.c_int),
+    "deft_tree_append_slots": ([_i64, C.c_int, _vp, _vp], C.c_int),
+    "deft_tree_extend_node": ([_i64, _i64, C.c_int, _vp], C.c_int),
+    "deft_tree_set_node_kv": ([_i64, _i64, C.c_int, _vp], C.c_int),
+    "deft_tree_clear_node_kv": ([_i64, _i64], C.c_int),
+    "deft_tree_node_len": ([_i64, _i64], _i64),
+    "deft_tree_node_kv": ([_i64, _i64, _vp, _i64], _i64),
+    "deft_tree_node_refs": ([_i64, _i64, _vp, _i64], _i64),
+    "deft_tree_path_slots": ([_i64, _i64, _vp, _i64], _i64),
+    "deft_tree_leaf_ids": ([_i64, _vp, C.c_int], C.c_int),
+    "deft_tree_stats": ([_i64, _vp], C.c_int),
+    "deft_tree_build_md": ([_i64, C.c_int, C.c_int, C.c_int], _i64),
+    "deft_tree_layout": ([_i64, C.c_int, _vp], C.c_int),
+    "deft_tree_layout_fetch": ([_i64, _vp, _vp, _vp, _vp, _vp, _vp], C.c_int),
+    "deft_tree_md_sizes": ([_i64, C.c_int, C.c_int, C.c_int, C.c_int, _vp], C.c_int),
+    "deft_tree_dev_scratch_bytes": ([C.c_int, C.c_int, C.c_int], _sz),
+    "deft_tree_dev_advance": ([C.c_int, C.c_int, C.c_int] + [_vp] * 9, C.c_int),
+    "deft_tree_dev_build_md": ([C.c_int, C.c_int, C.c_int] + [_vp] * 6 + [C.c_int] * 4 + [_vp, _sz] + [_vp] * 12 + [_vp], C.c_int),
+}
+for _f, (_a, _r) in _TREE_FUNCS.items():
+    getattr(lib, _f).argtypes = _a
+    getattr(lib, _f).restype = _r
 
 EXPORTED = (
     "deft_abi_version", "deft_last_error", "deft_supported", "deft_plan_variant",
@@ -125,9 +141,8 @@ EXPORTED = (
     "deft_node_decode_f16", "deft_node_decode_append_f16",
     "deft_prefill_f16", "deft_rope_qk_f16", "deft_seq_plan_bytes", "deft_seq_workspace_bytes", "deft_seq_build_plan", "deft_seq_decode_f16", "deft_seq_decode_append_f16",
     "deft_kv_append_f16", "deft_md_build", "deft_md_sizes", "deft_md_fetch", "deft_md_free",
-    "deft_tree_create", "deft_tree_free", "deft_tree_add_node", "deft_tree_remove_node", "deft_tree_set_leaf",
-    "deft_tree_append_slots", "deft_tree_extend_node", "deft_tree_clear_node_kv", "deft_tree_stats", "deft_tree_build_md",
-)
+    "deft_tree_create",
+) + tuple(_TREE_FUNCS)
 
 _ERR_NAMES = {-1: "DEFT_EINVAL", -2: "DEFT_EUNSUPPORTED", -3: "DEFT_EHIP", -4: "DEFT_EWORKSPACE"}
 

@@ -288,6 +288,7 @@ __global__ __launch_bounds__(256, 2) void stage1_kernel(Stage1Params p) {
 }  // namespace deft
 #include "plan_records.h"
 #include "plan_kernels.h"
+#include "tree_plan.h"
 #include "merge.h"
 #include "stage1_np.h"
 #include "prefill.h"
@@ -1413,3 +1414,100 @@ extern "C" int deft_prefill_f16(const void* q, int64_t q_stride_tok, int64_t q_s
                        static_cast<hipStream_t>(stream), p);
     return check_launch("prefill launch");
 }
+
+
+// ---------------------------------------------------------------------------
+// Device-side TreeMetadata (tree_plan.h): TreeMetadata.from_tree_cache (tree_cache.py:618-881) from the compact tree
+// that lives on the GPU.  The host-side tree (tree.cpp) lays the tree out and computes the sizes; these calls
+// only launch.
+// ---------------------------------------------------------------------------
+namespace deft {
+static TreeScratch tree_scratch_view(void* base, int n, int nqw, int nbp_cap, size_t* bytes) {
+    TreeScratch s;
+    char* p = static_cast<char*>(base);
+    size_t off = 0;
+    auto take = [&](size_t count, size_t elem) {
+        char* r = p + off;
+        off = align_up(off + count * elem, 256);
+        return r;
+    };
+    s.dims = reinterpret_cast<int32_t*>(take(TREE_DIMS, 4));
+    s.pos = reinterpret_cast<int32_t*>(take((size_t)n + 1, 4));
+    s.e_off = reinterpret_cast<int32_t*>(take((size_t)n + 1, 4));
+    s.q_off = reinterpret_cast<int32_t*>(take((size_t)n + 1, 4));
+    s.kv_off = reinterpret_cast<int32_t*>(take((size_t)n + 1, 4));
+    s.b_first = reinterpret_cast<int32_t*>(take((size_t)nbp_cap + 1, 4));
+    s.b_eoff = reinterpret_cast<int32_t*>(take((size_t)nbp_cap + 1, 4));
+    s.b_poff = reinterpret_cast<int32_t*>(take((size_t)nbp_cap + 1, 4));
+    s.b_union = reinterpret_cast<unsigned long long*>(take((size_t)(nbp_cap + 1) * (size_t)nqw, 8));
+    *bytes = off;
+    return s;
+}
+}  // namespace deft
+
+extern "C" {
+
+/* scratch of deft_tree_dev_build_md; its first 16 int32 are dims[]: query_num, NE, total_kv, len(node_q), len(node_kv),
+ * NB, P, len(block_kv), physical blocks, error flags (bit 0: a leaf outgrew its room, bit 1: more blocks than nbp_cap) --
+ * zero them when a layout is uploaded */
+size_t deft_tree_dev_scratch_bytes(int n_nodes, int nqw, int nbp_cap) {
+    if (n_nodes < 0 || nqw < 1 || nbp_cap < 0) return 0;
+    size_t bytes = 0;
+    tree_scratch_view(nullptr, n_nodes, nqw, nbp_cap, &bytes);
+    return bytes;
+}
+
+int deft_tree_dev_advance(int n_nodes, int nq, int nqw, const int32_t* node_start, int32_t* node_len, const int32_t* node_cap,
+                          const uint64_t* refs, const int32_t* leaf_node, int32_t* slots, const int32_t* cache_loc,
+                          void* scratch, void* stream) {
+    if (nq == 0) return DEFT_OK;
+    if (n_nodes <= 0 || nq < 0 || nqw < 1 || !node_start || !node_len || !node_cap || !refs || !leaf_node || !slots || !cache_loc ||
+        !scratch) {
+        set_error("deft_tree_dev_advance: bad arguments (nodes=%d nq=%d)", n_nodes, nq);
+        return DEFT_EINVAL;
+    }
+    TreeDev t{n_nodes, nq, nqw, node_start, node_len, node_cap, reinterpret_cast<const unsigned long long*>(refs), leaf_node, slots};
+    hipLaunchKernelGGL(tree_advance_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), t,
+                       cache_loc, static_cast<int32_t*>(scratch) + TREE_ERR);
+    return check_launch("tree advance launch");
+}
+
+int deft_tree_dev_build_md(int n_nodes, int nq, int nqw, const int32_t* node_start, int32_t* node_len, const int32_t* node_cap,
+                           const uint64_t* refs, const int32_t* leaf_node, int32_t* slots, int max_q_len, int block_len,
+                           int max_block_len, int nbp_cap, void* scratch, size_t scratch_bytes, int64_t* node_q, int64_t* node_kv,
+                           int64_t* node_q_len, int64_t* node_kv_len, int64_t* node_q_offset, int64_t* node_kv_offset,
+                           int64_t* block_q, int64_t* block_q_cnts, int64_t* block_q_offset, int64_t* block_bitmasks,
+                           int64_t* block_kv, int64_t* block_lens, void* stream) {
+    if (n_nodes <= 0 || nq < 0 || nqw < 1 || nbp_cap < 0 || !node_start || !node_len || !node_cap || !refs || !leaf_node || !slots ||
+        !scratch || !node_q || !node_kv || !node_q_len || !node_kv_len || !node_q_offset || !node_kv_offset || !block_q ||
+        !block_q_cnts || !block_q_offset || !block_bitmasks || !block_kv || !block_lens) {
+        set_error("deft_tree_dev_build_md: bad arguments (nodes=%d nq=%d)", n_nodes, nq);
+        return DEFT_EINVAL;
+    }
+    if (max_q_len < 1 || max_q_len > 63 || block_len < 1 || block_len > 1024 || (max_block_len < 1 && max_block_len != -1)) {
+        set_error("deft_tree_dev_build_md: bad config max_q_len=%d block_len=%d max_block_len=%d", max_q_len, block_len, max_block_len);
+        return DEFT_EINVAL;
+    }
+    size_t need = 0;
+    const TreeScratch sc = tree_scratch_view(scratch, n_nodes, nqw, nbp_cap, &need);
+    if (scratch_bytes < need) {
+        set_error("tree scratch too small: %zu < %zu", scratch_bytes, need);
+        return DEFT_EWORKSPACE;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    TreeDev t{n_nodes, nq, nqw, node_start, node_len, node_cap, reinterpret_cast<const unsigned long long*>(refs), leaf_node, slots};
+    TreeMdOut o{node_q, node_kv, node_q_len, node_kv_len, node_q_offset, node_kv_offset,
+                block_q, block_q_cnts, block_q_offset, block_bitmasks, block_kv, block_lens};
+    hipLaunchKernelGGL(tree_md_scan_kernel, dim3(1), dim3(1024), 0, st, t, sc, max_q_len, block_len, max_block_len, nbp_cap);
+    int rc = check_launch("tree scan launch");
+    if (rc) return rc;
+    if (nbp_cap > 0) {
+        hipLaunchKernelGGL(tree_md_blocks_kernel, dim3((unsigned)nbp_cap), dim3(128), 0, st, t, sc, o, max_q_len, block_len);
+        rc = check_launch("tree blocks launch");
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(tree_md_nodes_kernel, dim3((unsigned)n_nodes, 4), dim3(256), 0, st, t, sc, o, max_q_len, max_block_len);
+    return check_launch("tree nodes launch");
+}
+
+}  // extern "C"

@@ -314,154 +314,4 @@ int deft_md_free(int64_t handle) {
 }
 
 
-// ---- persistent tree mirror ----------------------------------------------------------------
-// The host-side TreeCache (deft_amd/tree_cache.py) forwards every mutation of the tree here, so building
-// the operator metadata for a decode step needs no per-step marshalling of Python lists (0.3 ms for a
-// 10k-token tree, three times the build itself): SURVEY.md §8f-1.
-namespace deft {
-struct MirrorNode {
-    int64_t parent = -1;
-    uint8_t leaf = 0;
-    std::vector<int64_t> kv;
-};
-struct TreeMirror {
-    std::unordered_map<int64_t, MirrorNode> nodes;
-    std::mutex mu;
-};
-static std::unordered_map<int64_t, std::unique_ptr<TreeMirror>> g_trees;
-static TreeMirror* find_tree(int64_t h) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    auto it = g_trees.find(h);
-    return it == g_trees.end() ? nullptr : it->second.get();
-}
-}  // namespace deft
-
-int64_t deft_tree_create(void) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    const int64_t hnd = g_next++;
-    g_trees[hnd] = std::make_unique<TreeMirror>();
-    return hnd;
-}
-
-int deft_tree_free(int64_t tree) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    if (!g_trees.erase(tree)) {
-        set_error("deft_tree_free: bad handle");
-        return DEFT_EINVAL;
-    }
-    return DEFT_OK;
-}
-
-#define DEFT_TREE_OR_FAIL(t, h, what)                   \
-    TreeMirror* t = find_tree(h);                       \
-    if (!t) {                                           \
-        set_error(what ": bad tree handle");            \
-        return DEFT_EINVAL;                             \
-    }                                                   \
-    std::lock_guard<std::mutex> tree_lock(t->mu)
-
-int deft_tree_add_node(int64_t tree, int64_t id, int64_t parent_id) {
-    DEFT_TREE_OR_FAIL(t, tree, "deft_tree_add_node");
-    if (t->nodes.count(id) || (parent_id >= 0 && !t->nodes.count(parent_id))) {
-        set_error("deft_tree_add_node: id %lld exists or parent %lld unknown", (long long)id, (long long)parent_id);
-        return DEFT_EINVAL;
-    }
-    t->nodes[id].parent = parent_id;
-    return DEFT_OK;
-}
-
-int deft_tree_remove_node(int64_t tree, int64_t id) {
-    DEFT_TREE_OR_FAIL(t, tree, "deft_tree_remove_node");
-    if (!t->nodes.erase(id)) {
-        set_error("deft_tree_remove_node: unknown node %lld", (long long)id);
-        return DEFT_EINVAL;
-    }
-    return DEFT_OK;
-}
-
-int deft_tree_set_leaf(int64_t tree, int64_t id, int is_leaf) {
-    DEFT_TREE_OR_FAIL(t, tree, "deft_tree_set_leaf");
-    auto it = t->nodes.find(id);
-    if (it == t->nodes.end()) {
-        set_error("deft_tree_set_leaf: unknown node %lld", (long long)id);
-        return DEFT_EINVAL;
-    }
-    it->second.leaf = is_leaf ? 1 : 0;
-    return DEFT_OK;
-}
-
-int deft_tree_append_slots(int64_t tree, int n, const int64_t* ids, const int64_t* slots) {
-    DEFT_TREE_OR_FAIL(t, tree, "deft_tree_append_slots");
-    for (int i = 0; i < n; ++i) {
-        auto it = t->nodes.find(ids[i]);
-        if (it == t->nodes.end()) {
-            set_error("deft_tree_append_slots: unknown node %lld", (long long)ids[i]);
-            return DEFT_EINVAL;
-        }
-        it->second.kv.push_back(slots[i]);
-    }
-    return DEFT_OK;
-}
-
-int deft_tree_extend_node(int64_t tree, int64_t id, int n, const int64_t* slots) {
-    DEFT_TREE_OR_FAIL(t, tree, "deft_tree_extend_node");
-    auto it = t->nodes.find(id);
-    if (it == t->nodes.end() || n < 0) {
-        set_error("deft_tree_extend_node: unknown node %lld", (long long)id);
-        return DEFT_EINVAL;
-    }
-    it->second.kv.insert(it->second.kv.end(), slots, slots + n);
-    return DEFT_OK;
-}
-
-int deft_tree_clear_node_kv(int64_t tree, int64_t id) {
-    DEFT_TREE_OR_FAIL(t, tree, "deft_tree_clear_node_kv");
-    auto it = t->nodes.find(id);
-    if (it == t->nodes.end()) {
-        set_error("deft_tree_clear_node_kv: unknown node %lld", (long long)id);
-        return DEFT_EINVAL;
-    }
-    it->second.kv.clear();
-    return DEFT_OK;
-}
-
-int deft_tree_stats(int64_t tree, int64_t stats[3]) {
-    DEFT_TREE_OR_FAIL(t, tree, "deft_tree_stats");
-    int64_t leaves = 0, kv = 0;
-    for (const auto& kvp : t->nodes) {
-        leaves += kvp.second.leaf;
-        kv += (int64_t)kvp.second.kv.size();
-    }
-    stats[0] = (int64_t)t->nodes.size();
-    stats[1] = leaves;
-    stats[2] = kv;
-    return DEFT_OK;
-}
-
-int64_t deft_tree_build_md(int64_t tree, int max_q_len, int block_len, int max_block_len) {
-    std::vector<int64_t> node_id, parent_id, kv_offset, kv_slots;
-    std::vector<uint8_t> is_leaf;
-    {
-        DEFT_TREE_OR_FAIL(t, tree, "deft_tree_build_md");
-        const size_t n = t->nodes.size();
-        node_id.reserve(n);
-        parent_id.reserve(n);
-        is_leaf.reserve(n);
-        kv_offset.reserve(n + 1);
-        kv_offset.push_back(0);
-        size_t total = 0;
-        for (const auto& kvp : t->nodes) total += kvp.second.kv.size();
-        kv_slots.reserve(total);
-        for (const auto& kvp : t->nodes) {
-            node_id.push_back(kvp.first);
-            parent_id.push_back(kvp.second.parent);
-            is_leaf.push_back(kvp.second.leaf);
-            kv_slots.insert(kv_slots.end(), kvp.second.kv.begin(), kvp.second.kv.end());
-            kv_offset.push_back((int64_t)kv_slots.size());
-        }
-    }
-    return deft_md_build((int)node_id.size(), node_id.data(), parent_id.data(), is_leaf.data(), kv_offset.data(),
-                         kv_slots.data(), max_q_len, block_len, max_block_len);
-}
-
 }  // extern "C"

@@ -1,0 +1,578 @@
+// Host-only part of libdeft_amd.so: the decoding tree over the paged KV pool.
+//
+// The state machine behind deft_amd.TreeCache (the reference: DeFT/deft/tree_decoding/tree_cache.py:147-403, :504-516 --
+// init_prompt / branch / alloc / cut / merge_nodes / reset_node_KV / add_ref / remove_ref): nodes with a parent, children in
+// creation order, the pool slots of their tokens, and which nodes are live leaves.  Stated on flat data: a node keeps the
+// NUMBER of live leaves below it (the reference keeps the set, `node.refs`; membership is recomputed on demand), leaves live in
+// an ordered set (query row r = the r-th live leaf by id, tree_cache.py:650-652), and cutting a leaf walks up while that count
+// is zero.  The Python classes are attribute views over this object.
+//
+// The same object lays the tree out for the GPU (deft_tree_layout_*): nodes in DFS pre-order, every node's slots
+// sorted and given room to grow, the leaf sets as bit sets -- what the device-side metadata kernels (tree_plan.h) read.
+#include <algorithm>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <set>
+#include <unordered_map>
+#include <vector>
+
+#include "common.h"
+
+namespace deft {
+
+struct TNode {
+    int64_t parent = -1;
+    uint8_t leaf = 0;
+    int64_t nrefs = 0;  // live leaves in the subtree (this node included)
+    std::vector<int64_t> kv;        // pool slots in the order they were appended
+    std::vector<int64_t> children;  // ids, creation order
+};
+
+// GPU layout of one structural epoch (tree_plan.h): valid until the structure changes or a node outgrows its room.
+struct Layout {
+    bool valid = false;
+    int slack = 0;
+    std::vector<int64_t> dfs;         // node ids in DFS pre-order
+    std::unordered_map<int64_t, int> index;  // id -> DFS index
+    std::vector<int32_t> start, cap;  // per DFS index: first slot of the node's region, its capacity
+    std::vector<int32_t> leaf_node;   // per query row: DFS index of its leaf
+    int nqw = 0;                      // 64-bit words per leaf set
+    int64_t total_cap = 0;
+};
+
+struct Tree {
+    std::unordered_map<int64_t, TNode> nodes;
+    std::set<int64_t> leaves;  // live leaves, ascending id
+    int64_t root = -1;
+    int64_t epoch = 1;  // bumped by every change the GPU layout cannot absorb
+    Layout lay;
+    std::mutex mu;
+};
+
+static std::mutex g_tree_mu;
+static std::unordered_map<int64_t, std::unique_ptr<Tree>> g_tree_map;
+static int64_t g_tree_next = 1;
+
+static Tree* find_tree(int64_t h) {
+    std::lock_guard<std::mutex> lk(g_tree_mu);
+    auto it = g_tree_map.find(h);
+    return it == g_tree_map.end() ? nullptr : it->second.get();
+}
+
+static void structure_changed(Tree* t) {
+    ++t->epoch;
+    t->lay.valid = false;
+}
+
+static void add_refs(Tree* t, int64_t id, int64_t d) {
+    for (int64_t cur = id; cur >= 0;) {
+        auto it = t->nodes.find(cur);
+        if (it == t->nodes.end()) break;
+        it->second.nrefs += d;
+        cur = it->second.parent;
+    }
+}
+
+// DFS pre-order, children in ascending id (= creation order, tree_cache.py:790)
+static bool dfs_order(Tree* t, std::vector<int64_t>& out) {
+    out.clear();
+    if (t->root < 0) return false;
+    std::vector<int64_t> stack{t->root};
+    while (!stack.empty()) {
+        const int64_t u = stack.back();
+        stack.pop_back();
+        out.push_back(u);
+        const TNode& n = t->nodes.at(u);
+        for (auto it = n.children.rbegin(); it != n.children.rend(); ++it) stack.push_back(*it);
+    }
+    return out.size() == t->nodes.size();
+}
+
+static void build_layout(Tree* t, int slack) {
+    Layout& L = t->lay;
+    L = Layout();
+    L.slack = slack;
+    if (!dfs_order(t, L.dfs)) return;
+    const int n = (int)L.dfs.size();
+    L.start.resize(n);
+    L.cap.resize(n);
+    int64_t off = 0;
+    for (int i = 0; i < n; ++i) {
+        const TNode& nd = t->nodes.at(L.dfs[i]);
+        L.index[L.dfs[i]] = i;
+        // only live leaves grow between structural changes (one slot per decode step)
+        const int64_t room = (int64_t)nd.kv.size() + (nd.leaf ? slack : 0);
+        L.start[i] = (int32_t)off;
+        L.cap[i] = (int32_t)((room + 3) / 4 * 4);
+        off += L.cap[i];
+    }
+    L.total_cap = off;
+    L.leaf_node.clear();
+    for (int64_t id : t->leaves) L.leaf_node.push_back(L.index.at(id));
+    L.nqw = std::max(1, ((int)t->leaves.size() + 63) / 64);
+    L.valid = off <= 0x7fffffffLL;
+}
+
+}  // namespace deft
+
+using namespace deft;
+
+#define DEFT_TREE_OR_FAIL(t, h, what)        \
+    Tree* t = find_tree(h);                  \
+    if (!t) {                                \
+        set_error(what ": bad tree handle"); \
+        return DEFT_EINVAL;                  \
+    }                                        \
+    std::lock_guard<std::mutex> tree_lock(t->mu)
+
+extern "C" {
+
+int64_t deft_tree_create(void) {
+    std::lock_guard<std::mutex> lk(g_tree_mu);
+    const int64_t hnd = g_tree_next++;
+    g_tree_map[hnd] = std::make_unique<Tree>();
+    return hnd;
+}
+
+int deft_tree_free(int64_t tree) {
+    std::lock_guard<std::mutex> lk(g_tree_mu);
+    if (!g_tree_map.erase(tree)) {
+        set_error("deft_tree_free: bad handle");
+        return DEFT_EINVAL;
+    }
+    return DEFT_OK;
+}
+
+int deft_tree_add_node(int64_t tree, int64_t id, int64_t parent_id) {
+    DEFT_TREE_OR_FAIL(t, tree, "deft_tree_add_node");
+    if (id < 0 || t->nodes.count(id) || (parent_id >= 0 && !t->nodes.count(parent_id)) || (parent_id < 0 && t->root >= 0)) {
+        set_error("deft_tree_add_node: id %lld exists, parent %lld unknown, or a second root", (long long)id, (long long)parent_id);
+        return DEFT_EINVAL;
+    }
+    TNode& n = t->nodes[id];
+    n.parent = parent_id;
+    if (parent_id >= 0) t->nodes[parent_id].children.push_back(id);
+    else t->root = id;
+    structure_changed(t);
+    return DEFT_OK;
+}
+
+int deft_tree_remove_node(int64_t tree, int64_t id) {
+    DEFT_TREE_OR_FAIL(t, tree, "deft_tree_remove_node");
+    auto it = t->nodes.find(id);
+    if (it == t->nodes.end() || !it->second.children.empty()) {
+        set_error("deft_tree_remove_node: unknown node %lld, or it has children", (long long)id);
+        return DEFT_EINVAL;
+    }
+    if (it->second.leaf) {
+        add_refs(t, id, -1);
+        t->leaves.erase(id);
+    }
+    const int64_t par = it->second.parent;
+    if (par >= 0) {
+        auto& ch = t->nodes[par].children;
+        ch.erase(std::remove(ch.begin(), ch.end(), id), ch.end());
+    } else {
+        t->root = -1;
+    }
+    t->nodes.erase(it);
+    structure_changed(t);
+    return DEFT_OK;
+}
+
+int deft_tree_set_leaf(int64_t tree, int64_t id, int is_leaf) {
+    DEFT_TREE_OR_FAIL(t, tree, "deft_tree_set_leaf");
+    auto it = t->nodes.find(id);
+    if (it == t->nodes.end()) {
+        set_error("deft_tree_set_leaf: unknown node %lld", (long long)id);
+        return DEFT_EINVAL;
+    }
+    const uint8_t want = is_leaf ? 1 : 0;
+    if (it->second.leaf != want) {
+        it->second.leaf = want;
+        add_refs(t, id, want ? 1 : -1);
+        if (want) t->leaves.insert(id);
+        else t->leaves.erase(id);
+        structure_changed(t);
+    }
+    return DEFT_OK;
+}
+
+// TreeCache.branch (tree_cache.py:338-370): `id` stops being a leaf, `cnt` new leaves first_id .. first_id + cnt - 1 hang below it.
+int deft_tree_branch(int64_t tree, int64_t id, int cnt, int64_t first_id) {
+    DEFT_TREE_OR_FAIL(t, tree, "deft_tree_branch");
+    auto it = t->nodes.find(id);
+    if (it == t->nodes.end() || !it->second.leaf || cnt < 0) {
+        set_error("deft_tree_branch: node %lld is not a live leaf", (long long)id);
+        return DEFT_EINVAL;
+    }
+    for (int i = 0; i < cnt; ++i)
+        if (t->nodes.count(first_id + i)) {
+            set_error("deft_tree_branch: node id %lld exists", (long long)(first_id + i));
+            return DEFT_EINVAL;
+        }
+    it->second.leaf = 0;
+    add_refs(t, id, -1);
+    t->leaves.erase(id);
+    for (int i = 0; i < cnt; ++i) {
+        TNode& c = t->nodes[first_id + i];
+        c.parent = id;
+        c.leaf = 1;
+        t->nodes[id].children.push_back(first_id + i);
+        add_refs(t, first_id + i, 1);
+        t->leaves.insert(first_id + i);
+    }
+    structure_changed(t);
+    return DEFT_OK;
+}
+
+// TreeCache.cut (tree_cache.py:373-403): the leaf goes, and every ancestor that is left without a live leaf below it.
+// deleted_ids (leaf first, then upwards) and the slots of the deleted nodes are returned; *n_ids / *n_slots always report
+// how many there are (the call fails without changing anything if a buffer is too small).
+int deft_tree_cut(int64_t tree, int64_t id, int64_t* deleted_ids, int cap_ids, int* n_ids, int64_t* freed_slots,
+                  int64_t cap_slots, int64_t* n_slots) {
+    DEFT_TREE_OR_FAIL(t, tree, "deft_tree_cut");
+    auto it = t->nodes.find(id);
+    if (it == t->nodes.end() || !it->second.leaf || !it->second.children.empty() || !n_ids || !n_slots) {
+        set_error("deft_tree_cut: node %lld is not a childless live leaf", (long long)id);
+        return DEFT_EINVAL;
+    }
+    // dry run: which nodes go
+    std::vector<int64_t> gone;
+    int64_t slots = 0;
+    for (int64_t cur = id; cur >= 0;) {
+        const TNode& n = t->nodes.at(cur);
+        if (n.nrefs - 1 > 0) break;  // another live leaf below this ancestor
+        gone.push_back(cur);
+        slots += (int64_t)n.kv.size();
+        cur = n.parent;
+    }
+    *n_ids = (int)gone.size();
+    *n_slots = slots;
+    if ((int)gone.size() > cap_ids || slots > cap_slots || (!deleted_ids && !gone.empty()) || (!freed_slots && slots > 0)) {
+        set_error("deft_tree_cut: output buffers too small (%d nodes, %lld slots)", (int)gone.size(), (long long)slots);
+        return DEFT_EWORKSPACE;
+    }
+    add_refs(t, id, -1);
+    t->leaves.erase(id);
+    int64_t w = 0;
+    for (size_t k = 0; k < gone.size(); ++k) {
+        const int64_t cur = gone[k];
+        TNode& n = t->nodes.at(cur);
+        deleted_ids[k] = cur;
+        std::copy(n.kv.begin(), n.kv.end(), freed_slots + w);
+        w += (int64_t)n.kv.size();
+        const int64_t par = n.parent;
+        if (par >= 0) {
+            auto& ch = t->nodes.at(par).children;
+            ch.erase(std::remove(ch.begin(), ch.end(), cur), ch.end());
+        } else {
+            t->root = -1;
+        }
+        t->nodes.erase(cur);
+    }
+    structure_changed(t);
+    return DEFT_OK;
+}
+
+// TreeCache.alloc (tree_cache.py:261-283): one new slot for every live leaf, in ascending leaf id.  Absorbed by the GPU
+// layout while every leaf has room (the epoch stays; the device appends the same slots itself, tree_plan.h).
+int deft_tree_alloc_step(int64_t tree, int n, const int64_t* slots) {
+    DEFT_TREE_OR_FAIL(t, tree, "deft_tree_alloc_step");
+    if (n != (int)t->leaves.size() || (n > 0 && !slots)) {
+        set_error("deft_tree_alloc_step: %d slots for %d live leaves", n, (int)t->leaves.size());
+        return DEFT_EINVAL;
+    }
+    int i = 0;
+    bool fits = t->lay.valid;
+    for (int64_t id : t->leaves) {
+        TNode& nd = t->nodes.at(id);
+        nd.kv.push_back(slots[i++]);
+        if (fits && (int64_t)nd.kv.size() > t->lay.cap[t->lay.index.at(id)]) fits = false;
+    }
+    if (!fits) structure_changed(t);
+    return DEFT_OK;
+}
+
+int deft_tree_append_slots(int64_t tree, int n, const int64_t* ids, const int64_t* slots) {
+    DEFT_TREE_OR_FAIL(t, tree, "deft_tree_append_slots");
+    for (int i = 0; i < n; ++i) {
+        auto it = t->nodes.find(ids[i]);
+        if (it == t->nodes.end()) {
+            set_error("deft_tree_append_slots: unknown node %lld", (long long)ids[i]);
+            return DEFT_EINVAL;
+        }
+        it->second.kv.push_back(slots[i]);
+    }
+    structure_changed(t);
+    return DEFT_OK;
+}
+
+int deft_tree_extend_node(int64_t tree, int64_t id, int n, const int64_t* slots) {
+    DEFT_TREE_OR_FAIL(t, tree, "deft_tree_extend_node");
+    auto it = t->nodes.find(id);
+    if (it == t->nodes.end() || n < 0) {
+        set_error("deft_tree_extend_node: unknown node %lld", (long long)id);
+        return DEFT_EINVAL;
+    }
+    it->second.kv.insert(it->second.kv.end(), slots, slots + n);
+    structure_changed(t);
+    return DEFT_OK;
+}
+
+int deft_tree_set_node_kv(int64_t tree, int64_t id, int n, const int64_t* slots) {
+    DEFT_TREE_OR_FAIL(t, tree, "deft_tree_set_node_kv");
+    auto it = t->nodes.find(id);
+    if (it == t->nodes.end() || n < 0) {
+        set_error("deft_tree_set_node_kv: unknown node %lld", (long long)id);
+        return DEFT_EINVAL;
+    }
+    it->second.kv.assign(slots, slots + n);
+    structure_changed(t);
+    return DEFT_OK;
+}
+
+int deft_tree_clear_node_kv(int64_t tree, int64_t id) { return deft_tree_set_node_kv(tree, id, 0, nullptr); }
+
+int64_t deft_tree_node_len(int64_t tree, int64_t id) {
+    DEFT_TREE_OR_FAIL(t, tree, "deft_tree_node_len");
+    auto it = t->nodes.find(id);
+    if (it == t->nodes.end()) {
+        set_error("deft_tree_node_len: unknown node %lld", (long long)id);
+        return DEFT_EINVAL;
+    }
+    return (int64_t)it->second.kv.size();
+}
+
+// out[0 .. min(cap, len)) = the node's slots in append order; returns the node's length
+int64_t deft_tree_node_kv(int64_t tree, int64_t id, int64_t* out, int64_t cap) {
+    DEFT_TREE_OR_FAIL(t, tree, "deft_tree_node_kv");
+    auto it = t->nodes.find(id);
+    if (it == t->nodes.end()) {
+        set_error("deft_tree_node_kv: unknown node %lld", (long long)id);
+        return DEFT_EINVAL;
+    }
+    const int64_t n = (int64_t)it->second.kv.size();
+    if (out) std::copy(it->second.kv.begin(), it->second.kv.begin() + std::min(n, cap), out);
+    return n;
+}
+
+// ids of the live leaves below (or at) a node, ascending: the reference's `node.refs`; returns how many there are
+int64_t deft_tree_node_refs(int64_t tree, int64_t id, int64_t* out, int64_t cap) {
+    DEFT_TREE_OR_FAIL(t, tree, "deft_tree_node_refs");
+    if (!t->nodes.count(id)) {
+        set_error("deft_tree_node_refs: unknown node %lld", (long long)id);
+        return DEFT_EINVAL;
+    }
+    int64_t n = 0;
+    for (int64_t leaf : t->leaves) {  // a leaf is below `id` iff `id` is on its path to the root
+        for (int64_t cur = leaf; cur >= 0; cur = t->nodes.at(cur).parent)
+            if (cur == id) {
+                if (out && n < cap) out[n] = leaf;
+                ++n;
+                break;
+            }
+    }
+    return n;
+}
+
+// root -> leaf slots of a leaf's path (what sequential attention over the leaf reads); returns the path length
+int64_t deft_tree_path_slots(int64_t tree, int64_t id, int64_t* out, int64_t cap) {
+    DEFT_TREE_OR_FAIL(t, tree, "deft_tree_path_slots");
+    if (!t->nodes.count(id)) {
+        set_error("deft_tree_path_slots: unknown node %lld", (long long)id);
+        return DEFT_EINVAL;
+    }
+    std::vector<int64_t> chain;
+    for (int64_t cur = id; cur >= 0; cur = t->nodes.at(cur).parent) chain.push_back(cur);
+    int64_t n = 0;
+    for (auto it = chain.rbegin(); it != chain.rend(); ++it)
+        for (int64_t s : t->nodes.at(*it).kv) {
+            if (out && n < cap) out[n] = s;
+            ++n;
+        }
+    return n;
+}
+
+// {nodes, live leaves, total KV slots, epoch}
+int deft_tree_stats(int64_t tree, int64_t stats[4]) {
+    DEFT_TREE_OR_FAIL(t, tree, "deft_tree_stats");
+    int64_t kv = 0;
+    for (const auto& kvp : t->nodes) kv += (int64_t)kvp.second.kv.size();
+    stats[0] = (int64_t)t->nodes.size();
+    stats[1] = (int64_t)t->leaves.size();
+    stats[2] = kv;
+    stats[3] = t->epoch;
+    return DEFT_OK;
+}
+
+int64_t deft_tree_build_md(int64_t tree, int max_q_len, int block_len, int max_block_len) {
+    std::vector<int64_t> node_id, parent_id, kv_offset, kv_slots;
+    std::vector<uint8_t> is_leaf;
+    {
+        DEFT_TREE_OR_FAIL(t, tree, "deft_tree_build_md");
+        const size_t n = t->nodes.size();
+        node_id.reserve(n);
+        parent_id.reserve(n);
+        is_leaf.reserve(n);
+        kv_offset.reserve(n + 1);
+        kv_offset.push_back(0);
+        size_t total = 0;
+        for (const auto& kvp : t->nodes) total += kvp.second.kv.size();
+        kv_slots.reserve(total);
+        for (const auto& kvp : t->nodes) {
+            node_id.push_back(kvp.first);
+            parent_id.push_back(kvp.second.parent);
+            is_leaf.push_back(kvp.second.leaf);
+            kv_slots.insert(kv_slots.end(), kvp.second.kv.begin(), kvp.second.kv.end());
+            kv_offset.push_back((int64_t)kv_slots.size());
+        }
+    }
+    return deft_md_build((int)node_id.size(), node_id.data(), parent_id.data(), is_leaf.data(), kv_offset.data(),
+                         kv_slots.data(), max_q_len, block_len, max_block_len);
+}
+
+// ---- GPU layout (tree_plan.h) -------------------------------------------------------------------------------
+// sizes = {nodes, queries (live leaves), 64-bit words per leaf set, total slot capacity, epoch}.  (Re)builds the layout when
+// the structure changed since the last call; `slack` = decode steps a leaf can grow before the next re-layout.
+int deft_tree_layout(int64_t tree, int slack, int64_t sizes[5]) {
+    DEFT_TREE_OR_FAIL(t, tree, "deft_tree_layout");
+    if (slack < 0 || !sizes) {
+        set_error("deft_tree_layout: bad arguments");
+        return DEFT_EINVAL;
+    }
+    if (!t->lay.valid || t->lay.slack != slack) build_layout(t, slack);
+    if (!t->lay.valid) {
+        set_error("deft_tree_layout: the tree has no root, unreachable nodes, or more than 2^31 slots");
+        return DEFT_EINVAL;
+    }
+    sizes[0] = (int64_t)t->lay.dfs.size();
+    sizes[1] = (int64_t)t->lay.leaf_node.size();
+    sizes[2] = t->lay.nqw;
+    sizes[3] = t->lay.total_cap;
+    sizes[4] = t->epoch;
+    return DEFT_OK;
+}
+
+// Fill the upload image of the current layout (host memory, sizes from deft_tree_layout):
+//   node_start / node_len / node_cap [nodes] int32, refs [nodes][nqw] uint64 (bit r = query row r is below the node),
+//   leaf_node [queries] int32 (DFS index of the leaf), slots [total_cap] int32 (each node's slots ASCENDING -- the
+//   reference sorts them, tree_cache.py:736 -- at node_start, unused room = -1)
+int deft_tree_layout_fetch(int64_t tree, int32_t* node_start, int32_t* node_len, int32_t* node_cap, uint64_t* refs,
+                           int32_t* leaf_node, int32_t* slots) {
+    DEFT_TREE_OR_FAIL(t, tree, "deft_tree_layout_fetch");
+    const Layout& L = t->lay;
+    if (!L.valid || !node_start || !node_len || !node_cap || !refs || !leaf_node || !slots) {
+        set_error("deft_tree_layout_fetch: no valid layout (call deft_tree_layout first) or null buffer");
+        return DEFT_EINVAL;
+    }
+    const int n = (int)L.dfs.size();
+    std::fill(slots, slots + L.total_cap, -1);
+    std::fill(refs, refs + (size_t)n * L.nqw, 0ull);
+    std::vector<int64_t> kv;
+    for (int i = 0; i < n; ++i) {
+        const TNode& nd = t->nodes.at(L.dfs[i]);
+        node_start[i] = L.start[i];
+        node_len[i] = (int32_t)nd.kv.size();
+        node_cap[i] = L.cap[i];
+        kv = nd.kv;
+        if (!std::is_sorted(kv.begin(), kv.end())) std::sort(kv.begin(), kv.end());
+        for (size_t k = 0; k < kv.size(); ++k) slots[L.start[i] + (int64_t)k] = (int32_t)kv[k];
+    }
+    int r = 0;
+    for (int64_t leaf : t->leaves) {  // query row r sets its bit on every node of its path
+        leaf_node[r] = L.index.at(leaf);
+        for (int64_t cur = leaf; cur >= 0; cur = t->nodes.at(cur).parent)
+            refs[(size_t)L.index.at(cur) * L.nqw + (r >> 6)] |= 1ull << (r & 63);
+        ++r;
+    }
+    return DEFT_OK;
+}
+
+// Sizes of the metadata the device kernels will produce for the CURRENT lengths, each leaf `grow` tokens longer
+// (0 = now; the layout's slack = the most the buffers must ever hold): sizes[0..7] as deft_md_sizes, sizes[8] = physical
+// 128-slot blocks.  O(nodes + blocks), touches no slot.
+int deft_tree_md_sizes(int64_t tree, int max_q_len, int block_len, int max_block_len, int grow, int64_t sizes[9]) {
+    DEFT_TREE_OR_FAIL(t, tree, "deft_tree_md_sizes");
+    const Layout& L = t->lay;
+    if (!L.valid || !sizes || max_q_len < 1 || block_len < 1 || grow < 0) {
+        set_error("deft_tree_md_sizes: no valid layout or bad arguments");
+        return DEFT_EINVAL;
+    }
+    const int n = (int)L.dfs.size();
+    std::vector<int64_t> len(n), nq(n);
+    for (int i = 0; i < n; ++i) {
+        const TNode& nd = t->nodes.at(L.dfs[i]);
+        len[i] = (int64_t)nd.kv.size() + (nd.leaf ? grow : 0);
+        nq[i] = nd.nrefs;
+    }
+    int64_t NE = 0, total = 0, n_node_q = 0, n_node_kv = 0;
+    for (int i = 0; i < n; ++i) {
+        total += len[i];
+        const int64_t qch = (nq[i] + max_q_len - 1) / max_q_len;
+        const int64_t step = max_block_len == -1 ? len[i] : max_block_len;
+        const int64_t kch = step > 0 ? (len[i] + step - 1) / step : 0;
+        NE += qch * kch;
+        n_node_q += nq[i] * kch;
+        n_node_kv += len[i] * qch;
+    }
+    // flattened split: union of the leaf sets of the nodes that touch each physical block
+    const int64_t NBp = (total + block_len - 1) / block_len;
+    int64_t NB = 0, P = 0;
+    {
+        // leaf sets as sorted row lists per node would cost O(nodes x leaves); the union size of a block is counted
+        // with bit sets built from the leaves' paths instead
+        const int nqw = L.nqw;
+        std::vector<uint64_t> refs((size_t)n * nqw, 0ull);
+        int r = 0;
+        for (int64_t leaf : t->leaves) {
+            for (int64_t cur = leaf; cur >= 0; cur = t->nodes.at(cur).parent)
+                refs[(size_t)L.index.at(cur) * nqw + (r >> 6)] |= 1ull << (r & 63);
+            ++r;
+        }
+        std::vector<uint64_t> uni(nqw);
+        int i = 0;
+        int64_t pos = 0;  // flattened position of node i's first slot
+        for (int64_t b = 0; b < NBp; ++b) {
+            const int64_t lo = b * block_len, hi = std::min(total, lo + block_len);
+            std::fill(uni.begin(), uni.end(), 0ull);
+            while (i < n && pos + len[i] <= lo) pos += len[i++];
+            int j = i;
+            int64_t pj = pos;
+            while (j < n && pj < hi) {
+                if (len[j] > 0)
+                    for (int w = 0; w < nqw; ++w) uni[w] |= refs[(size_t)j * nqw + w];
+                pj += len[j++];
+            }
+            int64_t c = 0;
+            for (int w = 0; w < nqw; ++w) c += __builtin_popcountll(uni[w]);
+            NB += (c + max_q_len - 1) / max_q_len;
+            P += c;
+        }
+    }
+    sizes[0] = (int64_t)t->leaves.size();
+    sizes[1] = NE;
+    sizes[2] = total;
+    sizes[3] = n_node_q;
+    sizes[4] = n_node_kv;
+    sizes[5] = NB;
+    sizes[6] = P;
+    sizes[7] = NB * block_len;
+    sizes[8] = NBp;
+    return DEFT_OK;
+}
+
+// ids of the live leaves in query-row order
+int deft_tree_leaf_ids(int64_t tree, int64_t* out, int cap) {
+    DEFT_TREE_OR_FAIL(t, tree, "deft_tree_leaf_ids");
+    int n = 0;
+    for (int64_t id : t->leaves) {
+        if (out && n < cap) out[n] = id;
+        ++n;
+    }
+    return n;
+}
+
+}  // extern "C"

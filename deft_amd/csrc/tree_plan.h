@@ -1,0 +1,281 @@
+// Device-side TreeMetadata: the KV-guided grouping and the flattened split of
+// TreeMetadata.from_tree_cache (DeFT/deft/tree_decoding/tree_cache.py:618-881) as HIP kernels over a compact tree that
+// LIVES on the GPU, so that a decode step uploads nothing but its nq new slot numbers.
+//
+// Compact tree (laid out by the host-side tree, tree.cpp deft_tree_layout_*, uploaded when the STRUCTURE changes --
+// branch / cut / merge -- not per step):
+//   node_start / node_len / node_cap [n] int32   nodes in DFS pre-order; a node's pool slots, ascending, at
+//                                                slots[node_start .. + node_len), with room for node_cap
+//   refs [n][nqw] uint64                         bit r: query row r (the r-th live leaf by id) is below the node
+//   leaf_node [nq] int32                         DFS index of query row r's leaf
+// Per decode step: tree_advance_kernel appends this step's slots (cache_loc) to the leaves, then three kernels emit
+// the reference's twelve int64 arrays, bit for bit what deft_md_build (host.cpp) returns for the same tree:
+//   tree_md_scan_kernel    one workgroup: prefix sums over nodes and 128-slot blocks, sizes -> dims[]
+//   tree_md_blocks_kernel  one workgroup per physical block: block_kv / block_bitmasks / block_q ... (flattened split,
+//                          tree_cache.py:653-723, :763-799; a block whose nodes have more than max_q_len queries is
+//                          emitted once per query chunk)
+//   tree_md_nodes_kernel   one workgroup per node: node_q / node_kv ... (KV-guided grouping, :725-762)
+//
+// Included by deft_kernels.hip.
+#pragma once
+
+namespace deft {
+
+struct TreeDev {
+    int n, nq, nqw;
+    const int32_t* node_start;
+    int32_t* node_len;
+    const int32_t* node_cap;
+    const unsigned long long* refs;
+    const int32_t* leaf_node;
+    int32_t* slots;
+};
+
+struct TreeMdOut {  // the reference's arrays (tree_cache.py:813-857), int64 on the device, capacities checked by the host
+    int64_t *node_q, *node_kv, *node_q_len, *node_kv_len, *node_q_offset, *node_kv_offset;
+    int64_t *block_q, *block_q_cnts, *block_q_offset, *block_bitmasks, *block_kv, *block_lens;
+};
+
+// scratch of one build (int32 unless noted), carved by the host wrapper
+struct TreeScratch {
+    int32_t* pos;       // [n + 1]   flattened position of every node's first slot
+    int32_t* e_off;     // [n + 1]   first Node entry of every node
+    int32_t* q_off;     // [n + 1]   first node_q element
+    int32_t* kv_off;    // [n + 1]   first node_kv element
+    int32_t* b_first;   // [nbp]     first node that has a slot in the block
+    int32_t* b_eoff;    // [nbp + 1] first emitted block of the physical block
+    int32_t* b_poff;    // [nbp + 1] first block_q element
+    unsigned long long* b_union;  // [nbp][nqw]
+    int32_t* dims;      // [16] query_num, NE, total_kv, len(node_q), len(node_kv), NB, P, len(block_kv), physical blocks, error
+};
+constexpr int TREE_DIMS = 16;
+constexpr int TREE_ERR = 9;
+
+// one slot per live leaf, kept ascending inside the node (the pool hands out ascending slots, so the new one almost
+// always goes to the end; after a cut freed slots come back lower and are inserted)
+__global__ __launch_bounds__(256) void tree_advance_kernel(TreeDev t, const int32_t* cache_loc, int32_t* err) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= t.nq) return;
+    const int i = t.leaf_node[r];
+    const int len = t.node_len[i];
+    if (len >= t.node_cap[i]) {
+        atomicOr(err, 1);  // out of room: the host re-lays the tree out before this can happen
+        return;
+    }
+    int32_t* s = t.slots + t.node_start[i];
+    const int32_t v = cache_loc[r];
+    int p = len;
+    while (p > 0 && s[p - 1] > v) {
+        s[p] = s[p - 1];
+        --p;
+    }
+    s[p] = v;
+    t.node_len[i] = len + 1;
+}
+
+// exclusive scan of f(i), i < m, into out[0 .. m] by the whole workgroup (1024 threads, chunks of 1024 with a carry)
+template <class F>
+__device__ inline void block_exclusive_scan(int m, F f, int32_t* out, int* sWave, int* sCarry) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) *sCarry = 0;
+    __syncthreads();
+    for (int base = 0; base < m; base += 1024) {
+        const int i = base + tid;
+        const int v = i < m ? f(i) : 0;
+        int inc = v;
+        for (int d = 1; d < 64; d <<= 1) {
+            const int u = __shfl_up(inc, d, 64);
+            if (lane >= d) inc += u;
+        }
+        if (lane == 63) sWave[wave] = inc;
+        __syncthreads();
+        int wbase = 0;
+        for (int k = 0; k < wave; ++k) wbase += sWave[k];
+        const int carry = *sCarry;
+        if (i < m) out[i] = carry + wbase + inc - v;
+        __syncthreads();
+        if (tid == 1023) *sCarry = carry + wbase + inc;
+        __syncthreads();
+    }
+    if (tid == 0) out[m] = *sCarry;
+    __syncthreads();
+}
+
+__device__ inline int refs_count(const unsigned long long* r, int nqw) {
+    int c = 0;
+    for (int w = 0; w < nqw; ++w) c += __popcll(r[w]);
+    return c;
+}
+
+__global__ __launch_bounds__(1024) void tree_md_scan_kernel(TreeDev t, TreeScratch s, int max_q_len, int block_len,
+                                                            int max_block_len, int nbp_cap) {
+    __shared__ int sWave[16];
+    __shared__ int sCarry;
+    const int n = t.n, nqw = t.nqw;
+    const int tid = threadIdx.x;
+    auto qch = [&](int i) { return (refs_count(t.refs + (size_t)i * nqw, nqw) + max_q_len - 1) / max_q_len; };
+    auto kch = [&](int i) {
+        const int len = t.node_len[i];
+        const int step = max_block_len == -1 ? len : max_block_len;
+        return step > 0 ? (len + step - 1) / step : 0;
+    };
+    block_exclusive_scan(n, [&](int i) { return t.node_len[i]; }, s.pos, sWave, &sCarry);
+    block_exclusive_scan(n, [&](int i) { return qch(i) * kch(i); }, s.e_off, sWave, &sCarry);
+    block_exclusive_scan(n, [&](int i) { return refs_count(t.refs + (size_t)i * nqw, nqw) * kch(i); }, s.q_off, sWave, &sCarry);
+    block_exclusive_scan(n, [&](int i) { return t.node_len[i] * qch(i); }, s.kv_off, sWave, &sCarry);
+    const int total = s.pos[n];
+    const int nbp = (total + block_len - 1) / block_len;
+    if (nbp > nbp_cap) {
+        if (tid == 0) {
+            s.dims[8] = nbp;
+            atomicOr(s.dims + TREE_ERR, 2);
+        }
+        return;
+    }
+    // physical blocks: first node with a slot in the block (largest i with pos[i] <= lo among nodes that have slots),
+    // union of the leaf sets of its nodes
+    for (int b = tid; b < nbp; b += 1024) {
+        const int lo = b * block_len, hi = min(total, lo + block_len);
+        int a = 0, z = n - 1;  // largest i with pos[i] <= lo
+        while (a < z) {
+            const int mid = (a + z + 1) >> 1;
+            if (s.pos[mid] <= lo) a = mid;
+            else z = mid - 1;
+        }
+        while (a < n && s.pos[a + 1] <= lo) ++a;  // (skip empty nodes that share the position)
+        s.b_first[b] = a;
+        unsigned long long* u = s.b_union + (size_t)b * nqw;
+        for (int w = 0; w < nqw; ++w) u[w] = 0ull;
+        for (int j = a; j < n && s.pos[j] < hi; ++j)
+            if (t.node_len[j] > 0)
+                for (int w = 0; w < nqw; ++w) u[w] |= t.refs[(size_t)j * nqw + w];
+    }
+    __syncthreads();
+    block_exclusive_scan(nbp, [&](int b) { return (refs_count(s.b_union + (size_t)b * nqw, nqw) + max_q_len - 1) / max_q_len; },
+                         s.b_eoff, sWave, &sCarry);
+    block_exclusive_scan(nbp, [&](int b) { return refs_count(s.b_union + (size_t)b * nqw, nqw); }, s.b_poff, sWave, &sCarry);
+    if (tid == 0) {
+        s.dims[0] = t.nq;
+        s.dims[1] = s.e_off[n];
+        s.dims[2] = total;
+        s.dims[3] = s.q_off[n];
+        s.dims[4] = s.kv_off[n];
+        s.dims[5] = s.b_eoff[nbp];
+        s.dims[6] = s.b_poff[nbp];
+        s.dims[7] = s.b_eoff[nbp] * block_len;
+        s.dims[8] = nbp;
+    }
+}
+
+// k-th (0-based) set bit of a bit set, or -1
+__device__ inline int nth_set_bit(const unsigned long long* u, int nqw, int k) {
+    for (int w = 0; w < nqw; ++w) {
+        const int c = __popcll(u[w]);
+        if (k < c) {
+            unsigned long long x = u[w];
+            for (int j = 0; j < k; ++j) x &= x - 1;
+            return 64 * w + __ffsll((long long)x) - 1;
+        }
+        k -= c;
+    }
+    return -1;
+}
+// number of set bits of u below position q
+__device__ inline int rank_below(const unsigned long long* u, int q) {
+    int c = 0;
+    for (int w = 0; w < (q >> 6); ++w) c += __popcll(u[w]);
+    return c + __popcll(u[q >> 6] & ((1ull << (q & 63)) - 1ull));
+}
+
+__global__ __launch_bounds__(128) void tree_md_blocks_kernel(TreeDev t, TreeScratch s, TreeMdOut o, int max_q_len, int block_len) {
+    const int b = blockIdx.x;
+    if (s.dims[TREE_ERR] || b >= s.dims[8]) return;
+    const int nqw = t.nqw, n = t.n;
+    const int total = s.dims[2];
+    const int lo = b * block_len, cur_len = min(block_len, total - lo);
+    const unsigned long long* uni = s.b_union + (size_t)b * nqw;
+    const int nqs = refs_count(uni, nqw);
+    const int chunks = (nqs + max_q_len - 1) / max_q_len;
+    const int e0 = s.b_eoff[b], p0 = s.b_poff[b];
+    for (int k = threadIdx.x; k < block_len; k += blockDim.x) {
+        int64_t slot = -1;
+        int j = -1;
+        if (k < cur_len) {
+            j = s.b_first[b];
+            while (j + 1 < n && s.pos[j + 1] <= lo + k) ++j;  // (a block touches few nodes; empty nodes are skipped)
+            slot = t.slots[t.node_start[j] + (lo + k - s.pos[j])];
+        }
+        for (int c = 0; c < chunks; ++c) {
+            int64_t mask = 0;
+            if (j >= 0) {  // rows of this chunk = union ranks [c * max_q_len, (c + 1) * max_q_len)
+                const unsigned long long* rj = t.refs + (size_t)j * nqw;
+                for (int w = 0; w < nqw; ++w) {
+                    unsigned long long x = rj[w];
+                    while (x) {
+                        const int q = 64 * w + __ffsll((long long)x) - 1;
+                        x &= x - 1;
+                        const int rk = rank_below(uni, q) - c * max_q_len;
+                        if (rk >= 0 && rk < max_q_len) mask |= (int64_t)1 << rk;
+                    }
+                }
+            }
+            o.block_kv[(int64_t)(e0 + c) * block_len + k] = slot;
+            o.block_bitmasks[(int64_t)(e0 + c) * block_len + k] = mask;
+        }
+    }
+    for (int c = 0; c < chunks; ++c) {
+        const int cnt = min(max_q_len, nqs - c * max_q_len);
+        for (int k = threadIdx.x; k < cnt; k += blockDim.x)
+            o.block_q[p0 + c * max_q_len + k] = nth_set_bit(uni, nqw, c * max_q_len + k);
+        if (threadIdx.x == 0) {
+            o.block_q_cnts[e0 + c] = cnt;
+            o.block_q_offset[e0 + c] = p0 + c * max_q_len;
+            o.block_lens[e0 + c] = cur_len;
+        }
+    }
+}
+
+// grid (nodes, parts): the parts of a row share a node's slot copy
+__global__ __launch_bounds__(256) void tree_md_nodes_kernel(TreeDev t, TreeScratch s, TreeMdOut o, int max_q_len, int max_block_len) {
+    const int i = blockIdx.x;
+    if (s.dims[TREE_ERR] || i >= t.n) return;
+    const int nqw = t.nqw;
+    const unsigned long long* ri = t.refs + (size_t)i * nqw;
+    const int nq_i = refs_count(ri, nqw);
+    const int len = t.node_len[i];
+    if (len <= 0 || nq_i <= 0) return;
+    const int step = max_block_len == -1 ? len : max_block_len;
+    const int kchunks = (len + step - 1) / step, qchunks = (nq_i + max_q_len - 1) / max_q_len;
+    const int e0 = s.e_off[i], q0 = s.q_off[i], kv0 = s.kv_off[i];
+    const int32_t* sl = t.slots + t.node_start[i];
+    const int tid = blockIdx.y * blockDim.x + threadIdx.x, nth = gridDim.y * blockDim.x;
+    // entries: q chunks outer, KV chunks inner (tree_cache.py:744-758)
+    for (int e = tid; e < qchunks * kchunks; e += nth) {
+        const int qc = e / kchunks, kc = e - qc * kchunks;
+        const int qcnt = min(max_q_len, nq_i - qc * max_q_len), klen = min(step, len - kc * step);
+        o.node_q_len[e0 + e] = qcnt;
+        o.node_kv_len[e0 + e] = klen;
+        o.node_q_offset[e0 + e] = q0 + qc * kchunks * max_q_len + kc * qcnt;
+        o.node_kv_offset[e0 + e] = kv0 + qc * len + kc * step;
+    }
+    // node_q: per entry its q chunk
+    const int nqel = nq_i * kchunks;
+    for (int x = tid; x < nqel; x += nth) {
+        // element x of the node's node_q stretch: full q chunks take kchunks * max_q_len elements each
+        const int per_full = kchunks * max_q_len;
+        int qc = x / per_full;
+        int rem = x - qc * per_full;
+        if (qc >= qchunks) {  // (only when the last chunk is full too)
+            qc = qchunks - 1;
+            rem = x - qc * per_full;
+        }
+        const int qcnt = min(max_q_len, nq_i - qc * max_q_len);
+        const int within = rem % qcnt;
+        o.node_q[q0 + x] = nth_set_bit(ri, nqw, qc * max_q_len + within);
+    }
+    // node_kv: the node's slots once per q chunk
+    const int64_t nkv = (int64_t)len * qchunks;
+    for (int64_t x = tid; x < nkv; x += nth) o.node_kv[kv0 + x] = sl[x % len];
+}
+
+}  // namespace deft

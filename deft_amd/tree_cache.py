@@ -1,6 +1,6 @@
 """Decoding tree over the paged KV pool + the attention metadata contract.
 
-Mirrors the paged half of DeFT/deft/tree_decoding/tree_cache.py with the same
+The drop-in surface of the paged half of DeFT/deft/tree_decoding/tree_cache.py -- same
 names, argument meaning and error behaviour:
 
   KVCacheUpdater (:52-91)    new K/V rows -> pool slots (here: one fused HIP kernel)
@@ -14,17 +14,29 @@ names, argument meaning and error behaviour:
 Out of scope (and rejected loudly): unpaged KV (`use_paged_memory=False`) and the
 WIP tree-index mode (`use_tree_index=True`).
 
-MI355X-side differences (results identical):
-  * `from_tree_cache` runs in the native builder of libdeft_amd.so
-    (`deft_md_build`, deft_amd/csrc/host.cpp) and ships all twelve int64 arrays
-    to the GPU in ONE host-to-device copy; the reference walks Python sets and
-    issues ~12 separate `torch.tensor(..., device="cuda")` copies per step.
-  * `alloc()` takes slots from the host-side allocator and writes the page table
-    with one batched index_put instead of a `.item()` + scalar store per leaf.
+How it is built here (results identical, checked bit for bit against reference outputs):
+
+  * The tree itself -- parents, children, pool slots, which nodes are live leaves, how many
+    live leaves hang below every node -- is ONE native object (`deft_tree_*`,
+    deft_amd/csrc/tree.cpp).  `TreeCache` translates the reference's calls into operations
+    on it; `TreeNode.kv_indices`, `.refs` are views into it, the `nodes` / `leaves` dicts
+    hold the Python handles.  Token ids and positions are host-side bookkeeping of the
+    decode loop and stay on the handles.
+  * `alloc()` takes its slots from the host-side allocator, appends them to all leaves in
+    one native call and writes the page table with one batched index_put (the reference:
+    a `.item()` + scalar store per leaf).
+  * `TreeMetadata.from_tree_cache` on a GPU pool runs ON THE GPU: the tree has a compact
+    device copy (`_DeviceTree`, deft_amd/csrc/tree_plan.h) that is uploaded when the
+    STRUCTURE changes (branch / cut / merge) and advanced by a kernel on every `alloc()`;
+    three kernels then emit the reference's twelve int64 arrays.  Per decode step nothing
+    but the nq new slot numbers crosses PCIe.  On CPU pools (and with
+    `device_build=False`) the native host builder `deft_md_build` produces the same
+    arrays; the reference walks Python sets and issues ~12 H2D copies per step.
 """
 from __future__ import annotations
 
 import ctypes as C
+from collections.abc import MutableSequence
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Set
 
@@ -36,6 +48,8 @@ from .memory_pool import ReqToTokenPool, TokenToKVPool
 
 BLOCK_CONFIG = {"BLOCK_LEN": 128, "MAX_BLOCK_LEN": -1}  # tree_cache.py:587
 TRAVERSAL_CONFIG = {"METHOD": "dfs"}  # tree_cache.py:588 (only DFS exists upstream)
+
+_ptr = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
 
 
 class KVCacheUpdater:
@@ -64,8 +78,81 @@ class KVCacheUpdater:
         kv_append(self.token_to_kv_pool.kv_data[layer_id], self.cache_loc, cache_k, cache_v)
 
 
+class _Slots(MutableSequence):
+    """`node.kv_indices` of a node that belongs to a tree: the pool slots the native tree holds for it, in the
+    order they were appended.  Reads fetch them, edits (scripts written against the reference append to and
+    assign this list directly) are written through, so the tree never sees a stale slot list."""
+
+    __slots__ = ("_h", "_id")
+
+    def __init__(self, handle: int, node_id: int) -> None:
+        self._h, self._id = handle, node_id
+
+    def _get(self) -> np.ndarray:
+        n = int(lib.deft_tree_node_len(self._h, self._id))
+        if n < 0:
+            check(n, "deft_tree_node_len")
+        out = np.empty(n, dtype=np.int64)
+        if n:
+            lib.deft_tree_node_kv(self._h, self._id, _ptr(out), n)
+        return out
+
+    def _put(self, values) -> None:
+        arr = np.ascontiguousarray(values, dtype=np.int64).reshape(-1)
+        check(lib.deft_tree_set_node_kv(self._h, self._id, len(arr), _ptr(arr)), "deft_tree_set_node_kv")
+
+    def __len__(self) -> int:
+        n = int(lib.deft_tree_node_len(self._h, self._id))
+        if n < 0:
+            check(n, "deft_tree_node_len")
+        return n
+
+    def __getitem__(self, i):
+        v = self._get()[i]
+        return v.tolist() if isinstance(i, slice) else int(v)
+
+    def __setitem__(self, i, value) -> None:
+        cur = self._get().tolist()
+        cur[i] = value
+        self._put(cur)
+
+    def __delitem__(self, i) -> None:
+        cur = self._get().tolist()
+        del cur[i]
+        self._put(cur)
+
+    def insert(self, i: int, value) -> None:
+        cur = self._get().tolist()
+        cur.insert(i, int(value))
+        self._put(cur)
+
+    def append(self, value) -> None:  # (the common edit: one native call, no round trip of the list)
+        v = np.asarray([int(value)], dtype=np.int64)
+        check(lib.deft_tree_extend_node(self._h, self._id, 1, _ptr(v)), "deft_tree_extend_node")
+
+    def extend(self, values) -> None:
+        v = np.ascontiguousarray(list(values), dtype=np.int64)
+        check(lib.deft_tree_extend_node(self._h, self._id, len(v), _ptr(v)), "deft_tree_extend_node")
+
+    def __iter__(self):
+        return iter(self._get().tolist())
+
+    def tolist(self) -> List[int]:
+        return self._get().tolist()
+
+    def __eq__(self, other) -> bool:
+        try:
+            return self._get().tolist() == list(other)
+        except TypeError:
+            return NotImplemented
+
+    def __repr__(self) -> str:
+        return repr(self._get().tolist())
+
+
 class TreeNode:
-    """tree_cache.py:94-130."""
+    """tree_cache.py:94-130: a handle.  Token ids / positions live here; the slots and the leaf set are read from
+    the tree the node belongs to."""
 
     def __init__(self, id: int, node_indices_id: Optional[int] = None, node_indices=None) -> None:
         self.id = id
@@ -73,14 +160,14 @@ class TreeNode:
         self.token_ids: List[int] = []
         self.positions: List[int] = []
         self.position_offset = 0
-        self.kv_indices: List[int] = []
         self.kv_data = None
         self.parent: Optional["TreeNode"] = None
-        self.refs: Set["TreeNode"] = set()
         self.paused = False
         self.node_indices_id = node_indices_id
         self.node_indices = node_indices
         self.cumulative_logprob = 0.0
+        self._tree: Optional["TreeCache"] = None
+        self._local_kv: List[int] = []  # a node outside any tree keeps an ordinary list
 
     def get_len(self) -> int:
         return len(self.token_ids)
@@ -93,6 +180,32 @@ class TreeNode:
 
     def append_index(self, index: int) -> None:
         self.kv_indices.append(index)
+
+    @property
+    def kv_indices(self):
+        t = self._tree
+        return _Slots(t._native, self.id) if t is not None and t._native else self._local_kv
+
+    @kv_indices.setter
+    def kv_indices(self, values) -> None:
+        t = self._tree
+        if t is not None and t._native:
+            _Slots(t._native, self.id)._put(list(values))
+        else:
+            self._local_kv = list(values)
+
+    @property
+    def refs(self) -> Set["TreeNode"]:
+        """The live leaves below (or at) this node (tree_cache.py:504-516 keeps them as a set per node)."""
+        t = self._tree
+        if t is None or not t._native:
+            return set()
+        n = int(lib.deft_tree_node_refs(t._native, self.id, None, 0))
+        if n < 0:
+            return set()
+        out = np.empty(max(n, 1), dtype=np.int64)
+        lib.deft_tree_node_refs(t._native, self.id, _ptr(out), n)
+        return {t.nodes[int(i)] for i in out[:n] if int(i) in t.nodes}
 
 
 class TreeCache:
@@ -128,9 +241,8 @@ class TreeCache:
         self.use_tree_index = False
         self.layer_num = layer_num
         self.deleted_token_num = 0
-        # native mirror of the tree (csrc/host.cpp): mutations are forwarded so that from_tree_cache does not
-        # re-marshal every node's slot list each decode step
         self._native = int(lib.deft_tree_create())
+        self._device_tree: Optional["_DeviceTree"] = None
 
     def __del__(self):  # noqa: D105
         h = getattr(self, "_native", 0)
@@ -141,62 +253,75 @@ class TreeCache:
                 pass
             self._native = 0
 
-    def _mirror(self, rc: int, what: str) -> None:
-        check(rc, what)
+    # ---- helpers ------------------------------------------------------------------------------------
+    def _handle(self, node_id: int, parent: Optional[TreeNode]) -> TreeNode:
+        node = TreeNode(node_id)
+        node._tree = self
+        node.parent = parent
+        if parent is not None:
+            node.position_offset = parent.position_offset + len(parent.positions)
+            parent.children[node_id] = node
+        self.nodes[node_id] = node
+        return node
+
+    def _epoch(self) -> int:
+        st = np.zeros(4, dtype=np.int64)
+        check(lib.deft_tree_stats(self._native, _ptr(st)), "deft_tree_stats")
+        return int(st[3])
+
+    def _consistent(self) -> bool:
+        """The dicts are handles onto the native tree; code that pops / adds entries behind TreeCache's back is caught
+        by the counts (slot lists cannot go stale: `kv_indices` is a view)."""
+        st = np.zeros(4, dtype=np.int64)
+        if not self._native or lib.deft_tree_stats(self._native, _ptr(st)) != 0:
+            return False
+        return int(st[0]) == len(self.nodes) and int(st[1]) == len(self.leaves)
 
     # ---- :192-230 -------------------------------------------------------------
     def init_prompt(self, prompt_ids) -> KVCacheUpdater:
         ids = [int(t) for t in torch.as_tensor(prompt_ids).reshape(-1).tolist()]
-        self.root = TreeNode(0)
-        self.nodes[0] = self.root
+        check(lib.deft_tree_add_node(self._native, 0, -1), "deft_tree_add_node")
+        check(lib.deft_tree_set_leaf(self._native, 0, 1), "deft_tree_set_leaf")
+        self.root = self._handle(0, None)
         self.root.token_ids = ids
-        self.root.position_offset = 0
         self.root.positions = list(range(len(ids)))
-        self.leaves[self.root.id] = self.root
-        self.add_ref(self.root)
+        self.leaves[0] = self.root
 
         req = self.req_to_token_pool.alloc(1)
         assert req is not None
         req_id = int(req[0])
-        self.leaf_to_req[self.root.id] = req_id
+        self.leaf_to_req[0] = req_id
         loc = self.token_to_kv_pool.alloc_host(len(ids))
         assert loc is not None
-        self.root.kv_indices = loc.tolist()
-        self._mirror(lib.deft_tree_add_node(self._native, 0, -1), "deft_tree_add_node")
-        self._mirror(lib.deft_tree_set_leaf(self._native, 0, 1), "deft_tree_set_leaf")
-        loc64 = np.ascontiguousarray(loc, dtype=np.int64)
-        self._mirror(lib.deft_tree_extend_node(self._native, 0, len(loc64), loc64.ctypes.data_as(C.c_void_p)),
-                     "deft_tree_extend_node")
+        self.root.kv_indices = loc
         cache_loc = torch.from_numpy(loc).to(self.token_to_kv_pool.device)
-        self.req_to_token_pool.req_to_token[req_id, : len(ids)] = cache_loc.to(self.req_to_token_pool.req_to_token.device)
+        table = self.req_to_token_pool.req_to_token
+        table[req_id, : len(ids)] = cache_loc.to(table.device)
         return KVCacheUpdater(True, self.token_to_kv_pool, cache_loc, None, True)
 
     # ---- :242-259 -------------------------------------------------------------
     def new_node(self, parent: TreeNode) -> TreeNode:
-        node = TreeNode(self.node_cnt)
+        node_id = self.node_cnt
         self.node_cnt += 1
-        node.parent = parent
-        node.position_offset = parent.position_offset + len(parent.positions)
-        parent.children[node.id] = node
-        self.nodes[node.id] = node
-        self._mirror(lib.deft_tree_add_node(self._native, node.id, parent.id), "deft_tree_add_node")
-        return node
+        check(lib.deft_tree_add_node(self._native, node_id, parent.id), "deft_tree_add_node")
+        return self._handle(node_id, parent)
 
     # ---- :261-283 -------------------------------------------------------------
     def alloc(self) -> KVCacheUpdater:
-        loc = self.token_to_kv_pool.alloc_host(len(self.leaves))
+        """One pool slot per live leaf, leaves in id order (what the reference's loop over sorted leaves does)."""
+        n = len(self.leaves)
+        loc = self.token_to_kv_pool.alloc_host(n)
         assert loc is not None
-        reqs, poss, ids = [], [], []
-        for idx, leaf in enumerate(sorted(self.leaves.values(), key=lambda x: x.id)):
-            leaf.append_index(int(loc[idx]))
-            reqs.append(self.leaf_to_req[leaf.id])
-            poss.append(leaf.positions[-1])
-            ids.append(leaf.id)
-        ids64 = np.asarray(ids, dtype=np.int64)
-        loc64 = np.ascontiguousarray(loc, dtype=np.int64)
-        self._mirror(lib.deft_tree_append_slots(self._native, len(ids), ids64.ctypes.data_as(C.c_void_p),
-                                                loc64.ctypes.data_as(C.c_void_p)), "deft_tree_append_slots")
+        dev = self._device_tree
+        synced = dev is not None and dev.epoch == self._epoch()
+        loc64 = loc.astype(np.int64)
+        check(lib.deft_tree_alloc_step(self._native, n, _ptr(loc64)), "deft_tree_alloc_step")
         cache_loc = torch.from_numpy(loc).to(self.token_to_kv_pool.device, non_blocking=True)
+        if synced and dev.epoch == self._epoch():
+            dev.advance(cache_loc)  # the device copy of the tree appends the same slots itself
+        order = sorted(self.leaves)
+        reqs = [self.leaf_to_req[i] for i in order]
+        poss = [self.leaves[i].positions[-1] for i in order]
         table = self.req_to_token_pool.req_to_token
         idx = torch.from_numpy(np.asarray([reqs, poss], dtype=np.int64)).to(table.device, non_blocking=True)
         table[idx[0], idx[1]] = cache_loc.to(table.device)  # one batched page-table write
@@ -204,91 +329,79 @@ class TreeCache:
 
     # ---- :300-336 -------------------------------------------------------------
     def merge_nodes(self, node_A: TreeNode, node_B: TreeNode, pruneB_flag: Optional[bool] = True) -> None:
+        """node_A takes over node_B's tokens and slots (speculative decoding: accepted tokens move into the root);
+        the slots gain a reference, so pruning B afterwards does not free them."""
+        moved = node_B.kv_indices.tolist()
         for token_id in node_B.token_ids:
+            # (the reference records the position twice -- here and inside append_token, tree_cache.py:307-311 --
+            #  and later position arithmetic on the node depends on it)
             node_A.positions.append(node_A.position_offset + len(node_A.token_ids))
             node_A.append_token(token=token_id)
-        for kv_idx in node_B.kv_indices:
-            node_A.append_index(index=kv_idx)
-        b64 = np.asarray(node_B.kv_indices, dtype=np.int64)
-        self._mirror(lib.deft_tree_extend_node(self._native, node_A.id, len(b64), b64.ctypes.data_as(C.c_void_p)),
-                     "deft_tree_extend_node")
-        self.token_to_kv_pool.add_refs(node_B.kv_indices)
+        node_A.kv_indices.extend(moved)
+        self.token_to_kv_pool.add_refs(moved)
         if pruneB_flag:
             self.cut(node_B)
 
     def reset_node_KV(self, node: TreeNode, diff: int) -> None:
-        self.token_to_kv_pool.free(node.kv_indices)
+        self.token_to_kv_pool.free(node.kv_indices.tolist())
         node.kv_indices = []
-        self._mirror(lib.deft_tree_clear_node_kv(self._native, node.id), "deft_tree_clear_node_kv")
         node.position_offset += diff
         node.positions = [pos + diff for pos in node.positions]
 
     # ---- :338-370 -------------------------------------------------------------
     def branch(self, node: TreeNode, branch_cnt: int) -> List[TreeNode]:
         assert node.id in self.leaves
+        first = self.node_cnt
+        check(lib.deft_tree_branch(self._native, node.id, branch_cnt, first), "deft_tree_branch")
+        self.node_cnt += branch_cnt
         self.leaves.pop(node.id)
-        self._mirror(lib.deft_tree_set_leaf(self._native, node.id, 0), "deft_tree_set_leaf")
-        path_len = node.positions[-1] + 1
         req = self.leaf_to_req.pop(node.id)
-        is_first = True
-        new_nodes: List[TreeNode] = []
-        for _ in range(branch_cnt):
-            child = self.new_node(node)
-            new_nodes.append(child)
+        path_len = node.positions[-1] + 1
+        kids = [self._handle(first + i, node) for i in range(branch_cnt)]
+        for i, child in enumerate(kids):
             self.leaves[child.id] = child
-            self._mirror(lib.deft_tree_set_leaf(self._native, child.id, 1), "deft_tree_set_leaf")
-            if is_first:
+            if i == 0:  # the first child inherits the parent's page-table row, the others get a copy of it
                 self.leaf_to_req[child.id] = req
-                is_first = False
-            else:
-                new_req = self.req_to_token_pool.alloc(1)
-                assert new_req is not None
-                new_req_id = int(new_req[0])
-                self.req_to_token_pool.copy(req, new_req_id, path_len)
-                self.leaf_to_req[child.id] = new_req_id
-        self.remove_ref(node)
-        for child in new_nodes:
-            self.add_ref(child)
-        return new_nodes
+                continue
+            row = self.req_to_token_pool.alloc(1)
+            assert row is not None
+            self.req_to_token_pool.copy(req, int(row[0]), path_len)
+            self.leaf_to_req[child.id] = int(row[0])
+        return kids
 
     # ---- :373-403 -------------------------------------------------------------
     def cut(self, node: TreeNode, record_deleted: bool = False) -> List[TreeNode]:
         assert len(node.children) == 0
         assert node.id in self.leaves
+        st = np.zeros(4, dtype=np.int64)
+        check(lib.deft_tree_stats(self._native, _ptr(st)), "deft_tree_stats")
+        ids = np.empty(max(int(st[0]), 1), dtype=np.int64)
+        slots = np.empty(max(int(st[2]), 1), dtype=np.int64)
+        n_ids, n_slots = C.c_int(0), C.c_int64(0)
+        check(lib.deft_tree_cut(self._native, node.id, _ptr(ids), len(ids), C.byref(n_ids), _ptr(slots), len(slots),
+                                C.byref(n_slots)), "deft_tree_cut")
         self.leaves.pop(node.id)
-        self.remove_ref(node)
-        req = self.leaf_to_req.pop(node.id)
-        self.req_to_token_pool.free(req)
-        assert len(node.refs) == 0
-        deleted_nodes = []
-        cur: Optional[TreeNode] = node
-        while cur is not None and len(cur.refs) == 0:
-            deleted_nodes.append(self.nodes.pop(cur.id))
-            self._mirror(lib.deft_tree_remove_node(self._native, cur.id), "deft_tree_remove_node")
-            self.token_to_kv_pool.free(cur.kv_indices)
-            parent = cur.parent
-            if parent is not None:
-                parent.children.pop(cur.id)
-            cur = parent
-        if record_deleted:
-            for deleted in deleted_nodes:
-                self.deleted_token_num += len(deleted.token_ids)
-        return deleted_nodes
+        self.req_to_token_pool.free(self.leaf_to_req.pop(node.id))
+        self.token_to_kv_pool.free(slots[: n_slots.value])
+        gone = []
+        for i in ids[: n_ids.value].tolist():  # the leaf, then every ancestor it was the last live leaf of
+            h = self.nodes.pop(i)
+            if h.parent is not None:
+                h.parent.children.pop(i, None)
+            h._local_kv = []
+            h._tree = None
+            gone.append(h)
+            if record_deleted:
+                self.deleted_token_num += len(h.token_ids)
+        return gone
 
     # ---- :504-516 -------------------------------------------------------------
     def add_ref(self, node: TreeNode) -> None:
-        ref = node
-        node.refs.add(ref)
-        while node.parent is not None:
-            node = node.parent
-            node.refs.add(ref)
+        """The reference adds `node` to the `refs` set of every ancestor; here: the node counts as a live leaf."""
+        check(lib.deft_tree_set_leaf(self._native, node.id, 1), "deft_tree_set_leaf")
 
     def remove_ref(self, node: TreeNode) -> None:
-        ref = node
-        node.refs.remove(ref)
-        while node.parent is not None:
-            node = node.parent
-            node.refs.remove(ref)
+        check(lib.deft_tree_set_leaf(self._native, node.id, 0), "deft_tree_set_leaf")
 
     def free(self) -> None:  # :518-523
         self.root = None
@@ -297,21 +410,19 @@ class TreeCache:
         self.node_cnt = 0
         lib.deft_tree_free(self._native)
         self._native = int(lib.deft_tree_create())
+        self._device_tree = None
 
     def get_tree_token_number(self) -> int:  # :569-584
         return sum(len(n.token_ids) for n in self.nodes.values()) + self.deleted_token_num
 
     def leaf_path_slots(self, leaf: TreeNode) -> List[int]:
         """Root->leaf pool slots (what sequential attention over this leaf reads)."""
-        chain = []
-        cur: Optional[TreeNode] = leaf
-        while cur is not None:
-            chain.append(cur)
-            cur = cur.parent
-        out: List[int] = []
-        for n in reversed(chain):
-            out.extend(n.kv_indices)
-        return out
+        n = int(lib.deft_tree_path_slots(self._native, leaf.id, None, 0))
+        if n < 0:
+            check(n, "deft_tree_path_slots")
+        out = np.empty(max(n, 1), dtype=np.int64)
+        lib.deft_tree_path_slots(self._native, leaf.id, _ptr(out), n)
+        return out[:n].tolist()
 
 
 _FIELDS = (
@@ -320,41 +431,44 @@ _FIELDS = (
 )
 
 
+def _lens_from_sizes(sizes) -> Dict[str, int]:
+    query_num, NE, total_kv, n_node_q, n_node_kv, NB, P, n_block_kv = (int(x) for x in sizes[:8])
+    return {
+        "node_q": n_node_q, "node_kv": n_node_kv, "node_q_len": NE, "node_kv_len": NE,
+        "node_q_offset": NE, "node_kv_offset": NE,
+        "block_q": P, "block_q_cnts": NB, "block_q_offset": NB,
+        "block_bitmasks": n_block_kv, "block_kv": n_block_kv, "block_lens": NB,
+    }
+
+
 def _mirror_consistent(tree: TreeCache) -> bool:
-    """The mirror sees every mutation made through TreeCache's methods; code that edits `node.kv_indices` or
-    `tree.leaves` directly (the reference's scripts are free to) is caught here by counts and sends the build
-    down the marshalling path."""
-    if not getattr(tree, "_native", 0):
-        return False
-    stats = np.zeros(3, dtype=np.int64)
-    if lib.deft_tree_stats(tree._native, stats.ctypes.data_as(C.c_void_p)) != 0:
-        return False
-    return (int(stats[0]) == len(tree.nodes) and int(stats[1]) == len(tree.leaves)
-            and int(stats[2]) == sum(len(nd.kv_indices) for nd in tree.nodes.values()))
+    return tree._consistent()
 
 
 def _marshal_and_build(tree: TreeCache, max_q_len: int, block_len: int, max_block_len: int) -> int:
+    """deft_md_build on arrays marshalled from the Python-visible tree (the stateless entry point of the C ABI)."""
     nodes = list(tree.nodes.values())
     n = len(nodes)
     node_id = np.fromiter((nd.id for nd in nodes), dtype=np.int64, count=n)
     parent_id = np.fromiter((nd.parent.id if nd.parent is not None else -1 for nd in nodes), dtype=np.int64, count=n)
     is_leaf = np.fromiter((nd.id in tree.leaves for nd in nodes), dtype=np.uint8, count=n)
+    lists = [nd.kv_indices.tolist() if isinstance(nd.kv_indices, _Slots) else list(nd.kv_indices) for nd in nodes]
     kv_offset = np.zeros(n + 1, dtype=np.int64)
-    np.cumsum([len(nd.kv_indices) for nd in nodes], out=kv_offset[1:])
+    np.cumsum([len(x) for x in lists], out=kv_offset[1:])
     kv_slots = np.empty(int(kv_offset[-1]), dtype=np.int64)
-    for i, nd in enumerate(nodes):
-        kv_slots[kv_offset[i] : kv_offset[i + 1]] = nd.kv_indices
-
-    ptr = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
-    return int(lib.deft_md_build(n, ptr(node_id), ptr(parent_id), ptr(is_leaf), ptr(kv_offset), ptr(kv_slots),
+    for i, x in enumerate(lists):
+        kv_slots[kv_offset[i] : kv_offset[i + 1]] = x
+    return int(lib.deft_md_build(n, _ptr(node_id), _ptr(parent_id), _ptr(is_leaf), _ptr(kv_offset), _ptr(kv_slots),
                                  int(max_q_len), int(block_len), int(max_block_len)))
 
 
 def build_metadata_host(tree: TreeCache, max_q_len: int, block_len: int, max_block_len: int,
                         use_mirror: bool = True, alloc=None) -> Dict[str, object]:
-    """Run the native builder; returns numpy int64 arrays that alias ONE packed buffer."""
-    ptr = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
-    if use_mirror and _mirror_consistent(tree):
+    """Run the native HOST builder; returns numpy int64 arrays that alias ONE packed buffer."""
+    if not tree._consistent():
+        raise RuntimeError("tree.nodes / tree.leaves were edited behind TreeCache's back: mutate the tree through "
+                           "init_prompt / branch / alloc / cut / merge_nodes / reset_node_KV")
+    if use_mirror:
         handle = int(lib.deft_tree_build_md(tree._native, int(max_q_len), int(block_len), int(max_block_len)))
     else:
         handle = _marshal_and_build(tree, max_q_len, block_len, max_block_len)
@@ -362,28 +476,118 @@ def build_metadata_host(tree: TreeCache, max_q_len: int, block_len: int, max_blo
         check(int(handle), "deft_md_build")
     try:
         sizes = np.zeros(8, dtype=np.int64)
-        check(lib.deft_md_sizes(handle, ptr(sizes)), "deft_md_sizes")
-        query_num, NE, total_kv, n_node_q, n_node_kv, NB, P, n_block_kv = (int(x) for x in sizes)
-        lens = {
-            "node_q": n_node_q, "node_kv": n_node_kv, "node_q_len": NE, "node_kv_len": NE,
-            "node_q_offset": NE, "node_kv_offset": NE,
-            "block_q": P, "block_q_cnts": NB, "block_q_offset": NB,
-            "block_bitmasks": n_block_kv, "block_kv": n_block_kv, "block_lens": NB,
-        }
+        check(lib.deft_md_sizes(handle, _ptr(sizes)), "deft_md_sizes")
+        lens = _lens_from_sizes(sizes)
         total = sum(lens.values())
         packed = np.empty(total, dtype=np.int64) if alloc is None else alloc(total)  # e.g. a pinned staging buffer
         views, off = {}, 0
         for k in _FIELDS:
             views[k] = packed[off : off + lens[k]]
             off += lens[k]
-        leaf_ids = np.empty(query_num, dtype=np.int64)
-        check(lib.deft_md_fetch(handle, *[ptr(views[k]) for k in _FIELDS], ptr(leaf_ids)), "deft_md_fetch")
+        leaf_ids = np.empty(int(sizes[0]), dtype=np.int64)
+        check(lib.deft_md_fetch(handle, *[_ptr(views[k]) for k in _FIELDS], _ptr(leaf_ids)), "deft_md_fetch")
     finally:
         lib.deft_md_free(handle)
     out: Dict[str, object] = dict(views)
-    out.update(query_num=query_num, node_num=NE, total_kv_len=total_kv, block_len=block_len,
+    out.update(query_num=int(sizes[0]), node_num=int(sizes[1]), total_kv_len=int(sizes[2]), block_len=block_len,
                leaf_to_q={int(l): i for i, l in enumerate(leaf_ids)}, _packed=packed, _lens=lens)
     return out
+
+
+class _DeviceTree:
+    """The compact copy of a tree on the GPU and the buffers the metadata kernels write (deft_amd/csrc/tree_plan.h).
+
+    One upload per structural EPOCH of the tree (branch / cut / merge / a leaf outgrowing its room): node table,
+    leaf sets as bit sets, every node's slots.  Within an epoch `alloc()` advances the device copy with a kernel, and
+    `build()` launches the three metadata kernels into buffers sized for the largest tree the epoch can hold."""
+
+    SLACK = 256  # decode steps a leaf can grow before the tree is laid out again
+
+    def __init__(self, tree: TreeCache, device: torch.device, max_q_len: int, block_len: int, max_block_len: int) -> None:
+        self.tree, self.device = tree, device
+        self.cfg = (int(max_q_len), int(block_len), int(max_block_len))
+        self.epoch = -1
+        self.stage = None  # pinned staging buffer of the upload image
+        self.stage_event = None
+
+    def _upload(self) -> None:
+        t, (mq, bl, mbl) = self.tree, self.cfg
+        sizes = np.zeros(5, dtype=np.int64)
+        check(lib.deft_tree_layout(t._native, self.SLACK, _ptr(sizes)), "deft_tree_layout")
+        n, nq, nqw, total_cap, epoch = (int(x) for x in sizes)
+        self.n, self.nq, self.nqw = n, nq, nqw
+        # upload image: [node_start | node_len | node_cap | leaf_node | slots] int32, then refs uint64
+        n32 = 3 * n + nq + total_cap
+        n32 += n32 & 1  # keep the uint64 part 8-byte aligned
+        words = n32 + 2 * n * nqw
+        if self.stage is None or self.stage.numel() < words:
+            self.stage = torch.empty(max(2 * words, 1 << 12), dtype=torch.int32).pin_memory()
+        elif self.stage_event is not None:
+            self.stage_event.synchronize()  # the previous upload has left the staging buffer
+        img = self.stage.numpy()[:words]
+        v_start, v_len, v_cap = img[0:n], img[n : 2 * n], img[2 * n : 3 * n]
+        v_leaf, v_slots = img[3 * n : 3 * n + nq], img[3 * n + nq : 3 * n + nq + total_cap]
+        v_refs = img[n32:words].view(np.uint64)
+        check(lib.deft_tree_layout_fetch(t._native, _ptr(v_start), _ptr(v_len), _ptr(v_cap), _ptr(v_refs), _ptr(v_leaf),
+                                         _ptr(v_slots)), "deft_tree_layout_fetch")
+        dev = self.stage[:words].to(self.device, non_blocking=True)
+        self.stage_event = torch.cuda.Event()
+        self.stage_event.record(torch.cuda.current_stream(self.device))
+        self.image = dev
+        base = dev.data_ptr()
+        self.p_start, self.p_len, self.p_cap = base, base + 4 * n, base + 8 * n
+        self.p_leaf, self.p_slots, self.p_refs = base + 12 * n, base + 4 * (3 * n + nq), base + 4 * n32
+        # output buffers for the largest tree of this epoch (every leaf SLACK tokens longer)
+        cap = np.zeros(9, dtype=np.int64)
+        # (a node's room is rounded up to a multiple of four slots, so a leaf can outgrow SLACK by three)
+        check(lib.deft_tree_md_sizes(t._native, mq, bl, mbl, self.SLACK + 4, _ptr(cap)), "deft_tree_md_sizes")
+        self.cap_lens = _lens_from_sizes(cap)
+        self.nbp_cap = int(cap[8])
+        self.out = torch.empty(sum(self.cap_lens.values()) + 1, dtype=torch.int64, device=self.device)
+        sb = int(lib.deft_tree_dev_scratch_bytes(n, nqw, self.nbp_cap))
+        self.scratch = torch.zeros(sb, dtype=torch.uint8, device=self.device)  # (dims[] start at zero)
+        self.scratch_bytes = sb
+        self.epoch = epoch
+
+    def sync(self) -> None:
+        if self.epoch != self.tree._epoch():
+            self._upload()
+
+    def _tree_args(self):
+        return (self.n, self.nq, self.nqw, self.p_start, self.p_len, self.p_cap, self.p_refs, self.p_leaf, self.p_slots)
+
+    def advance(self, cache_loc: torch.Tensor) -> None:
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        check(lib.deft_tree_dev_advance(*self._tree_args(), cache_loc.data_ptr(), self.scratch.data_ptr(), stream),
+              "deft_tree_dev_advance")
+
+    def build(self) -> Dict[str, object]:
+        """Launch the metadata kernels; returns device tensors (views of the epoch's buffers) shaped by sizes the
+        host computes from node lengths alone."""
+        self.sync()
+        t, (mq, bl, mbl) = self.tree, self.cfg
+        sizes = np.zeros(9, dtype=np.int64)
+        check(lib.deft_tree_md_sizes(t._native, mq, bl, mbl, 0, _ptr(sizes)), "deft_tree_md_sizes")
+        lens = _lens_from_sizes(sizes)
+        views, ptrs, off = {}, [], 0
+        for k in _FIELDS:
+            if lens[k] > self.cap_lens[k]:
+                raise RuntimeError(f"device metadata buffer {k} too small ({lens[k]} > {self.cap_lens[k]})")
+            views[k] = self.out[off : off + lens[k]]
+            ptrs.append(self.out.data_ptr() + 8 * off)
+            off += self.cap_lens[k]
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        check(lib.deft_tree_dev_build_md(*self._tree_args(), mq, bl, mbl, self.nbp_cap, self.scratch.data_ptr(),
+                                         self.scratch_bytes, *ptrs, stream), "deft_tree_dev_build_md")
+        leaf_ids = np.empty(max(int(sizes[0]), 1), dtype=np.int64)
+        nl = int(lib.deft_tree_leaf_ids(t._native, _ptr(leaf_ids), len(leaf_ids)))
+        views.update(query_num=int(sizes[0]), node_num=int(sizes[1]), total_kv_len=int(sizes[2]),
+                     leaf_to_q={int(l): i for i, l in enumerate(leaf_ids[:nl])})
+        return views
+
+    def dims(self) -> List[int]:
+        """dims[] as the device wrote them (debug / tests; synchronises)."""
+        return self.scratch[:64].view(torch.int32).tolist()
 
 
 @dataclass
@@ -418,12 +622,23 @@ class TreeMetadata:
         max_q_len: int = 32,
         max_block_len: int = -1,
         device: Optional[str] = None,
+        device_build: Optional[bool] = None,
     ) -> "TreeMetadata":
+        """`device_build` (GPU pools): None / True = the arrays are built on the GPU from the device copy of the tree;
+        False = by the host builder and uploaded in one copy (the round-1 path, kept as the checker)."""
         assert tree.root is not None
         block_len = BLOCK_CONFIG["BLOCK_LEN"]
         if max_block_len == -1:
             max_block_len = BLOCK_CONFIG["MAX_BLOCK_LEN"]
         dev = torch.device(device) if device is not None else tree.token_to_kv_pool.device
+        if dev.type != "cpu" and device_build is not False:
+            if not tree._consistent():
+                raise RuntimeError("tree.nodes / tree.leaves were edited behind TreeCache's back")
+            dt = tree._device_tree
+            if dt is None or dt.device != dev or dt.cfg != (int(max_q_len), int(block_len), int(max_block_len)):
+                dt = tree._device_tree = _DeviceTree(tree, dev, max_q_len, block_len, max_block_len)
+            views = dt.build()
+            return cls(block_len=block_len, **views)
         if dev.type == "cpu":
             host = build_metadata_host(tree, max_q_len, block_len, max_block_len)
             packed = torch.from_numpy(host["_packed"])

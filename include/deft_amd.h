@@ -296,22 +296,63 @@ int deft_md_fetch(
 int deft_md_free(int64_t handle);
 
 /*
- * Persistent mirror of the decoding tree (host only).  The host-side TreeCache forwards its mutations
- * (tree_cache.py:192-403: init_prompt / new_node / alloc / branch / cut / merge_nodes / reset_node_KV) so that a
- * decode step's metadata is built without re-marshalling the whole tree: deft_tree_build_md(tree, ...) ==
- * deft_md_build(<the mirrored arrays>, ...), handle consumed with deft_md_sizes / _fetch / _free as above.
- * deft_tree_stats: {nodes, leaves, total KV slots}, for the caller's consistency check.
+ * The decoding tree over the paged pool (host side; deft_amd/csrc/tree.cpp).  The state machine behind TreeCache
+ * (tree_cache.py:147-403, :504-516): nodes with a parent and children in creation order, their pool slots, which nodes are
+ * live leaves and how many live leaves sit below every node (the reference's `refs` sets).  deft_amd.TreeCache / TreeNode are
+ * attribute views over this object.  Query row r of a decode step = the r-th live leaf by id (tree_cache.py:650-652).
  */
 int64_t deft_tree_create(void);
 int deft_tree_free(int64_t tree);
 int deft_tree_add_node(int64_t tree, int64_t id, int64_t parent_id /* -1 = root */);
 int deft_tree_remove_node(int64_t tree, int64_t id);
 int deft_tree_set_leaf(int64_t tree, int64_t id, int is_leaf);
+/* TreeCache.branch (:338-370): `id` stops being a leaf; cnt new live leaves first_id .. first_id + cnt - 1 below it */
+int deft_tree_branch(int64_t tree, int64_t id, int cnt, int64_t first_id);
+/* TreeCache.cut (:373-403): the leaf and every ancestor left without a live leaf; returns their ids (leaf first) and slots.
+ * *n_ids / *n_slots always report the counts; DEFT_EWORKSPACE (nothing changed) if a buffer is too small. */
+int deft_tree_cut(int64_t tree, int64_t id, int64_t* deleted_ids, int cap_ids, int* n_ids, int64_t* freed_slots,
+                  int64_t cap_slots, int64_t* n_slots);
+/* TreeCache.alloc (:261-283): one new slot per live leaf, ascending leaf id */
+int deft_tree_alloc_step(int64_t tree, int n, const int64_t* slots);
 int deft_tree_append_slots(int64_t tree, int n, const int64_t* ids, const int64_t* slots); /* one slot per id */
 int deft_tree_extend_node(int64_t tree, int64_t id, int n, const int64_t* slots);
+int deft_tree_set_node_kv(int64_t tree, int64_t id, int n, const int64_t* slots);
 int deft_tree_clear_node_kv(int64_t tree, int64_t id);
-int deft_tree_stats(int64_t tree, int64_t stats[3]);
+int64_t deft_tree_node_len(int64_t tree, int64_t id);
+int64_t deft_tree_node_kv(int64_t tree, int64_t id, int64_t* out, int64_t cap);    /* returns the length */
+int64_t deft_tree_node_refs(int64_t tree, int64_t id, int64_t* out, int64_t cap);  /* live leaves below, ascending */
+int64_t deft_tree_path_slots(int64_t tree, int64_t id, int64_t* out, int64_t cap); /* root -> node slots */
+int deft_tree_leaf_ids(int64_t tree, int64_t* out, int cap);                       /* query-row order; returns the count */
+int deft_tree_stats(int64_t tree, int64_t stats[4]); /* nodes, live leaves, total KV slots, structure epoch */
+/* == deft_md_build(<the tree>); handle consumed with deft_md_sizes / _fetch / _free */
 int64_t deft_tree_build_md(int64_t tree, int max_q_len, int block_len, int max_block_len);
+
+/*
+ * The same tree on the GPU: KV-guided grouping and flattened split as HIP kernels (deft_amd/csrc/tree_plan.h), so a decode
+ * step uploads nothing but its nq new slot numbers.
+ *   deft_tree_layout        nodes in DFS pre-order, room for `slack` more tokens per live leaf; sizes = {nodes, queries,
+ *                           64-bit words per leaf set, total slot capacity, epoch}.  The layout (and the device copy made from
+ *                           deft_tree_layout_fetch) stays valid while the epoch does: deft_tree_alloc_step keeps it as long as
+ *                           every leaf has room; every other mutation bumps it.
+ *   deft_tree_md_sizes      sizes of the metadata for the current lengths + `grow` tokens per leaf: sizes[0..7] as
+ *                           deft_md_sizes, sizes[8] = physical 128-slot blocks (capacity planning and tensor shapes; no slot touched)
+ *   deft_tree_dev_advance   device: append cache_loc[r] to query row r's leaf (kept ascending inside the node)
+ *   deft_tree_dev_build_md  device: the twelve int64 arrays of TreeMetadata, bit for bit deft_md_build's
+ */
+int deft_tree_layout(int64_t tree, int slack, int64_t sizes[5]);
+int deft_tree_layout_fetch(int64_t tree, int32_t* node_start, int32_t* node_len, int32_t* node_cap, uint64_t* refs,
+                           int32_t* leaf_node, int32_t* slots);
+int deft_tree_md_sizes(int64_t tree, int max_q_len, int block_len, int max_block_len, int grow, int64_t sizes[9]);
+size_t deft_tree_dev_scratch_bytes(int n_nodes, int nqw, int nbp_cap);
+int deft_tree_dev_advance(int n_nodes, int nq, int nqw, const int32_t* node_start, int32_t* node_len, const int32_t* node_cap,
+                          const uint64_t* refs, const int32_t* leaf_node, int32_t* slots, const int32_t* cache_loc,
+                          void* scratch, void* stream);
+int deft_tree_dev_build_md(int n_nodes, int nq, int nqw, const int32_t* node_start, int32_t* node_len, const int32_t* node_cap,
+                           const uint64_t* refs, const int32_t* leaf_node, int32_t* slots, int max_q_len, int block_len,
+                           int max_block_len, int nbp_cap, void* scratch, size_t scratch_bytes, int64_t* node_q, int64_t* node_kv,
+                           int64_t* node_q_len, int64_t* node_kv_len, int64_t* node_q_offset, int64_t* node_kv_offset,
+                           int64_t* block_q, int64_t* block_q_cnts, int64_t* block_q_offset, int64_t* block_bitmasks,
+                           int64_t* block_kv, int64_t* block_lens, void* stream);
 
 #ifdef __cplusplus
 }

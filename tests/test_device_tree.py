@@ -1,0 +1,141 @@
+"""Device-side TreeMetadata (deft_amd/csrc/tree_plan.h) against the host builder deft_md_build -- which is pinned bit
+for bit on the reference's own from_tree_cache outputs (tests/golden/*.npz, test_host_logic.py) -- and against those
+goldens directly.  Integer work: everything here is bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+import deft_amd
+from deft_amd import tree_cache as tc
+from product_helpers import MD_FIELDS, md_numpy, product_metadata, product_tree
+from scenarios import SCENARIOS
+
+pytestmark = pytest.mark.gpu
+
+
+def _both(tree, **kw):
+    dev = deft_amd.TreeMetadata.from_tree_cache(tree, device_build=True, **kw)
+    host = deft_amd.TreeMetadata.from_tree_cache(tree, device_build=False, **kw)
+    torch.cuda.synchronize()
+    return dev, host
+
+
+def _assert_same(dev, host):
+    a, b = md_numpy(dev), md_numpy(host)
+    for k in MD_FIELDS:
+        assert a[k].shape == b[k].shape, k
+        assert np.array_equal(a[k], b[k]), k
+    assert (dev.query_num, dev.node_num, dev.total_kv_len, dev.leaf_to_q) == (host.query_num, host.node_num, host.total_kv_len,
+                                                                              host.leaf_to_q)
+
+
+@pytest.mark.parametrize("name", list(SCENARIOS))
+def test_device_metadata_equals_reference_golden(name, golden):
+    """Every scripted tree (BASELINE's configurations among them), built on the GPU: the twelve arrays equal the
+    reference's own `from_tree_cache` output."""
+    sc = SCENARIOS[name]
+    tree = product_tree(name, device="cuda")
+    saved = dict(deft_amd.BLOCK_CONFIG)
+    deft_amd.BLOCK_CONFIG["BLOCK_LEN"] = sc.block_len
+    try:
+        md = deft_amd.TreeMetadata.from_tree_cache(tree, max_q_len=sc.max_q_len, max_block_len=sc.max_block_len, device_build=True)
+        torch.cuda.synchronize()
+    finally:
+        deft_amd.BLOCK_CONFIG.update(saved)
+    g = golden(name)
+    got = md_numpy(md)
+    for k in MD_FIELDS:
+        assert np.array_equal(got[k], g[k]), k
+    assert [md.query_num, md.node_num, md.total_kv_len, md.block_len] == g["scalars"].tolist()
+    dims = tree._device_tree.dims()
+    assert dims[9] == 0 and dims[5] == len(g["block_lens"]) and dims[6] == len(g["block_q"])
+
+
+def test_device_tree_advances_without_uploads():
+    """A decode loop: after the first build the tree is uploaded ONCE per structural epoch; every alloc() advances the
+    device copy by a kernel (cache_loc is the only thing that crosses PCIe) and the metadata stays equal to the host
+    builder's at every step -- through 128-slot block boundaries and past the 32-query chunk limit."""
+    Hkv, D = 2, 128
+    req = deft_amd.ReqToTokenPool(64, 4096, device="cuda")
+    pool = deft_amd.TokenToKVPool(4096, torch.float16, Hkv, D, 1, device="cuda")
+    tree = deft_amd.TreeCache(torch.float16, Hkv, D, 1, req, pool, None, True, False)
+    tree.init_prompt(torch.arange(1, 301, dtype=torch.int32))
+    tree.branch(tree.root, 40)
+    uploads = 0
+    orig = tc._DeviceTree._upload
+
+    def counting(self):
+        nonlocal uploads
+        uploads += 1
+        return orig(self)
+
+    tc._DeviceTree._upload = counting
+    try:
+        for step in range(70):
+            for leaf in list(tree.leaves.values()):
+                leaf.append_token(7)
+            tree.alloc()
+            dev, host = _both(tree)
+            _assert_same(dev, host)
+            assert tree._device_tree.dims()[9] == 0
+        assert uploads == 1  # branch -> first build; 70 steps of growth absorbed by the layout's slack
+        # structural change: cut three leaves (their slots return to the pool and come back LOWER than the survivors'
+        # newest slots, so the device has to insert, not append) and branch one
+        lv = sorted(tree.leaves.values(), key=lambda n: n.id)
+        for leaf in (lv[3], lv[17], lv[39]):
+            tree.cut(leaf)
+        tree.branch(lv[5], 3)
+        for step in range(12):
+            for leaf in list(tree.leaves.values()):
+                leaf.append_token(7)
+            tree.alloc()
+            dev, host = _both(tree)
+            _assert_same(dev, host)
+        assert uploads == 2
+    finally:
+        tc._DeviceTree._upload = orig
+
+
+def test_leaf_outgrowing_its_room_triggers_a_new_layout():
+    Hkv, D = 1, 128
+    req = deft_amd.ReqToTokenPool(16, 2048, device="cuda")
+    pool = deft_amd.TokenToKVPool(2048, torch.float16, Hkv, D, 1, device="cuda")
+    tree = deft_amd.TreeCache(torch.float16, Hkv, D, 1, req, pool, None, True, False)
+    tree.init_prompt(torch.arange(1, 51, dtype=torch.int32))
+    tree.branch(tree.root, 3)
+    saved = tc._DeviceTree.SLACK
+    tc._DeviceTree.SLACK = 8
+    try:
+        epochs = set()
+        for step in range(30):
+            for leaf in list(tree.leaves.values()):
+                leaf.append_token(7)
+            tree.alloc()
+            dev, host = _both(tree)
+            _assert_same(dev, host)
+            epochs.add(tree._device_tree.epoch)
+        assert len(epochs) >= 3  # 30 steps with room for 8: re-laid out several times, never wrong
+    finally:
+        tc._DeviceTree.SLACK = saved
+
+
+def test_speculative_decoding_mock_on_the_device_tree(golden):
+    """merge_nodes / reset_node_KV every step (branch_func_example.py:374-442): each step is a structural change, the
+    device copy is re-uploaded and the attention over the device-built metadata matches fp64 truth."""
+    from helpers import leaf_paths, max_abs, oracle_tree, seeded_inputs
+    from oracle import attention as oa
+
+    name, geom = "spec_mock", (4, 4, 128)
+    Hq, Hkv, D = geom
+    tree = product_tree(name, device="cuda", heads=(Hkv, D))
+    md = deft_amd.TreeMetadata.from_tree_cache(tree, device_build=True)
+    q_np, kv_np = seeded_inputs(name, geom, md.query_num)
+    tree.token_to_kv_pool.kv_data[0].copy_(torch.from_numpy(kv_np))
+    pool = tree.token_to_kv_pool
+    q = torch.from_numpy(q_np).cuda()
+    o = torch.full((md.query_num, Hq, D), float("nan"), dtype=torch.float16, device="cuda")
+    deft_amd.tree_attention_subtree_fwd(q, pool.get_key_buffer(0), pool.get_value_buffer(0), o, md.block_len, md.block_q,
+                                        md.block_q_cnts, md.block_q_offset, md.block_bitmasks, md.block_kv, md.block_lens)
+    torch.cuda.synchronize()
+    assert max_abs(o.cpu().numpy(), golden(name)["o_flatten_4_4_128"]) < 1e-3
+    assert max_abs(o.cpu().numpy(), oa.sequential_truth(q_np, kv_np, leaf_paths(oracle_tree(name)))) < 5e-4

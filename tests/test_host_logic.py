@@ -170,45 +170,52 @@ def test_forest_metadata_is_the_offset_concatenation_of_its_trees():
 
 
 @pytest.mark.parametrize("name", sorted(SCENARIOS))
-def test_native_tree_mirror_tracks_every_mutation(name):
-    """TreeCache forwards init_prompt / branch / alloc / cut / merge_nodes / reset_node_KV to the native mirror
-    (deft_tree_*); the metadata built from the mirror equals the one built by marshalling the Python tree."""
+def test_native_tree_tracks_every_mutation(name):
+    """Every TreeCache mutation is an operation on the native tree (deft_tree_*); the metadata built from it equals
+    the one built by marshalling the Python-visible tree into the stateless deft_md_build."""
     from deft_amd import tree_cache as tc
 
-    tree = product_tree(name)
     sc = SCENARIOS[name]
+    tree = product_tree(name)
     assert tc._mirror_consistent(tree)
     a = tc.build_metadata_host(tree, sc.max_q_len, sc.block_len, sc.max_block_len, use_mirror=True)
     b = tc.build_metadata_host(tree, sc.max_q_len, sc.block_len, sc.max_block_len, use_mirror=False)
     for k in MD_FIELDS:
         assert np.array_equal(a[k], b[k]), k
     assert a["leaf_to_q"] == b["leaf_to_q"] and a["query_num"] == b["query_num"]
+    # the reference's `refs` sets, recomputed from the native tree: the live leaves below every node
+    for node in tree.nodes.values():
+        below = set()
+        stack = [node]
+        while stack:
+            cur = stack.pop()
+            if cur.id in tree.leaves:
+                below.add(cur.id)
+            stack.extend(cur.children.values())
+        assert {r.id for r in node.refs} == below
 
 
-def test_native_tree_mirror_detects_out_of_band_edits():
-    """Code that edits node.kv_indices directly (not through TreeCache) must not get stale metadata."""
+def test_direct_edits_of_kv_indices_reach_the_metadata():
+    """Scripts written against the reference append to / assign node.kv_indices directly: the list is a view of the
+    native tree, so the edit is in the next metadata; edits of tree.nodes / tree.leaves behind TreeCache's back are
+    refused instead of producing metadata of a different tree."""
     from deft_amd import tree_cache as tc
 
     tree = product_tree("multilevel")
     leaf = sorted(tree.leaves.values(), key=lambda n: n.id)[0]
     slot = tree.token_to_kv_pool.alloc_host(1)
-    leaf.kv_indices.append(int(slot[0]))  # bypasses the mirror
-    assert not tc._mirror_consistent(tree)
+    before = len(leaf.kv_indices)
+    leaf.kv_indices.append(int(slot[0]))
+    assert len(leaf.kv_indices) == before + 1 and leaf.kv_indices[-1] == int(slot[0])
+    assert tc._mirror_consistent(tree)
     md = deft_amd.TreeMetadata.from_tree_cache(tree, device="cpu")
     assert int(slot[0]) in md.block_kv.tolist()
+    saved = list(leaf.kv_indices)
+    leaf.kv_indices = saved[:-1]
+    assert leaf.kv_indices == saved[:-1]
+    tree.leaves.pop(leaf.id)  # behind TreeCache's back
+    assert not tc._mirror_consistent(tree)
+    with pytest.raises(RuntimeError, match="behind TreeCache"):
+        deft_amd.TreeMetadata.from_tree_cache(tree, device="cpu")
 
 
-def test_fixed_asm_registers_stay_clear_of_the_compiler():
-    """The ticket prefetches of the streaming form (v200 / v201) and of the resident-workgroup mode of the tile-parallel
-    form (v255) land in registers named in inline asm; the compiler's own allocation -- single registers and tuples --
-    must stay below them (tools/check_asm.sh rebuilds the device assembly and checks)."""
-    import os
-    import shutil
-    import subprocess
-
-    if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
-        pytest.skip("hipcc not available")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run(["bash", os.path.join(root, "tools", "check_asm.sh")], capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout + r.stderr
-    assert r.stdout.count("reserved from") == 2

@@ -1,4 +1,5 @@
-python -m pytest tests -m gpu -x -q 2>&1 | tail -4
-for wl in northstar_4kx32 medusa64_node tot50_4k fewshot_1kx32 forest_8kx8 gqa_4kx32; do
-  python bench.py --workload $wl --no-cpu-baseline --no-extras --steps 100 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('   ', d['config']['name'], 'us/layer', d['attention_latency_us_per_layer'], 'stage1', (d['roofline'] or {}).get('avg_launch_us'), 'plan us', d['plan_build_us_per_step'])"
+export DEFT_AMD_LIB=$GRAFT_REPO_ROOT/deft_amd/lib/libdeft_amd_exp.so
+for wl in northstar_4kx32 fewshot_1kx32 tot50_4k medusa64_node forest_8kx8; do
+  echo "== $wl"
+  timeout 400 python tools/ab_step.py --workload $wl --steps 40 --rounds 2 DEFT_NP_FAST=0,512,768,100000 2>&1 | grep "\->"
 done
