@@ -10,8 +10,10 @@ caller of the path, reported separately (`metadata_build_ms`), not timed, and so
 device-side repack, once per step for all layers (`plan_build_us_per_step`).
 
 Contract: `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on
-rank 0.  For N > 1 launch with torch.distributed.run (one rank per GPU); every rank
-decodes its own independent tree (weak scaling, no data-path collective).
+rank 0.  For N > 1 launch with torch.distributed.run (one rank per GPU; `--gpus N` outside a
+launcher starts one); every rank decodes its own independent tree (weak scaling, no data-path
+collective), and BASELINE configs[4] -- the 8 N-tree forest sharded 8 per GPU by `shard_trees`
+-- is measured in the same run (`cfg5_sharded_forest`).
 """
 from __future__ import annotations
 
@@ -43,7 +45,8 @@ class Bench:
         if w.trees > 1:  # a batch of independent trees in one pool, one operator call per layer
             self.forest, self.pool = build_forest(w, w.trees, layers, str(device))
         else:
-            tree, self.pool = build_tree(w, layers, str(device))
+            # (room for the advancing-tree loop: every leaf grows by a token per step)
+            tree, self.pool = build_tree(w, layers, str(device), extra_slots=256 + 64 * max(w.width, 1))
             self.forest = deft_amd.Forest([tree])
         self.tree_build_s = time.perf_counter() - t0
         builds = []
@@ -220,12 +223,67 @@ class Bench:
         return sorted(ts)[len(ts) // 2]
 
     def cpu_baseline(self, budget_s: float):
+        """the PyTorch-CPU sequential attention in fp32 AND in fp16, same tree, same run."""
         from oracle.cpu_baseline import time_cpu_baseline  # the checker/baseline, never the product path
 
         paths = self.forest.leaf_paths()
         q = self.q[0].view(self.nq, self.Hq, self.D).float().cpu()
         kv = self.pool.kv_data[0].float().cpu()
-        return time_cpu_baseline(q, kv, paths, self.layers, budget_s=budget_s)
+        f32 = time_cpu_baseline(q, kv, paths, self.layers, budget_s=budget_s * 0.6)
+        f16 = time_cpu_baseline(q, kv, paths, self.layers, budget_s=budget_s * 0.4, dtype=torch.float16)
+        return f32, f16
+
+    def step_percentiles(self, steps: int):
+        """Per-step GPU time, one HIP event pair per step on the launching stream: p10 / p50 / p90 (us)."""
+        stream = torch.cuda.current_stream(self.device)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+        for _ in range(5):
+            self.step()
+        ev[0].record(stream)
+        for i in range(steps):
+            self.step()
+            ev[i + 1].record(stream)
+        torch.cuda.synchronize(self.device)
+        ts = sorted(ev[i].elapsed_time(ev[i + 1]) * 1e3 for i in range(steps))
+        pick = lambda f: round(ts[min(len(ts) - 1, int(f * len(ts)))], 1)
+        return {"p10_us": pick(0.10), "p50_us": pick(0.50), "p90_us": pick(0.90), "steps": steps}
+
+    def end_to_end(self, steps: int):
+        """The decode loop a runner really executes, with the tree ADVANCING: per step every leaf takes a token,
+        `alloc()` (host allocator, nq slot numbers to the GPU, device tree advanced by a kernel), `from_tree_cache`
+        (metadata built on the GPU), the per-step plan, then the 32 attention layers (fused append + stage 1 + merge),
+        eager launches, no host sync inside the loop.  Wall clock over the loop / steps."""
+        if self.w.trees > 1 or self.w.mode == "seq":
+            return None
+        tree = self.forest.trees[0]
+        mode = deft_amd.forward_mode_from_cli(self.w.mode)
+
+        def one():
+            for leaf in tree.leaves.values():
+                leaf.append_token(7)
+            upd = tree.alloc()
+            md = deft_amd.TreeMetadata.from_tree_cache(tree)
+            deft_amd.register_tree_metadata(md)
+            meta = deft_amd.InputMetadata(mode, upd, self.pool)
+            for l in range(self.layers):
+                self.attn[l](self.q[l], self.k_new[l], self.v_new[l], meta)
+
+        for _ in range(3):
+            one()
+        torch.cuda.synchronize(self.device)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()
+        for _ in range(steps):
+            one()
+        e1.record()
+        host_s = time.perf_counter() - t0
+        torch.cuda.synchronize(self.device)
+        wall_s = time.perf_counter() - t0
+        return {"steps": steps, "ms_per_step": round(wall_s / steps * 1e3, 4), "tokens_per_s": round(self.nq / (wall_s / steps), 1),
+                "gpu_ms_per_step": round(e0.elapsed_time(e1) / steps, 4), "host_ms_per_step": round(host_s / steps * 1e3, 4),
+                "what": "alloc + device-side TreeMetadata + per-step plan + 32 x (fused append, stage 1, merge), eager, the "
+                        "tree one token per leaf longer every step; only the nq new slot numbers cross PCIe per step"}
 
 
 def run_timed(b: Bench, steps: int, warmup: int, dist_on: bool):
@@ -250,6 +308,88 @@ def run_timed(b: Bench, steps: int, warmup: int, dist_on: bool):
     return dt
 
 
+def measure_traffic(args, kernel: str):
+    """HBM bytes per launch of the dominant kernel, measured NOW: this same command re-run as a child under
+    `rocprofv3 --pmc FETCH_SIZE --kernel-trace` (own pass, nothing else enabled), read as the guide prescribes
+    (/opt/skills/guides/MI355X_MICROARCH.md, "HBM": FETCH_SIZE counts 64 B per 128 B request for 16-byte-per-lane
+    streams on gfx950 -> x2).  None when rocprofv3 is not there."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    rp = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if rp is None:
+        return None
+    out = tempfile.mkdtemp(prefix="deft_pmc_", dir="/tmp")
+    cmd = [rp, "--pmc", "FETCH_SIZE", "--kernel-trace", "--output-format", "csv", "-d", out, "--", sys.executable,
+           os.path.abspath(__file__), "--workload", args.workload, "--steps", "3", "--warmup", "1", "--child"]
+    if args.branch_len is not None:
+        cmd += ["--branch-len", str(args.branch_len)]
+    if args.layers:
+        cmd += ["--layers", str(args.layers)]
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    try:
+        subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=False)
+        vals = []
+        for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+            with open(f, newline="") as fh:
+                for row in csv.DictReader(fh):
+                    if kernel in row["Kernel_Name"] and row["Counter_Name"] == "FETCH_SIZE":
+                        vals.append(float(row["Counter_Value"]))
+        if not vals:
+            return None
+        return {"bytes": int(sum(vals) / len(vals) * 1024 * 2.0), "launches": len(vals)}
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+
+
+def gpu_state():
+    """Clock / power mode of the GPU the numbers were taken on (state it)."""
+    import shutil
+    import subprocess
+
+    smi = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    try:
+        out = subprocess.run([smi, "--showperflevel", "--showpower", "--showclocks", "--json"], capture_output=True, text=True,
+                             timeout=20).stdout
+        d = json.loads(out)
+        c = d.get("card0", next(iter(d.values())))
+        keep = {k: v for k, v in c.items() if any(t in k.lower() for t in ("performance level", "sclk", "mclk", "power"))}
+        return keep or None
+    except Exception:
+        return None
+
+
+def cfg5_line(device, layers_model: str, n_gpus: int, rank: int, dist_on: bool, steps: int, warmup: int, use_graph: bool):
+    """BASELINE configs[4]: a batch of 8 N independent 8k-prefix trees (Llama-3-8B, 8 branches x 64 tokens) sharded
+    over the N GPUs -- `shard_trees`, 8 trees per GPU at any N (weak scaling), every rank decodes its share as ONE
+    Forest call per layer, no data-path collective (RCCL carries the timing barrier and MAX only)."""
+    from deft_amd.utils.sharding import cfg5_shard
+
+    w = WORKLOADS["forest_8kx8"]
+    mine = cfg5_shard(n_gpus, rank, trees_per_gpu=w.trees)
+    wv = Workload(**{**w.__dict__, "trees": len(mine)})
+    b = Bench(wv, GEOMETRY[w.model][3], device, seed=100 + rank)
+    b.prepare(use_graph=use_graph)
+    dt = run_timed(b, steps, warmup, dist_on)
+    s1 = b.time_stage1(reps=2)
+    algo = b.algorithmic_bytes_per_layer()
+    return {"workload": "BASELINE configs[4]: %d independent trees (8192-token prefix x 8 branches x 64 tokens, Llama-3-8B "
+                        "DeFT-Flatten) over %d GPU(s), %d per GPU" % (n_gpus * w.trees, n_gpus, len(mine)),
+            "trees_this_rank": mine, "queries_per_gpu": b.nq, "kv_tokens_per_gpu": b.n_kv,
+            "tokens_per_s": round(n_gpus * b.nq / (dt / steps), 1), "ms_per_step": round(dt / steps * 1e3, 4),
+            "us_per_layer": round(dt / steps * 1e6 / b.layers, 2), "steps": steps,
+            "stage1_us": round(s1["mean_us"], 2) if s1 else None,
+            "stage1_hbm_frac": round(algo / (s1["mean_us"] * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4) if s1 else None,
+            "collectives_in_data_path": 0, "rccl": "control plane only (barrier + MAX of the step time)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -261,12 +401,28 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary workloads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 FETCH_SIZE child pass")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the advancing-tree end-to-end loop")
+    ap.add_argument("--no-cfg5", action="store_true", help="skip the sharded-forest (BASELINE configs[4]) measurement")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
+    ap.add_argument("--child", action="store_true", help=argparse.SUPPRESS)  # the PMC child: timed steps only
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        # `python bench.py --gpus N` outside a launcher: become the launcher (one rank per GPU, RCCL rendezvous on 127.0.0.1)
+        import socket
+        import subprocess
+
+        sock = socket.socket()
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+        sock.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr",
+               "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.run(cmd).returncode)
     dist_on = world > 1
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: deft_amd has no CPU path")
@@ -278,8 +434,6 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=device)
     n_gpus = world if dist_on else 1
-    if args.gpus != n_gpus and rank == 0:
-        print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}; using {n_gpus}", file=sys.stderr)
 
     w = WORKLOADS[args.workload]
     if args.branch_len is not None:
@@ -291,34 +445,49 @@ def main():
     dt = run_timed(b, args.steps, args.warmup, dist_on)
     ms_per_step = dt / args.steps * 1e3
     tokens_per_s = n_gpus * b.nq / (dt / args.steps)
+    if args.child:  # PMC child: the parent only wants the kernels to have run
+        if w.mode == "flatten":
+            b.time_stage1(reps=1)
+        return
 
     s1 = b.time_stage1(reps=3)
+    pct = b.step_percentiles(min(args.steps, 200))
     plan_us = b.time_plan()
     algo = b.algorithmic_bytes_per_layer()
     roofline = None
     if s1 is not None:
         achieved = algo / (s1["mean_us"] * 1e-6) / 1e9
-        # HBM bytes per launch from the committed PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE, own pass,
-        # x2 gfx950 correction, /opt/skills/guides/MI355X_MICROARCH.md "HBM"); null for workloads that were not profiled
         kind = "stage1_np_kernel"
-        pmc_file = "r1e_pmc_fetch_size_np.json"
-        traffic = None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
-            if w.name == "northstar_4kx32" and w.branch_len == 200:
-                k = [v for n, v in pmc["kernels"].items() if kind in n]
-                traffic = k[0]["hbm_read_bytes_per_launch"] if k else None
-        except Exception:
-            traffic = None
+        traffic, traffic_source = None, None
+        if rank == 0 and not dist_on and not args.no_traffic:
+            t = measure_traffic(args, kind)
+            if t:
+                traffic = t["bytes"]
+                traffic_source = (f"measured in this run: rocprofv3 --pmc FETCH_SIZE --kernel-trace on a child of this command "
+                                  f"({t['launches']} launches), x2 gfx950 correction (MI355X_MICROARCH.md, HBM)")
+        if traffic is None:
+            try:  # fall back to the committed pass of the same command, and say so
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r2a_pmc_fetch_size_northstar_4kx32.json")))
+                if w.name == "northstar_4kx32" and w.branch_len == 200:
+                    k = [v for n, v in pmc["kernels"].items() if kind in n]
+                    traffic = k[0]["hbm_read_bytes_per_launch"] if k else None
+                    traffic_source = "profiles/r2a_pmc_fetch_size_northstar_4kx32.json (committed pass, NOT this run)" if traffic else None
+            except Exception:
+                traffic = None
         roofline = {"bound": "hbm", "kernel": f"deft::{kind}<128> (Flatten stage 1)",
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                    "traffic_source": f"profiles/{pmc_file} (read bytes; separate --pmc pass)" if traffic else None,
+                    "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_source,
                     "algorithmic_bytes_per_launch": algo, "avg_launch_us": round(s1["mean_us"], 2),
                     "median_launch_us": round(s1["median_us"], 2), "launches_timed": s1["launches"],
                     "timing": "HIP events around a hipGraph of one launch per layer pool" if s1.get("launch") == "hipgraph"
                               else "HIP events around eager launches"}
     step_achieved = algo * layers / (dt / args.steps) / 1e9
+    e2e = None
+    if rank == 0 and not dist_on and not args.no_e2e:
+        try:
+            e2e = b.end_to_end(min(50, max(10, args.steps // 4)))
+        except Exception as e:
+            e2e = {"error": f"{type(e).__name__}: {e}"}
 
     extras = {}
     if not args.no_extras and rank == 0 and not dist_on:
@@ -326,7 +495,7 @@ def main():
         if w.kind == "few_shot" and args.branch_len is None:
             variants += [(f"{w.name}_len1", Workload(**{**w.__dict__, "branch_len": 1})),
                          (f"{w.name}_len400", Workload(**{**w.__dict__, "branch_len": 400}))]
-        for name in ("fewshot_1kx32", "medusa64_node", "tot50_4k", "gqa_4kx32", "forest_8kx8_single", "forest_8kx8",
+        for name in ("fewshot_1kx32", "medusa64_node", "tot50_4k", "gqa_4kx32", "forest_8kx8_single",
                      "northstar_4kx32_seq", "fewshot_1kx32_seq"):
             if name != w.name:
                 variants.append((name, WORKLOADS[name]))
@@ -337,15 +506,16 @@ def main():
                 torch.cuda.empty_cache()
                 bv = Bench(wv, GEOMETRY[wv.model][3], device, seed=1)
                 bv.prepare(use_graph=not args.no_graph)
-                n = max(10, args.steps // 4)
-                dtv = run_timed(bv, n, max(2, args.warmup // 4), False)
+                n = max(100, args.steps // 2)  # >= 100 timed steps
+                dtv = run_timed(bv, n, max(5, args.warmup // 2), False)
                 s1v = bv.time_stage1(reps=1)
                 av = bv.algorithmic_bytes_per_layer()
                 extras[name] = {
-                    "model": wv.model, "mode": wv.mode, "trees": wv.trees, "nq": bv.nq, "kv_tokens": bv.n_kv,
+                    "model": wv.model, "mode": wv.mode, "trees": wv.trees, "nq": bv.nq, "kv_tokens": bv.n_kv, "steps": n,
                     "us_per_step": round(dtv / n * 1e6, 1), "us_per_layer": round(dtv / n * 1e6 / bv.layers, 2),
                     "tokens_per_s": round(bv.nq / (dtv / n), 1),
                     "step_GBps": round(av * bv.layers / (dtv / n) / 1e9, 1),
+                    "step_hbm_frac": round(av * bv.layers / (dtv / n) / 1e9 / HBM_PEAK_GBPS, 4),
                     "stage1_us": round(s1v["mean_us"], 2) if s1v else None,
                     "stage1_hbm_frac": round(av / (s1v["mean_us"] * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4) if s1v else None,
                     "metadata_build_ms": round(bv.metadata_build_ms, 3), "launch": bv.launch,
@@ -355,15 +525,30 @@ def main():
             except Exception as e:  # an extra must never take the headline down
                 extras[name] = {"error": f"{type(e).__name__}: {e}"}
 
+    cfg5 = None
+    if not args.no_cfg5:
+        try:
+            del b.graph
+            b.graph = None
+            torch.cuda.empty_cache()
+            cfg5 = cfg5_line(device, w.model, n_gpus, rank, dist_on, max(50, args.steps // 4), max(5, args.warmup // 4),
+                             not args.no_graph)
+        except Exception as e:
+            cfg5 = {"error": f"{type(e).__name__}: {e}"}
+            if dist_on:
+                raise
+
     cpu = None
     if rank == 0 and not dist_on and not args.no_cpu_baseline:
-        c = b.cpu_baseline(args.cpu_budget_s)
+        c, c16 = b.cpu_baseline(args.cpu_budget_s)
         cpu = {"value": round(c["tokens_per_s"], 4), "unit": "tokens/s", "cores": c["cores"], "kind": "port",
                "sample": f"1 of {layers} layer-steps of the same tree ({b.nq} leaves, {b.n_kv} unique KV tokens), "
                          f"PyTorch SDPA {c['dtype']} per leaf incl. page-table gather, {c['cores']} threads (best of 8/16/32/all), "
                          f"best of {c['reps']}, "
                          f"x{layers} layers extrapolated",
-               "ms_per_layer_step": round(c["seconds_per_layer_step"] * 1e3, 2), "host_cores": c["host_cores"]}
+               "ms_per_layer_step": round(c["seconds_per_layer_step"] * 1e3, 2), "host_cores": c["host_cores"],
+               "fp16": {"value": round(c16["tokens_per_s"], 4), "ms_per_layer_step": round(c16["seconds_per_layer_step"] * 1e3, 2),
+                        "cores": c16["cores"], "reps": c16["reps"]}}
 
     if rank == 0:
         Hq, Hkv, D, _ = GEOMETRY[w.model]
@@ -376,14 +561,19 @@ def main():
                                    f"(Hq={Hq}, Hkv={Hkv}, D={D}); {w.trees} independent tree(s) per GPU",
                        "name": w.name, "queries": b.nq, "unique_kv_tokens": b.n_kv, "layers": layers,
                        "blocks": int(b.md.block_q_cnts.shape[0]), "partial_rows": int(b.md.block_q.shape[0]),
-                       "launch": b.launch},
+                       "launch": b.launch,
+                       "timed_region": "attention-only replay of ONE frozen decode step (hipGraph of 32 x (fused append, stage 1, "
+                                       "merge)); metadata / plan of that step are built before it; `end_to_end` below is the "
+                                       "advancing-tree loop with them inside"},
             "attention_latency_us_per_step": round(ms_per_step * 1e3, 1),
             "attention_latency_us_per_layer": round(ms_per_step * 1e3 / layers, 2),
+            "step_time_percentiles": pct,
             "step_algorithmic_GBps": round(step_achieved, 1),
             "step_hbm_frac": round(step_achieved / HBM_PEAK_GBPS, 4),
             "metadata_build_ms": round(b.metadata_build_ms, 3),
             "plan_build_us_per_step": round(plan_us, 1) if plan_us is not None else None,
-            "roofline": roofline, "cpu_baseline": cpu, "other_workloads": extras,
+            "end_to_end": e2e, "gpu_state": gpu_state(),
+            "roofline": roofline, "cpu_baseline": cpu, "cfg5_sharded_forest": cfg5, "other_workloads": extras,
         }
         print(json.dumps(line), flush=True)
     if dist_on:

@@ -147,6 +147,15 @@ EXPORTED = (
 _ERR_NAMES = {-1: "DEFT_EINVAL", -2: "DEFT_EUNSUPPORTED", -3: "DEFT_EHIP", -4: "DEFT_EWORKSPACE"}
 
 
+def tensor_version(t) -> int:
+    """In-place version counter of a tensor, or -1 for inference tensors (created under torch.inference_mode(): they
+    keep none, and `t._version` raises).  Callers that cache per-step plans by (data_ptr, version) must not cache on -1."""
+    try:
+        return t._version
+    except RuntimeError:
+        return -1
+
+
 def check(rc: int, what: str) -> None:
     if rc != 0:
         msg = lib.deft_last_error().decode("utf-8", "replace")

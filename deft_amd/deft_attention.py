@@ -16,12 +16,10 @@ launch-only, so 32 layers can be replayed from one hipGraph.
 """
 from __future__ import annotations
 
-import os
-
 import torch
 from torch import nn
 
-from ._lib import check, lib
+from ._lib import check, lib, tensor_version
 from .forward_mode import ForwardMode, InputMetadata
 from .context_attention import context_attention_fwd
 from .token_attention import seq_append_attention, token_attention_fwd
@@ -30,10 +28,11 @@ from .tree_attention import (flatten_append_attention, node_append_attention, tr
 from .tree_cache import get_global_tree_metadata
 
 
+FUSED_APPEND = True  # False: store_kv_cache (its own launch), then the operator -- the reference's two-call form, for A/B
+
+
 def _fused_append_enabled() -> bool:
-    # DEFT_NO_FUSED_APPEND=1 restores the two-call form (store_kv_cache, then the operator).  Looked up through the
-    # process environment table directly: os.environ.get costs several microseconds per call on this path.
-    return os.getenv("DEFT_NO_FUSED_APPEND") in (None, "", "0")
+    return FUSED_APPEND
 
 
 class _DecodeStep:
@@ -52,7 +51,9 @@ class _DecodeStep:
         if not (q.is_cuda and kv0.is_cuda and q.dtype == torch.float16 and kv0.dtype == torch.float16):
             raise TypeError("decode step needs fp16 CUDA tensors")
         self.mode, self.md, self.pool, self.cache_loc = mode, md, pool, cache_loc
-        self.cache_loc_version = cache_loc._version
+        # (an inference tensor has no version counter, -1: the step is then identified by the objects alone -- a
+        #  TreeMetadata and a cache_loc tensor are made anew every decode step)
+        self.cache_loc_version = tensor_version(cache_loc)
         self.Hq, self.Hkv, self.D, self.nq = Hq, Hkv, D, q.shape[0]
         self.q_shape, self.q_stride, self.k_stride = tuple(q.shape), q.stride(0), k.stride(0)
         self.device = q.device
@@ -92,7 +93,7 @@ class _DecodeStep:
 
     def matches(self, mode, md, pool, cache_loc, q, k) -> bool:
         return (mode is self.mode and md is self.md and pool is self.pool and cache_loc is self.cache_loc
-                and cache_loc._version == self.cache_loc_version and tuple(q.shape) == self.q_shape
+                and tensor_version(cache_loc) == self.cache_loc_version and tuple(q.shape) == self.q_shape
                 and q.stride(0) == self.q_stride and k.stride(0) == self.k_stride and q.dtype == torch.float16)
 
     def run(self, layer_id: int, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> torch.Tensor:

@@ -15,7 +15,7 @@ from __future__ import annotations
 
 import torch
 
-from ._lib import DeftLibraryError, check, lib
+from ._lib import DeftLibraryError, check, lib, tensor_version
 from .tree_attention import _check_qkv, _stream_ptr
 
 __all__ = ["token_attention_fwd", "seq_append_attention"]
@@ -31,13 +31,6 @@ def _i32(t: torch.Tensor, name: str, device) -> torch.Tensor:
     return t.contiguous()
 
 
-def _version(t: torch.Tensor) -> int:
-    try:
-        return t._version
-    except RuntimeError:  # inference tensors keep no version counter: never reuse a plan built from one
-        return -1
-
-
 def _seq_plan(req_to_token, b_req_idx, b_start_loc, b_seq_len, total_num_tokens: int, Hq: int, Hkv: int, q_strides,
               kv_stride_slot: int, stream: int, cache_loc=None, new_stride: int = 0):
     """Per-step plan (page table -> slot lists -> tile records), cached on b_start_loc like the Flatten / Node plans:
@@ -45,10 +38,10 @@ def _seq_plan(req_to_token, b_req_idx, b_start_loc, b_seq_len, total_num_tokens:
     tensors as they are (the reference builds seq_lens as positions + 1, i.e. int64); int32 copies are made only
     when a plan is actually built."""
     nq = b_req_idx.shape[0]
-    versions = tuple((t.data_ptr(), _version(t)) for t in (req_to_token, b_req_idx, b_start_loc, b_seq_len))
+    versions = tuple((t.data_ptr(), tensor_version(t)) for t in (req_to_token, b_req_idx, b_start_loc, b_seq_len))
     key = (lib.deft_plan_variant(), nq, int(total_num_tokens), Hq, Hkv, tuple(q_strides), kv_stride_slot) + versions
     if cache_loc is not None:
-        key += (cache_loc.data_ptr(), _version(cache_loc), cache_loc.shape[0], new_stride)
+        key += (cache_loc.data_ptr(), tensor_version(cache_loc), cache_loc.shape[0], new_stride)
     cacheable = all(v >= 0 for _, v in versions)
     cached = getattr(b_start_loc, "_deft_plan", None)
     if cacheable and cached is not None and cached[0] == key:

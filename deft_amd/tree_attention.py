@@ -20,7 +20,7 @@ from __future__ import annotations
 
 import torch
 
-from ._lib import DeftLibraryError, check, lib
+from ._lib import DeftLibraryError, check, lib, tensor_version
 
 __all__ = ["tree_attention_subtree_fwd", "tree_attention_fwd", "flatten_append_attention", "kv_append",
            "flatten_stage1_partials"]
@@ -59,10 +59,12 @@ def _flatten_plan(md, NB: int, P: int, Hq: int, Hkv: int, q_strides, kv_stride_s
     strides.  Fresh
     tensors (or an in-place edit) simply rebuild it; results never depend on the cache."""
     block_q = md[0]
-    key = (lib.deft_plan_variant(), kv_stride_slot, NB, P, Hq, Hkv, tuple(q_strides)) + tuple((t.data_ptr(), t._version) for t in md)
+    versions = [tensor_version(t) for t in md] + ([tensor_version(cache_loc)] if cache_loc is not None else [])
+    cacheable = min(versions) >= 0  # inference tensors keep no version counter: their plans are never reused
+    key = (lib.deft_plan_variant(), kv_stride_slot, NB, P, Hq, Hkv, tuple(q_strides)) + tuple(t.data_ptr() for t in md) + tuple(versions)
     if cache_loc is not None:  # fused-append plans mark this step's new slots
-        key += (cache_loc.data_ptr(), cache_loc._version, cache_loc.shape[0], new_stride)
-    cached = getattr(block_q, "_deft_plan", None)
+        key += (cache_loc.data_ptr(), cache_loc.shape[0], new_stride)
+    cached = getattr(block_q, "_deft_plan", None) if cacheable else None
     if cached is not None and cached[0] == key:
         return cached[1]
     nbytes = lib.deft_flatten_plan_bytes(NB, P, Hq, Hkv)
@@ -71,10 +73,11 @@ def _flatten_plan(md, NB: int, P: int, Hq: int, Hkv: int, q_strides, kv_stride_s
                                       kv_stride_slot, cache_loc.data_ptr() if cache_loc is not None else None,
                                       cache_loc.shape[0] if cache_loc is not None else 0, new_stride,
                                       plan.data_ptr(), nbytes, stream), "deft_flatten_build_plan")
-    try:
-        block_q._deft_plan = (key, plan)
-    except Exception:  # tensors that refuse attributes just do not cache
-        pass
+    if cacheable:
+        try:
+            block_q._deft_plan = (key, plan)
+        except Exception:  # tensors that refuse attributes just do not cache
+            pass
     return plan
 
 
@@ -82,10 +85,12 @@ def _node_plan(md, NE: int, P: int, total_kv: int, Hq: int, Hkv: int, q_strides,
                cache_loc=None, new_stride: int = 0):
     """Node-mode counterpart of `_flatten_plan`; cached on the KVMapQ_List (node_q) tensor."""
     node_q = md[3]
-    key = (lib.deft_plan_variant(), kv_stride_slot, NE, P, total_kv, Hq, Hkv, tuple(q_strides)) + tuple((t.data_ptr(), t._version) for t in md)
+    versions = [tensor_version(t) for t in md] + ([tensor_version(cache_loc)] if cache_loc is not None else [])
+    cacheable = min(versions) >= 0
+    key = (lib.deft_plan_variant(), kv_stride_slot, NE, P, total_kv, Hq, Hkv, tuple(q_strides)) + tuple(t.data_ptr() for t in md) + tuple(versions)
     if cache_loc is not None:  # fused-append plans mark this step's new slots
-        key += (cache_loc.data_ptr(), cache_loc._version, cache_loc.shape[0], new_stride)
-    cached = getattr(node_q, "_deft_plan", None)
+        key += (cache_loc.data_ptr(), cache_loc.shape[0], new_stride)
+    cached = getattr(node_q, "_deft_plan", None) if cacheable else None
     if cached is not None and cached[0] == key:
         return cached[1]
     nbytes = lib.deft_node_plan_bytes(NE, P, total_kv, Hq, Hkv)
@@ -94,10 +99,11 @@ def _node_plan(md, NE: int, P: int, total_kv: int, Hq: int, Hkv: int, q_strides,
                                    kv_stride_slot, cache_loc.data_ptr() if cache_loc is not None else None,
                                    cache_loc.shape[0] if cache_loc is not None else 0, new_stride,
                                    plan.data_ptr(), nbytes, stream), "deft_node_build_plan")
-    try:
-        node_q._deft_plan = (key, plan)
-    except Exception:
-        pass
+    if cacheable:
+        try:
+            node_q._deft_plan = (key, plan)
+        except Exception:
+            pass
     return plan
 
 

@@ -48,6 +48,7 @@ from .memory_pool import ReqToTokenPool, TokenToKVPool
 
 BLOCK_CONFIG = {"BLOCK_LEN": 128, "MAX_BLOCK_LEN": -1}  # tree_cache.py:587
 TRAVERSAL_CONFIG = {"METHOD": "dfs"}  # tree_cache.py:588 (only DFS exists upstream)
+DEVICE_METADATA = True  # GPU pools: from_tree_cache builds on the GPU (False: host builder + one upload, for A/B)
 
 _ptr = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
 
@@ -307,6 +308,22 @@ class TreeCache:
         return self._handle(node_id, parent)
 
     # ---- :261-283 -------------------------------------------------------------
+    def _staging(self, n: int):
+        """Pinned staging for one step's uploads (slot numbers, page-table coordinates): a pageable source would make
+        the copy wait for the stream to drain -- the host would run in lock-step with the GPU.  Four buffers in rotation,
+        each guarded by the event of its last upload."""
+        ring = self.__dict__.setdefault("_pin_ring", [])
+        k = self.__dict__["_pin_idx"] = (self.__dict__.get("_pin_idx", -1) + 1) % 4
+        while len(ring) <= k:
+            ring.append(None)
+        ent = ring[k]
+        if ent is None or ent[0].numel() < n:
+            cap = max(64, 2 * n)
+            ent = ring[k] = [torch.empty(cap, dtype=torch.int32).pin_memory(), torch.empty((2, cap), dtype=torch.int64).pin_memory(), None]
+        if ent[2] is not None:
+            ent[2].synchronize()
+        return ent
+
     def alloc(self) -> KVCacheUpdater:
         """One pool slot per live leaf, leaves in id order (what the reference's loop over sorted leaves does)."""
         n = len(self.leaves)
@@ -316,14 +333,25 @@ class TreeCache:
         synced = dev is not None and dev.epoch == self._epoch()
         loc64 = loc.astype(np.int64)
         check(lib.deft_tree_alloc_step(self._native, n, _ptr(loc64)), "deft_tree_alloc_step")
-        cache_loc = torch.from_numpy(loc).to(self.token_to_kv_pool.device, non_blocking=True)
+        order = sorted(self.leaves)
+        table = self.req_to_token_pool.req_to_token
+        pool_dev = self.token_to_kv_pool.device
+        if pool_dev.type == "cuda":
+            ent = self._staging(n)
+            ent[0].numpy()[:n] = loc
+            idx_h = ent[1].numpy()
+            idx_h[0, :n] = [self.leaf_to_req[i] for i in order]
+            idx_h[1, :n] = [self.leaves[i].positions[-1] for i in order]
+            cache_loc = ent[0][:n].to(pool_dev, non_blocking=True)
+            idx = ent[1][:, :n].to(table.device, non_blocking=True)
+            ent[2] = torch.cuda.Event()
+            ent[2].record(torch.cuda.current_stream(pool_dev))
+        else:
+            cache_loc = torch.from_numpy(loc)
+            idx = torch.from_numpy(np.asarray([[self.leaf_to_req[i] for i in order],
+                                               [self.leaves[i].positions[-1] for i in order]], dtype=np.int64)).to(table.device)
         if synced and dev.epoch == self._epoch():
             dev.advance(cache_loc)  # the device copy of the tree appends the same slots itself
-        order = sorted(self.leaves)
-        reqs = [self.leaf_to_req[i] for i in order]
-        poss = [self.leaves[i].positions[-1] for i in order]
-        table = self.req_to_token_pool.req_to_token
-        idx = torch.from_numpy(np.asarray([reqs, poss], dtype=np.int64)).to(table.device, non_blocking=True)
         table[idx[0], idx[1]] = cache_loc.to(table.device)  # one batched page-table write
         return KVCacheUpdater(True, self.token_to_kv_pool, cache_loc, None, False)
 
@@ -631,7 +659,7 @@ class TreeMetadata:
         if max_block_len == -1:
             max_block_len = BLOCK_CONFIG["MAX_BLOCK_LEN"]
         dev = torch.device(device) if device is not None else tree.token_to_kv_pool.device
-        if dev.type != "cpu" and device_build is not False:
+        if dev.type != "cpu" and (DEVICE_METADATA if device_build is None else device_build):
             if not tree._consistent():
                 raise RuntimeError("tree.nodes / tree.leaves were edited behind TreeCache's back")
             dt = tree._device_tree

@@ -25,6 +25,11 @@ def shard_trees(kv_tokens_per_tree: Sequence[int], world_size: int) -> List[List
     return [sorted(s) for s in shards]
 
 
+def cfg5_shard(world_size: int, rank: int, trees_per_gpu: int = 8, kv_tokens_per_tree: int = 8704) -> List[int]:
+    """BASELINE configs[4]: the batch has `trees_per_gpu` x world_size equal trees (64 on 8 GPUs); this rank's share."""
+    return shard_trees([kv_tokens_per_tree] * (trees_per_gpu * world_size), world_size)[rank]
+
+
 def max_over_ranks(seconds: float, device: torch.device) -> float:
     """Slowest rank's time (bench contract: barrier, time, MAX over ranks)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:

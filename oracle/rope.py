@@ -10,8 +10,12 @@ Restates RotaryEmbedding as the reference's decode path runs it:
              (2i, 2i+1)], fp32 arithmetic on fp16 inputs, one rounding back to fp16, dims >= rot untouched.
              `forward_native` (:129-155) is the same formula with cos / sin first rounded to the activation dtype; it
              is the module's CPU path, not the decode path.
-Parity note: unpinned against flashinfer itself (absent here); pinned against `forward_native`'s formula with an fp32
-cache, which is what the two have in common.
+Parity: PINNED on outputs of the reference itself -- tools/gen_golden_rope.py runs the reference's `get_rope` +
+`forward_native` in the build container (an empty stand-in module object satisfies the flashinfer import; none of its
+code exists or runs) and tests/golden/rope.npz holds the cache rows and both results: this function is bit-exact
+against forward_native on fp32-upcast inputs (fp32 arithmetic, one rounding: the decode kernel's arithmetic) and
+within a few fp16 ulps of forward_native on the fp16 tensors (tests/test_rope.py).  flashinfer's own binary remains
+unavailable; what it has in common with forward_native -- cache, pairing, signs, fp32 products -- is what is pinned.
 """
 from __future__ import annotations
 

@@ -646,3 +646,94 @@ def test_plan_build_forms_give_identical_plans(shape):
         assert torch.equal(o, outs[0])
         assert torch.equal(hd, plans[0][0])
         assert torch.equal(rec, plans[0][1])
+
+
+def test_decode_step_inside_inference_mode():
+    """The reference decorates its operators with @torch.inference_mode() and runners wrap the whole loop in it: tensors
+    made there keep no version counter (`t._version` raises).  alloc() + from_tree_cache + every layer's forward, Flatten and
+    Node, inside inference mode, against fp64 truth."""
+    name, geom = "multilevel", (8, 2, 128)
+    Hq, Hkv, D = geom
+    otree = oracle_tree(name)
+    with torch.inference_mode():
+        tree = product_tree(name, device="cuda", heads=(Hkv, D), layers=2)
+        q_np, kv_np = seeded_inputs(name, geom, len(tree.leaves))
+        for leaf in list(tree.leaves.values()):
+            leaf.append_token(7)
+        for leaf in list(otree.leaves.values()):
+            leaf.append_token(7)
+        upd = tree.alloc()
+        otree.alloc()
+        md = deft_amd.TreeMetadata.from_tree_cache(tree)
+        deft_amd.register_tree_metadata(md)
+        pool = tree.token_to_kv_pool
+        for l in range(2):
+            pool.kv_data[l].copy_(torch.from_numpy(kv_np))
+        nq = md.query_num
+        q = torch.from_numpy(q_np).cuda().view(nq, Hq * D)
+        k_new = torch.from_numpy(dyadic_rows(nq, Hkv * D, 3)).cuda()
+        v_new = torch.from_numpy(dyadic_rows(nq, Hkv * D, 4)).cuda()
+        outs = {}
+        for mode in ("flatten", "node"):
+            meta = deft_amd.InputMetadata(deft_amd.forward_mode_from_cli(mode), upd, pool)
+            attn = [deft_amd.DeFTAttention(Hq, D, D ** -0.5, Hkv, l) for l in range(2)]
+            outs[mode] = [attn[l](q, k_new, v_new, meta) for l in range(2)]
+        torch.cuda.synchronize()
+    kv_ref = kv_np.copy()
+    loc = upd.cache_loc.cpu().numpy()
+    kv_ref[loc, 0] = k_new.cpu().numpy().reshape(nq, Hkv, D)
+    kv_ref[loc, 1] = v_new.cpu().numpy().reshape(nq, Hkv, D)
+    truth = oa.sequential_truth(q_np, kv_ref, leaf_paths(otree))
+    for mode, os_ in outs.items():
+        for o in os_:
+            assert max_abs(o.view(nq, Hq, D).cpu().numpy(), truth) < TOL_EXACT, mode
+
+
+def dyadic_rows(n, width, seed):
+    from deft_amd.utils.synthetic import dyadic_normal
+
+    return dyadic_normal((n, width), seed)
+
+
+@pytest.mark.parametrize("mode", ["flatten", "node"])
+def test_cfg5_forest_at_full_size_matches_the_single_tree_golden(mode, golden):
+    """BASELINE configs[4], one GPU's share at FULL size: eight 8192-token-prefix trees (8 branches x 64 tokens, Llama-3-8B
+    geometry 32/8/128) in ONE pool, attended by ONE operator call over the concatenated metadata (deft_amd.Forest).  Every
+    tree holds the KV of the single-tree golden scenario, so each tree's eight output rows must equal the reference's
+    output for that scenario (tests/golden/forest_tree_8kx8.npz, generated by the reference itself)."""
+    name, geom, n_trees = "forest_tree_8kx8", (32, 8, 128), 8
+    Hq, Hkv, D = geom
+    sc = SCENARIOS[name]
+    per_tree = 8192 + 8 * 64
+    req = deft_amd.ReqToTokenPool(n_trees * 16, per_tree + 16, device="cuda")
+    pool = deft_amd.TokenToKVPool(n_trees * per_tree + 64, torch.float16, Hkv, D, 1, device="cuda")
+    trees = []
+    for t in range(n_trees):
+        tree = deft_amd.TreeCache(torch.float16, Hkv, D, 1, req, pool, None, True, False)
+        sc.script(tree, lambda n: torch.arange(1, n + 1, dtype=torch.int32))
+        # built one after the other on a first-free allocator: tree t occupies the single tree's slots shifted by t * per_tree
+        assert sorted(s for nd in tree.nodes.values() for s in nd.kv_indices) == list(range(t * per_tree, (t + 1) * per_tree))
+        trees.append(tree)
+    forest = deft_amd.Forest(trees)
+    md = forest.metadata()
+    q_np, kv_np = seeded_inputs(name, geom, 8)
+    kv = torch.from_numpy(kv_np[:per_tree]).cuda()
+    for t in range(n_trees):
+        pool.kv_data[0][t * per_tree: (t + 1) * per_tree].copy_(kv)
+    q = torch.from_numpy(np.concatenate([q_np] * n_trees)).cuda()
+    o = torch.full((md.query_num, Hq, D), float("nan"), dtype=torch.float16, device="cuda")
+    if mode == "flatten":
+        deft_amd.tree_attention_subtree_fwd(q, pool.get_key_buffer(0), pool.get_value_buffer(0), o, md.block_len, md.block_q,
+                                            md.block_q_cnts, md.block_q_offset, md.block_bitmasks, md.block_kv, md.block_lens)
+    else:
+        deft_amd.tree_attention_fwd(q, pool.get_key_buffer(0), pool.get_value_buffer(0), o, md.node_kv, md.node_kv_offset,
+                                    md.node_kv_len, md.node_q, md.node_q_offset, md.node_q_len)
+    torch.cuda.synchronize()
+    out = o.cpu().numpy()
+    ref = golden(name)["o_%s_%d_%d_%d" % ((mode,) + geom)]
+    assert md.query_num == 8 * n_trees and md.total_kv_len == n_trees * per_tree
+    for t in range(n_trees):
+        assert max_abs(out[8 * t: 8 * t + 8], ref) < TOL, t
+    if mode == "flatten":  # the same tree eight times: the same blocks, chunks and fp32 order per tree, so the same bits
+        for t in range(1, n_trees):  # (Node mode packs small entries ACROSS neighbouring trees: same values, other order)
+            assert np.array_equal(out[8 * t: 8 * t + 8], out[:8]), t

@@ -10,7 +10,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from deft_amd.utils.sharding import all_gather_outputs, max_over_ranks, shard_trees
+from deft_amd.utils.sharding import all_gather_outputs, cfg5_shard, max_over_ranks, shard_trees
 
 
 def test_shard_trees_lpt():
@@ -54,6 +54,11 @@ def _worker(rank, world, port, ret):
             digest += int(sum(int(v.sum()) for v in md_numpy(md).values()))
         slow = max_over_ranks(0.001 * (rank + 1), torch.device("cpu"))
         outs = all_gather_outputs(torch.full((len(mine), 4), float(rank)))
+        # bench.py's multi-GPU selection (BASELINE configs[4]): 8 trees per rank, disjoint, every tree once
+        share = cfg5_shard(world, rank)
+        both = [None] * world
+        dist.all_gather_object(both, share)
+        assert len(share) == 8 and sorted(i for s_ in both for i in s_) == list(range(8 * world))
         ret[rank] = (mine, digest, slow, [tuple(o.shape) for o in outs], [float(o.flatten()[0]) if o.numel() else -1 for o in outs])
     finally:
         dist.destroy_process_group()

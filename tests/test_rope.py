@@ -70,3 +70,51 @@ def test_gpu_rope_is_bit_exact_on_fused_qkv_views(Hq, Hkv, D, rot, neox):
     assert np.array_equal(out[:, : Hq * D].reshape(n, Hq, D), q_ref)
     assert np.array_equal(out[:, Hq * D: (Hq + Hkv) * D].reshape(n, Hkv, D), k_ref)
     assert np.array_equal(out[:, (Hq + Hkv) * D:], qkv_np[:, (Hq + Hkv) * D:])  # v untouched
+
+
+# ---- pinned on the reference's own rotary embedding (tools/gen_golden_rope.py: get_rope + forward_native run in the build
+#      container) -----------------------------------------------------------------------------------------------------------
+def _rope_cases():
+    import os
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "rope.npz"))
+    for ci, row in enumerate(g["cases"]):
+        Hq, Hkv, D, rot, neox, maxpos, base = int(row[0]), int(row[1]), int(row[2]), int(row[3]), bool(row[4]), int(row[5]), float(row[6])
+        yield ci, g, (Hq, Hkv, D, rot, neox, maxpos, base)
+
+
+def _rope_inputs(ci, Hq, Hkv, D, n):
+    return dyadic_normal((n, Hq * D), 100 + ci), dyadic_normal((n, Hkv * D), 200 + ci)
+
+
+def test_oracle_rope_is_bit_exact_on_reference_outputs():
+    """oracle.rope.apply_rope on the reference's cache rows == the reference's forward_native in fp32 arithmetic, bit for bit;
+    the reference's fp16-arithmetic result (cos / sin and products rounded to fp16) is within a few fp16 ulps of it."""
+    for ci, g, (Hq, Hkv, D, rot, neox, maxpos, base) in _rope_cases():
+        pos = g[f"pos_{ci}"]
+        n = len(pos)
+        q, k = _rope_inputs(ci, Hq, Hkv, D, n)
+        full = np.zeros((maxpos, rot), dtype=np.float32)
+        full[pos] = g[f"cache_{ci}"]
+        for x, H, name in ((q, Hq, "q"), (k, Hkv, "k")):
+            out = orope.apply_rope(x.reshape(n, H, D), pos, full, rot, neox).reshape(n, H * D)
+            assert np.array_equal(out, g[f"{name}_f32_{ci}"]), (ci, name)
+            assert np.abs(out.astype(np.float32) - g[f"{name}_f16_{ci}"].astype(np.float32)).max() < 1.2e-2
+        # the product module builds the same cache as the reference's _compute_cos_sin_cache, bit for bit
+        mod = deft_amd.RotaryEmbedding(D, rot, maxpos, base, neox)
+        assert np.array_equal(mod.cos_sin_cache.numpy()[pos], g[f"cache_{ci}"])
+        assert np.abs(orope.cos_sin_cache(rot, maxpos, base)[pos] - g[f"cache_{ci}"]).max() < 2e-3  # numpy vs torch cos of fp32 angles
+
+
+@pytest.mark.gpu
+def test_gpu_rope_is_bit_exact_on_reference_outputs():
+    for ci, g, (Hq, Hkv, D, rot, neox, maxpos, base) in _rope_cases():
+        pos = g[f"pos_{ci}"]
+        n = len(pos)
+        q_np, k_np = _rope_inputs(ci, Hq, Hkv, D, n)
+        q, k = torch.from_numpy(q_np).cuda(), torch.from_numpy(k_np).cuda()
+        mod = deft_amd.get_rope(D, rot, maxpos, base, neox).cuda()
+        mod(torch.from_numpy(pos).cuda(), q, k)
+        torch.cuda.synchronize()
+        assert np.array_equal(q.cpu().numpy(), g[f"q_f32_{ci}"]), ci
+        assert np.array_equal(k.cpu().numpy(), g[f"k_f32_{ci}"]), ci

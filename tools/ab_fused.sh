@@ -1,5 +1,3 @@
-export DEFT_AMD_LIB=$GRAFT_REPO_ROOT/deft_amd/lib/libdeft_amd_exp.so
-for wl in northstar_4kx32 fewshot_1kx32 tot50_4k medusa64_node forest_8kx8; do
-  echo "== $wl"
-  timeout 400 python tools/ab_step.py --workload $wl --steps 40 --rounds 2 DEFT_NP_FAST=0,512,768,100000 2>&1 | grep "\->"
-done
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats -d /tmp/prof_e2e -- python $GRAFT_REPO_ROOT/bench.py --no-extras --no-cpu-baseline --no-cfg5 --no-traffic --steps 5 --warmup 1 > /dev/null 2>&1
+python $GRAFT_REPO_ROOT/tools/prof_summary.py /tmp/prof_e2e 2>&1 | head -18 | cut -c1-150

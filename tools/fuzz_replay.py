@@ -67,7 +67,9 @@ while time.time() < t_end and runs < max_runs:
             ref = torch.einsum("hs,hsd->hd", torch.softmax(s, dim=-1), vv)
             err = (od[i] - ref).abs().max().item()
             worst = max(worst, err)
-            assert err < 5e-4 + 2.0 ** -11 * ref.abs().max().item(), (err, mode, task, Hq, Hkv, prompt, i, len(slots))
+            # per ELEMENT: 5e-4 + half an fp16 ulp of that element (tests/test_prefill.py::_close_to_truth), well inside north_star's 1e-3
+            bad = ((od[i] - ref).abs() > 5e-4 + 2.0 ** -11 * ref.abs()).sum().item()
+            assert bad == 0, (bad, err, mode, task, Hq, Hkv, prompt, i, len(slots))
         steps += 1
         return out
     attn0.forward = checked

@@ -27,8 +27,12 @@ ap.add_argument("--tree-size", type=int, default=64)
 ap.add_argument("--sd-steps", type=int, default=100)
 ap.add_argument("--pipelined", action="store_true", help="no per-step sync: host runs ahead of the GPU")
 ap.add_argument("--no-warmup", action="store_true", help="do not run the first mode once untimed before the table")
+ap.add_argument("--host-metadata", action="store_true", help="TreeMetadata by the host builder + one upload per step (round-1 path)")
 ap.add_argument("--out", default=None)
 a = ap.parse_args()
+if a.host_metadata:
+    import deft_amd.tree_cache as _tc
+    _tc.DEVICE_METADATA = False
 Hq, Hkv, D, L = GEOMETRY[a.model]
 L = a.layers or L
 
