@@ -881,7 +881,7 @@ int deft_flatten_decode_append_f16(const void* q, int64_t q_stride_tok, int64_t 
 }
 
 static int launch_node_plan(const Stage1Params& p, int NE, int64_t rows_cap, const PlanView& pv, const AppendArgs& ap,
-                            hipStream_t stream) {
+                            hipStream_t stream, int keep_err = 0) {
     const UnitList ul = unit_list(pv);
     // a run table in LDS: 8 words per run and every possible run (the kernel then writes units and
     // record order with all its waves), or as many runs as fit (it falls back to one lane if more turn up)
@@ -899,7 +899,7 @@ static int launch_node_plan(const Stage1Params& p, int NE, int64_t rows_cap, con
         while (sizeof(int) * (3 * (size_t)run_cap + 8) > UNIT_LDS && run_cap > 1) run_cap /= 2;
     hipLaunchKernelGGL(node_units_kernel, dim3(1), dim3(1024), sizeof(int) * ((par ? 8 : 3) * (size_t)run_cap + 8), stream,
                        p.node_kv_len, p.node_q_len, NE, p.G, (int)pv.cap, rows_cap, ul, pv.hdr, pv.row_q, p.Hkv,
-                       2 * num_cus(), np_chunk_knob(), (int)run_cap, par);
+                       2 * num_cus(), np_chunk_knob(), (int)run_cap, par, keep_err);
     rc = check_launch("node units launch");
     if (rc) return rc;
     hipLaunchKernelGGL(node_records_kernel, dim3((unsigned)(pv.cap + 1)), dim3(128), 0, stream, p.node_kv, p.node_kv_offset,
@@ -1149,15 +1149,22 @@ namespace deft {
 
 __global__ __launch_bounds__(256) void seq_to_node_kernel(const int32_t* req_to_token, int64_t req_stride,
                                                            const int32_t* b_req_idx, const int32_t* b_start_loc,
-                                                           const int32_t* b_seq_len, int nq, int64_t* node_kv,
+                                                           const int32_t* b_seq_len, int nq, int64_t total, int64_t* node_kv,
                                                            int64_t* node_kv_offset, int64_t* node_kv_len, int64_t* node_q,
-                                                           int64_t* node_q_offset, int64_t* node_q_len) {
+                                                           int64_t* node_q_offset, int64_t* node_q_len, int32_t* hdr) {
     const int i = blockIdx.x;
     if (i >= nq) return;
-    const int64_t start = b_start_loc[i];
-    const int len = b_seq_len[i];
+    // start / len come from device memory, the buffer was sized from the host's total_num_tokens: a request that does
+    // not fit is cut short (and flagged in the plan header) instead of writing past the end
+    int64_t start = b_start_loc[i];
+    int64_t len = b_seq_len[i];
+    if (start < 0 || len < 0 || start + len > total) {
+        if (blockIdx.y == 0 && threadIdx.x == 0) atomicOr(hdr + HDR_ERR, 2);
+        start = start < 0 ? 0 : (start > total ? total : start);
+        len = len < 0 ? 0 : (start + len > total ? total - start : len);
+    }
     const int32_t* row = req_to_token + (int64_t)b_req_idx[i] * req_stride;
-    for (int j = blockIdx.y * blockDim.x + threadIdx.x; j < len; j += gridDim.y * blockDim.x) node_kv[start + j] = row[j];
+    for (int64_t j = blockIdx.y * blockDim.x + threadIdx.x; j < len; j += gridDim.y * blockDim.x) node_kv[start + j] = row[j];
     if (blockIdx.y == 0 && threadIdx.x == 0) {
         node_kv_offset[i] = start;
         node_kv_len[i] = len;
@@ -1227,10 +1234,14 @@ int deft_seq_build_plan(const int32_t* req_to_token, int64_t req_stride, const i
     }
     if (nq == 0) return DEFT_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (hipMemsetAsync(static_cast<int32_t*>(sp.node_plan) + HDR_ERR, 0, sizeof(int32_t), st) != hipSuccess) {
+        set_error("hipMemsetAsync(plan header) failed");
+        return DEFT_EHIP;
+    }
     const unsigned gy = (unsigned)((total_tokens / nq + 255) / 256 < 1 ? 1 : ((total_tokens / nq + 255) / 256 > 64 ? 64 : (total_tokens / nq + 255) / 256));
     hipLaunchKernelGGL(seq_to_node_kernel, dim3((unsigned)nq, gy), dim3(256), 0, st, req_to_token, req_stride, b_req_idx,
-                       b_start_loc, b_seq_len, nq, sp.node_kv, sp.node_kv_offset, sp.node_kv_len, sp.node_q,
-                       sp.node_q_offset, sp.node_q_len);
+                       b_start_loc, b_seq_len, nq, total_tokens, sp.node_kv, sp.node_kv_offset, sp.node_kv_len, sp.node_q,
+                       sp.node_q_offset, sp.node_q_len, static_cast<int32_t*>(sp.node_plan));
     int rc = check_launch("seq_to_node launch");
     if (rc) return rc;
     const int64_t tiles = node_max_tiles(nq, total_tokens);
@@ -1254,7 +1265,7 @@ int deft_seq_build_plan(const int32_t* req_to_token, int64_t req_stride, const i
         ap.n_new = n_new;
         ap.new_st = new_stride_tok;
     }
-    return launch_node_plan(p, nq, tiles, pv, ap, st);
+    return launch_node_plan(p, nq, tiles, pv, ap, st, 1);
 }
 
 static int seq_decode_impl(const void* q, int64_t q_stride_tok, int64_t q_stride_head, const void* k_base,

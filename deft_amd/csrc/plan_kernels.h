@@ -12,9 +12,49 @@ namespace deft {
 // Plan kernels (once per decode step): metadata -> unit list -> records
 // ---------------------------------------------------------------------------
 // Byte offset of a pool slot's row, or (bit 63 | offset into k_new / v_new) when the slot is one of
-// this step's new tokens and the caller uses the fused append.
+// this step's new tokens and the caller uses the fused append.  A record workgroup first hashes the step's new slots
+// into LDS (open addressing, slot -> new row), so the test is O(1) per slot instead of a scan over all new tokens
+// (a batched forest has hundreds); more new tokens than the table holds fall back to the scan.
+constexpr int NEWMAP_SIZE = 2048;  // entries (power of two); holds up to NEWMAP_SIZE / 2 new tokens
+struct NewMap {
+    int* keys;  // [NEWMAP_SIZE] slot or -1
+    int* vals;  // [NEWMAP_SIZE] new-row index
+    bool hashed;
+};
+__device__ inline NewMap newmap_build(int* keys, int* vals, const int32_t* cache_loc, int n_new) {
+    NewMap m{keys, vals, n_new > 0 && n_new <= NEWMAP_SIZE / 2};
+    if (m.hashed) {
+        for (int i = threadIdx.x; i < NEWMAP_SIZE; i += blockDim.x) keys[i] = -1;
+        __syncthreads();
+        for (int i = threadIdx.x; i < n_new; i += blockDim.x) {
+            const int s = cache_loc[i];
+            unsigned h = ((unsigned)s * 2654435761u) & (NEWMAP_SIZE - 1);
+            while (true) {
+                const int prev = atomicCAS(&keys[h], -1, s);
+                if (prev == -1 || prev == s) {
+                    if (prev == -1) vals[h] = i;
+                    else atomicMin(&vals[h], i);  // (a slot listed twice: the first row, as the scan would find)
+                    break;
+                }
+                h = (h + 1) & (NEWMAP_SIZE - 1);
+            }
+        }
+        __syncthreads();
+    }
+    return m;
+}
 __device__ __forceinline__ int64_t plan_rowoff(int64_t slot, int64_t kv_stride_slot, const int32_t* cache_loc, int n_new,
-                                               int64_t new_row_bytes) {
+                                               int64_t new_row_bytes, const NewMap& m) {
+    if (m.hashed) {
+        unsigned h = ((unsigned)(int)slot * 2654435761u) & (NEWMAP_SIZE - 1);
+        while (true) {
+            const int k = m.keys[h];
+            if (k == -1) break;
+            if (k == (int)slot) return ((int64_t)1 << 63) | ((int64_t)m.vals[h] * new_row_bytes);
+            h = (h + 1) & (NEWMAP_SIZE - 1);
+        }
+        return slot * kv_stride_slot * 2;
+    }
     for (int i = 0; i < n_new; ++i)
         if ((int64_t)cache_loc[i] == slot) return ((int64_t)1 << 63) | ((int64_t)i * new_row_bytes);
     return slot * kv_stride_slot * 2;  // fp16 bytes
@@ -508,6 +548,7 @@ __global__ __launch_bounds__(128) void flatten_records_kernel(const int64_t* blo
                                                               const int32_t* hdr, char* plan, int32_t* row_q,
                                                               const int32_t* cache_loc, int n_new, int64_t new_row_bytes) {
     constexpr int np = 1;
+    __shared__ int sKeys[NEWMAP_SIZE], sVals[NEWMAP_SIZE];
     const int r = blockIdx.x;
     const int k = threadIdx.x;
     const int R = hdr[0];
@@ -531,6 +572,7 @@ __global__ __launch_bounds__(128) void flatten_records_kernel(const int64_t* blo
         }
         return;
     }
+    const NewMap nm = newmap_build(sKeys, sVals, cache_loc, n_new);
     const int u = np ? ul.perm[r] : r;  // unit packed into this record
     const int t = ul.src[u];
     const int ps = ul.pass[u];
@@ -538,7 +580,7 @@ __global__ __launch_bounds__(128) void flatten_records_kernel(const int64_t* blo
     const int len = (int)block_lens[t];
     const int cnt = (int)block_q_cnts[t];
     const bool live = k < len;
-    ro[k] = plan_rowoff(block_kv[(int64_t)t * TILE + (live ? k : 0)], kv_stride_slot, cache_loc, n_new, new_row_bytes);
+    ro[k] = plan_rowoff(block_kv[(int64_t)t * TILE + (live ? k : 0)], kv_stride_slot, cache_loc, n_new, new_row_bytes, nm);
     const uint32_t qmask = live ? (uint32_t)block_bitmasks[(int64_t)t * TILE + k] : 0u;
     if (ul.aux[u] > 0) {
         // ---- member of a union group: virtual row v = (union query v / G, head v % G); a query that is not in
@@ -622,7 +664,7 @@ __global__ __launch_bounds__(128) void flatten_records_kernel(const int64_t* blo
 __global__ __launch_bounds__(1024) void node_units_kernel(const int64_t* node_kv_len, const int64_t* node_q_len, int NE, int G,
                                                           int cap, int64_t rows_cap, UnitList ul, int32_t* hdr,
                                                           int32_t* row_q, int Hkv, int slots, int chunk_c, int run_cap,
-                                                          int par) {
+                                                          int par, int keep_err) {
     constexpr int np = 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int* sRun = reinterpret_cast<int*>(smem);
@@ -714,7 +756,7 @@ __global__ __launch_bounds__(1024) void node_units_kernel(const int64_t* node_kv
             if (lane == 0) {
                 hdr[0] = r;
                 hdr[1] = 0;
-                hdr[HDR_ERR] = 0;
+                if (!keep_err) hdr[HDR_ERR] = 0;  // (the sequential plan's slot-list kernel has already run and may have flagged)
                 hdr[HDR_QLISTS] = 0;
                 if (par && rt.n <= rt.cap) {
                     sMeta[0] = r;
@@ -753,6 +795,7 @@ __global__ __launch_bounds__(128) void node_records_kernel(const int64_t* node_k
                                                            UnitList ul, const int32_t* hdr, char* plan, int32_t* row_q,
                                                            const int32_t* cache_loc, int n_new, int64_t new_row_bytes) {
     constexpr int np = 1;
+    __shared__ int sKeys[NEWMAP_SIZE], sVals[NEWMAP_SIZE];
     const int r = blockIdx.x;
     const int k = threadIdx.x;
     const int R = hdr[0];
@@ -776,6 +819,7 @@ __global__ __launch_bounds__(128) void node_records_kernel(const int64_t* node_k
         }
         return;
     }
+    const NewMap nm = newmap_build(sKeys, sVals, cache_loc, n_new);
     const int u = np ? ul.perm[r] : r;  // unit packed into this record
     if (k == 0) {
         desc[4] = np ? ul.ch_n[r] : 0;
@@ -811,7 +855,7 @@ __global__ __launch_bounds__(128) void node_records_kernel(const int64_t* node_k
         }
         const bool live = kj >= 0;
         const int64_t slot = live ? node_kv[node_kv_offset[kj] + kpos] : node_kv[node_kv_offset[first_slot_e]];
-        ro[k] = plan_rowoff(slot, kv_stride_slot, cache_loc, n_new, new_row_bytes);
+        ro[k] = plan_rowoff(slot, kv_stride_slot, cache_loc, n_new, new_row_bytes, nm);
         mk[k] = live ? ((knv >= 32 ? 0xffffffffu : ((1u << knv) - 1u)) << kvb) : 0u;
         if (k < MQ) {
             int qs, orow = 0;
@@ -842,7 +886,7 @@ __global__ __launch_bounds__(128) void node_records_kernel(const int64_t* node_k
     const int ql = (int)node_q_len[e];
     const int nv = min(MQ, ql * G - MQ * ps);
     const bool live = k < len;
-    ro[k] = plan_rowoff(node_kv[kv0 + (live ? k : 0)], kv_stride_slot, cache_loc, n_new, new_row_bytes);
+    ro[k] = plan_rowoff(node_kv[kv0 + (live ? k : 0)], kv_stride_slot, cache_loc, n_new, new_row_bytes, nm);
     mk[k] = live ? (nv >= 32 ? 0xffffffffu : ((1u << nv) - 1u)) : 0u;
     if (k < MQ) {
         int qs = 0, orow = 0;
