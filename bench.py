@@ -248,27 +248,37 @@ class Bench:
         pick = lambda f: round(ts[min(len(ts) - 1, int(f * len(ts)))], 1)
         return {"p10_us": pick(0.10), "p50_us": pick(0.50), "p90_us": pick(0.90), "steps": steps}
 
-    def end_to_end(self, steps: int):
-        """The decode loop a runner really executes, with the tree ADVANCING: per step every leaf takes a token,
-        `alloc()` (host allocator, nq slot numbers to the GPU, device tree advanced by a kernel), `from_tree_cache`
-        (metadata built on the GPU), the per-step plan, then the 32 attention layers (fused append + stage 1 + merge),
-        eager launches, no host sync inside the loop.  Wall clock over the loop / steps."""
-        if self.w.trees > 1 or self.w.mode == "seq":
+    def end_to_end(self, steps: int, graphed: bool):
+        """The decode loop a runner really executes, with the tree ADVANCING: per step every leaf takes a token, the host
+        allocator hands out nq slots (the only thing that crosses PCIe), the device copy of the tree is advanced by a
+        kernel, TreeMetadata and the per-step plan are built on the GPU, then the 32 attention layers (fused append +
+        stage 1 + merge).  `graphed`: deft_amd.FlattenDecodeSession -- that whole device-side sequence captured ONCE per
+        structural epoch of the tree and replayed per step; otherwise the reference-shaped calls (tree.alloc(),
+        TreeMetadata.from_tree_cache, DeFTAttention.forward per layer), eager launches.  No host sync inside the loop."""
+        if self.w.trees > 1 or self.w.mode != "flatten":
             return None
         tree = self.forest.trees[0]
         mode = deft_amd.forward_mode_from_cli(self.w.mode)
+        if graphed:
+            sess = deft_amd.FlattenDecodeSession(tree, self.Hq, self.Hkv, self.D, self.layers,
+                                                 lambda l: (self.q[l], self.k_new[l], self.v_new[l]))
 
-        def one():
-            for leaf in tree.leaves.values():
-                leaf.append_token(7)
-            upd = tree.alloc()
-            md = deft_amd.TreeMetadata.from_tree_cache(tree)
-            deft_amd.register_tree_metadata(md)
-            meta = deft_amd.InputMetadata(mode, upd, self.pool)
-            for l in range(self.layers):
-                self.attn[l](self.q[l], self.k_new[l], self.v_new[l], meta)
+            def one():
+                for leaf in tree.leaves.values():
+                    leaf.append_token(7)
+                sess.step()
+        else:
+            def one():
+                for leaf in tree.leaves.values():
+                    leaf.append_token(7)
+                upd = tree.alloc()
+                md = deft_amd.TreeMetadata.from_tree_cache(tree)
+                deft_amd.register_tree_metadata(md)
+                meta = deft_amd.InputMetadata(mode, upd, self.pool)
+                for l in range(self.layers):
+                    self.attn[l](self.q[l], self.k_new[l], self.v_new[l], meta)
 
-        for _ in range(3):
+        for _ in range(4):
             one()
         torch.cuda.synchronize(self.device)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -282,8 +292,8 @@ class Bench:
         wall_s = time.perf_counter() - t0
         return {"steps": steps, "ms_per_step": round(wall_s / steps * 1e3, 4), "tokens_per_s": round(self.nq / (wall_s / steps), 1),
                 "gpu_ms_per_step": round(e0.elapsed_time(e1) / steps, 4), "host_ms_per_step": round(host_s / steps * 1e3, 4),
-                "what": "alloc + device-side TreeMetadata + per-step plan + 32 x (fused append, stage 1, merge), eager, the "
-                        "tree one token per leaf longer every step; only the nq new slot numbers cross PCIe per step"}
+                "launch": "one hipGraph per structural epoch of the tree (deft_amd.FlattenDecodeSession)" if graphed
+                          else "eager (tree.alloc, TreeMetadata.from_tree_cache, DeFTAttention.forward per layer)"}
 
 
 def run_timed(b: Bench, steps: int, warmup: int, dist_on: bool):
@@ -483,11 +493,19 @@ def main():
                               else "HIP events around eager launches"}
     step_achieved = algo * layers / (dt / args.steps) / 1e9
     e2e = None
-    if rank == 0 and not dist_on and not args.no_e2e:
-        try:
-            e2e = b.end_to_end(min(50, max(10, args.steps // 4)))
-        except Exception as e:
-            e2e = {"error": f"{type(e).__name__}: {e}"}
+    if rank == 0 and not dist_on and not args.no_e2e and w.trees == 1 and w.mode == "flatten":
+        e2e = {"what": "the decode loop with the tree ADVANCING (one token per leaf and step, from the benchmarked tree on): "
+                       "host slot allocation + nq slot numbers over PCIe + device tree advance + TreeMetadata and plan built on the "
+                       "GPU + 32 x (fused append, stage 1, merge); wall clock over the loop, no host sync inside"}
+        for key, graphed in (("graphed", True), ("eager", False)):
+            try:  # each on a fresh tree (the loop grows it)
+                torch.cuda.empty_cache()
+                be = Bench(w, layers, device, seed=7)
+                be.prepare(use_graph=False)
+                e2e[key] = be.end_to_end(min(50, max(10, args.steps // 4)), graphed)
+                del be
+            except Exception as e:
+                e2e[key] = {"error": f"{type(e).__name__}: {e}"}
 
     extras = {}
     if not args.no_extras and rank == 0 and not dist_on:

@@ -510,7 +510,8 @@ static int np_chunk_knob() { return knob("DEFT_NP_CHUNK", 0); }  // tiles per ch
 static int np_union_knob() { return knob("DEFT_NP_UNION", 0); }  // leaf tiles per union group (1 = off, 0 = rule)
 
 // Flatten plan: unit list (one workgroup) then one record per unit.
-static int launch_plan(const Stage1Params& p, int NB, const PlanView& pv, const AppendArgs& ap, hipStream_t stream) {
+static int launch_plan(const Stage1Params& p, int NB, const PlanView& pv, const AppendArgs& ap, hipStream_t stream,
+                       const int32_t* dims = nullptr) {
     if (NB <= 0) return DEFT_OK;
     // The unit kernel is one workgroup and may use the CU's whole LDS: 9216 blocks = 1.18 M KV tokens per call,
     // more than a 7B model's KV cache fits in 288 GB.
@@ -539,7 +540,7 @@ static int launch_plan(const Stage1Params& p, int NB, const PlanView& pv, const 
     const UnitList ul = unit_list(pv);
     hipLaunchKernelGGL(flatten_units_kernel, dim3(1), dim3(1024), lds, stream, p.block_q, p.block_q_cnts, p.block_q_offset, NB,
                        p.G, (int)pv.cap, ul, pv.hdr, p.Hkv, 2 * num_cus(), np_chunk_knob(), np_union_knob(), (int)run_cap, qtab,
-                       par);
+                       par, dims, pv.row_q, (int)pv.rows);
     rc = check_launch("flatten units launch");
     if (rc) return rc;
     hipLaunchKernelGGL(flatten_records_kernel, dim3((unsigned)(pv.cap + 1)), dim3(128), 0, stream, p.block_q, p.block_q_cnts,
@@ -803,6 +804,45 @@ int deft_flatten_build_plan(const int64_t* block_q, const int64_t* block_q_cnts,
     return launch_plan(p, NB, pv, ap, static_cast<hipStream_t>(stream));
 }
 
+// The same for metadata that was built ON THE DEVICE (deft_tree_dev_build_md): NB and P are the CAPACITIES of the arrays
+// (they size the plan, the grids and the partial-row stride) and the block count of this step is read from `dims`
+// (dims[5], the scratch header of deft_tree_dev_build_md) by the kernel -- so the launch has the same arguments for every
+// decode step of a structural epoch of the tree and can sit in a captured hipGraph.
+int deft_flatten_build_plan_dims(const int64_t* block_q, const int64_t* block_q_cnts, const int64_t* block_q_offset,
+                                 const int64_t* block_bitmasks, const int64_t* block_kv, const int64_t* block_lens, int NB, int P,
+                                 const int32_t* dims, int Hq, int Hkv, int64_t q_stride_tok, int64_t q_stride_head,
+                                 int64_t kv_stride_slot, const int32_t* cache_loc, int n_new, int64_t new_stride_tok, void* plan,
+                                 size_t plan_bytes, void* stream) {
+    if (NB < 0 || P < 0 || !plan || !dims || n_new < 0 || Hq <= 0 || Hkv <= 0 || Hq % Hkv ||
+        (NB > 0 && (!block_q || !block_q_cnts || !block_q_offset || !block_bitmasks || !block_kv || !block_lens))) {
+        set_error("bad plan arguments (NB=%d P=%d Hq=%d Hkv=%d)", NB, P, Hq, Hkv);
+        return DEFT_EINVAL;
+    }
+    const PlanView pv = plan_view(plan, flatten_unit_cap(NB, Hq / Hkv), P);
+    if (plan_bytes < pv.bytes) {
+        set_error("plan buffer too small: %zu < %zu", plan_bytes, pv.bytes);
+        return DEFT_EWORKSPACE;
+    }
+    Stage1Params p{};
+    p.block_q = block_q;
+    p.block_q_cnts = block_q_cnts;
+    p.block_q_offset = block_q_offset;
+    p.block_bitmasks = block_bitmasks;
+    p.block_kv = block_kv;
+    p.block_lens = block_lens;
+    p.rows = P;
+    p.G = Hq / Hkv;
+    p.Hkv = Hkv;
+    p.q_st = q_stride_tok;
+    p.q_sh = q_stride_head;
+    p.kv_ss = kv_stride_slot;
+    AppendArgs ap;
+    ap.cache_loc = cache_loc;
+    ap.n_new = cache_loc ? n_new : 0;
+    ap.new_st = new_stride_tok;
+    return launch_plan(p, NB, pv, ap, static_cast<hipStream_t>(stream), dims);
+}
+
 int deft_flatten_stage1_f16(const void* q, int64_t q_stride_tok, int64_t q_stride_head, const void* k_base,
                             const void* v_base, int64_t kv_stride_slot, int64_t kv_stride_head, const int64_t* block_q,
                             const int64_t* block_q_cnts, const int64_t* block_q_offset, const int64_t* block_bitmasks,
@@ -881,7 +921,7 @@ int deft_flatten_decode_append_f16(const void* q, int64_t q_stride_tok, int64_t 
 }
 
 static int launch_node_plan(const Stage1Params& p, int NE, int64_t rows_cap, const PlanView& pv, const AppendArgs& ap,
-                            hipStream_t stream, int keep_err = 0) {
+                            hipStream_t stream, int keep_err = 0, const int32_t* dims = nullptr) {
     const UnitList ul = unit_list(pv);
     // a run table in LDS: 8 words per run and every possible run (the kernel then writes units and
     // record order with all its waves), or as many runs as fit (it falls back to one lane if more turn up)
@@ -899,7 +939,7 @@ static int launch_node_plan(const Stage1Params& p, int NE, int64_t rows_cap, con
         while (sizeof(int) * (3 * (size_t)run_cap + 8) > UNIT_LDS && run_cap > 1) run_cap /= 2;
     hipLaunchKernelGGL(node_units_kernel, dim3(1), dim3(1024), sizeof(int) * ((par ? 8 : 3) * (size_t)run_cap + 8), stream,
                        p.node_kv_len, p.node_q_len, NE, p.G, (int)pv.cap, rows_cap, ul, pv.hdr, pv.row_q, p.Hkv,
-                       2 * num_cus(), np_chunk_knob(), (int)run_cap, par, keep_err);
+                       2 * num_cus(), np_chunk_knob(), (int)run_cap, par, keep_err, dims);
     rc = check_launch("node units launch");
     if (rc) return rc;
     hipLaunchKernelGGL(node_records_kernel, dim3((unsigned)(pv.cap + 1)), dim3(128), 0, stream, p.node_kv, p.node_kv_offset,

@@ -309,19 +309,25 @@ __device__ inline int union_group(int t, int NB, int ulen, int ucap, const int* 
 // to union_len tiles and UNION_CAP queries, into ONE run over the union of their queries (per-slot masks keep a
 // query away from keys that are not on its path), so that one workgroup folds them and writes one partial per query.
 __global__ __launch_bounds__(1024) void flatten_units_kernel(const int64_t* block_q, const int64_t* block_q_cnts,
-                                                            const int64_t* block_q_offset, int NB, int G, int cap,
+                                                            const int64_t* block_q_offset, int NBc, int G, int cap,
                                                             UnitList ul, int32_t* hdr, int Hkv, int slots, int chunk_c,
-                                                            int union_len, int run_cap, int qtab, int par) {
+                                                            int union_len, int run_cap, int qtab, int par,
+                                                            const int32_t* dims, int32_t* row_q, int rows) {
     constexpr int np = 1;  // records in the tile-parallel order (leaders first); the only stage-1 form
+    // NBc = block CAPACITY (sizes the tables); with `dims` (device-side metadata, tree_plan.h) the block count of this
+    // step is read from the device, so that one captured launch serves every step of a structural epoch
+    const int NB = dims ? min(dims[5], NBc) : NBc;
+    if (dims)  // rows beyond this step's partial rows must read "dead" (the row lists are built over the capacity)
+        for (int i = threadIdx.x; i < rows; i += blockDim.x) row_q[i] = -1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    int* sOpen = reinterpret_cast<int*>(smem);  // [NB]
-    int* sPass = sOpen + NB;                    // [NB]
-    int* sCnt = sPass + NB;                     // [NB] block_q_cnts
-    int* sOff = sCnt + NB;                      // [NB] block_q_offset
-    // [NB][UNION_CAP] query lists of the blocks small enough to join a union group (qtab: the table fits in LDS):
+    int* sOpen = reinterpret_cast<int*>(smem);  // [NBc]
+    int* sPass = sOpen + NBc;                   // [NBc]
+    int* sCnt = sPass + NBc;                    // [NBc] block_q_cnts
+    int* sOff = sCnt + NBc;                     // [NBc] block_q_offset
+    // [NBc][UNION_CAP] query lists of the blocks small enough to join a union group (qtab: the table fits in LDS):
     // the one-thread phase below otherwise waits for a global load per leaf tile
-    int* sQ = sOff + NB;
-    int* sRun = sQ + (qtab ? UNION_CAP * NB : 0);
+    int* sQ = sOff + NBc;
+    int* sRun = sQ + (qtab ? UNION_CAP * NBc : 0);
     RunTable rt{sRun, sRun + run_cap, sRun + 2 * run_cap, 0, run_cap};
     for (int t = threadIdx.x; t < NB; t += blockDim.x) {
         const int cnt = (int)block_q_cnts[t];
@@ -661,11 +667,12 @@ __global__ __launch_bounds__(128) void flatten_records_kernel(const int64_t* blo
 // has 64 one-token nodes: 2 tiles instead of 64).  A packed unit has aux = -(entries in it).
 // One workgroup.  Wave 0 walks the entries and decides the runs (packs are sequential by nature), all waves then write the units and the record order from the LDS run table -- as in
 // flatten_units_kernel; `par` = 0 (tables beyond the LDS) or an overflowing table: lane 0 emits as it walks.
-__global__ __launch_bounds__(1024) void node_units_kernel(const int64_t* node_kv_len, const int64_t* node_q_len, int NE, int G,
+__global__ __launch_bounds__(1024) void node_units_kernel(const int64_t* node_kv_len, const int64_t* node_q_len, int NEc, int G,
                                                           int cap, int64_t rows_cap, UnitList ul, int32_t* hdr,
                                                           int32_t* row_q, int Hkv, int slots, int chunk_c, int run_cap,
-                                                          int par, int keep_err) {
+                                                          int par, int keep_err, const int32_t* dims) {
     constexpr int np = 1;
+    const int NE = dims ? min(dims[1], NEc) : NEc;  // (device-side metadata: this step's entry count, see flatten_units_kernel)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int* sRun = reinterpret_cast<int*>(smem);
     RunTable rt{sRun, sRun + run_cap, sRun + 2 * run_cap, 0, run_cap};

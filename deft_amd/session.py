@@ -1,0 +1,158 @@
+"""A decode loop over ONE tree as captured hipGraphs: one graph per structural epoch of the tree.
+
+What a runner does per decode step around the attention path (DeFT/deft/tree_decoding/generation/tree_generate.py:93-131,
+model_runner.py:162-231): `tree.alloc()`, `TreeMetadata.from_tree_cache(tree)`, then the model's forward, whose every
+layer appends this step's K/V rows and calls the tree-attention operator.  With the tree's compact copy on the GPU
+(deft_amd/csrc/tree_plan.h) every launch of that sequence has the SAME arguments on every step until the tree's structure
+changes -- the arrays and the plan live in buffers sized for the epoch, the block count of the step is read on the device --
+so the whole step is captured once and replayed:
+
+    page-table write, device tree advance (this step's slots)      tree_advance_kernel
+    TreeMetadata on the GPU                                          tree_md_scan / _blocks / _nodes
+    per-step plan                                                    flatten_units / _records, qrows_hist / _fill
+    layers x (fused paged append + stage 1, merge)                   stage1_np_kernel, merge_kernel
+
+Per step the host picks the new slots (its allocator mirrors the pool), appends them to the native tree, copies
+nq slot numbers and page-table coordinates from pinned memory, and replays: ~0.1 ms of host time, nothing else crosses
+PCIe.  A branch / cut / merge (or a leaf outgrowing its room) starts a new epoch: upload the compact tree, capture again.
+
+DeFT-Flatten, head_dim 128.  The eager path (`tree.alloc()` + `TreeMetadata.from_tree_cache` + `DeFTAttention`) gives the same
+results step for step (tests/test_session.py).
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional
+
+import numpy as np
+import torch
+
+from ._lib import check, lib
+from .tree_cache import BLOCK_CONFIG, TreeCache, _DeviceTree, _FIELDS, _ptr
+
+__all__ = ["FlattenDecodeSession"]
+
+
+class FlattenDecodeSession:
+    def __init__(self, tree: TreeCache, num_heads: int, num_kv_heads: int, head_dim: int, layers: int,
+                 qkv: Callable[[int], tuple], max_q_len: int = 32, use_graph: bool = True) -> None:
+        """`qkv(layer)` -> (q [nq, Hq*D], k_new [nq, Hkv*D], v_new [nq, Hkv*D]) fp16 CUDA tensors at FIXED addresses (the
+        model writes this step's projections there); outputs are in `self.out[layer]` ([nq, Hq*D])."""
+        pool = tree.token_to_kv_pool
+        assert pool.device.type == "cuda" and head_dim == 128
+        self.tree, self.pool, self.device = tree, pool, pool.device
+        self.Hq, self.Hkv, self.D, self.layers = num_heads, num_kv_heads, head_dim, layers
+        self.qkv, self.max_q_len, self.use_graph = qkv, max_q_len, use_graph
+        self.graph: Optional[torch.cuda.CUDAGraph] = None
+        self.graph_epoch = -1
+        self.captures = 0
+        self.out: List[torch.Tensor] = []
+        self._pin = None
+
+    # ---- per epoch ----------------------------------------------------------------------------------------
+    def _epoch_setup(self) -> None:
+        tree, dev = self.tree, self.device
+        block_len = BLOCK_CONFIG["BLOCK_LEN"]
+        dt = tree._device_tree
+        cfg = (int(self.max_q_len), int(block_len), int(BLOCK_CONFIG["MAX_BLOCK_LEN"]))
+        if dt is None or dt.device != dev or dt.cfg != cfg:
+            dt = tree._device_tree = _DeviceTree(tree, dev, *cfg)
+        dt.sync()
+        self.dt = dt
+        self.nq = dt.nq
+        self.NB, self.P = dt.cap_lens["block_lens"], dt.cap_lens["block_q"]
+        off, self.md_ptrs = 0, {}
+        for k in _FIELDS:
+            self.md_ptrs[k] = dt.out.data_ptr() + 8 * off
+            off += dt.cap_lens[k]
+        Hq, Hkv, D = self.Hq, self.Hkv, self.D
+        self.plan_bytes = int(lib.deft_flatten_plan_bytes(self.NB, self.P, Hq, Hkv))
+        self.plan = torch.empty(max(self.plan_bytes, 1), dtype=torch.uint8, device=dev)
+        self.ws_bytes = int(lib.deft_flatten_workspace_bytes(self.NB, self.P, self.nq, Hq, Hkv, D))
+        self.ws = torch.empty(max(self.ws_bytes, 1), dtype=torch.uint8, device=dev)
+        self.cache_loc = torch.zeros(max(self.nq, 1), dtype=torch.int32, device=dev)
+        self.idx = torch.zeros((2, max(self.nq, 1)), dtype=torch.int64, device=dev)
+        self.out = [torch.empty((self.nq, Hq * D), dtype=torch.float16, device=dev) for _ in range(self.layers)]
+        order = sorted(tree.leaves)
+        self.leaf_handles = [tree.leaves[i] for i in order]
+        self.leaf_reqs = np.asarray([tree.leaf_to_req[i] for i in order], dtype=np.int64)
+        self.graph, self.graph_epoch = None, dt.epoch
+
+    def _launch_step(self, advance: bool = True) -> None:
+        """The device side of one decode step; identical arguments on every step of the epoch.  `advance=False`: the first
+        step of an epoch -- the tree that was just uploaded already holds this step's slots."""
+        dt, dev = self.dt, self.device
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        table = self.tree.req_to_token_pool.req_to_token
+        table[self.idx[0], self.idx[1]] = self.cache_loc  # page table rows of this step's tokens
+        if advance:
+            check(lib.deft_tree_dev_advance(*dt._tree_args(), self.cache_loc.data_ptr(), dt.scratch.data_ptr(), stream),
+                  "deft_tree_dev_advance")
+        mq, bl, mbl = dt.cfg
+        check(lib.deft_tree_dev_build_md(*dt._tree_args(), mq, bl, mbl, dt.nbp_cap, dt.scratch.data_ptr(), dt.scratch_bytes,
+                                         *[self.md_ptrs[k] for k in _FIELDS], stream), "deft_tree_dev_build_md")
+        Hq, Hkv, D = self.Hq, self.Hkv, self.D
+        q0, k0, _ = self.qkv(0)
+        mdl = [self.md_ptrs[k] for k in ("block_q", "block_q_cnts", "block_q_offset", "block_bitmasks", "block_kv", "block_lens")]
+        kv0 = self.pool.kv_data[0]
+        check(lib.deft_flatten_build_plan_dims(*mdl, self.NB, self.P, dt.scratch.data_ptr(), Hq, Hkv, q0.stride(0), D, kv0.stride(0),
+                                               self.cache_loc.data_ptr(), self.nq, k0.stride(0), self.plan.data_ptr(),
+                                               self.plan_bytes, stream), "deft_flatten_build_plan_dims")
+        v_off = kv0.stride(1) * 2
+        for l in range(self.layers):
+            q, k, v = self.qkv(l)
+            kptr = self.pool.kv_data[l].data_ptr()
+            check(lib.deft_flatten_decode_append_f16(q.data_ptr(), q.stride(0), D, kptr, kptr + v_off, kv0.stride(0), kv0.stride(2),
+                                                     self.out[l].data_ptr(), Hq * D, D, *mdl, self.NB, self.P, self.nq, Hq, Hkv, D,
+                                                     1.0 / (D ** 0.5), self.cache_loc.data_ptr(), k.data_ptr(), v.data_ptr(),
+                                                     k.stride(0), self.nq, self.plan.data_ptr(), self.ws.data_ptr(), self.ws_bytes,
+                                                     stream), "deft_flatten_decode_append_f16")
+
+    # ---- per step ------------------------------------------------------------------------------------------
+    def step(self) -> List[torch.Tensor]:
+        """One decode step: every live leaf has taken its token (`leaf.append_token`); returns the per-layer outputs."""
+        tree = self.tree
+        n = len(tree.leaves)
+        loc = self.pool.alloc_host(n)
+        assert loc is not None
+        loc64 = loc.astype(np.int64)
+        check(lib.deft_tree_alloc_step(tree._native, n, _ptr(loc64)), "deft_tree_alloc_step")
+        if tree._epoch() != self.graph_epoch:
+            # a new structural epoch (branch / cut / merge since the last step, or a leaf outgrew its room): the upload made
+            # now already contains this step's slots, so this step runs eagerly without the advance; the next one captures
+            self._epoch_setup()
+            self._write_staging(loc)
+            self._launch_step(advance=False)
+            return self.out
+        self._write_staging(loc)
+        if not self.use_graph:
+            self._launch_step()
+            return self.out
+        if self.graph is None:
+            self._capture()
+        self.graph.replay()
+        return self.out
+
+    def _write_staging(self, loc: np.ndarray) -> None:
+        """This step's slot numbers and page-table coordinates: pinned staging -> the fixed device tensors the graph reads."""
+        ent = self.tree._staging(self.nq)
+        n = self.nq
+        ent[0].numpy()[:n] = loc
+        idx_h = ent[1].numpy()
+        idx_h[0, :n] = self.leaf_reqs
+        idx_h[1, :n] = [lf.positions[-1] for lf in self.leaf_handles]
+        self.cache_loc.copy_(ent[0][:n], non_blocking=True)
+        self.idx.copy_(ent[1][:, :n], non_blocking=True)
+        ent[2] = torch.cuda.Event()
+        ent[2].record(torch.cuda.current_stream(self.device))
+
+    def _capture(self) -> None:
+        dev = self.device
+        graph = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(graph, stream=side):
+                self._launch_step()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        self.graph = graph
+        self.captures += 1

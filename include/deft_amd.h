@@ -90,6 +90,18 @@ int deft_flatten_build_plan(
     const int32_t* cache_loc /* nullable */, int n_new, int64_t new_stride_tok,
     void* plan, size_t plan_bytes, void* stream);
 
+/* The plan for metadata built ON THE DEVICE (deft_tree_dev_build_md below): NB and P are the CAPACITIES of the arrays --
+ * they size the plan, the grids and the partial-row stride; pass the same two values to the decode call -- and the block
+ * count of the current step is read by the kernel from dims[5] (the first words of deft_tree_dev_build_md's scratch).
+ * The launch therefore has identical arguments on every decode step of a structural epoch of the tree and can be part
+ * of a captured hipGraph of the whole step (deft_amd/session.py). */
+int deft_flatten_build_plan_dims(
+    const int64_t* block_q, const int64_t* block_q_cnts, const int64_t* block_q_offset,
+    const int64_t* block_bitmasks, const int64_t* block_kv, const int64_t* block_lens,
+    int NB, int P, const int32_t* dims, int Hq, int Hkv, int64_t q_stride_tok, int64_t q_stride_head, int64_t kv_stride_slot,
+    const int32_t* cache_loc /* nullable */, int n_new, int64_t new_stride_tok,
+    void* plan, size_t plan_bytes, void* stream);
+
 /*
  * out[nq,Hq,D] = tree attention of q over the flattened-tree blocks.
  *   q, out              fp16, [nq][Hq][D] with the given token/head strides

@@ -1,0 +1,71 @@
+"""The captured decode loop (deft_amd.FlattenDecodeSession: one hipGraph per structural epoch of the tree) against the eager
+path (tree.alloc + TreeMetadata.from_tree_cache + DeFTAttention), step for step, through branches and cuts."""
+import numpy as np
+import pytest
+import torch
+
+import deft_amd
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(Hkv, D, layers, prefix, width, size):
+    req = deft_amd.ReqToTokenPool(64, size, device="cuda")
+    pool = deft_amd.TokenToKVPool(size, torch.float16, Hkv, D, layers, device="cuda")
+    tree = deft_amd.TreeCache(torch.float16, Hkv, D, layers, req, pool, None, True, False)
+    tree.init_prompt(torch.arange(1, prefix + 1, dtype=torch.int32))
+    tree.branch(tree.root, width)
+    return tree, pool
+
+
+@pytest.mark.parametrize("use_graph", [True, False])
+def test_session_equals_eager_step_for_step(use_graph):
+    Hq, Hkv, D, layers, prefix, width = 8, 2, 128, 3, 700, 6
+    g = torch.Generator(device="cuda").manual_seed(3)
+    kv_init = torch.randn((layers, 4096, 2, Hkv, D), dtype=torch.float16, device="cuda", generator=g)
+    trees = []
+    for _ in range(2):  # the same tree twice: one decoded eagerly, one through the session
+        tree, pool = _mk(Hkv, D, layers, prefix, width, 4096)
+        pool._storage.copy_(kv_init)
+        trees.append((tree, pool))
+    (te, pe), (ts, ps) = trees
+    cap = 16
+    q = torch.randn((layers, cap, Hq * D), dtype=torch.float16, device="cuda", generator=g)
+    k = torch.randn((layers, cap, Hkv * D), dtype=torch.float16, device="cuda", generator=g)
+    v = torch.randn((layers, cap, Hkv * D), dtype=torch.float16, device="cuda", generator=g)
+    nq_now = [width]
+    sess = deft_amd.FlattenDecodeSession(ts, Hq, Hkv, D, layers, lambda l: (q[l, : nq_now[0]], k[l, : nq_now[0]], v[l, : nq_now[0]]),
+                                         use_graph=use_graph)
+    attn = [deft_amd.DeFTAttention(Hq, D, D ** -0.5, Hkv, l) for l in range(layers)]
+    mode = deft_amd.forward_mode_from_cli("flatten")
+
+    def both_steps(steps):
+        for _ in range(steps):
+            for tree in (te, ts):
+                for leaf in tree.leaves.values():
+                    leaf.append_token(7)
+            upd = te.alloc()
+            md = deft_amd.TreeMetadata.from_tree_cache(te)
+            deft_amd.register_tree_metadata(md)
+            meta = deft_amd.InputMetadata(mode, upd, pe)
+            n = md.query_num
+            nq_now[0] = n
+            ref = [attn[l](q[l, :n], k[l, :n], v[l, :n], meta) for l in range(layers)]
+            out = sess.step()
+            torch.cuda.synchronize()
+            for l in range(layers):
+                assert torch.equal(out[l][:n], ref[l]), l
+            assert torch.equal(pe._storage, ps._storage)  # the fused append wrote the same rows
+            ea = te.req_to_token_pool.req_to_token
+            sa = ts.req_to_token_pool.req_to_token
+            assert torch.equal(ea, sa)  # and the page tables agree
+
+    both_steps(140)  # crosses 128-slot block boundaries many times inside one epoch
+    assert sess.captures == (1 if use_graph else 0)
+    for tree in (te, ts):  # structural change: cut two leaves, branch one
+        lv = sorted(tree.leaves.values(), key=lambda n: n.id)
+        tree.cut(lv[1])
+        tree.cut(lv[4])
+        tree.branch(lv[0], 3)
+    both_steps(20)
+    assert sess.captures == (2 if use_graph else 0)
