@@ -99,7 +99,7 @@ template <int D, int MODE>
 __global__ __launch_bounds__(256, 2) void stage1_kernel(Stage1Params p) {
     constexpr int CH = D / 8;    // 16-byte chunks per K/V row
     constexpr int KS = D / 16;   // MFMA k-steps of S^T = K Q^T
-    constexpr int MB = D / 32;   // 32-column output blocks of O^T
+    constexpr int MB = (D + 31) / 32;  // 32-column output blocks of O^T (head_dim 16: one block, half of it unused)
     using SM = Stage1Smem<D>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     _Float16* sK = reinterpret_cast<_Float16*>(smem + SM::K_OFF);
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256, 2) void stage1_kernel(Stage1Params p) {
             for (int ks = 0; ks < TILE / 16; ++ks) {
                 half8 a;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) a[j] = vcol[(16 * ks + 8 * h + j) * D];
+                for (int j = 0; j < 8; ++j) a[j] = (32 * w + c < D) ? vcol[(16 * ks + 8 * h + j) * D] : (_Float16)0.f;
                 const half8 b = *reinterpret_cast<const half8*>(prow_p + (((2 * ks + h) ^ (c & 15)) * 8));
                 o = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, o, 0, 0, 0);
             }
@@ -273,6 +273,7 @@ __global__ __launch_bounds__(256, 2) void stage1_kernel(Stage1Params p) {
                 float* po = p.partial_o + prow_idx * D + 32 * w + 4 * h;
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
+                    if (32 * w + 8 * g4 + 4 * h >= D) continue;  // (head_dim 16: columns 16..31 of the MFMA block do not exist)
                     floatx4 v4 = {o[4 * g4] * inv, o[4 * g4 + 1] * inv, o[4 * g4 + 2] * inv, o[4 * g4 + 3] * inv};
                     *reinterpret_cast<floatx4*>(po + 8 * g4) = v4;
                 }
@@ -441,7 +442,8 @@ static int num_cus() {
     }
     return d.cus;
 }
-enum : unsigned { ATTR_V1_64_0 = 1, ATTR_V1_64_1 = 2, ATTR_NP = 4, ATTR_UNITS = 8, ATTR_NODE_UNITS = 16, ATTR_PREFILL = 32, ATTR_TREE = 64 };
+enum : unsigned { ATTR_NP = 4,  // (bits 0-1, 8-11: the head_dim 64 / 32 / 16 kernels)
+                  ATTR_UNITS = 8, ATTR_NODE_UNITS = 16, ATTR_PREFILL = 32, ATTR_TREE = 64 };
 static int raise_lds(const void* fn, int bytes, unsigned bit, const char* what) {  // idempotent; races are harmless
     DeviceState& d = dev_state();
     if (d.attrs & bit) return DEFT_OK;
@@ -454,11 +456,12 @@ static int raise_lds(const void* fn, int bytes, unsigned bit, const char* what) 
     return DEFT_OK;
 }
 
-// head_dim 64: one workgroup per (tile, KV head)
-template <int MODE>
-static int launch_stage1_d64(const Stage1Params& p, int64_t tiles, hipStream_t stream) {
-    using SM = Stage1Smem<64>;
-    int rc = raise_lds(reinterpret_cast<const void*>(&stage1_kernel<64, MODE>), SM::BYTES, MODE ? ATTR_V1_64_1 : ATTR_V1_64_0, "stage1");
+// head_dim 16 / 32 / 64: one workgroup per (tile, KV head)
+template <int D, int MODE>
+static int launch_stage1_small(const Stage1Params& p, int64_t tiles, hipStream_t stream) {
+    using SM = Stage1Smem<D>;
+    constexpr unsigned bit = (D == 64 ? 1u : (D == 32 ? 256u : 1024u)) << MODE;
+    int rc = raise_lds(reinterpret_cast<const void*>(&stage1_kernel<D, MODE>), SM::BYTES, bit, "stage1");
     if (rc) return rc;
     const int64_t grid = tiles * p.Hkv;
     if (grid <= 0) return DEFT_OK;
@@ -466,8 +469,16 @@ static int launch_stage1_d64(const Stage1Params& p, int64_t tiles, hipStream_t s
         set_error("stage1 grid too large: %lld", (long long)grid);
         return DEFT_EINVAL;
     }
-    hipLaunchKernelGGL((stage1_kernel<64, MODE>), dim3((unsigned)grid), dim3(256), SM::BYTES, stream, p);
+    hipLaunchKernelGGL((stage1_kernel<D, MODE>), dim3((unsigned)grid), dim3(256), SM::BYTES, stream, p);
     return check_launch("stage1 launch");
+}
+template <int MODE>
+static int launch_stage1_d64(int D, const Stage1Params& p, int64_t tiles, hipStream_t stream) {
+    if (D == 64) return launch_stage1_small<64, MODE>(p, tiles, stream);
+    if (D == 32) return launch_stage1_small<32, MODE>(p, tiles, stream);
+    if (D == 16) return launch_stage1_small<16, MODE>(p, tiles, stream);
+    set_error("unsupported head_dim %d", D);
+    return DEFT_EUNSUPPORTED;
 }
 
 // Optional fused paged append (deft_*_decode_append_f16): this step's new K/V rows and their pool slots.
@@ -607,8 +618,14 @@ static int launch_merge(int D, const Workspace& ws, const PlanView* pv, const in
     if (D == 128)
         hipLaunchKernelGGL((merge_kernel<128>), grid, dim3(256), lds, stream, ws.partial_o, ws.partial_lse, row_q, rows,
                            static_cast<_Float16*>(out), o_st, o_sh, Hq, cap, hdr, qoff, qlist);
-    else
+    else if (D == 64)
         hipLaunchKernelGGL((merge_kernel<64>), grid, dim3(256), lds, stream, ws.partial_o, ws.partial_lse, row_q, rows,
+                           static_cast<_Float16*>(out), o_st, o_sh, Hq, cap, hdr, qoff, qlist);
+    else if (D == 32)
+        hipLaunchKernelGGL((merge_kernel<32>), grid, dim3(256), lds, stream, ws.partial_o, ws.partial_lse, row_q, rows,
+                           static_cast<_Float16*>(out), o_st, o_sh, Hq, cap, hdr, qoff, qlist);
+    else
+        hipLaunchKernelGGL((merge_kernel<16>), grid, dim3(256), lds, stream, ws.partial_o, ws.partial_lse, row_q, rows,
                            static_cast<_Float16*>(out), o_st, o_sh, Hq, cap, hdr, qoff, qlist);
     return check_launch("merge launch");
 }
@@ -626,7 +643,7 @@ static int check_common(const void* q, int64_t q_st, int64_t q_sh, const void* k
         return DEFT_EINVAL;
     }
     if (!deft_supported(Hq, Hkv, D)) {
-        set_error("unsupported geometry Hq=%d Hkv=%d D=%d (D must be 64 or 128)", Hq, Hkv, D);
+        set_error("unsupported geometry Hq=%d Hkv=%d D=%d (head_dim must be 16, 32, 64 or 128)", Hq, Hkv, D);
         return DEFT_EUNSUPPORTED;
     }
     if (!aligned16(q) || !aligned16(k) || !aligned16(v) || (q_st % 8) || (q_sh % 8) || (kv_ss % 8) || (kv_sh % 8)) {
@@ -666,7 +683,9 @@ void deft_debug_plan_form(int serial, int runcap) {
 void deft_debug_set_buffer(void* dev_ptr) { g_dbg = static_cast<unsigned long long*>(dev_ptr); }
 #endif
 
-int deft_supported(int Hq, int Hkv, int D) { return (Hq > 0 && Hkv > 0 && Hq % Hkv == 0 && (D == 64 || D == 128)) ? 1 : 0; }
+int deft_supported(int Hq, int Hkv, int D) {
+    return (Hq > 0 && Hkv > 0 && Hq % Hkv == 0 && (D == 16 || D == 32 || D == 64 || D == 128)) ? 1 : 0;
+}
 
 size_t deft_flatten_workspace_bytes(int NB, int P, int nq, int Hq, int Hkv, int D) {
     (void)nq;
@@ -761,7 +780,7 @@ static int flatten_stage1_impl(const void* q, int64_t q_stride_tok, int64_t q_st
         if (rc) return rc;
     }
     *row_q_out = ws.row_q;
-    return launch_stage1_d64<0>(p, NB, st);
+    return launch_stage1_d64<0>(D, p, NB, st);
 }
 
 size_t deft_flatten_plan_bytes(int NB, int P, int Hq, int Hkv) {
@@ -1082,7 +1101,7 @@ static int node_decode_impl(const void* q, int64_t q_stride_tok, int64_t q_strid
     rc = check_launch("node prep launch");
     if (rc) return rc;
     p.desc = ws.desc;
-    rc = launch_stage1_d64<1>(p, tiles, st);
+    rc = launch_stage1_d64<1>(D, p, tiles, st);
     if (rc) return rc;
     return launch_merge(D, ws, nullptr, ws.row_q, rows, out, o_stride_tok, o_stride_head, nq, Hq, st);
 }

@@ -61,8 +61,8 @@ const char* deft_last_error(void);
  * experiments build (`make -C deft_amd/csrc exp`, A/B measurements only) folds its plan knobs into it. */
 int deft_plan_variant(void);
 
-/* 1 if (Hq, Hkv, D) is covered: Hq % Hkv == 0, D in {64, 128}
- * (the reference asserts D in {16,32,64,128}, tree_attention.py:100,305,582). */
+/* 1 if (Hq, Hkv, D) is covered: Hq % Hkv == 0, D in {16, 32, 64, 128} -- the head dims the reference asserts
+ * (tree_attention.py:100,305,582).  D = 128 (Llama) runs the LDS-DMA chunk kernel; the smaller ones a tile-per-workgroup kernel. */
 int deft_supported(int Hq, int Hkv, int D);
 
 /* ---- DeFT-Flatten ------------------------------------------------------- */

@@ -187,6 +187,14 @@ FULL_GEOMETRY = {"fewshot_1k": (32, 32, 128), "fewshot_4k": (32, 32, 128), "fews
 GQA_GEOMETRY = {"medusa64": (32, 8, 128), "tot50": (32, 8, 128), "forest_tree_8kx8": (32, 8, 128)}
 
 
+# the reference's other head dims (`assert Lk in {16, 32, 64, 128}`, tree_attention.py:100, :582): two trees each
+SMALL_D_GEOMETRY = {"multilevel": [(4, 4, 32), (4, 2, 16)], "wide40": [(4, 4, 32), (4, 2, 16)]}
+
+
+def small_d_cases():
+    return [(name, geom) for name, geoms in SMALL_D_GEOMETRY.items() for geom in geoms]
+
+
 def big_cases():
     """(scenario, geometry) pairs of the full-size goldens, each once."""
     seen = []

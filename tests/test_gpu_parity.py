@@ -14,7 +14,7 @@ from deft_amd.tree_attention import flatten_stage1_partials
 from helpers import leaf_paths, max_abs, oracle_metadata, oracle_tree, seeded_inputs
 from oracle import attention as oa
 from product_helpers import md_numpy, product_metadata, product_tree
-from scenarios import SCENARIOS, SMALL_GEOMETRIES, big_cases
+from scenarios import SCENARIOS, SMALL_GEOMETRIES, big_cases, small_d_cases
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-3
@@ -47,6 +47,7 @@ def _cases():
             for geom in SMALL_GEOMETRIES:
                 yield name, geom
     yield from big_cases()  # BASELINE's own configurations at full geometry
+    yield from small_d_cases()  # head_dim 32 and 16
 
 
 @pytest.mark.parametrize("mode", ["flatten", "node"])
@@ -202,11 +203,18 @@ def test_kv_append_and_module_forward():
 
 
 def test_unsupported_head_dim_fails_loudly():
-    q = torch.zeros(1, 4, 32, dtype=torch.float16, device="cuda")
-    kv = torch.zeros(8, 4, 32, dtype=torch.float16, device="cuda")
+    """The reference asserts head_dim in {16, 32, 64, 128} (tree_attention.py:100, :582); so does the shim, and the C ABI
+    reports DEFT_EUNSUPPORTED for anything else."""
+    q = torch.zeros(1, 4, 48, dtype=torch.float16, device="cuda")
+    kv = torch.zeros(8, 4, 48, dtype=torch.float16, device="cuda")
     i64 = torch.zeros(128, dtype=torch.int64, device="cuda")
-    with pytest.raises(deft_amd.DeftLibraryError, match="DEFT_EUNSUPPORTED"):
+    with pytest.raises(AssertionError):
         deft_amd.tree_attention_subtree_fwd(q, kv, kv, q.clone(), 128, i64[:1], i64[:1] + 1, i64[:1], i64, i64, i64[:1] + 1)
+    assert deft_amd.lib.deft_supported(4, 4, 48) == 0 and deft_amd.lib.deft_supported(4, 4, 16) == 1
+    ws = torch.zeros(1 << 20, dtype=torch.uint8, device="cuda")
+    rc = deft_amd.lib.deft_flatten_decode_f16(q.data_ptr(), 4 * 48, 48, kv.data_ptr(), kv.data_ptr(), 4 * 48, 48, q.data_ptr(), 4 * 48, 48,
+                                              *[i64.data_ptr()] * 6, 1, 1, 1, 4, 4, 48, 0.1, None, ws.data_ptr(), ws.numel(), None)
+    assert rc == -2  # DEFT_EUNSUPPORTED
 
 
 def _flatten_args(md):

@@ -13,7 +13,7 @@ import pytest
 from helpers import leaf_paths, max_abs, oracle_metadata, oracle_tree, seeded_inputs
 from oracle import attention as oa
 from oracle.metadata import ARRAY_FIELDS
-from scenarios import FULL_GEOMETRY, GQA_GEOMETRY, SCENARIOS, SMALL_GEOMETRIES
+from scenarios import FULL_GEOMETRY, GQA_GEOMETRY, SCENARIOS, SMALL_GEOMETRIES, small_d_cases
 
 TOL = 1e-3  # BASELINE.json north_star: "within 1e-3 fp16 tolerance"
 
@@ -56,6 +56,7 @@ def _kernel_cases():
                 yield name, geom
     for name, geom in GQA_GEOMETRY.items():
         yield name, geom
+    yield from small_d_cases()
 
 
 @pytest.mark.parametrize("name,geom", list(_kernel_cases()))

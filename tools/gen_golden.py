@@ -53,6 +53,7 @@ from scenarios import (  # noqa: E402
     FULL_GEOMETRY,
     GQA_GEOMETRY,
     SCENARIOS,
+    SMALL_D_GEOMETRY,
     SMALL_GEOMETRIES,
     input_seeds,
 )
@@ -124,6 +125,7 @@ def main() -> None:
                 geoms.append(FULL_GEOMETRY[name])
             if name in GQA_GEOMETRY:
                 geoms.append(GQA_GEOMETRY[name])
+            geoms += SMALL_D_GEOMETRY.get(name, [])
             for (Hq, Hkv, D) in geoms:
                 seeds = input_seeds(name, (Hq, Hkv, D))
                 nq = md.query_num
