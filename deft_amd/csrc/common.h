@@ -66,6 +66,7 @@ struct PlanView {
     int32_t* row_q;
     int32_t* qoff;   // [rows + 1] first entry of every query's row list (queries are < rows: each has a partial row)
     int32_t* qlist;  // [rows] live partial rows grouped by query, ascending within a query
+    int32_t* qinl;   // [rows][16] per query one 64-byte line: {count, first 15 rows} -- count and rows in ONE load for the usual query
     int64_t cap;
     int64_t rows;
     size_t bytes;
@@ -87,6 +88,8 @@ inline PlanView plan_view(void* base, int64_t cap, int64_t rows) {
     off = align_up(off + sizeof(int32_t) * (size_t)((rows > 0 ? rows : 1) + 1), 256);
     v.qlist = reinterpret_cast<int32_t*>(p + off);
     off = align_up(off + sizeof(int32_t) * (size_t)(rows > 0 ? rows : 1), 256);
+    v.qinl = reinterpret_cast<int32_t*>(p + off);
+    off = align_up(off + sizeof(int32_t) * 16 * (size_t)(rows > 0 ? rows : 1), 256);
     v.bytes = off;
     return v;
 }

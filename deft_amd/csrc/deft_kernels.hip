@@ -351,18 +351,26 @@ constexpr int MERGE_LIST_CAP = 4096;  // row ids per wave in LDS; longer lists a
 template <int D>
 __global__ __launch_bounds__(256) void merge_kernel(const float* partial_o, const float* partial_lse, const int32_t* row_q,
                                                      int64_t rows, _Float16* out, int64_t o_st, int64_t o_sh, int Hq, int cap,
-                                                     const int32_t* hdr, const int32_t* qoff, const int32_t* qlist) {
+                                                     int lists, const int32_t* qoff, const int32_t* qlist, const int32_t* qinl) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;  // (uniform: buffer descriptors stay in SGPRs)
     const int q = blockIdx.x, hq = blockIdx.y * 4 + w;
     if (hq >= Hq) return;
     _Float16* out_q = out + (int64_t)q * o_st;
-    if (hdr && hdr[HDR_QLISTS]) {  // the plan lists every query's rows: one round trip for the list, one for the rows
-        const int o = qoff[q], n = qoff[q + 1] - o;
-        merge_heads_wave<D, 0, 1>(partial_o, partial_lse, row_q, rows, q, hq, 1, Hq, const_cast<int*>(qlist) + o, n, n, out_q, o_sh, lane);
+    int* list = reinterpret_cast<int*>(smem) + w * cap;
+    if (lists) {  // the plan lists every query's rows: ONE round trip for {count, rows}, one for the rows themselves
+        const int mine = lane < 16 ? qinl[q * 16 + lane] : 0;
+        const int n = __builtin_amdgcn_readfirstlane(mine);
+        if (n <= 15 && n <= cap) {
+            if (lane >= 1 && lane <= n) list[lane - 1] = mine;
+            __builtin_amdgcn_wave_barrier();
+            merge_heads_wave<D, 0, 1>(partial_o, partial_lse, row_q, rows, q, hq, 1, Hq, list, cap, n, out_q, o_sh, lane);
+        } else {  // a long list: the query's stretch of qlist (global memory, read in place)
+            const int o = qoff[q];
+            merge_heads_wave<D, 0, 1>(partial_o, partial_lse, row_q, rows, q, hq, 1, Hq, const_cast<int*>(qlist) + o, n, n, out_q, o_sh, lane);
+        }
         return;
     }
-    int* list = reinterpret_cast<int*>(smem) + w * cap;
     int have = scan_rows_wave(row_q, 0, rows < cap ? rows : cap, q, list, cap, lane);
     if (rows > cap) have = -1;
     __builtin_amdgcn_wave_barrier();
@@ -513,7 +521,8 @@ static int launch_qrows(const PlanView& pv, hipStream_t stream) {
     hipLaunchKernelGGL(qrows_hist_kernel, dim3(1), dim3(1024), sizeof(int) * (size_t)rows, stream, pv.row_q, (int)rows, pv.qoff, pv.hdr);
     int rc = check_launch("qrows hist launch");
     if (rc) return rc;
-    hipLaunchKernelGGL(qrows_fill_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, pv.row_q, (int)rows, pv.qoff, pv.qlist);
+    hipLaunchKernelGGL(qrows_fill_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, pv.row_q, (int)rows, pv.qoff, pv.qlist,
+                       pv.qinl);
     return check_launch("qrows fill launch");
 }
 
@@ -612,21 +621,19 @@ static int launch_merge(int D, const Workspace& ws, const PlanView* pv, const in
     const int cap = (int)std::min<int64_t>(std::max<int64_t>(rows, 64), MERGE_LIST_CAP);
     const size_t lds = sizeof(int) * 4 * (size_t)cap;
     dim3 grid((unsigned)nq, (unsigned)((Hq + 3) / 4));
-    const int32_t* hdr = pv ? pv->hdr : nullptr;
+    // the plan's per-query row lists exist iff its row count fits the histogram kernel (launch_qrows): known on the host
+    const int lists = pv && pv->rows > 0 && pv->rows <= QROWS_MAX ? 1 : 0;
     const int32_t* qoff = pv ? pv->qoff : nullptr;
     const int32_t* qlist = pv ? pv->qlist : nullptr;
-    if (D == 128)
-        hipLaunchKernelGGL((merge_kernel<128>), grid, dim3(256), lds, stream, ws.partial_o, ws.partial_lse, row_q, rows,
-                           static_cast<_Float16*>(out), o_st, o_sh, Hq, cap, hdr, qoff, qlist);
-    else if (D == 64)
-        hipLaunchKernelGGL((merge_kernel<64>), grid, dim3(256), lds, stream, ws.partial_o, ws.partial_lse, row_q, rows,
-                           static_cast<_Float16*>(out), o_st, o_sh, Hq, cap, hdr, qoff, qlist);
-    else if (D == 32)
-        hipLaunchKernelGGL((merge_kernel<32>), grid, dim3(256), lds, stream, ws.partial_o, ws.partial_lse, row_q, rows,
-                           static_cast<_Float16*>(out), o_st, o_sh, Hq, cap, hdr, qoff, qlist);
-    else
-        hipLaunchKernelGGL((merge_kernel<16>), grid, dim3(256), lds, stream, ws.partial_o, ws.partial_lse, row_q, rows,
-                           static_cast<_Float16*>(out), o_st, o_sh, Hq, cap, hdr, qoff, qlist);
+    const int32_t* qinl = pv ? pv->qinl : nullptr;
+#define DEFT_MERGE_LAUNCH(DD)                                                                                              \
+    hipLaunchKernelGGL((merge_kernel<DD>), grid, dim3(256), lds, stream, ws.partial_o, ws.partial_lse, row_q, rows,         \
+                       static_cast<_Float16*>(out), o_st, o_sh, Hq, cap, lists, qoff, qlist, qinl)
+    if (D == 128) DEFT_MERGE_LAUNCH(128);
+    else if (D == 64) DEFT_MERGE_LAUNCH(64);
+    else if (D == 32) DEFT_MERGE_LAUNCH(32);
+    else DEFT_MERGE_LAUNCH(16);
+#undef DEFT_MERGE_LAUNCH
     return check_launch("merge launch");
 }
 

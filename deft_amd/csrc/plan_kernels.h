@@ -973,11 +973,13 @@ __global__ __launch_bounds__(1024) void qrows_hist_kernel(const int32_t* row_q, 
 }
 
 // one wave per query (four per workgroup): the query's rows, ascending, into qlist[qoff[q] ..)
-__global__ __launch_bounds__(256) void qrows_fill_kernel(const int32_t* row_q, int rows, const int32_t* qoff, int32_t* qlist) {
+__global__ __launch_bounds__(256) void qrows_fill_kernel(const int32_t* row_q, int rows, const int32_t* qoff, int32_t* qlist,
+                                                         int32_t* qinl) {
     const int lane = threadIdx.x & 63;
     const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (q >= rows) return;
     const int o = qoff[q], n = qoff[q + 1] - o;
+    if (lane == 0) qinl[q * 16] = n;  // {count, first 15 rows}: what the merge of the usual query needs, in one 64-byte line
     if (n <= 0) return;  // (not a query of this step)
     int found = 0;
     for (int base = 0; base < rows && found < n; base += 512) {
@@ -991,7 +993,11 @@ __global__ __launch_bounds__(256) void qrows_fill_kernel(const int32_t* row_q, i
         for (int u = 0; u < 8; ++u) {
             const bool hit = val[u] == q;
             const unsigned long long mask = __ballot(hit);
-            if (hit) qlist[o + found + __popcll(mask & ((1ull << lane) - 1ull))] = base + 64 * u + lane;
+            if (hit) {
+                const int pos = found + __popcll(mask & ((1ull << lane) - 1ull));
+                qlist[o + pos] = base + 64 * u + lane;
+                if (pos < 15) qinl[q * 16 + 1 + pos] = base + 64 * u + lane;
+            }
             found += __popcll(mask);
         }
     }
