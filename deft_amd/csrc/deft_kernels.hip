@@ -365,7 +365,12 @@ __global__ __launch_bounds__(256) void merge_kernel(const float* partial_o, cons
             if (lane >= 1 && lane <= n) list[lane - 1] = mine;
             __builtin_amdgcn_wave_barrier();
             merge_heads_wave<D, 0, 1>(partial_o, partial_lse, row_q, rows, q, hq, 1, Hq, list, cap, n, out_q, o_sh, lane);
-        } else {  // a long list: the query's stretch of qlist (global memory, read in place)
+        } else if (n <= cap) {  // a longer list: the query's stretch of qlist, staged in LDS with one coalesced read
+            const int o = qoff[q];
+            for (int j = lane; j < n; j += 64) list[j] = qlist[o + j];
+            __builtin_amdgcn_wave_barrier();
+            merge_heads_wave<D, 0, 1>(partial_o, partial_lse, row_q, rows, q, hq, 1, Hq, list, cap, n, out_q, o_sh, lane);
+        } else {  // longer than the LDS area: read in place
             const int o = qoff[q];
             merge_heads_wave<D, 0, 1>(partial_o, partial_lse, row_q, rows, q, hq, 1, Hq, const_cast<int*>(qlist) + o, n, n, out_q, o_sh, lane);
         }
