@@ -11,7 +11,7 @@ from .forest import Forest, concat_metadata_host  # noqa: F401
 from .forward_mode import ForwardMode, InputMetadata, forward_mode_from_cli  # noqa: F401
 from .memory_pool import ReqToTokenPool, TokenToKVPool  # noqa: F401
 from .rotary_embedding import RotaryEmbedding, get_rope  # noqa: F401
-from .session import FlattenDecodeSession  # noqa: F401
+from .session import DecodeSession, FlattenDecodeSession  # noqa: F401
 from .token_attention import token_attention_fwd  # noqa: F401
 from .tree_attention import kv_append, tree_attention_fwd, tree_attention_subtree_fwd  # noqa: F401
 from .tree_cache import (  # noqa: F401

@@ -988,11 +988,11 @@ size_t deft_node_plan_bytes(int NE, int P, int64_t total_kv, int Hq, int Hkv) {
     return plan_view(nullptr, tiles * (Hq / Hkv), tiles * DEFT_MAX_Q_LEN).bytes;
 }
 
-int deft_node_build_plan(const int64_t* node_kv, const int64_t* node_kv_offset, const int64_t* node_kv_len,
-                         const int64_t* node_q, const int64_t* node_q_offset, const int64_t* node_q_len, int NE, int P,
-                         int64_t total_kv, int Hq, int Hkv, int64_t q_stride_tok, int64_t q_stride_head,
-                         int64_t kv_stride_slot, const int32_t* cache_loc, int n_new, int64_t new_stride_tok, void* plan,
-                         size_t plan_bytes, void* stream) {
+static int node_build_plan_impl(const int64_t* node_kv, const int64_t* node_kv_offset, const int64_t* node_kv_len,
+                                const int64_t* node_q, const int64_t* node_q_offset, const int64_t* node_q_len, int NE, int P,
+                                int64_t total_kv, const int32_t* dims, int Hq, int Hkv, int64_t q_stride_tok,
+                                int64_t q_stride_head, int64_t kv_stride_slot, const int32_t* cache_loc, int n_new,
+                                int64_t new_stride_tok, void* plan, size_t plan_bytes, void* stream) {
     if (NE < 0 || P < 0 || total_kv < 0 || total_kv > 0x7fffffffLL || !plan || Hq <= 0 || Hkv <= 0 || Hq % Hkv ||
         (NE > 0 && (!node_kv || !node_kv_offset || !node_kv_len || !node_q || !node_q_offset || !node_q_len))) {
         set_error("bad node plan arguments (NE=%d P=%d total_kv=%lld)", NE, P, (long long)total_kv);
@@ -1028,7 +1028,33 @@ int deft_node_build_plan(const int64_t* node_kv, const int64_t* node_kv_offset, 
         ap.n_new = n_new;
         ap.new_st = new_stride_tok;
     }
-    return launch_node_plan(p, NE, rows, pv, ap, static_cast<hipStream_t>(stream));
+    return launch_node_plan(p, NE, rows, pv, ap, static_cast<hipStream_t>(stream), 0, dims);
+}
+
+int deft_node_build_plan(const int64_t* node_kv, const int64_t* node_kv_offset, const int64_t* node_kv_len,
+                         const int64_t* node_q, const int64_t* node_q_offset, const int64_t* node_q_len, int NE, int P,
+                         int64_t total_kv, int Hq, int Hkv, int64_t q_stride_tok, int64_t q_stride_head,
+                         int64_t kv_stride_slot, const int32_t* cache_loc, int n_new, int64_t new_stride_tok, void* plan,
+                         size_t plan_bytes, void* stream) {
+    return node_build_plan_impl(node_kv, node_kv_offset, node_kv_len, node_q, node_q_offset, node_q_len, NE, P, total_kv, nullptr, Hq,
+                                Hkv, q_stride_tok, q_stride_head, kv_stride_slot, cache_loc, n_new, new_stride_tok, plan, plan_bytes,
+                                stream);
+}
+
+// Node-mode counterpart of deft_flatten_build_plan_dims: NE, P, total_kv are the CAPACITIES of the device-built arrays, this
+// step's entry count is read from dims[1] on the device.
+int deft_node_build_plan_dims(const int64_t* node_kv, const int64_t* node_kv_offset, const int64_t* node_kv_len,
+                              const int64_t* node_q, const int64_t* node_q_offset, const int64_t* node_q_len, int NE, int P,
+                              int64_t total_kv, const int32_t* dims, int Hq, int Hkv, int64_t q_stride_tok,
+                              int64_t q_stride_head, int64_t kv_stride_slot, const int32_t* cache_loc, int n_new,
+                              int64_t new_stride_tok, void* plan, size_t plan_bytes, void* stream) {
+    if (!dims) {
+        set_error("deft_node_build_plan_dims: null dims");
+        return DEFT_EINVAL;
+    }
+    return node_build_plan_impl(node_kv, node_kv_offset, node_kv_len, node_q, node_q_offset, node_q_len, NE, P, total_kv, dims, Hq,
+                                Hkv, q_stride_tok, q_stride_head, kv_stride_slot, cache_loc, n_new, new_stride_tok, plan, plan_bytes,
+                                stream);
 }
 
 }  // extern "C"

@@ -16,7 +16,7 @@ Per step the host picks the new slots (its allocator mirrors the pool), appends 
 nq slot numbers and page-table coordinates from pinned memory, and replays: ~0.1 ms of host time, nothing else crosses
 PCIe.  A branch / cut / merge (or a leaf outgrowing its room) starts a new epoch: upload the compact tree, capture again.
 
-DeFT-Flatten, head_dim 128.  The eager path (`tree.alloc()` + `TreeMetadata.from_tree_cache` + `DeFTAttention`) gives the same
+DeFT-Flatten and DeFT-Node, head_dim 128.  The eager path (`tree.alloc()` + `TreeMetadata.from_tree_cache` + `DeFTAttention`) gives the same
 results step for step (tests/test_session.py).
 """
 from __future__ import annotations
@@ -29,16 +29,17 @@ import torch
 from ._lib import check, lib
 from .tree_cache import BLOCK_CONFIG, TreeCache, _DeviceTree, _FIELDS, _ptr
 
-__all__ = ["FlattenDecodeSession"]
+__all__ = ["DecodeSession", "FlattenDecodeSession"]
 
 
-class FlattenDecodeSession:
+class DecodeSession:
     def __init__(self, tree: TreeCache, num_heads: int, num_kv_heads: int, head_dim: int, layers: int,
-                 qkv: Callable[[int], tuple], max_q_len: int = 32, use_graph: bool = True) -> None:
+                 qkv: Callable[[int], tuple], max_q_len: int = 32, use_graph: bool = True, mode: str = "flatten") -> None:
         """`qkv(layer)` -> (q [nq, Hq*D], k_new [nq, Hkv*D], v_new [nq, Hkv*D]) fp16 CUDA tensors at FIXED addresses (the
         model writes this step's projections there); outputs are in `self.out[layer]` ([nq, Hq*D])."""
         pool = tree.token_to_kv_pool
-        assert pool.device.type == "cuda" and head_dim == 128
+        assert pool.device.type == "cuda" and head_dim == 128 and mode in ("flatten", "node")
+        self.mode = mode
         self.tree, self.pool, self.device = tree, pool, pool.device
         self.Hq, self.Hkv, self.D, self.layers = num_heads, num_kv_heads, head_dim, layers
         self.qkv, self.max_q_len, self.use_graph = qkv, max_q_len, use_graph
@@ -65,9 +66,14 @@ class FlattenDecodeSession:
             self.md_ptrs[k] = dt.out.data_ptr() + 8 * off
             off += dt.cap_lens[k]
         Hq, Hkv, D = self.Hq, self.Hkv, self.D
-        self.plan_bytes = int(lib.deft_flatten_plan_bytes(self.NB, self.P, Hq, Hkv))
+        if self.mode == "flatten":
+            self.plan_bytes = int(lib.deft_flatten_plan_bytes(self.NB, self.P, Hq, Hkv))
+            self.ws_bytes = int(lib.deft_flatten_workspace_bytes(self.NB, self.P, self.nq, Hq, Hkv, D))
+        else:  # Node arrays: capacities of node_q_len (entries), node_q (pairs), node_kv (slots, repeated per query chunk)
+            self.NE, self.PN, self.TKV = dt.cap_lens["node_q_len"], dt.cap_lens["node_q"], dt.cap_lens["node_kv"]
+            self.plan_bytes = int(lib.deft_node_plan_bytes(self.NE, self.PN, self.TKV, Hq, Hkv))
+            self.ws_bytes = int(lib.deft_node_workspace_bytes(self.NE, self.PN, self.TKV, self.nq, Hq, Hkv, D))
         self.plan = torch.empty(max(self.plan_bytes, 1), dtype=torch.uint8, device=dev)
-        self.ws_bytes = int(lib.deft_flatten_workspace_bytes(self.NB, self.P, self.nq, Hq, Hkv, D))
         self.ws = torch.empty(max(self.ws_bytes, 1), dtype=torch.uint8, device=dev)
         self.cache_loc = torch.zeros(max(self.nq, 1), dtype=torch.int32, device=dev)
         self.idx = torch.zeros((2, max(self.nq, 1)), dtype=torch.int64, device=dev)
@@ -92,20 +98,26 @@ class FlattenDecodeSession:
                                          *[self.md_ptrs[k] for k in _FIELDS], stream), "deft_tree_dev_build_md")
         Hq, Hkv, D = self.Hq, self.Hkv, self.D
         q0, k0, _ = self.qkv(0)
-        mdl = [self.md_ptrs[k] for k in ("block_q", "block_q_cnts", "block_q_offset", "block_bitmasks", "block_kv", "block_lens")]
         kv0 = self.pool.kv_data[0]
-        check(lib.deft_flatten_build_plan_dims(*mdl, self.NB, self.P, dt.scratch.data_ptr(), Hq, Hkv, q0.stride(0), D, kv0.stride(0),
-                                               self.cache_loc.data_ptr(), self.nq, k0.stride(0), self.plan.data_ptr(),
-                                               self.plan_bytes, stream), "deft_flatten_build_plan_dims")
         v_off = kv0.stride(1) * 2
+        if self.mode == "flatten":
+            mdl = [self.md_ptrs[k] for k in ("block_q", "block_q_cnts", "block_q_offset", "block_bitmasks", "block_kv", "block_lens")]
+            check(lib.deft_flatten_build_plan_dims(*mdl, self.NB, self.P, dt.scratch.data_ptr(), Hq, Hkv, q0.stride(0), D,
+                                                   kv0.stride(0), self.cache_loc.data_ptr(), self.nq, k0.stride(0),
+                                                   self.plan.data_ptr(), self.plan_bytes, stream), "deft_flatten_build_plan_dims")
+            fn, tail = lib.deft_flatten_decode_append_f16, (self.NB, self.P, self.nq, Hq, Hkv, D, 1.0 / (D ** 0.5))
+        else:
+            mdl = [self.md_ptrs[k] for k in ("node_kv", "node_kv_offset", "node_kv_len", "node_q", "node_q_offset", "node_q_len")]
+            check(lib.deft_node_build_plan_dims(*mdl, self.NE, self.PN, self.TKV, dt.scratch.data_ptr(), Hq, Hkv, q0.stride(0), D,
+                                                kv0.stride(0), self.cache_loc.data_ptr(), self.nq, k0.stride(0),
+                                                self.plan.data_ptr(), self.plan_bytes, stream), "deft_node_build_plan_dims")
+            fn, tail = lib.deft_node_decode_append_f16, (self.NE, self.PN, self.TKV, self.nq, Hq, Hkv, D, 1.0 / (D ** 0.5))
         for l in range(self.layers):
             q, k, v = self.qkv(l)
             kptr = self.pool.kv_data[l].data_ptr()
-            check(lib.deft_flatten_decode_append_f16(q.data_ptr(), q.stride(0), D, kptr, kptr + v_off, kv0.stride(0), kv0.stride(2),
-                                                     self.out[l].data_ptr(), Hq * D, D, *mdl, self.NB, self.P, self.nq, Hq, Hkv, D,
-                                                     1.0 / (D ** 0.5), self.cache_loc.data_ptr(), k.data_ptr(), v.data_ptr(),
-                                                     k.stride(0), self.nq, self.plan.data_ptr(), self.ws.data_ptr(), self.ws_bytes,
-                                                     stream), "deft_flatten_decode_append_f16")
+            check(fn(q.data_ptr(), q.stride(0), D, kptr, kptr + v_off, kv0.stride(0), kv0.stride(2), self.out[l].data_ptr(), Hq * D, D,
+                     *mdl, *tail, self.cache_loc.data_ptr(), k.data_ptr(), v.data_ptr(), k.stride(0), self.nq, self.plan.data_ptr(),
+                     self.ws.data_ptr(), self.ws_bytes, stream), "decode layer")
 
     # ---- per step ------------------------------------------------------------------------------------------
     def step(self) -> List[torch.Tensor]:
@@ -156,3 +168,11 @@ class FlattenDecodeSession:
         torch.cuda.current_stream(dev).wait_stream(side)
         self.graph = graph
         self.captures += 1
+
+
+class FlattenDecodeSession(DecodeSession):
+    """DeFT-Flatten (the north-star mode)."""
+
+    def __init__(self, *args, **kw) -> None:
+        kw["mode"] = "flatten"
+        super().__init__(*args, **kw)

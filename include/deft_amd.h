@@ -155,6 +155,15 @@ int deft_node_build_plan(
     const int32_t* cache_loc /* nullable */, int n_new, int64_t new_stride_tok,
     void* plan, size_t plan_bytes, void* stream);
 
+/* For metadata built on the device (see deft_flatten_build_plan_dims): NE, P, total_kv are capacities, dims[1] = this step's entries. */
+int deft_node_build_plan_dims(
+    const int64_t* node_kv, const int64_t* node_kv_offset, const int64_t* node_kv_len,
+    const int64_t* node_q, const int64_t* node_q_offset, const int64_t* node_q_len,
+    int NE, int P, int64_t total_kv, const int32_t* dims, int Hq, int Hkv,
+    int64_t q_stride_tok, int64_t q_stride_head, int64_t kv_stride_slot,
+    const int32_t* cache_loc /* nullable */, int n_new, int64_t new_stride_tok,
+    void* plan, size_t plan_bytes, void* stream);
+
 /*
  *   node_kv[total_kv]       pool slots of every entry, concatenated
  *   node_kv_offset/len[NE]  slice of node_kv per entry

@@ -18,8 +18,9 @@ def _mk(Hkv, D, layers, prefix, width, size):
     return tree, pool
 
 
+@pytest.mark.parametrize("mode", ["flatten", "node"])
 @pytest.mark.parametrize("use_graph", [True, False])
-def test_session_equals_eager_step_for_step(use_graph):
+def test_session_equals_eager_step_for_step(use_graph, mode):
     Hq, Hkv, D, layers, prefix, width = 8, 2, 128, 3, 700, 6
     g = torch.Generator(device="cuda").manual_seed(3)
     kv_init = torch.randn((layers, 4096, 2, Hkv, D), dtype=torch.float16, device="cuda", generator=g)
@@ -34,10 +35,10 @@ def test_session_equals_eager_step_for_step(use_graph):
     k = torch.randn((layers, cap, Hkv * D), dtype=torch.float16, device="cuda", generator=g)
     v = torch.randn((layers, cap, Hkv * D), dtype=torch.float16, device="cuda", generator=g)
     nq_now = [width]
-    sess = deft_amd.FlattenDecodeSession(ts, Hq, Hkv, D, layers, lambda l: (q[l, : nq_now[0]], k[l, : nq_now[0]], v[l, : nq_now[0]]),
-                                         use_graph=use_graph)
+    sess = deft_amd.DecodeSession(ts, Hq, Hkv, D, layers, lambda l: (q[l, : nq_now[0]], k[l, : nq_now[0]], v[l, : nq_now[0]]),
+                                  use_graph=use_graph, mode=mode)
     attn = [deft_amd.DeFTAttention(Hq, D, D ** -0.5, Hkv, l) for l in range(layers)]
-    mode = deft_amd.forward_mode_from_cli("flatten")
+    fmode = deft_amd.forward_mode_from_cli(mode)
 
     def both_steps(steps):
         for _ in range(steps):
@@ -47,7 +48,7 @@ def test_session_equals_eager_step_for_step(use_graph):
             upd = te.alloc()
             md = deft_amd.TreeMetadata.from_tree_cache(te)
             deft_amd.register_tree_metadata(md)
-            meta = deft_amd.InputMetadata(mode, upd, pe)
+            meta = deft_amd.InputMetadata(fmode, upd, pe)
             n = md.query_num
             nq_now[0] = n
             ref = [attn[l](q[l, :n], k[l, :n], v[l, :n], meta) for l in range(layers)]
