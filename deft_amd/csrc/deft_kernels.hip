@@ -1585,7 +1585,7 @@ int deft_tree_dev_build_md(int n_nodes, int nq, int nqw, const int32_t* node_sta
                            int max_block_len, int nbp_cap, void* scratch, size_t scratch_bytes, int64_t* node_q, int64_t* node_kv,
                            int64_t* node_q_len, int64_t* node_kv_len, int64_t* node_q_offset, int64_t* node_kv_offset,
                            int64_t* block_q, int64_t* block_q_cnts, int64_t* block_q_offset, int64_t* block_bitmasks,
-                           int64_t* block_kv, int64_t* block_lens, void* stream) {
+                           int64_t* block_kv, int64_t* block_lens, const int32_t* advance_loc, void* stream) {
     if (n_nodes <= 0 || nq < 0 || nqw < 1 || nbp_cap < 0 || !node_start || !node_len || !node_cap || !refs || !leaf_node || !slots ||
         !scratch || !node_q || !node_kv || !node_q_len || !node_kv_len || !node_q_offset || !node_kv_offset || !block_q ||
         !block_q_cnts || !block_q_offset || !block_bitmasks || !block_kv || !block_lens) {
@@ -1606,8 +1606,17 @@ int deft_tree_dev_build_md(int n_nodes, int nq, int nqw, const int32_t* node_sta
     TreeDev t{n_nodes, nq, nqw, node_start, node_len, node_cap, reinterpret_cast<const unsigned long long*>(refs), leaf_node, slots};
     TreeMdOut o{node_q, node_kv, node_q_len, node_kv_len, node_q_offset, node_kv_offset,
                 block_q, block_q_cnts, block_q_offset, block_bitmasks, block_kv, block_lens};
-    hipLaunchKernelGGL(tree_md_scan_kernel, dim3(1), dim3(1024), 0, st, t, sc, max_q_len, block_len, max_block_len, nbp_cap);
-    int rc = check_launch("tree scan launch");
+    // node tables in LDS when the tree fits: 6 x (n + 1) words + one per block
+    size_t scan_lds = 0;
+    if (n_nodes <= TREE_LDS_NODES) {
+        scan_lds = sizeof(int32_t) * 6 * ((size_t)n_nodes + 1);
+        if (nbp_cap <= TREE_LDS_BLOCKS) scan_lds += sizeof(int32_t) * ((size_t)nbp_cap + 1);
+    }
+    int rc = raise_lds(reinterpret_cast<const void*>(&tree_md_scan_kernel), 156 * 1024, ATTR_TREE, "tree_md_scan");
+    if (rc) return rc;
+    hipLaunchKernelGGL(tree_md_scan_kernel, dim3(1), dim3(1024), scan_lds, st, t, sc, max_q_len, block_len, max_block_len, nbp_cap,
+                       advance_loc);
+    rc = check_launch("tree scan launch");
     if (rc) return rc;
     if (nbp_cap > 0) {
         hipLaunchKernelGGL(tree_md_blocks_kernel, dim3((unsigned)nbp_cap), dim3(128), 0, st, t, sc, o, max_q_len, block_len);

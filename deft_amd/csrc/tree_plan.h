@@ -107,23 +107,69 @@ __device__ inline int refs_count(const unsigned long long* r, int nqw) {
     return c;
 }
 
+// One workgroup.  `adv` (cache_loc != null): first append this step's slots to the leaves (tree_advance_kernel's work,
+// folded in: one launch fewer per step).  The scans run over tables in LDS when the tree fits (TREE_LDS_NODES nodes,
+// TREE_LDS_BLOCKS blocks: every tree but a pathological one) -- a scan whose input and output live in global memory pays
+// an L2 round trip per phase, seven phases -- and the results are written out once at the end.
+constexpr int TREE_LDS_NODES = 4096;
+constexpr int TREE_LDS_BLOCKS = 8192;
+
 __global__ __launch_bounds__(1024) void tree_md_scan_kernel(TreeDev t, TreeScratch s, int max_q_len, int block_len,
-                                                            int max_block_len, int nbp_cap) {
+                                                            int max_block_len, int nbp_cap, const int32_t* cache_loc) {
     __shared__ int sWave[16];
     __shared__ int sCarry;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int n = t.n, nqw = t.nqw;
     const int tid = threadIdx.x;
-    auto qch = [&](int i) { return (refs_count(t.refs + (size_t)i * nqw, nqw) + max_q_len - 1) / max_q_len; };
+    if (cache_loc) {  // advance: one slot per live leaf, kept ascending inside the node
+        for (int r = tid; r < t.nq; r += 1024) {
+            const int i = t.leaf_node[r];
+            const int len = t.node_len[i];
+            if (len >= t.node_cap[i]) {
+                atomicOr(s.dims + TREE_ERR, 1);
+                continue;
+            }
+            int32_t* sl = t.slots + t.node_start[i];
+            const int32_t v = cache_loc[r];
+            int p = len;
+            while (p > 0 && sl[p - 1] > v) {
+                sl[p] = sl[p - 1];
+                --p;
+            }
+            sl[p] = v;
+            t.node_len[i] = len + 1;
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+    const bool in_lds = n <= TREE_LDS_NODES;
+    // tables: [n+1] each -- LDS when the tree fits, else the global scratch directly
+    int32_t* pos = in_lds ? reinterpret_cast<int32_t*>(smem) : s.pos;
+    int32_t* e_off = in_lds ? pos + (n + 1) : s.e_off;
+    int32_t* q_off = in_lds ? e_off + (n + 1) : s.q_off;
+    int32_t* kv_off = in_lds ? q_off + (n + 1) : s.kv_off;
+    int32_t* nlen = in_lds ? kv_off + (n + 1) : nullptr;   // node_len copy
+    int32_t* nqc = in_lds ? nlen + (n + 1) : nullptr;      // leaf count per node
+    if (in_lds) {
+        for (int i = tid; i < n; i += 1024) {
+            nlen[i] = t.node_len[i];
+            nqc[i] = refs_count(t.refs + (size_t)i * nqw, nqw);
+        }
+        __syncthreads();
+    }
+    auto len_of = [&](int i) { return in_lds ? nlen[i] : t.node_len[i]; };
+    auto nq_of = [&](int i) { return in_lds ? nqc[i] : refs_count(t.refs + (size_t)i * nqw, nqw); };
+    auto qch = [&](int i) { return (nq_of(i) + max_q_len - 1) / max_q_len; };
     auto kch = [&](int i) {
-        const int len = t.node_len[i];
+        const int len = len_of(i);
         const int step = max_block_len == -1 ? len : max_block_len;
         return step > 0 ? (len + step - 1) / step : 0;
     };
-    block_exclusive_scan(n, [&](int i) { return t.node_len[i]; }, s.pos, sWave, &sCarry);
-    block_exclusive_scan(n, [&](int i) { return qch(i) * kch(i); }, s.e_off, sWave, &sCarry);
-    block_exclusive_scan(n, [&](int i) { return refs_count(t.refs + (size_t)i * nqw, nqw) * kch(i); }, s.q_off, sWave, &sCarry);
-    block_exclusive_scan(n, [&](int i) { return t.node_len[i] * qch(i); }, s.kv_off, sWave, &sCarry);
-    const int total = s.pos[n];
+    block_exclusive_scan(n, [&](int i) { return len_of(i); }, pos, sWave, &sCarry);
+    block_exclusive_scan(n, [&](int i) { return qch(i) * kch(i); }, e_off, sWave, &sCarry);
+    block_exclusive_scan(n, [&](int i) { return nq_of(i) * kch(i); }, q_off, sWave, &sCarry);
+    block_exclusive_scan(n, [&](int i) { return len_of(i) * qch(i); }, kv_off, sWave, &sCarry);
+    const int total = pos[n];
     const int nbp = (total + block_len - 1) / block_len;
     if (nbp > nbp_cap) {
         if (tid == 0) {
@@ -132,6 +178,8 @@ __global__ __launch_bounds__(1024) void tree_md_scan_kernel(TreeDev t, TreeScrat
         }
         return;
     }
+    const bool blk_lds = in_lds && nbp <= TREE_LDS_BLOCKS;
+    int32_t* b_cnt = blk_lds ? nqc + (n + 1) : nullptr;  // [nbp] union size per block
     // physical blocks: first node with a slot in the block (largest i with pos[i] <= lo among nodes that have slots),
     // union of the leaf sets of its nodes
     for (int b = tid; b < nbp; b += 1024) {
@@ -139,27 +187,39 @@ __global__ __launch_bounds__(1024) void tree_md_scan_kernel(TreeDev t, TreeScrat
         int a = 0, z = n - 1;  // largest i with pos[i] <= lo
         while (a < z) {
             const int mid = (a + z + 1) >> 1;
-            if (s.pos[mid] <= lo) a = mid;
+            if (pos[mid] <= lo) a = mid;
             else z = mid - 1;
         }
-        while (a < n && s.pos[a + 1] <= lo) ++a;  // (skip empty nodes that share the position)
+        while (a < n && pos[a + 1] <= lo) ++a;  // (skip empty nodes that share the position)
         s.b_first[b] = a;
         unsigned long long* u = s.b_union + (size_t)b * nqw;
-        for (int w = 0; w < nqw; ++w) u[w] = 0ull;
-        for (int j = a; j < n && s.pos[j] < hi; ++j)
-            if (t.node_len[j] > 0)
-                for (int w = 0; w < nqw; ++w) u[w] |= t.refs[(size_t)j * nqw + w];
+        int cnt = 0;
+        for (int w = 0; w < nqw; ++w) {
+            unsigned long long acc = 0ull;
+            for (int j = a; j < n && pos[j] < hi; ++j)
+                if (len_of(j) > 0) acc |= t.refs[(size_t)j * nqw + w];
+            u[w] = acc;
+            cnt += __popcll(acc);
+        }
+        if (blk_lds) b_cnt[b] = cnt;
     }
     __syncthreads();
-    block_exclusive_scan(nbp, [&](int b) { return (refs_count(s.b_union + (size_t)b * nqw, nqw) + max_q_len - 1) / max_q_len; },
-                         s.b_eoff, sWave, &sCarry);
-    block_exclusive_scan(nbp, [&](int b) { return refs_count(s.b_union + (size_t)b * nqw, nqw); }, s.b_poff, sWave, &sCarry);
+    auto bcount = [&](int b) { return blk_lds ? b_cnt[b] : refs_count(s.b_union + (size_t)b * nqw, nqw); };
+    block_exclusive_scan(nbp, [&](int b) { return (bcount(b) + max_q_len - 1) / max_q_len; }, s.b_eoff, sWave, &sCarry);
+    block_exclusive_scan(nbp, [&](int b) { return bcount(b); }, s.b_poff, sWave, &sCarry);
+    if (in_lds)  // the node tables leave the LDS in one pass
+        for (int i = tid; i <= n; i += 1024) {
+            s.pos[i] = pos[i];
+            s.e_off[i] = e_off[i];
+            s.q_off[i] = q_off[i];
+            s.kv_off[i] = kv_off[i];
+        }
     if (tid == 0) {
         s.dims[0] = t.nq;
-        s.dims[1] = s.e_off[n];
+        s.dims[1] = e_off[n];
         s.dims[2] = total;
-        s.dims[3] = s.q_off[n];
-        s.dims[4] = s.kv_off[n];
+        s.dims[3] = q_off[n];
+        s.dims[4] = kv_off[n];
         s.dims[5] = s.b_eoff[nbp];
         s.dims[6] = s.b_poff[nbp];
         s.dims[7] = s.b_eoff[nbp] * block_len;

@@ -90,12 +90,11 @@ class DecodeSession:
         stream = torch.cuda.current_stream(dev).cuda_stream
         table = self.tree.req_to_token_pool.req_to_token
         table[self.idx[0], self.idx[1]] = self.cache_loc  # page table rows of this step's tokens
-        if advance:
-            check(lib.deft_tree_dev_advance(*dt._tree_args(), self.cache_loc.data_ptr(), dt.scratch.data_ptr(), stream),
-                  "deft_tree_dev_advance")
         mq, bl, mbl = dt.cfg
+        # (the append of this step's slots to the device tree rides in the first metadata kernel)
         check(lib.deft_tree_dev_build_md(*dt._tree_args(), mq, bl, mbl, dt.nbp_cap, dt.scratch.data_ptr(), dt.scratch_bytes,
-                                         *[self.md_ptrs[k] for k in _FIELDS], stream), "deft_tree_dev_build_md")
+                                         *[self.md_ptrs[k] for k in _FIELDS], self.cache_loc.data_ptr() if advance else None, stream),
+              "deft_tree_dev_build_md")
         Hq, Hkv, D = self.Hq, self.Hkv, self.D
         q0, k0, _ = self.qkv(0)
         kv0 = self.pool.kv_data[0]

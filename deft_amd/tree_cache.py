@@ -606,7 +606,7 @@ class _DeviceTree:
             off += self.cap_lens[k]
         stream = torch.cuda.current_stream(self.device).cuda_stream
         check(lib.deft_tree_dev_build_md(*self._tree_args(), mq, bl, mbl, self.nbp_cap, self.scratch.data_ptr(),
-                                         self.scratch_bytes, *ptrs, stream), "deft_tree_dev_build_md")
+                                         self.scratch_bytes, *ptrs, None, stream), "deft_tree_dev_build_md")
         leaf_ids = np.empty(max(int(sizes[0]), 1), dtype=np.int64)
         nl = int(lib.deft_tree_leaf_ids(t._native, _ptr(leaf_ids), len(leaf_ids)))
         views.update(query_num=int(sizes[0]), node_num=int(sizes[1]), total_kv_len=int(sizes[2]),

@@ -24,6 +24,8 @@ from ..tree_cache import TreeCache
 GEOMETRY: Dict[str, Tuple[int, int, int, int]] = {
     "llama2-7b": (32, 32, 128, 32),
     "llama3-8b": (32, 8, 128, 32),
+    # a head_dim-64 geometry (GPT-2-XL / Pythia-class heads) for the tile-per-workgroup kernel that serves head dims < 128
+    "mha-d64": (32, 32, 64, 32),
 }
 
 
@@ -57,6 +59,8 @@ WORKLOADS: Dict[str, Workload] = {
     # one GPU's share = 8 trees, decoded as ONE batch; and a single tree of the same shape for comparison
     "forest_8kx8": Workload("forest_8kx8", "llama3-8b", "flatten", "few_shot", 8192, 8, 64, 8),
     "forest_8kx8_single": Workload("forest_8kx8_single", "llama3-8b", "flatten", "few_shot", 8192, 8, 64),
+    # head_dim 64 (not a Llama geometry; measured once so the number exists): the north-star tree shape
+    "northstar_4kx32_d64": Workload("northstar_4kx32_d64", "mha-d64", "flatten", "few_shot", 4096, 32, 200),
 }
 
 

@@ -358,7 +358,8 @@ int64_t deft_tree_build_md(int64_t tree, int max_q_len, int block_len, int max_b
  *   deft_tree_md_sizes      sizes of the metadata for the current lengths + `grow` tokens per leaf: sizes[0..7] as
  *                           deft_md_sizes, sizes[8] = physical 128-slot blocks (capacity planning and tensor shapes; no slot touched)
  *   deft_tree_dev_advance   device: append cache_loc[r] to query row r's leaf (kept ascending inside the node)
- *   deft_tree_dev_build_md  device: the twelve int64 arrays of TreeMetadata, bit for bit deft_md_build's
+ *   deft_tree_dev_build_md  device: the twelve int64 arrays of TreeMetadata, bit for bit deft_md_build's; with `advance_loc`
+ *                           (this step's cache_loc, nullable) the append of deft_tree_dev_advance is folded into its first kernel
  */
 int deft_tree_layout(int64_t tree, int slack, int64_t sizes[5]);
 int deft_tree_layout_fetch(int64_t tree, int32_t* node_start, int32_t* node_len, int32_t* node_cap, uint64_t* refs,
@@ -373,7 +374,7 @@ int deft_tree_dev_build_md(int n_nodes, int nq, int nqw, const int32_t* node_sta
                            int max_block_len, int nbp_cap, void* scratch, size_t scratch_bytes, int64_t* node_q, int64_t* node_kv,
                            int64_t* node_q_len, int64_t* node_kv_len, int64_t* node_q_offset, int64_t* node_kv_offset,
                            int64_t* block_q, int64_t* block_q_cnts, int64_t* block_q_offset, int64_t* block_bitmasks,
-                           int64_t* block_kv, int64_t* block_lens, void* stream);
+                           int64_t* block_kv, int64_t* block_lens, const int32_t* advance_loc /* nullable */, void* stream);
 
 #ifdef __cplusplus
 }
