@@ -77,6 +77,15 @@ lib.deft_node_decode_f16.restype = C.c_int
 lib.deft_node_decode_append_f16.argtypes = (_QKV + _OUT + _MD6 + [_i32, _i32, _i64, _i32, _i32, _i32, _i32, _f32]
                                             + [_vp, _vp, _vp, _i64, _i32] + [_vp, _vp, _sz, _vp])
 lib.deft_node_decode_append_f16.restype = C.c_int
+_ROPE = [_vp, _i32, _i32]  # cos_sin_rows, rotary_dim, is_neox_style
+lib.deft_flatten_decode_rope_append_f16.argtypes = (_QKV + _OUT + _MD6 + [_i32] * 6 + [_f32] + [_vp, _vp, _vp, _i64, _i32] + _ROPE
+                                                    + [_vp, _vp, _sz, _vp])
+lib.deft_flatten_decode_rope_append_f16.restype = C.c_int
+lib.deft_node_decode_rope_append_f16.argtypes = (_QKV + _OUT + _MD6 + [_i32, _i32, _i64, _i32, _i32, _i32, _i32, _f32]
+                                                 + [_vp, _vp, _vp, _i64, _i32] + _ROPE + [_vp, _vp, _sz, _vp])
+lib.deft_node_decode_rope_append_f16.restype = C.c_int
+lib.deft_rope_gather_rows.argtypes = [_vp, _vp, _i64, _i32, _i32, _vp, _vp]
+lib.deft_rope_gather_rows.restype = C.c_int
 lib.deft_prefill_f16.argtypes = [_vp, _i64, _i64] * 4 + [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp]
 lib.deft_prefill_f16.restype = C.c_int
 lib.deft_rope_qk_f16.argtypes = [_vp, _i64, _i64, _i32, _vp, _i64, _i64, _i32, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]
@@ -142,7 +151,7 @@ EXPORTED = (
     "deft_flatten_workspace_bytes", "deft_flatten_plan_bytes", "deft_flatten_build_plan", "deft_flatten_build_plan_dims",
     "deft_flatten_decode_f16", "deft_flatten_decode_append_f16", "deft_flatten_stage1_f16",
     "deft_flatten_read_partials", "deft_node_workspace_bytes", "deft_node_plan_bytes", "deft_node_build_plan", "deft_node_build_plan_dims",
-    "deft_node_decode_f16", "deft_node_decode_append_f16",
+    "deft_node_decode_f16", "deft_node_decode_append_f16", "deft_flatten_decode_rope_append_f16", "deft_node_decode_rope_append_f16", "deft_rope_gather_rows",
     "deft_prefill_f16", "deft_rope_qk_f16", "deft_seq_plan_bytes", "deft_seq_workspace_bytes", "deft_seq_build_plan", "deft_seq_decode_f16", "deft_seq_decode_append_f16",
     "deft_kv_append_f16", "deft_md_build", "deft_md_sizes", "deft_md_fetch", "deft_md_free",
     "deft_tree_create",

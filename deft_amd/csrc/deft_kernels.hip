@@ -456,7 +456,7 @@ static int num_cus() {
     return d.cus;
 }
 enum : unsigned { ATTR_NP = 4,  // (bits 0-1, 8-11: the head_dim 64 / 32 / 16 kernels)
-                  ATTR_UNITS = 8, ATTR_NODE_UNITS = 16, ATTR_PREFILL = 32, ATTR_TREE = 64 };
+                  ATTR_UNITS = 8, ATTR_NODE_UNITS = 16, ATTR_PREFILL = 32, ATTR_TREE = 64, ATTR_NP_ROPE = 128 };
 static int raise_lds(const void* fn, int bytes, unsigned bit, const char* what) {  // idempotent; races are harmless
     DeviceState& d = dev_state();
     if (d.attrs & bit) return DEFT_OK;
@@ -501,6 +501,8 @@ struct AppendArgs {
     const int32_t* cache_loc = nullptr;
     int64_t new_st = 0;
     int n_new = 0;
+    // fused rotary embedding (optional, with the fused append only): cos | sin row of every new token, [n_new][D] fp32
+    const float* cos_sin = nullptr;
 };
 
 static UnitList unit_list(const PlanView& pv) {
@@ -581,7 +583,9 @@ static int launch_plan(const Stage1Params& p, int NB, const PlanView& pv, const 
 static int launch_stage1_np(const Stage1Params& p, int64_t unit_cap, const PlanView& pv, const AppendArgs& ap,
                             hipStream_t stream) {
     using SM = NpSmem<128>;
-    int rc = raise_lds(reinterpret_cast<const void*>(&stage1_np_kernel<128>), SM::BYTES, ATTR_NP, "stage1_np");
+    const bool rope = ap.cos_sin != nullptr;
+    int rc = rope ? raise_lds(reinterpret_cast<const void*>(&stage1_np_kernel<128, true>), SM::BYTES, ATTR_NP_ROPE, "stage1_np_rope")
+                  : raise_lds(reinterpret_cast<const void*>(&stage1_np_kernel<128, false>), SM::BYTES, ATTR_NP, "stage1_np");
     if (rc) return rc;
     if (unit_cap <= 0) return DEFT_OK;
     int64_t grid = unit_cap * p.Hkv;
@@ -616,7 +620,9 @@ static int launch_stage1_np(const Stage1Params& p, int64_t unit_cap, const PlanV
     npp.new_st = ap.new_st;
     npp.n_new = ap.k_new ? ap.n_new : 0;
     npp.dbg = g_dbg;
-    hipLaunchKernelGGL((stage1_np_kernel<128>), dim3((unsigned)grid), dim3(256), SM::BYTES, stream, npp);
+    npp.cos_sin = ap.cos_sin;
+    if (rope) hipLaunchKernelGGL((stage1_np_kernel<128, true>), dim3((unsigned)grid), dim3(256), SM::BYTES, stream, npp);
+    else hipLaunchKernelGGL((stage1_np_kernel<128, false>), dim3((unsigned)grid), dim3(256), SM::BYTES, stream, npp);
     return check_launch("stage1 np launch");
 }
 
@@ -722,6 +728,27 @@ static int check_append(const AppendArgs& ap, int Hkv, int D) {
         set_error("bad fused-append arguments (n_new=%d new_stride=%lld)", ap.n_new, (long long)ap.new_st);
         return DEFT_EINVAL;
     }
+    return DEFT_OK;
+}
+
+// Fused rotary embedding (the *_rope_append_* entry points): NeoX pairing over the whole head, head_dim 128 (the
+// tile-parallel kernel), token-major q so that a virtual row's query index is its element offset / q_stride_tok.
+static int fill_rope(AppendArgs& ap, const float* cos_sin_rows, int rotary_dim, int is_neox_style, int64_t q_st,
+                     int64_t q_sh, int Hq, int D) {
+    if (!cos_sin_rows || !aligned16(cos_sin_rows)) {
+        set_error("bad fused-rope arguments (cos_sin_rows: [n_new][head_dim] fp32, 16-byte aligned)");
+        return DEFT_EINVAL;
+    }
+    if (D != 128 || rotary_dim != D || !is_neox_style) {
+        set_error("fused rope: head_dim 128, rotary_dim == head_dim, NeoX pairing (got D=%d rotary_dim=%d neox=%d); "
+                  "use deft_rope_qk_f16 + the append entry point", D, rotary_dim, is_neox_style);
+        return DEFT_EUNSUPPORTED;
+    }
+    if (q_st <= 0 || q_st > 0x7fffffffLL || (int64_t)(Hq - 1) * q_sh + D > q_st || q_sh < 0) {
+        set_error("fused rope needs token-major q (q_stride_tok=%lld q_stride_head=%lld)", (long long)q_st, (long long)q_sh);
+        return DEFT_EUNSUPPORTED;
+    }
+    ap.cos_sin = cos_sin_rows;
     return DEFT_OK;
 }
 
@@ -946,6 +973,31 @@ int deft_flatten_decode_append_f16(const void* q, int64_t q_stride_tok, int64_t 
         set_error("fused append needs k_new, v_new and cache_loc");
         return DEFT_EINVAL;
     }
+    return flatten_decode_impl(q, q_stride_tok, q_stride_head, k_base, v_base, kv_stride_slot, kv_stride_head, out,
+                               o_stride_tok, o_stride_head, block_q, block_q_cnts, block_q_offset, block_bitmasks, block_kv,
+                               block_lens, NB, P, nq, Hq, Hkv, D, scale, plan, workspace, workspace_bytes, stream, ap);
+}
+
+int deft_flatten_decode_rope_append_f16(const void* q, int64_t q_stride_tok, int64_t q_stride_head, void* k_base, void* v_base,
+                                        int64_t kv_stride_slot, int64_t kv_stride_head, void* out, int64_t o_stride_tok,
+                                        int64_t o_stride_head, const int64_t* block_q, const int64_t* block_q_cnts,
+                                        const int64_t* block_q_offset, const int64_t* block_bitmasks, const int64_t* block_kv,
+                                        const int64_t* block_lens, int NB, int P, int nq, int Hq, int Hkv, int D, float scale,
+                                        const int32_t* cache_loc, const void* k_new, const void* v_new, int64_t new_stride_tok,
+                                        int n_new, const float* cos_sin_rows, int rotary_dim, int is_neox_style,
+                                        const void* plan, void* workspace, size_t workspace_bytes, void* stream) {
+    AppendArgs ap;
+    ap.k_new = static_cast<const _Float16*>(k_new);
+    ap.v_new = static_cast<const _Float16*>(v_new);
+    ap.cache_loc = cache_loc;
+    ap.new_st = new_stride_tok;
+    ap.n_new = n_new;
+    if (!k_new || !v_new || !cache_loc) {
+        set_error("fused append needs k_new, v_new and cache_loc");
+        return DEFT_EINVAL;
+    }
+    const int rc = fill_rope(ap, cos_sin_rows, rotary_dim, is_neox_style, q_stride_tok, q_stride_head, Hq, D);
+    if (rc) return rc;
     return flatten_decode_impl(q, q_stride_tok, q_stride_head, k_base, v_base, kv_stride_slot, kv_stride_head, out,
                                o_stride_tok, o_stride_head, block_q, block_q_cnts, block_q_offset, block_bitmasks, block_kv,
                                block_lens, NB, P, nq, Hq, Hkv, D, scale, plan, workspace, workspace_bytes, stream, ap);
@@ -1177,6 +1229,32 @@ int deft_node_decode_append_f16(const void* q, int64_t q_stride_tok, int64_t q_s
         set_error("fused append needs k_new, v_new and cache_loc");
         return DEFT_EINVAL;
     }
+    return node_decode_impl(q, q_stride_tok, q_stride_head, k_base, v_base, kv_stride_slot, kv_stride_head, out,
+                            o_stride_tok, o_stride_head, node_kv, node_kv_offset, node_kv_len, node_q, node_q_offset,
+                            node_q_len, NE, P, total_kv, nq, Hq, Hkv, D, scale, plan, workspace, workspace_bytes, stream, ap);
+}
+
+int deft_node_decode_rope_append_f16(const void* q, int64_t q_stride_tok, int64_t q_stride_head, void* k_base, void* v_base,
+                                     int64_t kv_stride_slot, int64_t kv_stride_head, void* out, int64_t o_stride_tok,
+                                     int64_t o_stride_head, const int64_t* node_kv, const int64_t* node_kv_offset,
+                                     const int64_t* node_kv_len, const int64_t* node_q, const int64_t* node_q_offset,
+                                     const int64_t* node_q_len, int NE, int P, int64_t total_kv, int nq, int Hq, int Hkv, int D,
+                                     float scale, const int32_t* cache_loc, const void* k_new, const void* v_new,
+                                     int64_t new_stride_tok, int n_new, const float* cos_sin_rows, int rotary_dim,
+                                     int is_neox_style, const void* plan, void* workspace, size_t workspace_bytes,
+                                     void* stream) {
+    AppendArgs ap;
+    ap.k_new = static_cast<const _Float16*>(k_new);
+    ap.v_new = static_cast<const _Float16*>(v_new);
+    ap.cache_loc = cache_loc;
+    ap.new_st = new_stride_tok;
+    ap.n_new = n_new;
+    if (!k_new || !v_new || !cache_loc) {
+        set_error("fused append needs k_new, v_new and cache_loc");
+        return DEFT_EINVAL;
+    }
+    const int rc = fill_rope(ap, cos_sin_rows, rotary_dim, is_neox_style, q_stride_tok, q_stride_head, Hq, D);
+    if (rc) return rc;
     return node_decode_impl(q, q_stride_tok, q_stride_head, k_base, v_base, kv_stride_slot, kv_stride_head, out,
                             o_stride_tok, o_stride_head, node_kv, node_kv_offset, node_kv_len, node_q, node_q_offset,
                             node_q_len, NE, P, total_kv, nq, Hq, Hkv, D, scale, plan, workspace, workspace_bytes, stream, ap);
@@ -1466,6 +1544,30 @@ extern "C" int deft_rope_qk_f16(void* q, int64_t q_stride_tok, int64_t q_stride_
                        static_cast<_Float16*>(k), k_stride_tok, k_stride_head, Hk, positions, cos_sin_cache, cache_stride, n,
                        D, rotary_dim, is_neox_style ? 1 : 0);
     return deft::check_launch("rope launch");
+}
+
+namespace deft {
+__global__ __launch_bounds__(256) void rope_gather_kernel(const int64_t* positions, const float* cos_sin, int64_t cache_stride,
+                                                         int n, int rot, float* out) {
+    const int64_t total = (int64_t)n * rot;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / rot), j = (int)(i - (int64_t)r * rot);
+        out[i] = cos_sin[positions[r] * cache_stride + j];
+    }
+}
+}  // namespace deft
+
+extern "C" int deft_rope_gather_rows(const int64_t* positions, const float* cos_sin_cache, int64_t cache_stride, int n,
+                                     int rotary_dim, float* rows_out, void* stream) {
+    if (n == 0) return DEFT_OK;
+    if (!positions || !cos_sin_cache || !rows_out || n < 0 || rotary_dim <= 0 || cache_stride < rotary_dim) {
+        set_error("bad rope-gather arguments (n=%d rotary_dim=%d)", n, rotary_dim);
+        return DEFT_EINVAL;
+    }
+    const int64_t blocks = ((int64_t)n * rotary_dim + 255) / 256;
+    hipLaunchKernelGGL(deft::rope_gather_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), positions, cos_sin_cache, cache_stride, n, rotary_dim, rows_out);
+    return deft::check_launch("rope gather launch");
 }
 
 

@@ -45,7 +45,40 @@ struct NpParams {
     int64_t new_st;
     int n_new;
     unsigned long long* dbg;  // internal: per-workgroup wall-clock stamps [workgroup][8], or null
+    // fused rotary embedding (stage1_np_kernel<D, true>; NeoX pairing over the whole head_dim): q rows are rotated as they
+    // become MFMA fragments, this step's k rows on their way into the pool and inside the tiles that read them from k_new
+    const float* cos_sin;  // [n_new][D] fp32: cos(D/2) | sin(D/2) of new row j = query row j (deft_rope_gather_rows)
 };
+
+// o1 = x1 cos - x2 sin, o2 = x2 cos + x1 sin in fp32 without FMA contraction, one rounding to fp16: the arithmetic of
+// rope_qk_kernel (deft_kernels.hip) and of oracle/rope.py, so that the fused form is bit-identical to rope + decode.
+__device__ __forceinline__ void rope_pair(float x1, float x2, float cs, float sn, _Float16& o1, _Float16& o2) {
+#pragma clang fp contract(off)
+    const float a = x1 * cs, b = x2 * sn, c = x2 * cs, d = x1 * sn;
+    o1 = (_Float16)(a - b);
+    o2 = (_Float16)(c + d);
+}
+
+// One 16-byte chunk (8 halves at d = 8 ch ..) of a row rotated against its partner chunk ch ^ 8 (d +- D/2):
+// cs = cos values of d & (D/2 - 1), sn = the sines.
+__device__ __forceinline__ uintx4 rope_chunk(uintx4 own_u, uintx4 par_u, bool first_half, floatx4 c0, floatx4 c1, floatx4 s0,
+                                             floatx4 s1) {
+    union {
+        uintx4 u;
+        half8 h8;
+    } own, par, res;
+    own.u = own_u;
+    par.u = par_u;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float cs = e < 4 ? c0[e & 3] : c1[e & 3], sn = e < 4 ? s0[e & 3] : s1[e & 3];
+        _Float16 o1, o2;
+        if (first_half) rope_pair((float)own.h8[e], (float)par.h8[e], cs, sn, o1, o2);
+        else rope_pair((float)par.h8[e], (float)own.h8[e], cs, sn, o2, o1);
+        res.h8[e] = o1;
+    }
+    return res.u;
+}
 
 template <int D>
 struct NpSmem {
@@ -72,7 +105,7 @@ struct NpSmem {
 #define DBG ((unsigned long long*)nullptr)
 #endif
 
-template <int D>
+template <int D, bool ROPE>
 __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
     constexpr int KS = D / 16;
     constexpr int LPT = 32 * (D / 8) / 64;  // DMA instructions per wave per K (or V) slice
@@ -95,12 +128,31 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
     for (int copy_job = W - 1 - bid; copy_job < np.n_new; copy_job += W) {
         const int64_t dst = (int64_t)np.cache_loc[copy_job] * p.kv_ss;
         const int chunks = p.Hkv * (D / 8);
+        const float* cs_row = nullptr;
+        if constexpr (ROPE) cs_row = np.cos_sin + (int64_t)copy_job * D;
         for (int i = tid; i < chunks; i += blockDim.x) {
             const int hd = i / (D / 8), ch = i - hd * (D / 8);
             const int64_t so = (int64_t)copy_job * np.new_st + hd * D + ch * 8;
             const int64_t d_o = dst + (int64_t)hd * p.kv_sh + ch * 8;
-            const uintx4 kk = *reinterpret_cast<const uintx4*>(np.k_new + so);
+            uintx4 kk = *reinterpret_cast<const uintx4*>(np.k_new + so);
             const uintx4 vv = *reinterpret_cast<const uintx4*>(np.v_new + so);
+            if constexpr (ROPE) {  // the k row enters the pool rotated: chunk ch pairs with chunk ch ^ 8 (d, d + D/2)
+                union {
+                    uintx4 u;
+                    half8 h8;
+                } own, par, res;
+                own.u = kk;
+                par.u = *reinterpret_cast<const uintx4*>(np.k_new + so + (ch < D / 16 ? D / 2 : -(D / 2)));
+                const float* cs = cs_row + 8 * (ch & (D / 16 - 1));
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    _Float16 o1, o2;
+                    if (ch < D / 16) rope_pair((float)own.h8[e], (float)par.h8[e], cs[e], cs[D / 2 + e], o1, o2);
+                    else rope_pair((float)par.h8[e], (float)own.h8[e], cs[e], cs[D / 2 + e], o2, o1);
+                    res.h8[e] = o1;
+                }
+                kk = res.u;
+            }
             *reinterpret_cast<uintx4*>(const_cast<_Float16*>(p.k) + d_o) = kk;
             *reinterpret_cast<uintx4*>(const_cast<_Float16*>(p.v) + d_o) = vv;
         }
@@ -223,6 +275,29 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
     // ---- prologue: aux(0) -> Q, K(0), aux(1), V(0) -----------------------------------------------------
     wait_vm<0>();
     load_rowoff(0);
+    // fused rotary embedding of Q: every wave rotates, in LDS, the 8 rows it stages itself -- lane (dpos, dkey) owns
+    // position dpos of rows 8 w + dkey and 8 w + 4 + dkey, i.e. source chunk dpos ^ (row & 15), partner chunk at position
+    // dpos ^ 8 -- before the barrier that publishes the rows.  The cos | sin values of its two chunks are plain loads
+    // issued IN FRONT of the Q / K / V DMA (older, so they have landed when K(0) has; the compiler's own wait at their first
+    // use also drains V(0) and aux(1), which makes the counted waits of the first tile conservative).  Measured against
+    // inline-asm loads + a counted wait that lets the rotation run while K(0) / V(0) are in flight: that form was 0.3-0.9 us
+    // per layer faster on the small trees and 1.6 us SLOWER on the north-star tree (tools/rope_fused_ab.py); not kept.
+    floatx4 rq[ROPE ? 8 : 1];
+    if constexpr (ROPE) {
+        const int32_t* qs = reinterpret_cast<const int32_t*>(smem + aux0 + 256 + 128);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = 8 * w + 4 * i + dkey;
+            const int ch = dpos ^ (row & 15);
+            const int qrow = qs[row] / (int)p.q_st;
+            const float* cs = np.cos_sin + (int64_t)qrow * D + 8 * (ch & 7);
+            rq[4 * i + 0] = *reinterpret_cast<const floatx4*>(cs);
+            rq[4 * i + 1] = *reinterpret_cast<const floatx4*>(cs + 4);
+            rq[4 * i + 2] = *reinterpret_cast<const floatx4*>(cs + D / 2);
+            rq[4 * i + 3] = *reinterpret_cast<const floatx4*>(cs + D / 2 + 4);
+        }
+    }
+
     issue_q();
     issue_k();
     if (n > 1) issue_aux(1, 1);
@@ -236,18 +311,76 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[b][r] = 0.f;
 
+    if constexpr (ROPE) {
+        // Q rows are rotated and the fragments built in front of the tile loop (the cos / sin registers die here).
+        if (n > 1) wait_vm<LPT + 2>();  // K(0) landed, hence this wave's Q rows
+        else wait_vm<LPT>();
+        if (DBG) t_k0 = wall_clock64();
+        {
+            uintx4 own[2], par[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const char* rowp = smem + SM::Q_OFF + (8 * w + 4 * i + dkey) * 256;
+                own[i] = *reinterpret_cast<const uintx4*>(rowp + dpos * 16);
+                par[i] = *reinterpret_cast<const uintx4*>(rowp + (dpos ^ 8) * 16);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every lane has read before any lane writes
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row = 8 * w + 4 * i + dkey;
+                const int ch = dpos ^ (row & 15);
+                *reinterpret_cast<uintx4*>(smem + SM::Q_OFF + row * 256 + dpos * 16) =
+                    rope_chunk(own[i], par[i], ch < 8, rq[4 * i], rq[4 * i + 1], rq[4 * i + 2], rq[4 * i + 3]);
+            }
+        }
+        lds_barrier();  // rotated Q rows of all four waves visible
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+            qf[ks] = *reinterpret_cast<const half8*>(smem + SM::Q_OFF + c * D * 2 + (((2 * ks + h) ^ (c & 15)) * 16));
+    }
     for (int i = 0; i < n; ++i) {
         const bool has1 = i + 1 < n, has2 = i + 2 < n;
         const int slot = i & 1;
         // ---- K(i) (and Q) landed: younger than it are aux(i+1) [2] and V(i) [8] -------------------------
         if (has1) wait_vm<LPT + 2>();
         else wait_vm<LPT>();
-        if (i == 0) {
+        if (!ROPE && i == 0) {
             if (DBG) t_k0 = wall_clock64();
             lds_barrier();  // Q rows of all four waves visible
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
                 qf[ks] = *reinterpret_cast<const half8*>(smem + SM::Q_OFF + c * D * 2 + (((2 * ks + h) ^ (c & 15)) * 16));
+        }
+        if constexpr (ROPE) {
+            // rows of this wave's K slice that came from k_new (this step's tokens) are rotated in LDS before QK^T:
+            // lane (dpos, dkey) of DMA piece j owns the 16 bytes at position dpos of row 4 j + dkey, i.e. source chunk
+            // dpos ^ (row & 15); its partner chunk (d +- 64) sits at position dpos ^ 8 of the same row.
+            bool mine_new = false;
+#pragma unroll
+            for (int j = 0; j < LPT; ++j) mine_new |= rowoff[j] < 0;
+            if (__builtin_amdgcn_ballot_w64(mine_new) != 0ull) {
+                // (rare -- the tiles that hold this step's tokens: a real loop over the eight DMA pieces, offsets re-read
+                //  from this tile's aux slot, so that no registers of the tile loop are spent on it)
+                const int64_t* ro = reinterpret_cast<const int64_t*>(smem + aux0 + slot * SM::AUX_SLOT);
+#pragma unroll 1
+                for (int j = 0; j < LPT; ++j) {
+                    const int64_t ro_j = ro[4 * j + dkey];
+                    if (ro_j < 0) {
+                        char* rowp = smem + ldsK + j * 1024 + dkey * 256;
+                        const uintx4 own = *reinterpret_cast<const uintx4*>(rowp + dpos * 16);
+                        const uintx4 par = *reinterpret_cast<const uintx4*>(rowp + (dpos ^ 8) * 16);
+                        const int ch = dpos ^ ((4 * (j & 3) + dkey) & 15);
+                        const uint32_t new_idx = (uint32_t)(ro_j & ~NEW_ROW) / (uint32_t)(np.new_st * 2);
+                        const float* cs =
+                            np.cos_sin + (int64_t)new_idx * D + 8 * (ch & 7);
+                        const floatx4 c0 = *reinterpret_cast<const floatx4*>(cs), c1 = *reinterpret_cast<const floatx4*>(cs + 4);
+                        const floatx4 s0 = *reinterpret_cast<const floatx4*>(cs + D / 2);
+                        const floatx4 s1 = *reinterpret_cast<const floatx4*>(cs + D / 2 + 4);
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // both reads of every lane before any write
+                        *reinterpret_cast<uintx4*>(rowp + dpos * 16) = rope_chunk(own, par, ch < 8, c0, c1, s0, s1);
+                    }
+                }
+            }
         }
         // key masks of this lane's 16 keys (keys 8 g4 + 4 h + j of the wave's 32)
         uintx4 m4[4];

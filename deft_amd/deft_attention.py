@@ -28,6 +28,7 @@ from .tree_attention import (flatten_append_attention, node_append_attention, tr
 from .tree_cache import get_global_tree_metadata
 
 
+ROPE_FUSE_MAX_KV_BYTES = 24 << 20  # DeFTAttention.forward(fuse_rope=None): fuse the rotary embedding below this much KV per layer
 FUSED_APPEND = True  # False: store_kv_cache (its own launch), then the operator -- the reference's two-call form, for A/B
 
 
@@ -74,6 +75,7 @@ class _DecodeStep:
             self.ws_bytes = lib.deft_flatten_workspace_bytes(self.NB, self.P, self.nq, Hq, Hkv, D)
             self.tail = (self.NB, self.P, self.nq, Hq, Hkv, D, self.scale)
             self.fn = lib.deft_flatten_decode_append_f16
+            self.fn_rope = lib.deft_flatten_decode_rope_append_f16
         else:
             mdl = [md.node_kv, md.node_kv_offset, md.node_kv_len, md.node_q, md.node_q_offset, md.node_q_len]
             NE, P, total = md.node_kv_offset.shape[0], md.node_q.shape[0], md.node_kv.shape[0]
@@ -82,6 +84,7 @@ class _DecodeStep:
             self.ws_bytes = lib.deft_node_workspace_bytes(NE, P, total, self.nq, Hq, Hkv, D)
             self.tail = (NE, P, total, self.nq, Hq, Hkv, D, self.scale)
             self.fn = lib.deft_node_decode_append_f16
+            self.fn_rope = lib.deft_node_decode_rope_append_f16
         for t in mdl:
             if t.dtype != torch.int64 or not t.is_cuda or not t.is_contiguous():
                 raise TypeError("TreeMetadata arrays must be contiguous int64 CUDA tensors")
@@ -90,13 +93,16 @@ class _DecodeStep:
         self.cache_loc_ptr = cache_loc.data_ptr()
         self.plan_ptr = self.plan.data_ptr()
         self.ws = {}  # raw stream -> workspace (calls on one stream are ordered; streams must not share scratch)
+        self._rope_key, self._rope_rows = None, None
 
     def matches(self, mode, md, pool, cache_loc, q, k) -> bool:
         return (mode is self.mode and md is self.md and pool is self.pool and cache_loc is self.cache_loc
                 and tensor_version(cache_loc) == self.cache_loc_version and tuple(q.shape) == self.q_shape
                 and q.stride(0) == self.q_stride and k.stride(0) == self.k_stride and q.dtype == torch.float16)
 
-    def run(self, layer_id: int, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
+    def run(self, layer_id: int, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, rope=None) -> torch.Tensor:
+        """`rope` = (positions int64 [nq], cos_sin_cache fp32 [max_pos][rotary_dim], rotary_dim, is_neox_style): q and k are
+        the UNROTATED rows; the rotation happens inside the stage-1 launch (deft_*_decode_rope_append_f16)."""
         Hq, D = self.Hq, self.D
         if q.stride(1) != 1 or k.stride(1) != 1 or v.stride(1) != 1 or v.stride(0) != self.k_stride or k.dtype != torch.float16:
             raise ValueError("q / k / v rows must be contiguous fp16, k and v with the same row stride")
@@ -106,12 +112,32 @@ class _DecodeStep:
         if ws is None:
             ws = self.ws[stream] = torch.empty(max(self.ws_bytes, 1), dtype=torch.uint8, device=self.device)
         kptr = self.layer_ptrs[layer_id]
-        rc = self.fn(q.data_ptr(), self.q_stride, D, kptr, kptr + self.v_off_bytes, self.kv_ss, self.kv_sh,
-                     o.data_ptr(), Hq * D, D, *self.md_ptrs, *self.tail,
-                     self.cache_loc_ptr, k.data_ptr(), v.data_ptr(), self.k_stride, self.n_new,
-                     self.plan_ptr, ws.data_ptr(), self.ws_bytes, stream)
+        head = (q.data_ptr(), self.q_stride, D, kptr, kptr + self.v_off_bytes, self.kv_ss, self.kv_sh,
+                o.data_ptr(), Hq * D, D, *self.md_ptrs, *self.tail,
+                self.cache_loc_ptr, k.data_ptr(), v.data_ptr(), self.k_stride, self.n_new)
+        if rope is None:
+            rc = self.fn(*head, self.plan_ptr, ws.data_ptr(), self.ws_bytes, stream)
+        else:
+            positions, cache, rotary_dim, neox = rope
+            # cos|sin rows of this step's positions, gathered ONCE per step (the 32 layers share them): the kernel reads
+            # row j for query row j -- no positions -> cache indirection in front of a workgroup's first MFMA
+            if (self._rope_key is None or self._rope_key[0] is not positions
+                    or self._rope_key[1] != tensor_version(positions) or self._rope_key[2] is not cache):
+                rows = torch.empty((self.nq, rotary_dim), dtype=torch.float32, device=self.device)
+                check(lib.deft_rope_gather_rows(positions.data_ptr(), cache.data_ptr(), cache.stride(0), self.nq, rotary_dim,
+                                                rows.data_ptr(), stream), "deft_rope_gather_rows")
+                self._rope_rows = rows
+                self._rope_key = (positions, tensor_version(positions), cache)
+            rc = self.fn_rope(*head, self._rope_rows.data_ptr(), rotary_dim, 1 if neox else 0,
+                              self.plan_ptr, ws.data_ptr(), self.ws_bytes, stream)
         check(rc, "decode step")
         return o
+
+
+def rope_fusable(rotary_emb, head_dim: int) -> bool:
+    """The configurations deft_*_decode_rope_append_f16 take (the reference's Llama: NeoX pairing over the whole head)."""
+    return (head_dim == 128 and rotary_emb.rotary_dim == head_dim and rotary_emb.head_size == head_dim
+            and bool(rotary_emb.is_neox_style))
 
 
 def _decode_step(mode, md, input_metadata, q, k, Hq, Hkv, D):
@@ -260,8 +286,38 @@ class DeFTAttention(nn.Module):
         )
         return o
 
-    def forward(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, input_metadata: InputMetadata) -> torch.Tensor:
+    def forward(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, input_metadata: InputMetadata,
+                rotary_emb=None, positions: torch.Tensor = None, fuse_rope: bool = None) -> torch.Tensor:
+        """`rotary_emb` + `positions` (optional, not in the reference's signature): hand the rotary embedding that
+        LlamaAttention.forward applies in front of this call (llama2.py:108-110) to the attention launch itself.  In the
+        two DeFT decode modes with Llama's rotary configuration the rotation is fused into stage 1 (no launch of its own, q
+        and k stay unrotated); in every other case `rotary_emb(positions, q, k)` runs first, in place, as the reference does.
+        `fuse_rope`: True / False forces the choice; None fuses where it measured faster than the rotation's own launch --
+        launches of less than ~24 MB of KV per layer (tools/rope_fused_ab.py on MI355X: Medusa-64 19.2 vs 19.8 us per layer
+        fused vs rope + attention, ToT-50 27.2 vs 26.0, the north-star tree 43.7 vs 42.6: on the HBM-bound trees the
+        cos|sin fetch and the LDS pass in front of every workgroup's first MFMA cost more than the 3 us launch they save)."""
         mode = input_metadata.forward_mode
+        if rotary_emb is not None:
+            if positions is None:
+                raise ValueError("rotary_emb needs positions")
+            if (fuse_rope is not False and mode in (ForwardMode.TREE_DECODE_FLATTEN, ForwardMode.TREE_DECODE_NODE)
+                    and rope_fusable(rotary_emb, self.head_dim)):
+                md = get_global_tree_metadata()
+                if fuse_rope is None and md is not None:
+                    kv_bytes = 4 * int(getattr(md, "total_kv_len", 1 << 40)) * self.tp_k_head_num * self.head_dim
+                    if kv_bytes >= ROPE_FUSE_MAX_KV_BYTES:
+                        md = None  # (falls through to the rotation's own launch)
+                step = None if md is None else _decode_step(mode, md, input_metadata, q, k, self.tp_q_head_num,
+                                                            self.tp_k_head_num, self.head_dim)
+                if step is not None:
+                    pos = positions.flatten()
+                    if pos.dtype != torch.int64 or not pos.is_cuda or pos.shape[0] != step.nq:
+                        raise TypeError("positions must be an int64 CUDA tensor with one entry per query row")
+                    if rotary_emb.cos_sin_cache.device != q.device:
+                        rotary_emb.cos_sin_cache = rotary_emb.cos_sin_cache.to(q.device)
+                    return step.run(self.layer_id, q, k, v,
+                                    rope=(pos, rotary_emb.cos_sin_cache, rotary_emb.rotary_dim, rotary_emb.is_neox_style))
+            rotary_emb(positions, q, k)
         if mode == ForwardMode.DECODE:
             return self.radix_attention_forward(q, k, v, input_metadata)
         if mode == ForwardMode.PREFILL:

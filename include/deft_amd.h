@@ -196,6 +196,39 @@ int deft_node_decode_append_f16(
     const int32_t* cache_loc, const void* k_new, const void* v_new, int64_t new_stride_tok, int n_new,
     const void* plan, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- rotary embedding + paged append + attention in ONE stage-1 launch ---------------
+ *
+ * What LlamaAttention.forward does between the qkv projection and the output projection (llama2.py:108-111:
+ * rotary_emb(positions, q, k) -> attn(q, k, v)), as one call: q and k_new are the UNROTATED rows of the fused qkv;
+ * the kernel rotates a query row while it becomes an MFMA operand, this step's key rows on their way into the pool
+ * and inside the tiles that attend to them.  q / k_new are left unrotated (the reference rotates them in place, then
+ * only reads them here).  Arithmetic = deft_rope_qk_f16 (fp32, no contraction, one rounding): outputs and pool bytes
+ * are bit-identical to deft_rope_qk_f16 followed by the *_decode_append_f16 call.
+ * cos_sin_rows[n_new][head_dim] fp32 = cos_sin_cache[positions[j]] for row j of q / k_new (query row j), gathered
+ * ONCE per decode step and shared by all layers (deft_rope_gather_rows: positions and cache as in deft_rope_qk_f16) --
+ * so that no positions -> cache indirection stands in front of a workgroup's first MFMA.
+ * Supported: head_dim 128, rotary_dim == head_dim, NeoX pairing, token-major q (DEFT_EUNSUPPORTED otherwise: call
+ * deft_rope_qk_f16 and the append entry point instead).
+ */
+int deft_flatten_decode_rope_append_f16(
+    const void* q, int64_t q_stride_tok, int64_t q_stride_head, void* k_base, void* v_base, int64_t kv_stride_slot,
+    int64_t kv_stride_head, void* out, int64_t o_stride_tok, int64_t o_stride_head,
+    const int64_t* block_q, const int64_t* block_q_cnts, const int64_t* block_q_offset, const int64_t* block_bitmasks,
+    const int64_t* block_kv, const int64_t* block_lens, int NB, int P, int nq, int Hq, int Hkv, int D, float scale,
+    const int32_t* cache_loc, const void* k_new, const void* v_new, int64_t new_stride_tok, int n_new,
+    const float* cos_sin_rows, int rotary_dim, int is_neox_style,
+    const void* plan, void* workspace, size_t workspace_bytes, void* stream);
+int deft_rope_gather_rows(const int64_t* positions, const float* cos_sin_cache, int64_t cache_stride, int n, int rotary_dim,
+                          float* rows_out, void* stream);
+int deft_node_decode_rope_append_f16(
+    const void* q, int64_t q_stride_tok, int64_t q_stride_head, void* k_base, void* v_base, int64_t kv_stride_slot,
+    int64_t kv_stride_head, void* out, int64_t o_stride_tok, int64_t o_stride_head,
+    const int64_t* node_kv, const int64_t* node_kv_offset, const int64_t* node_kv_len, const int64_t* node_q,
+    const int64_t* node_q_offset, const int64_t* node_q_len, int NE, int P, int64_t total_kv, int nq, int Hq, int Hkv, int D,
+    float scale, const int32_t* cache_loc, const void* k_new, const void* v_new, int64_t new_stride_tok, int n_new,
+    const float* cos_sin_rows, int rotary_dim, int is_neox_style,
+    const void* plan, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- causal prefill attention over the prompt (TTFT) -------------------------------------------------------
  *
  * Replaces context_attention_fwd (DeFT/deft/layers/attention/context_flashattention_nopad.py:130-195) behind

@@ -118,3 +118,73 @@ def test_gpu_rope_is_bit_exact_on_reference_outputs():
         torch.cuda.synchronize()
         assert np.array_equal(q.cpu().numpy(), g[f"q_f32_{ci}"]), ci
         assert np.array_equal(k.cpu().numpy(), g[f"k_f32_{ci}"]), ci
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["flatten", "node"])
+@pytest.mark.parametrize("name,geom", [("multilevel", (8, 2, 128)), ("spec_mock", (4, 4, 128)), ("after_cut", (32, 8, 128)), ("wide40", (4, 4, 128))])
+def test_fused_rope_equals_rope_then_attention(name, geom, mode):
+    """rotary embedding + paged append + attention in ONE stage-1 launch
+    (deft_{flatten,node}_decode_rope_append_f16, DeFTAttention.forward(..., rotary_emb=, positions=)) is bit-identical --
+    outputs AND pool bytes -- to the reference's sequence rotary_emb(positions, q, k) -> attn(q, k, v)
+    (llama2.py:108-111), q / k being rows of a fused qkv projection; the fused form leaves q and k unrotated."""
+    from product_helpers import product_tree
+    Hq, Hkv, D = geom
+    outs, pools = [], []
+    rope = deft_amd.get_rope(D, D, 2048, 10000.0, True)
+    for fused in (False, True):
+        tree = product_tree(name, device="cuda", heads=(Hkv, D))
+        for leaf in list(tree.leaves.values()):
+            leaf.append_token(9)
+        updater = tree.alloc()
+        md = deft_amd.TreeMetadata.from_tree_cache(tree)
+        nq = md.query_num
+        g = torch.Generator(device="cuda")
+        g.manual_seed(5)
+        pool = tree.token_to_kv_pool
+        pool.kv_data[0].normal_(generator=g)
+        qkv = torch.randn((nq, (Hq + 2 * Hkv) * D), dtype=torch.float16, device="cuda", generator=g)
+        q, k, v = qkv.split([Hq * D, Hkv * D, Hkv * D], dim=-1)  # strided views, like llama2.py:107
+        # positions: the length of every leaf's path (distinct values, some far apart)
+        positions = torch.tensor([len(tree.leaf_path_slots(lf)) - 1 + 37 * i for i, lf in
+                                  enumerate(sorted(tree.leaves.values(), key=lambda n: n.id))], dtype=torch.int64, device="cuda")
+        assert positions.shape[0] == nq
+        before = qkv.clone()
+        attn = deft_amd.DeFTAttention(Hq, D, D ** -0.5, Hkv, layer_id=0)
+        fm = deft_amd.ForwardMode.TREE_DECODE_FLATTEN if mode == "flatten" else deft_amd.ForwardMode.TREE_DECODE_NODE
+        meta = deft_amd.InputMetadata(fm, updater, pool)
+        deft_amd.register_tree_metadata(md)
+        try:
+            if fused:
+                o = attn(q, k, v, meta, rotary_emb=rope, positions=positions, fuse_rope=True)
+                torch.cuda.synchronize()
+                assert torch.equal(qkv, before)  # nothing rotated in place
+            else:
+                rope(positions, q, k)
+                o = attn(q, k, v, meta)
+                torch.cuda.synchronize()
+                assert not torch.equal(qkv, before)
+        finally:
+            deft_amd.unregister_tree_metadata()
+        outs.append(o.cpu())
+        pools.append(pool.kv_data[0].cpu())
+    assert torch.equal(pools[0], pools[1])
+    assert torch.equal(outs[0], outs[1])
+    assert torch.isfinite(outs[1].float()).all() and outs[1].float().abs().max() > 0
+
+
+@pytest.mark.gpu
+def test_fused_rope_refuses_what_it_does_not_cover():
+    """GPT-J pairing / partial rotary dims are not fused: the C ABI says DEFT_EUNSUPPORTED, the module runs the rotation
+    as its own launch first (same results as the reference's sequence by construction)."""
+    i64 = torch.zeros(256, dtype=torch.int64, device="cuda")
+    f16 = torch.zeros(4 * 128 * 8, dtype=torch.float16, device="cuda")
+    f32 = torch.zeros(1024, dtype=torch.float32, device="cuda")
+    i32 = torch.zeros(8, dtype=torch.int32, device="cuda")
+    ws = torch.zeros(1 << 22, dtype=torch.uint8, device="cuda")
+    def call(rot, neox):
+        return deft_amd.lib.deft_flatten_decode_rope_append_f16(
+            f16.data_ptr(), 512, 128, f16.data_ptr(), f16.data_ptr(), 1024, 128, f16.data_ptr(), 512, 128,
+            *[i64.data_ptr()] * 6, 1, 1, 1, 4, 4, 128, 128 ** -0.5, i32.data_ptr(), f16.data_ptr(), f16.data_ptr(), 512, 1,
+            f32.data_ptr(), rot, neox, None, ws.data_ptr(), ws.numel(), None)
+    assert call(64, 1) == -2 and call(128, 0) == -2  # DEFT_EUNSUPPORTED
