@@ -1620,7 +1620,13 @@ extern "C" int deft_prefill_f16(const void* q, int64_t q_stride_tok, int64_t q_s
     p.G = Hq / Hkv;
     p.scale_log2e = scale * LOG2E;
     p.nblk = (max_input_len + 255) / 256;
-    hipLaunchKernelGGL((prefill_kernel<128>), dim3((unsigned)p.nblk, (unsigned)Hq, (unsigned)batch), dim3(512), SM::BYTES,
+    p.Hq = Hq;
+    p.batch = batch;
+    if ((int64_t)p.nblk * Hq * batch > 0x7fffffffLL) {
+        set_error("prefill grid too large (%d query blocks x %d heads x %d sequences)", p.nblk, Hq, batch);
+        return DEFT_EINVAL;
+    }
+    hipLaunchKernelGGL((prefill_kernel<128>), dim3((unsigned)((int64_t)p.nblk * Hq * batch)), dim3(512), SM::BYTES,
                        static_cast<hipStream_t>(stream), p);
     return check_launch("prefill launch");
 }

@@ -17,7 +17,7 @@
 //   * one online-softmax step per 128-key tile: 32 QK^T MFMAs on four independent accumulators, one max / rescale,
 //     32 PV MFMAs;
 //   * causal structure: query block m needs key tiles 0 .. 2m+1; only the last two touch the diagonal and are masked,
-//     a wave skips tiles that lie entirely above its queries; workgroups are launched longest first.
+//     a wave skips tiles that lie entirely above its queries; workgroups are launched longest first over the whole grid.
 #pragma once
 
 namespace deft {
@@ -33,6 +33,7 @@ struct PrefillParams {
     int G;  // query heads per KV head
     float scale_log2e;
     int nblk;  // query blocks per sequence in the grid: ceil(max_input_len / 256)
+    int Hq, batch;
 };
 
 template <int D>
@@ -57,9 +58,19 @@ __global__ __launch_bounds__(512, 1) void prefill_kernel(PrefillParams p) {
     const int l = tid & 63;
     const int c = l & 31;
     const int h = l >> 5;
-    const int m = p.nblk - 1 - (int)blockIdx.x;  // longest query blocks first
-    const int head = blockIdx.y;
-    const int b = blockIdx.z;
+    // One linear grid, query block major, LONGEST BLOCKS FIRST ACROSS ALL HEADS AND SEQUENCES: the dispatcher hands
+    // workgroups out in index order, so this is longest-processing-time-first list scheduling (with the block index
+    // fastest and the head slowest -- the first form -- a 4k-token prompt ran 64 tile times on its busiest CU for a mean of
+    // 34: the CU that finished a head's shortest block was handed the next head's LONGEST one).  Within a block row the
+    // q heads of one KV head land on one XCD (workgroup index mod 8), whose L2 then holds 4 KV heads, not all of them.
+    const int per_row = p.Hq * p.batch;
+    const int L = (int)blockIdx.x;
+    const int m = p.nblk - 1 - L / per_row;
+    const int rem = L - (L / per_row) * per_row;
+    const int b = rem / p.Hq;
+    const int hi = rem - b * p.Hq;
+    const int Hkv = p.Hq / p.G;
+    const int head = (hi % Hkv) * p.G + hi / Hkv;
     const int len = p.b_seq_len[b];
     const int64_t start = p.b_start_loc[b];
     if (m * QB >= len) return;
