@@ -105,7 +105,9 @@ struct NpSmem {
 #define DBG ((unsigned long long*)nullptr)
 #endif
 
-template <int D, bool ROPE>
+// PEEL: Q fragments built in front of the tile loop (what ROPE needs; for the plain kernel measured neutral, tools/ab.py:
+// north-star 35.96 / 36.10 us, ToT-50 18.41 / 18.20, Llama-3 north-star tree 17.93 / 17.66 -- the loop form stays)
+template <int D, bool ROPE, bool PEEL = ROPE>
 __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
     constexpr int KS = D / 16;
     constexpr int LPT = 32 * (D / 8) / 64;  // DMA instructions per wave per K (or V) slice
@@ -311,12 +313,12 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[b][r] = 0.f;
 
-    if constexpr (ROPE) {
+    if constexpr (ROPE || PEEL) {
         // Q rows are rotated and the fragments built in front of the tile loop (the cos / sin registers die here).
         if (n > 1) wait_vm<LPT + 2>();  // K(0) landed, hence this wave's Q rows
         else wait_vm<LPT>();
         if (DBG) t_k0 = wall_clock64();
-        {
+        if constexpr (ROPE) {
             uintx4 own[2], par[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -344,7 +346,7 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
         // ---- K(i) (and Q) landed: younger than it are aux(i+1) [2] and V(i) [8] -------------------------
         if (has1) wait_vm<LPT + 2>();
         else wait_vm<LPT>();
-        if (!ROPE && i == 0) {
+        if (!ROPE && !PEEL && i == 0) {
             if (DBG) t_k0 = wall_clock64();
             lds_barrier();  // Q rows of all four waves visible
 #pragma unroll
