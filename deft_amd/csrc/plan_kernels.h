@@ -142,6 +142,10 @@ __device__ inline void np_record_order(const UnitList& ul, int R, int Hkv, int G
             for_runs([&](int, int nt, int uni) { n += uni ? 1 : (nt + C - 1) / C; });
             if (10 * n * Hkv >= 3LL * slots) break;
         }
+        // ... but no run is cut into more than 16 chunks while chunks may still grow (<= 8 tiles): every chunk of a
+        // shared prefix is one more partial row for EVERY query below it, and the merge reads its rows 16 at a time
+        // (one 8192-token prefix under 8 branches, Llama-3-8B: 32 chunks of 2 tiles 23.7 us per layer, 16 of 4 tiles 21.1).
+        while (C < 8 && lmax > 16 * C) C <<= 1;
     }
     int NL = 0;
     for_runs([&](int, int nt, int uni) { NL += uni ? 1 : (nt + C - 1) / C; });
@@ -197,6 +201,7 @@ __device__ inline void record_order_parallel(const UnitList& ul, const RunTable&
                 const int64_t n = wave_sum([C](int nt, int uni) { return uni ? 1 : (nt + C - 1) / C; });
                 if (10 * n * Hkv >= 3LL * slots) break;
             }
+            while (C < 8 && lmax > 16 * C) C <<= 1;  // (np_record_order: at most 16 chunks per run while C < 8)
         }
         int lead = 0, foll = 0;
         for (int base = 0; base < NR; base += 64) {
