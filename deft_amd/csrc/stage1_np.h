@@ -465,7 +465,8 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
         if (has1) issue_v();  // V(i+1); rowoff still holds tile i+1's offsets
     }
 
-    if (ABL(16)) {
+    if (ABL(16)) {  // (experiments build: no epilogue at all)
+        if (item + W >= NI) break;
         lds_barrier();
         item += W;
         continue;
