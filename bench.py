@@ -400,6 +400,34 @@ def cfg5_line(device, layers_model: str, n_gpus: int, rank: int, dist_on: bool, 
             "collectives_in_data_path": 0, "rccl": "control plane only (barrier + MAX of the step time)"}
 
 
+def prefill_lines(device, model: str):
+    """Causal prefill attention of one prompt (deft_prefill_f16 behind context_attention_fwd), q / k / v = strided views of
+    a fused qkv projection; TFLOP/s counts the causal half against the dense fp16 MFMA peak (2.5 PFLOP/s)."""
+    Hq, Hkv, D, _ = GEOMETRY[model]
+    out = {"kernel": "deft::prefill_kernel<128>", "bound": "mfma", "peak_TFLOPs": 2500.0, "prompts": {}}
+    for S in (4096, 16384):
+        qkv = torch.randn((S, (Hq + 2 * Hkv) * D), dtype=torch.float16, device=device)
+        q, k, v = (t.view(S, -1, D) for t in qkv.split([Hq * D, Hkv * D, Hkv * D], dim=-1))
+        o = torch.empty((S, Hq, D), dtype=torch.float16, device=device)
+        start = torch.zeros(1, dtype=torch.int32, device=device)
+        lens = torch.tensor([S], dtype=torch.int32, device=device)
+        for _ in range(3):
+            deft_amd.context_attention_fwd(q, k, v, o, start, lens, S)
+        n = 20
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            deft_amd.context_attention_fwd(q, k, v, o, start, lens, S)
+        e1.record()
+        e1.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / n
+        flops = 2.0 * 2.0 * (S * (S + 1) / 2) * D * Hq
+        out["prompts"][str(S)] = {"us_per_layer": round(us, 1), "TFLOPs": round(flops / us / 1e6, 1),
+                                  "frac": round(flops / us / 1e6 / 2500.0, 4)}
+        del qkv, o
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -543,6 +571,15 @@ def main():
             except Exception as e:  # an extra must never take the headline down
                 extras[name] = {"error": f"{type(e).__name__}: {e}"}
 
+    prefill = None
+    if not args.no_extras and rank == 0 and not dist_on:
+        # the causal prefill in front of the decode path (TTFT of the prompt), same geometry; MFMA-bound
+        try:
+            torch.cuda.empty_cache()
+            prefill = prefill_lines(device, w.model)
+        except Exception as e:
+            prefill = {"error": f"{type(e).__name__}: {e}"}
+
     cfg5 = None
     if not args.no_cfg5:
         try:
@@ -591,7 +628,8 @@ def main():
             "metadata_build_ms": round(b.metadata_build_ms, 3),
             "plan_build_us_per_step": round(plan_us, 1) if plan_us is not None else None,
             "end_to_end": e2e, "gpu_state": gpu_state(),
-            "roofline": roofline, "cpu_baseline": cpu, "cfg5_sharded_forest": cfg5, "other_workloads": extras,
+            "roofline": roofline, "cpu_baseline": cpu, "cfg5_sharded_forest": cfg5, "prefill": prefill,
+            "other_workloads": extras,
         }
         print(json.dumps(line), flush=True)
     if dist_on:
