@@ -293,6 +293,9 @@ __global__ __launch_bounds__(256, 2) void stage1_kernel(Stage1Params p) {
 #include "merge.h"
 #include "stage1_np.h"
 #include "prefill.h"
+#ifdef DEFT_EXPERIMENTS
+#include "prefill_pipe.h"  // software-pipelined form: parity-green, 15-20 % slower; experiments build only
+#endif
 namespace deft {
 
 // ---------------------------------------------------------------------------
@@ -456,7 +459,7 @@ static int num_cus() {
     return d.cus;
 }
 enum : unsigned { ATTR_NP = 4,  // (bits 0-1, 8-11: the head_dim 64 / 32 / 16 kernels)
-                  ATTR_UNITS = 8, ATTR_NODE_UNITS = 16, ATTR_PREFILL = 32, ATTR_TREE = 64, ATTR_NP_ROPE = 128 };
+                  ATTR_UNITS = 8, ATTR_NODE_UNITS = 16, ATTR_PREFILL = 32, ATTR_TREE = 64, ATTR_NP_ROPE = 128, ATTR_PREFILL_PIPE = 256 };
 static int raise_lds(const void* fn, int bytes, unsigned bit, const char* what) {  // idempotent; races are harmless
     DeviceState& d = dev_state();
     if (d.attrs & bit) return DEFT_OK;
@@ -1597,9 +1600,16 @@ extern "C" int deft_prefill_f16(const void* q, int64_t q_stride_tok, int64_t q_s
         set_error("prefill: q/k/v rows must be 16-byte aligned, out rows 8-byte aligned");
         return DEFT_EINVAL;
     }
-    using SM = PrefillSmem<128>;
+#ifdef DEFT_EXPERIMENTS
+    const bool pipe = knob("DEFT_PREFILL_PIPE", 0) != 0;
+    if (pipe) {
+        const int rc = raise_lds(reinterpret_cast<const void*>(&prefill_pipe_kernel<128>), PrefillPipeSmem<128>::BYTES,
+                                 ATTR_PREFILL_PIPE, "prefill_pipe");
+        if (rc) return rc;
+    }
+#endif
     {
-        const int rc = raise_lds(reinterpret_cast<const void*>(&prefill_kernel<128>), SM::BYTES, ATTR_PREFILL, "prefill");
+        const int rc = raise_lds(reinterpret_cast<const void*>(&prefill_kernel<128>), PrefillSmem<128>::BYTES, ATTR_PREFILL, "prefill");
         if (rc) return rc;
     }
     PrefillParams p{};
@@ -1622,12 +1632,19 @@ extern "C" int deft_prefill_f16(const void* q, int64_t q_stride_tok, int64_t q_s
     p.nblk = (max_input_len + 255) / 256;
     p.Hq = Hq;
     p.batch = batch;
+    p.dbg = g_dbg;
     if ((int64_t)p.nblk * Hq * batch > 0x7fffffffLL) {
         set_error("prefill grid too large (%d query blocks x %d heads x %d sequences)", p.nblk, Hq, batch);
         return DEFT_EINVAL;
     }
-    hipLaunchKernelGGL((prefill_kernel<128>), dim3((unsigned)((int64_t)p.nblk * Hq * batch)), dim3(512), SM::BYTES,
-                       static_cast<hipStream_t>(stream), p);
+    const dim3 grid((unsigned)((int64_t)p.nblk * Hq * batch));
+#ifdef DEFT_EXPERIMENTS
+    if (pipe) {
+        hipLaunchKernelGGL((prefill_pipe_kernel<128>), grid, dim3(512), PrefillPipeSmem<128>::BYTES, static_cast<hipStream_t>(stream), p);
+        return check_launch("prefill (pipelined) launch");
+    }
+#endif
+    hipLaunchKernelGGL((prefill_kernel<128>), grid, dim3(512), PrefillSmem<128>::BYTES, static_cast<hipStream_t>(stream), p);
     return check_launch("prefill launch");
 }
 

@@ -40,6 +40,17 @@ __device__ __forceinline__ void dma16(const void* gsrc, uint32_t lds_dst) {
         : "memory");
 }
 
+// The same with a scalar base and a 32-bit per-lane byte offset (saddr form: no 64-bit address per lane)
+__device__ __forceinline__ void dma16s(const void* sbase, uint32_t voff, uint32_t lds_dst) {
+    asm volatile(
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %0, %1"
+        :
+        : "v"(voff), "s"(sbase), "s"(lds_dst)
+        : "memory");
+}
+
 // 64 lanes x 4 bytes, global (per-lane address) -> LDS (lds_dst + 4*lane)
 __device__ __forceinline__ void dma4(const void* gsrc, uint32_t lds_dst) {
     asm volatile(

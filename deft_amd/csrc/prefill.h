@@ -34,6 +34,7 @@ struct PrefillParams {
     float scale_log2e;
     int nblk;  // query blocks per sequence in the grid: ceil(max_input_len / 256)
     int Hq, batch;
+    unsigned long long* dbg;  // experiments build: per-workgroup wall-clock stamps [workgroup][8], or null
 };
 
 template <int D>
@@ -74,6 +75,10 @@ __global__ __launch_bounds__(512, 1) void prefill_kernel(PrefillParams p) {
     const int len = p.b_seq_len[b];
     const int64_t start = p.b_start_loc[b];
     if (m * QB >= len) return;
+#ifdef DEFT_EXPERIMENTS
+    unsigned long long t_start = 0, t_loop = 0, t_epi = 0;
+    if (p.dbg) t_start = wall_clock64();
+#endif
     const int kvh = head / p.G;
 
     // ---- lane constants (LDS layouts of stage1_np.h: K chunks XOR-ed by key & 15, V chunks by 4*(key & 3)) ----------
@@ -134,6 +139,9 @@ __global__ __launch_bounds__(512, 1) void prefill_kernel(PrefillParams p) {
         for (int r = 0; r < 16; ++r) o[bk][r] = 0.f;
     const int q_lo = m * QB + 32 * w;  // first query of this wave
 
+#ifdef DEFT_EXPERIMENTS
+    if (p.dbg) t_loop = wall_clock64();
+#endif
     for (int t = 0; t < ntiles; ++t) {
         const int stg = t & 1;
         wait_vm<0>();   // tile t landed (this wave's part)
@@ -231,6 +239,9 @@ __global__ __launch_bounds__(512, 1) void prefill_kernel(PrefillParams p) {
         }
     }
     wait_vm<0>();
+#ifdef DEFT_EXPERIMENTS
+    if (p.dbg) t_epi = wall_clock64();
+#endif
     // ---- normalise and store: lane (c, h) holds d = 32 bk + 8 j + 4 h + (0..3) of query c ---------------------
     if (qi < len) {
         const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
@@ -244,6 +255,19 @@ __global__ __launch_bounds__(512, 1) void prefill_kernel(PrefillParams p) {
                 *reinterpret_cast<half4*>(op + 32 * bk + 8 * j) = v4;
             }
     }
+#ifdef DEFT_EXPERIMENTS
+    if (p.dbg && tid == 0 && L < 8192) {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        unsigned long long* d = p.dbg + (int64_t)L * 8;
+        d[0] = t_start;
+        d[1] = t_loop;
+        d[2] = t_epi;
+        d[3] = wall_clock64();
+        d[4] = (unsigned long long)ntiles;
+        d[5] = (unsigned long long)xcc;
+    }
+#endif
 }
 
 }  // namespace deft
