@@ -1712,9 +1712,16 @@ int deft_tree_dev_build_md(int n_nodes, int nq, int nqw, const int32_t* node_sta
                            int64_t* block_q, int64_t* block_q_cnts, int64_t* block_q_offset, int64_t* block_bitmasks,
                            int64_t* block_kv, int64_t* block_lens, const int32_t* advance_loc, void* stream) {
     if (n_nodes <= 0 || nq < 0 || nqw < 1 || nbp_cap < 0 || !node_start || !node_len || !node_cap || !refs || !leaf_node || !slots ||
-        !scratch || !node_q || !node_kv || !node_q_len || !node_kv_len || !node_q_offset || !node_kv_offset || !block_q ||
-        !block_q_cnts || !block_q_offset || !block_bitmasks || !block_kv || !block_lens) {
+        !scratch) {
         set_error("deft_tree_dev_build_md: bad arguments (nodes=%d nq=%d)", n_nodes, nq);
+        return DEFT_EINVAL;
+    }
+    // either group of six arrays may be omitted as a whole (all six pointers null): a DeFT-Flatten step reads only the
+    // block arrays, a DeFT-Node step only the node arrays, and the kernel that writes the other six is then not launched
+    const int n_node_ptrs = !!node_q + !!node_kv + !!node_q_len + !!node_kv_len + !!node_q_offset + !!node_kv_offset;
+    const int n_block_ptrs = !!block_q + !!block_q_cnts + !!block_q_offset + !!block_bitmasks + !!block_kv + !!block_lens;
+    if ((n_node_ptrs != 0 && n_node_ptrs != 6) || (n_block_ptrs != 0 && n_block_ptrs != 6) || n_node_ptrs + n_block_ptrs == 0) {
+        set_error("deft_tree_dev_build_md: the node arrays and the block arrays are each given as a whole or not at all");
         return DEFT_EINVAL;
     }
     if (max_q_len < 1 || max_q_len > 63 || block_len < 1 || block_len > 1024 || (max_block_len < 1 && max_block_len != -1)) {
@@ -1743,11 +1750,12 @@ int deft_tree_dev_build_md(int n_nodes, int nq, int nqw, const int32_t* node_sta
                        advance_loc);
     rc = check_launch("tree scan launch");
     if (rc) return rc;
-    if (nbp_cap > 0) {
+    if (nbp_cap > 0 && n_block_ptrs) {
         hipLaunchKernelGGL(tree_md_blocks_kernel, dim3((unsigned)nbp_cap), dim3(128), 0, st, t, sc, o, max_q_len, block_len);
         rc = check_launch("tree blocks launch");
         if (rc) return rc;
     }
+    if (!n_node_ptrs) return DEFT_OK;
     hipLaunchKernelGGL(tree_md_nodes_kernel, dim3((unsigned)n_nodes, 4), dim3(256), 0, st, t, sc, o, max_q_len, max_block_len);
     return check_launch("tree nodes launch");
 }

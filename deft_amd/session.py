@@ -92,8 +92,11 @@ class DecodeSession:
         table[self.idx[0], self.idx[1]] = self.cache_loc  # page table rows of this step's tokens
         mq, bl, mbl = dt.cfg
         # (the append of this step's slots to the device tree rides in the first metadata kernel)
+        # (only the six arrays this mode's operator reads are written: the kernel of the other group is not launched)
+        wanted = _FIELDS[6:] if self.mode == "flatten" else _FIELDS[:6]
         check(lib.deft_tree_dev_build_md(*dt._tree_args(), mq, bl, mbl, dt.nbp_cap, dt.scratch.data_ptr(), dt.scratch_bytes,
-                                         *[self.md_ptrs[k] for k in _FIELDS], self.cache_loc.data_ptr() if advance else None, stream),
+                                         *[self.md_ptrs[k] if k in wanted else None for k in _FIELDS],
+                                         self.cache_loc.data_ptr() if advance else None, stream),
               "deft_tree_dev_build_md")
         Hq, Hkv, D = self.Hq, self.Hkv, self.D
         q0, k0, _ = self.qkv(0)

@@ -392,7 +392,9 @@ int64_t deft_tree_build_md(int64_t tree, int max_q_len, int block_len, int max_b
  *                           deft_md_sizes, sizes[8] = physical 128-slot blocks (capacity planning and tensor shapes; no slot touched)
  *   deft_tree_dev_advance   device: append cache_loc[r] to query row r's leaf (kept ascending inside the node)
  *   deft_tree_dev_build_md  device: the twelve int64 arrays of TreeMetadata, bit for bit deft_md_build's; with `advance_loc`
- *                           (this step's cache_loc, nullable) the append of deft_tree_dev_advance is folded into its first kernel
+ *                           (this step's cache_loc, nullable) the append of deft_tree_dev_advance is folded into its first kernel;
+ *                           the six node_* pointers or the six block_* pointers may all be NULL: that group is not written
+ *                           (a Flatten step reads only the block arrays, a Node step only the node arrays)
  */
 int deft_tree_layout(int64_t tree, int slack, int64_t sizes[5]);
 int deft_tree_layout_fetch(int64_t tree, int32_t* node_start, int32_t* node_len, int32_t* node_cap, uint64_t* refs,
