@@ -459,7 +459,7 @@ static int num_cus() {
     return d.cus;
 }
 enum : unsigned { ATTR_NP = 4,  // (bits 0-1, 8-11: the head_dim 64 / 32 / 16 kernels)
-                  ATTR_UNITS = 8, ATTR_NODE_UNITS = 16, ATTR_PREFILL = 32, ATTR_TREE = 64, ATTR_NP_ROPE = 128, ATTR_PREFILL_PIPE = 256 };
+                  ATTR_UNITS = 8, ATTR_NODE_UNITS = 16, ATTR_PREFILL = 32, ATTR_TREE = 64, ATTR_NP_ROPE = 128, ATTR_PREFILL_PIPE = 4096, ATTR_NP_T = 8192, ATTR_NP_ROPE_T = 16384 };
 static int raise_lds(const void* fn, int bytes, unsigned bit, const char* what) {  // idempotent; races are harmless
     DeviceState& d = dev_state();
     if (d.attrs & bit) return DEFT_OK;
@@ -584,11 +584,20 @@ static int launch_plan(const Stage1Params& p, int NB, const PlanView& pv, const 
 // Stage 1 (head_dim 128): one workgroup per record slot and KV head; slots that are not chunk leaders exit at once
 // (they are at the end of the grid).
 static int launch_stage1_np(const Stage1Params& p, int64_t unit_cap, const PlanView& pv, const AppendArgs& ap,
-                            hipStream_t stream) {
+                            hipStream_t stream, int nq, bool reread = false) {
     using SM = NpSmem<128>;
     const bool rope = ap.cos_sin != nullptr;
-    int rc = rope ? raise_lds(reinterpret_cast<const void*>(&stage1_np_kernel<128, true>), SM::BYTES, ATTR_NP_ROPE, "stage1_np_rope")
-                  : raise_lds(reinterpret_cast<const void*>(&stage1_np_kernel<128, false>), SM::BYTES, ATTR_NP, "stage1_np");
+    // K / V rows by NON-TEMPORAL LDS-DMA wherever a row is read by the few 32-row passes of its tile and never again: the
+    // tree modes.  Same box, stage 1 (tools/ab.py, experiments build DEFT_NP_NT=0/1): north-star tree 36.0 -> 32.3 us, 1k x 32
+    // 26.5 -> 24.1, 400-token branches 54.0 -> 48.4; whole layer: 8-tree forest 64.7 -> 60.0, Llama-3 north-star tree 23.5 ->
+    // 22.8, Medusa-64 18.7 -> 18.0, ToT-50 (six passes per root tile) 24.0 -> 24.3.  NOT the sequential comparator, where every
+    // leaf re-reads the shared prefix through the caches: 216 -> 298 us per layer (`reread`).
+    const bool nt = knob("DEFT_NP_NT", 1) != 0 && !reread && (int64_t)nq * p.G <= 1024;
+    int rc;
+    if (rope) rc = nt ? raise_lds(reinterpret_cast<const void*>(&stage1_np_kernel<128, true, true>), SM::BYTES, ATTR_NP_ROPE, "stage1_np_rope")
+                      : raise_lds(reinterpret_cast<const void*>(&stage1_np_kernel<128, true, false>), SM::BYTES, ATTR_NP_ROPE_T, "stage1_np_rope_t");
+    else rc = nt ? raise_lds(reinterpret_cast<const void*>(&stage1_np_kernel<128, false, true>), SM::BYTES, ATTR_NP, "stage1_np")
+                 : raise_lds(reinterpret_cast<const void*>(&stage1_np_kernel<128, false, false>), SM::BYTES, ATTR_NP_T, "stage1_np_t");
     if (rc) return rc;
     if (unit_cap <= 0) return DEFT_OK;
     int64_t grid = unit_cap * p.Hkv;
@@ -624,8 +633,11 @@ static int launch_stage1_np(const Stage1Params& p, int64_t unit_cap, const PlanV
     npp.n_new = ap.k_new ? ap.n_new : 0;
     npp.dbg = g_dbg;
     npp.cos_sin = ap.cos_sin;
-    if (rope) hipLaunchKernelGGL((stage1_np_kernel<128, true>), dim3((unsigned)grid), dim3(256), SM::BYTES, stream, npp);
-    else hipLaunchKernelGGL((stage1_np_kernel<128, false>), dim3((unsigned)grid), dim3(256), SM::BYTES, stream, npp);
+    const dim3 g((unsigned)grid), b(256);
+    if (rope && nt) hipLaunchKernelGGL((stage1_np_kernel<128, true, true>), g, b, SM::BYTES, stream, npp);
+    else if (rope) hipLaunchKernelGGL((stage1_np_kernel<128, true, false>), g, b, SM::BYTES, stream, npp);
+    else if (nt) hipLaunchKernelGGL((stage1_np_kernel<128, false, true>), g, b, SM::BYTES, stream, npp);
+    else hipLaunchKernelGGL((stage1_np_kernel<128, false, false>), g, b, SM::BYTES, stream, npp);
     return check_launch("stage1 np launch");
 }
 
@@ -814,7 +826,7 @@ static int flatten_stage1_impl(const void* q, int64_t q_stride_tok, int64_t q_st
         }
         *row_q_out = pv.row_q;
         *pv_out = pv;
-        return launch_stage1_np(p, cap, pv, ap, st);
+        return launch_stage1_np(p, cap, pv, ap, st, nq);
     }
     if (ap.k_new) {  // head_dim 64 (tile-per-workgroup form): separate append launch first
         rc = deft_kv_append_f16(const_cast<void*>(k_base), const_cast<void*>(v_base), kv_stride_slot, kv_stride_head,
@@ -1174,7 +1186,7 @@ static int node_decode_impl(const void* q, int64_t q_stride_tok, int64_t q_strid
             rc = launch_node_plan(p, NE, rows, pv, ap, st);
             if (rc) return rc;
         }
-        rc = launch_stage1_np(p, tiles * G, pv, ap, st);
+        rc = launch_stage1_np(p, tiles * G, pv, ap, st, nq, /*reread=*/rows_per_tile == 1);
         if (rc) return rc;
         return launch_merge(D, ws, &pv, pv.row_q, rows, out, o_stride_tok, o_stride_head, nq, Hq, st);
     }

@@ -40,6 +40,18 @@ __device__ __forceinline__ void dma16(const void* gsrc, uint32_t lds_dst) {
         : "memory");
 }
 
+// The same with the non-temporal cache policy: a row that exactly one workgroup of the launch reads (MHA decode) need not
+// displace anything in L2 / Infinity Cache on its way in
+__device__ __forceinline__ void dma16nt(const void* gsrc, uint32_t lds_dst) {
+    asm volatile(
+        "s_mov_b32 m0, %1\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %0, off nt"
+        :
+        : "v"(gsrc), "s"(lds_dst)
+        : "memory");
+}
+
 // The same with a scalar base and a 32-bit per-lane byte offset (saddr form: no 64-bit address per lane)
 __device__ __forceinline__ void dma16s(const void* sbase, uint32_t voff, uint32_t lds_dst) {
     asm volatile(

@@ -107,7 +107,8 @@ struct NpSmem {
 
 // PEEL: Q fragments built in front of the tile loop (what ROPE needs; for the plain kernel measured neutral, tools/ab.py:
 // north-star 35.96 / 36.10 us, ToT-50 18.41 / 18.20, Llama-3 north-star tree 17.93 / 17.66 -- the loop form stays)
-template <int D, bool ROPE, bool PEEL = ROPE>
+// NT: K / V rows arrive by non-temporal LDS-DMA (tree modes: a row is read by the few passes of its tile and never again)
+template <int D, bool ROPE, bool NT, bool PEEL = ROPE>
 __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
     constexpr int KS = D / 16;
     constexpr int LPT = 32 * (D / 8) / 64;  // DMA instructions per wave per K (or V) slice
@@ -210,14 +211,18 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
 #pragma unroll
         for (int i = 0; i < LPT; ++i) {
             const char* src = rowoff[i] < 0 ? kb_new + (rowoff[i] & ~NEW_ROW) : kb_pool + rowoff[i];
-            dma16(src + kchunk_b[i & 3], ldsK + (uint32_t)i * 1024u);
+            if constexpr (NT) dma16nt(src + kchunk_b[i & 3], ldsK + (uint32_t)i * 1024u);
+            else dma16(src + kchunk_b[i & 3], ldsK + (uint32_t)i * 1024u);
         }
     };
     auto issue_v = [&]() {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int i = 0; i < LPT; ++i)
-            dma16(rowoff[i] < 0 ? vb_new + (rowoff[i] & ~NEW_ROW) : vb_pool + rowoff[i], ldsV + (uint32_t)i * 1024u);
+        for (int i = 0; i < LPT; ++i) {
+            const char* src = rowoff[i] < 0 ? vb_new + (rowoff[i] & ~NEW_ROW) : vb_pool + rowoff[i];
+            if constexpr (NT) dma16nt(src, ldsV + (uint32_t)i * 1024u);
+            else dma16(src, ldsV + (uint32_t)i * 1024u);
+        }
     };
     auto issue_q = [&]() {  // rows 8w .. 8w+7 of the shared Q buffer, offsets from aux slot 0
         const int32_t* qs = reinterpret_cast<const int32_t*>(smem + aux0 + 256 + 128);
