@@ -527,6 +527,8 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
             const floatx4 res = a * inv;
             const float lse = (L > 0.f) ? (M + __builtin_amdgcn_logf(L)) * LN2 : -INFINITY;
             const int64_t row = head_rows + orow_q;
+            // (ordinary stores: non-temporal partial stores, and non-temporal loads of them in the merge, each cost the
+            //  north-star layer ~1 us and both ~2.3 -- profiles/r2n_nontemporal.txt)
             *reinterpret_cast<floatx4*>(p.partial_o + row * D + 4 * k4) = res;
             if (k4 == 0) p.partial_lse[row] = lse;
         }
