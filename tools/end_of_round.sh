@@ -2,7 +2,7 @@
 # End-of-round evidence on ONE MI355X box (run as `gpurun -- bash tools/end_of_round.sh [tag]`): replay tables, the default
 # bench line, the rocprofv3 kernel-trace summary of the same command and the two PMC passes (own runs, --kernel-trace
 # only).  Writes gpurun_out/<tag>/<tag>_*; the files judged are copied from there into profiles/ (see profiles/README.md).
-TAG=${1:-r2e}
+TAG=${1:-r2z}
 R=$GRAFT_REPO_ROOT; export PYTHONPATH=$R; O=$R/gpurun_out/$TAG; mkdir -p $O
 cd $R
 timeout 300 python tools/replay.py --task few_shot --width 32 --prompt-len 4096 --max-gen-len 200 --out $O/${TAG}_replay_few_shot_4kx32.json > $O/replay_fs.log 2>&1
