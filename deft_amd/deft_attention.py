@@ -19,7 +19,7 @@ from __future__ import annotations
 import torch
 from torch import nn
 
-from ._lib import check, lib, tensor_version
+from ._lib import DeftLibraryError, check, lib, tensor_version
 from .forward_mode import ForwardMode, InputMetadata
 from .context_attention import context_attention_fwd
 from .token_attention import seq_append_attention, token_attention_fwd
@@ -59,6 +59,9 @@ class _DecodeStep:
         self.q_shape, self.q_stride, self.k_stride = tuple(q.shape), q.stride(0), k.stride(0)
         self.device = q.device
         self.dev_index = q.device.index if q.device.index is not None else torch.cuda.current_device()
+        if self.dev_index != torch.cuda.current_device():  # (the library's per-device state follows HIP's current device)
+            raise DeftLibraryError(f"tensors on cuda:{self.dev_index} but the current device is cuda:{torch.cuda.current_device()}: "
+                                   "call inside `with torch.cuda.device(tensor.device):`")
         self.kv_ss, self.kv_sh = kv0.stride(0), kv0.stride(2)
         self.v_off_bytes = kv0.stride(1) * 2
         self.layer_ptrs = [t.data_ptr() for t in pool.kv_data]

@@ -27,6 +27,12 @@ __all__ = ["tree_attention_subtree_fwd", "tree_attention_fwd", "flatten_append_a
 
 
 def _stream_ptr(t: torch.Tensor) -> int:
+    """torch's current stream on the tensor's device.  The library keeps per-device facts (CU count, raised LDS limits) under
+    HIP's CURRENT device, so the tensors must live on it -- one process per GPU with torch.cuda.set_device(local_rank), or
+    `with torch.cuda.device(t.device):` around the call."""
+    if t.device.index is not None and t.device.index != torch.cuda.current_device():
+        raise DeftLibraryError(f"tensors on {t.device} but the current device is cuda:{torch.cuda.current_device()}: "
+                               "call inside `with torch.cuda.device(tensor.device):`")
     return torch.cuda.current_stream(t.device).cuda_stream
 
 

@@ -18,8 +18,12 @@ for rep in range(3):
     torch.cuda.synchronize()
     lib.deft_debug_set_buffer(dbg.data_ptr())
     l = rep % b.layers
+    ev0, ev1, ev2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    ev0.record()
     b.attn[l](b.q[l], b.k_new[l], b.v_new[l], b.meta)
+    ev1.record()
     torch.cuda.synchronize()
+    print(f"rep {rep}: HIP events around the layer call (stage 1 + merge): {ev0.elapsed_time(ev1) * 1e3:.1f} us")
     lib.deft_debug_set_buffer(None)
     if rep == 0: continue
     d = dbg.cpu().numpy()[: NW * 8].reshape(NW, 8)
