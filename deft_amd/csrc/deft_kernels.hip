@@ -727,12 +727,16 @@ size_t deft_flatten_workspace_bytes(int NB, int P, int nq, int Hq, int Hkv, int 
     return carve(nullptr, Hq, D, P, 0, plan_view(nullptr, flatten_unit_cap(NB, Hq / Hkv), P).bytes).bytes;
 }
 
+// Partial rows per tile of a Node launch: an entry has at most DEFT_MAX_Q_LEN queries -- and never more than the P (query, entry)
+// pairs of the whole call, which is what keeps the scratch of a 100k-token prefix under three branches at a tenth of the
+// 32-rows-per-tile figure.  Every sizing function and the launch derive it from P alone, so they agree.
+static inline int64_t node_rows_per_tile(int P) { return P <= 0 ? 1 : (P < DEFT_MAX_Q_LEN ? P : DEFT_MAX_Q_LEN); }
+
 size_t deft_node_workspace_bytes(int NE, int P, int64_t total_kv, int nq, int Hq, int Hkv, int D) {
-    (void)P;
     (void)nq;
     if (Hq <= 0 || Hkv <= 0 || Hq % Hkv) return 0;
     const int64_t tiles = node_max_tiles(NE, total_kv);
-    const int64_t rows = tiles * DEFT_MAX_Q_LEN;
+    const int64_t rows = tiles * node_rows_per_tile(P);
     return carve(nullptr, Hq, D, rows, tiles, plan_view(nullptr, tiles * (Hq / Hkv), rows).bytes).bytes;
 }
 
@@ -1049,10 +1053,9 @@ static int launch_node_plan(const Stage1Params& p, int NE, int64_t rows_cap, con
 }
 
 size_t deft_node_plan_bytes(int NE, int P, int64_t total_kv, int Hq, int Hkv) {
-    (void)P;
     if (Hq <= 0 || Hkv <= 0 || Hq % Hkv) return 0;
     const int64_t tiles = node_max_tiles(NE, total_kv);
-    return plan_view(nullptr, tiles * (Hq / Hkv), tiles * DEFT_MAX_Q_LEN).bytes;
+    return plan_view(nullptr, tiles * (Hq / Hkv), tiles * node_rows_per_tile(P)).bytes;
 }
 
 static int node_build_plan_impl(const int64_t* node_kv, const int64_t* node_kv_offset, const int64_t* node_kv_len,
@@ -1066,7 +1069,7 @@ static int node_build_plan_impl(const int64_t* node_kv, const int64_t* node_kv_o
         return DEFT_EINVAL;
     }
     const int64_t tiles = node_max_tiles(NE, total_kv);
-    const int64_t rows = tiles * DEFT_MAX_Q_LEN;
+    const int64_t rows = tiles * node_rows_per_tile(P);
     const PlanView pv = plan_view(plan, tiles * (Hq / Hkv), rows);
     if (plan_bytes < pv.bytes) {
         set_error("plan buffer too small: %zu < %zu", plan_bytes, pv.bytes);
@@ -1132,7 +1135,7 @@ static int node_decode_impl(const void* q, int64_t q_stride_tok, int64_t q_strid
                             const int64_t* node_kv_offset, const int64_t* node_kv_len, const int64_t* node_q,
                             const int64_t* node_q_offset, const int64_t* node_q_len, int NE, int P, int64_t total_kv, int nq,
                             int Hq, int Hkv, int D, float scale, const void* plan, void* workspace, size_t workspace_bytes,
-                            void* stream, const AppendArgs& ap, int rows_per_tile = DEFT_MAX_Q_LEN) {
+                            void* stream, const AppendArgs& ap, int rows_per_tile = 0 /* 0: from P; 1: the sequential comparator */) {
     int rc = check_common(q, q_stride_tok, q_stride_head, k_base, v_base, kv_stride_slot, kv_stride_head, out,
                           o_stride_tok, o_stride_head, nq, Hq, Hkv, D);
     if (rc) return rc;
@@ -1149,7 +1152,7 @@ static int node_decode_impl(const void* q, int64_t q_stride_tok, int64_t q_strid
     if (rc) return rc;
     const int G = Hq / Hkv;
     const int64_t tiles = node_max_tiles(NE, total_kv);
-    const int64_t rows = tiles * rows_per_tile;  // every entry has at most rows_per_tile queries
+    const int64_t rows = tiles * (rows_per_tile > 0 ? rows_per_tile : node_rows_per_tile(P));  // every entry has at most that many queries
     const Workspace ws = carve(workspace, Hq, D, rows, tiles, plan_view(nullptr, tiles * G, rows).bytes);
     if (workspace_bytes < ws.bytes) {
         set_error("workspace too small: %zu < %zu", workspace_bytes, ws.bytes);
