@@ -50,7 +50,11 @@ __device__ inline void merge_accumulate(MergeState (&st)[NH], const __amdgpu_buf
                                         const __amdgpu_buffer_rsrc_t (&lse)[NH], const int* list, int n, int lane) {
     constexpr int LPR = D / 4;     // lanes per row (16 bytes each)
     constexpr int RPS = 64 / LPR;  // rows per wave-wide load
-    constexpr int NU = NH >= 4 ? 4 : 8;  // loads in flight per lane and head
+    // Loads in flight per lane and head.  4 (= 8 rows of head_dim 128 per round trip) measured best: 8 cost EVERY layer
+    // 1.2-2.2 us (north-star 36.2 -> 34.9 us per layer, Medusa-64 16.2 -> 15.0, ToT-50 23.6 -> 22.3, one 8k x 8 tree 18.8 ->
+    // 16.6; 198 -> 70 VGPRs: the zero-fills, predicated loads and weighted adds of the unused slots are per-batch fixed cost
+    // for the usual 3-11 rows), 16 cost 3-8 us, 3 ties, 2 and 1 lose 0.2-1.5 us on the long lists
+    constexpr int NU = 4;
     const int sub = lane / LPR, col = lane % LPR;
     for (int cbase = 0; cbase < n; cbase += 64) {
         const int cn = n - cbase < 64 ? n - cbase : 64;
