@@ -128,6 +128,7 @@ _TREE_FUNCS = {
     "deft_tree_extend_node": ([_i64, _i64, C.c_int, _vp], C.c_int),
     "deft_tree_set_node_kv": ([_i64, _i64, C.c_int, _vp], C.c_int),
     "deft_tree_clear_node_kv": ([_i64, _i64], C.c_int),
+    "deft_tree_take_nodes_kv": ([_i64, C.c_int, _vp, _vp, _i64], _i64),
     "deft_tree_node_len": ([_i64, _i64], _i64),
     "deft_tree_node_kv": ([_i64, _i64, _vp, _i64], _i64),
     "deft_tree_node_refs": ([_i64, _i64, _vp, _i64], _i64),

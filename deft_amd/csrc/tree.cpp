@@ -336,6 +336,33 @@ int deft_tree_set_node_kv(int64_t tree, int64_t id, int n, const int64_t* slots)
 
 int deft_tree_clear_node_kv(int64_t tree, int64_t id) { return deft_tree_set_node_kv(tree, id, 0, nullptr); }
 
+// The slot lists of n nodes moved out in one call: out[0 .. total) = the nodes' slots, node after node in `ids` order, each
+// in append order (at most `cap` are written); every list is left empty.  Returns the total (the reference's speculative-
+// decoding mock resets every leaf after every step, branch_func_example.py:430-436: one call instead of three per leaf).
+int64_t deft_tree_take_nodes_kv(int64_t tree, int n, const int64_t* ids, int64_t* out, int64_t cap) {
+    DEFT_TREE_OR_FAIL(t, tree, "deft_tree_take_nodes_kv");
+    if (n < 0 || (n > 0 && !ids) || cap < 0 || (cap > 0 && !out)) {
+        set_error("deft_tree_take_nodes_kv: bad arguments (n=%d)", n);
+        return DEFT_EINVAL;
+    }
+    for (int i = 0; i < n; ++i)
+        if (!t->nodes.count(ids[i])) {
+            set_error("deft_tree_take_nodes_kv: unknown node %lld", (long long)ids[i]);
+            return DEFT_EINVAL;
+        }
+    int64_t total = 0;
+    for (int i = 0; i < n; ++i) {
+        auto& kv = t->nodes.find(ids[i])->second.kv;
+        for (const int64_t s : kv) {
+            if (total < cap) out[total] = s;
+            ++total;
+        }
+        kv.clear();
+    }
+    if (total > 0) structure_changed(t);
+    return total;
+}
+
 int64_t deft_tree_node_len(int64_t tree, int64_t id) {
     DEFT_TREE_OR_FAIL(t, tree, "deft_tree_node_len");
     auto it = t->nodes.find(id);

@@ -103,6 +103,11 @@ class TokenToKVPool:
 
     def _add(self, idx: np.ndarray) -> None:
         self.alloc_ct += len(idx)
+        if len(idx) <= 8:  # (ufunc.at costs microseconds per call whatever the length: a leaf's one or two slots go by hand)
+            ms = self.mem_state
+            for i in idx.tolist():
+                ms[i] += 1
+            return
         np.add.at(self.mem_state, idx, 1)
 
     def add_refs(self, token_index) -> None:
@@ -111,6 +116,11 @@ class TokenToKVPool:
     def decrease_refs(self, token_index) -> int:
         idx = self._as_index(token_index)
         self.alloc_ct -= len(idx)
+        if len(idx) <= 8:
+            ms, lst = self.mem_state, idx.tolist()
+            for i in lst:
+                ms[i] -= 1
+            return sum(int(ms[i] == 0) for i in lst)  # (per occurrence, like the vector form below)
         np.subtract.at(self.mem_state, idx, 1)
         return int(np.sum(self.mem_state[idx] == 0))
 

@@ -280,8 +280,7 @@ def branch_speculative_decoding(tree: TreeCache, iter: int, max_gen_len: int, lo
     for i in range(min(verified, len(leaves))):
         tree.merge_nodes(tree.root, leaves[i], pruneB_flag=False)
     diff = len(tree.root.kv_indices) - before
-    for leaf in leaves:
-        tree.reset_node_KV(leaf, diff)
+    tree.reset_nodes_KV(leaves, diff)  # (= reset_node_KV leaf by leaf, :430-436; one refcount update for all of them)
     assert diff == min(verified, len(leaves))
     return False
 

@@ -376,6 +376,27 @@ class TreeCache:
         node.position_offset += diff
         node.positions = [pos + diff for pos in node.positions]
 
+    def reset_nodes_KV(self, nodes: List[TreeNode], diff: int) -> None:
+        """`reset_node_KV` for many nodes at once (not in the reference, whose speculative-decoding mock calls it leaf by
+        leaf, branch_func_example.py:430-436): the slots of all nodes are released by ONE refcount update -- per node the
+        work is a slot fetch and a clear in the native tree, no numpy call."""
+        if not nodes:
+            return
+        ids = np.fromiter((n.id for n in nodes), dtype=np.int64, count=len(nodes))
+        st = np.zeros(4, dtype=np.int64)
+        check(lib.deft_tree_stats(self._native, _ptr(st)), "deft_tree_stats")
+        cap = max(int(st[2]), 1)  # every slot of the tree: no subset of nodes holds more
+        buf = np.empty(cap, dtype=np.int64)
+        total = int(lib.deft_tree_take_nodes_kv(self._native, len(nodes), _ptr(ids), _ptr(buf), cap))
+        if total < 0:
+            check(total, "deft_tree_take_nodes_kv")
+        assert total <= cap, "slot lists longer than the tree"
+        for n in nodes:
+            n.position_offset += diff
+            n.positions = [pos + diff for pos in n.positions]
+        if total:
+            self.token_to_kv_pool.free(buf[:total])
+
     # ---- :338-370 -------------------------------------------------------------
     def branch(self, node: TreeNode, branch_cnt: int) -> List[TreeNode]:
         assert node.id in self.leaves

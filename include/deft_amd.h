@@ -372,6 +372,7 @@ int deft_tree_append_slots(int64_t tree, int n, const int64_t* ids, const int64_
 int deft_tree_extend_node(int64_t tree, int64_t id, int n, const int64_t* slots);
 int deft_tree_set_node_kv(int64_t tree, int64_t id, int n, const int64_t* slots);
 int deft_tree_clear_node_kv(int64_t tree, int64_t id);
+int64_t deft_tree_take_nodes_kv(int64_t tree, int n, const int64_t* ids, int64_t* out, int64_t cap); /* slots of n nodes moved out (lists left empty); returns the total */
 int64_t deft_tree_node_len(int64_t tree, int64_t id);
 int64_t deft_tree_node_kv(int64_t tree, int64_t id, int64_t* out, int64_t cap);    /* returns the length */
 int64_t deft_tree_node_refs(int64_t tree, int64_t id, int64_t* out, int64_t cap);  /* live leaves below, ascending */
