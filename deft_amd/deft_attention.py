@@ -97,6 +97,9 @@ class _DecodeStep:
         self.plan_ptr = self.plan.data_ptr()
         self.ws = {}  # raw stream -> workspace (calls on one stream are ordered; streams must not share scratch)
         self._rope_key, self._rope_rows = None, None
+        nl = len(self.layer_ptrs)
+        self._o_all = torch.empty((nl, self.nq, Hq * D), dtype=torch.float16, device=self.device) if nl * self.nq * Hq * D <= (64 << 20) else None
+        self._o_used = [False] * nl  # (a layer called twice within a step gets a fresh tensor the second time)
 
     def matches(self, mode, md, pool, cache_loc, q, k) -> bool:
         return (mode is self.mode and md is self.md and pool is self.pool and cache_loc is self.cache_loc
@@ -109,7 +112,13 @@ class _DecodeStep:
         Hq, D = self.Hq, self.D
         if q.stride(1) != 1 or k.stride(1) != 1 or v.stride(1) != 1 or v.stride(0) != self.k_stride or k.dtype != torch.float16:
             raise ValueError("q / k / v rows must be contiguous fp16, k and v with the same row stride")
-        o = torch.empty((self.nq, Hq * D), dtype=torch.float16, device=self.device)
+        # outputs of the step's layers are rows of ONE allocation made with the step (a step object lives for one decode
+        # step, so nothing is overwritten): saves an allocator round trip per layer call
+        if self._o_all is None or layer_id >= self._o_all.shape[0] or self._o_used[layer_id]:
+            o = torch.empty((self.nq, Hq * D), dtype=torch.float16, device=self.device)
+        else:
+            o = self._o_all[layer_id]
+            self._o_used[layer_id] = True
         stream = torch._C._cuda_getCurrentRawStream(self.dev_index)
         ws = self.ws.get(stream)
         if ws is None:
