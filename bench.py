@@ -390,14 +390,67 @@ def cfg5_line(device, layers_model: str, n_gpus: int, rank: int, dist_on: bool, 
     dt = run_timed(b, steps, warmup, dist_on)
     s1 = b.time_stage1(reps=2)
     algo = b.algorithmic_bytes_per_layer()
+    e2e = None
+    if not dist_on:
+        try:  # the advancing loop of the same share, the batch as ONE tree object (TreeCache.init_forest) through the session
+            e2e = forest_end_to_end(b, wv, device, min(steps, 40))
+        except Exception as e:
+            e2e = {"error": f"{type(e).__name__}: {e}"}
     return {"workload": "BASELINE configs[4]: %d independent trees (8192-token prefix x 8 branches x 64 tokens, Llama-3-8B "
                         "DeFT-Flatten) over %d GPU(s), %d per GPU" % (n_gpus * w.trees, n_gpus, len(mine)),
+            "end_to_end": e2e,
             "trees_this_rank": mine, "queries_per_gpu": b.nq, "kv_tokens_per_gpu": b.n_kv,
             "tokens_per_s": round(n_gpus * b.nq / (dt / steps), 1), "ms_per_step": round(dt / steps * 1e3, 4),
             "us_per_layer": round(dt / steps * 1e6 / b.layers, 2), "steps": steps,
             "stage1_us": round(s1["mean_us"], 2) if s1 else None,
             "stage1_hbm_frac": round(algo / (s1["mean_us"] * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4) if s1 else None,
             "collectives_in_data_path": 0, "rccl": "control plane only (barrier + MAX of the step time)"}
+
+
+def forest_end_to_end(b: "Bench", w: Workload, device, steps: int):
+    """cfg5's decode LOOP on one GPU: the rank's trees as one tree object (a root without tokens), every leaf growing a token per
+    step, deft_amd.FlattenDecodeSession (tree advance, TreeMetadata and plan on the GPU, 32 layers, one hipGraph), wall clock
+    without host syncs; next to it the host time of `Forest.metadata()` for the same batch -- what the per-step metadata of
+    separate trees costs when it is built on the host."""
+    from deft_amd.utils.workloads import build_forest_tree
+
+    t0 = time.perf_counter()
+    for _ in range(3):
+        b.forest.metadata()
+    torch.cuda.synchronize(device)
+    host_md_ms = (time.perf_counter() - t0) / 3 * 1e3
+    layers = b.layers
+    q, k_new, v_new = b.q, b.k_new, b.v_new
+    del b.graph
+    b.graph = None
+    tree, pool = build_forest_tree(w, w.trees, layers, str(device), extra_slots=256 + 64 * w.trees * w.width)
+    g = torch.Generator(device=device)
+    g.manual_seed(5)
+    for l in range(layers):
+        pool._storage[l].normal_(generator=g)
+    sess = deft_amd.FlattenDecodeSession(tree, b.Hq, b.Hkv, b.D, layers, lambda l: (q[l], k_new[l], v_new[l]))
+
+    def one():
+        for leaf in tree.leaves.values():
+            leaf.append_token(7)
+        sess.step()
+
+    for _ in range(4):
+        one()
+    torch.cuda.synchronize(device)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(steps):
+        one()
+    e1.record()
+    torch.cuda.synchronize(device)
+    wall = time.perf_counter() - t0
+    return {"what": "the rank's trees as ONE tree object (TreeCache.init_forest) through deft_amd.FlattenDecodeSession, every leaf "
+                    "growing a token per step; no host sync inside the loop",
+            "steps": steps, "ms_per_step": round(wall / steps * 1e3, 4), "gpu_ms_per_step": round(e0.elapsed_time(e1) / steps, 4),
+            "tokens_per_s": round(len(tree.leaves) / (wall / steps), 1), "graph_captures": sess.captures,
+            "host_metadata_ms_of_separate_trees": round(host_md_ms, 3)}
 
 
 def prefill_lines(device, model: str):

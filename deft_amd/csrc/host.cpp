@@ -211,7 +211,11 @@ int64_t deft_md_build(int n_nodes, const int64_t* node_id, const int64_t* parent
         // (a 100k-token prompt: the O(n) check instead of ~1.5 ms of std::sort per step)
         if (!std::is_sorted(kv.begin(), kv.end())) std::sort(kv.begin(), kv.end());
         const int n = (int)kv.size();
-        if (n == 0) {  // the reference raises here (range() with step 0, tree_cache.py:746-748)
+        if (n == 0) {
+            // A ROOT without tokens is a forest's virtual root (independent trees hanging below one tree object, so that one
+            // device tree / one decode session serves the batch): it contributes nothing.  Any other empty node is the
+            // reference's error (range() with step 0, tree_cache.py:746-748).
+            if (u == pre[0]) continue;
             set_error("deft_md_build: node %lld has no KV slot (call alloc() first)", (long long)node_id[u]);
             return DEFT_EINVAL;
         }

@@ -94,6 +94,8 @@ struct RunTable {
     int cap;  // capacity; n > cap = overflow, fall back to scanning the unit arrays
 };
 
+constexpr int LONG_CHUNK = 4;  // tiles per chunk from which a chunk's leader is dispatched ahead of the short ones
+
 __device__ inline void np_record_order(const UnitList& ul, int R, int Hkv, int G, int slots, int chunk_c, int32_t* hdr,
                                        RunTable rt) {
     if (rt.n > rt.cap) {  // rebuild the table is impossible: scan (slow path, huge trees only)
@@ -147,11 +149,20 @@ __device__ inline void np_record_order(const UnitList& ul, int R, int Hkv, int G
         // (one 8192-token prefix under 8 branches, Llama-3-8B: 32 chunks of 2 tiles 23.7 us per layer, 16 of 4 tiles 21.1).
         while (C < 8 && lmax > 16 * C) C <<= 1;
     }
-    int NL = 0;
-    for_runs([&](int, int nt, int uni) { NL += uni ? 1 : (nt + C - 1) / C; });
-    int li = 0, fi = NL;
+    // Leaders of LONG chunks (>= LONG_CHUNK tiles: the shared prefixes) come before all others, whatever run they belong
+    // to: a capped grid hands item b + W to the workgroup that finishes item b, so with the leaders run by run a batch of
+    // trees (prefix chunks, leaf tiles, prefix chunks, leaf tiles, ...) gave the workgroups that already held one
+    // 8-tile chunk a second one (8 trees of 8k x 8 as one tree object: 71 -> 57 us per layer).  Longest first, as in prefill.
+    int NL = 0, NLong = 0;
+    for_runs([&](int, int nt, int uni) {
+        const int S = uni ? 1 : (nt + C - 1) / C;
+        NL += S;
+        if (!uni && nt / S >= LONG_CHUNK) NLong += S;
+    });
+    int liL = 0, liS = NLong, fi = NL;
     for_runs([&](int r, int nt, int uni) {
         const int S = uni ? 1 : (nt + C - 1) / C;  // a union group is one chunk
+        int& li = (!uni && nt / S >= LONG_CHUNK) ? liL : liS;
         for (int p = 0; p < S; ++p) {
             const int cnt = (nt - p + S - 1) / S;
             ul.perm[li] = r + p;
@@ -203,30 +214,36 @@ __device__ inline void record_order_parallel(const UnitList& ul, const RunTable&
             }
             while (C < 8 && lmax > 16 * C) C <<= 1;  // (np_record_order: at most 16 chunks per run while C < 8)
         }
-        int lead = 0, foll = 0;
+        // leaders: long chunks first (np_record_order), each class in run order; followers in run order
+        int leadL = 0, leadS = 0, foll = 0;
         for (int base = 0; base < NR; base += 64) {
             const int k = base + lane;
             const int nt = k < NR ? rt.nt[k] : 0;
             const int S = k < NR ? (rt.uni[k] ? 1 : (nt + C - 1) / C) : 0;
-            int a = S, b = nt - S;  // inclusive scans over the lanes
+            const bool lng = k < NR && !rt.uni[k] && S > 0 && nt / S >= LONG_CHUNK;
+            int aL = lng ? S : 0, aS = lng ? 0 : S, b = nt - S;  // inclusive scans over the lanes
             for (int d = 1; d < 64; d <<= 1) {
-                const int ua = __shfl_up(a, d, 64), ub = __shfl_up(b, d, 64);
+                const int uL = __shfl_up(aL, d, 64), uS = __shfl_up(aS, d, 64), ub = __shfl_up(b, d, 64);
                 if (lane >= d) {
-                    a += ua;
+                    aL += uL;
+                    aS += uS;
                     b += ub;
                 }
             }
             if (k < NR) {
-                rT0[k] = lead + a - S;
+                rT0[k] = lng ? leadL + aL - S : -(leadS + aS - S) - 1;  // short runs: position inside their class, resolved below
                 rSp[k] = foll + b - (nt - S);
             }
-            lead += __shfl(a, 63, 64);
+            leadL += __shfl(aL, 63, 64);
+            leadS += __shfl(aS, 63, 64);
             foll += __shfl(b, 63, 64);
         }
+        for (int k = lane; k < NR; k += 64)
+            if (rT0[k] < 0) rT0[k] = leadL + (-rT0[k] - 1);
         if (lane == 0) {
             sMeta[2] = C;
-            sMeta[3] = lead;
-            hdr[1] = lead;
+            sMeta[3] = leadL + leadS;
+            hdr[1] = leadL + leadS;
         }
     }
     __syncthreads();

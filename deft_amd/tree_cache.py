@@ -300,6 +300,38 @@ class TreeCache:
         table[req_id, : len(ids)] = cache_loc.to(table.device)
         return KVCacheUpdater(True, self.token_to_kv_pool, cache_loc, None, True)
 
+    def init_forest(self, prompts) -> KVCacheUpdater:
+        """A batch of INDEPENDENT trees as one tree object (not in the reference, which decodes one tree per process): a root
+        without tokens whose children are the trees' roots, child t holding `prompts[t]`.  Trees share nothing -- no KV
+        slot lies on two trees' paths -- so every operator, the metadata kernels on the GPU and `DecodeSession` serve the
+        batch unchanged; the Flatten blocks simply keep packing across tree boundaries (the per-slot query masks keep a
+        query off another tree's keys).  Query rows: live leaves by ascending node id, as always.  Returns the updater
+        of all prompt tokens (tree 0's slots, then tree 1's, ...), like `init_prompt`."""
+        self.init_prompt(torch.empty(0, dtype=torch.int32))
+        kids = self.branch(self.root, len(prompts))
+        locs = []
+        for kid, prompt in zip(kids, prompts):
+            locs.append(self.extend_leaf(kid, prompt).cache_loc)
+        return KVCacheUpdater(True, self.token_to_kv_pool, torch.cat(locs) if locs else None, None, True)
+
+    def extend_leaf(self, leaf: TreeNode, token_ids) -> KVCacheUpdater:
+        """`token_ids` appended to a live leaf in one go, with their pool slots and page-table entries (what `init_prompt`
+        does for the root; `append_token` + `alloc` would take a decode step per token)."""
+        assert leaf.id in self.leaves
+        ids = [int(t) for t in torch.as_tensor(token_ids).reshape(-1).tolist()]
+        n = len(ids)
+        start = leaf.position_offset + len(leaf.token_ids)
+        loc = self.token_to_kv_pool.alloc_host(n)
+        assert loc is not None
+        loc64 = loc.astype(np.int64)
+        check(lib.deft_tree_extend_node(self._native, leaf.id, n, _ptr(loc64)), "deft_tree_extend_node")
+        leaf.token_ids.extend(ids)
+        leaf.positions.extend(range(start, start + n))
+        cache_loc = torch.from_numpy(loc).to(self.token_to_kv_pool.device)
+        table = self.req_to_token_pool.req_to_token
+        table[self.leaf_to_req[leaf.id], start : start + n] = cache_loc.to(table.device)
+        return KVCacheUpdater(True, self.token_to_kv_pool, cache_loc, None, True)
+
     # ---- :242-259 -------------------------------------------------------------
     def new_node(self, parent: TreeNode) -> TreeNode:
         node_id = self.node_cnt
@@ -405,7 +437,7 @@ class TreeCache:
         self.node_cnt += branch_cnt
         self.leaves.pop(node.id)
         req = self.leaf_to_req.pop(node.id)
-        path_len = node.positions[-1] + 1
+        path_len = node.positions[-1] + 1 if node.positions else node.position_offset  # (a node without tokens: a forest's virtual root)
         kids = [self._handle(first + i, node) for i in range(branch_cnt)]
         for i, child in enumerate(kids):
             self.leaves[child.id] = child

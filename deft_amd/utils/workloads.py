@@ -127,3 +127,23 @@ def build_forest(w: Workload, n_trees: int, layers: int, device: str, extra_slot
     pool = TokenToKVPool(size, torch.float16, Hkv, D, layers, device=device)
     trees = [build_tree(w, layers, device, pools=(req, pool))[0] for _ in range(n_trees)]
     return Forest(trees), pool
+
+
+def build_forest_tree(w: Workload, n_trees: int, layers: int, device: str, extra_slots: int = 256):
+    """The same batch as ONE tree object (`TreeCache.init_forest`: a root without tokens, the trees below it), which is what
+    the device-side metadata kernels and `DecodeSession` take: per decode step only the new slot numbers cross PCIe, where
+    `Forest.metadata()` rebuilds and concatenates every tree's metadata on the host.  few_shot shapes.  Returns (tree, pool)."""
+    assert w.kind == "few_shot"
+    Hq, Hkv, D, _ = GEOMETRY[w.model]
+    size = n_trees * tree_tokens(w) + extra_slots
+    req = ReqToTokenPool(n_trees * (w.width + 8) + 8, tree_tokens(w) + 512, device=device)
+    pool = TokenToKVPool(size, torch.float16, Hkv, D, layers, device=device)
+    tree = TreeCache(torch.float16, Hkv, D, layers, req, pool, None, True, False)
+    tree.init_forest([torch.arange(1, w.prefix + 1, dtype=torch.int32) for _ in range(n_trees)])
+    for root in sorted(tree.leaves.values(), key=lambda n: n.id):
+        tree.branch(root, w.width)
+    for _ in range(w.branch_len):
+        for leaf in tree.leaves.values():
+            leaf.append_token(7)
+        tree.alloc()
+    return tree, pool

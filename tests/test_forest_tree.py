@@ -1,0 +1,114 @@
+"""A batch of independent trees as ONE tree object (`TreeCache.init_forest`: a root without tokens): host builder, device
+metadata kernels, operators and the captured decode session all serve it unchanged; results equal per-leaf attention over
+each leaf's own root-to-leaf slots (fp64), i.e. what separate trees would give."""
+import numpy as np
+import pytest
+import torch
+
+import deft_amd
+import deft_amd.tree_cache as tc
+from deft_amd.tree_cache import _FIELDS
+
+
+def _forest(device, Hkv=2, D=128, layers=1, prompts=(300, 200, 77), width=3, size=4096):
+    req = deft_amd.ReqToTokenPool(64, size, device=device)
+    pool = deft_amd.TokenToKVPool(size, torch.float16, Hkv, D, layers, device=device)
+    tree = deft_amd.TreeCache(torch.float16, Hkv, D, layers, req, pool, None, True, False)
+    tree.init_forest([torch.arange(1, n + 1, dtype=torch.int32) for n in prompts])
+    for kid in list(tree.leaves.values()):
+        tree.branch(kid, width)
+    return tree, pool
+
+
+def _step(tree):
+    for leaf in tree.leaves.values():
+        leaf.append_token(7)
+    return tree.alloc()
+
+
+def test_forest_tree_host_side():
+    """Slots, positions and page tables of a virtual-root tree; every query sees exactly its own tree's path."""
+    tree, pool = _forest("cpu", layers=0)
+    for _ in range(5):
+        _step(tree)
+    md = deft_amd.TreeMetadata.from_tree_cache(tree)
+    order = sorted(tree.leaves.values(), key=lambda n: n.id)
+    assert md.query_num == 9 and md.total_kv_len == 300 + 200 + 77 + 9 * 5
+    assert [lf.positions[-1] for lf in order] == [304] * 3 + [204] * 3 + [81] * 3  # positions restart with every tree
+    tab = tree.req_to_token_pool.req_to_token
+    for lf in order:
+        n = lf.positions[-1] + 1
+        assert tab[tree.leaf_to_req[lf.id], :n].tolist() == tree.leaf_path_slots(lf)
+    bq, cnt, off, masks, bkv, bl = [t.numpy() for t in (md.block_q, md.block_q_cnts, md.block_q_offset, md.block_bitmasks,
+                                                         md.block_kv, md.block_lens)]
+    seen = {q: set() for q in range(md.query_num)}
+    for b in range(len(cnt)):
+        for k in range(bl[b]):
+            for i in range(cnt[b]):
+                if (masks[b * 128 + k] >> i) & 1:
+                    seen[int(bq[off[b] + i])].add(int(bkv[b * 128 + k]))
+    for q, lf in enumerate(order):
+        assert seen[q] == set(tree.leaf_path_slots(lf))
+
+
+@pytest.mark.gpu
+def test_forest_tree_device_metadata_equals_host_builder(monkeypatch):
+    tree, pool = _forest("cuda")
+    for step in range(40):  # crosses block boundaries; the blocks straddle tree boundaries
+        _step(tree)
+        if step % 13 == 0:
+            monkeypatch.setattr(tc, "DEVICE_METADATA", True)
+            dev = deft_amd.TreeMetadata.from_tree_cache(tree)
+            monkeypatch.setattr(tc, "DEVICE_METADATA", False)
+            host = deft_amd.TreeMetadata.from_tree_cache(tree)
+            for f in _FIELDS:
+                assert torch.equal(getattr(dev, f).cpu(), getattr(host, f).cpu()), (step, f)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["flatten", "node"])
+def test_forest_tree_session_and_truth(mode):
+    """DecodeSession over the virtual-root tree == the eager path bit for bit, and both == fp64 attention of every leaf over
+    its own path."""
+    Hq, Hkv, D, layers = 8, 2, 128, 2
+    g = torch.Generator(device="cuda").manual_seed(11)
+    kv_init = torch.randn((layers, 4096, 2, Hkv, D), dtype=torch.float16, device="cuda", generator=g)
+    (te, pe), (ts, ps) = [_forest("cuda", Hkv, D, layers) for _ in range(2)]
+    pe._storage.copy_(kv_init)
+    ps._storage.copy_(kv_init)
+    nq = 9
+    q = torch.randn((layers, nq, Hq * D), dtype=torch.float16, device="cuda", generator=g)
+    k = torch.randn((layers, nq, Hkv * D), dtype=torch.float16, device="cuda", generator=g)
+    v = torch.randn((layers, nq, Hkv * D), dtype=torch.float16, device="cuda", generator=g)
+    sess = deft_amd.DecodeSession(ts, Hq, Hkv, D, layers, lambda l: (q[l], k[l], v[l]), mode=mode)
+    attn = [deft_amd.DeFTAttention(Hq, D, D ** -0.5, Hkv, l) for l in range(layers)]
+    fmode = deft_amd.forward_mode_from_cli(mode)
+    for step in range(30):
+        for tree in (te, ts):
+            for leaf in tree.leaves.values():
+                leaf.append_token(7)
+        upd = te.alloc()
+        md = deft_amd.TreeMetadata.from_tree_cache(te)
+        deft_amd.register_tree_metadata(md)
+        try:
+            ref = [attn[l](q[l], k[l], v[l], deft_amd.InputMetadata(fmode, upd, pe)) for l in range(layers)]
+        finally:
+            deft_amd.unregister_tree_metadata()
+        out = sess.step()
+        torch.cuda.synchronize()
+        for l in range(layers):
+            assert torch.equal(out[l], ref[l]), (step, l)
+        assert torch.equal(pe._storage, ps._storage)
+    assert sess.captures == 1
+    # fp64 truth, layer 0: every leaf over its own root-to-leaf slots
+    order = sorted(te.leaves.values(), key=lambda n: n.id)
+    kv = pe.kv_data[0].double()
+    o = ref[0].view(nq, Hq, D).double()
+    G = Hq // Hkv
+    for qi, lf in enumerate(order):
+        slots = torch.tensor(te.leaf_path_slots(lf), device="cuda")
+        K, V = kv[slots, 0], kv[slots, 1]  # [n, Hkv, D]
+        for h in range(Hq):
+            s = (K[:, h // G] @ q[0, qi].view(Hq, D)[h].double()) * D ** -0.5
+            truth = torch.softmax(s, 0) @ V[:, h // G]
+            assert (o[qi, h] - truth).abs().max() < 1e-3, (qi, h)
