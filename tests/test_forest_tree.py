@@ -112,3 +112,31 @@ def test_forest_tree_session_and_truth(mode):
             s = (K[:, h // G] @ q[0, qi].view(Hq, D)[h].double()) * D ** -0.5
             truth = torch.softmax(s, 0) @ V[:, h // G]
             assert (o[qi, h] - truth).abs().max() < 1e-3, (qi, h)
+
+
+def test_reset_nodes_kv_equals_reset_node_kv_leaf_by_leaf():
+    """The batched form (one native call, one refcount update) leaves tree, pool refcounts and positions exactly as the
+    reference's leaf-by-leaf loop does (branch_func_example.py:430-436)."""
+    states = []
+    for batched in (False, True):
+        tree, pool = _forest("cpu", layers=0, prompts=(40,), width=5)
+        for _ in range(3):
+            _step(tree)
+        leaves = sorted(tree.leaves.values(), key=lambda n: n.id)
+        if batched:
+            tree.reset_nodes_KV(leaves, 2)
+        else:
+            for lf in leaves:
+                tree.reset_node_KV(lf, 2)
+        states.append((pool.mem_state.copy(), pool.alloc_ct, [list(lf.kv_indices) for lf in leaves],
+                       [lf.positions for lf in leaves], [lf.position_offset for lf in leaves]))
+    a, b = states
+    assert np.array_equal(a[0], b[0]) and a[1:] == b[1:]
+    assert all(len(x) == 0 for x in b[2])
+
+
+def test_an_empty_node_that_is_not_the_root_is_still_an_error():
+    """Only a ROOT without tokens is skipped (the forest's virtual root); elsewhere the reference raises and so do we."""
+    tree, pool = _forest("cpu", layers=0, prompts=(40, 30), width=2)
+    with pytest.raises(deft_amd.DeftLibraryError):
+        deft_amd.TreeMetadata.from_tree_cache(tree)  # the new leaves hold no token yet
