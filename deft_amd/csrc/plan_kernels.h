@@ -148,6 +148,17 @@ __device__ inline void np_record_order(const UnitList& ul, int R, int Hkv, int G
         // shared prefix is one more partial row for EVERY query below it, and the merge reads its rows 16 at a time
         // (one 8192-token prefix under 8 branches, Llama-3-8B: 32 chunks of 2 tiles 23.7 us per layer, 16 of 4 tiles 21.1).
         while (C < 8 && lmax > 16 * C) C <<= 1;
+        // A launch that leaves CUs empty (fewer chunks than CUs = slots / 2) takes the next shorter chunk length -- powers
+        // of two or not -- as long as that still fits one workgroup per CU: Medusa-64 (an 8-tile root under two query
+        // chunks, 32 KV heads) 192 workgroups of 4 tiles -> 256 of 3: 15.8 -> 14.9 us per layer.
+        if (C > 2 && lmax <= 16 * (C - 1)) {
+            int64_t n0 = 0, n1 = 0;
+            for_runs([&](int, int nt, int uni) {
+                n0 += uni ? 1 : (nt + C - 1) / C;
+                n1 += uni ? 1 : (nt + C - 2) / (C - 1);
+            });
+            if (2 * n0 * Hkv < slots && 2 * n1 * Hkv <= slots) --C;
+        }
     }
     // Leaders of LONG chunks (>= LONG_CHUNK tiles: the shared prefixes) come before all others, whatever run they belong
     // to: a capped grid hands item b + W to the workgroup that finishes item b, so with the leaders run by run a batch of
@@ -213,6 +224,11 @@ __device__ inline void record_order_parallel(const UnitList& ul, const RunTable&
                 if (10 * n * Hkv >= 3LL * slots) break;
             }
             while (C < 8 && lmax > 16 * C) C <<= 1;  // (np_record_order: at most 16 chunks per run while C < 8)
+            if (C > 2 && lmax <= 16 * (C - 1)) {       // (np_record_order: fill the CUs of a launch that leaves some empty)
+                const int64_t n0 = wave_sum([C](int nt, int uni) { return uni ? 1 : (nt + C - 1) / C; });
+                const int64_t n1 = wave_sum([C](int nt, int uni) { return uni ? 1 : (nt + C - 2) / (C - 1); });
+                if (2 * n0 * Hkv < slots && 2 * n1 * Hkv <= slots) --C;
+            }
         }
         // leaders: long chunks first (np_record_order), each class in run order; followers in run order
         int leadL = 0, leadS = 0, foll = 0;
