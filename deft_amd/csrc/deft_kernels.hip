@@ -294,6 +294,7 @@ __global__ __launch_bounds__(256, 2) void stage1_kernel(Stage1Params p) {
 #include "stage1_np.h"
 #include "prefill.h"
 #ifdef DEFT_EXPERIMENTS
+#include "prefill_w4.h"    // 4 waves x 2 workgroups per CU: experiment
 #include "prefill_pipe.h"  // software-pipelined form: parity-green, 15-20 % slower; experiments build only
 #endif
 namespace deft {
@@ -1657,6 +1658,17 @@ extern "C" int deft_prefill_f16(const void* q, int64_t q_stride_tok, int64_t q_s
     if (pipe) {
         hipLaunchKernelGGL((prefill_pipe_kernel<128>), grid, dim3(512), PrefillPipeSmem<128>::BYTES, static_cast<hipStream_t>(stream), p);
         return check_launch("prefill (pipelined) launch");
+    }
+    if (knob("DEFT_PREFILL_W4", 0)) {
+        static bool once = false;
+        if (!once) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&prefill_w4_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, PrefillW4Smem<128>::BYTES);
+            once = true;
+        }
+        p.nblk = (max_input_len + 127) / 128;
+        hipLaunchKernelGGL((prefill_w4_kernel<128>), dim3((unsigned)((int64_t)p.nblk * Hq * batch)), dim3(256), PrefillW4Smem<128>::BYTES,
+                           static_cast<hipStream_t>(stream), p);
+        return check_launch("prefill (4-wave) launch");
     }
 #endif
     hipLaunchKernelGGL((prefill_kernel<128>), grid, dim3(512), PrefillSmem<128>::BYTES, static_cast<hipStream_t>(stream), p);

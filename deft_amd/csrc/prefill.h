@@ -169,7 +169,7 @@ __global__ __launch_bounds__(512, 1) void prefill_kernel(PrefillParams p) {
         }
         // ---- one online-softmax step per tile (one rescale of O per 128 keys) ----------------------------------
         // (VALU-bound: per score one max, one fma feeding exp2, one conversion and half a dot2 -- the scale rides in the
-        //  fma, the row sum over the ROUNDED probabilities is a packed fp16 dot with ones)
+        //  fma; the row sum is a chain of fp32 adds, see below)
         float mx = -INFINITY;
         if (diag) {
 #pragma unroll
@@ -192,18 +192,21 @@ __global__ __launch_bounds__(512, 1) void prefill_kernel(PrefillParams p) {
         const float alpha = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run - msafe);
         half8 pb[4][2];
         float sum = 0.f;
-        typedef _Float16 half2v __attribute__((ext_vector_type(2)));
-        const half2v ones = {(_Float16)1.f, (_Float16)1.f};
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
-                const _Float16 p0 = (_Float16)__builtin_amdgcn_exp2f(__builtin_fmaf(acc[kb][r], p.scale_log2e, -msafe));
-                const _Float16 p1 = (_Float16)__builtin_amdgcn_exp2f(__builtin_fmaf(acc[kb][r + 1], p.scale_log2e, -msafe));
-                pb[kb][r >> 3][r & 7] = p0;
-                pb[kb][r >> 3][(r & 7) + 1] = p1;
-                const half2v pp = {p0, p1};
-                sum = __builtin_amdgcn_fdot2(pp, ones, sum, false);
+                // Row sums in fp32 over the UNROUNDED probabilities, as ONE dependent chain of single adds (the reference sums the
+                // unrounded p too, context_flashattention_nopad.py:96-103).  Round 1 summed the rounded values with packed
+                // fp16 dots (v_dot2c_f32_f16): fewer instructions, but that opcode competes with the other wave's MFMAs for
+                // the matrix pipe -- plain adds: Llama-2-7B 779 -> 820 TFLOP/s at 4k tokens, 962 -> 985 at 16k (two side-by-side
+                // chains would be packed into v_pk_add_f32, which is as bad)
+                const float e0 = __builtin_amdgcn_exp2f(__builtin_fmaf(acc[kb][r], p.scale_log2e, -msafe));
+                const float e1 = __builtin_amdgcn_exp2f(__builtin_fmaf(acc[kb][r + 1], p.scale_log2e, -msafe));
+                pb[kb][r >> 3][r & 7] = (_Float16)e0;
+                pb[kb][r >> 3][(r & 7) + 1] = (_Float16)e1;
+                sum += e0;
+                sum += e1;
             }
         sum += __shfl_xor(sum, 32);
         l_run = l_run * alpha + sum;
@@ -212,7 +215,7 @@ __global__ __launch_bounds__(512, 1) void prefill_kernel(PrefillParams p) {
 #pragma unroll
             for (int bk = 0; bk < 4; ++bk)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) o[bk][r] *= alpha;
+                for (int r = 0; r < 16; ++r) o[bk][r] *= alpha;  // (packed by the compiler; 64 single multiplies measured the same)
         }
         // ---- O^T += V^T P^T: 32 MFMAs on four independent accumulators -------------------------------------------
         const int vstage = SM::V_OFF + stg * SM::STAGE;
