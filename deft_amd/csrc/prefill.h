@@ -158,14 +158,22 @@ __global__ __launch_bounds__(512, 1) void prefill_kernel(PrefillParams p) {
             for (int r = 0; r < 16; ++r) acc[kb][r] = 0.f;
         // (fragment addresses = a per-lane base kept in a register + the stage + an immediate: one add per k-step)
         const int kstage = SM::K_OFF + stg * SM::STAGE;
+        // K fragments double-buffered by k-step: the four reads of k-step ks + 1 are issued BEFORE the four MFMAs of ks (left to
+        // itself the compiler reads two fragments, waits, issues two MFMAs -- every pair of MFMAs behind an LDS round trip)
+        half8 af[2][4];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) af[0][kb] = *reinterpret_cast<const half8*>(smem + (kfrag_b[0] + kstage) + 32 * kb * D * 2);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            const char* kp = smem + (kfrag_b[ks] + kstage);
+            if (ks + 1 < KS) {
+                const char* kp = smem + (kfrag_b[ks + 1] + kstage);
 #pragma unroll
-            for (int kb = 0; kb < 4; ++kb) {
-                const half8 a = *reinterpret_cast<const half8*>(kp + 32 * kb * D * 2);
-                acc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qf[ks], acc[kb], 0, 0, 0);
+                for (int kb = 0; kb < 4; ++kb) af[(ks + 1) & 1][kb] = *reinterpret_cast<const half8*>(kp + 32 * kb * D * 2);
             }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) acc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks & 1][kb], qf[ks], acc[kb], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         // ---- one online-softmax step per tile (one rescale of O per 128 keys) ----------------------------------
         // (VALU-bound: per score one max, one fma feeding exp2, one conversion and half a dot2 -- the scale rides in the
@@ -222,23 +230,32 @@ __global__ __launch_bounds__(512, 1) void prefill_kernel(PrefillParams p) {
         int vfrag[4];
 #pragma unroll
         for (int bk = 0; bk < 4; ++bk) vfrag[bk] = vfrag_b[bk] + vstage;
+        // V^T fragments double-buffered by (key block, k-step) group: the eight transpose reads of group g + 1 go out before the
+        // four MFMAs of group g
+        typedef __attribute__((address_space(3))) short4v* lds_s4;
+        union VFrag {
+            short4v s4[2];
+            half8 h8;
+        };
+        VFrag vf[2][4];
+        auto load_group = [&](int g, VFrag (&dst)[4]) {
+            const int kb = g >> 1, tt = g & 1;
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb) {
-#pragma unroll
-            for (int tt = 0; tt < 2; ++tt) {
-#pragma unroll
-                for (int bk = 0; bk < 4; ++bk) {
-                    typedef __attribute__((address_space(3))) short4v* lds_s4;
-                    const int vb = vfrag[bk] + (32 * kb * D * 2 + (16 * tt) * D * 2);
-                    union {
-                        short4v s4[2];
-                        half8 h8;
-                    } av;
-                    av.s4[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(uintptr_t)(vb));
-                    av.s4[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(uintptr_t)(vb + 8 * D * 2));
-                    o[bk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av.h8, pb[kb][tt], o[bk], 0, 0, 0);
-                }
+            for (int bk = 0; bk < 4; ++bk) {
+                const int vb = vfrag[bk] + (32 * kb * D * 2 + (16 * tt) * D * 2);
+                dst[bk].s4[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(uintptr_t)(vb));
+                dst[bk].s4[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(uintptr_t)(vb + 8 * D * 2));
             }
+        };
+        load_group(0, vf[0]);
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            if (g + 1 < 8) load_group(g + 1, vf[(g + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int bk = 0; bk < 4; ++bk)
+                o[bk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[g & 1][bk].h8, pb[g >> 1][g & 1], o[bk], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     wait_vm<0>();
