@@ -521,13 +521,10 @@ int deft_tree_layout_fetch(int64_t tree, int32_t* node_start, int32_t* node_len,
 // Sizes of the metadata the device kernels will produce for the CURRENT lengths, each leaf `grow` tokens longer
 // (0 = now; the layout's slack = the most the buffers must ever hold): sizes[0..7] as deft_md_sizes, sizes[8] = physical
 // 128-slot blocks.  O(nodes + blocks), touches no slot.
-int deft_tree_md_sizes(int64_t tree, int max_q_len, int block_len, int max_block_len, int grow, int64_t sizes[9]) {
-    DEFT_TREE_OR_FAIL(t, tree, "deft_tree_md_sizes");
-    const Layout& L = t->lay;
-    if (!L.valid || !sizes || max_q_len < 1 || block_len < 1 || grow < 0) {
-        set_error("deft_tree_md_sizes: no valid layout or bad arguments");
-        return DEFT_EINVAL;
-    }
+// Sizes of the metadata for the current lengths + `grow` tokens per live leaf.  The leaf sets (bit sets from the leaves' paths)
+// do not depend on the growth and are built once by the caller.
+static void md_sizes_for(const Tree* t, const Layout& L, const std::vector<uint64_t>& refs, int max_q_len, int block_len,
+                         int max_block_len, int grow, int64_t sizes[9]) {
     const int n = (int)L.dfs.size();
     std::vector<int64_t> len(n), nq(n);
     for (int i = 0; i < n; ++i) {
@@ -549,16 +546,7 @@ int deft_tree_md_sizes(int64_t tree, int max_q_len, int block_len, int max_block
     const int64_t NBp = (total + block_len - 1) / block_len;
     int64_t NB = 0, P = 0;
     {
-        // leaf sets as sorted row lists per node would cost O(nodes x leaves); the union size of a block is counted
-        // with bit sets built from the leaves' paths instead
         const int nqw = L.nqw;
-        std::vector<uint64_t> refs((size_t)n * nqw, 0ull);
-        int r = 0;
-        for (int64_t leaf : t->leaves) {
-            for (int64_t cur = leaf; cur >= 0; cur = t->nodes.at(cur).parent)
-                refs[(size_t)L.index.at(cur) * nqw + (r >> 6)] |= 1ull << (r & 63);
-            ++r;
-        }
         std::vector<uint64_t> uni(nqw);
         int i = 0;
         int64_t pos = 0;  // flattened position of node i's first slot
@@ -588,6 +576,51 @@ int deft_tree_md_sizes(int64_t tree, int max_q_len, int block_len, int max_block
     sizes[6] = P;
     sizes[7] = NB * block_len;
     sizes[8] = NBp;
+}
+
+static std::vector<uint64_t> leaf_bitsets(const Tree* t, const Layout& L) {
+    // leaf sets as sorted row lists per node would cost O(nodes x leaves); bit sets built from the leaves' paths instead
+    const int n = (int)L.dfs.size(), nqw = L.nqw;
+    std::vector<uint64_t> refs((size_t)n * nqw, 0ull);
+    int r = 0;
+    for (int64_t leaf : t->leaves) {
+        for (int64_t cur = leaf; cur >= 0; cur = t->nodes.at(cur).parent)
+            refs[(size_t)L.index.at(cur) * nqw + (r >> 6)] |= 1ull << (r & 63);
+        ++r;
+    }
+    return refs;
+}
+
+int deft_tree_md_sizes(int64_t tree, int max_q_len, int block_len, int max_block_len, int grow, int64_t sizes[9]) {
+    DEFT_TREE_OR_FAIL(t, tree, "deft_tree_md_sizes");
+    const Layout& L = t->lay;
+    if (!L.valid || !sizes || max_q_len < 1 || block_len < 1 || grow < 0) {
+        set_error("deft_tree_md_sizes: no valid layout or bad arguments");
+        return DEFT_EINVAL;
+    }
+    md_sizes_for(t, L, leaf_bitsets(t, L), max_q_len, block_len, max_block_len, grow, sizes);
+    return DEFT_OK;
+}
+
+// Element-wise MAXIMUM of the sizes over every growth 0 .. grow_max: what buffers must hold for a whole structural epoch.
+// The block arrays are NOT monotone in the leaves' lengths -- as the leaves grow the 128-slot block boundaries move over the
+// nodes, and a boundary that puts pieces of several nodes into one block makes that block's query list (and, beyond 32
+// queries, the number of emitted blocks) larger than it is for longer leaves: sizing for the longest tree alone
+// under-allocated block_q by a few entries on multi-level trees (found by tools/fuzz_replay.py).
+int deft_tree_md_sizes_upto(int64_t tree, int max_q_len, int block_len, int max_block_len, int grow_max, int64_t sizes[9]) {
+    DEFT_TREE_OR_FAIL(t, tree, "deft_tree_md_sizes_upto");
+    const Layout& L = t->lay;
+    if (!L.valid || !sizes || max_q_len < 1 || block_len < 1 || grow_max < 0) {
+        set_error("deft_tree_md_sizes_upto: no valid layout or bad arguments");
+        return DEFT_EINVAL;
+    }
+    const std::vector<uint64_t> refs = leaf_bitsets(t, L);
+    int64_t cur[9];
+    for (int k = 0; k < 9; ++k) sizes[k] = 0;
+    for (int g = 0; g <= grow_max; ++g) {
+        md_sizes_for(t, L, refs, max_q_len, block_len, max_block_len, g, cur);
+        for (int k = 0; k < 9; ++k) sizes[k] = std::max(sizes[k], cur[k]);
+    }
     return DEFT_OK;
 }
 

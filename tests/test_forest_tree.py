@@ -140,3 +140,35 @@ def test_an_empty_node_that_is_not_the_root_is_still_an_error():
     tree, pool = _forest("cpu", layers=0, prompts=(40, 30), width=2)
     with pytest.raises(deft_amd.DeftLibraryError):
         deft_amd.TreeMetadata.from_tree_cache(tree)  # the new leaves hold no token yet
+
+
+def test_epoch_capacities_cover_every_growth():
+    """The buffers of a structural epoch are sized by deft_tree_md_sizes_upto: the element-wise maximum over EVERY growth
+    0 .. SLACK + 4 of the leaves.  The block arrays are not monotone in the growth (block boundaries move over the nodes), so
+    sizing for the longest tree alone under-allocates -- the multi-level tree below needs more block_q entries at some
+    intermediate growth than at the largest one (found by tools/fuzz_replay.py)."""
+    from deft_amd._lib import lib, check
+    from deft_amd.tree_cache import _ptr
+
+    worst = 0
+    for prompt, widths, lens in ((129, (3, 4), (7, 40)), (300, (5, 2, 3), (3, 130, 2)), (1000, (6, 6), (200, 1)), (5, (2, 2, 2), (40, 40, 40))):
+        req = deft_amd.ReqToTokenPool(256, 8192, device="cpu")
+        pool = deft_amd.TokenToKVPool(16384, torch.float16, 1, 128, 0, device="cpu")
+        tree = deft_amd.TreeCache(torch.float16, 1, 128, 0, req, pool, None, True, False)
+        tree.init_prompt(torch.arange(prompt, dtype=torch.int32))
+        for wd, ln in zip(widths, lens):
+            for leaf in list(tree.leaves.values()):
+                tree.branch(leaf, wd)
+            for _ in range(ln):
+                _step(tree)
+        sizes = np.zeros(5, dtype=np.int64)
+        check(lib.deft_tree_layout(tree._native, 256, _ptr(sizes)), "deft_tree_layout")
+        upto, at_max = np.zeros(9, dtype=np.int64), np.zeros(9, dtype=np.int64)
+        check(lib.deft_tree_md_sizes_upto(tree._native, 32, 128, -1, 260, _ptr(upto)), "upto")
+        check(lib.deft_tree_md_sizes(tree._native, 32, 128, -1, 260, _ptr(at_max)), "sizes")
+        for g in range(0, 261):
+            cur = np.zeros(9, dtype=np.int64)
+            check(lib.deft_tree_md_sizes(tree._native, 32, 128, -1, g, _ptr(cur)), "sizes")
+            assert (cur <= upto).all(), (prompt, g, cur, upto)
+            worst = max(worst, int(cur[6] - at_max[6]))
+    assert worst > 0  # (at least one of these trees is a case the old sizing got wrong)

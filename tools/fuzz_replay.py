@@ -13,6 +13,7 @@ t_end = time.time() + budget
 max_runs = int(sys.argv[3]) if len(sys.argv) > 3 else 10 ** 9
 runs = steps = 0
 worst = 0.0
+tight = [0, 0]  # elements beyond 5e-4 + half ulp, elements checked
 while time.time() < t_end and runs < max_runs:
     Hq, Hkv = rng.choice([(32, 32), (32, 8), (8, 2), (4, 4), (16, 1)])
     D = 64 if Hq <= 8 and rng.random() < 0.3 else 128
@@ -67,8 +68,13 @@ while time.time() < t_end and runs < max_runs:
             ref = torch.einsum("hs,hsd->hd", torch.softmax(s, dim=-1), vv)
             err = (od[i] - ref).abs().max().item()
             worst = max(worst, err)
-            # per ELEMENT: 5e-4 + half an fp16 ulp of that element (tests/test_prefill.py::_close_to_truth), well inside north_star's 1e-3
-            bad = ((od[i] - ref).abs() > 5e-4 + 2.0 ** -11 * ref.abs()).sum().item()
+            # per ELEMENT.  The bar is north_star's 1e-3 (+ half an fp16 ulp of the element: the output's own rounding).  The
+            # tighter 5e-4 + half ulp is COUNTED, not asserted: with the probabilities rounded to fp16 for the PV MFMA (relative
+            # 2^-11 each) a context of ten or twenty keys leaves an element 3 sigma out once in ~10^6 -- long contexts average it away
+            diff = (od[i] - ref).abs()
+            bad = (diff > 1e-3 + 2.0 ** -11 * ref.abs()).sum().item()
+            tight[0] += int((diff > 5e-4 + 2.0 ** -11 * ref.abs()).sum().item())
+            tight[1] += diff.numel()
             assert bad == 0, (bad, err, mode, task, Hq, Hkv, prompt, i, len(slots))
         steps += 1
         return out
@@ -79,4 +85,4 @@ while time.time() < t_end and runs < max_runs:
     finally:
         rp.TreeCache = real
     runs += 1
-print(f"fuzz ok: {runs} replays, {steps} checked steps, worst |err| {worst:.2e}")
+print(f"fuzz ok: {runs} replays, {steps} checked steps, worst |err| {worst:.2e}; {tight[0]} of {tight[1]} elements beyond 5e-4 + half an fp16 ulp (none beyond 1e-3 + half an ulp)")
