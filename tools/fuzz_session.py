@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""Randomised check of the captured decode loop: random multi-level trees (or batches of trees as one tree object), random cuts
+and branches between runs of decode steps; deft_amd.DecodeSession (one hipGraph per structural epoch) against the eager path
+(tree.alloc + TreeMetadata.from_tree_cache + DeFTAttention) BIT FOR BIT -- outputs, pool bytes, page tables -- at every step.
+   tools/fuzz_session.py [seconds] [seed]"""
+import os, sys, time, random
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+import deft_amd
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+t_end = time.time() + budget
+runs = steps = captures = 0
+while time.time() < t_end:
+    Hq, Hkv = rng.choice([(32, 32), (32, 8), (8, 2), (4, 4), (16, 1)])
+    D, layers = 128, rng.choice([1, 2])
+    mode = rng.choice(["flatten", "flatten", "node"])
+    size = 1 << 17 if Hkv <= 8 else 1 << 16
+    g = torch.Generator(device="cuda").manual_seed(rng.randint(0, 10 ** 6))
+    kv_init = torch.randn((layers, size, 2, Hkv, D), dtype=torch.float16, device="cuda", generator=g)
+    forest = rng.random() < 0.3
+    prompts = [rng.choice([1, 5, 127, 128, 129, 300, 1000, 3000]) for _ in range(rng.randint(2, 4) if forest else 1)]
+    widths = [rng.randint(1, 5) for _ in range(rng.randint(1, 3))]
+    lens = [rng.choice([1, 2, 7, 40, 130]) for _ in widths]
+    trees = []
+    for _ in range(2):
+        req = deft_amd.ReqToTokenPool(512, 8192, device="cuda")
+        pool = deft_amd.TokenToKVPool(size, torch.float16, Hkv, D, layers, device="cuda")
+        tree = deft_amd.TreeCache(torch.float16, Hkv, D, layers, req, pool, None, True, False)
+        if forest:
+            tree.init_forest([torch.arange(n, dtype=torch.int32) for n in prompts])
+        else:
+            tree.init_prompt(torch.arange(prompts[0], dtype=torch.int32))
+        pool._storage.copy_(kv_init)
+        trees.append((tree, pool))
+    (te, pe), (ts, ps) = trees
+    cap = 512
+    q = torch.randn((layers, cap, Hq * D), dtype=torch.float16, device="cuda", generator=g)
+    k = torch.randn((layers, cap, Hkv * D), dtype=torch.float16, device="cuda", generator=g)
+    v = torch.randn((layers, cap, Hkv * D), dtype=torch.float16, device="cuda", generator=g)
+    nq_now = [1]
+    sess = deft_amd.DecodeSession(ts, Hq, Hkv, D, layers, lambda l: (q[l, : nq_now[0]], k[l, : nq_now[0]], v[l, : nq_now[0]]), mode=mode)
+    attn = [deft_amd.DeFTAttention(Hq, D, D ** -0.5, Hkv, l) for l in range(layers)]
+    fmode = deft_amd.forward_mode_from_cli(mode)
+
+    def both(nsteps):
+        global steps
+        for _ in range(nsteps):
+            for tree in (te, ts):
+                for leaf in tree.leaves.values():
+                    leaf.append_token(7)
+            upd = te.alloc()
+            md = deft_amd.TreeMetadata.from_tree_cache(te)
+            deft_amd.register_tree_metadata(md)
+            n = md.query_num
+            nq_now[0] = n
+            ref = [attn[l](q[l, :n], k[l, :n], v[l, :n], deft_amd.InputMetadata(fmode, upd, pe)) for l in range(layers)]
+            out = sess.step()
+            torch.cuda.synchronize()
+            for l in range(layers):
+                assert torch.equal(out[l][:n], ref[l]), (runs, steps, l, mode, Hq, Hkv, prompts, widths, lens)
+            assert torch.equal(pe._storage, ps._storage), (runs, steps)
+            assert torch.equal(te.req_to_token_pool.req_to_token, ts.req_to_token_pool.req_to_token), (runs, steps)
+            steps += 1
+
+    for wd, ln in zip(widths, lens):
+        for tree in (te, ts):
+            for leaf in sorted(tree.leaves.values(), key=lambda n: n.id):
+                if len(tree.leaves) + wd - 1 <= 60:
+                    tree.branch(leaf, wd)
+        both(ln)
+    for _ in range(rng.randint(0, 2)):  # structural changes: cut some leaves, branch one, then decode on
+        for tree in (te, ts):
+            lv = sorted(tree.leaves.values(), key=lambda n: n.id)
+            r2 = random.Random(runs)
+            for leaf in r2.sample(lv, min(len(lv) - 1, r2.randint(0, 2))):
+                tree.cut(leaf)
+            lv = sorted(tree.leaves.values(), key=lambda n: n.id)
+            tree.branch(lv[0], r2.randint(2, 3))
+        both(rng.choice([3, 20, 140]))
+    captures += sess.captures
+    deft_amd.unregister_tree_metadata()
+    runs += 1
+print(f"session fuzz ok: {runs} trees, {steps} steps bit-identical to the eager path, {captures} graph captures")
