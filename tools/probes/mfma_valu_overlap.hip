@@ -9,6 +9,7 @@
 //   mode 7 / 8: waves 0-3 / all 8 waves: 64 MFMAs whose A operand is a FRESH 1 KB fragment from LDS each (ds_read_b128, conflict-free,
 //               fragments of MFMA i + 4 read before MFMA i): the prefill kernel's LDS diet without its VALU work
 //   mode 9: all 8 waves: mode 8's MFMAs + LDS reads with the VALU phase after them (the prefill tile's shape)
+//   mode 10: mode 9 + one workgroup barrier per iteration        mode 11: mode 10 + 8 LDS-DMA instructions (8 KB) per wave and iteration
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -54,7 +55,7 @@ __device__ __forceinline__ void lds_mfma_phase(floatx16 (&acc)[4], const char* l
         __builtin_amdgcn_sched_barrier(0);
     }
 }
-__global__ __launch_bounds__(512, 1) void k(float* out, int mode, int iters) {
+__global__ __launch_bounds__(512, 1) void k(float* out, int mode, int iters, const char* src) {
     extern __shared__ char smem[];
     const int w = threadIdx.x >> 6;
     floatx16 acc[4] = {};
@@ -70,6 +71,19 @@ __global__ __launch_bounds__(512, 1) void k(float* out, int mode, int iters) {
     for (int it = 0; it < iters; ++it) {
         if (mode == 7 || mode == 8) { lds_mfma_phase(acc, lds, b); }
         else if (mode == 9) { lds_mfma_phase(acc, lds, b); valu_phase(x, 0.999f); }
+        else if (mode == 10 || mode == 11) {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (mode == 11) {
+                const char* g = src + ((size_t)(blockIdx.x * 37 + it) % 960) * 65536 + w * 8192 + (threadIdx.x & 63) * 16;
+#pragma unroll
+                for (int d = 0; d < 8; ++d) {
+                    const unsigned dst = __builtin_amdgcn_readfirstlane(64 * 1024 + w * 8192 + d * 1024);
+                    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(g + d * 1024), "s"(dst) : "memory");
+                }
+            }
+            lds_mfma_phase(acc, lds, b);
+            valu_phase(x, 0.999f);
+        }
         else if (mode >= 5) { mixed_phase(acc, a, b, x, 0.999f); }
         else if (mode == 0 || (mode == 2 && lo)) { mfma_phase(acc, a, b); mfma_phase(acc, a, b); }
         else if (mode == 1 || (mode == 2 && !lo)) { valu_phase(x, 0.999f); }
@@ -86,10 +100,11 @@ int main() {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const int iters = 2000;
     hipFuncSetAttribute(reinterpret_cast<const void*>(&k), hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024);
-    for (int mode = 0; mode < 10; ++mode) {
-        hipLaunchKernelGGL(k, dim3(256), dim3(512), 136 * 1024, 0, out, mode, 100);
+    char* src; hipMalloc(&src, 64 << 20); hipMemset(src, 0, 64 << 20);
+    for (int mode = 0; mode < 12; ++mode) {
+        hipLaunchKernelGGL(k, dim3(256), dim3(512), 136 * 1024, 0, out, mode, 100, src);
         hipDeviceSynchronize();
-        hipEventRecord(e0); hipLaunchKernelGGL(k, dim3(256), dim3(512), 136 * 1024, 0, out, mode, iters); hipEventRecord(e1); hipEventSynchronize(e1);
+        hipEventRecord(e0); hipLaunchKernelGGL(k, dim3(256), dim3(512), 136 * 1024, 0, out, mode, iters, src); hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         printf("mode %d: %.1f us total, %.3f us per iteration (64 MFMAs and/or one VALU phase per wave)\n", mode, ms * 1e3, ms * 1e3 / iters);
     }
