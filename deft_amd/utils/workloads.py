@@ -59,6 +59,9 @@ WORKLOADS: Dict[str, Workload] = {
     # one GPU's share = 8 trees, decoded as ONE batch; and a single tree of the same shape for comparison
     "forest_8kx8": Workload("forest_8kx8", "llama3-8b", "flatten", "few_shot", 8192, 8, 64, 8),
     "forest_8kx8_single": Workload("forest_8kx8_single", "llama3-8b", "flatten", "few_shot", 8192, 8, 64),
+    # a long shared prefix (not a BASELINE configuration: where the kernel goes when the launch is long)
+    "fewshot_16kx32": Workload("fewshot_16kx32", "llama2-7b", "flatten", "few_shot", 16384, 32, 200),
+    "fewshot_64kx8_gqa": Workload("fewshot_64kx8_gqa", "llama3-8b", "flatten", "few_shot", 65536, 8, 200),
     # head_dim 64 (not a Llama geometry; measured once so the number exists): the north-star tree shape
     "northstar_4kx32_d64": Workload("northstar_4kx32_d64", "mha-d64", "flatten", "few_shot", 4096, 32, 200),
 }
