@@ -386,6 +386,84 @@ __global__ __launch_bounds__(256) void merge_kernel(const float* partial_o, cons
     merge_heads_wave<D, 0, 1>(partial_o, partial_lse, row_q, rows, q, hq, 1, Hq, list, cap, have, out_q, o_sh, lane);
 }
 
+// Long row lists (a long shared prefix under few queries: 64k tokens x 8 branches is 66 rows per query, and only
+// nq x Hq / 4 workgroups): ONE (query, head) pair per workgroup, its row list dealt round-robin to the four waves, each
+// folding a quarter (merge_accumulate: 8 rows per round trip, so 66 rows cost 3 trips instead of 9), then one combine of the
+// four (m, L, acc) states through LDS.  Deterministic (the deal is a function of the list); its fp32 order differs from
+// merge_kernel's, so a launch uses one or the other as a function of its SHAPE only (launch_merge).
+template <int D>
+__global__ __launch_bounds__(256) void merge_coop_kernel(const float* partial_o, const float* partial_lse, int64_t rows, _Float16* out,
+                                                          int64_t o_st, int64_t o_sh, int cap, const int32_t* qoff,
+                                                          const int32_t* qlist, const int32_t* qinl) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int LPR = D / 4;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int q = blockIdx.x, hq = blockIdx.y;
+    int* sub = reinterpret_cast<int*>(smem) + w * cap;                         // this wave's quarter of the list
+    float* xacc = reinterpret_cast<float*>(smem + sizeof(int) * 4 * (size_t)cap);  // [4][D]
+    float* xml = xacc + 4 * D;                                                 // [4][2]: m, L
+    const int mine = lane < 16 ? qinl[q * 16 + lane] : 0;
+    const int n = __builtin_amdgcn_readfirstlane(mine);
+    if (n <= 8) {  // one round trip's worth: wave 0 alone, in merge_kernel's order (same bits), no combine
+        if (w == 0) {
+            if (lane >= 1 && lane <= n) sub[lane - 1] = mine;
+            __builtin_amdgcn_wave_barrier();
+            merge_heads_wave<D, 0, 1>(partial_o, partial_lse, nullptr, rows, q, hq, 1, hq + 1, sub, cap, n, out + (int64_t)q * o_st, o_sh, lane);
+        }
+        return;
+    }
+    int nw = 0;  // rows of this wave: list entries w, w + 4, ...
+    if (n <= 15) {
+        const int src = 1 + w + 4 * lane;  // lane i takes entry w + 4 i
+        const int v = __shfl(mine, src < 16 ? src : 0);
+        nw = (n - w + 3) / 4;
+        if (lane < nw) sub[lane] = v;
+    } else {
+        const int o = qoff[q];
+        nw = (n - w + 3) / 4;
+        for (int j = lane; j < nw && j < cap; j += 64) sub[j] = qlist[o + w + 4 * j];
+        if (nw > cap) nw = cap;  // (launch_merge sizes cap >= rows / 4 + 1: never)
+    }
+    __builtin_amdgcn_wave_barrier();
+    __amdgpu_buffer_rsrc_t po[1] = {make_rsrc(partial_o + (int64_t)hq * rows * D)};
+    __amdgpu_buffer_rsrc_t ls[1] = {make_rsrc(partial_lse + (int64_t)hq * rows)};
+    MergeState st[1];
+    if (nw > 0) merge_accumulate<D, 0, 1>(st, po, ls, sub, nw, lane);
+    floatx4 a = st[0].acc;
+#pragma unroll
+    for (int off = LPR; off < 64; off <<= 1)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[e] += __shfl_xor(a[e], off);
+    if (lane < LPR) *reinterpret_cast<floatx4*>(xacc + w * D + 4 * lane) = a;
+    if (lane == 0) {
+        xml[2 * w] = st[0].m;
+        xml[2 * w + 1] = st[0].L;
+    }
+    __syncthreads();
+    if (w == 0 && lane < LPR) {
+        float m[4], M = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            m[i] = xml[2 * i];
+            M = fmaxf(M, m[i]);
+        }
+        float L = 0.f;
+        floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float f = (m[i] == -INFINITY) ? 0.f : __expf(m[i] - M);
+            L += f * xml[2 * i + 1];
+            acc += *reinterpret_cast<const floatx4*>(xacc + i * D + 4 * lane) * f;
+        }
+        const float inv = L > 0.f ? 1.f / L : 0.f;
+        _Float16* dst = out + (int64_t)q * o_st + (int64_t)hq * o_sh;
+        half2v lo = {(_Float16)(acc[0] * inv), (_Float16)(acc[1] * inv)};
+        half2v hi = {(_Float16)(acc[2] * inv), (_Float16)(acc[3] * inv)};
+        *reinterpret_cast<half2v*>(dst + 4 * lane) = lo;
+        *reinterpret_cast<half2v*>(dst + 4 * lane + 2) = hi;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // paged KV append: one 16-byte piece per thread
 // ---------------------------------------------------------------------------
@@ -653,6 +731,17 @@ static int launch_merge(int D, const Workspace& ws, const PlanView* pv, const in
     const int32_t* qoff = pv ? pv->qoff : nullptr;
     const int32_t* qlist = pv ? pv->qlist : nullptr;
     const int32_t* qinl = pv ? pv->qinl : nullptr;
+    // Few queries (where a long shared prefix means long row lists and merge_kernel's grid leaves most CUs empty): the
+    // cooperative form.  The choice depends on nq and Hq alone -- NOT on row capacities, which differ between the eager
+    // path and a captured session of the same step -- and the kernel itself falls back to merge_kernel's single-wave order
+    // for lists of up to 8 rows, so the two paths stay bit-identical.
+    if (D == 128 && lists && nq <= 16 && (int64_t)nq * Hq <= 1024) {
+        const int ccap = (int)std::min<int64_t>(std::max<int64_t>(rows / 4 + 2, 16), MERGE_LIST_CAP);  // (>= 8: the single-wave path stages up to 8 rows)
+        const size_t clds = sizeof(int) * 4 * (size_t)ccap + sizeof(float) * (4 * 128 + 8);
+        hipLaunchKernelGGL((merge_coop_kernel<128>), dim3((unsigned)nq, (unsigned)Hq), dim3(256), clds, stream, ws.partial_o,
+                           ws.partial_lse, rows, static_cast<_Float16*>(out), o_st, o_sh, ccap, qoff, qlist, qinl);
+        return check_launch("merge (cooperative) launch");
+    }
 #define DEFT_MERGE_LAUNCH(DD)                                                                                              \
     hipLaunchKernelGGL((merge_kernel<DD>), grid, dim3(256), lds, stream, ws.partial_o, ws.partial_lse, row_q, rows,         \
                        static_cast<_Float16*>(out), o_st, o_sh, Hq, cap, lists, qoff, qlist, qinl)
