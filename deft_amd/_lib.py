@@ -140,6 +140,7 @@ _TREE_FUNCS = {
     "deft_tree_layout_fetch": ([_i64, _vp, _vp, _vp, _vp, _vp, _vp], C.c_int),
     "deft_tree_md_sizes": ([_i64, C.c_int, C.c_int, C.c_int, C.c_int, _vp], C.c_int),
     "deft_tree_md_sizes_upto": ([_i64, C.c_int, C.c_int, C.c_int, C.c_int, _vp], C.c_int),
+    "deft_tree_md_caps": ([_i64, C.c_int, C.c_int, C.c_int, C.c_int, _vp], C.c_int),
     "deft_tree_dev_scratch_bytes": ([C.c_int, C.c_int, C.c_int], _sz),
     "deft_tree_dev_advance": ([C.c_int, C.c_int, C.c_int] + [_vp] * 9, C.c_int),
     "deft_tree_dev_build_md": ([C.c_int, C.c_int, C.c_int] + [_vp] * 6 + [C.c_int] * 4 + [_vp, _sz] + [_vp] * 12 + [_vp, _vp], C.c_int),

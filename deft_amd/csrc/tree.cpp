@@ -624,6 +624,58 @@ int deft_tree_md_sizes_upto(int64_t tree, int max_q_len, int block_len, int max_
     return DEFT_OK;
 }
 
+// Upper bounds of deft_tree_md_sizes over every growth 0..grow_max, in O(nodes): what an epoch's buffers are sized with.
+// The node arrays, the total and the physical block count grow with the leaves, so their largest value is the one at
+// grow_max.  The block arrays are not monotone (block boundaries move over the nodes as the leaves in front of them grow), and
+// the exact maximum (deft_tree_md_sizes_upto) costs one pass over all blocks per growth -- 0.3 ms for a 64-leaf tree, paid
+// at EVERY step of a speculative-decoding loop, where each step is a new epoch.  Bound instead: a block's query list is at
+// most the concatenation of the lists of the nodes that touch it, and a node of len > 0 positions touches at most
+// ceil((len - 1) / block_len) + 1 blocks wherever it starts -- exactly (last / block_len - first / block_len + 1) when
+// nothing in front of it grows (the shared prefix: the nodes before the first leaf in DFS order).
+int deft_tree_md_caps(int64_t tree, int max_q_len, int block_len, int max_block_len, int grow_max, int64_t sizes[9]) {
+    DEFT_TREE_OR_FAIL(t, tree, "deft_tree_md_caps");
+    const Layout& L = t->lay;
+    if (!L.valid || !sizes || max_q_len < 1 || block_len < 1 || grow_max < 0) {
+        set_error("deft_tree_md_caps: no valid layout or bad arguments");
+        return DEFT_EINVAL;
+    }
+    const int n = (int)L.dfs.size();
+    int64_t NE = 0, total = 0, n_node_q = 0, n_node_kv = 0, NB = 0, P = 0, fixed_pos = 0;
+    bool fixed = true;  // no leaf so far: this node's first position does not move during the epoch
+    for (int i = 0; i < n; ++i) {
+        const TNode& nd = t->nodes.at(L.dfs[i]);
+        const int64_t len = (int64_t)nd.kv.size() + (nd.leaf ? grow_max : 0), nq = nd.nrefs;
+        total += len;
+        const int64_t qch = (nq + max_q_len - 1) / max_q_len;
+        const int64_t step = max_block_len == -1 ? len : max_block_len;
+        const int64_t kch = step > 0 ? (len + step - 1) / step : 0;
+        NE += qch * kch;
+        n_node_q += nq * kch;
+        n_node_kv += len * qch;
+        if (nd.leaf && grow_max > 0) fixed = false;
+        int64_t touched = 0;
+        if (len > 0)
+            touched = fixed ? (fixed_pos + len - 1) / block_len - fixed_pos / block_len + 1 : (len - 1 + block_len - 1) / block_len + 1;
+        if (fixed) fixed_pos += len;
+        NB += qch * touched;
+        P += nq * touched;
+    }
+    // (many short nodes per block: a list holds no leaf twice, and a block of c queries is ceil(c / max_q_len) <= 1 + c / max_q_len blocks)
+    const int64_t NBp = (total + block_len - 1) / block_len, nleaves = (int64_t)t->leaves.size();
+    P = std::min(P, NBp * nleaves);
+    NB = std::min(NB, NBp + P / max_q_len);
+    sizes[0] = nleaves;
+    sizes[1] = NE;
+    sizes[2] = total;
+    sizes[3] = n_node_q;
+    sizes[4] = n_node_kv;
+    sizes[5] = NB;
+    sizes[6] = P;
+    sizes[7] = NB * block_len;
+    sizes[8] = NBp;
+    return DEFT_OK;
+}
+
 // ids of the live leaves in query-row order
 int deft_tree_leaf_ids(int64_t tree, int64_t* out, int cap) {
     DEFT_TREE_OR_FAIL(t, tree, "deft_tree_leaf_ids");

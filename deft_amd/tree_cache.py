@@ -621,8 +621,8 @@ class _DeviceTree:
         # output buffers for the largest tree of this epoch (every leaf SLACK tokens longer)
         cap = np.zeros(9, dtype=np.int64)
         # (a node's room is rounded up to a multiple of four slots, so a leaf can outgrow SLACK by three)
-        # (the maximum over EVERY growth up to that: block counts and query lists are not monotone in the leaves' lengths)
-        check(lib.deft_tree_md_sizes_upto(t._native, mq, bl, mbl, self.SLACK + 4, _ptr(cap)), "deft_tree_md_sizes_upto")
+        # (upper bounds over EVERY growth up to that: block counts and query lists are not monotone in the leaves' lengths)
+        check(lib.deft_tree_md_caps(t._native, mq, bl, mbl, self.SLACK + 4, _ptr(cap)), "deft_tree_md_caps")
         self.cap_lens = _lens_from_sizes(cap)
         self.nbp_cap = int(cap[8])
         self.out = torch.empty(sum(self.cap_lens.values()) + 1, dtype=torch.int64, device=self.device)

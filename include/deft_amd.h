@@ -402,6 +402,7 @@ int deft_tree_layout_fetch(int64_t tree, int32_t* node_start, int32_t* node_len,
                            int32_t* leaf_node, int32_t* slots);
 int deft_tree_md_sizes(int64_t tree, int max_q_len, int block_len, int max_block_len, int grow, int64_t sizes[9]);
 int deft_tree_md_sizes_upto(int64_t tree, int max_q_len, int block_len, int max_block_len, int grow_max, int64_t sizes[9]); /* element-wise max over every growth 0..grow_max: epoch capacities (the block arrays are not monotone in the growth) */
+int deft_tree_md_caps(int64_t tree, int max_q_len, int block_len, int max_block_len, int grow_max, int64_t sizes[9]); /* O(nodes) upper bounds of the same maxima: what an epoch's buffers are sized with (_upto is the exact checker) */
 size_t deft_tree_dev_scratch_bytes(int n_nodes, int nqw, int nbp_cap);
 int deft_tree_dev_advance(int n_nodes, int nq, int nqw, const int32_t* node_start, int32_t* node_len, const int32_t* node_cap,
                           const uint64_t* refs, const int32_t* leaf_node, int32_t* slots, const int32_t* cache_loc,

@@ -143,10 +143,11 @@ def test_an_empty_node_that_is_not_the_root_is_still_an_error():
 
 
 def test_epoch_capacities_cover_every_growth():
-    """The buffers of a structural epoch are sized by deft_tree_md_sizes_upto: the element-wise maximum over EVERY growth
-    0 .. SLACK + 4 of the leaves.  The block arrays are not monotone in the growth (block boundaries move over the nodes), so
-    sizing for the longest tree alone under-allocates -- the multi-level tree below needs more block_q entries at some
-    intermediate growth than at the largest one (found by tools/fuzz_replay.py)."""
+    """The buffers of a structural epoch must hold the metadata of EVERY growth 0 .. SLACK + 4 of the leaves.  The block arrays
+    are not monotone in the growth (block boundaries move over the nodes), so sizing for the longest tree alone under-allocates
+    -- the multi-level trees below need more block_q entries at some intermediate growth than at the largest one (found by
+    tools/fuzz_replay.py).  deft_tree_md_sizes_upto is the exact element-wise maximum (one pass over the blocks per growth);
+    the buffers are sized by deft_tree_md_caps, O(nodes) upper bounds of it, which must cover it without being wasteful."""
     from deft_amd._lib import lib, check
     from deft_amd.tree_cache import _ptr
 
@@ -166,9 +167,48 @@ def test_epoch_capacities_cover_every_growth():
         upto, at_max = np.zeros(9, dtype=np.int64), np.zeros(9, dtype=np.int64)
         check(lib.deft_tree_md_sizes_upto(tree._native, 32, 128, -1, 260, _ptr(upto)), "upto")
         check(lib.deft_tree_md_sizes(tree._native, 32, 128, -1, 260, _ptr(at_max)), "sizes")
+        caps = np.zeros(9, dtype=np.int64)
+        check(lib.deft_tree_md_caps(tree._native, 32, 128, -1, 260, _ptr(caps)), "caps")
+        assert (upto <= caps).all(), (prompt, upto, caps)
+        assert (caps[[0, 1, 2, 3, 4, 8]] == upto[[0, 1, 2, 3, 4, 8]]).all()  # the monotone ones are exact
+        assert caps[5] <= 2 * upto[5] + 8 and caps[6] <= 2 * upto[6] + 8, (prompt, upto, caps)
         for g in range(0, 261):
             cur = np.zeros(9, dtype=np.int64)
             check(lib.deft_tree_md_sizes(tree._native, 32, 128, -1, g, _ptr(cur)), "sizes")
             assert (cur <= upto).all(), (prompt, g, cur, upto)
             worst = max(worst, int(cur[6] - at_max[6]))
     assert worst > 0  # (at least one of these trees is a case the old sizing got wrong)
+
+
+def test_epoch_capacity_bounds_on_random_trees():
+    """deft_tree_md_caps >= deft_tree_md_sizes_upto element-wise on random multi-level trees and batches of trees as one tree object
+    (several max_q_len / block_len / growth settings), and equal on the arrays that grow with the leaves."""
+    import random
+    from deft_amd._lib import lib, check
+    from deft_amd.tree_cache import _ptr
+
+    rng = random.Random(11)
+    for _ in range(60):
+        req = deft_amd.ReqToTokenPool(512, 8192, device="cpu")
+        pool = deft_amd.TokenToKVPool(1 << 16, torch.float16, 1, 128, 0, device="cpu")
+        tree = deft_amd.TreeCache(torch.float16, 1, 128, 0, req, pool, None, True, False)
+        if rng.random() < 0.3:
+            tree.init_forest([torch.arange(rng.choice([1, 5, 127, 128, 129, 300, 1000]), dtype=torch.int32) for _ in range(rng.randint(2, 4))])
+        else:
+            tree.init_prompt(torch.arange(rng.choice([1, 5, 127, 128, 129, 300, 1000, 3000]), dtype=torch.int32))
+        for _lvl in range(rng.randint(0, 3)):
+            for leaf in list(tree.leaves.values()):
+                if len(tree.leaves) < 60 and rng.random() < 0.8:
+                    tree.branch(leaf, rng.randint(1, 5))
+            for _s in range(rng.choice([1, 2, 7, 40, 130])):
+                _step(tree)
+        if len(tree.leaves) > 2 and rng.random() < 0.5:
+            tree.cut(rng.choice(list(tree.leaves.values())))
+        sizes = np.zeros(5, dtype=np.int64)
+        check(lib.deft_tree_layout(tree._native, 256, _ptr(sizes)), "deft_tree_layout")
+        for mq, bl, mbl, grow in ((32, 128, -1, 260), (4, 16, 64, 37), (32, 128, 128, 0)):
+            upto, caps = np.zeros(9, dtype=np.int64), np.zeros(9, dtype=np.int64)
+            check(lib.deft_tree_md_sizes_upto(tree._native, mq, bl, mbl, grow, _ptr(upto)), "upto")
+            check(lib.deft_tree_md_caps(tree._native, mq, bl, mbl, grow, _ptr(caps)), "caps")
+            assert (upto <= caps).all(), (mq, bl, mbl, grow, upto, caps)
+            assert (caps[[0, 1, 2, 3, 4, 8]] == upto[[0, 1, 2, 3, 4, 8]]).all()
