@@ -14,7 +14,11 @@ def run(name):
     from deft_amd.utils.workloads import WORKLOADS, GEOMETRY
     w = WORKLOADS[name]
     b = Bench(w, GEOMETRY[w.model][3], torch.device("cuda", 0)); b.prepare(use_graph=False)
-    print(b.end_to_end(30, True))
+    if w.trees > 1:  # a batch of trees: as ONE tree object through the session (bench.py forest_end_to_end)
+        from bench import forest_end_to_end
+        print(forest_end_to_end(b, w, torch.device("cuda", 0), 30))
+    else:
+        print(b.end_to_end(30, True))
 
 
 def analyse(path):
