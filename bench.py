@@ -299,6 +299,15 @@ class Bench:
 def run_timed(b: Bench, steps: int, warmup: int, dist_on: bool):
     import torch.distributed as dist
 
+    if dist_on:
+        # rehearse the bracket once, untimed: the first barrier / all-reduce of a process group sets up RCCL's connections
+        # and loads its kernels lazily (milliseconds -- a visible share of a 20-step timed region)
+        from deft_amd.utils.sharding import max_over_ranks
+
+        dist.barrier()
+        torch.cuda.synchronize(b.device)
+        max_over_ranks(0.0, b.device)
+        dist.barrier()
     for _ in range(warmup):
         b.step()
     if dist_on:
