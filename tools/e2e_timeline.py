@@ -28,7 +28,7 @@ def analyse(path):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
     rows.sort()
     short = lambda n: n.split("(")[0].replace("deft::", "").replace("void ", "")[:40]
-    starts = [i for i, r in enumerate(rows) if "tree_md_scan" in r[2]]
+    starts = [i for i, r in enumerate(rows) if "index_elementwise" in r[2] or "index_put" in r[2]]  # the page-table write opens a step's layers
     print("kernels", len(rows), "steps", len(starts))
     for a, b in list(zip(starts, starts[1:]))[-6:]:
         seg = rows[a:b]
@@ -45,6 +45,14 @@ def analyse(path):
         print(f"   gaps > 2.5 us: {len(big)}, total {tot:.1f} us")
         for g, x, y in sorted(big, reverse=True)[:8]:
             print(f"     {g:7.1f} us after {x} before {y}")
+        # kernels that ran beside another one (a later start before an earlier end): the prepared step under the layers
+        over = 0.0
+        end_max = seg[0][1]
+        for s_, e_, n_ in seg[1:]:
+            if s_ < end_max:
+                over += (min(e_, end_max) - s_) / 1e3
+            end_max = max(end_max, e_)
+        print(f"   overlapped kernel time {over:.1f} us")
         names = {}
         for s, e, n in seg:
             k = short(n); names[k] = names.get(k, 0) + (e - s) / 1e3
