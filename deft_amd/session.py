@@ -75,8 +75,12 @@ class DecodeSession:
             self.ws_bytes = int(lib.deft_node_workspace_bytes(self.NE, self.PN, self.TKV, self.nq, Hq, Hkv, D))
         self.plan = torch.empty(max(self.plan_bytes, 1), dtype=torch.uint8, device=dev)
         self.ws = torch.empty(max(self.ws_bytes, 1), dtype=torch.uint8, device=dev)
-        self.cache_loc = torch.zeros(max(self.nq, 1), dtype=torch.int32, device=dev)
-        self.idx = torch.zeros((2, max(self.nq, 1)), dtype=torch.int64, device=dev)
+        # what the host supplies per step, in ONE allocation (one upload): [cache_loc int32[nq] | page-table coordinates int64[2][nq]]
+        nqm = max(self.nq, 1)
+        cb = (4 * nqm + 255) // 256 * 256
+        self._small = torch.zeros(cb + 16 * nqm, dtype=torch.uint8, device=dev)
+        self.cache_loc = self._small[: 4 * nqm].view(torch.int32)
+        self.idx = self._small[cb:].view(torch.int64).view(2, nqm)
         self.out = [torch.empty((self.nq, Hq * D), dtype=torch.float16, device=dev) for _ in range(self.layers)]
         order = sorted(tree.leaves)
         self.leaf_handles = [tree.leaves[i] for i in order]
@@ -147,17 +151,29 @@ class DecodeSession:
         return self.out
 
     def _write_staging(self, loc: np.ndarray) -> None:
-        """This step's slot numbers and page-table coordinates: pinned staging -> the fixed device tensors the graph reads."""
-        ent = self.tree._staging(self.nq)
-        n = self.nq
-        ent[0].numpy()[:n] = loc
-        idx_h = ent[1].numpy()
+        """This step's slot numbers and page-table coordinates: pinned staging -> the fixed device tensors the graph reads, in
+        one copy.  Four pinned buffers in rotation, each guarded by the event of its last upload (a pageable source would make
+        the copy wait for the stream to drain -- the host would run in lock-step with the GPU)."""
+        n, nb = self.nq, self._small.numel()
+        self._pin_k = (getattr(self, "_pin_k", -1) + 1) % 4
+        if self._pin is None:
+            self._pin = []
+        while len(self._pin) <= self._pin_k:
+            self._pin.append(None)
+        ent = self._pin[self._pin_k]
+        if ent is None or ent[0].numel() != nb:
+            ent = self._pin[self._pin_k] = [torch.zeros(nb, dtype=torch.uint8).pin_memory(), None]
+        if ent[1] is not None:
+            ent[1].synchronize()
+        h = ent[0].numpy()
+        nqm = max(n, 1)
+        h[: 4 * n].view(np.int32)[:] = loc
+        idx_h = h[nb - 16 * nqm :].view(np.int64).reshape(2, nqm)
         idx_h[0, :n] = self.leaf_reqs
         idx_h[1, :n] = [lf.positions[-1] for lf in self.leaf_handles]
-        self.cache_loc.copy_(ent[0][:n], non_blocking=True)
-        self.idx.copy_(ent[1][:, :n], non_blocking=True)
-        ent[2] = torch.cuda.Event()
-        ent[2].record(torch.cuda.current_stream(self.device))
+        self._small.copy_(ent[0], non_blocking=True)
+        ent[1] = torch.cuda.Event()
+        ent[1].record(torch.cuda.current_stream(self.device))
 
     def _capture(self) -> None:
         dev = self.device
