@@ -71,6 +71,7 @@ class TokenToKVPool:
         self.device = torch.device(device)
         self.mem_state = np.zeros(size, dtype=np.int16)  # refcounts, host side
         self.alloc_ct = 0
+        self._lo = 0  # every slot below this index is in use: where the search for free slots starts
         # [layer][size, key/value, head_num, head_dim] — memory_pool.py:61-66
         self._storage = torch.empty((layer_num, size, 2, head_num, head_dim), dtype=dtype, device=device)
         self.kv_data = [self._storage[i] for i in range(layer_num)]
@@ -83,11 +84,34 @@ class TokenToKVPool:
 
     # -- host-side slot allocator -------------------------------------------------
     def alloc_host(self, need_size: int) -> Optional[np.ndarray]:
-        idx = np.flatnonzero(self.mem_state == 0)[:need_size]
-        if idx.shape[0] < need_size:
+        """The `need_size` LOWEST free slots (what `torch.nonzero(mem_state == 0)[:need_size]` picks, memory_pool.py:75-84).
+        The scan starts at the lowest slot that can be free and stops when it has enough: a decode step's handful of slots
+        costs microseconds whatever the pool's size (a full scan of a 500k-slot pool is ~0.4 ms, per step)."""
+        if need_size <= 0:
+            return np.zeros(0, dtype=np.int32)
+        idx = self._lowest_free(self._lo, need_size)
+        if idx is None and self._lo > 0:
+            idx = self._lowest_free(0, need_size)  # (entries of mem_state cleared directly, below the hint)
+        if idx is None:
             return None
+        self._lo = int(idx[-1]) + 1
         self._add(idx)
         return idx.astype(np.int32)
+
+    def _lowest_free(self, start: int, need: int) -> Optional[np.ndarray]:
+        ms, size = self.mem_state, self.size
+        chunk = max(4096, 4 * need)
+        found, cnt = [], 0
+        while start < size and cnt < need:
+            seg = np.flatnonzero(ms[start : start + chunk] == 0)
+            if seg.size:
+                seg = seg[: need - cnt] + start
+                found.append(seg)
+                cnt += seg.size
+            start += chunk
+        if cnt < need:
+            return None
+        return found[0] if len(found) == 1 else np.concatenate(found)
 
     def alloc(self, need_size: int) -> Optional[torch.Tensor]:
         idx = self.alloc_host(need_size)
@@ -120,9 +144,15 @@ class TokenToKVPool:
             ms, lst = self.mem_state, idx.tolist()
             for i in lst:
                 ms[i] -= 1
+                if ms[i] == 0 and i < self._lo:
+                    self._lo = i
             return sum(int(ms[i] == 0) for i in lst)  # (per occurrence, like the vector form below)
         np.subtract.at(self.mem_state, idx, 1)
-        return int(np.sum(self.mem_state[idx] == 0))
+        freed = self.mem_state[idx] == 0
+        n_free = int(np.sum(freed))
+        if n_free:
+            self._lo = min(self._lo, int(idx[freed].min()))
+        return n_free
 
     def free(self, free_index) -> int:
         return self.decrease_refs(free_index)
@@ -136,3 +166,4 @@ class TokenToKVPool:
     def clear(self) -> None:
         self.mem_state[:] = 0
         self.alloc_ct = 0
+        self._lo = 0

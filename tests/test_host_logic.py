@@ -219,3 +219,56 @@ def test_direct_edits_of_kv_indices_reach_the_metadata():
         deft_amd.TreeMetadata.from_tree_cache(tree, device="cpu")
 
 
+
+
+def test_pool_allocator_picks_the_lowest_free_slots():
+    """TokenToKVPool.alloc_host searches from a hint (lowest slot that can be free) in chunks instead of scanning the whole pool
+    per decode step; it must hand out exactly what the reference's `nonzero(mem_state == 0)[:n]` would (memory_pool.py:75-84)
+    through any mix of allocs, partial frees, extra references and clears."""
+    import random
+
+    from deft_amd.memory_pool import TokenToKVPool
+
+    rng = random.Random(1)
+    for _trial in range(12):
+        size = rng.choice([50, 5000, 20000])
+        pool = TokenToKVPool(size, torch.float16, 1, 8, 0, device="cpu")
+        ref = np.zeros(size, dtype=np.int16)
+        held = []
+        for _op in range(300):
+            r = rng.random()
+            if r < 0.5:
+                need = rng.choice([0, 1, 3, 17, 64, 300, 5000])
+                exp = np.flatnonzero(ref == 0)[:need]
+                got = pool.alloc_host(need)
+                if exp.shape[0] < need:
+                    assert got is None
+                else:
+                    assert got is not None and np.array_equal(got, exp)
+                    np.add.at(ref, exp, 1)
+                    held.append(exp)
+            elif r < 0.85 and held:
+                blk = held.pop(rng.randrange(len(held)))
+                k = rng.randint(0, len(blk))
+                if k < len(blk):
+                    held.append(blk[k:])
+                if k:
+                    pool.free(torch.from_numpy(blk[:k])) if rng.random() < 0.5 else pool.decrease_refs(blk[:k])
+                    np.subtract.at(ref, blk[:k], 1)
+            elif r < 0.93 and held:
+                blk = held[rng.randrange(len(held))][:3]
+                pool.add_refs(blk)
+                np.add.at(ref, blk, 1)
+                held.append(blk.copy())
+            elif r < 0.96:
+                pool.clear()
+                ref[:] = 0
+                held = []
+            assert np.array_equal(pool.mem_state, ref)
+    # entries cleared behind the allocator's back (below its hint) are found once the hinted search runs dry
+    pool = TokenToKVPool(100, torch.float16, 1, 8, 0, device="cpu")
+    assert np.array_equal(pool.alloc_host(90), np.arange(90))
+    pool.mem_state[:40] = 0
+    got = pool.alloc_host(30)
+    assert got is not None and len(set(got.tolist())) == 30 and (pool.mem_state[got] == 1).all()
+    assert pool.alloc_host(21) is None and pool.alloc_host(20) is not None
