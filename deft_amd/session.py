@@ -47,7 +47,8 @@ class DecodeSession:
         self.graph_epoch = -1
         self.captures = 0
         self.out: List[torch.Tensor] = []
-        self._pin = None
+        self._pin: list = []  # pinned staging buffers in rotation: [buffer, event of its last upload]
+        self._pin_k = -1
 
     # ---- per epoch ----------------------------------------------------------------------------------------
     def _epoch_setup(self) -> None:
@@ -155,9 +156,7 @@ class DecodeSession:
         one copy.  Four pinned buffers in rotation, each guarded by the event of its last upload (a pageable source would make
         the copy wait for the stream to drain -- the host would run in lock-step with the GPU)."""
         n, nb = self.nq, self._small.numel()
-        self._pin_k = (getattr(self, "_pin_k", -1) + 1) % 4
-        if self._pin is None:
-            self._pin = []
+        self._pin_k = (self._pin_k + 1) % 4
         while len(self._pin) <= self._pin_k:
             self._pin.append(None)
         ent = self._pin[self._pin_k]
