@@ -604,7 +604,7 @@ def main():
             variants += [(f"{w.name}_len1", Workload(**{**w.__dict__, "branch_len": 1})),
                          (f"{w.name}_len400", Workload(**{**w.__dict__, "branch_len": 400}))]
         for name in ("fewshot_1kx32", "medusa64_node", "tot50_4k", "gqa_4kx32", "forest_8kx8_single",
-                     "northstar_4kx32_seq", "fewshot_1kx32_seq", "northstar_4kx32_d64"):
+                     "northstar_4kx32_node", "northstar_4kx32_seq", "fewshot_1kx32_seq", "northstar_4kx32_d64"):
             if name != w.name:
                 variants.append((name, WORKLOADS[name]))
         del b.graph

@@ -49,6 +49,8 @@ WORKLOADS: Dict[str, Workload] = {
     # the same two trees through the sequential comparator (token_attention_fwd): what DeFT is measured against
     "northstar_4kx32_seq": Workload("northstar_4kx32_seq", "llama2-7b", "seq", "few_shot", 4096, 32, 200),
     "fewshot_1kx32_seq": Workload("fewshot_1kx32_seq", "llama2-7b", "seq", "few_shot", 1024, 32, 200),
+    # the north-star tree through DeFT-Node (the reference's other tree mode: one entry per node, no bit masks)
+    "northstar_4kx32_node": Workload("northstar_4kx32_node", "llama2-7b", "node", "few_shot", 4096, 32, 200),
     # configs[2]: Medusa depth-4 width-10 template as the reference mocks it (tree_size64), DeFT-Node
     "medusa64_node": Workload("medusa64_node", "llama2-7b", "node", "medusa", 1016, 64, 1),
     # the north-star tree on a GQA model (Llama-3-8B: 32 branches x 4 query heads per KV head = 128 rows per tile)
