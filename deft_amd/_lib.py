@@ -38,8 +38,9 @@ _vp, _i64, _i32, _f32, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_size
 
 lib.deft_abi_version.restype = C.c_int
 lib.deft_plan_variant.restype = C.c_int
-lib.deft_debug_plan_form.argtypes = [C.c_int, C.c_int]  # test hooks, not part of include/deft_amd.h
-lib.deft_debug_plan_form.restype = None
+if hasattr(lib, "deft_debug_plan_form"):  # experiments build only (DEFT_AMD_LIB=.../libdeft_amd_exp.so): a test hook
+    lib.deft_debug_plan_form.argtypes = [C.c_int, C.c_int]
+    lib.deft_debug_plan_form.restype = None
 lib.deft_last_error.restype = C.c_char_p
 lib.deft_supported.argtypes = [_i32, _i32, _i32]
 lib.deft_supported.restype = C.c_int

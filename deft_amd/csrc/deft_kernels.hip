@@ -497,13 +497,14 @@ static int knob(const char* name, int dflt) {
     return e ? atoi(e) : dflt;
 }
 static unsigned long long* g_dbg = nullptr;  // per-workgroup time stamps, see deft_debug_set_buffer
+// Test hook (deft_debug_plan_form, experiments build only): force the plan kernels' fallback forms, which are otherwise
+// reached only by trees whose run tables exceed the LDS.
+static int g_plan_serial = 0, g_plan_runcap = 0;
 #else
 static inline int knob(const char*, int dflt) { return dflt; }
 static constexpr unsigned long long* g_dbg = nullptr;
+static constexpr int g_plan_serial = 0, g_plan_runcap = 0;
 #endif
-// Test hook (deft_debug_plan_form, not in the public header): force the plan kernels' fallback forms, which are
-// otherwise reached only by trees whose run tables exceed the LDS.
-static int g_plan_serial = 0, g_plan_runcap = 0;
 
 static int check_launch(const char* what) {
     const hipError_t e = hipGetLastError();
@@ -795,14 +796,15 @@ int deft_plan_variant(void) {
            ((g_plan_runcap & 0x3f) << 25);
 }
 
-// Internal hooks (not part of the public header).  deft_debug_plan_form: tests force the plan kernels' fallback
-// forms (serial: one lane emits the plan; runcap > 0: a run table of that many entries).  deft_debug_set_buffer
-// (experiments build only): device buffer of 8192 x 8 u64 receiving per-workgroup time stamps of stage 1.
+// Internal hooks of the EXPERIMENTS build only (libdeft_amd_exp.so; the shipped library exports exactly what
+// include/deft_amd.h declares).  deft_debug_plan_form: tests force the plan kernels' fallback forms (serial: one lane emits
+// the plan; runcap > 0: a run table of that many entries).  deft_debug_set_buffer: device buffer of 8192 x 8 u64 receiving
+// per-workgroup time stamps of stage 1.
+#ifdef DEFT_EXPERIMENTS
 void deft_debug_plan_form(int serial, int runcap) {
     g_plan_serial = serial;
     g_plan_runcap = runcap;
 }
-#ifdef DEFT_EXPERIMENTS
 void deft_debug_set_buffer(void* dev_ptr) { g_dbg = static_cast<unsigned long long*>(dev_ptr); }
 #endif
 

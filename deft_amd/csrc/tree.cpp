@@ -52,13 +52,30 @@ struct Tree {
 };
 
 static std::mutex g_tree_mu;
-static std::unordered_map<int64_t, std::unique_ptr<Tree>> g_tree_map;
+static std::unordered_map<int64_t, std::shared_ptr<Tree>> g_tree_map;
 static int64_t g_tree_next = 1;
 
-static Tree* find_tree(int64_t h) {
+// (shared ownership: a call in flight keeps its tree alive across a concurrent deft_tree_free)
+static std::shared_ptr<Tree> find_tree(int64_t h) {
     std::lock_guard<std::mutex> lk(g_tree_mu);
     auto it = g_tree_map.find(h);
-    return it == g_tree_map.end() ? nullptr : it->second.get();
+    return it == g_tree_map.end() ? nullptr : it->second;
+}
+
+// Lookup that cannot throw across the C ABI (std::unordered_map::at would): nullptr for an unknown id.  The tree's own
+// invariant -- a node's parent exists as long as the node does: nothing with children is ever erased -- makes that a
+// "cannot happen" on every walk below; the walks still stop instead of aborting the process.
+static TNode* node_of(Tree* t, int64_t id) {
+    auto it = t->nodes.find(id);
+    return it == t->nodes.end() ? nullptr : &it->second;
+}
+static const TNode* node_of(const Tree* t, int64_t id) {
+    auto it = t->nodes.find(id);
+    return it == t->nodes.end() ? nullptr : &it->second;
+}
+static int64_t parent_of(const Tree* t, int64_t id) {
+    const TNode* n = node_of(t, id);
+    return n ? n->parent : -1;
 }
 
 static void structure_changed(Tree* t) {
@@ -84,8 +101,9 @@ static bool dfs_order(Tree* t, std::vector<int64_t>& out) {
         const int64_t u = stack.back();
         stack.pop_back();
         out.push_back(u);
-        const TNode& n = t->nodes.at(u);
-        for (auto it = n.children.rbegin(); it != n.children.rend(); ++it) stack.push_back(*it);
+        const TNode* n = node_of(t, u);
+        if (!n) return false;
+        for (auto it = n->children.rbegin(); it != n->children.rend(); ++it) stack.push_back(*it);
     }
     return out.size() == t->nodes.size();
 }
@@ -100,7 +118,7 @@ static void build_layout(Tree* t, int slack) {
     L.cap.resize(n);
     int64_t off = 0;
     for (int i = 0; i < n; ++i) {
-        const TNode& nd = t->nodes.at(L.dfs[i]);
+        const TNode& nd = *node_of(t, L.dfs[i]);  // (dfs_order visited it)
         L.index[L.dfs[i]] = i;
         // only live leaves grow between structural changes (one slot per decode step)
         const int64_t room = (int64_t)nd.kv.size() + (nd.leaf ? slack : 0);
@@ -110,7 +128,11 @@ static void build_layout(Tree* t, int slack) {
     }
     L.total_cap = off;
     L.leaf_node.clear();
-    for (int64_t id : t->leaves) L.leaf_node.push_back(L.index.at(id));
+    for (int64_t id : t->leaves) {
+        auto li = L.index.find(id);
+        if (li == L.index.end()) return;  // a live leaf the DFS did not reach: no valid layout
+        L.leaf_node.push_back(li->second);
+    }
     L.nqw = std::max(1, ((int)t->leaves.size() + 63) / 64);
     L.valid = off <= 0x7fffffffLL;
 }
@@ -119,12 +141,13 @@ static void build_layout(Tree* t, int slack) {
 
 using namespace deft;
 
-#define DEFT_TREE_OR_FAIL(t, h, what)        \
-    Tree* t = find_tree(h);                  \
-    if (!t) {                                \
-        set_error(what ": bad tree handle"); \
-        return DEFT_EINVAL;                  \
-    }                                        \
+#define DEFT_TREE_OR_FAIL(t, h, what)               \
+    std::shared_ptr<Tree> t##_owner = find_tree(h); \
+    Tree* t = t##_owner.get();                      \
+    if (!t) {                                       \
+        set_error(what ": bad tree handle");        \
+        return DEFT_EINVAL;                         \
+    }                                               \
     std::lock_guard<std::mutex> tree_lock(t->mu)
 
 extern "C" {
@@ -132,7 +155,7 @@ extern "C" {
 int64_t deft_tree_create(void) {
     std::lock_guard<std::mutex> lk(g_tree_mu);
     const int64_t hnd = g_tree_next++;
-    g_tree_map[hnd] = std::make_unique<Tree>();
+    g_tree_map[hnd] = std::make_shared<Tree>();
     return hnd;
 }
 
@@ -242,12 +265,17 @@ int deft_tree_cut(int64_t tree, int64_t id, int64_t* deleted_ids, int cap_ids, i
     // dry run: which nodes go
     std::vector<int64_t> gone;
     int64_t slots = 0;
-    for (int64_t cur = id; cur >= 0;) {
-        const TNode& n = t->nodes.at(cur);
-        if (n.nrefs - 1 > 0) break;  // another live leaf below this ancestor
+    for (int64_t cur = id, from = -1; cur >= 0;) {
+        const TNode* n = node_of(t, cur);
+        if (!n || n->nrefs - 1 > 0) break;  // another live leaf below this ancestor
+        // An ancestor that keeps OTHER children (nodes made by new_node() that hold no live leaf) stays: the reference pops
+        // it from `nodes` and leaves those children dangling (tree_cache.py:387-397) -- a tree nothing can be built from;
+        // here the walk stops, so that every node that exists keeps a parent that exists.
+        if (from >= 0 && n->children.size() > 1) break;
         gone.push_back(cur);
-        slots += (int64_t)n.kv.size();
-        cur = n.parent;
+        slots += (int64_t)n->kv.size();
+        from = cur;
+        cur = n->parent;
     }
     *n_ids = (int)gone.size();
     *n_slots = slots;
@@ -260,15 +288,15 @@ int deft_tree_cut(int64_t tree, int64_t id, int64_t* deleted_ids, int cap_ids, i
     int64_t w = 0;
     for (size_t k = 0; k < gone.size(); ++k) {
         const int64_t cur = gone[k];
-        TNode& n = t->nodes.at(cur);
+        TNode& n = *node_of(t, cur);  // (found by the dry run above, under the same lock)
         deleted_ids[k] = cur;
         std::copy(n.kv.begin(), n.kv.end(), freed_slots + w);
         w += (int64_t)n.kv.size();
         const int64_t par = n.parent;
-        if (par >= 0) {
-            auto& ch = t->nodes.at(par).children;
+        if (TNode* pn = par >= 0 ? node_of(t, par) : nullptr) {
+            auto& ch = pn->children;
             ch.erase(std::remove(ch.begin(), ch.end(), cur), ch.end());
-        } else {
+        } else if (par < 0) {
             t->root = -1;
         }
         t->nodes.erase(cur);
@@ -288,9 +316,17 @@ int deft_tree_alloc_step(int64_t tree, int n, const int64_t* slots) {
     int i = 0;
     bool fits = t->lay.valid;
     for (int64_t id : t->leaves) {
-        TNode& nd = t->nodes.at(id);
+        TNode* ndp = node_of(t, id);
+        if (!ndp) {
+            set_error("deft_tree_alloc_step: live leaf %lld is not a node", (long long)id);
+            return DEFT_EINVAL;
+        }
+        TNode& nd = *ndp;
         nd.kv.push_back(slots[i++]);
-        if (fits && (int64_t)nd.kv.size() > t->lay.cap[t->lay.index.at(id)]) fits = false;
+        if (fits) {
+            auto li = t->lay.index.find(id);
+            if (li == t->lay.index.end() || (int64_t)nd.kv.size() > t->lay.cap[li->second]) fits = false;
+        }
     }
     if (!fits) structure_changed(t);
     return DEFT_OK;
@@ -395,7 +431,7 @@ int64_t deft_tree_node_refs(int64_t tree, int64_t id, int64_t* out, int64_t cap)
     }
     int64_t n = 0;
     for (int64_t leaf : t->leaves) {  // a leaf is below `id` iff `id` is on its path to the root
-        for (int64_t cur = leaf; cur >= 0; cur = t->nodes.at(cur).parent)
+        for (int64_t cur = leaf; cur >= 0; cur = parent_of(t, cur))
             if (cur == id) {
                 if (out && n < cap) out[n] = leaf;
                 ++n;
@@ -413,10 +449,10 @@ int64_t deft_tree_path_slots(int64_t tree, int64_t id, int64_t* out, int64_t cap
         return DEFT_EINVAL;
     }
     std::vector<int64_t> chain;
-    for (int64_t cur = id; cur >= 0; cur = t->nodes.at(cur).parent) chain.push_back(cur);
+    for (int64_t cur = id; cur >= 0 && node_of(t, cur); cur = parent_of(t, cur)) chain.push_back(cur);
     int64_t n = 0;
     for (auto it = chain.rbegin(); it != chain.rend(); ++it)
-        for (int64_t s : t->nodes.at(*it).kv) {
+        for (int64_t s : node_of(t, *it)->kv) {
             if (out && n < cap) out[n] = s;
             ++n;
         }
@@ -500,7 +536,12 @@ int deft_tree_layout_fetch(int64_t tree, int32_t* node_start, int32_t* node_len,
     std::fill(refs, refs + (size_t)n * L.nqw, 0ull);
     std::vector<int64_t> kv;
     for (int i = 0; i < n; ++i) {
-        const TNode& nd = t->nodes.at(L.dfs[i]);
+        const TNode* ndp = node_of(t, L.dfs[i]);
+        if (!ndp) {
+            set_error("deft_tree_layout_fetch: stale layout");
+            return DEFT_EINVAL;
+        }
+        const TNode& nd = *ndp;
         node_start[i] = L.start[i];
         node_len[i] = (int32_t)nd.kv.size();
         node_cap[i] = L.cap[i];
@@ -510,9 +551,12 @@ int deft_tree_layout_fetch(int64_t tree, int32_t* node_start, int32_t* node_len,
     }
     int r = 0;
     for (int64_t leaf : t->leaves) {  // query row r sets its bit on every node of its path
-        leaf_node[r] = L.index.at(leaf);
-        for (int64_t cur = leaf; cur >= 0; cur = t->nodes.at(cur).parent)
-            refs[(size_t)L.index.at(cur) * L.nqw + (r >> 6)] |= 1ull << (r & 63);
+        leaf_node[r] = L.leaf_node[r];
+        for (int64_t cur = leaf; cur >= 0; cur = parent_of(t, cur)) {
+            auto ci = L.index.find(cur);
+            if (ci == L.index.end()) break;
+            refs[(size_t)ci->second * L.nqw + (r >> 6)] |= 1ull << (r & 63);
+        }
         ++r;
     }
     return DEFT_OK;
@@ -528,7 +572,7 @@ static void md_sizes_for(const Tree* t, const Layout& L, const std::vector<uint6
     const int n = (int)L.dfs.size();
     std::vector<int64_t> len(n), nq(n);
     for (int i = 0; i < n; ++i) {
-        const TNode& nd = t->nodes.at(L.dfs[i]);
+        const TNode& nd = *node_of(t, L.dfs[i]);  // (a valid layout names existing nodes: every erase invalidates it)
         len[i] = (int64_t)nd.kv.size() + (nd.leaf ? grow : 0);
         nq[i] = nd.nrefs;
     }
@@ -584,11 +628,33 @@ static std::vector<uint64_t> leaf_bitsets(const Tree* t, const Layout& L) {
     std::vector<uint64_t> refs((size_t)n * nqw, 0ull);
     int r = 0;
     for (int64_t leaf : t->leaves) {
-        for (int64_t cur = leaf; cur >= 0; cur = t->nodes.at(cur).parent)
-            refs[(size_t)L.index.at(cur) * nqw + (r >> 6)] |= 1ull << (r & 63);
+        for (int64_t cur = leaf; cur >= 0; cur = parent_of(t, cur)) {
+            auto ci = L.index.find(cur);
+            if (ci == L.index.end()) break;
+            refs[(size_t)ci->second * nqw + (r >> 6)] |= 1ull << (r & 63);
+        }
         ++r;
     }
     return refs;
+}
+
+// What the host builder (deft_md_build, host.cpp) and the reference refuse, the device path refuses with the same words: a
+// node without a live leaf below it, and a node other than the root without a KV slot (`from_tree_cache` right after
+// `branch()` with no `alloc()`: range() with step 0 upstream, tree_cache.py:746-748).  The device kernels would skip such
+// nodes silently.
+static int check_buildable(const Tree* t, const Layout& L, const char* who) {
+    for (size_t i = 0; i < L.dfs.size(); ++i) {
+        const TNode& nd = *node_of(t, L.dfs[i]);
+        if (nd.nrefs <= 0) {
+            set_error("%s: node %lld has no live leaf below it", who, (long long)L.dfs[i]);
+            return DEFT_EINVAL;
+        }
+        if (nd.kv.empty() && i != 0) {
+            set_error("%s: node %lld has no KV slot (call alloc() first)", who, (long long)L.dfs[i]);
+            return DEFT_EINVAL;
+        }
+    }
+    return DEFT_OK;
 }
 
 int deft_tree_md_sizes(int64_t tree, int max_q_len, int block_len, int max_block_len, int grow, int64_t sizes[9]) {
@@ -598,6 +664,8 @@ int deft_tree_md_sizes(int64_t tree, int max_q_len, int block_len, int max_block
         set_error("deft_tree_md_sizes: no valid layout or bad arguments");
         return DEFT_EINVAL;
     }
+    if (grow == 0)
+        if (const int rc = check_buildable(t, L, "deft_tree_md_sizes")) return rc;
     md_sizes_for(t, L, leaf_bitsets(t, L), max_q_len, block_len, max_block_len, grow, sizes);
     return DEFT_OK;
 }
@@ -639,11 +707,12 @@ int deft_tree_md_caps(int64_t tree, int max_q_len, int block_len, int max_block_
         set_error("deft_tree_md_caps: no valid layout or bad arguments");
         return DEFT_EINVAL;
     }
+    if (const int rc = check_buildable(t, L, "deft_tree_md_caps")) return rc;
     const int n = (int)L.dfs.size();
     int64_t NE = 0, total = 0, n_node_q = 0, n_node_kv = 0, NB = 0, P = 0, fixed_pos = 0;
     bool fixed = true;  // no leaf so far: this node's first position does not move during the epoch
     for (int i = 0; i < n; ++i) {
-        const TNode& nd = t->nodes.at(L.dfs[i]);
+        const TNode& nd = *node_of(t, L.dfs[i]);
         const int64_t len = (int64_t)nd.kv.size() + (nd.leaf ? grow_max : 0), nq = nd.nrefs;
         total += len;
         const int64_t qch = (nq + max_q_len - 1) / max_q_len;

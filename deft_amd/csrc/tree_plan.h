@@ -178,7 +178,7 @@ __global__ __launch_bounds__(1024) void tree_md_scan_kernel(TreeDev t, TreeScrat
         }
         return;
     }
-    const bool blk_lds = in_lds && nbp <= TREE_LDS_BLOCKS;
+    const bool blk_lds = in_lds && nbp_cap <= TREE_LDS_BLOCKS;  // (as the host sized the LDS: by capacity, not by this step's count)
     int32_t* b_cnt = blk_lds ? nqc + (n + 1) : nullptr;  // [nbp] union size per block
     // physical blocks: first node with a slot in the block (largest i with pos[i] <= lo among nodes that have slots),
     // union of the leaf sets of its nodes

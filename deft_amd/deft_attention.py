@@ -148,8 +148,11 @@ class _DecodeStep:
 
 def rope_fusable(rotary_emb, head_dim: int) -> bool:
     """The configurations deft_*_decode_rope_append_f16 take (the reference's Llama: NeoX pairing over the whole head)."""
-    return (head_dim == 128 and rotary_emb.rotary_dim == head_dim and rotary_emb.head_size == head_dim
-            and bool(rotary_emb.is_neox_style))
+    cache = getattr(rotary_emb, "cos_sin_cache", None)
+    return (head_dim == 128 and getattr(rotary_emb, "rotary_dim", None) == head_dim
+            and getattr(rotary_emb, "head_size", None) == head_dim and bool(getattr(rotary_emb, "is_neox_style", False))
+            # the kernels read the cache as rows of fp32 cos | sin (rotary_embedding.py; the reference's get_rope builds it so)
+            and isinstance(cache, torch.Tensor) and cache.dtype == torch.float32 and cache.dim() == 2 and cache.stride(1) == 1)
 
 
 def _decode_step(mode, md, input_metadata, q, k, Hq, Hkv, D):
@@ -329,7 +332,10 @@ class DeFTAttention(nn.Module):
                         rotary_emb.cos_sin_cache = rotary_emb.cos_sin_cache.to(q.device)
                     return step.run(self.layer_id, q, k, v,
                                     rope=(pos, rotary_emb.cos_sin_cache, rotary_emb.rotary_dim, rotary_emb.is_neox_style))
-            rotary_emb(positions, q, k)
+            # (llama2.py:108-110 rebinds: a rotary module may rotate in place or return new tensors)
+            rotated = rotary_emb(positions, q, k)
+            if rotated is not None:
+                q, k = rotated
         if mode == ForwardMode.DECODE:
             return self.radix_attention_forward(q, k, v, input_metadata)
         if mode == ForwardMode.PREFILL:

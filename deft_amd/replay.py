@@ -4,11 +4,9 @@ model — the caller of the hot path on the other side of `TreeMetadata` (SURVEY
 
 What is mirrored, and from where:
 
-  ExecuteTreeNode / ExecuteTree   DeFT/deft/data_loader.py:9-77    a tree TEMPLATE: per node the iteration at which it
-                                  starts / ends and its children; `branch_record[iter][node] = children`,
-                                  `prune_record[iter] = [nodes]` are what the branch controller consults each step
-  build_tree(s) / load_trees      data_loader.py:80-132            dataset/generation/Reasoning/*.json
-  load_prompts / generate_accepted_len_list   :181-235             dataset/generation/Speculative_Decoding/*.json
+  tree templates                  DeFT/deft/data_loader.py:9-132, :181-235   `deft_amd/templates.py`: a template is a flat
+                                  node table plus per-iteration event lists (`branch_at[iter] = [(node, children)]`,
+                                  `prune_at[iter] = [nodes]`) -- what the branch controller consults each step
   branch_from_tree_template       DeFT/deft/tree_decoding/generation/branch_func_example.py:293-371
   branch_speculative_decoding     branch_func_example.py:374-442   (the reference's mock: all `tree_size` leaves are
                                   kept, the accepted tokens are squeezed into the root)
@@ -21,13 +19,11 @@ tree-state transitions, page-table updates, per-step metadata builds and attenti
 reports the reference's metrics (perf_metrics.py:98-116, :195-210): attention latency, decode latency of the replayed
 part, TPOT = latency / generated tokens.
 
-The dataset files themselves are not shipped (they belong to the reference repository); `load_trees(path)` /
-`load_prompts(path)` read them where the user has them, and `synthetic_*` build templates of the same form.
+The dataset files themselves are not shipped (they belong to the reference repository); `read_reasoning_file(path)` /
+`read_speculative_file(path)` read them where the user has them, and `synthetic_*` build templates of the same form.
 """
 from __future__ import annotations
 
-import json
-import random
 import time
 from dataclasses import dataclass, field
 from typing import Any, Callable, Dict, List, Optional
@@ -37,179 +33,15 @@ import torch
 
 from .forward_mode import ForwardMode, InputMetadata, forward_mode_from_cli
 from .memory_pool import ReqToTokenPool, TokenToKVPool
+from .templates import (TreeTemplate, fit_accept_lengths, read_reasoning_file, read_speculative_file,  # noqa: F401
+                        synthetic_few_shot_template, synthetic_reasoning_template, synthetic_speculative_template)
 from .tree_cache import TreeCache, TreeMetadata, register_tree_metadata
 
 __all__ = [
-    "ExecuteTreeNode", "ExecuteTree", "build_tree", "build_trees", "load_dataset", "load_trees", "load_prompts",
-    "generate_accepted_len_list", "synthetic_reasoning_template", "synthetic_speculative_template",
-    "synthetic_few_shot_template", "branch_from_tree_template", "branch_speculative_decoding", "branch_few_shot",
-    "ReplayReport", "TemplateReplay",
+    "TreeTemplate", "read_reasoning_file", "read_speculative_file", "fit_accept_lengths", "synthetic_reasoning_template",
+    "synthetic_speculative_template", "synthetic_few_shot_template", "branch_from_tree_template",
+    "branch_speculative_decoding", "branch_few_shot", "ReplayReport", "TemplateReplay",
 ]
-
-
-# ---------------------------------------------------------------------------
-# templates (data_loader.py)
-# ---------------------------------------------------------------------------
-class ExecuteTreeNode:
-    def __init__(self, id: int, value: int, start_offset: int, end_offset: int) -> None:
-        self.id = id
-        self.value = value  # tokens generated inside this node
-        self.start_offset = start_offset  # iteration at which the node appears
-        self.end_offset = end_offset  # iteration at which it branches or is pruned
-        self.children: List["ExecuteTreeNode"] = []
-        self.depth = 0
-        self.width = 0
-
-    def __repr__(self) -> str:
-        return (f"(id: {self.id}, value: {self.value}, start: {self.start_offset}, end: {self.end_offset}, "
-                f"children: {[c.id for c in self.children]})")
-
-
-class ExecuteTree:
-    def __init__(self, root: ExecuteTreeNode, nodes: List[ExecuteTreeNode], prompt: Optional[str] = None) -> None:
-        self.root = root
-        self.prompt = prompt
-        self.nodes = nodes
-        self.branch_record: Dict[int, Dict[int, List[int]]] = {}
-        self.prune_record: Dict[int, List[int]] = {}
-        self.max_depth = 0
-        self.max_width = 0
-        self.width_per_depth: Dict[int, int] = {}
-        self.build_tree_metadata(self.root, 0)
-        self.node_num = len(nodes)
-        self.accepted_len_list: Optional[List[int]] = None  # speculative decoding only
-
-    def build_tree_metadata(self, root: ExecuteTreeNode, depth: int) -> int:
-        """data_loader.py:51-77: a leaf is pruned at its end; an inner node branches at its end and is itself
-        released when the last node of its subtree ends."""
-        end_iter = root.end_offset
-        self.max_depth = max(self.max_depth, depth)
-        self.width_per_depth.setdefault(depth, 0)
-        root.depth = depth
-        root.width = self.width_per_depth[depth]
-        self.width_per_depth[depth] += 1
-        self.max_width = max(self.max_width, self.width_per_depth[depth])
-        if not root.children:
-            self.prune_record.setdefault(end_iter, []).append(root.id)
-            return end_iter
-        self.branch_record.setdefault(end_iter, {})[root.id] = [c.id for c in root.children]
-        for child in root.children:
-            end_iter = max(end_iter, self.build_tree_metadata(child, depth + 1))
-        self.prune_record[end_iter].append(root.id)
-        return end_iter
-
-
-def build_tree(data: Any) -> List[ExecuteTreeNode]:
-    nodes = [ExecuteTreeNode(i, 0, 0, 0) for i in range(len(data))]
-    for item in data.values():
-        n = nodes[int(item["id"])]
-        n.value = int(item["value"])
-        n.start_offset = int(item["start"])
-        n.end_offset = int(item["end"])
-        for child in item["children"]:
-            n.children.append(nodes[int(child)])
-    return nodes
-
-
-def build_trees(dataset: Any) -> List[ExecuteTree]:
-    trees = []
-    for item in dataset:
-        if "data" in item:
-            if item.get("incompleted"):
-                continue  # data_loader.py:101-104
-            nodes = build_tree(item["data"])
-        else:
-            nodes = build_tree(item)
-        trees.append(ExecuteTree(nodes[0], nodes, item.get("prompt") if isinstance(item, dict) else None))
-    return trees
-
-
-def load_dataset(path: str) -> Any:
-    if path.endswith(".json"):
-        with open(path, "r") as f:
-            return json.load(f)
-    if path.endswith(".pkl"):
-        import pickle
-
-        with open(path, "rb") as f:
-            return pickle.load(f)
-    raise NotImplementedError(f"Unsupported file format: {path}")
-
-
-def load_trees(path: str) -> List[ExecuteTree]:
-    return build_trees(load_dataset(path))
-
-
-def load_prompts(path: str) -> List[ExecuteTree]:
-    """Speculative-decoding records (data_loader.py:181-197): one flat template of `Token_Tree_size` nodes per
-    record, carrying the record's accepted lengths."""
-    dataset = load_dataset(path)
-    trees: List[ExecuteTree] = []
-    for rec in dataset["Records"]:
-        nodes = [ExecuteTreeNode(i, 0, 0, 0) for i in range(int(dataset["Token_Tree_size"]))]
-        tree = ExecuteTree(nodes[0], nodes, rec["prompt"])
-        tree.accepted_len_list = list(rec["Accept_length"])
-        trees.append(tree)
-    return trees
-
-
-def generate_accepted_len_list(max_gen_len: int, tree: ExecuteTree, rng: Optional[random.Random] = None) -> None:
-    """data_loader.py:200-235: truncate the record at max_gen_len accepted tokens, or extend it with lengths drawn
-    between the record's min and max."""
-    rng = rng or random
-    assert tree.accepted_len_list
-    out, s = [], 0
-    hi, lo = max(tree.accepted_len_list), min(tree.accepted_len_list)
-    for length in tree.accepted_len_list:
-        if s + length > max_gen_len:
-            break
-        out.append(length)
-        s += length
-    while s < max_gen_len:
-        length = min(rng.randint(lo, hi), max_gen_len - s)
-        out.append(length)
-        s += length
-    tree.accepted_len_list = out
-
-
-# ---- synthetic templates of the same form -------------------------------------------------
-def synthetic_reasoning_template(widths=(7, 6), lens=(128, 64)) -> ExecuteTree:
-    """A tree-of-thoughts template: level d has widths[d] children per node, each generating lens[d] tokens
-    (7 x 128 then 42 x 64 = 50 live nodes).  Node ids in creation (BFS) order, like the
-    reference's files."""
-    data: Dict[str, Dict[str, Any]] = {"0": {"id": 0, "value": 0, "start": 0, "end": 0, "children": []}}
-    frontier = [0]
-    end_of = {0: 0}
-    for width, n_tok in zip(widths, lens):
-        nxt = []
-        for parent in frontier:
-            for _ in range(width):
-                nid = len(data)
-                start = end_of[parent] + 1
-                data[str(nid)] = {"id": nid, "value": n_tok, "start": start, "end": start + n_tok - 1, "children": []}
-                end_of[nid] = start + n_tok - 1
-                data[str(parent)]["children"].append(nid)
-                nxt.append(nid)
-        frontier = nxt
-    nodes = build_tree(data)
-    return ExecuteTree(nodes[0], nodes, None)
-
-
-def synthetic_speculative_template(tree_size: int = 64, steps: int = 100, accept=(1, 4), seed: int = 0) -> ExecuteTree:
-    rng = random.Random(seed)
-    nodes = [ExecuteTreeNode(i, 0, 0, 0) for i in range(tree_size)]
-    tree = ExecuteTree(nodes[0], nodes, None)
-    tree.accepted_len_list = [rng.randint(accept[0], accept[1]) for _ in range(steps)]
-    return tree
-
-
-def synthetic_few_shot_template(width: int = 32) -> ExecuteTree:
-    """SimpleTree (branch_func_example.py:12-62): the root branches into `width` leaves after the prefill."""
-    data: Dict[str, Dict[str, Any]] = {"0": {"id": 0, "value": 0, "start": 0, "end": 0, "children": list(range(1, width + 1))}}
-    for i in range(1, width + 1):
-        data[str(i)] = {"id": i, "value": 1 << 30, "start": 1, "end": 1 << 30, "children": []}
-    nodes = build_tree(data)
-    return ExecuteTree(nodes[0], nodes, None)
 
 
 # ---------------------------------------------------------------------------
@@ -235,11 +67,11 @@ def _greedy(logits) -> List[int]:
 
 
 def branch_from_tree_template(tree: TreeCache, iter: int, max_gen_len: int, logits: torch.Tensor,
-                              execution_graph: ExecuteTree) -> bool:
-    """branch_func_example.py:293-371: a leaf whose id is a parent in branch_record[iter] branches (its children get
-    the top-k tokens of its row), a leaf in prune_record[iter] is cut, every other leaf appends its argmax."""
-    branch_pairs = execution_graph.branch_record.get(iter, {})
-    prune_nodes = execution_graph.prune_record.get(iter, [])
+                              execution_graph: TreeTemplate) -> bool:
+    """branch_func_example.py:293-371: a leaf that the template branches at this iteration branches (its children get
+    the top-k tokens of its row), a leaf it releases is cut, every other leaf appends its argmax."""
+    branch_pairs = dict(execution_graph.branch_at.get(iter, ()))
+    prune_nodes = set(execution_graph.prune_at.get(iter, ()))
     stop = 0 in prune_nodes  # the root is released: the whole template has run (:315-319)
     leaves = [tree.root] if iter == 0 else list(tree.leaves.values())
     greedy = _greedy(logits)
@@ -259,11 +91,11 @@ def branch_from_tree_template(tree: TreeCache, iter: int, max_gen_len: int, logi
 
 
 def branch_speculative_decoding(tree: TreeCache, iter: int, max_gen_len: int, logits: torch.Tensor,
-                                execution_graph: ExecuteTree) -> bool:
+                                execution_graph: TreeTemplate) -> bool:
     """branch_func_example.py:374-442, the reference's mock of Medusa-style verification: at iter 0 the root
     branches into `tree_size` one-token leaves; afterwards the first `Accept_length[iter]` leaves are merged into the
     root (their KV slots move to the root), every leaf's own KV is released and its positions shift."""
-    accepted = execution_graph.accepted_len_list
+    accepted = execution_graph.accept_lengths
     assert accepted is not None
     if iter == len(accepted):
         return True
@@ -285,9 +117,9 @@ def branch_speculative_decoding(tree: TreeCache, iter: int, max_gen_len: int, lo
     return False
 
 
-def branch_few_shot(tree: TreeCache, iter: int, max_gen_len: int, logits: torch.Tensor, execution_graph: ExecuteTree) -> bool:
+def branch_few_shot(tree: TreeCache, iter: int, max_gen_len: int, logits: torch.Tensor, execution_graph: TreeTemplate) -> bool:
     """branch_func_example.py:12-62 (SimpleTree): branch into `width` leaves after the prefill, then greedy."""
-    width = len(execution_graph.root.children)
+    width = execution_graph.root_width
     if iter == 0:
         ids = _topk_ids(logits, 0, width)
         for j, leaf in enumerate(tree.branch(tree.root, width)):
@@ -365,7 +197,7 @@ class TemplateReplay:
                              device=self.device)
         return req, pool
 
-    def run(self, template: ExecuteTree, task: str, prompt_len: int, max_gen_len: int, max_tokens: Optional[int] = None,
+    def run(self, template: TreeTemplate, task: str, prompt_len: int, max_gen_len: int, max_tokens: Optional[int] = None,
             max_leaves: int = 512, max_rows: int = 512, pipelined: bool = False) -> ReplayReport:
         """`pipelined=True`: no per-step synchronisation -- the host builds step t+1's tree state and metadata while the
         GPU still runs step t (the path is launch-only; the synthetic scores do not depend on the GPU's output, as
@@ -374,13 +206,13 @@ class TemplateReplay:
         would see."""
         branch = BRANCH_FUNCS[task]
         if task == "speculative_decoding":
-            max_gen_len = min(max_gen_len, len(template.accepted_len_list or []) + 1)
+            max_gen_len = min(max_gen_len, len(template.accept_lengths or []) + 1)
         if max_tokens is None:
-            budget = sum(max(n.value, 0) for n in template.nodes if n.value < (1 << 29))
+            budget = template.token_budget()
             if task == "speculative_decoding":
-                budget = sum(template.accepted_len_list or []) + 2 * template.node_num * 2
+                budget = sum(template.accept_lengths or []) + 2 * template.node_num * 2
             if task == "few_shot":
-                budget = len(template.root.children) * max_gen_len
+                budget = template.root_width * max_gen_len
             max_tokens = prompt_len + budget + max_leaves + 1024
         req, pool = self._pools(max_tokens, max_leaves)
         tree = TreeCache(torch.float16, self.Hkv, self.D, self.layers, req, pool, None, True, False)

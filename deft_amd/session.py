@@ -51,14 +51,17 @@ class DecodeSession:
         self._pin_k = -1
 
     # ---- per epoch ----------------------------------------------------------------------------------------
-    def _epoch_setup(self) -> None:
+    def _epoch_setup(self) -> bool:
+        """Buffers of a structural epoch; True iff the device copy of the tree was uploaded just now (then it already
+        holds this step's slots), False iff it was current before this step's `alloc_step` -- a device-built
+        `TreeMetadata.from_tree_cache(tree)` or another session got there first -- and still needs the step's slots."""
         tree, dev = self.tree, self.device
         block_len = BLOCK_CONFIG["BLOCK_LEN"]
         dt = tree._device_tree
         cfg = (int(self.max_q_len), int(block_len), int(BLOCK_CONFIG["MAX_BLOCK_LEN"]))
         if dt is None or dt.device != dev or dt.cfg != cfg:
             dt = tree._device_tree = _DeviceTree(tree, dev, *cfg)
-        dt.sync()
+        uploaded = dt.sync()
         self.dt = dt
         self.nq = dt.nq
         self.NB, self.P = dt.cap_lens["block_lens"], dt.cap_lens["block_q"]
@@ -87,10 +90,11 @@ class DecodeSession:
         self.leaf_handles = [tree.leaves[i] for i in order]
         self.leaf_reqs = np.asarray([tree.leaf_to_req[i] for i in order], dtype=np.int64)
         self.graph, self.graph_epoch = None, dt.epoch
+        return uploaded
 
     def _launch_step(self, advance: bool = True) -> None:
         """The device side of one decode step; identical arguments on every step of the epoch.  `advance=False`: the first
-        step of an epoch -- the tree that was just uploaded already holds this step's slots."""
+        step of an epoch when the tree was uploaded just now -- the image already holds this step's slots."""
         dt, dev = self.dt, self.device
         stream = torch.cuda.current_stream(dev).cuda_stream
         table = self.tree.req_to_token_pool.req_to_token
@@ -136,11 +140,12 @@ class DecodeSession:
         loc64 = loc.astype(np.int64)
         check(lib.deft_tree_alloc_step(tree._native, n, _ptr(loc64)), "deft_tree_alloc_step")
         if tree._epoch() != self.graph_epoch:
-            # a new structural epoch (branch / cut / merge since the last step, or a leaf outgrew its room): the upload made
-            # now already contains this step's slots, so this step runs eagerly without the advance; the next one captures
-            self._epoch_setup()
+            # a new structural epoch (branch / cut / merge since the last step, or a leaf outgrew its room): an upload made
+            # now already contains this step's slots, so this step runs eagerly without the advance; a device copy that was
+            # current BEFORE this step's alloc_step (and stayed in its epoch) appends them itself.  The next step captures.
+            uploaded = self._epoch_setup()
             self._write_staging(loc)
-            self._launch_step(advance=False)
+            self._launch_step(advance=not uploaded)
             return self.out
         self._write_staging(loc)
         if not self.use_graph:

@@ -631,9 +631,13 @@ class _DeviceTree:
         self.scratch_bytes = sb
         self.epoch = epoch
 
-    def sync(self) -> None:
+    def sync(self) -> bool:
+        """Bring the device copy to the tree's structural epoch; True iff an upload happened (the uploaded image holds
+        every slot the native tree holds NOW; a copy that was already current holds what it held before)."""
         if self.epoch != self.tree._epoch():
             self._upload()
+            return True
+        return False
 
     def _tree_args(self):
         return (self.n, self.nq, self.nqw, self.p_start, self.p_len, self.p_cap, self.p_refs, self.p_leaf, self.p_slots)

@@ -181,8 +181,9 @@ SCENARIOS: Dict[str, Scenario] = {
 SMALL_GEOMETRIES = ((4, 4, 128), (8, 2, 128), (4, 4, 64))
 # full Llama-2-7B geometry goldens (F3): scenario -> (Hq, Hkv, D).  BASELINE configs[1] (1k x 32), the north-star tree
 # at branch length 1 and at the benchmarked length 200, configs[2] (Medusa-64) at the model BASELINE names for it
-FULL_GEOMETRY = {"fewshot_1k": (32, 32, 128), "fewshot_4k": (32, 32, 128), "fewshot_4k_len200": (32, 32, 128),
-                 "medusa64": (32, 32, 128)}
+# (and configs[0], the 256-prefix x 2-branch plumbing case, at its own model's geometry too)
+FULL_GEOMETRY = {"cfgA_256x2": (32, 32, 128), "fewshot_1k": (32, 32, 128), "fewshot_4k": (32, 32, 128),
+                 "fewshot_4k_len200": (32, 32, 128), "medusa64": (32, 32, 128)}
 # Llama-3-8B GQA geometry: the Medusa tree, configs[3] (ToT-50) and one tree of configs[4] (8k x 8 x 64)
 GQA_GEOMETRY = {"medusa64": (32, 8, 128), "tot50": (32, 8, 128), "forest_tree_8kx8": (32, 8, 128)}
 

@@ -272,3 +272,58 @@ def test_pool_allocator_picks_the_lowest_free_slots():
     got = pool.alloc_host(30)
     assert got is not None and len(set(got.tolist())) == 30 and (pool.mem_state[got] == 1).all()
     assert pool.alloc_host(21) is None and pool.alloc_host(20) is not None
+
+
+def _small_tree(prefix=5, size=64):
+    req = deft_amd.ReqToTokenPool(16, size + 8, device="cpu")
+    pool = deft_amd.TokenToKVPool(size, torch.float16, 1, 8, 1, device="cpu")
+    tree = deft_amd.TreeCache(torch.float16, 1, 8, 1, req, pool, None, True, False)
+    tree.init_prompt(torch.arange(1, prefix + 1, dtype=torch.int32))
+    return tree
+
+
+def test_cut_keeps_an_ancestor_that_still_has_children():
+    """branch 2, new_node(root), cut both leaves -- the native tree erased the root although the node made by
+    new_node() still hung below it, and the next walk over that node threw std::out_of_range across the C ABI (abort).
+    The walk now stops at an ancestor that keeps other children; every later call returns instead of aborting."""
+    from deft_amd._lib import lib
+
+    tree = _small_tree()
+    a, b = tree.branch(tree.root, 2)
+    extra = tree.new_node(tree.root)  # holds no live leaf
+    for leaf in (a, b):
+        leaf.append_token(3)
+    tree.alloc()
+    gone = tree.cut(a)
+    assert [n.id for n in gone] == [a.id]
+    gone = tree.cut(b)
+    assert [n.id for n in gone] == [b.id]  # the root keeps `extra`, so it stays
+    assert 0 in tree.nodes and extra.id in tree.nodes
+    tree.add_ref(extra)  # (used to abort the process)
+    assert tree.leaf_path_slots(extra) == tree.root.kv_indices.tolist()
+    assert [n.id for n in tree.root.refs] == [extra.id]
+    assert lib.deft_tree_set_leaf(tree._native, 999, 1) == -1  # unknown ids are errors, not exceptions
+
+
+def test_device_path_sizes_reject_what_the_host_builder_rejects():
+    """`from_tree_cache` right after `branch()` with no `alloc()`: deft_md_build (and the reference, range() with step 0)
+    raise; the size call in front of the device kernels must too, instead of letting them skip the empty nodes."""
+    from deft_amd._lib import DeftLibraryError, check, lib
+    from deft_amd.tree_cache import _ptr
+
+    tree = _small_tree()
+    tree.branch(tree.root, 3)
+    with pytest.raises(DeftLibraryError, match="no KV slot"):
+        deft_amd.TreeMetadata.from_tree_cache(tree)  # host builder (CPU pool)
+    sizes = np.zeros(5, dtype=np.int64)
+    check(lib.deft_tree_layout(tree._native, 256, _ptr(sizes)), "layout")
+    out = np.zeros(9, dtype=np.int64)
+    assert lib.deft_tree_md_sizes(tree._native, 32, 128, -1, 0, _ptr(out)) == -1
+    assert b"no KV slot" in lib.deft_last_error()
+    assert lib.deft_tree_md_caps(tree._native, 32, 128, -1, 260, _ptr(out)) == -1
+    for leaf in tree.leaves.values():
+        leaf.append_token(1)
+    tree.alloc()
+    check(lib.deft_tree_layout(tree._native, 256, _ptr(sizes)), "layout")
+    check(lib.deft_tree_md_sizes(tree._native, 32, 128, -1, 0, _ptr(out)), "sizes")
+    assert out[0] == 3 and out[2] == 5 + 3

@@ -17,8 +17,7 @@ GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "templat
 @pytest.mark.parametrize("name", sorted(GOLD["reasoning"]))
 def test_template_records_match_reference(name):
     g = GOLD["reasoning"][name]
-    nodes = rp.build_tree(g["data"])
-    tree = rp.ExecuteTree(nodes[0], nodes)
+    tree = rp.TreeTemplate.from_node_table(g["data"])
     assert tree.node_num == g["node_num"] and tree.max_depth == g["max_depth"] and tree.max_width == g["max_width"]
     assert {str(k): {str(p): c for p, c in v.items()} for k, v in tree.branch_record.items()} == g["branch_record"]
     assert {str(k): v for k, v in tree.prune_record.items()} == g["prune_record"]
@@ -30,19 +29,19 @@ def test_load_trees_and_prompts_from_files(tmp_path):
     p = tmp_path / "toy.json"
     p.write_text(json.dumps([{"incompleted": True, "prompt": "x", "data": g["data"]},
                              {"incompleted": False, "prompt": "y", "data": g["data"]}]))
-    trees = rp.load_trees(str(p))
+    trees = rp.read_reasoning_file(str(p))
     assert len(trees) == 1 and trees[0].prompt == "y" and trees[0].node_num == g["node_num"]  # incompleted skipped
     sd = GOLD["speculative"]["tree_size64"]
     p2 = tmp_path / "sd.json"
     p2.write_text(json.dumps({"Tree_ID": 1, "Tree_Structure": [], "Token_Tree_size": sd["Token_Tree_size"],
                               "Records": [{"prompt": "q", "Accept_length": sd["Accept_length_0"]}]}))
-    t = rp.load_prompts(str(p2))[0]
-    assert t.node_num == sd["node_num"] == 64 and t.accepted_len_list == sd["Accept_length_0"]
+    t = rp.read_speculative_file(str(p2))[0]
+    assert t.node_num == sd["node_num"] == 64 and t.accept_lengths == sd["Accept_length_0"]
     import random
-    rp.generate_accepted_len_list(50, t, random.Random(0))
-    assert sum(t.accepted_len_list) == 50
+    rp.fit_accept_lengths(t, 50, random.Random(0))
+    assert sum(t.accept_lengths) == 50 and t.accept_lengths[:3] == sd["Accept_length_0"][:3]
     with pytest.raises(NotImplementedError):
-        rp.load_dataset("x.csv")
+        rp.read_reasoning_file("x.csv")
 
 
 def _cpu_replay(task, template, prompt_len, max_gen_len, mode="flatten"):
@@ -63,10 +62,9 @@ def test_reasoning_replay_follows_the_template_and_frees_everything():
 
 def test_reference_template_replay_runs_to_completion():
     g = GOLD["reasoning"]["docmergeToT"]
-    nodes = rp.build_tree(g["data"])
-    tpl = rp.ExecuteTree(nodes[0], nodes)
-    r, rep = _cpu_replay("reasoning", tpl, prompt_len=nodes[0].value, max_gen_len=100000)
-    assert rep.generated_tokens == sum(n.value for n in nodes[1:])
+    tpl = rp.TreeTemplate.from_node_table(g["data"])
+    r, rep = _cpu_replay("reasoning", tpl, prompt_len=int(tpl.value[0]), max_gen_len=100000)
+    assert rep.generated_tokens == int(tpl.value[1:].sum())
     assert len(r.tree.nodes) == 0 and int((r.pool.mem_state != 0).sum()) == 0
     assert 1 <= rep.summary()["max_live_leaves"] <= tpl.node_num  # leaves of several depths are live at once
 
@@ -74,7 +72,7 @@ def test_reference_template_replay_runs_to_completion():
 def test_speculative_replay_squeezes_accepted_tokens_into_the_root():
     tpl = rp.synthetic_speculative_template(tree_size=8, steps=6, accept=(1, 3), seed=3)
     r, rep = _cpu_replay("speculative_decoding", tpl, prompt_len=30, max_gen_len=100, mode="node")
-    acc = tpl.accepted_len_list
+    acc = tpl.accept_lengths
     assert rep.steps == len(acc)  # iterations 1 .. len(acc); the branch function stops at iter == len(acc) (:383-394)
     assert len(r.tree.root.kv_indices) == 30 + sum(acc[1:])  # branch_func_example.py:436-440
     assert all(int(s["nq"]) == 8 for s in rep.per_step)

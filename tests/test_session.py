@@ -70,3 +70,57 @@ def test_session_equals_eager_step_for_step(use_graph, mode):
         tree.branch(lv[0], 3)
     both_steps(20)
     assert sess.captures == (2 if use_graph else 0)
+
+
+@pytest.mark.parametrize("mode", ["flatten", "node"])
+def test_session_after_device_built_metadata_of_the_same_tree(mode):
+    """The session's tree already has a current device copy when an epoch's first step arrives (a device-built
+    `TreeMetadata.from_tree_cache(tree)` -- the default on GPU pools -- ran before it): nothing is uploaded then, so the step
+    has to append its own slots to the device copy (it ran with advance=False and every leaf lost a slot)."""
+    Hq, Hkv, D, layers, prefix, width = 8, 2, 128, 2, 300, 5
+    g = torch.Generator(device="cuda").manual_seed(11)
+    kv_init = torch.randn((layers, 2048, 2, Hkv, D), dtype=torch.float16, device="cuda", generator=g)
+    (te, pe), (ts, ps) = [_mk(Hkv, D, layers, prefix, width, 2048) for _ in range(2)]
+    for p in (pe, ps):
+        p._storage.copy_(kv_init)
+    cap = 16
+    q = torch.randn((layers, cap, Hq * D), dtype=torch.float16, device="cuda", generator=g)
+    k = torch.randn((layers, cap, Hkv * D), dtype=torch.float16, device="cuda", generator=g)
+    v = torch.randn((layers, cap, Hkv * D), dtype=torch.float16, device="cuda", generator=g)
+    nq_now = [width]
+    sess = deft_amd.DecodeSession(ts, Hq, Hkv, D, layers, lambda l: (q[l, : nq_now[0]], k[l, : nq_now[0]], v[l, : nq_now[0]]), mode=mode)
+    attn = [deft_amd.DeFTAttention(Hq, D, D ** -0.5, Hkv, l) for l in range(layers)]
+    fmode = deft_amd.forward_mode_from_cli(mode)
+
+    def both_steps(steps, peek_every=0):
+        for s in range(steps):
+            for tree in (te, ts):
+                for leaf in tree.leaves.values():
+                    leaf.append_token(7)
+            upd = te.alloc()
+            md = deft_amd.TreeMetadata.from_tree_cache(te)
+            deft_amd.register_tree_metadata(md)
+            n = md.query_num
+            nq_now[0] = n
+            ref = [attn[l](q[l, :n], k[l, :n], v[l, :n], deft_amd.InputMetadata(fmode, upd, pe)) for l in range(layers)]
+            out = sess.step()
+            torch.cuda.synchronize()
+            for l in range(layers):
+                assert torch.equal(out[l][:n], ref[l]), (s, l)
+            assert torch.equal(pe._storage, ps._storage)
+            if peek_every and s % peek_every == 0:  # a metadata build of the session's tree in the middle of an epoch
+                m2 = deft_amd.TreeMetadata.from_tree_cache(ts)
+                assert torch.equal(m2.block_lens, md.block_lens) and torch.equal(m2.node_kv, md.node_kv)
+
+    deft_amd.TreeMetadata.from_tree_cache(ts)  # the device copy of ts is current BEFORE the session's first step
+    both_steps(6, peek_every=2)
+    for tree in (te, ts):
+        lv = sorted(tree.leaves.values(), key=lambda n: n.id)
+        tree.cut(lv[2])
+        tree.branch(lv[0], 2)
+    deft_amd.TreeMetadata.from_tree_cache(ts)  # and again between two epochs
+    both_steps(5)
+    # a second session on the same tree starts from a device copy the first one left current
+    sess2 = deft_amd.DecodeSession(ts, Hq, Hkv, D, layers, lambda l: (q[l, : nq_now[0]], k[l, : nq_now[0]], v[l, : nq_now[0]]), mode=mode)
+    sess = sess2
+    both_steps(4)

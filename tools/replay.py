@@ -40,11 +40,11 @@ L = a.layers or L
 def template():
     if a.task == "reasoning":
         if a.template:
-            return rp.load_trees(a.template)[a.tree_index]
+            return rp.read_reasoning_file(a.template)[a.tree_index]
         return rp.synthetic_reasoning_template()
     if a.task == "speculative_decoding":
         if a.template:
-            t = rp.load_prompts(a.template)[a.tree_index]
+            t = rp.read_speculative_file(a.template)[a.tree_index]
             return t
         return rp.synthetic_speculative_template(a.tree_size, a.sd_steps)
     return rp.synthetic_few_shot_template(a.width)
