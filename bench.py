@@ -296,6 +296,13 @@ class Bench:
                           else "eager (tree.alloc, TreeMetadata.from_tree_cache, DeFTAttention.forward per layer)"}
 
 
+def _ctl_device(b: "Bench"):
+    """Where the control-plane tensors of the bracket live: the GPU under RCCL, host memory under gloo."""
+    import torch.distributed as dist
+
+    return b.device if dist.get_backend() == "nccl" else torch.device("cpu")
+
+
 def run_timed(b: Bench, steps: int, warmup: int, dist_on: bool):
     import torch.distributed as dist
 
@@ -306,7 +313,7 @@ def run_timed(b: Bench, steps: int, warmup: int, dist_on: bool):
 
         dist.barrier()
         torch.cuda.synchronize(b.device)
-        max_over_ranks(0.0, b.device)
+        max_over_ranks(0.0, _ctl_device(b))
         dist.barrier()
     for _ in range(warmup):
         b.step()
@@ -323,7 +330,7 @@ def run_timed(b: Bench, steps: int, warmup: int, dist_on: bool):
     if dist_on:
         from deft_amd.utils.sharding import max_over_ranks
 
-        dt = max_over_ranks(dt, b.device)  # control plane only; the data path has no collective
+        dt = max_over_ranks(dt, _ctl_device(b))  # control plane only; the data path has no collective
     return dt
 
 
@@ -400,23 +407,31 @@ def cfg5_line(device, layers_model: str, n_gpus: int, rank: int, dist_on: bool, 
     s1 = b.time_stage1(reps=2)
     algo = b.algorithmic_bytes_per_layer()
     e2e = None
-    if not dist_on:
-        try:  # the advancing loop of the same share, the batch as ONE tree object (TreeCache.init_forest) through the session
-            e2e = forest_end_to_end(b, wv, device, min(steps, 40))
-        except Exception as e:
-            e2e = {"error": f"{type(e).__name__}: {e}"}
+    try:  # the advancing loop of the same share, the batch as ONE tree object (TreeCache.init_forest) through the session
+        e2e = forest_end_to_end(b, wv, device, min(steps, 40), dist_on)
+    except Exception as e:
+        e2e = {"error": f"{type(e).__name__}: {e}"}
+        if dist_on:
+            raise  # (a rank that skips the loop's barriers would hang the others)
+    shares = [mine]
+    if dist_on:
+        import torch.distributed as dist
+
+        shares = [None] * n_gpus
+        dist.all_gather_object(shares, mine)  # (control plane, after the timed regions: what every rank decoded)
     return {"workload": "BASELINE configs[4]: %d independent trees (8192-token prefix x 8 branches x 64 tokens, Llama-3-8B "
                         "DeFT-Flatten) over %d GPU(s), %d per GPU" % (n_gpus * w.trees, n_gpus, len(mine)),
             "end_to_end": e2e,
-            "trees_this_rank": mine, "queries_per_gpu": b.nq, "kv_tokens_per_gpu": b.n_kv,
+            "trees_this_rank": mine, "trees_by_rank": shares, "queries_per_gpu": b.nq, "kv_tokens_per_gpu": b.n_kv,
             "tokens_per_s": round(n_gpus * b.nq / (dt / steps), 1), "ms_per_step": round(dt / steps * 1e3, 4),
             "us_per_layer": round(dt / steps * 1e6 / b.layers, 2), "steps": steps,
             "stage1_us": round(s1["mean_us"], 2) if s1 else None,
             "stage1_hbm_frac": round(algo / (s1["mean_us"] * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4) if s1 else None,
-            "collectives_in_data_path": 0, "rccl": "control plane only (barrier + MAX of the step time)"}
+            "collectives_in_data_path": 0, "rccl": "control plane only (barrier + MAX of the step time)",
+            "dist_backend": (__import__("torch").distributed.get_backend() if dist_on else None)}
 
 
-def forest_end_to_end(b: "Bench", w: Workload, device, steps: int):
+def forest_end_to_end(b: "Bench", w: Workload, device, steps: int, dist_on: bool = False):
     """cfg5's decode LOOP on one GPU: the rank's trees as one tree object (a root without tokens), every leaf growing a token per
     step, deft_amd.FlattenDecodeSession (tree advance, TreeMetadata and plan on the GPU, 32 layers, one hipGraph), wall clock
     without host syncs; next to it the host time of `Forest.metadata()` for the same batch -- what the per-step metadata of
@@ -446,6 +461,10 @@ def forest_end_to_end(b: "Bench", w: Workload, device, steps: int):
 
     for _ in range(4):
         one()
+    if dist_on:
+        import torch.distributed as dist
+
+        dist.barrier()
     torch.cuda.synchronize(device)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
@@ -454,7 +473,13 @@ def forest_end_to_end(b: "Bench", w: Workload, device, steps: int):
         one()
     e1.record()
     torch.cuda.synchronize(device)
+    if dist_on:
+        dist.barrier()
     wall = time.perf_counter() - t0
+    if dist_on:
+        from deft_amd.utils.sharding import max_over_ranks
+
+        wall = max_over_ranks(wall, _ctl_device(b))
     return {"what": "the rank's trees as ONE tree object (TreeCache.init_forest) through deft_amd.FlattenDecodeSession, every leaf "
                     "growing a token per step; no host sync inside the loop",
             "steps": steps, "ms_per_step": round(wall / steps * 1e3, 4), "gpu_ms_per_step": round(e0.elapsed_time(e1) / steps, 4),
@@ -505,6 +530,10 @@ def main():
     ap.add_argument("--no-e2e", action="store_true", help="skip the advancing-tree end-to-end loop")
     ap.add_argument("--no-cfg5", action="store_true", help="skip the sharded-forest (BASELINE configs[4]) measurement")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
+    ap.add_argument("--dist-backend", default="nccl", choices=("nccl", "gloo"),
+                    help="process-group backend of the N > 1 bracket (barrier + MAX of the step time; the data path has no "
+                         "collective).  nccl = RCCL, one rank per GPU.  gloo: control plane over TCP, and ranks beyond the visible "
+                         "GPUs share them round-robin -- rehearses every line of the N > 1 path on a ONE-GPU box")
     ap.add_argument("--child", action="store_true", help=argparse.SUPPRESS)  # the PMC child: timed steps only
     args = ap.parse_args()
 
@@ -526,13 +555,17 @@ def main():
     dist_on = world > 1
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: deft_amd has no CPU path")
-    device = torch.device("cuda", local_rank)
+    shared_gpus = args.dist_backend == "gloo" and world > torch.cuda.device_count()
+    device = torch.device("cuda", local_rank % torch.cuda.device_count() if shared_gpus else local_rank)
     torch.cuda.set_device(device)
     if dist_on:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group("gloo")
     n_gpus = world if dist_on else 1
 
     w = WORKLOADS[args.workload]
@@ -690,6 +723,8 @@ def main():
             "metadata_build_ms": round(b.metadata_build_ms, 3),
             "plan_build_us_per_step": round(plan_us, 1) if plan_us is not None else None,
             "end_to_end": e2e, "gpu_state": gpu_state(),
+            "dist": ({"backend": args.dist_backend, "world_size": world, "ranks_share_gpus": bool(shared_gpus),
+                      "visible_gpus": torch.cuda.device_count()} if dist_on else None),
             "roofline": roofline, "cpu_baseline": cpu, "cfg5_sharded_forest": cfg5, "prefill": prefill,
             "other_workloads": extras,
         }
