@@ -55,17 +55,12 @@ def _check_qkv(query_states, key_buffer, value_buffer, output):
     return nq, Hq, Hkv, D
 
 
-MULTIPASS = None  # A/B hook (like deft_attention.FUSED_APPEND): 0 / 1 force the launch option, None = the structural rule
-
-
 def multipass_launch(md, Hq: int, Hkv: int, D: int) -> int:
     """The launch option of the *_mp entry points: 1 when some node that holds tokens has more than 32 / (Hq / Hkv) live
     leaves below it -- its KV tiles then need more than one 32-row pass, and the multi-pass stage 1 stages each of them once.
     A STRUCTURAL property of the tree (TreeMetadata.max_node_queries, from the native tree): it changes only when the tree's
     structure does, so the eager path and a captured session of the same tree decide alike.  Metadata without the hint
     (arrays handed to the reference-shaped operators directly) takes the single-pass launch."""
-    if MULTIPASS is not None:
-        return 1 if (MULTIPASS and D == 128) else 0
     n = int(getattr(md, "max_node_queries", 0) or 0)
     return 1 if (D == 128 and Hkv > 0 and n * (Hq // Hkv) > 32) else 0
 

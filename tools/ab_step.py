@@ -25,8 +25,6 @@ for rnd in range(a.rounds):
         for n, v in zip(names, combo):
             if v == "-": os.environ.pop(n, None)
             else: os.environ[n] = v
-        import deft_amd.tree_attention as _ta
-        _ta.MULTIPASS = {"0": 0, "1": 1}.get(os.environ.get("DEFT_MULTIPASS", ""), None)  # (Python-side A/B hook)
         b.graph = None
         b.md.__dict__.pop("_deft_step", None)  # the per-step fast path holds the plan it was built with
         b.prepare(use_graph=True)  # plans are cached per deft_plan_variant(): a new knob value rebuilds them
