@@ -67,11 +67,6 @@ lib.deft_flatten_build_plan.argtypes = _MD6 + [_i32, _i32, _i32, _i32, _i64, _i6
 lib.deft_flatten_build_plan.restype = C.c_int
 lib.deft_flatten_build_plan_dims.argtypes = _MD6 + [_i32, _i32, _vp, _i32, _i32, _i64, _i64, _i64, _vp, _i32, _i64, _vp, _sz, _vp]
 lib.deft_flatten_build_plan_dims.restype = C.c_int
-lib.deft_flatten_build_plan_mp.argtypes = _MD6 + [_i32, _i32, _vp, _i32, _i32, _i64, _i64, _i64, _vp, _i32, _i64, _vp, _sz, _i32, _vp]
-lib.deft_flatten_build_plan_mp.restype = C.c_int
-lib.deft_flatten_decode_append_mp_f16.argtypes = (_QKV + _OUT + _MD6 + [_i32] * 6 + [_f32, _vp, _vp, _vp, _i64, _i32] +
-                                                  [_i32, _vp, _vp, _sz, _vp])
-lib.deft_flatten_decode_append_mp_f16.restype = C.c_int
 lib.deft_node_decode_f16.argtypes = _QKV + _OUT + _MD6 + [_i32, _i32, _i64, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _sz, _vp]
 lib.deft_node_plan_bytes.argtypes = [_i32, _i32, _i64, _i32, _i32]
 lib.deft_node_plan_bytes.restype = _sz
@@ -80,11 +75,6 @@ lib.deft_node_build_plan.restype = C.c_int
 lib.deft_node_build_plan_dims.argtypes = _MD6 + [_i32, _i32, _i64, _vp, _i32, _i32, _i64, _i64, _i64, _vp, _i32, _i64, _vp, _sz, _vp]
 lib.deft_node_build_plan_dims.restype = C.c_int
 lib.deft_node_decode_f16.restype = C.c_int
-lib.deft_node_build_plan_mp.argtypes = _MD6 + [_i32, _i32, _i64, _vp, _i32, _i32, _i64, _i64, _i64, _vp, _i32, _i64, _vp, _sz, _i32, _vp]
-lib.deft_node_build_plan_mp.restype = C.c_int
-lib.deft_node_decode_append_mp_f16.argtypes = (_QKV + _OUT + _MD6 + [_i32, _i32, _i64, _i32, _i32, _i32, _i32, _f32]
-                                               + [_vp, _vp, _vp, _i64, _i32] + [_i32, _vp, _vp, _sz, _vp])
-lib.deft_node_decode_append_mp_f16.restype = C.c_int
 lib.deft_node_decode_append_f16.argtypes = (_QKV + _OUT + _MD6 + [_i32, _i32, _i64, _i32, _i32, _i32, _i32, _f32]
                                             + [_vp, _vp, _vp, _i64, _i32] + [_vp, _vp, _sz, _vp])
 lib.deft_node_decode_append_f16.restype = C.c_int
@@ -129,7 +119,6 @@ lib.deft_tree_create.argtypes = []
 lib.deft_tree_create.restype = _i64
 _TREE_FUNCS = {
     "deft_tree_free": ([_i64], C.c_int),
-    "deft_tree_max_node_queries": ([_i64], _i64),
     "deft_tree_add_node": ([_i64, _i64, _i64], C.c_int),
     "deft_tree_remove_node": ([_i64, _i64], C.c_int),
     "deft_tree_set_leaf": ([_i64, _i64, C.c_int], C.c_int),
@@ -165,7 +154,6 @@ EXPORTED = (
     "deft_abi_version", "deft_last_error", "deft_supported", "deft_plan_variant",
     "deft_flatten_workspace_bytes", "deft_flatten_plan_bytes", "deft_flatten_build_plan", "deft_flatten_build_plan_dims",
     "deft_flatten_decode_f16", "deft_flatten_decode_append_f16", "deft_flatten_stage1_f16",
-    "deft_flatten_build_plan_mp", "deft_flatten_decode_append_mp_f16", "deft_node_build_plan_mp", "deft_node_decode_append_mp_f16",
     "deft_flatten_read_partials", "deft_node_workspace_bytes", "deft_node_plan_bytes", "deft_node_build_plan", "deft_node_build_plan_dims",
     "deft_node_decode_f16", "deft_node_decode_append_f16", "deft_flatten_decode_rope_append_f16", "deft_node_decode_rope_append_f16", "deft_rope_gather_rows",
     "deft_prefill_f16", "deft_rope_qk_f16", "deft_seq_plan_bytes", "deft_seq_workspace_bytes", "deft_seq_build_plan", "deft_seq_decode_f16", "deft_seq_decode_append_f16",

@@ -56,14 +56,13 @@ inline int64_t node_max_tiles(int NE, int64_t total_kv) { return (int64_t)NE + t
 //   header      4 KB  : int32 hdr[0] = records per KV head, hdr[1] = chunk leaders, hdr[2] = error flags,
 //                       hdr[3] = 1 when the per-query row lists below are valid (plan_records.h)
 //   records     (cap+1) x 2048 B (plan_records.h PLAN_*), cap = units-per-head capacity
-//   unit list   19 x cap int32 (src, aux, pass, flags, prow; tile-parallel order: perm, chunk tiles, first follower; union groups: n, 4 queries, 4 rows;
-//                                multi-pass order: first sibling leader, passes | stride)
+//   unit list   17 x cap int32 (src, aux, pass, flags, prow; tile-parallel order: perm, chunk tiles, first follower; union groups: n, 4 queries, 4 rows)
 //   row_q       rows int32 : partial row -> query row (-1 = dead row)
 //   qoff, qlist rows + 1, rows int32 : per query, its live partial rows in ascending order (what the merge reads)
 struct PlanView {
     int32_t* hdr;
     char* records;
-    int32_t* units;  // 19 arrays of `cap`
+    int32_t* units;  // 17 arrays of `cap`
     int32_t* row_q;
     int32_t* qoff;   // [rows + 1] first entry of every query's row list (queries are < rows: each has a partial row)
     int32_t* qlist;  // [rows] live partial rows grouped by query, ascending within a query
@@ -82,7 +81,7 @@ inline PlanView plan_view(void* base, int64_t cap, int64_t rows) {
     v.records = p + off;
     off = align_up(off + 2048 * (size_t)(cap + 1), 256);
     v.units = reinterpret_cast<int32_t*>(p + off);
-    off = align_up(off + sizeof(int32_t) * 19 * (size_t)(cap > 0 ? cap : 1), 256);
+    off = align_up(off + sizeof(int32_t) * 17 * (size_t)(cap > 0 ? cap : 1), 256);
     v.row_q = reinterpret_cast<int32_t*>(p + off);
     off = align_up(off + sizeof(int32_t) * (size_t)(rows > 0 ? rows : 1), 256);
     v.qoff = reinterpret_cast<int32_t*>(p + off);

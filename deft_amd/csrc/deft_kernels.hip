@@ -292,7 +292,6 @@ __global__ __launch_bounds__(256, 2) void stage1_kernel(Stage1Params p) {
 #include "tree_plan.h"
 #include "merge.h"
 #include "stage1_np.h"
-#include "stage1_wide.h"
 #include "prefill.h"
 #ifdef DEFT_EXPERIMENTS
 #include "prefill_w4.h"    // 4 waves x 2 workgroups per CU: experiment
@@ -540,7 +539,7 @@ static int num_cus() {
     return d.cus;
 }
 enum : unsigned { ATTR_NP = 4,  // (bits 0-1, 8-11: the head_dim 64 / 32 / 16 kernels)
-                  ATTR_UNITS = 8, ATTR_NODE_UNITS = 16, ATTR_PREFILL = 32, ATTR_TREE = 64, ATTR_NP_ROPE = 128, ATTR_PREFILL_PIPE = 4096, ATTR_NP_T = 8192, ATTR_NP_ROPE_T = 16384, ATTR_WIDE = 32768 };
+                  ATTR_UNITS = 8, ATTR_NODE_UNITS = 16, ATTR_PREFILL = 32, ATTR_TREE = 64, ATTR_NP_ROPE = 128, ATTR_PREFILL_PIPE = 4096, ATTR_NP_T = 8192, ATTR_NP_ROPE_T = 16384 };
 static int raise_lds(const void* fn, int bytes, unsigned bit, const char* what) {  // idempotent; races are harmless
     DeviceState& d = dev_state();
     if (d.attrs & bit) return DEFT_OK;
@@ -587,9 +586,6 @@ struct AppendArgs {
     int n_new = 0;
     // fused rotary embedding (optional, with the fused append only): cos | sin row of every new token, [n_new][D] fp32
     const float* cos_sin = nullptr;
-    // launch option of the *_mp entry points (not append-related; carried here because this struct reaches every launch
-    // helper): the multi-pass order of the plan / the multi-pass stage-1 kernel (stage1_wide.h)
-    int multipass = 0;
 };
 
 static UnitList unit_list(const PlanView& pv) {
@@ -605,8 +601,6 @@ static UnitList unit_list(const PlanView& pv) {
     ul.gn = pv.units + 8 * pv.cap;
     ul.gq = pv.units + 9 * pv.cap;
     ul.grow = pv.units + 13 * pv.cap;
-    ul.ch_sib = pv.units + 17 * pv.cap;
-    ul.ch_pn = pv.units + 18 * pv.cap;
     return ul;
 }
 
@@ -645,18 +639,18 @@ static int launch_plan(const Stage1Params& p, int NB, const PlanView& pv, const 
     const size_t blk = (qtab ? 8 : 4) * (size_t)NB;
     int64_t run_cap = pv.cap;
     int par = !g_plan_serial;
-    if (par && sizeof(int) * (blk + 6 * (size_t)run_cap + 8) > UNIT_LDS) {  // as many runs as fit (the kernel falls back if more turn up)
-        run_cap = ((int64_t)(UNIT_LDS / sizeof(int)) - (int64_t)blk - 8) / 6;
+    if (par && sizeof(int) * (blk + 5 * (size_t)run_cap + 8) > UNIT_LDS) {  // as many runs as fit (the kernel falls back if more turn up)
+        run_cap = ((int64_t)(UNIT_LDS / sizeof(int)) - (int64_t)blk - 8) / 5;
         if (run_cap < 256) par = 0, run_cap = pv.cap;
     }
     if (par && g_plan_runcap > 0) run_cap = std::max(1, std::min((int)run_cap, g_plan_runcap));  // tests: force the fallback
     if (!par)
         while (sizeof(int) * (blk + 3 * (size_t)run_cap + 8) > UNIT_LDS && run_cap > 0) run_cap /= 2;
-    const size_t lds = sizeof(int) * (blk + (par ? 6 : 3) * (size_t)run_cap + 8);
+    const size_t lds = sizeof(int) * (blk + (par ? 5 : 3) * (size_t)run_cap + 8);
     const UnitList ul = unit_list(pv);
     hipLaunchKernelGGL(flatten_units_kernel, dim3(1), dim3(1024), lds, stream, p.block_q, p.block_q_cnts, p.block_q_offset, NB,
                        p.G, (int)pv.cap, ul, pv.hdr, p.Hkv, 2 * num_cus(), np_chunk_knob(), np_union_knob(), (int)run_cap, qtab,
-                       par, dims, pv.row_q, (int)pv.rows, ap.multipass);
+                       par, dims, pv.row_q, (int)pv.rows);
     rc = check_launch("flatten units launch");
     if (rc) return rc;
     hipLaunchKernelGGL(flatten_records_kernel, dim3((unsigned)(pv.cap + 1)), dim3(128), 0, stream, p.block_q, p.block_q_cnts,
@@ -725,32 +719,6 @@ static int launch_stage1_np(const Stage1Params& p, int64_t unit_cap, const PlanV
     else if (nt) hipLaunchKernelGGL((stage1_np_kernel<128, false, true>), g, b, SM::BYTES, stream, npp);
     else hipLaunchKernelGGL((stage1_np_kernel<128, false, false>), g, b, SM::BYTES, stream, npp);
     return check_launch("stage1 np launch");
-}
-
-// Stage 1, multi-pass form (stage1_wide.h): one workgroup per CU; work items = the PRIMARY chunk leaders of a plan built in
-// the wide order (any plan works: without sibling groups every leader is primary and takes one pass).
-static int launch_stage1_wide(const Stage1Params& p, int64_t unit_cap, const PlanView& pv, const AppendArgs& ap, hipStream_t stream) {
-    using SM = WideSmem<128>;
-    int rc = raise_lds(reinterpret_cast<const void*>(&stage1_wide_kernel<128, true>), SM::BYTES, ATTR_WIDE, "stage1_wide");
-    if (rc) return rc;
-    if (unit_cap <= 0) return DEFT_OK;
-    // grid by record capacity, capped at a few workgroups per CU: one is resident per CU, and a workgroup takes items
-    // item, item + grid, ... in a loop (the item count lives on the device)
-    int64_t grid = unit_cap * p.Hkv;
-    const int64_t cap_wgs = (int64_t)knob("DEFT_WIDE_GRIDCAP", 2) * num_cus();
-    if (grid > cap_wgs) grid = cap_wgs;
-    NpParams npp{};
-    npp.s = p;
-    npp.hdr = pv.hdr;
-    npp.plan = pv.records;
-    npp.k_new = ap.k_new;
-    npp.v_new = ap.v_new;
-    npp.cache_loc = ap.cache_loc;
-    npp.new_st = ap.new_st;
-    npp.n_new = ap.k_new ? ap.n_new : 0;
-    npp.dbg = g_dbg;
-    hipLaunchKernelGGL((stage1_wide_kernel<128, true>), dim3((unsigned)grid), dim3(256), SM::BYTES, stream, npp);
-    return check_launch("stage1 (multi-pass) launch");
 }
 
 static int launch_merge(int D, const Workspace& ws, const PlanView* pv, const int32_t* row_q, int64_t rows, void* out,
@@ -954,7 +922,6 @@ static int flatten_stage1_impl(const void* q, int64_t q_stride_tok, int64_t q_st
         }
         *row_q_out = pv.row_q;
         *pv_out = pv;
-        if (ap.multipass && !ap.cos_sin) return launch_stage1_wide(p, cap, pv, ap, st);
         return launch_stage1_np(p, cap, pv, ap, st, nq);
     }
     if (ap.k_new) {  // head_dim 64 (tile-per-workgroup form): separate append launch first
@@ -971,11 +938,11 @@ size_t deft_flatten_plan_bytes(int NB, int P, int Hq, int Hkv) {
     return plan_view(nullptr, flatten_unit_cap(NB, Hq / Hkv), P).bytes;
 }
 
-static int flatten_build_plan_impl(const int64_t* block_q, const int64_t* block_q_cnts, const int64_t* block_q_offset,
-                                   const int64_t* block_bitmasks, const int64_t* block_kv, const int64_t* block_lens, int NB, int P,
-                                   const int32_t* dims, int Hq, int Hkv, int64_t q_stride_tok, int64_t q_stride_head,
-                                   int64_t kv_stride_slot, const int32_t* cache_loc, int n_new, int64_t new_stride_tok, void* plan,
-                                   size_t plan_bytes, int multipass, void* stream) {
+int deft_flatten_build_plan(const int64_t* block_q, const int64_t* block_q_cnts, const int64_t* block_q_offset,
+                            const int64_t* block_bitmasks, const int64_t* block_kv, const int64_t* block_lens, int NB, int P,
+                            int Hq, int Hkv, int64_t q_stride_tok, int64_t q_stride_head, int64_t kv_stride_slot,
+                            const int32_t* cache_loc, int n_new, int64_t new_stride_tok, void* plan, size_t plan_bytes,
+                            void* stream) {
     if (NB < 0 || P < 0 || !plan || n_new < 0 || Hq <= 0 || Hkv <= 0 || Hq % Hkv ||
         (NB > 0 && (!block_q || !block_q_cnts || !block_q_offset || !block_bitmasks || !block_kv || !block_lens))) {
         set_error("bad plan arguments (NB=%d P=%d Hq=%d Hkv=%d)", NB, P, Hq, Hkv);
@@ -1003,18 +970,7 @@ static int flatten_build_plan_impl(const int64_t* block_q, const int64_t* block_
     ap.cache_loc = cache_loc;
     ap.n_new = cache_loc ? n_new : 0;
     ap.new_st = new_stride_tok;
-    ap.multipass = multipass ? 1 : 0;
-    return launch_plan(p, NB, pv, ap, static_cast<hipStream_t>(stream), dims);
-}
-
-int deft_flatten_build_plan(const int64_t* block_q, const int64_t* block_q_cnts, const int64_t* block_q_offset,
-                            const int64_t* block_bitmasks, const int64_t* block_kv, const int64_t* block_lens, int NB, int P,
-                            int Hq, int Hkv, int64_t q_stride_tok, int64_t q_stride_head, int64_t kv_stride_slot,
-                            const int32_t* cache_loc, int n_new, int64_t new_stride_tok, void* plan, size_t plan_bytes,
-                            void* stream) {
-    return flatten_build_plan_impl(block_q, block_q_cnts, block_q_offset, block_bitmasks, block_kv, block_lens, NB, P, nullptr, Hq, Hkv,
-                                   q_stride_tok, q_stride_head, kv_stride_slot, cache_loc, n_new, new_stride_tok, plan, plan_bytes, 0,
-                                   stream);
+    return launch_plan(p, NB, pv, ap, static_cast<hipStream_t>(stream));
 }
 
 // The same for metadata that was built ON THE DEVICE (deft_tree_dev_build_md): NB and P are the CAPACITIES of the arrays
@@ -1026,28 +982,34 @@ int deft_flatten_build_plan_dims(const int64_t* block_q, const int64_t* block_q_
                                  const int32_t* dims, int Hq, int Hkv, int64_t q_stride_tok, int64_t q_stride_head,
                                  int64_t kv_stride_slot, const int32_t* cache_loc, int n_new, int64_t new_stride_tok, void* plan,
                                  size_t plan_bytes, void* stream) {
-    if (!dims) {
-        set_error("deft_flatten_build_plan_dims: null dims");
+    if (NB < 0 || P < 0 || !plan || !dims || n_new < 0 || Hq <= 0 || Hkv <= 0 || Hq % Hkv ||
+        (NB > 0 && (!block_q || !block_q_cnts || !block_q_offset || !block_bitmasks || !block_kv || !block_lens))) {
+        set_error("bad plan arguments (NB=%d P=%d Hq=%d Hkv=%d)", NB, P, Hq, Hkv);
         return DEFT_EINVAL;
     }
-    return flatten_build_plan_impl(block_q, block_q_cnts, block_q_offset, block_bitmasks, block_kv, block_lens, NB, P, dims, Hq, Hkv,
-                                   q_stride_tok, q_stride_head, kv_stride_slot, cache_loc, n_new, new_stride_tok, plan, plan_bytes, 0,
-                                   stream);
-}
-
-// Either of the two with a launch option: `multipass` != 0 orders the plan for the multi-pass stage 1 (stage1_wide.h) -- the
-// passes of one KV tile (GQA with many branches, nodes with more than 32 queries) are folded by one workgroup that stages
-// the tile once.  `dims` may be null (host-built metadata).  Pair it with deft_flatten_decode_append_mp_f16(multipass = the
-// same value).  The caller decides from the tree's STRUCTURE (some node with tokens has more than 32 / (Hq / Hkv) live leaves
-// below it); any plan is valid input to either stage-1 kernel, the option only changes speed and the (deterministic) split.
-int deft_flatten_build_plan_mp(const int64_t* block_q, const int64_t* block_q_cnts, const int64_t* block_q_offset,
-                               const int64_t* block_bitmasks, const int64_t* block_kv, const int64_t* block_lens, int NB, int P,
-                               const int32_t* dims, int Hq, int Hkv, int64_t q_stride_tok, int64_t q_stride_head,
-                               int64_t kv_stride_slot, const int32_t* cache_loc, int n_new, int64_t new_stride_tok, void* plan,
-                               size_t plan_bytes, int multipass, void* stream) {
-    return flatten_build_plan_impl(block_q, block_q_cnts, block_q_offset, block_bitmasks, block_kv, block_lens, NB, P, dims, Hq, Hkv,
-                                   q_stride_tok, q_stride_head, kv_stride_slot, cache_loc, n_new, new_stride_tok, plan, plan_bytes,
-                                   multipass, stream);
+    const PlanView pv = plan_view(plan, flatten_unit_cap(NB, Hq / Hkv), P);
+    if (plan_bytes < pv.bytes) {
+        set_error("plan buffer too small: %zu < %zu", plan_bytes, pv.bytes);
+        return DEFT_EWORKSPACE;
+    }
+    Stage1Params p{};
+    p.block_q = block_q;
+    p.block_q_cnts = block_q_cnts;
+    p.block_q_offset = block_q_offset;
+    p.block_bitmasks = block_bitmasks;
+    p.block_kv = block_kv;
+    p.block_lens = block_lens;
+    p.rows = P;
+    p.G = Hq / Hkv;
+    p.Hkv = Hkv;
+    p.q_st = q_stride_tok;
+    p.q_sh = q_stride_head;
+    p.kv_ss = kv_stride_slot;
+    AppendArgs ap;
+    ap.cache_loc = cache_loc;
+    ap.n_new = cache_loc ? n_new : 0;
+    ap.new_st = new_stride_tok;
+    return launch_plan(p, NB, pv, ap, static_cast<hipStream_t>(stream), dims);
 }
 
 int deft_flatten_stage1_f16(const void* q, int64_t q_stride_tok, int64_t q_stride_head, const void* k_base,
@@ -1127,31 +1089,6 @@ int deft_flatten_decode_append_f16(const void* q, int64_t q_stride_tok, int64_t 
                                block_lens, NB, P, nq, Hq, Hkv, D, scale, plan, workspace, workspace_bytes, stream, ap);
 }
 
-// deft_flatten_decode_append_f16 with the launch option of deft_flatten_build_plan_mp (head_dim 128; ignored otherwise)
-int deft_flatten_decode_append_mp_f16(const void* q, int64_t q_stride_tok, int64_t q_stride_head, void* k_base, void* v_base,
-                                      int64_t kv_stride_slot, int64_t kv_stride_head, void* out, int64_t o_stride_tok,
-                                      int64_t o_stride_head, const int64_t* block_q, const int64_t* block_q_cnts,
-                                      const int64_t* block_q_offset, const int64_t* block_bitmasks, const int64_t* block_kv,
-                                      const int64_t* block_lens, int NB, int P, int nq, int Hq, int Hkv, int D, float scale,
-                                      const int32_t* cache_loc, const void* k_new, const void* v_new, int64_t new_stride_tok,
-                                      int n_new, int multipass, const void* plan, void* workspace, size_t workspace_bytes,
-                                      void* stream) {
-    AppendArgs ap;
-    ap.k_new = static_cast<const _Float16*>(k_new);
-    ap.v_new = static_cast<const _Float16*>(v_new);
-    ap.cache_loc = cache_loc;
-    ap.new_st = new_stride_tok;
-    ap.n_new = n_new;
-    ap.multipass = (multipass && D == 128) ? 1 : 0;
-    if (!k_new || !v_new || !cache_loc) {
-        set_error("fused append needs k_new, v_new and cache_loc");
-        return DEFT_EINVAL;
-    }
-    return flatten_decode_impl(q, q_stride_tok, q_stride_head, k_base, v_base, kv_stride_slot, kv_stride_head, out,
-                               o_stride_tok, o_stride_head, block_q, block_q_cnts, block_q_offset, block_bitmasks, block_kv,
-                               block_lens, NB, P, nq, Hq, Hkv, D, scale, plan, workspace, workspace_bytes, stream, ap);
-}
-
 int deft_flatten_decode_rope_append_f16(const void* q, int64_t q_stride_tok, int64_t q_stride_head, void* k_base, void* v_base,
                                         int64_t kv_stride_slot, int64_t kv_stride_head, void* out, int64_t o_stride_tok,
                                         int64_t o_stride_head, const int64_t* block_q, const int64_t* block_q_cnts,
@@ -1187,16 +1124,16 @@ static int launch_node_plan(const Stage1Params& p, int NE, int64_t rows_cap, con
     if (rc) return rc;
     int64_t run_cap = pv.cap > 0 ? pv.cap : 1;
     int par = !g_plan_serial;
-    if (par && sizeof(int) * (9 * (size_t)run_cap + 8) > UNIT_LDS) {
-        run_cap = ((int64_t)(UNIT_LDS / sizeof(int)) - 8) / 9;
+    if (par && sizeof(int) * (8 * (size_t)run_cap + 8) > UNIT_LDS) {
+        run_cap = ((int64_t)(UNIT_LDS / sizeof(int)) - 8) / 8;
         if (run_cap < 256) par = 0, run_cap = pv.cap > 0 ? pv.cap : 1;
     }
     if (par && g_plan_runcap > 0) run_cap = std::max(1, std::min((int)run_cap, g_plan_runcap));  // tests: force the fallback
     if (!par)
         while (sizeof(int) * (3 * (size_t)run_cap + 8) > UNIT_LDS && run_cap > 1) run_cap /= 2;
-    hipLaunchKernelGGL(node_units_kernel, dim3(1), dim3(1024), sizeof(int) * ((par ? 9 : 3) * (size_t)run_cap + 8), stream,
+    hipLaunchKernelGGL(node_units_kernel, dim3(1), dim3(1024), sizeof(int) * ((par ? 8 : 3) * (size_t)run_cap + 8), stream,
                        p.node_kv_len, p.node_q_len, NE, p.G, (int)pv.cap, rows_cap, ul, pv.hdr, pv.row_q, p.Hkv,
-                       2 * num_cus(), np_chunk_knob(), (int)run_cap, par, keep_err, dims, ap.multipass, p.node_kv, p.node_kv_offset);
+                       2 * num_cus(), np_chunk_knob(), (int)run_cap, par, keep_err, dims);
     rc = check_launch("node units launch");
     if (rc) return rc;
     hipLaunchKernelGGL(node_records_kernel, dim3((unsigned)(pv.cap + 1)), dim3(128), 0, stream, p.node_kv, p.node_kv_offset,
@@ -1217,7 +1154,7 @@ static int node_build_plan_impl(const int64_t* node_kv, const int64_t* node_kv_o
                                 const int64_t* node_q, const int64_t* node_q_offset, const int64_t* node_q_len, int NE, int P,
                                 int64_t total_kv, const int32_t* dims, int Hq, int Hkv, int64_t q_stride_tok,
                                 int64_t q_stride_head, int64_t kv_stride_slot, const int32_t* cache_loc, int n_new,
-                                int64_t new_stride_tok, void* plan, size_t plan_bytes, void* stream, int multipass = 0) {
+                                int64_t new_stride_tok, void* plan, size_t plan_bytes, void* stream) {
     if (NE < 0 || P < 0 || total_kv < 0 || total_kv > 0x7fffffffLL || !plan || Hq <= 0 || Hkv <= 0 || Hq % Hkv ||
         (NE > 0 && (!node_kv || !node_kv_offset || !node_kv_len || !node_q || !node_q_offset || !node_q_len))) {
         set_error("bad node plan arguments (NE=%d P=%d total_kv=%lld)", NE, P, (long long)total_kv);
@@ -1253,7 +1190,6 @@ static int node_build_plan_impl(const int64_t* node_kv, const int64_t* node_kv_o
         ap.n_new = n_new;
         ap.new_st = new_stride_tok;
     }
-    ap.multipass = multipass ? 1 : 0;
     return launch_node_plan(p, NE, rows, pv, ap, static_cast<hipStream_t>(stream), 0, dims);
 }
 
@@ -1281,17 +1217,6 @@ int deft_node_build_plan_dims(const int64_t* node_kv, const int64_t* node_kv_off
     return node_build_plan_impl(node_kv, node_kv_offset, node_kv_len, node_q, node_q_offset, node_q_len, NE, P, total_kv, dims, Hq,
                                 Hkv, q_stride_tok, q_stride_head, kv_stride_slot, cache_loc, n_new, new_stride_tok, plan, plan_bytes,
                                 stream);
-}
-
-// Node-mode counterpart of deft_flatten_build_plan_mp (`dims` may be null)
-int deft_node_build_plan_mp(const int64_t* node_kv, const int64_t* node_kv_offset, const int64_t* node_kv_len,
-                            const int64_t* node_q, const int64_t* node_q_offset, const int64_t* node_q_len, int NE, int P,
-                            int64_t total_kv, const int32_t* dims, int Hq, int Hkv, int64_t q_stride_tok,
-                            int64_t q_stride_head, int64_t kv_stride_slot, const int32_t* cache_loc, int n_new,
-                            int64_t new_stride_tok, void* plan, size_t plan_bytes, int multipass, void* stream) {
-    return node_build_plan_impl(node_kv, node_kv_offset, node_kv_len, node_q, node_q_offset, node_q_len, NE, P, total_kv, dims, Hq,
-                                Hkv, q_stride_tok, q_stride_head, kv_stride_slot, cache_loc, n_new, new_stride_tok, plan, plan_bytes,
-                                stream, multipass);
 }
 
 }  // extern "C"
@@ -1356,8 +1281,7 @@ static int node_decode_impl(const void* q, int64_t q_stride_tok, int64_t q_strid
             rc = launch_node_plan(p, NE, rows, pv, ap, st);
             if (rc) return rc;
         }
-        if (ap.multipass && !ap.cos_sin && rows_per_tile != 1) rc = launch_stage1_wide(p, tiles * G, pv, ap, st);
-        else rc = launch_stage1_np(p, tiles * G, pv, ap, st, nq, /*reread=*/rows_per_tile == 1);
+        rc = launch_stage1_np(p, tiles * G, pv, ap, st, nq, /*reread=*/rows_per_tile == 1);
         if (rc) return rc;
         return launch_merge(D, ws, &pv, pv.row_q, rows, out, o_stride_tok, o_stride_head, nq, Hq, st);
     }
@@ -1411,31 +1335,6 @@ int deft_node_decode_append_f16(const void* q, int64_t q_stride_tok, int64_t q_s
     ap.cache_loc = cache_loc;
     ap.new_st = new_stride_tok;
     ap.n_new = n_new;
-    if (!k_new || !v_new || !cache_loc) {
-        set_error("fused append needs k_new, v_new and cache_loc");
-        return DEFT_EINVAL;
-    }
-    return node_decode_impl(q, q_stride_tok, q_stride_head, k_base, v_base, kv_stride_slot, kv_stride_head, out,
-                            o_stride_tok, o_stride_head, node_kv, node_kv_offset, node_kv_len, node_q, node_q_offset,
-                            node_q_len, NE, P, total_kv, nq, Hq, Hkv, D, scale, plan, workspace, workspace_bytes, stream, ap);
-}
-
-// deft_node_decode_append_f16 with the launch option of deft_node_build_plan_mp (head_dim 128; ignored otherwise)
-int deft_node_decode_append_mp_f16(const void* q, int64_t q_stride_tok, int64_t q_stride_head, void* k_base, void* v_base,
-                                   int64_t kv_stride_slot, int64_t kv_stride_head, void* out, int64_t o_stride_tok,
-                                   int64_t o_stride_head, const int64_t* node_kv, const int64_t* node_kv_offset,
-                                   const int64_t* node_kv_len, const int64_t* node_q, const int64_t* node_q_offset,
-                                   const int64_t* node_q_len, int NE, int P, int64_t total_kv, int nq, int Hq, int Hkv, int D,
-                                   float scale, const int32_t* cache_loc, const void* k_new, const void* v_new,
-                                   int64_t new_stride_tok, int n_new, int multipass, const void* plan, void* workspace,
-                                   size_t workspace_bytes, void* stream) {
-    AppendArgs ap;
-    ap.k_new = static_cast<const _Float16*>(k_new);
-    ap.v_new = static_cast<const _Float16*>(v_new);
-    ap.cache_loc = cache_loc;
-    ap.new_st = new_stride_tok;
-    ap.n_new = n_new;
-    ap.multipass = (multipass && D == 128) ? 1 : 0;
     if (!k_new || !v_new || !cache_loc) {
         set_error("fused append needs k_new, v_new and cache_loc");
         return DEFT_EINVAL;

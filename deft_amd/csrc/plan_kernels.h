@@ -70,11 +70,6 @@ struct UnitList {   // all int32, capacity `cap` each
     int32_t* perm;   // record -> unit
     int32_t* ch_n;   // tiles of the chunk this record leads (itself included); 0 = follower
     int32_t* ch_fb;  // record index of the chunk's first follower (followers are consecutive records)
-    // multi-pass ("wide") order, stage1_wide.h: sibling runs = consecutive runs over the SAME KV tiles (the 32-row passes of
-    // one block; the alternating blocks / entries of a node with more than 32 queries) are folded, up to WIDE_PASSES at a
-    // time, by ONE workgroup that stages every tile once.  Indexed by RECORD (leaders only):
-    int32_t* ch_sib;  // leader record of this chunk's first sibling pass (further siblings follow at stride S); 0 = none
-    int32_t* ch_pn;   // passes this leader's workgroup takes (0 = an absorbed sibling: some other leader's workgroup) | S << 4
     // union groups (Flatten, tile-parallel order), indexed by GROUP id = aux - 1: consecutive leaf tiles whose query
     // lists differ but are small are folded by ONE workgroup over the union of their queries
     int32_t* gn;    // queries in the union (<= UNION_CAP)
@@ -97,15 +92,7 @@ struct RunTable {
     int* uni;  // non-zero: a union group = one chunk whatever its length (the Flatten kernel keeps the group id + 1 here)
     int n;    // runs recorded
     int cap;  // capacity; n > cap = overflow, fall back to scanning the unit arrays
-    int* grp = nullptr;  // position in its set of sibling runs | set size << 8 (parallel form only; null = every run alone)
 };
-
-constexpr int WIDE_PASSES = 2;  // passes per workgroup of the multi-pass stage 1 (its register budget, stage1_wide.h)
-// How a set of `gsize` sibling runs is dealt to workgroups: ceil(gsize / WIDE_PASSES) groups of equal size (6 passes -> 3 + 3).
-__device__ __host__ inline int wide_group_len(int gsize) {
-    const int ng = (gsize + WIDE_PASSES - 1) / WIDE_PASSES;
-    return (gsize + ng - 1) / ng;
-}
 
 constexpr int LONG_CHUNK = 4;  // tiles per chunk from which a chunk's leader is dispatched ahead of the short ones
 
@@ -192,8 +179,6 @@ __device__ inline void np_record_order(const UnitList& ul, int R, int Hkv, int G
             ul.perm[li] = r + p;
             ul.ch_n[li] = cnt;
             ul.ch_fb[li] = fi;
-            ul.ch_sib[li] = 0;
-            ul.ch_pn[li] = 1 | (S << 4);  // (the serial form folds no sibling passes: every leader is its own work item)
             ++li;
             for (int j = 1; j < cnt; ++j, ++fi) {
                 ul.perm[fi] = r + p + j * S;
@@ -203,125 +188,78 @@ __device__ inline void np_record_order(const UnitList& ul, int R, int Hkv, int G
         }
     });
     hdr[1] = NL;
-    hdr[HDR_PRIMARIES] = NL;
 }
 
 // Record order of the tile-parallel stage 1, written by all waves of the unit kernel from its LDS run table (the
 // rules of np_record_order above, same result).  Called by every thread after the units are written; rT0 / rSp are
 // scratch arrays of run_cap words (the callers' run fields are dead by then), sMeta[2..3] two shared words.
-//
-// `wide` (the multi-pass stage 1, stage1_wide.h): a set of sibling runs -- consecutive runs over the same KV tiles, rt.grp --
-// is dealt to workgroups wide_group_len(set size) passes at a time.  The first run of each such group is PRIMARY: its chunk
-// leaders are the work items; the leaders of the other runs of the group are ABSORBED (still leaders -- their partial rows
-// are live -- but no workgroup starts from them).  Leader records: primaries of long chunks, other primaries, absorbed;
-// hdr[HDR_PRIMARIES] = number of primaries.  A primary's descriptor names its first sibling's leader of the same chunk
-// (ch_sib; the siblings' leaders of one chunk are S records apart: consecutive runs of one class keep their order).
 __device__ inline void record_order_parallel(const UnitList& ul, const RunTable& rt, int NR, int* rT0, int* rSp, int* sMeta,
-                                             int32_t* hdr, int Hkv, int G, int slots, int chunk_c, int wide) {
+                                             int32_t* hdr, int Hkv, int G, int slots, int chunk_c) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-    const bool groups = wide && rt.grp != nullptr;
-    // role of run k in the wide order: passes its workgroup takes (0 = absorbed), from its position in its sibling set
-    auto passes_of = [&](int k) {
-        if (!groups || rt.uni[k]) return 1;
-        const int g = rt.grp[k], gpos = g & 0xff, gsize = g >> 8;
-        if (gsize <= 1) return 1;
-        const int glen = wide_group_len(gsize);
-        if (gpos % glen) return 0;
-        return min(glen, gsize - gpos);
-    };
     __syncthreads();  // (rT0 / rSp are reused below)
     // Wave 0: chunk length C from sums / maxima over the runs, then each run's first leader and first follower record
     // by prefix sums over the runs' chunk counts.
     if (threadIdx.x < 64) {
         auto wave_sum = [&](auto&& f) {
             int acc = 0;
-            for (int k = lane; k < NR; k += 64) acc += f(rt.nt[k], rt.uni[k], k);
+            for (int k = lane; k < NR; k += 64) acc += f(rt.nt[k], rt.uni[k]);
             for (int m = 32; m > 0; m >>= 1) acc += __shfl_xor(acc, m, 64);
             return acc;
         };
         int C = chunk_c;
-        if (C <= 0 && wide) {
-            // One workgroup per CU, every tile staged once for all its passes: as few work items as fit the CUs at once --
-            // the smallest chunk length that leaves at most one item per CU (at most 1.5 when none does: leaf tiles are
-            // items of their own whatever C is), chunks of at most 8 tiles.
-            const int cus = slots / 2;
-            int lmax = 0;
-            for (int k = lane; k < NR; k += 64)
-                if (!rt.uni[k] && rt.nt[k] > lmax) lmax = rt.nt[k];
-            for (int m = 32; m > 0; m >>= 1) lmax = max(lmax, __shfl_xor(lmax, m, 64));
-            auto items = [&](int c) {
-                return (int64_t)Hkv * wave_sum([&](int nt, int uni, int k) { return passes_of(k) == 0 ? 0 : (uni ? 1 : (nt + c - 1) / c); });
-            };
-            C = 0;
-            for (int c = 1; c <= 4 && !C; ++c)
-                if (items(c) <= cus) C = c;
-            for (int c = 1; c <= 8 && !C; ++c)
-                if (2 * items(c) <= 3 * cus) C = c;
-            if (!C) C = 8;
-            if (C > lmax && lmax > 0) C = lmax;
-        } else if (C <= 0) {
+        if (C <= 0) {
             int lmax = 0;
             for (int k = lane; k < NR; k += 64)
                 if (!rt.uni[k] && rt.nt[k] > lmax) lmax = rt.nt[k];
             for (int m = 32; m > 0; m >>= 1) lmax = max(lmax, __shfl_xor(lmax, m, 64));
             C = lmax >= 32 ? 8 : (lmax >= 8 ? 4 : (lmax >= 4 ? 2 : 1));
             if (G > 1) {
-                const int64_t tiles_all = wave_sum([](int nt, int, int) { return nt; });
+                const int64_t tiles_all = wave_sum([](int nt, int) { return nt; });
                 int cmax = 1;
                 while (cmax < 8 && (int64_t)cmax * slots < tiles_all * Hkv) cmax <<= 1;
                 if (C > cmax) C = cmax;
             }
             for (; C > 1; C >>= 1) {
-                const int64_t n = wave_sum([C](int nt, int uni, int) { return uni ? 1 : (nt + C - 1) / C; });
+                const int64_t n = wave_sum([C](int nt, int uni) { return uni ? 1 : (nt + C - 1) / C; });
                 if (10 * n * Hkv >= 3LL * slots) break;
             }
             while (C < 8 && lmax > 16 * C) C <<= 1;  // (np_record_order: at most 16 chunks per run while C < 8)
             if (C > 2 && lmax <= 16 * (C - 1)) {       // (np_record_order: fill the CUs of a launch that leaves some empty)
-                const int64_t n0 = wave_sum([C](int nt, int uni, int) { return uni ? 1 : (nt + C - 1) / C; });
-                const int64_t n1 = wave_sum([C](int nt, int uni, int) { return uni ? 1 : (nt + C - 2) / (C - 1); });
+                const int64_t n0 = wave_sum([C](int nt, int uni) { return uni ? 1 : (nt + C - 1) / C; });
+                const int64_t n1 = wave_sum([C](int nt, int uni) { return uni ? 1 : (nt + C - 2) / (C - 1); });
                 if (2 * n0 * Hkv < slots && 2 * n1 * Hkv <= slots) --C;
             }
         }
-        // leaders: long chunks first (np_record_order), then the other work items, then absorbed siblings -- each class in
-        // run order; followers in run order
-        constexpr int SHORT_TAG = 1 << 29, ABS_TAG = 1 << 30;
-        int leadL = 0, leadS = 0, leadA = 0, foll = 0;
+        // leaders: long chunks first (np_record_order), each class in run order; followers in run order
+        int leadL = 0, leadS = 0, foll = 0;
         for (int base = 0; base < NR; base += 64) {
             const int k = base + lane;
             const int nt = k < NR ? rt.nt[k] : 0;
             const int S = k < NR ? (rt.uni[k] ? 1 : (nt + C - 1) / C) : 0;
-            const bool absorbed = k < NR && passes_of(k) == 0;
-            const bool lng = k < NR && !absorbed && !rt.uni[k] && S > 0 && nt / S >= LONG_CHUNK;
-            int aL = lng ? S : 0, aS = (lng || absorbed) ? 0 : S, aA = absorbed ? S : 0, b = nt - S;  // inclusive scans over the lanes
+            const bool lng = k < NR && !rt.uni[k] && S > 0 && nt / S >= LONG_CHUNK;
+            int aL = lng ? S : 0, aS = lng ? 0 : S, b = nt - S;  // inclusive scans over the lanes
             for (int d = 1; d < 64; d <<= 1) {
-                const int uL = __shfl_up(aL, d, 64), uS = __shfl_up(aS, d, 64), uA = __shfl_up(aA, d, 64), ub = __shfl_up(b, d, 64);
+                const int uL = __shfl_up(aL, d, 64), uS = __shfl_up(aS, d, 64), ub = __shfl_up(b, d, 64);
                 if (lane >= d) {
                     aL += uL;
                     aS += uS;
-                    aA += uA;
                     b += ub;
                 }
             }
             if (k < NR) {
-                // (positions inside the second and third class are resolved below, once the class sizes are known)
-                rT0[k] = lng ? leadL + aL - S : (absorbed ? (ABS_TAG | (leadA + aA - S)) : (SHORT_TAG | (leadS + aS - S)));
+                rT0[k] = lng ? leadL + aL - S : -(leadS + aS - S) - 1;  // short runs: position inside their class, resolved below
                 rSp[k] = foll + b - (nt - S);
             }
             leadL += __shfl(aL, 63, 64);
             leadS += __shfl(aS, 63, 64);
-            leadA += __shfl(aA, 63, 64);
             foll += __shfl(b, 63, 64);
         }
-        for (int k = lane; k < NR; k += 64) {
-            const int v = rT0[k];
-            if (v & ABS_TAG) rT0[k] = leadL + leadS + (v & ~ABS_TAG);
-            else if (v & SHORT_TAG) rT0[k] = leadL + (v & ~SHORT_TAG);
-        }
+        for (int k = lane; k < NR; k += 64)
+            if (rT0[k] < 0) rT0[k] = leadL + (-rT0[k] - 1);
         if (lane == 0) {
             sMeta[2] = C;
-            sMeta[3] = leadL + leadS + leadA;
-            hdr[1] = leadL + leadS + leadA;
-            hdr[HDR_PRIMARIES] = leadL + leadS;
+            sMeta[3] = leadL + leadS;
+            hdr[1] = leadL + leadS;
         }
     }
     __syncthreads();
@@ -331,8 +269,6 @@ __device__ inline void record_order_parallel(const UnitList& ul, const RunTable&
             const int first = rt.r0[k], nt = rt.nt[k];
             const int S = rt.uni[k] ? 1 : (nt + C - 1) / C;  // a union group is one chunk
             const int li = rT0[k], fi = NL + rSp[k];
-            const int pn = passes_of(k);
-            const int sib = pn > 1 ? rT0[k + 1] : 0;  // (sibling runs follow their primary; same tile count, so the same S)
             const int q = nt / S, rem = nt - q * S;  // chunk p folds units p, p + S, ...: q + 1 of them for p < rem, else q
             for (int u = lane; u < nt; u += 64) {
                 const int j = u / S, pc = u - j * S;
@@ -341,8 +277,6 @@ __device__ inline void record_order_parallel(const UnitList& ul, const RunTable&
                     ul.perm[li + pc] = first + pc;
                     ul.ch_n[li + pc] = q + (pc < rem ? 1 : 0);
                     ul.ch_fb[li + pc] = fb;
-                    ul.ch_sib[li + pc] = pn > 1 ? sib + pc : 0;
-                    ul.ch_pn[li + pc] = pn | (S << 4);
                 } else {
                     ul.perm[fb + j - 1] = first + u;
                     ul.ch_n[fb + j - 1] = 0;
@@ -416,7 +350,7 @@ __global__ __launch_bounds__(1024) void flatten_units_kernel(const int64_t* bloc
                                                             const int64_t* block_q_offset, int NBc, int G, int cap,
                                                             UnitList ul, int32_t* hdr, int Hkv, int slots, int chunk_c,
                                                             int union_len, int run_cap, int qtab, int par,
-                                                            const int32_t* dims, int32_t* row_q, int rows, int wide) {
+                                                            const int32_t* dims, int32_t* row_q, int rows) {
     constexpr int np = 1;  // records in the tile-parallel order (leaders first); the only stage-1 form
     // NBc = block CAPACITY (sizes the tables); with `dims` (device-side metadata, tree_plan.h) the block count of this
     // step is read from the device, so that one captured launch serves every step of a structural epoch
@@ -483,9 +417,7 @@ __global__ __launch_bounds__(1024) void flatten_units_kernel(const int64_t* bloc
     auto union_len_at = [&](int t) {
         (void)t;
         int ulen = union_len;
-        // (the multi-pass kernel runs one workgroup per CU, so a leaf tile on its own pays ramp and epilogue unhidden: groups of
-        //  four tiles there, with GQA too)
-        if (ulen <= 0) ulen = wide ? 4 : (G > 1 ? 1 : ((int64_t)NB * Hkv < 2048 ? 4 : 3));  // measured, tools/np_sweep.sh / tools/ab.py
+        if (ulen <= 0) ulen = G > 1 ? 1 : ((int64_t)NB * Hkv < 2048 ? 4 : 3);  // measured, tools/np_sweep.sh / tools/ab.py
         return ulen;
     };
     if (np && ucap >= 2)
@@ -509,11 +441,9 @@ __global__ __launch_bounds__(1024) void flatten_units_kernel(const int64_t* bloc
     // record order are then written by all waves (phases 3 and 4) -- one thread emitting them costs ~0.4 us per unit
     // and pass, 75 us per decode step for the north-star tree and 2 ms for a 100k-token prefix under 48 branches.
     // Otherwise (tables beyond the LDS) lane 0 emits as it walks.
-    int* sMeta = sRun + (par ? 6 : 3) * run_cap;  // [8]: units, runs, chunk length, leaders, "written by all waves"
+    int* sMeta = sRun + (par ? 5 : 3) * run_cap;  // [8]: units, runs, chunk length, leaders, "written by all waves"
     int* rT0 = sRun + 3 * run_cap;    // par: first block of the run;      later: the run's first leader record
     int* rSp = sRun + 4 * run_cap;    // par: block stride | pass << 8;   later: the run's first follower record - leaders
-    int* rG = sRun + 5 * run_cap;     // par: position in the run's set of sibling runs | set size << 8 (record_order_parallel)
-    if (par) rt.grp = rG;
     const int lane = threadIdx.x & 63;
     const int par_req = par;
     if (threadIdx.x < 64) {
@@ -532,10 +462,9 @@ __global__ __launch_bounds__(1024) void flatten_units_kernel(const int64_t* bloc
             return NB;
         };
         // units of one run: blocks t0, t0 + st, ... < te, pass ps, aux (0, or union group + 1)
-        // (gpos / gsize: the run is the gpos-th of gsize sibling runs over the same KV tiles -- 0 / 1 = alone)
-        auto emit_run = [&](int t0, int te, int st, int aux, int ps, int gpos, int gsize) {
+        auto emit_run = [&](int t0, int te, int st, int aux, int ps) {
             int n = st == 1 ? te - t0 : (te - t0 + st - 1) / st;
-            if (n > cap - r) n = cap - r, gpos = 0, gsize = 1;  // (a clipped run no longer matches its siblings)
+            if (n > cap - r) n = cap - r;
             if (n <= 0) return;
             const int first = r;
             if (par) {
@@ -545,7 +474,6 @@ __global__ __launch_bounds__(1024) void flatten_units_kernel(const int64_t* bloc
                     rt.uni[rt.n] = aux;
                     rT0[rt.n] = t0;
                     rSp[rt.n] = st | (ps << 8);
-                    rG[rt.n] = gpos | (gsize << 8);
                 }
                 ++rt.n;
             } else {
@@ -580,7 +508,7 @@ __global__ __launch_bounds__(1024) void flatten_units_kernel(const int64_t* bloc
                         ul.grow[j * cap + ng] = j < un ? urow[j] : 0;
                     }
                 }
-                emit_run(ta, ta + glen, 1, ng + 1, 0, 0, 1);
+                emit_run(ta, ta + glen, 1, ng + 1, 0);
                 ++ng;
                 ta += glen;
                 continue;
@@ -598,25 +526,15 @@ __global__ __launch_bounds__(1024) void flatten_units_kernel(const int64_t* bloc
                 }
                 if (P) {
                     const int te = find(ta + P, 1 << (P - 1));
-                    // the P alternating blocks hold the same 128 slots: all their passes are sibling runs -- as long as every
-                    // one of them covers the same number of tiles and the units fit the capacity
-                    int gsize = 0;
-                    bool even = (te - ta) % P == 0;
-                    for (int par_ = 0; par_ < P; ++par_) gsize += sPass[ta + par_];
-                    if (!even || (int64_t)gsize * ((te - ta) / P) > cap - r || gsize > 255) gsize = 0;
-                    int gpos = 0;
                     for (int par_ = 0; par_ < P; ++par_) {
                         const int pp = sPass[ta + par_];
-                        for (int ps = 0; ps < pp; ++ps, ++gpos) emit_run(ta + par_, te, P, 0, ps, gsize ? gpos : 0, gsize ? gsize : 1);
+                        for (int ps = 0; ps < pp; ++ps) emit_run(ta + par_, te, P, 0, ps);
                     }
                     ta = te;
                     continue;
                 }
             }
-            {
-                const bool fits = (int64_t)passes * (tb - ta) <= cap - r;
-                for (int ps = 0; ps < passes; ++ps) emit_run(ta, tb, 1, 0, ps, fits ? ps : 0, fits ? passes : 1);
-            }
+            for (int ps = 0; ps < passes; ++ps) emit_run(ta, tb, 1, 0, ps);
             ta = tb;
         }
         if (lane == 0) {
@@ -663,7 +581,7 @@ __global__ __launch_bounds__(1024) void flatten_units_kernel(const int64_t* bloc
     }
     if (!np) return;
     // Phase 4: record order of the tile-parallel stage 1
-    record_order_parallel(ul, rt, NR, rT0, rSp, sMeta, hdr, Hkv, G, slots, chunk_c, wide);
+    record_order_parallel(ul, rt, NR, rT0, rSp, sMeta, hdr, Hkv, G, slots, chunk_c);
 }
 
 // One workgroup of 128 threads per unit (+ the sentinel): pack its record.
@@ -743,8 +661,6 @@ __global__ __launch_bounds__(128) void flatten_records_kernel(const int64_t* blo
             desc[3] = ul.flags[u] >> 1;
             desc[4] = ul.ch_n[r];
             desc[5] = ul.ch_fb[r];
-            desc[6] = 0;
-            desc[7] = ul.ch_n[r] > 0 ? ul.ch_pn[r] : 0;
         }
         return;
     }
@@ -778,8 +694,6 @@ __global__ __launch_bounds__(128) void flatten_records_kernel(const int64_t* blo
         desc[3] = ul.flags[u] >> 1;  // run id: tiles with equal ids share one query list and may fold
         desc[4] = np ? ul.ch_n[r] : 0;
         desc[5] = np ? ul.ch_fb[r] : 0;
-        desc[6] = ul.ch_n[r] > 0 ? ul.ch_sib[r] : 0;
-        desc[7] = ul.ch_n[r] > 0 ? ul.ch_pn[r] : 0;
     }
 }
 
@@ -794,8 +708,7 @@ __global__ __launch_bounds__(128) void flatten_records_kernel(const int64_t* blo
 __global__ __launch_bounds__(1024) void node_units_kernel(const int64_t* node_kv_len, const int64_t* node_q_len, int NEc, int G,
                                                           int cap, int64_t rows_cap, UnitList ul, int32_t* hdr,
                                                           int32_t* row_q, int Hkv, int slots, int chunk_c, int run_cap,
-                                                          int par, int keep_err, const int32_t* dims, int wide,
-                                                          const int64_t* node_kv, const int64_t* node_kv_offset) {
+                                                          int par, int keep_err, const int32_t* dims) {
     constexpr int np = 1;
     const int NE = dims ? min(dims[1], NEc) : NEc;  // (device-side metadata: this step's entry count, see flatten_units_kernel)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -806,9 +719,7 @@ __global__ __launch_bounds__(1024) void node_units_kernel(const int64_t* node_kv
     int* rProw = sRun + 5 * run_cap;  // par: partial row of the run's first tile
     int* rQl = sRun + 6 * run_cap;    // par: partial rows per tile
     int* rAux = sRun + 7 * run_cap;   // par: 1 = tiles of one entry (aux = tile index), <= 0 = a pack (aux = -entries)
-    int* rG = sRun + 8 * run_cap;     // par: position in the run's set of sibling runs | set size << 8 (record_order_parallel)
-    int* sMeta = sRun + (par ? 9 : 3) * run_cap;  // [8]
-    if (par) rt.grp = rG;
+    int* sMeta = sRun + (par ? 8 : 3) * run_cap;  // [8]
     for (int64_t i = threadIdx.x; i < rows_cap; i += blockDim.x) row_q[i] = -1;
     const int lane = threadIdx.x & 63;
     const int par_req = par;
@@ -818,17 +729,11 @@ __global__ __launch_bounds__(1024) void node_units_kernel(const int64_t* node_kv
             rt.n = 0;
             int r = 0, rowbase = 0;
             int pack_r = -1, pack_k = -1, pack_n = 0, pack_keys = 0, pack_rows = 0;  // open pack: unit, run, entries, slots, virtual rows
-            // open set of sibling runs (wide order): the passes of one entry, and of the entries after it that hold the SAME
-            // slots -- a node with more than 32 queries is one entry per query chunk (tree_cache.py:744-758), slots repeated
-            int set_k = -1, set_n = 0, set_nt = 0, set_len = 0;
-            int64_t set_fs = -1;
-            auto emit_run = [&](int e, int n, int ps, int prow0, int ql, int aux, bool sibling) {
-                if (n > cap - r) n = cap - r, sibling = false;
+            auto emit_run = [&](int e, int n, int ps, int prow0, int ql, int aux) {
+                if (n > cap - r) n = cap - r;
                 if (n <= 0) return;
                 const int first = r;
                 if (par) {
-                    if (!sibling || set_k < 0 || n != set_nt || set_n >= 255) set_k = rt.n, set_n = 0, set_nt = n;
-                    ++set_n;
                     if (lane == 0 && rt.n < rt.cap) {
                         rt.r0[rt.n] = first;
                         rt.nt[rt.n] = n;
@@ -838,7 +743,6 @@ __global__ __launch_bounds__(1024) void node_units_kernel(const int64_t* node_kv
                         rProw[rt.n] = prow0;
                         rQl[rt.n] = ql;
                         rAux[rt.n] = aux;
-                        for (int k2 = set_k; k2 <= rt.n; ++k2) rG[k2] = (k2 - set_k) | (set_n << 8);  // (sets are a few runs long)
                     }
                 } else if (lane == 0) {
                     for (int j = 0; j < n; ++j) {
@@ -863,16 +767,12 @@ __global__ __launch_bounds__(1024) void node_units_kernel(const int64_t* node_kv
               const int mine = base + lane;
               const int vlen = mine < NE ? (int)node_kv_len[mine] : 0;
               const int vql = mine < NE ? (int)node_q_len[mine] : 0;
-              // first slot of the entry: two entries hold the same slots iff they start with the same one (a slot belongs to
-              // one node) and are equally long -- only looked at in the wide order
-              const int vfs = (wide && mine < NE && vlen > 0) ? (int)node_kv[node_kv_offset[mine]] : -1;
               const int lim = min(64, NE - base);
               for (int i = 0; i < lim; ++i) {
                 const int e = base + i;
                 const int len = __builtin_amdgcn_readlane(vlen, i);
                 const int nt = (len + TILE - 1) / TILE;
                 const int ql = __builtin_amdgcn_readlane(vql, i);
-                const int fs = __builtin_amdgcn_readlane(vfs, i);
                 const int npass = (ql * G + MQ - 1) / MQ;
                 if (nt == 1 && npass == 1 && r < cap) {
                     if (pack_r >= 0 && pack_n < MQ && pack_keys + len <= TILE && pack_rows + ql * G <= MQ) {
@@ -889,15 +789,11 @@ __global__ __launch_bounds__(1024) void node_units_kernel(const int64_t* node_kv
                         pack_n = 1;
                         pack_keys = len;
                         pack_rows = ql * G;
-                        emit_run(e, 1, 0, rowbase, 0, 0, false);  // a pack of one is an ordinary unit
-                        set_k = -1;
+                        emit_run(e, 1, 0, rowbase, 0, 0);  // a pack of one is an ordinary unit
                     }
                 } else {
                     pack_r = -1;
-                    const bool same = wide && set_k >= 0 && fs >= 0 && fs == set_fs && len == set_len;
-                    for (int ps = 0; ps < npass; ++ps) emit_run(e, nt, ps, rowbase, ql, 1, same || ps > 0);
-                    set_fs = fs;
-                    set_len = len;
+                    for (int ps = 0; ps < npass; ++ps) emit_run(e, nt, ps, rowbase, ql, 1);
                 }
                 rowbase += nt * ql;
               }
@@ -934,7 +830,7 @@ __global__ __launch_bounds__(1024) void node_units_kernel(const int64_t* node_kv
         }
     }
     if (!np) return;
-    record_order_parallel(ul, rt, NR, rT0, rSp, sMeta, hdr, Hkv, G, slots, chunk_c, wide);
+    record_order_parallel(ul, rt, NR, rT0, rSp, sMeta, hdr, Hkv, G, slots, chunk_c);
 }
 
 __global__ __launch_bounds__(128) void node_records_kernel(const int64_t* node_kv, const int64_t* node_kv_offset,
@@ -973,8 +869,6 @@ __global__ __launch_bounds__(128) void node_records_kernel(const int64_t* node_k
     if (k == 0) {
         desc[4] = np ? ul.ch_n[r] : 0;
         desc[5] = np ? ul.ch_fb[r] : 0;
-        desc[6] = ul.ch_n[r] > 0 ? ul.ch_sib[r] : 0;
-        desc[7] = ul.ch_n[r] > 0 ? ul.ch_pn[r] : 0;
     }
     const int e0 = ul.src[u], aux = ul.aux[u], ps = ul.pass[u], prow = ul.prow[u];
     if (aux < 0) {

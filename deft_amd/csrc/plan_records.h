@@ -16,8 +16,7 @@ typedef short short4v __attribute__((ext_vector_type(4)));
 constexpr int PLAN_BYTES = 2048;
 constexpr int PLAN_ROWOFF = 0;   // int64[128]  byte offset of each slot's row in the pool (pads alias slot 0)
 constexpr int PLAN_MASK = 1024;  // uint32[128] bit v set <=> virtual row v sees the slot (0 for pads)
-constexpr int PLAN_DESC = 1536;  // int32[8]    n_vrows, prow, opens_run, run_id, chunk tiles (0 = follower), first follower record,
-                                 //             first sibling-pass leader (0 = none), passes of this work item (0 = absorbed) | S << 4
+constexpr int PLAN_DESC = 1536;  // int32[8]    n_vrows, prow, opens_run, run_id, chunk tiles (0 = follower), first follower record, -, -
 constexpr int PLAN_QSRC = 1600;  // int32[32]   element offset of row v's Q vector from q + kvh*G*q_stride_head
 constexpr int PLAN_OROW = 1728;  // int32[32]   partial row of row v, relative to kvh*G*rows: g*rows + prow + qi
 
@@ -25,11 +24,9 @@ constexpr int PLAN_OROW = 1728;  // int32[32]   partial row of row v, relative t
 //   hdr[0]  R   records (units) per KV head          hdr[1]  NL  chunk leaders (work items per KV head)
 //   hdr[2]  error flags raised by the plan kernels (bit 1: sequential plan overflow)
 //   hdr[3]  1 = the per-query row lists (qoff / qlist) are valid; 0 = the merge scans row_q itself
-//   hdr[4]  NP  work items of the multi-pass stage 1 (= NL unless the plan was built in the wide order)
 constexpr int PLAN_HDR = 4096;
 constexpr int HDR_ERR = 2;
 constexpr int HDR_QLISTS = 3;
-constexpr int HDR_PRIMARIES = 4;  // leaders that are work items of the multi-pass stage 1 (the first hdr[4] leader records)
 
 // 64 lanes x 16 bytes, global (per-lane address) -> LDS (lds_dst + 16*lane).  M0 is not
 // otherwise used by the kernels (checked in the .s), so it is written, not saved.

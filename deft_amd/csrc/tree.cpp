@@ -471,14 +471,6 @@ int deft_tree_stats(int64_t tree, int64_t stats[4]) {
     return DEFT_OK;
 }
 
-int64_t deft_tree_max_node_queries(int64_t tree) {
-    DEFT_TREE_OR_FAIL(t, tree, "deft_tree_max_node_queries");
-    int64_t best = 0;
-    for (const auto& kvp : t->nodes)
-        if (!kvp.second.kv.empty() && kvp.second.nrefs > best) best = kvp.second.nrefs;
-    return best;
-}
-
 int64_t deft_tree_build_md(int64_t tree, int max_q_len, int block_len, int max_block_len) {
     std::vector<int64_t> node_id, parent_id, kv_offset, kv_slots;
     std::vector<uint8_t> is_leaf;

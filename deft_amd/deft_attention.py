@@ -46,7 +46,7 @@ class _DecodeStep:
 
     def __init__(self, mode: ForwardMode, md, pool, cache_loc: torch.Tensor, q: torch.Tensor, k: torch.Tensor,
                  Hq: int, Hkv: int, D: int) -> None:
-        from .tree_attention import _flatten_plan, _node_plan, multipass_launch
+        from .tree_attention import _flatten_plan, _node_plan
 
         kv0 = pool.kv_data[0]
         if not (q.is_cuda and kv0.is_cuda and q.dtype == torch.float16 and kv0.dtype == torch.float16):
@@ -70,26 +70,23 @@ class _DecodeStep:
         if cache_loc.dtype != torch.int32 or not cache_loc.is_cuda:
             raise TypeError("cache_loc must be an int32 CUDA tensor")
         self.n_new = cache_loc.shape[0]
-        # launch option: the multi-pass stage 1 where some KV tile is read by more than 32 virtual query rows (a structural
-        # property the metadata carries from the native tree); the rope-fused form has no multi-pass kernel
-        self.multipass = multipass_launch(md, Hq, Hkv, D)
         if mode == ForwardMode.TREE_DECODE_FLATTEN:
             mdl = [md.block_q, md.block_q_cnts, md.block_q_offset, md.block_bitmasks, md.block_kv, md.block_lens]
             self.NB, self.P = md.block_q_cnts.shape[0], md.block_q.shape[0]
             self.plan = _flatten_plan(mdl, self.NB, self.P, Hq, Hkv, (self.q_stride, D), self.kv_ss, stream,
-                                      cache_loc=cache_loc, new_stride=self.k_stride, multipass=self.multipass)
+                                      cache_loc=cache_loc, new_stride=self.k_stride)
             self.ws_bytes = lib.deft_flatten_workspace_bytes(self.NB, self.P, self.nq, Hq, Hkv, D)
             self.tail = (self.NB, self.P, self.nq, Hq, Hkv, D, self.scale)
-            self.fn = lib.deft_flatten_decode_append_mp_f16
+            self.fn = lib.deft_flatten_decode_append_f16
             self.fn_rope = lib.deft_flatten_decode_rope_append_f16
         else:
             mdl = [md.node_kv, md.node_kv_offset, md.node_kv_len, md.node_q, md.node_q_offset, md.node_q_len]
             NE, P, total = md.node_kv_offset.shape[0], md.node_q.shape[0], md.node_kv.shape[0]
             self.plan = _node_plan(mdl, NE, P, total, Hq, Hkv, (self.q_stride, D), self.kv_ss, stream,
-                                   cache_loc=cache_loc, new_stride=self.k_stride, multipass=self.multipass)
+                                   cache_loc=cache_loc, new_stride=self.k_stride)
             self.ws_bytes = lib.deft_node_workspace_bytes(NE, P, total, self.nq, Hq, Hkv, D)
             self.tail = (NE, P, total, self.nq, Hq, Hkv, D, self.scale)
-            self.fn = lib.deft_node_decode_append_mp_f16
+            self.fn = lib.deft_node_decode_append_f16
             self.fn_rope = lib.deft_node_decode_rope_append_f16
         for t in mdl:
             if t.dtype != torch.int64 or not t.is_cuda or not t.is_contiguous():
@@ -131,7 +128,7 @@ class _DecodeStep:
                 o.data_ptr(), Hq * D, D, *self.md_ptrs, *self.tail,
                 self.cache_loc_ptr, k.data_ptr(), v.data_ptr(), self.k_stride, self.n_new)
         if rope is None:
-            rc = self.fn(*head, self.multipass, self.plan_ptr, ws.data_ptr(), self.ws_bytes, stream)
+            rc = self.fn(*head, self.plan_ptr, ws.data_ptr(), self.ws_bytes, stream)
         else:
             positions, cache, rotary_dim, neox = rope
             # cos|sin rows of this step's positions, gathered ONCE per step (the 32 layers share them): the kernel reads

@@ -18,8 +18,6 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import numpy as np
 import torch
 
-from ._lib import lib
-
 from .tree_cache import BLOCK_CONFIG, KVCacheUpdater, TreeCache, TreeMetadata, _FIELDS, build_metadata_host
 
 # which arrays are shifted by what when tree t is appended to the batch
@@ -106,8 +104,7 @@ class Forest:
             views[k] = packed[off : off + n]
             off += n
         md = TreeMetadata(query_num=host["query_num"], node_num=host["node_num"], total_kv_len=host["total_kv_len"],
-                          leaf_to_q=host["leaf_to_q"], block_len=block_len,
-                          max_node_queries=max(int(lib.deft_tree_max_node_queries(t._native)) for t in self.trees), **views)
+                          leaf_to_q=host["leaf_to_q"], block_len=block_len, **views)
         md.q_bases = host["q_bases"]  # first query row of every tree
         return md
 

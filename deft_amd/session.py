@@ -86,8 +86,6 @@ class DecodeSession:
         self.cache_loc = self._small[: 4 * nqm].view(torch.int32)
         self.idx = self._small[cb:].view(torch.int64).view(2, nqm)
         self.out = [torch.empty((self.nq, Hq * D), dtype=torch.float16, device=dev) for _ in range(self.layers)]
-        # launch option of the epoch (a structural property: the same value the eager path reads off its TreeMetadata)
-        self.multipass = 1 if (D == 128 and int(lib.deft_tree_max_node_queries(tree._native)) * (Hq // Hkv) > 32) else 0
         order = sorted(tree.leaves)
         self.leaf_handles = [tree.leaves[i] for i in order]
         self.leaf_reqs = np.asarray([tree.leaf_to_req[i] for i in order], dtype=np.int64)
@@ -115,22 +113,22 @@ class DecodeSession:
         v_off = kv0.stride(1) * 2
         if self.mode == "flatten":
             mdl = [self.md_ptrs[k] for k in ("block_q", "block_q_cnts", "block_q_offset", "block_bitmasks", "block_kv", "block_lens")]
-            check(lib.deft_flatten_build_plan_mp(*mdl, self.NB, self.P, dt.scratch.data_ptr(), Hq, Hkv, q0.stride(0), D,
-                                                 kv0.stride(0), self.cache_loc.data_ptr(), self.nq, k0.stride(0),
-                                                 self.plan.data_ptr(), self.plan_bytes, self.multipass, stream), "deft_flatten_build_plan_mp")
-            fn, tail = lib.deft_flatten_decode_append_mp_f16, (self.NB, self.P, self.nq, Hq, Hkv, D, 1.0 / (D ** 0.5))
+            check(lib.deft_flatten_build_plan_dims(*mdl, self.NB, self.P, dt.scratch.data_ptr(), Hq, Hkv, q0.stride(0), D,
+                                                   kv0.stride(0), self.cache_loc.data_ptr(), self.nq, k0.stride(0),
+                                                   self.plan.data_ptr(), self.plan_bytes, stream), "deft_flatten_build_plan_dims")
+            fn, tail = lib.deft_flatten_decode_append_f16, (self.NB, self.P, self.nq, Hq, Hkv, D, 1.0 / (D ** 0.5))
         else:
             mdl = [self.md_ptrs[k] for k in ("node_kv", "node_kv_offset", "node_kv_len", "node_q", "node_q_offset", "node_q_len")]
-            check(lib.deft_node_build_plan_mp(*mdl, self.NE, self.PN, self.TKV, dt.scratch.data_ptr(), Hq, Hkv, q0.stride(0), D,
-                                              kv0.stride(0), self.cache_loc.data_ptr(), self.nq, k0.stride(0),
-                                              self.plan.data_ptr(), self.plan_bytes, self.multipass, stream), "deft_node_build_plan_mp")
-            fn, tail = lib.deft_node_decode_append_mp_f16, (self.NE, self.PN, self.TKV, self.nq, Hq, Hkv, D, 1.0 / (D ** 0.5))
+            check(lib.deft_node_build_plan_dims(*mdl, self.NE, self.PN, self.TKV, dt.scratch.data_ptr(), Hq, Hkv, q0.stride(0), D,
+                                                kv0.stride(0), self.cache_loc.data_ptr(), self.nq, k0.stride(0),
+                                                self.plan.data_ptr(), self.plan_bytes, stream), "deft_node_build_plan_dims")
+            fn, tail = lib.deft_node_decode_append_f16, (self.NE, self.PN, self.TKV, self.nq, Hq, Hkv, D, 1.0 / (D ** 0.5))
         for l in range(self.layers):
             q, k, v = self.qkv(l)
             kptr = self.pool.kv_data[l].data_ptr()
             check(fn(q.data_ptr(), q.stride(0), D, kptr, kptr + v_off, kv0.stride(0), kv0.stride(2), self.out[l].data_ptr(), Hq * D, D,
-                     *mdl, *tail, self.cache_loc.data_ptr(), k.data_ptr(), v.data_ptr(), k.stride(0), self.nq, self.multipass,
-                     self.plan.data_ptr(), self.ws.data_ptr(), self.ws_bytes, stream), "decode layer")
+                     *mdl, *tail, self.cache_loc.data_ptr(), k.data_ptr(), v.data_ptr(), k.stride(0), self.nq, self.plan.data_ptr(),
+                     self.ws.data_ptr(), self.ws_bytes, stream), "decode layer")
 
     # ---- per step ------------------------------------------------------------------------------------------
     def step(self) -> List[torch.Tensor]:

@@ -55,18 +55,8 @@ def _check_qkv(query_states, key_buffer, value_buffer, output):
     return nq, Hq, Hkv, D
 
 
-def multipass_launch(md, Hq: int, Hkv: int, D: int) -> int:
-    """The launch option of the *_mp entry points: 1 when some node that holds tokens has more than 32 / (Hq / Hkv) live
-    leaves below it -- its KV tiles then need more than one 32-row pass, and the multi-pass stage 1 stages each of them once.
-    A STRUCTURAL property of the tree (TreeMetadata.max_node_queries, from the native tree): it changes only when the tree's
-    structure does, so the eager path and a captured session of the same tree decide alike.  Metadata without the hint
-    (arrays handed to the reference-shaped operators directly) takes the single-pass launch."""
-    n = int(getattr(md, "max_node_queries", 0) or 0)
-    return 1 if (D == 128 and Hkv > 0 and n * (Hq // Hkv) > 32) else 0
-
-
 def _flatten_plan(md, NB: int, P: int, Hq: int, Hkv: int, q_strides, kv_stride_slot: int, stream: int,
-                  cache_loc=None, new_stride: int = 0, multipass: int = 0):
+                  cache_loc=None, new_stride: int = 0):
     """Device-side repack of the Flatten metadata, built once per decode step.
 
     The reference builds TreeMetadata once per step and all layers read the same tensor
@@ -77,7 +67,7 @@ def _flatten_plan(md, NB: int, P: int, Hq: int, Hkv: int, q_strides, kv_stride_s
     block_q = md[0]
     versions = [tensor_version(t) for t in md] + ([tensor_version(cache_loc)] if cache_loc is not None else [])
     cacheable = min(versions) >= 0  # inference tensors keep no version counter: their plans are never reused
-    key = (lib.deft_plan_variant(), multipass, kv_stride_slot, NB, P, Hq, Hkv, tuple(q_strides)) + tuple(t.data_ptr() for t in md) + tuple(versions)
+    key = (lib.deft_plan_variant(), kv_stride_slot, NB, P, Hq, Hkv, tuple(q_strides)) + tuple(t.data_ptr() for t in md) + tuple(versions)
     if cache_loc is not None:  # fused-append plans mark this step's new slots
         key += (cache_loc.data_ptr(), cache_loc.shape[0], new_stride)
     cached = getattr(block_q, "_deft_plan", None) if cacheable else None
@@ -85,10 +75,10 @@ def _flatten_plan(md, NB: int, P: int, Hq: int, Hkv: int, q_strides, kv_stride_s
         return cached[1]
     nbytes = lib.deft_flatten_plan_bytes(NB, P, Hq, Hkv)
     plan = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=block_q.device)
-    check(lib.deft_flatten_build_plan_mp(*[t.data_ptr() for t in md], NB, P, None, Hq, Hkv, q_strides[0], q_strides[1],
-                                         kv_stride_slot, cache_loc.data_ptr() if cache_loc is not None else None,
-                                         cache_loc.shape[0] if cache_loc is not None else 0, new_stride,
-                                         plan.data_ptr(), nbytes, multipass, stream), "deft_flatten_build_plan")
+    check(lib.deft_flatten_build_plan(*[t.data_ptr() for t in md], NB, P, Hq, Hkv, q_strides[0], q_strides[1],
+                                      kv_stride_slot, cache_loc.data_ptr() if cache_loc is not None else None,
+                                      cache_loc.shape[0] if cache_loc is not None else 0, new_stride,
+                                      plan.data_ptr(), nbytes, stream), "deft_flatten_build_plan")
     if cacheable:
         try:
             block_q._deft_plan = (key, plan)
@@ -98,12 +88,12 @@ def _flatten_plan(md, NB: int, P: int, Hq: int, Hkv: int, q_strides, kv_stride_s
 
 
 def _node_plan(md, NE: int, P: int, total_kv: int, Hq: int, Hkv: int, q_strides, kv_stride_slot: int, stream: int,
-               cache_loc=None, new_stride: int = 0, multipass: int = 0):
+               cache_loc=None, new_stride: int = 0):
     """Node-mode counterpart of `_flatten_plan`; cached on the KVMapQ_List (node_q) tensor."""
     node_q = md[3]
     versions = [tensor_version(t) for t in md] + ([tensor_version(cache_loc)] if cache_loc is not None else [])
     cacheable = min(versions) >= 0
-    key = (lib.deft_plan_variant(), multipass, kv_stride_slot, NE, P, total_kv, Hq, Hkv, tuple(q_strides)) + tuple(t.data_ptr() for t in md) + tuple(versions)
+    key = (lib.deft_plan_variant(), kv_stride_slot, NE, P, total_kv, Hq, Hkv, tuple(q_strides)) + tuple(t.data_ptr() for t in md) + tuple(versions)
     if cache_loc is not None:  # fused-append plans mark this step's new slots
         key += (cache_loc.data_ptr(), cache_loc.shape[0], new_stride)
     cached = getattr(node_q, "_deft_plan", None) if cacheable else None
@@ -111,10 +101,10 @@ def _node_plan(md, NE: int, P: int, total_kv: int, Hq: int, Hkv: int, q_strides,
         return cached[1]
     nbytes = lib.deft_node_plan_bytes(NE, P, total_kv, Hq, Hkv)
     plan = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=node_q.device)
-    check(lib.deft_node_build_plan_mp(*[t.data_ptr() for t in md], NE, P, total_kv, None, Hq, Hkv, q_strides[0], q_strides[1],
-                                      kv_stride_slot, cache_loc.data_ptr() if cache_loc is not None else None,
-                                      cache_loc.shape[0] if cache_loc is not None else 0, new_stride,
-                                      plan.data_ptr(), nbytes, multipass, stream), "deft_node_build_plan")
+    check(lib.deft_node_build_plan(*[t.data_ptr() for t in md], NE, P, total_kv, Hq, Hkv, q_strides[0], q_strides[1],
+                                   kv_stride_slot, cache_loc.data_ptr() if cache_loc is not None else None,
+                                   cache_loc.shape[0] if cache_loc is not None else 0, new_stride,
+                                   plan.data_ptr(), nbytes, stream), "deft_node_build_plan")
     if cacheable:
         try:
             node_q._deft_plan = (key, plan)

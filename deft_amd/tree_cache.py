@@ -700,10 +700,6 @@ class TreeMetadata:
     block_kv: torch.Tensor
     block_lens: torch.Tensor
 
-    # (not in the reference) most live leaves below any node that holds tokens -- from the native tree; lets the attention
-    # launch pick its multi-pass form (deft_amd.tree_attention.multipass_launch).  0 = unknown: single-pass launches.
-    max_node_queries: int = 0
-
     @classmethod
     def from_tree_cache(
         cls,
@@ -728,7 +724,7 @@ class TreeMetadata:
             if dt is None or dt.device != dev or dt.cfg != (int(max_q_len), int(block_len), int(max_block_len)):
                 dt = tree._device_tree = _DeviceTree(tree, dev, max_q_len, block_len, max_block_len)
             views = dt.build()
-            return cls(block_len=block_len, max_node_queries=int(lib.deft_tree_max_node_queries(tree._native)), **views)
+            return cls(block_len=block_len, **views)
         if dev.type == "cpu":
             host = build_metadata_host(tree, max_q_len, block_len, max_block_len)
             packed = torch.from_numpy(host["_packed"])
@@ -758,8 +754,7 @@ class TreeMetadata:
             off += n
         return cls(
             query_num=host["query_num"], node_num=host["node_num"], total_kv_len=host["total_kv_len"],
-            leaf_to_q=host["leaf_to_q"], block_len=block_len, max_node_queries=int(lib.deft_tree_max_node_queries(tree._native)),
-            **views,
+            leaf_to_q=host["leaf_to_q"], block_len=block_len, **views,
         )
 
 

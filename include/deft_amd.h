@@ -102,20 +102,6 @@ int deft_flatten_build_plan_dims(
     const int32_t* cache_loc /* nullable */, int n_new, int64_t new_stride_tok,
     void* plan, size_t plan_bytes, void* stream);
 
-/* Either of the two with a LAUNCH OPTION (`dims` may be null = host-built metadata).  multipass != 0 orders the plan for the
- * multi-pass stage 1 (deft_amd/csrc/stage1_wide.h): the 32-row passes over one KV tile -- GQA with many branches, a node with
- * more than 32 queries, which the reference emits once per 32-query chunk (tree_cache.py:763-799) -- are folded by ONE
- * workgroup that stages the tile once.  Use it when some node that holds tokens has more than 32 / (Hq / Hkv) live leaves
- * below it (deft_tree_max_node_queries) and pass the same value to deft_flatten_decode_append_mp_f16.  Every plan is valid
- * input to either stage-1 kernel; the option changes speed and the (deterministic) split into partial rows, not the result's
- * tolerance. */
-int deft_flatten_build_plan_mp(
-    const int64_t* block_q, const int64_t* block_q_cnts, const int64_t* block_q_offset,
-    const int64_t* block_bitmasks, const int64_t* block_kv, const int64_t* block_lens,
-    int NB, int P, const int32_t* dims /* nullable */, int Hq, int Hkv, int64_t q_stride_tok, int64_t q_stride_head,
-    int64_t kv_stride_slot, const int32_t* cache_loc /* nullable */, int n_new, int64_t new_stride_tok,
-    void* plan, size_t plan_bytes, int multipass, void* stream);
-
 /*
  * out[nq,Hq,D] = tree attention of q over the flattened-tree blocks.
  *   q, out              fp16, [nq][Hq][D] with the given token/head strides
@@ -155,19 +141,6 @@ int deft_flatten_decode_append_f16(
     const int32_t* cache_loc, const void* k_new, const void* v_new, int64_t new_stride_tok, int n_new,
     const void* plan, void* workspace, size_t workspace_bytes, void* stream);
 
-/* deft_flatten_decode_append_f16 with the launch option of deft_flatten_build_plan_mp: multipass != 0 (head_dim 128; ignored
- * otherwise) runs stage 1 as deft::stage1_wide_kernel -- one workgroup per CU, every tile staged once for up to two 32-row
- * passes, K / V double-buffered per wave.  Bit-identical to the single-pass kernel on the same plan. */
-int deft_flatten_decode_append_mp_f16(
-    const void* q, int64_t q_stride_tok, int64_t q_stride_head,
-    void* k_base, void* v_base, int64_t kv_stride_slot, int64_t kv_stride_head,
-    void* out, int64_t o_stride_tok, int64_t o_stride_head,
-    const int64_t* block_q, const int64_t* block_q_cnts, const int64_t* block_q_offset,
-    const int64_t* block_bitmasks, const int64_t* block_kv, const int64_t* block_lens,
-    int NB, int P, int nq, int Hq, int Hkv, int D, float scale,
-    const int32_t* cache_loc, const void* k_new, const void* v_new, int64_t new_stride_tok, int n_new,
-    int multipass, const void* plan, void* workspace, size_t workspace_bytes, void* stream);
-
 /* ---- DeFT-Node ---------------------------------------------------------- */
 
 size_t deft_node_workspace_bytes(int NE, int P, int64_t total_kv, int nq, int Hq, int Hkv, int D);
@@ -190,15 +163,6 @@ int deft_node_build_plan_dims(
     int64_t q_stride_tok, int64_t q_stride_head, int64_t kv_stride_slot,
     const int32_t* cache_loc /* nullable */, int n_new, int64_t new_stride_tok,
     void* plan, size_t plan_bytes, void* stream);
-
-/* Node-mode counterpart of deft_flatten_build_plan_mp. */
-int deft_node_build_plan_mp(
-    const int64_t* node_kv, const int64_t* node_kv_offset, const int64_t* node_kv_len,
-    const int64_t* node_q, const int64_t* node_q_offset, const int64_t* node_q_len,
-    int NE, int P, int64_t total_kv, const int32_t* dims /* nullable */, int Hq, int Hkv,
-    int64_t q_stride_tok, int64_t q_stride_head, int64_t kv_stride_slot,
-    const int32_t* cache_loc /* nullable */, int n_new, int64_t new_stride_tok,
-    void* plan, size_t plan_bytes, int multipass, void* stream);
 
 /*
  *   node_kv[total_kv]       pool slots of every entry, concatenated
@@ -231,17 +195,6 @@ int deft_node_decode_append_f16(
     int NE, int P, int64_t total_kv, int nq, int Hq, int Hkv, int D, float scale,
     const int32_t* cache_loc, const void* k_new, const void* v_new, int64_t new_stride_tok, int n_new,
     const void* plan, void* workspace, size_t workspace_bytes, void* stream);
-
-/* Node-mode counterpart of deft_flatten_decode_append_mp_f16. */
-int deft_node_decode_append_mp_f16(
-    const void* q, int64_t q_stride_tok, int64_t q_stride_head,
-    void* k_base, void* v_base, int64_t kv_stride_slot, int64_t kv_stride_head,
-    void* out, int64_t o_stride_tok, int64_t o_stride_head,
-    const int64_t* node_kv, const int64_t* node_kv_offset, const int64_t* node_kv_len,
-    const int64_t* node_q, const int64_t* node_q_offset, const int64_t* node_q_len,
-    int NE, int P, int64_t total_kv, int nq, int Hq, int Hkv, int D, float scale,
-    const int32_t* cache_loc, const void* k_new, const void* v_new, int64_t new_stride_tok, int n_new,
-    int multipass, const void* plan, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- rotary embedding + paged append + attention in ONE stage-1 launch ---------------
  *
@@ -426,9 +379,6 @@ int64_t deft_tree_node_refs(int64_t tree, int64_t id, int64_t* out, int64_t cap)
 int64_t deft_tree_path_slots(int64_t tree, int64_t id, int64_t* out, int64_t cap); /* root -> node slots */
 int deft_tree_leaf_ids(int64_t tree, int64_t* out, int cap);                       /* query-row order; returns the count */
 int deft_tree_stats(int64_t tree, int64_t stats[4]); /* nodes, live leaves, total KV slots, structure epoch */
-/* most live leaves below any node that holds tokens: x (Hq / Hkv) > 32 <=> some KV tile needs more than one 32-row pass
- * (the structural test for the multipass launch option; changes only with the structure epoch) */
-int64_t deft_tree_max_node_queries(int64_t tree);
 /* == deft_md_build(<the tree>); handle consumed with deft_md_sizes / _fetch / _free */
 int64_t deft_tree_build_md(int64_t tree, int max_q_len, int block_len, int max_block_len);
 
