@@ -112,12 +112,21 @@ def test_session_after_device_built_metadata_of_the_same_tree(mode):
                 m2 = deft_amd.TreeMetadata.from_tree_cache(ts)
                 assert torch.equal(m2.block_lens, md.block_lens) and torch.equal(m2.node_kv, md.node_kv)
 
+    for tree in (te, ts):  # one ordinary step first (a tree whose leaves hold no token yet cannot be built: the reference's error too)
+        for leaf in tree.leaves.values():
+            leaf.append_token(7)
+        tree.alloc()
     deft_amd.TreeMetadata.from_tree_cache(ts)  # the device copy of ts is current BEFORE the session's first step
     both_steps(6, peek_every=2)
     for tree in (te, ts):
         lv = sorted(tree.leaves.values(), key=lambda n: n.id)
         tree.cut(lv[2])
-        tree.branch(lv[0], 2)
+        for leaf in tree.branch(lv[0], 2):
+            leaf.append_token(9)
+        for leaf in tree.leaves.values():
+            if leaf.id != lv[0].id and len(leaf.kv_indices):
+                leaf.append_token(9)
+        tree.alloc()
     deft_amd.TreeMetadata.from_tree_cache(ts)  # and again between two epochs
     both_steps(5)
     # a second session on the same tree starts from a device copy the first one left current
