@@ -1823,12 +1823,27 @@ int deft_tree_dev_advance(int n_nodes, int nq, int nqw, const int32_t* node_star
     return check_launch("tree advance launch");
 }
 
-int deft_tree_dev_build_md(int n_nodes, int nq, int nqw, const int32_t* node_start, int32_t* node_len, const int32_t* node_cap,
+// Replay the host tree's journal of absorbed changes (deft_tree_journal_take: words[0 .. n)) on the device copy: `ops` is a DEVICE
+// buffer {n, words ...}.  deft_tree_dev_build_md_ops does the same inside its first kernel.
+int deft_tree_dev_apply_ops(int n_nodes, int nq, int nqw, const int32_t* node_start, int32_t* node_len, const int32_t* node_cap,
+                            const uint64_t* refs, const int32_t* leaf_node, int32_t* slots, const int32_t* ops, void* scratch,
+                            void* stream) {
+    if (n_nodes <= 0 || nq < 0 || nqw < 1 || !node_start || !node_len || !node_cap || !refs || !leaf_node || !slots || !ops || !scratch) {
+        set_error("deft_tree_dev_apply_ops: bad arguments (nodes=%d nq=%d)", n_nodes, nq);
+        return DEFT_EINVAL;
+    }
+    TreeDev t{n_nodes, nq, nqw, node_start, node_len, node_cap, reinterpret_cast<const unsigned long long*>(refs), leaf_node, slots};
+    hipLaunchKernelGGL(tree_ops_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), t, ops,
+                       static_cast<int32_t*>(scratch) + TREE_ERR);
+    return check_launch("tree ops launch");
+}
+
+static int tree_dev_build_md_impl(int n_nodes, int nq, int nqw, const int32_t* node_start, int32_t* node_len, const int32_t* node_cap,
                            const uint64_t* refs, const int32_t* leaf_node, int32_t* slots, int max_q_len, int block_len,
                            int max_block_len, int nbp_cap, void* scratch, size_t scratch_bytes, int64_t* node_q, int64_t* node_kv,
                            int64_t* node_q_len, int64_t* node_kv_len, int64_t* node_q_offset, int64_t* node_kv_offset,
                            int64_t* block_q, int64_t* block_q_cnts, int64_t* block_q_offset, int64_t* block_bitmasks,
-                           int64_t* block_kv, int64_t* block_lens, const int32_t* advance_loc, void* stream) {
+                           int64_t* block_kv, int64_t* block_lens, const int32_t* advance_loc, const int32_t* ops, void* stream) {
     if (n_nodes <= 0 || nq < 0 || nqw < 1 || nbp_cap < 0 || !node_start || !node_len || !node_cap || !refs || !leaf_node || !slots ||
         !scratch) {
         set_error("deft_tree_dev_build_md: bad arguments (nodes=%d nq=%d)", n_nodes, nq);
@@ -1865,7 +1880,7 @@ int deft_tree_dev_build_md(int n_nodes, int nq, int nqw, const int32_t* node_sta
     int rc = raise_lds(reinterpret_cast<const void*>(&tree_md_scan_kernel), 156 * 1024, ATTR_TREE, "tree_md_scan");
     if (rc) return rc;
     hipLaunchKernelGGL(tree_md_scan_kernel, dim3(1), dim3(1024), scan_lds, st, t, sc, max_q_len, block_len, max_block_len, nbp_cap,
-                       advance_loc);
+                       advance_loc, ops);
     rc = check_launch("tree scan launch");
     if (rc) return rc;
     if (nbp_cap > 0 && n_block_ptrs) {
@@ -1876,6 +1891,34 @@ int deft_tree_dev_build_md(int n_nodes, int nq, int nqw, const int32_t* node_sta
     if (!n_node_ptrs) return DEFT_OK;
     hipLaunchKernelGGL(tree_md_nodes_kernel, dim3((unsigned)n_nodes, 4), dim3(256), 0, st, t, sc, o, max_q_len, max_block_len);
     return check_launch("tree nodes launch");
+}
+
+int deft_tree_dev_build_md(int n_nodes, int nq, int nqw, const int32_t* node_start, int32_t* node_len, const int32_t* node_cap,
+                           const uint64_t* refs, const int32_t* leaf_node, int32_t* slots, int max_q_len, int block_len,
+                           int max_block_len, int nbp_cap, void* scratch, size_t scratch_bytes, int64_t* node_q, int64_t* node_kv,
+                           int64_t* node_q_len, int64_t* node_kv_len, int64_t* node_q_offset, int64_t* node_kv_offset,
+                           int64_t* block_q, int64_t* block_q_cnts, int64_t* block_q_offset, int64_t* block_bitmasks,
+                           int64_t* block_kv, int64_t* block_lens, const int32_t* advance_loc, void* stream) {
+    return tree_dev_build_md_impl(n_nodes, nq, nqw, node_start, node_len, node_cap, refs, leaf_node, slots, max_q_len, block_len,
+                                  max_block_len, nbp_cap, scratch, scratch_bytes, node_q, node_kv, node_q_len, node_kv_len,
+                                  node_q_offset, node_kv_offset, block_q, block_q_cnts, block_q_offset, block_bitmasks, block_kv,
+                                  block_lens, advance_loc, nullptr, stream);
+}
+
+// deft_tree_dev_build_md with the journal replay (deft_tree_dev_apply_ops) folded into its first kernel, in front of the
+// advance: `ops` = device buffer {n, words ...}, read at run time -- n = 0 on a step without absorbed changes -- so that the
+// launch has the same arguments on every step of an epoch (a captured decode step).
+int deft_tree_dev_build_md_ops(int n_nodes, int nq, int nqw, const int32_t* node_start, int32_t* node_len, const int32_t* node_cap,
+                               const uint64_t* refs, const int32_t* leaf_node, int32_t* slots, int max_q_len, int block_len,
+                               int max_block_len, int nbp_cap, void* scratch, size_t scratch_bytes, int64_t* node_q,
+                               int64_t* node_kv, int64_t* node_q_len, int64_t* node_kv_len, int64_t* node_q_offset,
+                               int64_t* node_kv_offset, int64_t* block_q, int64_t* block_q_cnts, int64_t* block_q_offset,
+                               int64_t* block_bitmasks, int64_t* block_kv, int64_t* block_lens, const int32_t* advance_loc,
+                               const int32_t* ops, void* stream) {
+    return tree_dev_build_md_impl(n_nodes, nq, nqw, node_start, node_len, node_cap, refs, leaf_node, slots, max_q_len, block_len,
+                                  max_block_len, nbp_cap, scratch, scratch_bytes, node_q, node_kv, node_q_len, node_kv_len,
+                                  node_q_offset, node_kv_offset, block_q, block_q_cnts, block_q_offset, block_bitmasks, block_kv,
+                                  block_lens, advance_loc, ops, stream);
 }
 
 }  // extern "C"

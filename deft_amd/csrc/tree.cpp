@@ -25,6 +25,8 @@ namespace deft {
 struct TNode {
     int64_t parent = -1;
     uint8_t leaf = 0;
+    uint8_t grew = 0;   // slots were appended to it while it was NOT a live leaf (speculative decoding squeezes accepted tokens
+                        // into the root every step): the next GPU layout gives it room to grow, like a leaf
     int64_t nrefs = 0;  // live leaves in the subtree (this node included)
     std::vector<int64_t> kv;        // pool slots in the order they were appended
     std::vector<int64_t> children;  // ids, creation order
@@ -42,12 +44,21 @@ struct Layout {
     int64_t total_cap = 0;
 };
 
+// Changes the GPU layout CAN absorb besides a decode step's one-slot-per-leaf: slots appended to a node that has room, and a
+// node's slots dropped.  They are journalled instead of starting a new epoch; whoever owns the device copy replays the journal
+// there (tree_plan.h tree_ops_kernel) before its next use.  Words: {JOP_EXTEND, DFS index, n, n slots ...} | {JOP_RESET, DFS
+// index, 0}.  What the reference's speculative-decoding mock does EVERY step (branch_func_example.py:420-437: merge_nodes of the
+// accepted leaves into the root, reset_node_KV of every leaf) is exactly that.
+enum : int32_t { JOP_EXTEND = 1, JOP_RESET = 2 };
+constexpr size_t JOURNAL_MAX = 1 << 16;  // words; a journal that would outgrow it becomes a structural change
+
 struct Tree {
     std::unordered_map<int64_t, TNode> nodes;
     std::set<int64_t> leaves;  // live leaves, ascending id
     int64_t root = -1;
     int64_t epoch = 1;  // bumped by every change the GPU layout cannot absorb
     Layout lay;
+    std::vector<int32_t> journal;  // absorbed changes the device copy has not seen yet (valid while lay.valid)
     std::mutex mu;
 };
 
@@ -81,6 +92,14 @@ static int64_t parent_of(const Tree* t, int64_t id) {
 static void structure_changed(Tree* t) {
     ++t->epoch;
     t->lay.valid = false;
+    t->journal.clear();  // (the next upload carries everything)
+}
+
+// DFS index of a node in the current layout if the layout is valid and the journal has room for `words` more, else -1
+static int absorbable(Tree* t, int64_t id, size_t words) {
+    if (!t->lay.valid || t->journal.size() + words > JOURNAL_MAX) return -1;
+    auto li = t->lay.index.find(id);
+    return li == t->lay.index.end() ? -1 : li->second;
 }
 
 static void add_refs(Tree* t, int64_t id, int64_t d) {
@@ -120,8 +139,8 @@ static void build_layout(Tree* t, int slack) {
     for (int i = 0; i < n; ++i) {
         const TNode& nd = *node_of(t, L.dfs[i]);  // (dfs_order visited it)
         L.index[L.dfs[i]] = i;
-        // only live leaves grow between structural changes (one slot per decode step)
-        const int64_t room = (int64_t)nd.kv.size() + (nd.leaf ? slack : 0);
+        // live leaves grow between structural changes (one slot per decode step), and nodes that have been appended to before
+        const int64_t room = (int64_t)nd.kv.size() + ((nd.leaf || nd.grew) ? slack : 0);
         L.start[i] = (int32_t)off;
         L.cap[i] = (int32_t)((room + 3) / 4 * 4);
         off += L.cap[i];
@@ -353,7 +372,24 @@ int deft_tree_extend_node(int64_t tree, int64_t id, int n, const int64_t* slots)
         set_error("deft_tree_extend_node: unknown node %lld", (long long)id);
         return DEFT_EINVAL;
     }
-    it->second.kv.insert(it->second.kv.end(), slots, slots + n);
+    TNode& nd = it->second;
+    if (n == 0) return DEFT_OK;
+    for (int i = 0; i < n; ++i)
+        if (slots[i] < 0 || slots[i] > 0x7fffffffLL) {
+            set_error("deft_tree_extend_node: slot %lld out of range", (long long)slots[i]);
+            return DEFT_EINVAL;
+        }
+    const int di = absorbable(t, id, 3 + (size_t)n);
+    const bool fits = di >= 0 && (int64_t)nd.kv.size() + n <= t->lay.cap[di];
+    nd.kv.insert(nd.kv.end(), slots, slots + n);
+    if (!nd.leaf) nd.grew = 1;
+    if (fits) {  // the device copy appends the same slots itself (journal): the epoch stays
+        t->journal.push_back(JOP_EXTEND);
+        t->journal.push_back(di);
+        t->journal.push_back(n);
+        for (int i = 0; i < n; ++i) t->journal.push_back((int32_t)slots[i]);
+        return DEFT_OK;
+    }
     structure_changed(t);
     return DEFT_OK;
 }
@@ -364,6 +400,19 @@ int deft_tree_set_node_kv(int64_t tree, int64_t id, int n, const int64_t* slots)
     if (it == t->nodes.end() || n < 0) {
         set_error("deft_tree_set_node_kv: unknown node %lld", (long long)id);
         return DEFT_EINVAL;
+    }
+    if (n == 0) {  // dropping a node's slots is absorbed by the layout (its room stays)
+        if (it->second.kv.empty()) return DEFT_OK;
+        const int di = absorbable(t, id, 3);
+        it->second.kv.clear();
+        if (di >= 0) {
+            t->journal.push_back(JOP_RESET);
+            t->journal.push_back(di);
+            t->journal.push_back(0);
+            return DEFT_OK;
+        }
+        structure_changed(t);
+        return DEFT_OK;
     }
     it->second.kv.assign(slots, slots + n);
     structure_changed(t);
@@ -386,6 +435,9 @@ int64_t deft_tree_take_nodes_kv(int64_t tree, int n, const int64_t* ids, int64_t
             set_error("deft_tree_take_nodes_kv: unknown node %lld", (long long)ids[i]);
             return DEFT_EINVAL;
         }
+    // absorbed by the layout (every node keeps its room) when all of them are in it and the journal has the space
+    bool absorb = t->lay.valid && t->journal.size() + 3 * (size_t)n <= JOURNAL_MAX;
+    for (int i = 0; i < n && absorb; ++i) absorb = t->lay.index.count(ids[i]) != 0;
     int64_t total = 0;
     for (int i = 0; i < n; ++i) {
         auto& kv = t->nodes.find(ids[i])->second.kv;
@@ -393,10 +445,32 @@ int64_t deft_tree_take_nodes_kv(int64_t tree, int n, const int64_t* ids, int64_t
             if (total < cap) out[total] = s;
             ++total;
         }
+        if (absorb && !kv.empty()) {
+            t->journal.push_back(JOP_RESET);
+            t->journal.push_back(t->lay.index.find(ids[i])->second);
+            t->journal.push_back(0);
+        }
         kv.clear();
     }
-    if (total > 0) structure_changed(t);
+    if (total > 0 && !absorb) structure_changed(t);
     return total;
+}
+
+// The journal of absorbed changes since the last call (or the last upload), oldest first; it is handed over ONCE: the caller
+// replays it on the device copy (deft_tree_dev_apply_ops) before that copy is advanced or read again.  Returns the number of
+// words written; a journal longer than `cap` is not handed over: the call starts a new structural epoch instead (returns -5),
+// whose upload carries everything.
+int64_t deft_tree_journal_take(int64_t tree, int32_t* out, int64_t cap) {
+    DEFT_TREE_OR_FAIL(t, tree, "deft_tree_journal_take");
+    const int64_t n = (int64_t)t->journal.size();
+    if (n == 0) return 0;
+    if (!out || n > cap) {
+        structure_changed(t);
+        return -5;
+    }
+    std::copy(t->journal.begin(), t->journal.end(), out);
+    t->journal.clear();
+    return n;
 }
 
 int64_t deft_tree_node_len(int64_t tree, int64_t id) {
@@ -713,7 +787,8 @@ int deft_tree_md_caps(int64_t tree, int max_q_len, int block_len, int max_block_
     bool fixed = true;  // no leaf so far: this node's first position does not move during the epoch
     for (int i = 0; i < n; ++i) {
         const TNode& nd = *node_of(t, L.dfs[i]);
-        const int64_t len = (int64_t)nd.kv.size() + (nd.leaf ? grow_max : 0), nq = nd.nrefs;
+        const bool grows = nd.leaf || nd.grew;  // (as build_layout gives room)
+        const int64_t len = (int64_t)nd.kv.size() + (grows ? grow_max : 0), nq = nd.nrefs;
         total += len;
         const int64_t qch = (nq + max_q_len - 1) / max_q_len;
         const int64_t step = max_block_len == -1 ? len : max_block_len;
@@ -721,7 +796,7 @@ int deft_tree_md_caps(int64_t tree, int max_q_len, int block_len, int max_block_
         NE += qch * kch;
         n_node_q += nq * kch;
         n_node_kv += len * qch;
-        if (nd.leaf && grow_max > 0) fixed = false;
+        if (grows && grow_max > 0) fixed = false;
         int64_t touched = 0;
         if (len > 0)
             touched = fixed ? (fixed_pos + len - 1) / block_len - fixed_pos / block_len + 1 : (len - 1 + block_len - 1) / block_len + 1;

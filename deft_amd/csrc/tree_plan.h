@@ -73,6 +73,92 @@ __global__ __launch_bounds__(256) void tree_advance_kernel(TreeDev t, const int3
     t.node_len[i] = len + 1;
 }
 
+// Replay of the host tree's journal (tree.cpp: changes a structural epoch absorbs) on the compact tree, by ONE workgroup of
+// 1024 threads: ops[0] = words that follow; {1 = EXTEND, node, n, n slots ...} | {2 = RESET, node, 0}, oldest first.
+//   RESET   the node's slots are dropped (its room stays)
+//   EXTEND  n slots join the node's ascending slot list -- appended when they are all larger than the node's last slot (a pool
+//           hands out ascending slots), otherwise merged in: the new slots are ranked among themselves in LDS, every existing
+//           slot behind the first insertion point moves right by the number of new slots below it (chunks of 1024 from the END, so
+//           nothing is overwritten before it is read), the new ones drop into the gaps.
+// What the reference's speculative-decoding mock does every step -- the accepted leaves' slots squeezed into the root, every
+// leaf's KV released (branch_func_example.py:420-437) -- is one EXTEND and nq RESETs, and the step stays inside its epoch.
+constexpr int TREE_OPS_NEW = 1024;  // slots per EXTEND (longer ones are split by the host)
+__device__ inline void tree_apply_ops(const TreeDev& t, const int32_t* ops, int32_t* err, int* sNew, int* sPos, int* sMeta) {
+    const int tid = threadIdx.x;
+    const int words = ops[0];
+    for (int at = 1; at + 2 < words + 1;) {  // (uniform: every thread reads the same words)
+        const int op = ops[at], node = ops[at + 1], k = ops[at + 2];
+        if (node < 0 || node >= t.n || k < 0 || at + 3 + k > words + 1 || k > TREE_OPS_NEW) {
+            if (tid == 0) atomicOr(err, 4);
+            break;
+        }
+        if (op == 2) {
+            if (tid == 0) t.node_len[node] = 0;
+        } else if (op == 1 && k > 0) {
+            int32_t* s = t.slots + t.node_start[node];
+            const int len = t.node_len[node];
+            if (len + k > t.node_cap[node]) {
+                if (tid == 0) atomicOr(err, 1);
+            } else {
+                // the new slots ascending: rank among themselves (slots are distinct; ties broken by index all the same)
+                if (tid < k) {
+                    const int v = ops[at + 3 + tid];
+                    int r = 0;
+                    for (int j = 0; j < k; ++j) {
+                        const int u = ops[at + 3 + j];
+                        r += (u < v || (u == v && j < tid)) ? 1 : 0;
+                    }
+                    sNew[r] = v;
+                }
+                __syncthreads();
+                // where each new slot goes: (existing slots below it) + (new slots below it)
+                if (tid < k) {
+                    const int v = sNew[tid];
+                    int lo = 0, hi = len;  // first existing slot >= v
+                    while (lo < hi) {
+                        const int mid = (lo + hi) >> 1;
+                        if (s[mid] < v) lo = mid + 1;
+                        else hi = mid;
+                    }
+                    sPos[tid] = lo;
+                    if (tid == 0) sMeta[0] = lo;  // first insertion point: nothing in front of it moves
+                }
+                __syncthreads();
+                const int p = sMeta[0];
+                for (int hi = len; hi > p;) {
+                    const int lo = hi - 1024 > p ? hi - 1024 : p;
+                    const int i = lo + tid;
+                    int x = 0, shift = 0;
+                    if (i < hi) {
+                        x = s[i];
+                        int a = 0, b = k;  // new slots below x
+                        while (a < b) {
+                            const int mid = (a + b) >> 1;
+                            if (sNew[mid] < x) a = mid + 1;
+                            else b = mid;
+                        }
+                        shift = a;
+                    }
+                    __syncthreads();
+                    if (i < hi) s[i + shift] = x;
+                    __syncthreads();
+                    hi = lo;
+                }
+                if (tid < k) s[sPos[tid] + tid] = sNew[tid];
+                if (tid == 0) t.node_len[node] = len + k;
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+        at += 3 + k;
+    }
+}
+
+__global__ __launch_bounds__(1024) void tree_ops_kernel(TreeDev t, const int32_t* ops, int32_t* err) {
+    __shared__ int sNew[TREE_OPS_NEW], sPos[TREE_OPS_NEW], sMeta[4];
+    tree_apply_ops(t, ops, err, sNew, sPos, sMeta);
+}
+
 // exclusive scan of f(i), i < m, into out[0 .. m] by the whole workgroup (1024 threads, chunks of 1024 with a carry)
 template <class F>
 __device__ inline void block_exclusive_scan(int m, F f, int32_t* out, int* sWave, int* sCarry) {
@@ -115,12 +201,17 @@ constexpr int TREE_LDS_NODES = 4096;
 constexpr int TREE_LDS_BLOCKS = 8192;
 
 __global__ __launch_bounds__(1024) void tree_md_scan_kernel(TreeDev t, TreeScratch s, int max_q_len, int block_len,
-                                                            int max_block_len, int nbp_cap, const int32_t* cache_loc) {
+                                                            int max_block_len, int nbp_cap, const int32_t* cache_loc,
+                                                            const int32_t* ops) {
     __shared__ int sWave[16];
     __shared__ int sCarry;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int n = t.n, nqw = t.nqw;
     const int tid = threadIdx.x;
+    if (ops && ops[0] > 0) {  // the journal of this step's absorbed changes first (uniform branch), then the step's new slots
+        __shared__ int sNew[TREE_OPS_NEW], sPos[TREE_OPS_NEW], sMeta[4];
+        tree_apply_ops(t, ops, s.dims + TREE_ERR, sNew, sPos, sMeta);
+    }
     if (cache_loc) {  // advance: one slot per live leaf, kept ascending inside the node
         for (int r = tid; r < t.nq; r += 1024) {
             const int i = t.leaf_node[r];

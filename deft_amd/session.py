@@ -79,16 +79,22 @@ class DecodeSession:
             self.ws_bytes = int(lib.deft_node_workspace_bytes(self.NE, self.PN, self.TKV, self.nq, Hq, Hkv, D))
         self.plan = torch.empty(max(self.plan_bytes, 1), dtype=torch.uint8, device=dev)
         self.ws = torch.empty(max(self.ws_bytes, 1), dtype=torch.uint8, device=dev)
-        # what the host supplies per step, in ONE allocation (one upload): [cache_loc int32[nq] | page-table coordinates int64[2][nq]]
+        # what the host supplies per step, in ONE allocation (one upload):
+        # [cache_loc int32[nq] | page-table coordinates int64[2][nq] | journal of absorbed changes int32 {words, ...}]
         nqm = max(self.nq, 1)
         cb = (4 * nqm + 255) // 256 * 256
-        self._small = torch.zeros(cb + 16 * nqm, dtype=torch.uint8, device=dev)
+        self.ops_cap = 64 + 8 * nqm  # one EXTEND of up to nq slots and a RESET per leaf, with room to spare (a speculative-decoding step)
+        ob = cb + 16 * nqm
+        self._small = torch.zeros(ob + 4 * (self.ops_cap + 1), dtype=torch.uint8, device=dev)
         self.cache_loc = self._small[: 4 * nqm].view(torch.int32)
-        self.idx = self._small[cb:].view(torch.int64).view(2, nqm)
+        self.idx = self._small[cb:ob].view(torch.int64).view(2, nqm)
+        self.ops = self._small[ob:].view(torch.int32)
+        self._ops_off = ob
         self.out = [torch.empty((self.nq, Hq * D), dtype=torch.float16, device=dev) for _ in range(self.layers)]
         order = sorted(tree.leaves)
         self.leaf_handles = [tree.leaves[i] for i in order]
         self.leaf_reqs = np.asarray([tree.leaf_to_req[i] for i in order], dtype=np.int64)
+        self._journal = np.zeros(self.ops_cap, dtype=np.int32)
         self.graph, self.graph_epoch = None, dt.epoch
         return uploaded
 
@@ -103,10 +109,11 @@ class DecodeSession:
         # (the append of this step's slots to the device tree rides in the first metadata kernel)
         # (only the six arrays this mode's operator reads are written: the kernel of the other group is not launched)
         wanted = _FIELDS[6:] if self.mode == "flatten" else _FIELDS[:6]
-        check(lib.deft_tree_dev_build_md(*dt._tree_args(), mq, bl, mbl, dt.nbp_cap, dt.scratch.data_ptr(), dt.scratch_bytes,
-                                         *[self.md_ptrs[k] if k in wanted else None for k in _FIELDS],
-                                         self.cache_loc.data_ptr() if advance else None, stream),
-              "deft_tree_dev_build_md")
+        # (first the journal of changes the epoch absorbed since the last step -- {0} when there are none --, then the advance)
+        check(lib.deft_tree_dev_build_md_ops(*dt._tree_args(), mq, bl, mbl, dt.nbp_cap, dt.scratch.data_ptr(), dt.scratch_bytes,
+                                             *[self.md_ptrs[k] if k in wanted else None for k in _FIELDS],
+                                             self.cache_loc.data_ptr() if advance else None, self.ops.data_ptr(), stream),
+              "deft_tree_dev_build_md_ops")
         Hq, Hkv, D = self.Hq, self.Hkv, self.D
         q0, k0, _ = self.qkv(0)
         kv0 = self.pool.kv_data[0]
@@ -139,15 +146,28 @@ class DecodeSession:
         assert loc is not None
         loc64 = loc.astype(np.int64)
         check(lib.deft_tree_alloc_step(tree._native, n, _ptr(loc64)), "deft_tree_alloc_step")
+        # changes the epoch absorbed since the last step (merge_nodes into a node with room, reset_node_KV): the journal rides in
+        # this step's upload and is replayed by the step's first kernel.  One that does not fit starts a new epoch instead.
+        jn = 0
+        if tree._epoch() == self.graph_epoch:
+            jn = int(lib.deft_tree_journal_take(tree._native, _ptr(self._journal), self.ops_cap))
+            if jn < 0 and jn != -5:
+                check(jn, "deft_tree_journal_take")
+            jn = max(jn, 0)
         if tree._epoch() != self.graph_epoch:
             # a new structural epoch (branch / cut / merge since the last step, or a leaf outgrew its room): an upload made
             # now already contains this step's slots, so this step runs eagerly without the advance; a device copy that was
             # current BEFORE this step's alloc_step (and stayed in its epoch) appends them itself.  The next step captures.
             uploaded = self._epoch_setup()
-            self._write_staging(loc)
+            jn = 0
+            if not uploaded:  # (a device copy that stays may still owe the journal)
+                jn = max(int(lib.deft_tree_journal_take(tree._native, _ptr(self._journal), self.ops_cap)), 0)
+                if tree._epoch() != self.graph_epoch:  # too long: that call started another epoch
+                    uploaded, jn = self._epoch_setup(), 0
+            self._write_staging(loc, jn)
             self._launch_step(advance=not uploaded)
             return self.out
-        self._write_staging(loc)
+        self._write_staging(loc, jn)
         if not self.use_graph:
             self._launch_step()
             return self.out
@@ -156,7 +176,7 @@ class DecodeSession:
         self.graph.replay()
         return self.out
 
-    def _write_staging(self, loc: np.ndarray) -> None:
+    def _write_staging(self, loc: np.ndarray, journal_words: int = 0) -> None:
         """This step's slot numbers and page-table coordinates: pinned staging -> the fixed device tensors the graph reads, in
         one copy.  Four pinned buffers in rotation, each guarded by the event of its last upload (a pageable source would make
         the copy wait for the stream to drain -- the host would run in lock-step with the GPU)."""
@@ -172,9 +192,13 @@ class DecodeSession:
         h = ent[0].numpy()
         nqm = max(n, 1)
         h[: 4 * n].view(np.int32)[:] = loc
-        idx_h = h[nb - 16 * nqm :].view(np.int64).reshape(2, nqm)
+        idx_h = h[self._ops_off - 16 * nqm : self._ops_off].view(np.int64).reshape(2, nqm)
         idx_h[0, :n] = self.leaf_reqs
         idx_h[1, :n] = [lf.positions[-1] for lf in self.leaf_handles]
+        ops_h = h[self._ops_off :].view(np.int32)
+        ops_h[0] = journal_words
+        if journal_words:
+            ops_h[1 : 1 + journal_words] = self._journal[:journal_words]
         self._small.copy_(ent[0], non_blocking=True)
         ent[1] = torch.cuda.Event()
         ent[1].record(torch.cuda.current_stream(self.device))

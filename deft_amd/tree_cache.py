@@ -383,6 +383,7 @@ class TreeCache:
             idx = torch.from_numpy(np.asarray([[self.leaf_to_req[i] for i in order],
                                                [self.leaves[i].positions[-1] for i in order]], dtype=np.int64)).to(table.device)
         if synced and dev.epoch == self._epoch():
+            dev.apply_journal()  # (absorbed changes since the last step -- merge_nodes / reset_node_KV -- come first)
             dev.advance(cache_loc)  # the device copy of the tree appends the same slots itself
         table[idx[0], idx[1]] = cache_loc.to(table.device)  # one batched page-table write
         return KVCacheUpdater(True, self.token_to_kv_pool, cache_loc, None, False)
@@ -633,11 +634,33 @@ class _DeviceTree:
 
     def sync(self) -> bool:
         """Bring the device copy to the tree's structural epoch; True iff an upload happened (the uploaded image holds
-        every slot the native tree holds NOW; a copy that was already current holds what it held before)."""
+        every slot the native tree holds NOW; a copy that was already current holds what it held before).  Changes the epoch
+        absorbed -- slots appended to a node with room, a node's slots dropped: the native tree's journal -- are replayed on a
+        copy that stays."""
         if self.epoch != self.tree._epoch():
             self._upload()
             return True
+        self.apply_journal()
         return False
+
+    def apply_journal(self) -> int:
+        """Hand the native tree's journal of absorbed changes to the device copy (eager: one small upload + one kernel); returns
+        the words replayed.  A captured session does the same inside its step graph (deft_tree_dev_build_md_ops)."""
+        cap = 64 + 8 * max(self.nq, 1) + 4 * self.n
+        buf = np.zeros(cap + 1, dtype=np.int32)
+        nw = int(lib.deft_tree_journal_take(self.tree._native, _ptr(buf[1:]), cap))
+        if nw == -5:  # too long for one replay: the call started a new epoch
+            self._upload()
+            return 0
+        if nw < 0:
+            check(nw, "deft_tree_journal_take")
+        if nw == 0:
+            return 0
+        buf[0] = nw
+        ops = torch.from_numpy(buf[: nw + 1]).to(self.device)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        check(lib.deft_tree_dev_apply_ops(*self._tree_args(), ops.data_ptr(), self.scratch.data_ptr(), stream), "deft_tree_dev_apply_ops")
+        return nw
 
     def _tree_args(self):
         return (self.n, self.nq, self.nqw, self.p_start, self.p_len, self.p_cap, self.p_refs, self.p_leaf, self.p_slots)

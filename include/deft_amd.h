@@ -414,6 +414,28 @@ int deft_tree_dev_build_md(int n_nodes, int nq, int nqw, const int32_t* node_sta
                            int64_t* block_q, int64_t* block_q_cnts, int64_t* block_q_offset, int64_t* block_bitmasks,
                            int64_t* block_kv, int64_t* block_lens, const int32_t* advance_loc /* nullable */, void* stream);
 
+/* Changes a structural epoch ABSORBS besides a decode step's one slot per leaf: slots appended to a node that has room in the
+ * layout (deft_tree_extend_node) and a node's slots dropped (deft_tree_take_nodes_kv, deft_tree_set_node_kv(n = 0)) -- what the
+ * reference's speculative-decoding mock does every step (branch_func_example.py:420-437: merge_nodes of the accepted leaves into
+ * the root, reset_node_KV of every leaf).  The host tree journals them instead of bumping the epoch:
+ *   deft_tree_journal_take   hands the journal over ONCE (int32 words, oldest first: {1 = EXTEND, DFS index, n, n slots} |
+ *                            {2 = RESET, DFS index, 0}); returns the words written, 0 = none, -5 = longer than `cap` (the call has
+ *                            then started a new epoch, whose upload carries everything)
+ *   deft_tree_dev_apply_ops  replays it on the device copy: `ops` = DEVICE buffer {words, journal ...}
+ *   deft_tree_dev_build_md_ops  = deft_tree_dev_build_md with that replay folded into its first kernel (in front of the advance),
+ *                            the word count read at run time: identical arguments on every step of an epoch (captured decode steps) */
+int64_t deft_tree_journal_take(int64_t tree, int32_t* out, int64_t cap);
+int deft_tree_dev_apply_ops(int n_nodes, int nq, int nqw, const int32_t* node_start, int32_t* node_len, const int32_t* node_cap,
+                            const uint64_t* refs, const int32_t* leaf_node, int32_t* slots, const int32_t* ops, void* scratch,
+                            void* stream);
+int deft_tree_dev_build_md_ops(int n_nodes, int nq, int nqw, const int32_t* node_start, int32_t* node_len, const int32_t* node_cap,
+                               const uint64_t* refs, const int32_t* leaf_node, int32_t* slots, int max_q_len, int block_len,
+                               int max_block_len, int nbp_cap, void* scratch, size_t scratch_bytes, int64_t* node_q,
+                               int64_t* node_kv, int64_t* node_q_len, int64_t* node_kv_len, int64_t* node_q_offset,
+                               int64_t* node_kv_offset, int64_t* block_q, int64_t* block_q_cnts, int64_t* block_q_offset,
+                               int64_t* block_bitmasks, int64_t* block_kv, int64_t* block_lens,
+                               const int32_t* advance_loc /* nullable */, const int32_t* ops /* nullable */, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

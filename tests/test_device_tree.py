@@ -139,3 +139,45 @@ def test_speculative_decoding_mock_on_the_device_tree(golden):
     torch.cuda.synchronize()
     assert max_abs(o.cpu().numpy(), golden(name)["o_flatten_4_4_128"]) < 1e-3
     assert max_abs(o.cpu().numpy(), oa.sequential_truth(q_np, kv_np, leaf_paths(oracle_tree(name)))) < 5e-4
+
+
+def test_speculative_decoding_steps_stay_in_one_epoch():
+    """The reference's speculative-decoding mock (branch_func_example.py:420-437) EVERY step: the accepted leaves' slots move into
+    the root (merge_nodes), every leaf's KV is released (reset_node_KV), then alloc() gives every leaf a slot -- which the pool
+    hands out LOWER than the root's newest slots, so the device copy has to merge the root's new slots in, not append them.
+    After the first such step (the root is laid out with room from then on) no step uploads anything, and the device-built
+    metadata equals the host builder's at every step."""
+    Hkv, D = 2, 128
+    req = deft_amd.ReqToTokenPool(128, 8192, device="cuda")
+    pool = deft_amd.TokenToKVPool(8192, torch.float16, Hkv, D, 1, device="cuda")
+    tree = deft_amd.TreeCache(torch.float16, Hkv, D, 1, req, pool, None, True, False)
+    tree.init_prompt(torch.arange(1, 1017, dtype=torch.int32))
+    leaves = tree.branch(tree.root, 64)
+    uploads = 0
+    orig = tc._DeviceTree._upload
+
+    def counting(self):
+        nonlocal uploads
+        uploads += 1
+        return orig(self)
+
+    tc._DeviceTree._upload = counting
+    rng = np.random.default_rng(5)
+    try:
+        for step in range(60):
+            for leaf in leaves:
+                leaf.append_token(7)
+            tree.alloc()
+            dev, host = _both(tree)
+            _assert_same(dev, host)
+            assert tree._device_tree.dims()[9] == 0
+            accept = int(rng.integers(1, 5))
+            before = len(tree.root.kv_indices)
+            order = rng.permutation(64)[:accept] if step % 3 == 2 else range(accept)  # (any leaves: the merge is not only of the newest slots)
+            for i in order:
+                tree.merge_nodes(tree.root, leaves[int(i)], pruneB_flag=False)
+            tree.reset_nodes_KV(leaves, len(tree.root.kv_indices) - before)
+        assert uploads == 2  # the first build, and the first merge into a root that had no room yet
+        assert len(tree.root.kv_indices) > 1016 + 60
+    finally:
+        tc._DeviceTree._upload = orig

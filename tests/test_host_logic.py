@@ -327,3 +327,62 @@ def test_device_path_sizes_reject_what_the_host_builder_rejects():
     check(lib.deft_tree_layout(tree._native, 256, _ptr(sizes)), "layout")
     check(lib.deft_tree_md_sizes(tree._native, 32, 128, -1, 0, _ptr(out)), "sizes")
     assert out[0] == 3 and out[2] == 5 + 3
+
+
+def test_absorbed_changes_are_journalled_not_new_epochs():
+    """merge_nodes into a node that has room in the GPU layout and reset_node(s)_KV keep the structural epoch: the native tree
+    journals them for the device copy (the reference's speculative-decoding mock does both every step,
+    branch_func_example.py:420-437).  The first merge into the root has no room yet -- only leaves are laid out with room -- and
+    starts an epoch; the root is remembered as growing and laid out with room from then on."""
+    from deft_amd._lib import check, lib
+    from deft_amd.tree_cache import _ptr
+
+    tree = _small_tree(prefix=8, size=256)  # (a node's room is rounded up to four slots: 8 leaves none)
+    leaves = tree.branch(tree.root, 4)
+
+    def step():
+        for lf in tree.leaves.values():
+            lf.append_token(5)
+        return tree.alloc().cache_loc.tolist()
+
+    def layout():
+        sizes = np.zeros(5, dtype=np.int64)
+        check(lib.deft_tree_layout(tree._native, 256, _ptr(sizes)), "layout")
+        return int(sizes[4])
+
+    def spec_step(accept):
+        before = len(tree.root.kv_indices)
+        for lf in leaves[:accept]:
+            tree.merge_nodes(tree.root, lf, pruneB_flag=False)
+        tree.reset_nodes_KV(leaves, len(tree.root.kv_indices) - before)
+
+    step()
+    e0 = layout()
+    buf = np.zeros(256, dtype=np.int32)
+    spec_step(2)  # root without room: a structural change
+    assert tree._epoch() > e0 and lib.deft_tree_journal_take(tree._native, _ptr(buf), 256) == 0
+    slots = step()
+    e1 = layout()  # (what an upload does) -- the root now has room
+    root_before = tree.root.kv_indices.tolist()
+    spec_step(3)
+    assert tree._epoch() == e1  # absorbed
+    assert tree.root.kv_indices.tolist() == root_before + slots[:3]
+    assert all(len(lf.kv_indices) == 0 for lf in leaves)
+    n = int(lib.deft_tree_journal_take(tree._native, _ptr(buf), 256))
+    words = buf[:n].tolist()
+    # three EXTENDs of one slot each into the root (DFS index 0), then a RESET per leaf (DFS indices 1..4)
+    assert words[:12] == [1, 0, 1, slots[0], 1, 0, 1, slots[1], 1, 0, 1, slots[2]]
+    assert words[12:] == [2, 1, 0, 2, 2, 0, 2, 3, 0, 2, 4, 0]
+    assert lib.deft_tree_journal_take(tree._native, _ptr(buf), 256) == 0  # handed over once
+    step()
+    assert tree._epoch() == e1  # a decode step still fits
+    # the host builder sees the same tree (root grown, leaves one token each)
+    md = deft_amd.TreeMetadata.from_tree_cache(tree)
+    assert md.total_kv_len == len(tree.root.kv_indices) + 4
+    # a journal that does not fit the caller's buffer becomes a structural change
+    spec_step(1)
+    assert lib.deft_tree_journal_take(tree._native, _ptr(buf), 4) == -5 and tree._epoch() > e1
+    # pool refcounts: accepted slots are held once (by the root), released leaf slots are free again
+    held = sorted(s for nd in tree.nodes.values() for s in nd.kv_indices)
+    assert sorted(np.nonzero(tree.token_to_kv_pool.mem_state)[0].tolist()) == held
+    assert set(np.asarray(tree.token_to_kv_pool.mem_state)[held].tolist()) == {1}

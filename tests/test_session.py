@@ -133,3 +133,45 @@ def test_session_after_device_built_metadata_of_the_same_tree(mode):
     sess2 = deft_amd.DecodeSession(ts, Hq, Hkv, D, layers, lambda l: (q[l, : nq_now[0]], k[l, : nq_now[0]], v[l, : nq_now[0]]), mode=mode)
     sess = sess2
     both_steps(4)
+
+
+@pytest.mark.parametrize("mode", ["flatten", "node"])
+def test_session_speculative_decoding_steps_replay_one_graph(mode):
+    """The captured loop through speculative-decoding steps (merge accepted leaves into the root, reset every leaf: the journal
+    of absorbed changes rides in the step's upload and is replayed by the step's first kernel): bit-identical to the eager path,
+    and the graph is captured once per epoch -- not once per step."""
+    Hq, Hkv, D, layers, prefix, width = 8, 2, 128, 2, 500, 40
+    g = torch.Generator(device="cuda").manual_seed(17)
+    kv_init = torch.randn((layers, 4096, 2, Hkv, D), dtype=torch.float16, device="cuda", generator=g)
+    (te, pe), (ts, ps) = [_mk(Hkv, D, layers, prefix, width, 4096) for _ in range(2)]
+    for p in (pe, ps):
+        p._storage.copy_(kv_init)
+    q = torch.randn((layers, width, Hq * D), dtype=torch.float16, device="cuda", generator=g)
+    k = torch.randn((layers, width, Hkv * D), dtype=torch.float16, device="cuda", generator=g)
+    v = torch.randn((layers, width, Hkv * D), dtype=torch.float16, device="cuda", generator=g)
+    sess = deft_amd.DecodeSession(ts, Hq, Hkv, D, layers, lambda l: (q[l], k[l], v[l]), mode=mode)
+    attn = [deft_amd.DeFTAttention(Hq, D, D ** -0.5, Hkv, l) for l in range(layers)]
+    fmode = deft_amd.forward_mode_from_cli(mode)
+    rng = np.random.default_rng(3)
+    for step in range(40):
+        for tree in (te, ts):
+            for leaf in tree.leaves.values():
+                leaf.append_token(7)
+        upd = te.alloc()
+        md = deft_amd.TreeMetadata.from_tree_cache(te)
+        deft_amd.register_tree_metadata(md)
+        ref = [attn[l](q[l], k[l], v[l], deft_amd.InputMetadata(fmode, upd, pe)) for l in range(layers)]
+        out = sess.step()
+        torch.cuda.synchronize()
+        for l in range(layers):
+            assert torch.equal(out[l], ref[l]), (step, l)
+        assert torch.equal(pe._storage, ps._storage)
+        accept = int(rng.integers(1, 5))
+        for tree in (te, ts):
+            lv = sorted(tree.leaves.values(), key=lambda n: n.id)
+            before = len(tree.root.kv_indices)
+            for lf in lv[:accept]:
+                tree.merge_nodes(tree.root, lf, pruneB_flag=False)
+            tree.reset_nodes_KV(lv, len(tree.root.kv_indices) - before)
+    # epochs: the first step; the first merge into a root without room.  Everything after replays the second epoch's graph.
+    assert sess.captures <= 2, sess.captures
