@@ -178,7 +178,11 @@ class TemplateReplay:
     layers would call it (llama2.py:108-113)."""
 
     def __init__(self, num_heads: int, num_kv_heads: int, head_dim: int, layers: int, mode: str = "flatten",
-                 device: str = "cuda", attention: bool = True, seed: int = 0, vocab: int = 4096) -> None:
+                 device: str = "cuda", attention: bool = True, seed: int = 0, vocab: int = 4096, session: Optional[bool] = None) -> None:
+        """`session`: drive the attention path through `deft_amd.DecodeSession` -- the whole decode step (tree advance,
+        TreeMetadata, plan, every layer's append + attention) as ONE captured hipGraph per structural epoch of the tree -- instead
+        of the reference-shaped eager calls (`tree.alloc()`, `TreeMetadata.from_tree_cache`, `DeFTAttention.forward` per layer).
+        None = wherever a session exists (DeFT-Flatten / DeFT-Node, head_dim 128, attention on)."""
         self.Hq, self.Hkv, self.D, self.layers = num_heads, num_kv_heads, head_dim, layers
         self.mode = mode
         self.forward_mode: ForwardMode = forward_mode_from_cli(mode)
@@ -186,6 +190,10 @@ class TemplateReplay:
         self.attention = attention
         self.vocab = vocab
         self.rng = np.random.default_rng(seed)
+        can = attention and mode in ("flatten", "node") and head_dim == 128
+        self.session = can if session is None else (bool(session) and can)
+        # test hook: called after every step's attention with (tree, layer-0 q rows [nq, Hq*D], layer-0 output [nq, Hq*D])
+        self.step_hook: Optional[Callable[[TreeCache, torch.Tensor, torch.Tensor], None]] = None
         if attention:
             from .deft_attention import DeFTAttention
 
@@ -226,6 +234,16 @@ class TemplateReplay:
             q_all = torch.randn((self.layers, max_rows, self.Hq * self.D), dtype=torch.float16, device=dev, generator=g)
             k_all = torch.randn((self.layers, max_rows, self.Hkv * self.D), dtype=torch.float16, device=dev, generator=g)
             v_all = torch.randn((self.layers, max_rows, self.Hkv * self.D), dtype=torch.float16, device=dev, generator=g)
+        sess = None
+        nq_now = [1]
+        if self.session:
+            from ._lib import lib
+            from .session import DecodeSession
+            from .tree_cache import _ptr
+
+            sess = DecodeSession(tree, self.Hq, self.Hkv, self.D, self.layers,
+                                 lambda l: (q_all[l, : nq_now[0]], k_all[l, : nq_now[0]], v_all[l, : nq_now[0]]), mode=self.mode)
+            sizes = np.zeros(9, dtype=np.int64)
         t_wall = time.perf_counter()
         tree.init_prompt(torch.arange(1, prompt_len + 1, dtype=torch.int32))
         logits = self.rng.random((1, self.vocab), dtype=np.float32)
@@ -241,6 +259,45 @@ class TemplateReplay:
                 break
             assert nq <= max_rows, f"{nq} live leaves exceed max_rows={max_rows}"
             tree.leaf_to_q = {leaf.id: i for i, leaf in enumerate(leaves)}
+            if sess is not None:
+                # ---- the captured step: slots from the host allocator, everything else on the GPU ----------------------------
+                nq_now[0] = nq
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                if pipelined and first_event is None:
+                    first_event = e0
+                outs = sess.step()
+                e1.record()
+                last_event = e1
+                if self.step_hook is not None:
+                    self.step_hook(tree, q_all[0, :nq], outs[0][:nq])
+                t_md = (time.perf_counter() - t0) * 1e3  # (host time of the whole step call: allocator, staging, graph launch)
+                t_attn = 0.0
+                if not pipelined:
+                    e1.synchronize()
+                    t_attn = e0.elapsed_time(e1)
+                # sizes for the reference's IO counters, from node lengths on the host (no device read)
+                lib.deft_tree_md_sizes(tree._native, 32, 128, -1, 0, _ptr(sizes))
+                kv_tokens, node_kv_n = int(sizes[2]), int(sizes[4])
+                t1 = time.perf_counter()
+                logits = self.rng.random((nq, self.vocab), dtype=np.float32)
+                stop = branch(tree, it, max_gen_len, logits, template)
+                t_br = (time.perf_counter() - t1) * 1e3
+                rep.per_step.append({"iter": it, "nq": nq, "kv_tokens": kv_tokens, "attention_ms": t_attn,
+                                     "metadata_ms": t_md, "branch_ms": t_br})
+                if self.forward_mode == ForwardMode.TREE_DECODE_FLATTEN:
+                    io_len = kv_tokens
+                    rep.mask_io_bytes += io_len * 8 * self.layers
+                else:
+                    io_len = node_kv_n
+                rep.kv_io_bytes += io_len * self.Hq * self.D * 4 * self.layers
+                rep.steps += 1
+                rep.decoded_rows += nq
+                rep.attention_ms += t_attn
+                rep.metadata_ms += t_md
+                rep.branch_ms += t_br
+                it += 1
+                continue
             updater = tree.alloc()
             md = None
             if self.forward_mode != ForwardMode.DECODE:
@@ -259,7 +316,9 @@ class TemplateReplay:
                 if pipelined and first_event is None:
                     first_event = e0
                 for l in range(self.layers):
-                    self.attn[l](q_all[l, :nq], k_all[l, :nq], v_all[l, :nq], meta)
+                    o_l = self.attn[l](q_all[l, :nq], k_all[l, :nq], v_all[l, :nq], meta)
+                    if l == 0 and self.step_hook is not None:
+                        self.step_hook(tree, q_all[0, :nq], o_l)
                 e1.record()
                 last_event = e1
                 if not pipelined:
@@ -293,4 +352,5 @@ class TemplateReplay:
         rep.wall_ms = (time.perf_counter() - t_wall) * 1e3
         rep.generated_tokens = tree.get_tree_token_number() - prompt_len
         self.tree, self.pool, self.req = tree, pool, req  # left for inspection by tests
+        self.graph_captures = sess.captures if sess is not None else None
         return rep

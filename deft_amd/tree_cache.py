@@ -151,6 +151,59 @@ class _Slots(MutableSequence):
         return repr(self._get().tolist())
 
 
+class _ShiftedPositions(MutableSequence):
+    """`node.positions` after `reset_nodes_KV`: the reference shifts every position of every leaf by the accepted length at every
+    speculative-decoding step (`[pos + diff for pos in node.positions]`, tree_cache.py:332-336) -- lists that grow by a token per
+    step, so the loop costs O(steps x leaves) per step.  Same values, the shift kept as ONE offset."""
+
+    __slots__ = ("_base", "_off")
+
+    def __init__(self, values, offset: int = 0) -> None:
+        self._base, self._off = list(values), int(offset)
+
+    def shift(self, d: int) -> None:
+        self._off += int(d)
+
+    def __len__(self) -> int:
+        return len(self._base)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [v + self._off for v in self._base[i]]
+        return self._base[i] + self._off
+
+    def __setitem__(self, i, value) -> None:
+        if isinstance(i, slice):
+            self._base[i] = [int(v) - self._off for v in value]
+        else:
+            self._base[i] = int(value) - self._off
+
+    def __delitem__(self, i) -> None:
+        del self._base[i]
+
+    def insert(self, i: int, value) -> None:
+        self._base.insert(i, int(value) - self._off)
+
+    def append(self, value) -> None:
+        self._base.append(int(value) - self._off)
+
+    def __iter__(self):
+        off = self._off
+        return (v + off for v in self._base)
+
+    def __eq__(self, other) -> bool:
+        try:
+            return list(self) == list(other)
+        except TypeError:
+            return NotImplemented
+
+    def __add__(self, other):
+        return list(self) + list(other)
+
+    def __repr__(self) -> str:
+        return repr(list(self))
+
+
 class TreeNode:
     """tree_cache.py:94-130: a handle.  Token ids / positions live here; the slots and the leaf set are read from
     the tree the node belongs to."""
@@ -426,7 +479,10 @@ class TreeCache:
         assert total <= cap, "slot lists longer than the tree"
         for n in nodes:
             n.position_offset += diff
-            n.positions = [pos + diff for pos in n.positions]
+            if isinstance(n.positions, _ShiftedPositions):
+                n.positions.shift(diff)
+            else:
+                n.positions = _ShiftedPositions(n.positions, diff)
         if total:
             self.token_to_kv_pool.free(buf[:total])
 

@@ -35,19 +35,11 @@ while time.time() < t_end and runs < max_runs:
         gen = min(gen, 30)  # the fp64 check walks every leaf's whole path at every step
     if os.environ.get("FUZZ_VERBOSE"):
         print(runs, Hq, Hkv, D, mode, task, prompt, gen, flush=True)
-    r = rp.TemplateReplay(Hq, Hkv, D, layers=1, mode=mode, device="cuda", attention=True, seed=rng.randint(0, 10 ** 6))
-    holder = {}
-    real = rp.TreeCache
+    r = rp.TemplateReplay(Hq, Hkv, D, layers=1, mode=mode, device="cuda", attention=True, seed=rng.randint(0, 10 ** 6),
+                          session=rng.random() < 0.6)  # (the captured session where one exists, the eager calls otherwise)
 
-    class Spy(real):
-        def __init__(self, *a, **kw):
-            super().__init__(*a, **kw); holder["tree"] = self
-
-    attn0 = r.attn[0]; orig = attn0.forward
-    def checked(q, k, v, meta, orig=orig):
+    def checked(tree, q, out):
         global steps, worst
-        out = orig(q, k, v, meta)
-        tree = holder["tree"]
         leaves = sorted(tree.leaves.values(), key=lambda n: n.id)
         kv = tree.token_to_kv_pool.kv_data[0].double()
         qd = q.view(-1, Hq, D).double(); od = out.view(-1, Hq, D).double()
@@ -77,12 +69,7 @@ while time.time() < t_end and runs < max_runs:
             tight[1] += diff.numel()
             assert bad == 0, (bad, err, mode, task, Hq, Hkv, prompt, i, len(slots))
         steps += 1
-        return out
-    attn0.forward = checked
-    rp.TreeCache = Spy
-    try:
-        r.run(tpl, task, prompt, gen, max_rows=512)
-    finally:
-        rp.TreeCache = real
+    r.step_hook = checked
+    r.run(tpl, task, prompt, gen, max_rows=512)
     runs += 1
 print(f"fuzz ok: {runs} replays, {steps} checked steps, worst |err| {worst:.2e}; {tight[0]} of {tight[1]} elements beyond 5e-4 + half an fp16 ulp (none beyond 1e-3 + half an ulp)")

@@ -28,6 +28,7 @@ ap.add_argument("--sd-steps", type=int, default=100)
 ap.add_argument("--pipelined", action="store_true", help="no per-step sync: host runs ahead of the GPU")
 ap.add_argument("--no-warmup", action="store_true", help="do not run the first mode once untimed before the table")
 ap.add_argument("--host-metadata", action="store_true", help="TreeMetadata by the host builder + one upload per step (round-1 path)")
+ap.add_argument("--eager", action="store_true", help="the reference-shaped eager calls per step instead of deft_amd.DecodeSession (one hipGraph per structural epoch)")
 ap.add_argument("--out", default=None)
 a = ap.parse_args()
 if a.host_metadata:
@@ -61,9 +62,12 @@ for idx, mode in enumerate(a_modes):
     tpl = template()
     prompt_len = a.prompt_len or (tpl.root.value if a.template and a.task == "reasoning" and tpl.root.value > 0 else
                                   (1016 if a.task == "speculative_decoding" else 4096))
-    r = rp.TemplateReplay(Hq, Hkv, D, L, mode=mode, device="cuda", attention=True)
+    r = rp.TemplateReplay(Hq, Hkv, D, L, mode=mode, device="cuda", attention=True, session=False if a.eager else None)
     rep = r.run(tpl, a.task, prompt_len, a.max_gen_len, max_rows=max(512, a.width, a.tree_size), pipelined=a.pipelined)
     s = rep.summary(); s["model"] = a.model; s["layers"] = L
+    s["path"] = "session (one hipGraph per structural epoch)" if r.session else "eager calls"
+    s["graph_captures"] = r.graph_captures; s["pipelined"] = bool(a.pipelined)
+    s["wall_over_attention"] = round(s["wall_ms"] / max(s["attention_latency_ms"], 1e-9), 3)
     if not a.no_warmup and idx == 0:
         del r
         torch.cuda.empty_cache()
