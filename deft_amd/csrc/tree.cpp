@@ -59,6 +59,7 @@ struct Tree {
     int64_t epoch = 1;  // bumped by every change the GPU layout cannot absorb
     Layout lay;
     std::vector<int32_t> journal;  // absorbed changes the device copy has not seen yet (valid while lay.valid)
+    int64_t last_ext = -1;         // position of the journal's LAST op if it is an EXTEND (the next one to the same node joins it)
     std::mutex mu;
 };
 
@@ -93,6 +94,7 @@ static void structure_changed(Tree* t) {
     ++t->epoch;
     t->lay.valid = false;
     t->journal.clear();  // (the next upload carries everything)
+    t->last_ext = -1;
 }
 
 // DFS index of a node in the current layout if the layout is valid and the journal has room for `words` more, else -1
@@ -380,13 +382,19 @@ int deft_tree_extend_node(int64_t tree, int64_t id, int n, const int64_t* slots)
             return DEFT_EINVAL;
         }
     const int di = absorbable(t, id, 3 + (size_t)n);
-    const bool fits = di >= 0 && (int64_t)nd.kv.size() + n <= t->lay.cap[di];
+    const bool fits = di >= 0 && n <= 1024 && (int64_t)nd.kv.size() + n <= t->lay.cap[di];  // (an op of the replay kernel holds <= 1024 slots)
     nd.kv.insert(nd.kv.end(), slots, slots + n);
     if (!nd.leaf) nd.grew = 1;
     if (fits) {  // the device copy appends the same slots itself (journal): the epoch stays
-        t->journal.push_back(JOP_EXTEND);
-        t->journal.push_back(di);
-        t->journal.push_back(n);
+        // (merge_nodes leaf after leaf is one EXTEND per leaf to the same node: they become ONE op, one pass on the device)
+        if (t->last_ext >= 0 && t->journal[(size_t)t->last_ext + 1] == di && t->journal[(size_t)t->last_ext + 2] + n <= 1024) {
+            t->journal[(size_t)t->last_ext + 2] += n;
+        } else {
+            t->last_ext = (int64_t)t->journal.size();
+            t->journal.push_back(JOP_EXTEND);
+            t->journal.push_back(di);
+            t->journal.push_back(n);
+        }
         for (int i = 0; i < n; ++i) t->journal.push_back((int32_t)slots[i]);
         return DEFT_OK;
     }
@@ -409,6 +417,7 @@ int deft_tree_set_node_kv(int64_t tree, int64_t id, int n, const int64_t* slots)
             t->journal.push_back(JOP_RESET);
             t->journal.push_back(di);
             t->journal.push_back(0);
+            t->last_ext = -1;
             return DEFT_OK;
         }
         structure_changed(t);
@@ -449,6 +458,7 @@ int64_t deft_tree_take_nodes_kv(int64_t tree, int n, const int64_t* ids, int64_t
             t->journal.push_back(JOP_RESET);
             t->journal.push_back(t->lay.index.find(ids[i])->second);
             t->journal.push_back(0);
+            t->last_ext = -1;
         }
         kv.clear();
     }
@@ -470,6 +480,7 @@ int64_t deft_tree_journal_take(int64_t tree, int32_t* out, int64_t cap) {
     }
     std::copy(t->journal.begin(), t->journal.end(), out);
     t->journal.clear();
+    t->last_ext = -1;
     return n;
 }
 

@@ -93,7 +93,19 @@ __device__ inline void tree_apply_ops(const TreeDev& t, const int32_t* ops, int3
             break;
         }
         if (op == 2) {
-            if (tid == 0) t.node_len[node] = 0;
+            // a RUN of RESETs (a speculative-decoding step has one per leaf) in one go: thread j looks at the j-th op from here
+            const int mine = at + 3 * tid;
+            const bool is_reset = mine + 2 < words + 1 && ops[mine] == 2 && ops[mine + 2] == 0 && ops[mine + 1] >= 0 && ops[mine + 1] < t.n;
+            if (tid == 0) sMeta[1] = 1024;
+            __syncthreads();
+            if (!is_reset) atomicMin(&sMeta[1], tid);
+            __syncthreads();
+            const int run = sMeta[1];  // >= 1: this op itself is a valid RESET
+            if (tid < run) t.node_len[ops[mine + 1]] = 0;
+            __threadfence_block();
+            __syncthreads();
+            at += 3 * run;
+            continue;
         } else if (op == 1 && k > 0) {
             int32_t* s = t.slots + t.node_start[node];
             const int len = t.node_len[node];

@@ -370,9 +370,9 @@ def test_absorbed_changes_are_journalled_not_new_epochs():
     assert all(len(lf.kv_indices) == 0 for lf in leaves)
     n = int(lib.deft_tree_journal_take(tree._native, _ptr(buf), 256))
     words = buf[:n].tolist()
-    # three EXTENDs of one slot each into the root (DFS index 0), then a RESET per leaf (DFS indices 1..4)
-    assert words[:12] == [1, 0, 1, slots[0], 1, 0, 1, slots[1], 1, 0, 1, slots[2]]
-    assert words[12:] == [2, 1, 0, 2, 2, 0, 2, 3, 0, 2, 4, 0]
+    # the three one-slot merges into the root (DFS index 0) as ONE EXTEND, then a RESET per leaf (DFS indices 1..4)
+    assert words[:6] == [1, 0, 3, slots[0], slots[1], slots[2]]
+    assert words[6:] == [2, 1, 0, 2, 2, 0, 2, 3, 0, 2, 4, 0]
     assert lib.deft_tree_journal_take(tree._native, _ptr(buf), 256) == 0  # handed over once
     step()
     assert tree._epoch() == e1  # a decode step still fits
