@@ -190,6 +190,10 @@ class TemplateReplay:
         self.attention = attention
         self.vocab = vocab
         self.rng = np.random.default_rng(seed)
+        # synthetic next-token scores: the branch functions use their arg-top-k only.  A table drawn ONCE and read through a
+        # rolling window -- drawing nq x vocab fresh numbers per decode step cost more host time than the step itself
+        self._score_table = self.rng.random((1024 + 257, vocab), dtype=np.float32)
+        self._score_at = 0
         can = attention and mode in ("flatten", "node") and head_dim == 128
         self.session = can if session is None else (bool(session) and can)
         # test hook: called after every step's attention with (tree, layer-0 q rows [nq, Hq*D], layer-0 output [nq, Hq*D])
@@ -198,6 +202,13 @@ class TemplateReplay:
             from .deft_attention import DeFTAttention
 
             self.attn = [DeFTAttention(num_heads, head_dim, head_dim ** -0.5, num_kv_heads, l) for l in range(layers)]
+
+    def _scores(self, rows: int) -> np.ndarray:
+        tab = self._score_table
+        if rows > tab.shape[0]:
+            return self.rng.random((rows, self.vocab), dtype=np.float32)
+        self._score_at = (self._score_at + 257) % (tab.shape[0] - rows + 1)  # (a different window every step)
+        return tab[self._score_at : self._score_at + rows]
 
     def _pools(self, max_tokens: int, max_leaves: int):
         req = ReqToTokenPool(max_leaves + 8, max_tokens + 8, device=self.device)
@@ -246,7 +257,7 @@ class TemplateReplay:
             sizes = np.zeros(9, dtype=np.int64)
         t_wall = time.perf_counter()
         tree.init_prompt(torch.arange(1, prompt_len + 1, dtype=torch.int32))
-        logits = self.rng.random((1, self.vocab), dtype=np.float32)
+        logits = self._scores(1)
         stop = branch(tree, 0, max_gen_len, logits, template)  # tree_generate.py:188-197
         it = 1
         first_event = last_event = None
@@ -280,7 +291,7 @@ class TemplateReplay:
                 lib.deft_tree_md_sizes(tree._native, 32, 128, -1, 0, _ptr(sizes))
                 kv_tokens, node_kv_n = int(sizes[2]), int(sizes[4])
                 t1 = time.perf_counter()
-                logits = self.rng.random((nq, self.vocab), dtype=np.float32)
+                logits = self._scores(nq)
                 stop = branch(tree, it, max_gen_len, logits, template)
                 t_br = (time.perf_counter() - t1) * 1e3
                 rep.per_step.append({"iter": it, "nq": nq, "kv_tokens": kv_tokens, "attention_ms": t_attn,
@@ -326,7 +337,7 @@ class TemplateReplay:
                     t_attn = e0.elapsed_time(e1)
             # ---- branch (tree_generate.py:226-236) ------------------------------------------------------------
             t1 = time.perf_counter()
-            logits = self.rng.random((nq, self.vocab), dtype=np.float32)
+            logits = self._scores(nq)
             kv_tokens = md.total_kv_len if md is not None else sum(len(n.kv_indices) for n in tree.nodes.values())
             stop = branch(tree, it, max_gen_len, logits, template)
             t_br = (time.perf_counter() - t1) * 1e3
