@@ -11,7 +11,7 @@ import deft_amd
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 t_end = time.time() + budget
-runs = steps = captures = 0
+runs = steps = captures = sd_runs = 0
 while time.time() < t_end:
     Hq, Hkv = rng.choice([(32, 32), (32, 8), (8, 2), (4, 4), (16, 1)])
     D, layers = 128, rng.choice([1, 2])
@@ -79,7 +79,27 @@ while time.time() < t_end:
             lv = sorted(tree.leaves.values(), key=lambda n: n.id)
             tree.branch(lv[0], r2.randint(2, 3))
         both(rng.choice([3, 20, 140]))
+    # speculative-decoding steps (branch_func_example.py:420-437): some leaves' slots are squeezed into an inner node -- the root,
+    # or the parent of the first leaf -- and every leaf's KV is released, between single decode steps.  Absorbed by the epoch
+    # (the native tree's journal, replayed by the step's first kernel) after the first one, which finds the node without room.
+    if rng.random() < 0.5:
+        cap_before = sess.captures
+        sd_steps = rng.choice([3, 12, 40])
+        for it in range(sd_steps):
+            r2 = random.Random(runs * 1000 + it)
+            for tree in (te, ts):
+                lv = sorted(tree.leaves.values(), key=lambda n: n.id)
+                target = tree.root if (r2.random() < 0.7 or lv[0].parent is None) else lv[0].parent
+                if len(target.kv_indices) == 0 and target is not tree.root:
+                    target = tree.root
+                before = len(target.kv_indices)
+                for leaf in r2.sample(lv, min(len(lv), r2.randint(0, 4))):
+                    tree.merge_nodes(target, leaf, pruneB_flag=False)
+                tree.reset_nodes_KV(lv, len(target.kv_indices) - before)
+            both(1)
+        assert sess.captures - cap_before <= 3 + sd_steps // 200, (sess.captures - cap_before, sd_steps)  # not one epoch per step
+        sd_runs += 1
     captures += sess.captures
     deft_amd.unregister_tree_metadata()
     runs += 1
-print(f"session fuzz ok: {runs} trees, {steps} steps bit-identical to the eager path, {captures} graph captures")
+print(f"session fuzz ok: {runs} trees ({sd_runs} with speculative-decoding merge / reset steps), {steps} steps bit-identical to the eager path, {captures} graph captures")
