@@ -86,8 +86,8 @@ while time.time() < t_end:
         cap_before = sess.captures
         sd_steps = rng.choice([3, 12, 40])
         for it in range(sd_steps):
-            r2 = random.Random(runs * 1000 + it)
             for tree in (te, ts):
+                r2 = random.Random(runs * 1000 + it)  # (the same draws for both trees)
                 lv = sorted(tree.leaves.values(), key=lambda n: n.id)
                 target = tree.root if (r2.random() < 0.7 or lv[0].parent is None) else lv[0].parent
                 if len(target.kv_indices) == 0 and target is not tree.root:
