@@ -539,7 +539,7 @@ static int num_cus() {
     return d.cus;
 }
 enum : unsigned { ATTR_NP = 4,  // (bits 0-1, 8-11: the head_dim 64 / 32 / 16 kernels)
-                  ATTR_UNITS = 8, ATTR_NODE_UNITS = 16, ATTR_PREFILL = 32, ATTR_TREE = 64, ATTR_NP_ROPE = 128, ATTR_PREFILL_PIPE = 4096, ATTR_NP_T = 8192, ATTR_NP_ROPE_T = 16384 };
+                  ATTR_UNITS = 8, ATTR_NODE_UNITS = 16, ATTR_PREFILL = 32, ATTR_TREE = 64, ATTR_NP_ROPE = 128, ATTR_PREFILL_PIPE = 4096, ATTR_NP_T = 8192, ATTR_NP_ROPE_T = 16384, ATTR_NP_HD2 = 32768, ATTR_NP_HD2_T = 65536 };
 static int raise_lds(const void* fn, int bytes, unsigned bit, const char* what) {  // idempotent; races are harmless
     DeviceState& d = dev_state();
     if (d.attrs & bit) return DEFT_OK;
@@ -663,10 +663,15 @@ static int launch_plan(const Stage1Params& p, int NB, const PlanView& pv, const 
 
 // Stage 1 (head_dim 128): one workgroup per record slot and KV head; slots that are not chunk leaders exit at once
 // (they are at the end of the grid).
+// head_dim 64 on the tile-parallel kernel: two adjacent KV heads per 256-byte pool row (stage1_np.h, HD2) -- an even number of
+// KV heads laid out contiguously ([slot][K|V][Hkv][64], the reference's pool, memory_pool.py:61-66)
+static bool hd2_geometry(int D, int Hkv, int64_t kv_sh) { return D == 64 && Hkv % 2 == 0 && kv_sh == 64; }
+
 static int launch_stage1_np(const Stage1Params& p, int64_t unit_cap, const PlanView& pv, const AppendArgs& ap,
-                            hipStream_t stream, int nq, bool reread = false) {
+                            hipStream_t stream, int nq, bool reread = false, bool hd2 = false) {
     using SM = NpSmem<128>;
     const bool rope = ap.cos_sin != nullptr;
+    const int HP = hd2 ? p.Hkv / 2 : p.Hkv;  // work items per chunk leader: KV heads, or head pairs
     // K / V rows by NON-TEMPORAL LDS-DMA wherever a row is read by the few 32-row passes of its tile and never again: the
     // tree modes.  Same box, stage 1 (tools/ab.py, experiments build DEFT_NP_NT=0/1): north-star tree 36.0 -> 32.3 us, 1k x 32
     // 26.5 -> 24.1, 400-token branches 54.0 -> 48.4; whole layer: 8-tree forest 64.7 -> 60.0, Llama-3 north-star tree 23.5 ->
@@ -674,13 +679,15 @@ static int launch_stage1_np(const Stage1Params& p, int64_t unit_cap, const PlanV
     // leaf re-reads the shared prefix through the caches: 216 -> 298 us per layer (`reread`).
     const bool nt = knob("DEFT_NP_NT", 1) != 0 && !reread && (int64_t)nq * p.G <= 1024;
     int rc;
-    if (rope) rc = nt ? raise_lds(reinterpret_cast<const void*>(&stage1_np_kernel<128, true, true>), SM::BYTES, ATTR_NP_ROPE, "stage1_np_rope")
+    if (hd2) rc = nt ? raise_lds(reinterpret_cast<const void*>(&stage1_np_kernel<128, false, true, false, true>), SM::BYTES, ATTR_NP_HD2, "stage1_np_hd2")
+                     : raise_lds(reinterpret_cast<const void*>(&stage1_np_kernel<128, false, false, false, true>), SM::BYTES, ATTR_NP_HD2_T, "stage1_np_hd2_t");
+    else if (rope) rc = nt ? raise_lds(reinterpret_cast<const void*>(&stage1_np_kernel<128, true, true>), SM::BYTES, ATTR_NP_ROPE, "stage1_np_rope")
                       : raise_lds(reinterpret_cast<const void*>(&stage1_np_kernel<128, true, false>), SM::BYTES, ATTR_NP_ROPE_T, "stage1_np_rope_t");
     else rc = nt ? raise_lds(reinterpret_cast<const void*>(&stage1_np_kernel<128, false, true>), SM::BYTES, ATTR_NP, "stage1_np")
                  : raise_lds(reinterpret_cast<const void*>(&stage1_np_kernel<128, false, false>), SM::BYTES, ATTR_NP_T, "stage1_np_t");
     if (rc) return rc;
     if (unit_cap <= 0) return DEFT_OK;
-    int64_t grid = unit_cap * p.Hkv;
+    int64_t grid = unit_cap * HP;
     if (grid > 0x7fffffffLL) {
         set_error("stage1 grid too large: %lld", (long long)grid);
         return DEFT_EINVAL;
@@ -695,7 +702,7 @@ static int launch_stage1_np(const Stage1Params& p, int64_t unit_cap, const PlanV
     {
         // GQA launches whose whole record capacity is within 8 x the resident slots (a single tree: the Llama-3
         // north-star tree, ToT-50) have about one item per workgroup anyway and gain 2 us from 2 x slots.
-        const bool small_gqa = unit_cap * p.Hkv <= 16LL * num_cus();
+        const bool small_gqa = unit_cap * HP <= 16LL * num_cus();
         const int capx = knob("DEFT_NP_GRIDCAP", p.G > 1 ? (small_gqa ? 2 : 1) : 3);
         const int64_t cap_wgs = (int64_t)capx * 2LL * num_cus();
         if (cap_wgs > 0 && grid > cap_wgs) grid = cap_wgs;
@@ -714,7 +721,9 @@ static int launch_stage1_np(const Stage1Params& p, int64_t unit_cap, const PlanV
     npp.dbg = g_dbg;
     npp.cos_sin = ap.cos_sin;
     const dim3 g((unsigned)grid), b(256);
-    if (rope && nt) hipLaunchKernelGGL((stage1_np_kernel<128, true, true>), g, b, SM::BYTES, stream, npp);
+    if (hd2 && nt) hipLaunchKernelGGL((stage1_np_kernel<128, false, true, false, true>), g, b, SM::BYTES, stream, npp);
+    else if (hd2) hipLaunchKernelGGL((stage1_np_kernel<128, false, false, false, true>), g, b, SM::BYTES, stream, npp);
+    else if (rope && nt) hipLaunchKernelGGL((stage1_np_kernel<128, true, true>), g, b, SM::BYTES, stream, npp);
     else if (rope) hipLaunchKernelGGL((stage1_np_kernel<128, true, false>), g, b, SM::BYTES, stream, npp);
     else if (nt) hipLaunchKernelGGL((stage1_np_kernel<128, false, true>), g, b, SM::BYTES, stream, npp);
     else hipLaunchKernelGGL((stage1_np_kernel<128, false, false>), g, b, SM::BYTES, stream, npp);
@@ -911,7 +920,8 @@ static int flatten_stage1_impl(const void* q, int64_t q_stride_tok, int64_t q_st
     p.scale_log2e = scale * LOG2E;
     *ws_out = ws;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (D == 128) {
+    const bool hd2 = hd2_geometry(D, Hkv, kv_stride_head) && !ap.cos_sin;
+    if (D == 128 || hd2) {
         PlanView pv;
         if (plan) {
             pv = plan_view(const_cast<void*>(plan), cap, P);
@@ -922,7 +932,7 @@ static int flatten_stage1_impl(const void* q, int64_t q_stride_tok, int64_t q_st
         }
         *row_q_out = pv.row_q;
         *pv_out = pv;
-        return launch_stage1_np(p, cap, pv, ap, st, nq);
+        return launch_stage1_np(p, cap, pv, ap, st, nq, false, hd2);
     }
     if (ap.k_new) {  // head_dim 64 (tile-per-workgroup form): separate append launch first
         rc = deft_kv_append_f16(const_cast<void*>(k_base), const_cast<void*>(v_base), kv_stride_slot, kv_stride_head,
@@ -1272,7 +1282,8 @@ static int node_decode_impl(const void* q, int64_t q_stride_tok, int64_t q_strid
     p.Hkv = Hkv;
     p.G = G;
     p.scale_log2e = scale * LOG2E;
-    if (D == 128) {
+    const bool hd2 = hd2_geometry(D, Hkv, kv_stride_head) && !ap.cos_sin && rows_per_tile != 1;
+    if (D == 128 || hd2) {
         PlanView pv;
         if (plan) {
             pv = plan_view(const_cast<void*>(plan), tiles * G, rows);
@@ -1281,7 +1292,7 @@ static int node_decode_impl(const void* q, int64_t q_stride_tok, int64_t q_strid
             rc = launch_node_plan(p, NE, rows, pv, ap, st);
             if (rc) return rc;
         }
-        rc = launch_stage1_np(p, tiles * G, pv, ap, st, nq, /*reread=*/rows_per_tile == 1);
+        rc = launch_stage1_np(p, tiles * G, pv, ap, st, nq, /*reread=*/rows_per_tile == 1, hd2);
         if (rc) return rc;
         return launch_merge(D, ws, &pv, pv.row_q, rows, out, o_stride_tok, o_stride_head, nq, Hq, st);
     }

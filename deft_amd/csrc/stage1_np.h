@@ -88,8 +88,8 @@ struct NpSmem {
     static constexpr int Q_OFF = 8 * SLICE;             // Q rows [32][D] fp16, chunks XOR-ed by (row & 15)
     static constexpr int AUX_OFF = Q_OFF + MQ * D * 2;  // per wave 2 slots x 512 B: int64 rowoff[32] | u32 vmask[32] | i32 qsrc[32]
     static constexpr int AUX_SLOT = 512;
-    static constexpr int X_OFF = AUX_OFF + 4 * 2 * AUX_SLOT;  // float m[4][32], l[4][32]
-    static constexpr int OROW_OFF = X_OFF + 2 * 4 * MQ * 4;   // int32 orow[32] of the leader record
+    static constexpr int X_OFF = AUX_OFF + 4 * 2 * AUX_SLOT;  // float m[2][4][32], l[2][4][32] (per head of the row: two with head_dim 64)
+    static constexpr int OROW_OFF = X_OFF + 2 * 2 * 4 * MQ * 4;   // int32 orow[32] of the leader record
     static constexpr int NEXT_OFF = OROW_OFF + 2 * MQ * 4;    // int32 next work item (orow is staged twice: one 64-lane DMA)
     static constexpr int BYTES = NEXT_OFF + 16;
     static_assert(2 * BYTES <= 160 * 1024, "two workgroups per CU");
@@ -108,11 +108,18 @@ struct NpSmem {
 // PEEL: Q fragments built in front of the tile loop (what ROPE needs; for the plain kernel measured neutral, tools/ab.py:
 // north-star 35.96 / 36.10 us, ToT-50 18.41 / 18.20, Llama-3 north-star tree 17.93 / 17.66 -- the loop form stays)
 // NT: K / V rows arrive by non-temporal LDS-DMA (tree modes: a row is read by the few passes of its tile and never again)
-template <int D, bool ROPE, bool NT, bool PEEL = ROPE>
+// HD2: head_dim 64 (the reference also takes 16 / 32 / 64, tree_attention.py:100, :582).  Two ADJACENT KV heads share one 256-byte
+//      pool row -- [slot][K|V][Hkv][64] with heads contiguous -- so a work item is a head PAIR and everything that moves data is
+//      the head_dim-128 kernel unchanged: the same DMA granules, the same LDS slices, the same fragment reads.  Only the
+//      arithmetic splits: k-steps 0-3 are head A's S^T, 4-7 head B's (two accumulators, two softmaxes), column blocks 0-1 of O^T
+//      take head A's probabilities, 2-3 head B's, and the epilogue writes two 64-float partial rows per virtual row.
+template <int D, bool ROPE, bool NT, bool PEEL = ROPE, bool HD2 = false>
 __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
     constexpr int KS = D / 16;
     constexpr int LPT = 32 * (D / 8) / 64;  // DMA instructions per wave per K (or V) slice
-    static_assert(D == 128 && LPT == 8, "tile-parallel stage 1 is instantiated for head_dim 128");
+    static_assert(D == 128 && LPT == 8, "tile-parallel stage 1 is instantiated for 256-byte rows (head_dim 128, or two heads of 64)");
+    static_assert(!(HD2 && ROPE), "the fused rotary embedding is head_dim 128 only");
+    constexpr int NH = HD2 ? 2 : 1;  // heads per row
     using SM = NpSmem<D>;
     const Stage1Params& p = np.s;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -125,18 +132,20 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
     const int bid = blockIdx.x;
     const int W = (int)gridDim.x;
     unsigned long long t_start = 0, t_k0 = 0, t_epi = 0;
+    const int HP = HD2 ? p.Hkv / 2 : p.Hkv;                  // rows (heads, or head pairs) per token
+    const int64_t kv_shp = HD2 ? 2 * p.kv_sh : p.kv_sh;      // elements between two of them
 
     // ---- fused paged append: new-token row j is copied into the pool by workgroup (grid-1-j) % grid (nobody reads
     //      those pool rows in this launch: rows flagged NEW in the plan are taken from k_new / v_new) ------------
     for (int copy_job = W - 1 - bid; copy_job < np.n_new; copy_job += W) {
         const int64_t dst = (int64_t)np.cache_loc[copy_job] * p.kv_ss;
-        const int chunks = p.Hkv * (D / 8);
+        const int chunks = HP * (D / 8);
         const float* cs_row = nullptr;
         if constexpr (ROPE) cs_row = np.cos_sin + (int64_t)copy_job * D;
         for (int i = tid; i < chunks; i += blockDim.x) {
             const int hd = i / (D / 8), ch = i - hd * (D / 8);
             const int64_t so = (int64_t)copy_job * np.new_st + hd * D + ch * 8;
-            const int64_t d_o = dst + (int64_t)hd * p.kv_sh + ch * 8;
+            const int64_t d_o = dst + (int64_t)hd * kv_shp + ch * 8;
             uintx4 kk = *reinterpret_cast<const uintx4*>(np.k_new + so);
             const uintx4 vv = *reinterpret_cast<const uintx4*>(np.v_new + so);
             if constexpr (ROPE) {  // the k row enters the pool rotated: chunk ch pairs with chunk ch ^ 8 (d, d + D/2)
@@ -226,19 +235,21 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
     };
     auto issue_q = [&]() {  // rows 8w .. 8w+7 of the shared Q buffer, offsets from aux slot 0
         const int32_t* qs = reinterpret_cast<const int32_t*>(smem + aux0 + 256 + 128);
-        const char* hb = reinterpret_cast<const char*>(p.q) + (int64_t)kvh * p.G * p.q_sh * 2;
+        const char* hb = reinterpret_cast<const char*>(p.q) + (int64_t)(HD2 ? 2 * kvh : kvh) * p.G * p.q_sh * 2;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int row = 8 * w + 4 * i + dkey;
             const int chunk = dpos ^ (row & 15);
-            dma16(hb + (int64_t)qs[row] * 2 + chunk * 16, SM::Q_OFF + (uint32_t)(8 * w + 4 * i) * 256u);
+            // (HD2: the LDS row is [head A's 64 | head B's 64]; B's query head is G heads after A's)
+            const int64_t src = HD2 ? (chunk < 8 ? chunk * 16 : (int64_t)p.G * p.q_sh * 2 + (chunk - 8) * 16) : chunk * 16;
+            dma16(hb + (int64_t)qs[row] * 2 + src, SM::Q_OFF + (uint32_t)(8 * w + 4 * i) * 256u);
         }
     };
 
     for (bool first = true;; first = false) {
     if (DBG) t_start = wall_clock64();
-    rec0 = item / p.Hkv;
-    kvh = item - rec0 * p.Hkv;
+    rec0 = item / HP;
+    kvh = item - rec0 * HP;  // (HD2: the head PAIR)
     const char* rec_lead = np.plan + (int64_t)rec0 * PLAN_BYTES;
     const int32_t* desc0 = reinterpret_cast<const int32_t*>(rec_lead + PLAN_DESC);
     // The workgroups that are resident when the launch starts set the ramp: for them tile 0's offsets / masks /
@@ -254,7 +265,7 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
     if (first) {
         const int nl = np.hdr[1];
         const int d4 = desc0[4], d0 = desc0[0], d5 = desc0[5];  // speculative for slots beyond the leaders: valid memory
-        NI = __builtin_amdgcn_readfirstlane(nl) * p.Hkv;
+        NI = __builtin_amdgcn_readfirstlane(nl) * HP;
         if (item >= NI) {  // this record slot leads no chunk: merge duty (single-launch decode) or nothing
             if (spec) wait_vm<0>();
             break;
@@ -270,8 +281,8 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
     const int n = sd4;  // tiles of this chunk (> 0: items only name leaders)
     const int nv = sd0;
     fb = sd5;
-    kb_pool = reinterpret_cast<const char*>(p.k) + (int64_t)kvh * p.kv_sh * 2;
-    vb_pool = reinterpret_cast<const char*>(p.v) + (int64_t)kvh * p.kv_sh * 2 + vchunk_b;
+    kb_pool = reinterpret_cast<const char*>(p.k) + (int64_t)kvh * kv_shp * 2;
+    vb_pool = reinterpret_cast<const char*>(p.v) + (int64_t)kvh * kv_shp * 2 + vchunk_b;
     kb_new = reinterpret_cast<const char*>(np.k_new) + (int64_t)kvh * D * 2;
     vb_new = reinterpret_cast<const char*>(np.v_new) + (int64_t)kvh * D * 2 + vchunk_b;
     // leader's partial rows (one per virtual query row), parked in LDS for the epilogue (wave 0, one DMA)
@@ -311,7 +322,9 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
     issue_v();
 
     half8 qf[KS];
-    float m_run = -INFINITY, l_run = 0.f;
+    float m_run[NH], l_run[NH];
+#pragma unroll
+    for (int hh = 0; hh < NH; ++hh) m_run[hh] = -INFINITY, l_run[hh] = 0.f;
     floatx16 o[4];
 #pragma unroll
     for (int b = 0; b < 4; ++b)
@@ -396,27 +409,35 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) m4[g4] = *reinterpret_cast<const uintx4*>(masks + 8 * g4 + 4 * h);
         }
-        // ---- S^T for this wave's 32 keys ---------------------------------------------------------------
-        floatx16 acc;
+        // ---- S^T for this wave's 32 keys (HD2: k-steps 0-3 = head A, 4-7 = head B) ---------------------------
+        floatx16 acc[NH];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        for (int hh = 0; hh < NH; ++hh)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[hh][r] = 0.f;
         if (!ABL(1)) {  // experiments build: 1 skip QK^T, 4 skip PV, 16 skip the epilogue, 32 skip the stores
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const half8 a = *reinterpret_cast<const half8*>(smem + krow_b + (kcol_b ^ (32 * ks)));
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qf[ks], acc, 0, 0, 0);
+                constexpr int HALF = KS / 2;
+                floatx16& dst = acc[HD2 ? (ks / HALF) : 0];
+                dst = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qf[ks], dst, 0, 0, 0);
             }
         }
-        float s[16];
-        float mx = -INFINITY;
+        float s[NH][16];
+        float mx[NH];
 #pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4)
+        for (int hh = 0; hh < NH; ++hh) {
+            mx[hh] = -INFINITY;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int r = 4 * g4 + j;
-                s[r] = ((m4[g4][j] >> c) & 1u) ? acc[r] * p.scale_log2e : -INFINITY;
-                mx = fmaxf(mx, s[r]);
-            }
+            for (int g4 = 0; g4 < 4; ++g4)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int r = 4 * g4 + j;
+                    s[hh][r] = ((m4[g4][j] >> c) & 1u) ? acc[hh][r] * p.scale_log2e : -INFINITY;
+                    mx[hh] = fmaxf(mx[hh], s[hh][r]);
+                }
+        }
         // ---- the K slice is free: next tile's row offsets -> K(i+1), aux(i+2) ---------------------------
         if (has1) {
             wait_vm<LPT>();  // aux(i+1) landed (younger: V(i))
@@ -424,27 +445,32 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
             issue_k();
             if (has2) issue_aux(i + 2, slot);
         }
-        // ---- wave-private online softmax ----------------------------------------------------------------
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const float m_new = fmaxf(m_run, mx);
-        const float msafe = (m_new == -INFINITY) ? 0.f : m_new;
-        const float alpha = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run - msafe);
-        half8 pb[2];
-        float sum = 0.f;
+        // ---- wave-private online softmax (per head of the row) ------------------------------------------------
+        half8 pb[NH][2];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const _Float16 ph = (_Float16)__builtin_amdgcn_exp2f(s[r] - msafe);
-            pb[r >> 3][r & 7] = ph;
-            sum += (float)ph;  // row sums over the ROUNDED probabilities: the weights sum to 1 exactly
-        }
-        sum += __shfl_xor(sum, 32);
-        l_run = l_run * alpha + sum;
-        m_run = m_new;
-        if (i > 0 && __builtin_amdgcn_ballot_w64(alpha != 1.f) != 0ull) {
+        for (int hh = 0; hh < NH; ++hh) {
+            const float mxx = fmaxf(mx[hh], __shfl_xor(mx[hh], 32));
+            const float m_new = fmaxf(m_run[hh], mxx);
+            const float msafe = (m_new == -INFINITY) ? 0.f : m_new;
+            const float alpha = (m_run[hh] == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run[hh] - msafe);
+            float sum = 0.f;
 #pragma unroll
-            for (int b = 0; b < 4; ++b)
+            for (int r = 0; r < 16; ++r) {
+                const _Float16 ph = (_Float16)__builtin_amdgcn_exp2f(s[hh][r] - msafe);
+                pb[hh][r >> 3][r & 7] = ph;
+                sum += (float)ph;  // row sums over the ROUNDED probabilities: the weights sum to 1 exactly
+            }
+            sum += __shfl_xor(sum, 32);
+            l_run[hh] = l_run[hh] * alpha + sum;
+            m_run[hh] = m_new;
+            if (i > 0 && __builtin_amdgcn_ballot_w64(alpha != 1.f) != 0ull) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) o[b][r] *= alpha;
+                for (int b = 0; b < 4; ++b) {
+                    if (HD2 && (b >> 1) != hh) continue;  // (column blocks 0-1 belong to head A, 2-3 to head B)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[b][r] *= alpha;
+                }
+            }
         }
         // ---- V(i) landed: younger are K(i+1) [8] and aux(i+2) [2] ---------------------------------------
         if (has2) wait_vm<LPT + 2>();
@@ -464,7 +490,7 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
                 } av;
                 av.s4[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(uintptr_t)(vb));
                 av.s4[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(uintptr_t)(vb + 8 * D * 2));
-                o[blk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av.h8, pb[t], o[blk], 0, 0, 0);
+                o[blk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av.h8, pb[HD2 ? (blk >> 1) : 0][t], o[blk], 0, 0, 0);
             }
         }
         if (has1) issue_v();  // V(i+1); rowoff still holds tile i+1's offsets
@@ -481,11 +507,14 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
     //      every wave parks its unscaled O (and m, l) in its own slices -- nobody else ever touched them -- and
     //      the readers rescale while they sum.  Rows of follower tiles are dead by construction: the plan gave
     //      them row_q = -1, so nothing is written for them.
-    float* xm = reinterpret_cast<float*>(smem + SM::X_OFF);
-    float* xl = xm + 4 * MQ;
+    float* xm = reinterpret_cast<float*>(smem + SM::X_OFF);  // [NH][4][32]
+    float* xl = xm + 2 * 4 * MQ;
     if (h == 0) {
-        xm[w * MQ + c] = m_run;
-        xl[w * MQ + c] = l_run;
+#pragma unroll
+        for (int hh = 0; hh < NH; ++hh) {
+            xm[(hh * 4 + w) * MQ + c] = m_run[hh];
+            xl[(hh * 4 + w) * MQ + c] = l_run[hh];
+        }
     }
     // query row c < 16 in the K slice, c >= 16 in the V slice; [row][128] floats, 16-byte chunk index XOR-ed by the row
     if (c < nv && !(ABL(64))) {
@@ -500,16 +529,18 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
             }
     }
     if (!(ABL(64))) lds_barrier();
-    const int64_t head_rows = (int64_t)kvh * p.G * p.rows;
     const int32_t* orow = reinterpret_cast<const int32_t*>(smem + SM::OROW_OFF);
-    // wave w sums the 16-byte chunks 8w .. 8w+7 of every row: lane = (row within a group of 8, chunk)
+    // wave w sums the 16-byte chunks 8w .. 8w+7 of every row: lane = (row within a group of 8, chunk).  HD2: chunks 0-15 are
+    // head A's 64 floats (waves 0, 1), chunks 16-31 head B's (waves 2, 3): each with its own head's (m, l), its own output row.
     const int k4 = 8 * w + (l & 7);
+    const int hh_out = HD2 ? (w >> 1) : 0;
+    const int64_t head_rows = (int64_t)((HD2 ? 2 * kvh + hh_out : kvh)) * p.G * p.rows;
     for (int q0 = 0; q0 < nv; q0 += 8) {
         const int qr = q0 + (l >> 3);
         if (qr < nv) {
             float mw[4];
 #pragma unroll
-            for (int ww = 0; ww < 4; ++ww) mw[ww] = xm[ww * MQ + qr];
+            for (int ww = 0; ww < 4; ++ww) mw[ww] = xm[(hh_out * 4 + ww) * MQ + qr];
             const float M = fmaxf(fmaxf(mw[0], mw[1]), fmaxf(mw[2], mw[3]));
             float L = 0.f;
             floatx4 a = {0.f, 0.f, 0.f, 0.f};
@@ -517,7 +548,7 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
 #pragma unroll
             for (int ww = 0; ww < 4; ++ww) {
                 const float f = (mw[ww] == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(mw[ww] - M);
-                L += f * xl[ww * MQ + qr];
+                L += f * xl[(hh_out * 4 + ww) * MQ + qr];
                 const floatx4 b = *reinterpret_cast<const floatx4*>(smem + off + ww * SM::SLICE);
                 a += b * f;
             }
@@ -529,8 +560,13 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
             const int64_t row = head_rows + orow_q;
             // (ordinary stores: non-temporal partial stores, and non-temporal loads of them in the merge, each cost the
             //  north-star layer ~1 us and both ~2.3 -- profiles/r2n_nontemporal.txt)
-            *reinterpret_cast<floatx4*>(p.partial_o + row * D + 4 * k4) = res;
-            if (k4 == 0) p.partial_lse[row] = lse;
+            if constexpr (HD2) {
+                *reinterpret_cast<floatx4*>(p.partial_o + row * (D / 2) + 4 * (k4 & 15)) = res;
+                if ((k4 & 15) == 0) p.partial_lse[row] = lse;
+            } else {
+                *reinterpret_cast<floatx4*>(p.partial_o + row * D + 4 * k4) = res;
+                if (k4 == 0) p.partial_lse[row] = lse;
+            }
         }
     }
     if (DBG && tid == 0 && item < 8192) {
