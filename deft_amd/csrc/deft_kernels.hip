@@ -619,6 +619,11 @@ static int launch_qrows(const PlanView& pv, hipStream_t stream) {
 static int np_chunk_knob() { return knob("DEFT_NP_CHUNK", 0); }  // tiles per chunk (0 = the plan kernel's rule)
 static int np_union_knob() { return knob("DEFT_NP_UNION", 0); }  // leaf tiles per union group (1 = off, 0 = rule)
 
+// Work items of stage 1 per chunk leader, for the plan's chunk-length rules (they weigh the number of workgroups against the
+// resident slots): one per KV head -- per head PAIR where stage 1 will run head_dim 64 two heads to a row (hd2_geometry).  The plan
+// calls carry no head_dim; the q head stride does (64 elements = contiguous heads of 64).  Only the rules depend on it.
+static int plan_items_per_leader(const Stage1Params& p) { return (p.q_sh == 64 && p.Hkv % 2 == 0) ? p.Hkv / 2 : p.Hkv; }
+
 // Flatten plan: unit list (one workgroup) then one record per unit.
 static int launch_plan(const Stage1Params& p, int NB, const PlanView& pv, const AppendArgs& ap, hipStream_t stream,
                        const int32_t* dims = nullptr) {
@@ -649,7 +654,7 @@ static int launch_plan(const Stage1Params& p, int NB, const PlanView& pv, const 
     const size_t lds = sizeof(int) * (blk + (par ? 5 : 3) * (size_t)run_cap + 8);
     const UnitList ul = unit_list(pv);
     hipLaunchKernelGGL(flatten_units_kernel, dim3(1), dim3(1024), lds, stream, p.block_q, p.block_q_cnts, p.block_q_offset, NB,
-                       p.G, (int)pv.cap, ul, pv.hdr, p.Hkv, 2 * num_cus(), np_chunk_knob(), np_union_knob(), (int)run_cap, qtab,
+                       p.G, (int)pv.cap, ul, pv.hdr, plan_items_per_leader(p), 2 * num_cus(), np_chunk_knob(), np_union_knob(), (int)run_cap, qtab,
                        par, dims, pv.row_q, (int)pv.rows);
     rc = check_launch("flatten units launch");
     if (rc) return rc;
@@ -1142,7 +1147,7 @@ static int launch_node_plan(const Stage1Params& p, int NE, int64_t rows_cap, con
     if (!par)
         while (sizeof(int) * (3 * (size_t)run_cap + 8) > UNIT_LDS && run_cap > 1) run_cap /= 2;
     hipLaunchKernelGGL(node_units_kernel, dim3(1), dim3(1024), sizeof(int) * ((par ? 8 : 3) * (size_t)run_cap + 8), stream,
-                       p.node_kv_len, p.node_q_len, NE, p.G, (int)pv.cap, rows_cap, ul, pv.hdr, pv.row_q, p.Hkv,
+                       p.node_kv_len, p.node_q_len, NE, p.G, (int)pv.cap, rows_cap, ul, pv.hdr, pv.row_q, plan_items_per_leader(p),
                        2 * num_cus(), np_chunk_knob(), (int)run_cap, par, keep_err, dims);
     rc = check_launch("node units launch");
     if (rc) return rc;
