@@ -248,10 +248,10 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
 
     for (bool first = true;; first = false) {
     if (DBG) t_start = wall_clock64();
-    rec0 = item / HP;
-    kvh = item - rec0 * HP;  // (HD2: the head PAIR)
+    // (wave-uniform by construction, made so explicitly: the quotient comes out of the vector ALU)
+    rec0 = __builtin_amdgcn_readfirstlane(item / HP);
+    kvh = __builtin_amdgcn_readfirstlane(item - (item / HP) * HP);  // (HD2: the head PAIR)
     const char* rec_lead = np.plan + (int64_t)rec0 * PLAN_BYTES;
-    const int32_t* desc0 = reinterpret_cast<const int32_t*>(rec_lead + PLAN_DESC);
     // The workgroups that are resident when the launch starts set the ramp: for them tile 0's offsets / masks /
     // partial rows are requested (LDS-DMA) before anything is known about the record -- its address only depends
     // on the block index, every record slot of the grid is allocated memory -- so that the leader count, the
@@ -262,22 +262,28 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
         if (w == 0) dma4(rec_lead + PLAN_OROW + 4 * (l & 31), SM::OROW_OFF);
         issue_aux(0, 0);
     }
+    // The descriptor (and, once, the leader count) by hand-written SCALAR loads, all in flight together, one wait.  Left to the
+    // compiler these are vector loads -- the kernel's own stores might alias them -- each followed by s_waitcnt vmcnt(0): two or
+    // three dependent round trips in front of every work item (round 3: seen in the ISA; a workgroup's ramp was 1.7-2.2 us).
+    typedef int32_t int8v __attribute__((ext_vector_type(8)));
+    int8v dsc;
     if (first) {
-        const int nl = np.hdr[1];
-        const int d4 = desc0[4], d0 = desc0[0], d5 = desc0[5];  // speculative for slots beyond the leaders: valid memory
-        NI = __builtin_amdgcn_readfirstlane(nl) * HP;
-        if (item >= NI) {  // this record slot leads no chunk: merge duty (single-launch decode) or nothing
+        int32_t nl;
+        asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dword %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&s"(dsc), "=&s"(nl)
+                     : "s"(rec_lead + PLAN_DESC), "s"(np.hdr + 1)
+                     : "memory");
+        NI = nl * HP;
+        if (item >= NI) {  // this record slot leads no chunk (speculative read of valid memory): nothing to do
             if (spec) wait_vm<0>();
             break;
         }
-        sd4 = __builtin_amdgcn_readfirstlane(d4);
-        sd0 = __builtin_amdgcn_readfirstlane(d0);
-        sd5 = __builtin_amdgcn_readfirstlane(d5);
     } else {
-        sd4 = __builtin_amdgcn_readfirstlane(desc0[4]);
-        sd0 = __builtin_amdgcn_readfirstlane(desc0[0]);
-        sd5 = __builtin_amdgcn_readfirstlane(desc0[5]);
+        asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(dsc) : "s"(rec_lead + PLAN_DESC) : "memory");
     }
+    sd4 = dsc[4];
+    sd0 = dsc[0];
+    sd5 = dsc[5];
     const int n = sd4;  // tiles of this chunk (> 0: items only name leaders)
     const int nv = sd0;
     fb = sd5;
