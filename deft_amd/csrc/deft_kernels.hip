@@ -622,7 +622,8 @@ static int np_union_knob() { return knob("DEFT_NP_UNION", 0); }  // leaf tiles p
 // Work items of stage 1 per chunk leader, for the plan's chunk-length rules (they weigh the number of workgroups against the
 // resident slots): one per KV head -- per head PAIR where stage 1 will run head_dim 64 two heads to a row (hd2_geometry).  The plan
 // calls carry no head_dim; the q head stride does (64 elements = contiguous heads of 64).  Only the rules depend on it.
-static int plan_items_per_leader(const Stage1Params& p) { return (p.q_sh == 64 && p.Hkv % 2 == 0) ? p.Hkv / 2 : p.Hkv; }
+// (head pairs are passed NEGATED: np_record_order)
+static int plan_items_per_leader(const Stage1Params& p) { return (p.q_sh == 64 && p.Hkv % 2 == 0) ? -(p.Hkv / 2) : p.Hkv; }
 
 // Flatten plan: unit list (one workgroup) then one record per unit.
 static int launch_plan(const Stage1Params& p, int NB, const PlanView& pv, const AppendArgs& ap, hipStream_t stream,

@@ -96,8 +96,14 @@ struct RunTable {
 
 constexpr int LONG_CHUNK = 4;  // tiles per chunk from which a chunk's leader is dispatched ahead of the short ones
 
+// `Hkv` = stage-1 work items per chunk leader: KV heads -- or, NEGATED, head PAIRS (head_dim 64 runs two heads to a pool row,
+// stage1_np.h HD2: half as many items as heads, each with two softmaxes' worth of arithmetic per tile, so its launches are
+// short of workgroups where the head_dim-128 launch of the same tree is not -- chunk lengths follow the GQA rule and then
+// shrink until the launch has 3/4 of a workgroup per resident slot).
 __device__ inline void np_record_order(const UnitList& ul, int R, int Hkv, int G, int slots, int chunk_c, int32_t* hdr,
                                        RunTable rt) {
+    const bool pairs = Hkv < 0;
+    Hkv = pairs ? -Hkv : Hkv;
     if (rt.n > rt.cap) {  // rebuild the table is impossible: scan (slow path, huge trees only)
         rt.n = 0;
         rt.cap = 0;
@@ -132,7 +138,7 @@ __device__ inline void np_record_order(const UnitList& ul, int R, int Hkv, int G
         // alone at the end (Llama-3 north-star tree: 2.8 tiles per slot, 8-tile chunks ran 18 us of a 25 us launch
         // with a quarter of the slots occupied; 4-tile chunks: 19.9 us).  MHA, every tile from HBM, measured the
         // other way (1-token branches, 2 tiles per slot: 8-tile chunks 19.1 us, 4-tile chunks 21.0).
-        if (G > 1) {
+        if (G > 1 || pairs) {
             int64_t tiles_all = 0;
             for_runs([&](int, int nt, int) { tiles_all += nt; });
             int cmax = 1;
@@ -142,7 +148,7 @@ __device__ inline void np_record_order(const UnitList& ul, int R, int Hkv, int G
         for (; C > 1; C >>= 1) {
             int64_t n = 0;
             for_runs([&](int, int nt, int uni) { n += uni ? 1 : (nt + C - 1) / C; });
-            if (10 * n * Hkv >= 3LL * slots) break;
+            if ((pairs ? 4 : 10) * n * Hkv >= 3LL * slots) break;
         }
         // ... but no run is cut into more than 16 chunks while chunks may still grow (<= 8 tiles): every chunk of a
         // shared prefix is one more partial row for EVERY query below it, and the merge reads its rows 16 at a time
@@ -196,6 +202,8 @@ __device__ inline void np_record_order(const UnitList& ul, int R, int Hkv, int G
 __device__ inline void record_order_parallel(const UnitList& ul, const RunTable& rt, int NR, int* rT0, int* rSp, int* sMeta,
                                              int32_t* hdr, int Hkv, int G, int slots, int chunk_c) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const bool pairs = Hkv < 0;  // (np_record_order: head pairs)
+    Hkv = pairs ? -Hkv : Hkv;
     __syncthreads();  // (rT0 / rSp are reused below)
     // Wave 0: chunk length C from sums / maxima over the runs, then each run's first leader and first follower record
     // by prefix sums over the runs' chunk counts.
@@ -213,7 +221,7 @@ __device__ inline void record_order_parallel(const UnitList& ul, const RunTable&
                 if (!rt.uni[k] && rt.nt[k] > lmax) lmax = rt.nt[k];
             for (int m = 32; m > 0; m >>= 1) lmax = max(lmax, __shfl_xor(lmax, m, 64));
             C = lmax >= 32 ? 8 : (lmax >= 8 ? 4 : (lmax >= 4 ? 2 : 1));
-            if (G > 1) {
+            if (G > 1 || pairs) {
                 const int64_t tiles_all = wave_sum([](int nt, int) { return nt; });
                 int cmax = 1;
                 while (cmax < 8 && (int64_t)cmax * slots < tiles_all * Hkv) cmax <<= 1;
@@ -221,7 +229,7 @@ __device__ inline void record_order_parallel(const UnitList& ul, const RunTable&
             }
             for (; C > 1; C >>= 1) {
                 const int64_t n = wave_sum([C](int nt, int uni) { return uni ? 1 : (nt + C - 1) / C; });
-                if (10 * n * Hkv >= 3LL * slots) break;
+                if ((pairs ? 4 : 10) * n * Hkv >= 3LL * slots) break;
             }
             while (C < 8 && lmax > 16 * C) C <<= 1;  // (np_record_order: at most 16 chunks per run while C < 8)
             if (C > 2 && lmax <= 16 * (C - 1)) {       // (np_record_order: fill the CUs of a launch that leaves some empty)
@@ -417,7 +425,8 @@ __global__ __launch_bounds__(1024) void flatten_units_kernel(const int64_t* bloc
     auto union_len_at = [&](int t) {
         (void)t;
         int ulen = union_len;
-        if (ulen <= 0) ulen = G > 1 ? 1 : ((int64_t)NB * Hkv < 2048 ? 4 : 3);  // measured, tools/np_sweep.sh / tools/ab.py
+        // (head pairs, Hkv < 0: groups of two -- their launches want workgroups, tools/ab_step.py on the head_dim-64 north-star tree)
+        if (ulen <= 0) ulen = G > 1 ? 1 : (Hkv < 0 ? 2 : ((int64_t)NB * Hkv < 2048 ? 4 : 3));  // measured, tools/np_sweep.sh / tools/ab.py
         return ulen;
     };
     if (np && ucap >= 2)
