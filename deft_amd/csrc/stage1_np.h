@@ -541,6 +541,9 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
     const int k4 = 8 * w + (l & 7);
     const int hh_out = HD2 ? (w >> 1) : 0;
     const int64_t head_rows = (int64_t)((HD2 ? 2 * kvh + hh_out : kvh)) * p.G * p.rows;
+    // (the four groups of eight rows are independent: unrolled, their LDS reads are in flight together -- a lone wave per SIMD,
+    //  the regime of the small trees, otherwise walks four dependent read -> exp2 -> sum chains one after the other)
+#pragma unroll 4
     for (int q0 = 0; q0 < nv; q0 += 8) {
         const int qr = q0 + (l >> 3);
         if (qr < nv) {
