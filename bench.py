@@ -290,7 +290,12 @@ class Bench:
         host_s = time.perf_counter() - t0
         torch.cuda.synchronize(self.device)
         wall_s = time.perf_counter() - t0
+        lens = [len(lf.kv_indices) for lf in tree.leaves.values()]
+        end_len = sum(lens) / max(len(lens), 1)
         return {"steps": steps, "ms_per_step": round(wall_s / steps * 1e3, 4), "tokens_per_s": round(self.nq / (wall_s / steps), 1),
+                # (the tree GROWS in this loop: its leaves averaged this many tokens over the timed steps -- compare with a frozen
+                #  step of THAT tree, `frozen_step_at_mean_len` below, not with the headline's shorter one)
+                "mean_branch_len": round(end_len - (steps - 1) / 2.0, 1),
                 "gpu_ms_per_step": round(e0.elapsed_time(e1) / steps, 4), "host_ms_per_step": round(host_s / steps * 1e3, 4),
                 "launch": "one hipGraph per structural epoch of the tree (deft_amd.FlattenDecodeSession)" if graphed
                           else "eager (tree.alloc, TreeMetadata.from_tree_cache, DeFTAttention.forward per layer)"}
@@ -530,6 +535,9 @@ def main():
     ap.add_argument("--no-e2e", action="store_true", help="skip the advancing-tree end-to-end loop")
     ap.add_argument("--no-cfg5", action="store_true", help="skip the sharded-forest (BASELINE configs[4]) measurement")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
+    ap.add_argument("--step-only", action="store_true",
+                    help="run the timed step graph and nothing else (no stage-1-only sweeps, percentiles, plan timing): for "
+                         "`rocprofv3 --kernel-trace --stats`, so that the per-kernel averages are those of the STEP's launches")
     ap.add_argument("--dist-backend", default="nccl", choices=("nccl", "gloo"),
                     help="process-group backend of the N > 1 bracket (barrier + MAX of the step time; the data path has no "
                          "collective).  nccl = RCCL, one rank per GPU.  gloo: control plane over TCP, and ranks beyond the visible "
@@ -582,6 +590,13 @@ def main():
         if w.mode == "flatten":
             b.time_stage1(reps=1)
         return
+    if args.step_only:
+        if rank == 0:
+            print(json.dumps({"metric": "tree_tokens_per_s", "value": round(tokens_per_s, 1), "unit": "tokens/s", "n_gpus": n_gpus,
+                              "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+                              "attention_latency_us_per_layer": round(ms_per_step * 1e3 / layers, 2),
+                              "note": "--step-only: the step graph alone (for kernel-trace statistics)"}), flush=True)
+        return
 
     s1 = b.time_stage1(reps=3)
     pct = b.step_percentiles(min(args.steps, 200))
@@ -629,6 +644,23 @@ def main():
                 del be
             except Exception as e:
                 e2e[key] = {"error": f"{type(e).__name__}: {e}"}
+        try:  # the attention-only replay of a FROZEN step of the tree the loop averaged over: what the loop's steps cost without
+            # the per-step work around the attention launches (slot upload, tree advance, TreeMetadata, plan)
+            mean_len = e2e.get("graphed", {}).get("mean_branch_len")
+            if mean_len and w.kind == "few_shot":
+                torch.cuda.empty_cache()
+                bf = Bench(Workload(**{**w.__dict__, "branch_len": int(round(mean_len))}), layers, device, seed=7)
+                bf.prepare(use_graph=not args.no_graph)
+                nf = min(50, max(10, args.steps // 4))
+                dtf = run_timed(bf, nf, 5, False)
+                fz = dtf / nf * 1e3
+                e2e["frozen_step_at_mean_len"] = {"branch_len": int(round(mean_len)), "ms_per_step": round(fz, 4), "steps": nf}
+                for key in ("graphed", "eager"):
+                    if isinstance(e2e.get(key), dict) and "ms_per_step" in e2e[key]:
+                        e2e[key]["over_frozen_step_at_mean_len"] = round(e2e[key]["ms_per_step"] / fz, 4)
+                del bf
+        except Exception as e:
+            e2e["frozen_step_at_mean_len"] = {"error": f"{type(e).__name__}: {e}"}
 
     extras = {}
     if not args.no_extras and rank == 0 and not dist_on:
@@ -715,6 +747,10 @@ def main():
                        "timed_region": "attention-only replay of ONE frozen decode step (hipGraph of 32 x (fused append, stage 1, "
                                        "merge)); metadata / plan of that step are built before it; `end_to_end` below is the "
                                        "advancing-tree loop with them inside"},
+            "value_definition": "queries per step x n_gpus / (wall clock of the K timed steps / K): the steps are replayed back to "
+                                "back from one hipGraph between two device synchronisations (the driver's contract); "
+                                "`step_time_percentiles` brackets EVERY step with its own HIP event pair, which adds ~10 us of "
+                                "event work per step -- the wall-clock mean is the headline, the percentiles show the spread",
             "attention_latency_us_per_step": round(ms_per_step * 1e3, 1),
             "attention_latency_us_per_layer": round(ms_per_step * 1e3 / layers, 2),
             "step_time_percentiles": pct,

@@ -788,9 +788,15 @@ class TreeMetadata:
         max_block_len: int = -1,
         device: Optional[str] = None,
         device_build: Optional[bool] = None,
+        copy: bool = False,
     ) -> "TreeMetadata":
         """`device_build` (GPU pools): None / True = the arrays are built on the GPU from the device copy of the tree;
-        False = by the host builder and uploaded in one copy (the round-1 path, kept as the checker)."""
+        False = by the host builder and uploaded in one copy (the round-1 path, kept as the checker).
+
+        ALIASING (device build): the twelve tensors are VIEWS of the tree's per-epoch output buffer -- the next
+        `from_tree_cache` of the same tree (the next decode step) overwrites them; the reference returns fresh tensors every
+        call (tree_cache.py:813-857).  A decode loop consumes a step's metadata before it builds the next one; a caller that
+        keeps metadata ACROSS steps passes `copy=True` (twelve small device-to-device copies on the current stream)."""
         assert tree.root is not None
         block_len = BLOCK_CONFIG["BLOCK_LEN"]
         if max_block_len == -1:
@@ -803,6 +809,8 @@ class TreeMetadata:
             if dt is None or dt.device != dev or dt.cfg != (int(max_q_len), int(block_len), int(max_block_len)):
                 dt = tree._device_tree = _DeviceTree(tree, dev, max_q_len, block_len, max_block_len)
             views = dt.build()
+            if copy:
+                views = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in views.items()}
             return cls(block_len=block_len, **views)
         if dev.type == "cpu":
             host = build_metadata_host(tree, max_q_len, block_len, max_block_len)

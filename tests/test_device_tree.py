@@ -181,3 +181,31 @@ def test_speculative_decoding_steps_stay_in_one_epoch():
         assert len(tree.root.kv_indices) > 1016 + 60
     finally:
         tc._DeviceTree._upload = orig
+
+
+def test_device_built_metadata_aliases_unless_copied():
+    """Device-built TreeMetadata tensors are views of the tree's per-epoch buffer: the next build of the same
+    tree overwrites them; `copy=True` returns tensors of their own, as the reference does."""
+    Hkv, D = 1, 128
+    req = deft_amd.ReqToTokenPool(16, 2048, device="cuda")
+    pool = deft_amd.TokenToKVPool(2048, torch.float16, Hkv, D, 1, device="cuda")
+    tree = deft_amd.TreeCache(torch.float16, Hkv, D, 1, req, pool, None, True, False)
+    tree.init_prompt(torch.arange(1, 201, dtype=torch.int32))
+    tree.branch(tree.root, 3)
+
+    def step():
+        for leaf in tree.leaves.values():
+            leaf.append_token(7)
+        tree.alloc()
+
+    step()
+    kept = deft_amd.TreeMetadata.from_tree_cache(tree, copy=True)
+    view = deft_amd.TreeMetadata.from_tree_cache(tree)
+    before = kept.block_kv.clone()
+    assert torch.equal(view.block_kv, before) and view.block_kv.data_ptr() != kept.block_kv.data_ptr()
+    step()
+    nxt = deft_amd.TreeMetadata.from_tree_cache(tree)
+    torch.cuda.synchronize()
+    assert torch.equal(kept.block_kv, before)            # the copy kept its step
+    assert nxt.block_kv.data_ptr() == view.block_kv.data_ptr()  # same buffer: `view` now shows the new step
+    assert not torch.equal(view.block_kv[: before.shape[0]], before)

@@ -1,26 +1,47 @@
 #!/bin/bash
 # End-of-round evidence on ONE MI355X box (run as `gpurun -- bash tools/end_of_round.sh [tag]`): replay tables, the default
-# bench line, the rocprofv3 kernel-trace summary of the same command and the two PMC passes (own runs, --kernel-trace
-# only).  Writes gpurun_out/<tag>/<tag>_*; the files judged are copied from there into profiles/ (see profiles/README.md).
-TAG=${1:-r2z}
+# bench line, the rocprofv3 kernel-trace summary of the STEP graph alone and the two PMC passes (own runs, --kernel-trace
+# only), the two-rank rehearsal of the N > 1 path over gloo, the fuzzers.  Writes gpurun_out/<tag>/<tag>_*; the files judged are
+# copied from there into profiles/ (see profiles/README.md).
+TAG=${1:-r3z}
 R=$GRAFT_REPO_ROOT; export PYTHONPATH=$R; O=$R/gpurun_out/$TAG; mkdir -p $O
 cd $R
+# replays: through the captured session (default) -- per-step synchronised (per-step attention times) and pipelined (the loop as a
+# caller sees it) -- and the eager calls for comparison
 timeout 300 python tools/replay.py --task few_shot --width 32 --prompt-len 4096 --max-gen-len 200 --out $O/${TAG}_replay_few_shot_4kx32.json > $O/replay_fs.log 2>&1
 timeout 300 python tools/replay.py --task few_shot --width 32 --prompt-len 4096 --max-gen-len 200 --modes flatten --pipelined --out $O/${TAG}_replay_few_shot_4kx32_pipelined.json > $O/replay_fsp.log 2>&1
 timeout 300 python tools/replay.py --task reasoning --out $O/${TAG}_replay_reasoning_tot50.json > $O/replay_tot.log 2>&1
+timeout 300 python tools/replay.py --task reasoning --modes flatten node --pipelined --out $O/${TAG}_replay_reasoning_tot50_pipelined.json > $O/replay_totp.log 2>&1
 timeout 300 python tools/replay.py --task reasoning --model llama3-8b --out $O/${TAG}_replay_reasoning_tot50_llama3.json > $O/replay_tot3.log 2>&1
 timeout 300 python tools/replay.py --task speculative_decoding --modes node flatten seq --tree-size 64 --out $O/${TAG}_replay_speculative_64.json > $O/replay_sd.log 2>&1
+timeout 300 python tools/replay.py --task speculative_decoding --modes node flatten --tree-size 64 --pipelined --out $O/${TAG}_replay_speculative_64_pipelined.json > $O/replay_sdp.log 2>&1
+timeout 300 python tools/replay.py --task speculative_decoding --modes node flatten --tree-size 64 --eager --out $O/${TAG}_replay_speculative_64_eager.json > $O/replay_sde.log 2>&1
 timeout 900 python bench.py > $O/${TAG}_bench_default.json 2> $O/bench.err
+# the N > 1 path on one GPU: two ranks over gloo (RCCL needs a GPU per rank; the driver's 8-GPU run uses it)
+timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --dist-backend gloo --steps 50 --warmup 10 --no-extras --no-cpu-baseline --no-traffic 2> $O/bench_2rank.err | grep '^{' > $O/${TAG}_bench_2rank_gloo_one_gpu.json
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_$TAG -- python $R/bench.py --steps 50 --warmup 5 --no-extras --no-cpu-baseline --no-traffic --no-e2e --no-cfg5 > $O/${TAG}_bench_under_rocprof_stats.json 2> $O/rocprof.err
+# per-kernel averages of the STEP graph alone (no stage-1-only sweeps, no eager percentiles): sum of the two averages <= step time / layers
+timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_$TAG -- python $R/bench.py --steps 100 --warmup 10 --step-only > $O/${TAG}_bench_under_rocprof_stats.json 2> $O/rocprof.err
 python $R/tools/prof_summary.py /tmp/prof_$TAG > $O/${TAG}_kernel_stats.txt 2>&1
 tail -c 600 $O/${TAG}_bench_default.json | head -c 300; echo; head -8 $O/${TAG}_kernel_stats.txt | cut -c1-160
+# the small BASELINE configurations under the kernel trace (configs[2], configs[3]) and head_dim 64
+for wl in medusa64_node tot50_4k gqa_4kx32 northstar_4kx32_d64; do
+  timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_${TAG}_$wl -- python $R/bench.py --workload $wl --steps 100 --warmup 10 --step-only > /dev/null 2>&1
+  python $R/tools/prof_summary.py /tmp/prof_${TAG}_$wl 2>&1 | head -6 | cut -c1-160 > $O/${TAG}_kernel_stats_$wl.txt
+done
 # HBM traffic of the same command: PMC counters, one pass each, with --kernel-trace only (MI355X_MICROARCH.md "HBM")
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -- python $R/bench.py --steps 10 --warmup 2 --no-extras --no-cpu-baseline --no-traffic --no-e2e --no-cfg5 > /dev/null 2> $O/pmc_$c.err
+  timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -- python $R/bench.py --steps 10 --warmup 2 --step-only > /dev/null 2> $O/pmc_$c.err
   python $R/tools/pmc_summary.py /tmp/pmc_$c > $O/${TAG}_pmc_$(echo $c | tr A-Z a-z).json 2>> $O/pmc_$c.err
 done
 grep -A3 stage1_np $O/${TAG}_pmc_fetch_size.json | head -5; grep -A3 stage1_np $O/${TAG}_pmc_write_size.json | head -5
 # the whole decode step with the tree advancing, under the kernel trace: what a step costs kernel by kernel
 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_rp_$TAG -- python $R/tools/replay.py --task few_shot --width 32 --prompt-len 4096 --max-gen-len 200 --modes flatten --no-warmup > /dev/null 2>&1
 python $R/tools/prof_summary.py /tmp/prof_rp_$TAG 2>&1 | head -18 | cut -c1-160 > $O/${TAG}_replay_kernel_stats.txt
+timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_sd_$TAG -- python $R/tools/replay.py --task speculative_decoding --modes flatten --tree-size 64 --pipelined --no-warmup > /dev/null 2>&1
+python $R/tools/prof_summary.py /tmp/prof_sd_$TAG 2>&1 | head -18 | cut -c1-160 > $O/${TAG}_replay_speculative_kernel_stats.txt
+cd $R
+# fuzzers: the captured loop against the eager path bit for bit (with speculative-decoding merge / reset steps); every step of random
+# replays against fp64 attention
+(timeout 400 python tools/fuzz_session.py 240 ${FUZZ_SEED:-31} 2>&1 | tail -2; timeout 300 python tools/fuzz_replay.py 180 ${FUZZ_SEED:-31} 2>&1 | tail -2) > $O/${TAG}_fuzz.txt
+cat $O/${TAG}_fuzz.txt
