@@ -127,11 +127,15 @@ __device__ inline void tree_apply_ops(const TreeDev& t, const int32_t* ops, int3
                 if (tid < k) {
                     const int v = sNew[tid];
                     int lo = 0, hi = len;  // first existing slot >= v
-                    while (lo < hi) {
-                        const int mid = (lo + hi) >> 1;
-                        if (s[mid] < v) lo = mid + 1;
-                        else hi = mid;
-                    }
+                    // (a pool hands out ascending slots, so the new one usually goes behind the node's last: ONE load decides
+                    //  that; the binary search is eleven dependent loads on a 1000-token node, 8 us of a decode step)
+                    if (len == 0 || s[len - 1] < v) lo = len;
+                    else
+                        while (lo < hi) {
+                            const int mid = (lo + hi) >> 1;
+                            if (s[mid] < v) lo = mid + 1;
+                            else hi = mid;
+                        }
                     sPos[tid] = lo;
                     if (tid == 0) sMeta[0] = lo;  // first insertion point: nothing in front of it moves
                 }
@@ -350,7 +354,14 @@ __device__ inline int rank_below(const unsigned long long* u, int q) {
     return c + __popcll(u[q >> 6] & ((1ull << (q & 63)) - 1ull));
 }
 
+// The masks of a block's positions depend on the position's NODE only (bit = rank of a leaf of the node among the block's
+// query list, per chunk of max_q_len): they are computed once per (node of the block, chunk) into an LDS table -- a thread per
+// node -- and every position looks its node's up.  (Computing them per position repeated the walk over the node's leaf set 128
+// times: 18 us per step on a Medusa-64 tree, whose root's 64 leaves are ranked for every one of its positions.)
+constexpr int BLK_TAB_NODES = 128, BLK_TAB_CHUNKS = 8;
+
 __global__ __launch_bounds__(128) void tree_md_blocks_kernel(TreeDev t, TreeScratch s, TreeMdOut o, int max_q_len, int block_len) {
+    __shared__ long long sMask[BLK_TAB_NODES * BLK_TAB_CHUNKS];
     const int b = blockIdx.x;
     if (s.dims[TREE_ERR] || b >= s.dims[8]) return;
     const int nqw = t.nqw, n = t.n;
@@ -360,28 +371,45 @@ __global__ __launch_bounds__(128) void tree_md_blocks_kernel(TreeDev t, TreeScra
     const int nqs = refs_count(uni, nqw);
     const int chunks = (nqs + max_q_len - 1) / max_q_len;
     const int e0 = s.b_eoff[b], p0 = s.b_poff[b];
+    // mask of node j for chunk c: rows of the chunk = union ranks [c * max_q_len, (c + 1) * max_q_len)
+    auto node_mask = [&](int j, int c) {
+        long long mask = 0;
+        const unsigned long long* rj = t.refs + (size_t)j * nqw;
+        for (int w = 0; w < nqw; ++w) {
+            unsigned long long x = rj[w];
+            while (x) {
+                const int q = 64 * w + __ffsll((long long)x) - 1;
+                x &= x - 1;
+                const int rk = rank_below(uni, q) - c * max_q_len;
+                if (rk >= 0 && rk < max_q_len) mask |= (long long)1 << rk;
+            }
+        }
+        return mask;
+    };
+    // the nodes that have a position in this block: j0 .. j0 + nn - 1 (empty nodes in between included: never looked up)
+    const int j0 = s.b_first[b];
+    int j1 = j0;
+    while (j1 + 1 < n && s.pos[j1 + 1] < lo + cur_len) ++j1;
+    const int nn = j1 - j0 + 1;
+    const bool tab = nn <= BLK_TAB_NODES && chunks <= BLK_TAB_CHUNKS;
+    if (tab) {
+        for (int x = threadIdx.x; x < nn * chunks; x += blockDim.x) {
+            const int jj = x / chunks, c = x - jj * chunks;
+            sMask[jj * BLK_TAB_CHUNKS + c] = node_mask(j0 + jj, c);
+        }
+        __syncthreads();
+    }
     for (int k = threadIdx.x; k < block_len; k += blockDim.x) {
         int64_t slot = -1;
         int j = -1;
         if (k < cur_len) {
-            j = s.b_first[b];
+            j = j0;
             while (j + 1 < n && s.pos[j + 1] <= lo + k) ++j;  // (a block touches few nodes; empty nodes are skipped)
             slot = t.slots[t.node_start[j] + (lo + k - s.pos[j])];
         }
         for (int c = 0; c < chunks; ++c) {
             int64_t mask = 0;
-            if (j >= 0) {  // rows of this chunk = union ranks [c * max_q_len, (c + 1) * max_q_len)
-                const unsigned long long* rj = t.refs + (size_t)j * nqw;
-                for (int w = 0; w < nqw; ++w) {
-                    unsigned long long x = rj[w];
-                    while (x) {
-                        const int q = 64 * w + __ffsll((long long)x) - 1;
-                        x &= x - 1;
-                        const int rk = rank_below(uni, q) - c * max_q_len;
-                        if (rk >= 0 && rk < max_q_len) mask |= (int64_t)1 << rk;
-                    }
-                }
-            }
+            if (j >= 0) mask = tab ? sMask[(j - j0) * BLK_TAB_CHUNKS + c] : node_mask(j, c);
             o.block_kv[(int64_t)(e0 + c) * block_len + k] = slot;
             o.block_bitmasks[(int64_t)(e0 + c) * block_len + k] = mask;
         }
