@@ -1894,8 +1894,8 @@ static int tree_dev_build_md_impl(int n_nodes, int nq, int nqw, const int32_t* n
         scan_lds = sizeof(int32_t) * 6 * ((size_t)n_nodes + 1);
         if (nbp_cap <= TREE_LDS_BLOCKS) scan_lds += sizeof(int32_t) * ((size_t)nbp_cap + 1);
     }
-    // (dynamic part: at most 6 x 4097 + 8193 words = 131 KB of tables, next to 8 KB of static LDS for the journal replay)
-    int rc = raise_lds(reinterpret_cast<const void*>(&tree_md_scan_kernel), 144 * 1024, ATTR_TREE, "tree_md_scan");
+    // (dynamic part: at most 6 x 4097 + 8193 words = 131 KB of tables, next to 16 KB of static LDS for the journal replay)
+    int rc = raise_lds(reinterpret_cast<const void*>(&tree_md_scan_kernel), 136 * 1024, ATTR_TREE, "tree_md_scan");
     if (rc) return rc;
     hipLaunchKernelGGL(tree_md_scan_kernel, dim3(1), dim3(1024), scan_lds, st, t, sc, max_q_len, block_len, max_block_len, nbp_cap,
                        advance_loc, ops);

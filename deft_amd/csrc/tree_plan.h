@@ -83,9 +83,18 @@ __global__ __launch_bounds__(256) void tree_advance_kernel(TreeDev t, const int3
 // What the reference's speculative-decoding mock does every step -- the accepted leaves' slots squeezed into the root, every
 // leaf's KV released (branch_func_example.py:420-437) -- is one EXTEND and nq RESETs, and the step stays inside its epoch.
 constexpr int TREE_OPS_NEW = 1024;  // slots per EXTEND (longer ones are split by the host)
-__device__ inline void tree_apply_ops(const TreeDev& t, const int32_t* ops, int32_t* err, int* sNew, int* sPos, int* sMeta) {
+constexpr int TREE_OPS_LDS = 2048;  // journal words staged in LDS (longer journals are parsed where they lie)
+__device__ inline void tree_apply_ops(const TreeDev& t, const int32_t* ops_g, int32_t* err, int* sNew, int* sPos, int* sMeta,
+                                      int* sOps) {
     const int tid = threadIdx.x;
-    const int words = ops[0];
+    const int words = ops_g[0];
+    // the journal in LDS by one coalesced read: parsing it word by word in global memory was a dependent round trip per op
+    const int32_t* ops = ops_g;
+    if (words + 1 <= TREE_OPS_LDS) {
+        for (int i = tid; i <= words; i += blockDim.x) sOps[i] = ops_g[i];
+        __syncthreads();
+        ops = sOps;
+    }
     for (int at = 1; at + 2 < words + 1;) {  // (uniform: every thread reads the same words)
         const int op = ops[at], node = ops[at + 1], k = ops[at + 2];
         if (node < 0 || node >= t.n || k < 0 || at + 3 + k > words + 1 || k > TREE_OPS_NEW) {
@@ -171,8 +180,8 @@ __device__ inline void tree_apply_ops(const TreeDev& t, const int32_t* ops, int3
 }
 
 __global__ __launch_bounds__(1024) void tree_ops_kernel(TreeDev t, const int32_t* ops, int32_t* err) {
-    __shared__ int sNew[TREE_OPS_NEW], sPos[TREE_OPS_NEW], sMeta[4];
-    tree_apply_ops(t, ops, err, sNew, sPos, sMeta);
+    __shared__ int sNew[TREE_OPS_NEW], sPos[TREE_OPS_NEW], sMeta[4], sOps[TREE_OPS_LDS];
+    tree_apply_ops(t, ops, err, sNew, sPos, sMeta, sOps);
 }
 
 // exclusive scan of f(i), i < m, into out[0 .. m] by the whole workgroup (1024 threads, chunks of 1024 with a carry)
@@ -225,8 +234,8 @@ __global__ __launch_bounds__(1024) void tree_md_scan_kernel(TreeDev t, TreeScrat
     const int n = t.n, nqw = t.nqw;
     const int tid = threadIdx.x;
     if (ops && ops[0] > 0) {  // the journal of this step's absorbed changes first (uniform branch), then the step's new slots
-        __shared__ int sNew[TREE_OPS_NEW], sPos[TREE_OPS_NEW], sMeta[4];
-        tree_apply_ops(t, ops, s.dims + TREE_ERR, sNew, sPos, sMeta);
+        __shared__ int sNew[TREE_OPS_NEW], sPos[TREE_OPS_NEW], sMeta[4], sOps[TREE_OPS_LDS];
+        tree_apply_ops(t, ops, s.dims + TREE_ERR, sNew, sPos, sMeta, sOps);
     }
     if (cache_loc) {  // advance: one slot per live leaf, kept ascending inside the node
         for (int r = tid; r < t.nq; r += 1024) {
@@ -362,6 +371,7 @@ constexpr int BLK_TAB_NODES = 128, BLK_TAB_CHUNKS = 8;
 
 __global__ __launch_bounds__(128) void tree_md_blocks_kernel(TreeDev t, TreeScratch s, TreeMdOut o, int max_q_len, int block_len) {
     __shared__ long long sMask[BLK_TAB_NODES * BLK_TAB_CHUNKS];
+    __shared__ int sPosN[BLK_TAB_NODES + 1];  // first flattened position of the block's nodes (and of the node behind them)
     const int b = blockIdx.x;
     if (s.dims[TREE_ERR] || b >= s.dims[8]) return;
     const int nqw = t.nqw, n = t.n;
@@ -397,15 +407,30 @@ __global__ __launch_bounds__(128) void tree_md_blocks_kernel(TreeDev t, TreeScra
             const int jj = x / chunks, c = x - jj * chunks;
             sMask[jj * BLK_TAB_CHUNKS + c] = node_mask(j0 + jj, c);
         }
+        for (int x = threadIdx.x; x <= nn; x += blockDim.x) sPosN[x] = s.pos[j0 + x];  // (pos has n + 1 entries)
         __syncthreads();
     }
     for (int k = threadIdx.x; k < block_len; k += blockDim.x) {
         int64_t slot = -1;
         int j = -1;
         if (k < cur_len) {
-            j = j0;
-            while (j + 1 < n && s.pos[j + 1] <= lo + k) ++j;  // (a block touches few nodes; empty nodes are skipped)
-            slot = t.slots[t.node_start[j] + (lo + k - s.pos[j])];
+            if (tab) {
+                // the LAST node of the block whose first position is <= lo + k (empty nodes share a position with their
+                // successor and are skipped that way): a search in LDS -- walking pos[] node by node in global memory was one
+                // dependent load per node, 64 of them for a block of one-token leaves
+                int a = 0, z = nn - 1;
+                while (a < z) {
+                    const int mid = (a + z + 1) >> 1;
+                    if (sPosN[mid] <= lo + k) a = mid;
+                    else z = mid - 1;
+                }
+                j = j0 + a;
+                slot = t.slots[t.node_start[j] + (lo + k - sPosN[a])];
+            } else {
+                j = j0;
+                while (j + 1 < n && s.pos[j + 1] <= lo + k) ++j;  // (a block touches few nodes; empty nodes are skipped)
+                slot = t.slots[t.node_start[j] + (lo + k - s.pos[j])];
+            }
         }
         for (int c = 0; c < chunks; ++c) {
             int64_t mask = 0;
