@@ -298,26 +298,40 @@ __global__ __launch_bounds__(1024) void tree_md_scan_kernel(TreeDev t, TreeScrat
     int32_t* b_cnt = blk_lds ? nqc + (n + 1) : nullptr;  // [nbp] union size per block
     // physical blocks: first node with a slot in the block (largest i with pos[i] <= lo among nodes that have slots),
     // union of the leaf sets of its nodes
-    for (int b = tid; b < nbp; b += 1024) {
-        const int lo = b * block_len, hi = min(total, lo + block_len);
-        int a = 0, z = n - 1;  // largest i with pos[i] <= lo
-        while (a < z) {
-            const int mid = (a + z + 1) >> 1;
-            if (pos[mid] <= lo) a = mid;
-            else z = mid - 1;
+    // (sixteen lanes per block: the nodes of a block are OR-ed together by the lanes in parallel -- one thread per block walked
+    //  them one global load after the other, 64 of them for the block of one-token leaves of a Medusa-64 step: 15 us of a step)
+    {
+        const int sub = tid & 15, grp = tid >> 4;  // 64 groups of 16 lanes
+        for (int b = grp; b < nbp; b += 64) {
+            const int lo = b * block_len, hi = min(total, lo + block_len);
+            int a = 0, z = n - 1;  // largest i with pos[i] <= lo
+            while (a < z) {
+                const int mid = (a + z + 1) >> 1;
+                if (pos[mid] <= lo) a = mid;
+                else z = mid - 1;
+            }
+            while (a < n && pos[a + 1] <= lo) ++a;  // (skip empty nodes that share the position)
+            int e = a + 1, ze = n;  // first node behind a whose first position is >= hi (n if none)
+            while (e < ze) {
+                const int mid = (e + ze) >> 1;
+                if (pos[mid] >= hi) ze = mid;
+                else e = mid + 1;
+            }
+            unsigned long long* u = s.b_union + (size_t)b * nqw;
+            int cnt = 0;
+            for (int w = 0; w < nqw; ++w) {
+                unsigned long long acc = 0ull;
+                for (int j = a + sub; j < e; j += 16)
+                    if (len_of(j) > 0) acc |= t.refs[(size_t)j * nqw + w];
+                for (int m = 8; m > 0; m >>= 1) acc |= __shfl_xor(acc, m, 16);
+                if (sub == 0) u[w] = acc;
+                cnt += __popcll(acc);
+            }
+            if (sub == 0) {
+                s.b_first[b] = a;
+                if (blk_lds) b_cnt[b] = cnt;
+            }
         }
-        while (a < n && pos[a + 1] <= lo) ++a;  // (skip empty nodes that share the position)
-        s.b_first[b] = a;
-        unsigned long long* u = s.b_union + (size_t)b * nqw;
-        int cnt = 0;
-        for (int w = 0; w < nqw; ++w) {
-            unsigned long long acc = 0ull;
-            for (int j = a; j < n && pos[j] < hi; ++j)
-                if (len_of(j) > 0) acc |= t.refs[(size_t)j * nqw + w];
-            u[w] = acc;
-            cnt += __popcll(acc);
-        }
-        if (blk_lds) b_cnt[b] = cnt;
     }
     __syncthreads();
     auto bcount = [&](int b) { return blk_lds ? b_cnt[b] : refs_count(s.b_union + (size_t)b * nqw, nqw); };
@@ -377,7 +391,14 @@ __global__ __launch_bounds__(128) void tree_md_blocks_kernel(TreeDev t, TreeScra
     const int nqw = t.nqw, n = t.n;
     const int total = s.dims[2];
     const int lo = b * block_len, cur_len = min(block_len, total - lo);
+    // (the block's query list as a bit set, staged in LDS when it is short: every rank below reads it)
+    __shared__ unsigned long long sUni[16];
     const unsigned long long* uni = s.b_union + (size_t)b * nqw;
+    if (nqw <= 16) {
+        if ((int)threadIdx.x < nqw) sUni[threadIdx.x] = uni[threadIdx.x];
+        __syncthreads();
+        uni = sUni;
+    }
     const int nqs = refs_count(uni, nqw);
     const int chunks = (nqs + max_q_len - 1) / max_q_len;
     const int e0 = s.b_eoff[b], p0 = s.b_poff[b];
@@ -398,8 +419,14 @@ __global__ __launch_bounds__(128) void tree_md_blocks_kernel(TreeDev t, TreeScra
     };
     // the nodes that have a position in this block: j0 .. j0 + nn - 1 (empty nodes in between included: never looked up)
     const int j0 = s.b_first[b];
-    int j1 = j0;
-    while (j1 + 1 < n && s.pos[j1 + 1] < lo + cur_len) ++j1;
+    // (the last of them from the NEXT block's first node -- it either straddles the boundary or starts right behind it --
+    //  instead of a walk over pos[], one dependent load per node)
+    int j1 = n - 1;
+    if (b + 1 < s.dims[8]) {
+        const int jn = s.b_first[b + 1];
+        j1 = s.pos[jn] < lo + cur_len ? jn : jn - 1;
+    }
+    if (j1 < j0) j1 = j0;
     const int nn = j1 - j0 + 1;
     const bool tab = nn <= BLK_TAB_NODES && chunks <= BLK_TAB_CHUNKS;
     if (tab) {
