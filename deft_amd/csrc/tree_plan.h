@@ -406,6 +406,13 @@ __global__ __launch_bounds__(128) void tree_md_blocks_kernel(TreeDev t, TreeScra
     auto node_mask = [&](int j, int c) {
         long long mask = 0;
         const unsigned long long* rj = t.refs + (size_t)j * nqw;
+        // a node whose leaves are the whole list (a shared-prefix block): every row of the chunk, no ranking
+        bool all = true;
+        for (int w = 0; w < nqw; ++w) all &= (rj[w] & uni[w]) == uni[w];
+        if (all) {
+            const int cnt = min(max_q_len, nqs - c * max_q_len);
+            return cnt >= 64 ? (long long)-1 : (long long)((1ull << cnt) - 1ull);
+        }
         for (int w = 0; w < nqw; ++w) {
             unsigned long long x = rj[w];
             while (x) {
