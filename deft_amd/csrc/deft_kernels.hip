@@ -1860,7 +1860,8 @@ static int tree_dev_build_md_impl(int n_nodes, int nq, int nqw, const int32_t* n
                            int max_block_len, int nbp_cap, void* scratch, size_t scratch_bytes, int64_t* node_q, int64_t* node_kv,
                            int64_t* node_q_len, int64_t* node_kv_len, int64_t* node_q_offset, int64_t* node_kv_offset,
                            int64_t* block_q, int64_t* block_q_cnts, int64_t* block_q_offset, int64_t* block_bitmasks,
-                           int64_t* block_kv, int64_t* block_lens, const int32_t* advance_loc, const int32_t* ops, void* stream) {
+                           int64_t* block_kv, int64_t* block_lens, const int32_t* advance_loc, const int32_t* ops, PageWrite pw,
+                           void* stream) {
     if (n_nodes <= 0 || nq < 0 || nqw < 1 || nbp_cap < 0 || !node_start || !node_len || !node_cap || !refs || !leaf_node || !slots ||
         !scratch) {
         set_error("deft_tree_dev_build_md: bad arguments (nodes=%d nq=%d)", n_nodes, nq);
@@ -1898,7 +1899,7 @@ static int tree_dev_build_md_impl(int n_nodes, int nq, int nqw, const int32_t* n
     int rc = raise_lds(reinterpret_cast<const void*>(&tree_md_scan_kernel), 136 * 1024, ATTR_TREE, "tree_md_scan");
     if (rc) return rc;
     hipLaunchKernelGGL(tree_md_scan_kernel, dim3(1), dim3(1024), scan_lds, st, t, sc, max_q_len, block_len, max_block_len, nbp_cap,
-                       advance_loc, ops);
+                       advance_loc, ops, pw);
     rc = check_launch("tree scan launch");
     if (rc) return rc;
     if (nbp_cap > 0 && n_block_ptrs) {
@@ -1920,23 +1921,30 @@ int deft_tree_dev_build_md(int n_nodes, int nq, int nqw, const int32_t* node_sta
     return tree_dev_build_md_impl(n_nodes, nq, nqw, node_start, node_len, node_cap, refs, leaf_node, slots, max_q_len, block_len,
                                   max_block_len, nbp_cap, scratch, scratch_bytes, node_q, node_kv, node_q_len, node_kv_len,
                                   node_q_offset, node_kv_offset, block_q, block_q_cnts, block_q_offset, block_bitmasks, block_kv,
-                                  block_lens, advance_loc, nullptr, stream);
+                                  block_lens, advance_loc, nullptr, PageWrite{nullptr, 0, nullptr, nullptr}, stream);
 }
 
 // deft_tree_dev_build_md with the journal replay (deft_tree_dev_apply_ops) folded into its first kernel, in front of the
 // advance: `ops` = device buffer {n, words ...}, read at run time -- n = 0 on a step without absorbed changes -- so that the
-// launch has the same arguments on every step of an epoch (a captured decode step).
+// launch has the same arguments on every step of an epoch (a captured decode step).  `page_table` (nullable, int32
+// [requests][page_stride]): the same kernel also writes the page-table entries of the step's new tokens,
+// page_table[page_rows[r]][page_cols[r]] = advance_loc[r] -- what TreeCache.alloc does with an index_put.
 int deft_tree_dev_build_md_ops(int n_nodes, int nq, int nqw, const int32_t* node_start, int32_t* node_len, const int32_t* node_cap,
                                const uint64_t* refs, const int32_t* leaf_node, int32_t* slots, int max_q_len, int block_len,
                                int max_block_len, int nbp_cap, void* scratch, size_t scratch_bytes, int64_t* node_q,
                                int64_t* node_kv, int64_t* node_q_len, int64_t* node_kv_len, int64_t* node_q_offset,
                                int64_t* node_kv_offset, int64_t* block_q, int64_t* block_q_cnts, int64_t* block_q_offset,
                                int64_t* block_bitmasks, int64_t* block_kv, int64_t* block_lens, const int32_t* advance_loc,
-                               const int32_t* ops, void* stream) {
+                               const int32_t* ops, int32_t* page_table, int64_t page_stride, const int64_t* page_rows,
+                               const int64_t* page_cols, void* stream) {
+    if (page_table && (!advance_loc || !page_rows || !page_cols || page_stride <= 0)) {
+        set_error("deft_tree_dev_build_md_ops: the page-table write needs advance_loc, rows, cols and a row stride");
+        return DEFT_EINVAL;
+    }
     return tree_dev_build_md_impl(n_nodes, nq, nqw, node_start, node_len, node_cap, refs, leaf_node, slots, max_q_len, block_len,
                                   max_block_len, nbp_cap, scratch, scratch_bytes, node_q, node_kv, node_q_len, node_kv_len,
                                   node_q_offset, node_kv_offset, block_q, block_q_cnts, block_q_offset, block_bitmasks, block_kv,
-                                  block_lens, advance_loc, ops, stream);
+                                  block_lens, advance_loc, ops, PageWrite{page_table, page_stride, page_rows, page_cols}, stream);
 }
 
 }  // extern "C"

@@ -218,6 +218,15 @@ __device__ inline int refs_count(const unsigned long long* r, int nqw) {
     return c;
 }
 
+// The page-table rows of a step's new tokens (ReqToTokenPool.req_to_token[row[r], col[r]] = cache_loc[r], what TreeCache.alloc
+// writes with one index_put, tree_cache.py:270-283): folded into the advance -- one launch fewer per captured step.
+struct PageWrite {
+    int32_t* table;        // null: nothing to write
+    int64_t stride;        // elements per page-table row
+    const int64_t* rows;   // [nq] request row of every query
+    const int64_t* cols;   // [nq] position of its new token
+};
+
 // One workgroup.  `adv` (cache_loc != null): first append this step's slots to the leaves (tree_advance_kernel's work,
 // folded in: one launch fewer per step).  The scans run over tables in LDS when the tree fits (TREE_LDS_NODES nodes,
 // TREE_LDS_BLOCKS blocks: every tree but a pathological one) -- a scan whose input and output live in global memory pays
@@ -227,7 +236,7 @@ constexpr int TREE_LDS_BLOCKS = 8192;
 
 __global__ __launch_bounds__(1024) void tree_md_scan_kernel(TreeDev t, TreeScratch s, int max_q_len, int block_len,
                                                             int max_block_len, int nbp_cap, const int32_t* cache_loc,
-                                                            const int32_t* ops) {
+                                                            const int32_t* ops, PageWrite pw) {
     __shared__ int sWave[16];
     __shared__ int sCarry;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -237,6 +246,8 @@ __global__ __launch_bounds__(1024) void tree_md_scan_kernel(TreeDev t, TreeScrat
         __shared__ int sNew[TREE_OPS_NEW], sPos[TREE_OPS_NEW], sMeta[4], sOps[TREE_OPS_LDS];
         tree_apply_ops(t, ops, s.dims + TREE_ERR, sNew, sPos, sMeta, sOps);
     }
+    if (cache_loc && pw.table)
+        for (int r = tid; r < t.nq; r += 1024) pw.table[pw.rows[r] * pw.stride + pw.cols[r]] = cache_loc[r];
     if (cache_loc) {  // advance: one slot per live leaf, kept ascending inside the node
         for (int r = tid; r < t.nq; r += 1024) {
             const int i = t.leaf_node[r];

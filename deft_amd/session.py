@@ -104,7 +104,11 @@ class DecodeSession:
         dt, dev = self.dt, self.device
         stream = torch.cuda.current_stream(dev).cuda_stream
         table = self.tree.req_to_token_pool.req_to_token
-        table[self.idx[0], self.idx[1]] = self.cache_loc  # page table rows of this step's tokens
+        # (page-table entries of this step's tokens: written by the step's first kernel when the table is what the kernel
+        #  expects -- int32, contiguous rows, on this device --, by an index_put otherwise)
+        fold = advance and table.dtype == torch.int32 and table.device == dev and table.dim() == 2 and table.stride(1) == 1
+        if not fold:
+            table[self.idx[0], self.idx[1]] = self.cache_loc
         mq, bl, mbl = dt.cfg
         # (the append of this step's slots to the device tree rides in the first metadata kernel)
         # (only the six arrays this mode's operator reads are written: the kernel of the other group is not launched)
@@ -112,7 +116,9 @@ class DecodeSession:
         # (first the journal of changes the epoch absorbed since the last step -- {0} when there are none --, then the advance)
         check(lib.deft_tree_dev_build_md_ops(*dt._tree_args(), mq, bl, mbl, dt.nbp_cap, dt.scratch.data_ptr(), dt.scratch_bytes,
                                              *[self.md_ptrs[k] if k in wanted else None for k in _FIELDS],
-                                             self.cache_loc.data_ptr() if advance else None, self.ops.data_ptr(), stream),
+                                             self.cache_loc.data_ptr() if advance else None, self.ops.data_ptr(),
+                                             table.data_ptr() if fold else None, table.stride(0) if fold else 0,
+                                             self.idx[0].data_ptr() if fold else None, self.idx[1].data_ptr() if fold else None, stream),
               "deft_tree_dev_build_md_ops")
         Hq, Hkv, D = self.Hq, self.Hkv, self.D
         q0, k0, _ = self.qkv(0)

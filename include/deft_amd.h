@@ -434,7 +434,11 @@ int deft_tree_dev_build_md_ops(int n_nodes, int nq, int nqw, const int32_t* node
                                int64_t* node_kv, int64_t* node_q_len, int64_t* node_kv_len, int64_t* node_q_offset,
                                int64_t* node_kv_offset, int64_t* block_q, int64_t* block_q_cnts, int64_t* block_q_offset,
                                int64_t* block_bitmasks, int64_t* block_kv, int64_t* block_lens,
-                               const int32_t* advance_loc /* nullable */, const int32_t* ops /* nullable */, void* stream);
+                               const int32_t* advance_loc /* nullable */, const int32_t* ops /* nullable */,
+                               /* optional: page_table[page_rows[r] * page_stride + page_cols[r]] = advance_loc[r], r < nq -- the
+                                  page-table write of TreeCache.alloc (tree_cache.py:270-283) in the same kernel */
+                               int32_t* page_table /* nullable */, int64_t page_stride, const int64_t* page_rows,
+                               const int64_t* page_cols, void* stream);
 
 #ifdef __cplusplus
 }
