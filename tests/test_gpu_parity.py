@@ -685,3 +685,55 @@ def test_cfg5_forest_at_full_size_matches_the_single_tree_golden(mode, golden):
     if mode == "flatten":  # the same tree eight times: the same blocks, chunks and fp32 order per tree, so the same bits
         for t in range(1, n_trees):  # (Node mode packs small entries ACROSS neighbouring trees: same values, other order)
             assert np.array_equal(out[8 * t: 8 * t + 8], out[:8]), t
+
+
+@pytest.mark.parametrize("mode", ["flatten", "node"])
+@pytest.mark.parametrize("geom", [(8, 2, 64), (8, 4, 64), (16, 16, 64), (12, 6, 64), (6, 3, 64)])
+@pytest.mark.parametrize("name", ["multilevel", "wide40", "spec_mock"])
+def test_head_dim_64_head_pairs_against_truth(name, geom, mode):
+    """head_dim 64 on the tile-parallel kernel (two adjacent KV heads per 256-byte pool row, stage1_np.h HD2) with GQA, with MHA,
+    with a head-pair count that is not a power of two -- and with an ODD number of KV heads, which keeps the tile-per-workgroup
+    kernel: the module path (paged append fused in) against fp64 per-leaf attention, and against the separate append + operator."""
+    from deft_amd.tree_attention import flatten_append_attention, node_append_attention
+    from deft_amd.utils.synthetic import dyadic_normal
+
+    Hq, Hkv, D = geom
+    outs = []
+    for fused in (True, False):
+        tree = product_tree(name, device="cuda", heads=(Hkv, D))
+        for leaf in list(tree.leaves.values()):
+            leaf.append_token(9)
+        updater = tree.alloc()
+        md = deft_amd.TreeMetadata.from_tree_cache(tree)
+        nq = md.query_num
+        pool = tree.token_to_kv_pool
+        kv = torch.from_numpy(dyadic_normal(tuple(pool.kv_data[0].shape), 21)).cuda()
+        pool.kv_data[0].copy_(kv)
+        q = torch.from_numpy(dyadic_normal((nq, Hq, D), 22)).cuda()
+        k_new = torch.from_numpy(dyadic_normal((nq, Hkv, D), 23)).cuda()
+        v_new = torch.from_numpy(dyadic_normal((nq, Hkv, D), 24)).cuda()
+        o = torch.full((nq, Hq, D), float("nan"), dtype=torch.float16, device="cuda")
+        node_args = (md.node_kv, md.node_kv_offset, md.node_kv_len, md.node_q, md.node_q_offset, md.node_q_len)
+        if fused and mode == "flatten":
+            flatten_append_attention(q, pool.kv_data[0], o, updater.cache_loc, k_new, v_new, *_flatten_args(md))
+        elif fused:
+            node_append_attention(q, pool.kv_data[0], o, updater.cache_loc, k_new, v_new, *node_args)
+        else:
+            deft_amd.kv_append(pool.kv_data[0], updater.cache_loc, k_new, v_new)
+            if mode == "flatten":
+                deft_amd.tree_attention_subtree_fwd(q, pool.get_key_buffer(0), pool.get_value_buffer(0), o, *_flatten_args(md))
+            else:
+                deft_amd.tree_attention_fwd(q, pool.get_key_buffer(0), pool.get_value_buffer(0), o, *node_args)
+        torch.cuda.synchronize()
+        outs.append(o)
+        if fused:
+            kvd = pool.kv_data[0].double()
+            leaves = sorted(tree.leaves.values(), key=lambda n: n.id)
+            for i, lf in enumerate(leaves):
+                slots = torch.tensor(tree.leaf_path_slots(lf), device="cuda")
+                kk = kvd[slots, 0].repeat_interleave(Hq // Hkv, dim=1).transpose(0, 1)
+                vv = kvd[slots, 1].repeat_interleave(Hq // Hkv, dim=1).transpose(0, 1)
+                s = torch.einsum("hd,hsd->hs", q[i].double(), kk) / D ** 0.5
+                ref = torch.einsum("hs,hsd->hd", torch.softmax(s, dim=-1), vv)
+                assert (o[i].double() - ref).abs().max().item() < TOL_EXACT, (i, geom, mode)
+    assert torch.equal(outs[0], outs[1])
