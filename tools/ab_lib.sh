@@ -9,7 +9,7 @@ for lib in $A $B; do
   export DEFT_AMD_LIB=$(realpath $lib)
   echo "== $lib (rep $rep)"
   for wl in $WLS; do
-    python bench.py --workload $wl --no-cpu-baseline --no-extras --steps 40 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('   ', d['config']['name'], d['attention_latency_us_per_layer'], (d['roofline'] or {}).get('avg_launch_us'))"
+    python bench.py --workload $wl --no-cpu-baseline --no-extras --no-traffic --no-e2e --no-cfg5 --steps 100 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('   ', d['config']['name'], d['attention_latency_us_per_layer'], (d['roofline'] or {}).get('avg_launch_us'))"
   done
 done
 done
