@@ -209,3 +209,55 @@ def test_device_built_metadata_aliases_unless_copied():
     assert torch.equal(kept.block_kv, before)            # the copy kept its step
     assert nxt.block_kv.data_ptr() == view.block_kv.data_ptr()  # same buffer: `view` now shows the new step
     assert not torch.equal(view.block_kv[: before.shape[0]], before)
+
+
+def test_journal_path_reproduces_the_reference_golden(golden):
+    """The `spec_mock` script (two merge / reset iterations, tests/scenarios.py) with a device build after every alloc, so that the
+    device copy exists and the second iteration's merge + resets reach it through the JOURNAL (the first finds the root without
+    room and starts an epoch): the final device-built arrays equal the REFERENCE's own `from_tree_cache` output for that script."""
+    sc = SCENARIOS["spec_mock"]
+    req = deft_amd.ReqToTokenPool(128, sc.pool_size + 8, device="cuda")
+    pool = deft_amd.TokenToKVPool(sc.pool_size, torch.float16, 1, 8, 1, device="cuda")
+    tree = deft_amd.TreeCache(torch.float16, 1, 8, 1, req, pool, None, True, False)
+    uploads, replayed = 0, 0
+    orig_up, orig_j = tc._DeviceTree._upload, tc._DeviceTree.apply_journal
+
+    def counting_up(self):
+        nonlocal uploads
+        uploads += 1
+        return orig_up(self)
+
+    def counting_j(self):
+        nonlocal replayed
+        n = orig_j(self)
+        replayed += n
+        return n
+
+    tc._DeviceTree._upload, tc._DeviceTree.apply_journal = counting_up, counting_j
+    try:
+        tree.init_prompt(torch.arange(1, 101, dtype=torch.int32))
+        tree.branch(tree.root, 8)
+        for leaf in list(tree.leaves.values()):
+            leaf.append_token(7)
+        tree.alloc()
+        deft_amd.TreeMetadata.from_tree_cache(tree, device_build=True)
+        for accepted in (2, 1):
+            leaves = list(tree.leaves.values())
+            before = len(tree.root.kv_indices)
+            for i in range(accepted):
+                tree.merge_nodes(tree.root, leaves[i], pruneB_flag=False)
+            diff = len(tree.root.kv_indices) - before
+            for leaf in leaves:
+                tree.reset_node_KV(leaf, diff)
+            tree.alloc()
+            md = deft_amd.TreeMetadata.from_tree_cache(tree, device_build=True)
+        torch.cuda.synchronize()
+    finally:
+        tc._DeviceTree._upload, tc._DeviceTree.apply_journal = orig_up, orig_j
+    assert uploads == 2 and replayed > 0  # first build; first merge (no room).  The second iteration went through the journal.
+    g = golden("spec_mock")
+    got = md_numpy(md)
+    for k in MD_FIELDS:
+        assert np.array_equal(got[k], g[k]), k
+    assert [md.query_num, md.node_num, md.total_kv_len, md.block_len] == g["scalars"].tolist()
+    assert np.array_equal(pool.mem_state, g["pool_refcounts"])
