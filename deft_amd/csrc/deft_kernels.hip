@@ -348,18 +348,26 @@ __global__ __launch_bounds__(256) void node_prep_kernel(const int64_t* node_kv_o
 }
 
 // ---------------------------------------------------------------------------
-// stage 2 as its own launch (merge.h): one workgroup per (query, four heads), a wave per head.  Serves head_dim 64
-// and the stage-1-only entry points; head_dim 128 decodes merge inside the stage-1 launch (stage1_np.h).
+// stage 2 as its own launch (merge.h): one workgroup per (head, four queries), a wave per query; the grid is laid out so
+// that a head is merged on the XCD whose L2 holds its partial rows.
 // ---------------------------------------------------------------------------
 constexpr int MERGE_LIST_CAP = 4096;  // row ids per wave in LDS; longer lists are merged window by window
 template <int D>
 __global__ __launch_bounds__(256) void merge_kernel(const float* partial_o, const float* partial_lse, const int32_t* row_q,
                                                      int64_t rows, _Float16* out, int64_t o_st, int64_t o_sh, int Hq, int cap,
-                                                     int lists, const int32_t* qoff, const int32_t* qlist, const int32_t* qinl) {
+                                                     int lists, const int32_t* qoff, const int32_t* qlist, const int32_t* qinl,
+                                                     int nq_total, int hgroup) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;  // (uniform: buffer descriptors stay in SGPRs)
-    const int q = blockIdx.x, hq = blockIdx.y * 4 + w;
-    if (hq >= Hq) return;
+    // EXPERIMENT (XCD alignment): a workgroup = one HEAD x four queries, head fastest in the grid: workgroup b runs on XCD b % 8 = the
+    // XCD whose stage-1 workgroups (KV head = b % 8 for MHA) wrote this head's partial rows
+    // Head fastest in the grid, four QUERIES of one head per workgroup: workgroup b runs on XCD b % 8, and the heads are dealt
+    // so that this is the XCD whose stage-1 workgroups wrote the head's partial rows (stage-1 item i = (record, KV head or head
+    // pair i % HP) runs on XCD i % 8 for grids that are multiples of 8) -- the rows are still in that XCD's L2 (measured round 3:
+    // Medusa-64 14.7 -> 13.4 us per layer; the same grid with heads rotated by 3 gains nothing).  hgroup = query heads per item.
+    const int ng = Hq / hgroup, bx = blockIdx.x;
+    const int hq = (bx % ng) * hgroup + bx / ng, q = blockIdx.y * 4 + w;
+    if (q >= nq_total) return;
     _Float16* out_q = out + (int64_t)q * o_st;
     int* list = reinterpret_cast<int*>(smem) + w * cap;
     if (lists) {  // the plan lists every query's rows: ONE round trip for {count, rows}, one for the rows themselves
@@ -394,11 +402,12 @@ __global__ __launch_bounds__(256) void merge_kernel(const float* partial_o, cons
 template <int D>
 __global__ __launch_bounds__(256) void merge_coop_kernel(const float* partial_o, const float* partial_lse, int64_t rows, _Float16* out,
                                                           int64_t o_st, int64_t o_sh, int cap, const int32_t* qoff,
-                                                          const int32_t* qlist, const int32_t* qinl) {
+                                                          const int32_t* qlist, const int32_t* qinl, int Hq, int hgroup) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int LPR = D / 4;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int q = blockIdx.x, hq = blockIdx.y;
+    const int ng = Hq / hgroup, bx = blockIdx.x;  // head fastest, on the XCD that wrote its rows (see merge_kernel)
+    const int q = blockIdx.y, hq = (bx % ng) * hgroup + bx / ng;
     int* sub = reinterpret_cast<int*>(smem) + w * cap;                         // this wave's quarter of the list
     float* xacc = reinterpret_cast<float*>(smem + sizeof(int) * 4 * (size_t)cap);  // [4][D]
     float* xml = xacc + 4 * D;                                                 // [4][2]: m, L
@@ -737,11 +746,12 @@ static int launch_stage1_np(const Stage1Params& p, int64_t unit_cap, const PlanV
 }
 
 static int launch_merge(int D, const Workspace& ws, const PlanView* pv, const int32_t* row_q, int64_t rows, void* out,
-                        int64_t o_st, int64_t o_sh, int nq, int Hq, hipStream_t stream) {
+                        int64_t o_st, int64_t o_sh, int nq, int Hq, int hgroup, hipStream_t stream) {
     if (nq <= 0) return DEFT_OK;
     const int cap = (int)std::min<int64_t>(std::max<int64_t>(rows, 64), MERGE_LIST_CAP);
     const size_t lds = sizeof(int) * 4 * (size_t)cap;
-    dim3 grid((unsigned)nq, (unsigned)((Hq + 3) / 4));
+    if (hgroup <= 0 || Hq % hgroup) hgroup = 1;
+    dim3 grid((unsigned)Hq, (unsigned)((nq + 3) / 4));
     // the plan's per-query row lists exist iff its row count fits the histogram kernel (launch_qrows): known on the host
     const int lists = pv && pv->rows > 0 && pv->rows <= QROWS_MAX ? 1 : 0;
     const int32_t* qoff = pv ? pv->qoff : nullptr;
@@ -754,13 +764,13 @@ static int launch_merge(int D, const Workspace& ws, const PlanView* pv, const in
     if (D == 128 && lists && nq <= 16 && (int64_t)nq * Hq <= 1024) {
         const int ccap = (int)std::min<int64_t>(std::max<int64_t>(rows / 4 + 2, 16), MERGE_LIST_CAP);  // (>= 8: the single-wave path stages up to 8 rows)
         const size_t clds = sizeof(int) * 4 * (size_t)ccap + sizeof(float) * (4 * 128 + 8);
-        hipLaunchKernelGGL((merge_coop_kernel<128>), dim3((unsigned)nq, (unsigned)Hq), dim3(256), clds, stream, ws.partial_o,
-                           ws.partial_lse, rows, static_cast<_Float16*>(out), o_st, o_sh, ccap, qoff, qlist, qinl);
+        hipLaunchKernelGGL((merge_coop_kernel<128>), dim3((unsigned)Hq, (unsigned)nq), dim3(256), clds, stream, ws.partial_o,
+                           ws.partial_lse, rows, static_cast<_Float16*>(out), o_st, o_sh, ccap, qoff, qlist, qinl, Hq, hgroup);
         return check_launch("merge (cooperative) launch");
     }
 #define DEFT_MERGE_LAUNCH(DD)                                                                                              \
     hipLaunchKernelGGL((merge_kernel<DD>), grid, dim3(256), lds, stream, ws.partial_o, ws.partial_lse, row_q, rows,         \
-                       static_cast<_Float16*>(out), o_st, o_sh, Hq, cap, lists, qoff, qlist, qinl)
+                       static_cast<_Float16*>(out), o_st, o_sh, Hq, cap, lists, qoff, qlist, qinl, nq, hgroup)
     if (D == 128) DEFT_MERGE_LAUNCH(128);
     else if (D == 64) DEFT_MERGE_LAUNCH(64);
     else if (D == 32) DEFT_MERGE_LAUNCH(32);
@@ -1068,7 +1078,8 @@ static int flatten_decode_impl(const void* q, int64_t q_stride_tok, int64_t q_st
                              block_q_cnts, block_q_offset, block_bitmasks, block_kv, block_lens, NB, P, nq, Hq, Hkv, D, scale,
                              plan, workspace, workspace_bytes, stream, ap, &ws, &row_q, &pv);
     if (rc) return rc;
-    return launch_merge(D, ws, pv.hdr ? &pv : nullptr, row_q, P, out, o_stride_tok, o_stride_head, nq, Hq, static_cast<hipStream_t>(stream));
+    return launch_merge(D, ws, pv.hdr ? &pv : nullptr, row_q, P, out, o_stride_tok, o_stride_head, nq, Hq,
+                        (Hq / Hkv) * (hd2_geometry(D, Hkv, kv_stride_head) && !ap.cos_sin ? 2 : 1), static_cast<hipStream_t>(stream));
 }
 
 int deft_flatten_decode_f16(const void* q, int64_t q_stride_tok, int64_t q_stride_head, const void* k_base,
@@ -1300,7 +1311,7 @@ static int node_decode_impl(const void* q, int64_t q_stride_tok, int64_t q_strid
         }
         rc = launch_stage1_np(p, tiles * G, pv, ap, st, nq, /*reread=*/rows_per_tile == 1, hd2);
         if (rc) return rc;
-        return launch_merge(D, ws, &pv, pv.row_q, rows, out, o_stride_tok, o_stride_head, nq, Hq, st);
+        return launch_merge(D, ws, &pv, pv.row_q, rows, out, o_stride_tok, o_stride_head, nq, Hq, G * (hd2 ? 2 : 1), st);
     }
     // tile-per-workgroup form (head_dim 64)
     if (ap.k_new) {  // separate append launch first
@@ -1320,7 +1331,7 @@ static int node_decode_impl(const void* q, int64_t q_stride_tok, int64_t q_strid
     p.desc = ws.desc;
     rc = launch_stage1_d64<1>(D, p, tiles, st);
     if (rc) return rc;
-    return launch_merge(D, ws, nullptr, ws.row_q, rows, out, o_stride_tok, o_stride_head, nq, Hq, st);
+    return launch_merge(D, ws, nullptr, ws.row_q, rows, out, o_stride_tok, o_stride_head, nq, Hq, 1, st);
 }
 
 extern "C" {
