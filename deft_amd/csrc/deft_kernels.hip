@@ -548,8 +548,7 @@ static int num_cus() {
     return d.cus;
 }
 enum : unsigned { ATTR_NP = 4,  // (bits 0-1, 8-11: the head_dim 64 / 32 / 16 kernels)
-                  ATTR_UNITS = 8, ATTR_NODE_UNITS = 16, ATTR_PREFILL = 32, ATTR_TREE = 64, ATTR_NP_ROPE = 128, ATTR_PREFILL_PIPE = 4096, ATTR_NP_T = 8192, ATTR_NP_ROPE_T = 16384, ATTR_NP_HD2 = 32768, ATTR_NP_HD2_T = 65536,
-                  ATTR_NP_DEEP = 1u << 17, ATTR_NP_DEEP_T = 1u << 18, ATTR_NP_DEEP_HD2 = 1u << 19, ATTR_NP_DEEP_HD2_T = 1u << 20 };
+                  ATTR_UNITS = 8, ATTR_NODE_UNITS = 16, ATTR_PREFILL = 32, ATTR_TREE = 64, ATTR_NP_ROPE = 128, ATTR_PREFILL_PIPE = 4096, ATTR_NP_T = 8192, ATTR_NP_ROPE_T = 16384, ATTR_NP_HD2 = 32768, ATTR_NP_HD2_T = 65536 };
 static int raise_lds(const void* fn, int bytes, unsigned bit, const char* what) {  // idempotent; races are harmless
     DeviceState& d = dev_state();
     if (d.attrs & bit) return DEFT_OK;
@@ -683,7 +682,6 @@ static int launch_plan(const Stage1Params& p, int NB, const PlanView& pv, const 
 // KV heads laid out contiguously ([slot][K|V][Hkv][64], the reference's pool, memory_pool.py:61-66)
 static bool hd2_geometry(int D, int Hkv, int64_t kv_sh) { return D == 64 && Hkv % 2 == 0 && kv_sh == 64; }
 
-constexpr int NP_DEEP_ITEMS_PER_CU = 0;  // (experiment: off unless DEFT_NP_DEEP=1)
 static int launch_stage1_np(const Stage1Params& p, int64_t unit_cap, const PlanView& pv, const AppendArgs& ap,
                             hipStream_t stream, int nq, bool reread = false, bool hd2 = false) {
     using SM = NpSmem<128>;
@@ -695,17 +693,8 @@ static int launch_stage1_np(const Stage1Params& p, int64_t unit_cap, const PlanV
     // 22.8, Medusa-64 18.7 -> 18.0, ToT-50 (six passes per root tile) 24.0 -> 24.3.  NOT the sequential comparator, where every
     // leaf re-reads the shared prefix through the caches: 216 -> 298 us per layer (`reread`).
     const bool nt = knob("DEFT_NP_NT", 1) != 0 && !reread && (int64_t)nq * p.G <= 1024;
-    // The deep-pipeline form (stage1_np.h, DEEP: one workgroup per CU, two K / V slices per wave) for the launches that are paced
-    // by memory latency: whole record capacity within DEEP_ITEMS work items.  Bit-identical to the plain form.
-    const int deep_knob = knob("DEFT_NP_DEEP", -1);
-    const bool deep = !rope && (deep_knob < 0 ? unit_cap * HP <= (int64_t)NP_DEEP_ITEMS_PER_CU * num_cus() : deep_knob != 0);
-    using SMD = NpSmem<128, true>;
     int rc;
-    if (deep && hd2) rc = nt ? raise_lds(reinterpret_cast<const void*>(&stage1_np_kernel<128, false, true, false, true, true>), SMD::BYTES, ATTR_NP_DEEP_HD2, "stage1_np_deep_hd2")
-                             : raise_lds(reinterpret_cast<const void*>(&stage1_np_kernel<128, false, false, false, true, true>), SMD::BYTES, ATTR_NP_DEEP_HD2_T, "stage1_np_deep_hd2_t");
-    else if (deep) rc = nt ? raise_lds(reinterpret_cast<const void*>(&stage1_np_kernel<128, false, true, false, false, true>), SMD::BYTES, ATTR_NP_DEEP, "stage1_np_deep")
-                           : raise_lds(reinterpret_cast<const void*>(&stage1_np_kernel<128, false, false, false, false, true>), SMD::BYTES, ATTR_NP_DEEP_T, "stage1_np_deep_t");
-    else if (hd2) rc = nt ? raise_lds(reinterpret_cast<const void*>(&stage1_np_kernel<128, false, true, false, true>), SM::BYTES, ATTR_NP_HD2, "stage1_np_hd2")
+    if (hd2) rc = nt ? raise_lds(reinterpret_cast<const void*>(&stage1_np_kernel<128, false, true, false, true>), SM::BYTES, ATTR_NP_HD2, "stage1_np_hd2")
                      : raise_lds(reinterpret_cast<const void*>(&stage1_np_kernel<128, false, false, false, true>), SM::BYTES, ATTR_NP_HD2_T, "stage1_np_hd2_t");
     else if (rope) rc = nt ? raise_lds(reinterpret_cast<const void*>(&stage1_np_kernel<128, true, true>), SM::BYTES, ATTR_NP_ROPE, "stage1_np_rope")
                       : raise_lds(reinterpret_cast<const void*>(&stage1_np_kernel<128, true, false>), SM::BYTES, ATTR_NP_ROPE_T, "stage1_np_rope_t");
@@ -732,12 +721,11 @@ static int launch_stage1_np(const Stage1Params& p, int64_t unit_cap, const PlanV
         const int capx = knob("DEFT_NP_GRIDCAP", p.G > 1 ? (small_gqa ? 2 : 1) : 3);
         const int64_t cap_wgs = (int64_t)capx * 2LL * num_cus();
         if (cap_wgs > 0 && grid > cap_wgs) grid = cap_wgs;
-        if (deep && grid > num_cus()) grid = num_cus();  // one resident workgroup per CU; further items in its loop
     }
     NpParams npp{};
     npp.s = p;
     npp.hdr = pv.hdr;
-    npp.fast_n = knob("DEFT_NP_FAST", (deep ? 1 : 2) * num_cus());
+    npp.fast_n = knob("DEFT_NP_FAST", 2 * num_cus());
     npp.s.ablate = knob("DEFT_STAGE1_ABLATE", 0);
     npp.plan = pv.records;
     npp.k_new = ap.k_new;
@@ -748,11 +736,7 @@ static int launch_stage1_np(const Stage1Params& p, int64_t unit_cap, const PlanV
     npp.dbg = g_dbg;
     npp.cos_sin = ap.cos_sin;
     const dim3 g((unsigned)grid), b(256);
-    if (deep && hd2 && nt) hipLaunchKernelGGL((stage1_np_kernel<128, false, true, false, true, true>), g, b, SMD::BYTES, stream, npp);
-    else if (deep && hd2) hipLaunchKernelGGL((stage1_np_kernel<128, false, false, false, true, true>), g, b, SMD::BYTES, stream, npp);
-    else if (deep && nt) hipLaunchKernelGGL((stage1_np_kernel<128, false, true, false, false, true>), g, b, SMD::BYTES, stream, npp);
-    else if (deep) hipLaunchKernelGGL((stage1_np_kernel<128, false, false, false, false, true>), g, b, SMD::BYTES, stream, npp);
-    else if (hd2 && nt) hipLaunchKernelGGL((stage1_np_kernel<128, false, true, false, true>), g, b, SM::BYTES, stream, npp);
+    if (hd2 && nt) hipLaunchKernelGGL((stage1_np_kernel<128, false, true, false, true>), g, b, SM::BYTES, stream, npp);
     else if (hd2) hipLaunchKernelGGL((stage1_np_kernel<128, false, false, false, true>), g, b, SM::BYTES, stream, npp);
     else if (rope && nt) hipLaunchKernelGGL((stage1_np_kernel<128, true, true>), g, b, SM::BYTES, stream, npp);
     else if (rope) hipLaunchKernelGGL((stage1_np_kernel<128, true, false>), g, b, SM::BYTES, stream, npp);

@@ -80,22 +80,19 @@ __device__ __forceinline__ uintx4 rope_chunk(uintx4 own_u, uintx4 par_u, bool fi
     return res.u;
 }
 
-template <int D, bool DEEP = false>
+template <int D>
 struct NpSmem {
-    static constexpr int NBUF = DEEP ? 2 : 1;           // K (and V) slices per wave: tiles in flight ahead of the one in use
-    static constexpr int NSLOT = DEEP ? 4 : 2;          // aux slots per wave
     static constexpr int SLICE = 32 * D * 2;            // one wave's 32 keys of K (or V)
-    static constexpr int BUF = 4 * SLICE;               // one buffer: the four waves' slices
-    static constexpr int K_OFF = 0;                     // [NBUF][4][SLICE]
-    static constexpr int V_OFF = NBUF * BUF;            // [NBUF][4][SLICE]
-    static constexpr int Q_OFF = 2 * NBUF * BUF;        // Q rows [32][D] fp16, chunks XOR-ed by (row & 15)
-    static constexpr int AUX_OFF = Q_OFF + MQ * D * 2;  // per wave NSLOT slots x 512 B: int64 rowoff[32] | u32 vmask[32] | i32 qsrc[32]
+    static constexpr int K_OFF = 0;                     // [4][SLICE]
+    static constexpr int V_OFF = 4 * SLICE;             // [4][SLICE]
+    static constexpr int Q_OFF = 8 * SLICE;             // Q rows [32][D] fp16, chunks XOR-ed by (row & 15)
+    static constexpr int AUX_OFF = Q_OFF + MQ * D * 2;  // per wave 2 slots x 512 B: int64 rowoff[32] | u32 vmask[32] | i32 qsrc[32]
     static constexpr int AUX_SLOT = 512;
-    static constexpr int X_OFF = AUX_OFF + 4 * NSLOT * AUX_SLOT;  // float m[2][4][32], l[2][4][32] (per head of the row: two with head_dim 64)
+    static constexpr int X_OFF = AUX_OFF + 4 * 2 * AUX_SLOT;  // float m[2][4][32], l[2][4][32] (per head of the row: two with head_dim 64)
     static constexpr int OROW_OFF = X_OFF + 2 * 2 * 4 * MQ * 4;   // int32 orow[32] of the leader record
     static constexpr int NEXT_OFF = OROW_OFF + 2 * MQ * 4;    // int32 next work item (orow is staged twice: one 64-lane DMA)
     static constexpr int BYTES = NEXT_OFF + 16;
-    static_assert((DEEP ? 1 : 2) * BYTES <= 160 * 1024, "two workgroups per CU (DEEP: one)");
+    static_assert(2 * BYTES <= 160 * 1024, "two workgroups per CU");
 };
 
 // Profiling hooks exist in the experiments build only (make exp: -DDEFT_EXPERIMENTS); the shipped kernel has neither
@@ -116,21 +113,14 @@ struct NpSmem {
 //      the head_dim-128 kernel unchanged: the same DMA granules, the same LDS slices, the same fragment reads.  Only the
 //      arithmetic splits: k-steps 0-3 are head A's S^T, 4-7 head B's (two accumulators, two softmaxes), column blocks 0-1 of O^T
 //      take head A's probabilities, 2-3 head B's, and the epilogue writes two 64-float partial rows per virtual row.
-// DEEP: the latency-bound launches (round 3).  A launch with at most one work item per CU runs one wave per
-//      SIMD, and its tile chain is paced by MEMORY LATENCY, not by arithmetic: with QK^T, PV and the epilogue compiled out a
-//      Medusa-64 layer is 11.7 us instead of 13.5 -- K(i+1) can only be requested when QK^T(i) has released the wave's one K
-//      slice, half a tile before it is needed.  This form has the whole LDS of the CU (one workgroup per CU, 150 KB): TWO K and
-//      two V slices per wave and four aux slots, K(i+2) requested when QK^T(i) is done, V(i+2) after PV(i), aux(i+3) with
-//      K(i+2) -- a tile and a half of slack instead of half a tile.  Same arithmetic in the same order: bit-identical outputs.
-template <int D, bool ROPE, bool NT, bool PEEL = ROPE, bool HD2 = false, bool DEEP = false>
-__global__ __launch_bounds__(256, DEEP ? 1 : 2) void stage1_np_kernel(NpParams np) {
+template <int D, bool ROPE, bool NT, bool PEEL = ROPE, bool HD2 = false>
+__global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
     constexpr int KS = D / 16;
     constexpr int LPT = 32 * (D / 8) / 64;  // DMA instructions per wave per K (or V) slice
     static_assert(D == 128 && LPT == 8, "tile-parallel stage 1 is instantiated for 256-byte rows (head_dim 128, or two heads of 64)");
     static_assert(!(HD2 && ROPE), "the fused rotary embedding is head_dim 128 only");
-    static_assert(!(DEEP && (ROPE || PEEL)), "the deep pipeline is built for the plain form");
     constexpr int NH = HD2 ? 2 : 1;  // heads per row
-    using SM = NpSmem<D, DEEP>;
+    using SM = NpSmem<D>;
     const Stage1Params& p = np.s;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -196,7 +186,7 @@ __global__ __launch_bounds__(256, DEEP ? 1 : 2) void stage1_np_kernel(NpParams n
     const int vchunk_b = (dpos ^ (4 * (dkey & 3))) * 16;
     const uint32_t ldsK = SM::K_OFF + (uint32_t)w * SM::SLICE;
     const uint32_t ldsV = SM::V_OFF + (uint32_t)w * SM::SLICE;
-    const uint32_t aux0 = SM::AUX_OFF + (uint32_t)w * (uint32_t)(SM::NSLOT * SM::AUX_SLOT);
+    const uint32_t aux0 = SM::AUX_OFF + (uint32_t)w * 2u * SM::AUX_SLOT;
     // S^T A fragments: key row c of this wave's slice, chunk (2ks + h) ^ (c & 15)
     const int krow_b = SM::K_OFF + w * SM::SLICE + c * D * 2;
     const int kcol_b = ((h ^ c) & 15) * 16;
@@ -225,24 +215,24 @@ __global__ __launch_bounds__(256, DEEP ? 1 : 2) void stage1_np_kernel(NpParams n
 #pragma unroll
         for (int i = 0; i < LPT; ++i) rowoff[i] = ro[4 * i + dkey];
     };
-    auto issue_k = [&](uint32_t buf = 0) {  // buf: byte offset of the buffer (DEEP: 0 or SM::BUF)
+    auto issue_k = [&]() {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of the slice being overwritten
 #pragma unroll
         for (int i = 0; i < LPT; ++i) {
-            if (ABL(8)) continue;  // (experiments: no K / V requests at all; 128: every row is the pool's first -- cache hits)
+            if (ABL(8)) continue;  // (experiments: 8 no K / V requests at all; 128 every row is the pool's first -- cache hits)
             const char* src = ABL(128) ? kb_pool : rowoff[i] < 0 ? kb_new + (rowoff[i] & ~NEW_ROW) : kb_pool + rowoff[i];
-            if constexpr (NT) dma16nt(src + kchunk_b[i & 3], ldsK + buf + (uint32_t)i * 1024u);
-            else dma16(src + kchunk_b[i & 3], ldsK + buf + (uint32_t)i * 1024u);
+            if constexpr (NT) dma16nt(src + kchunk_b[i & 3], ldsK + (uint32_t)i * 1024u);
+            else dma16(src + kchunk_b[i & 3], ldsK + (uint32_t)i * 1024u);
         }
     };
-    auto issue_v = [&](uint32_t buf = 0) {
+    auto issue_v = [&]() {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int i = 0; i < LPT; ++i) {
             if (ABL(8)) continue;
             const char* src = ABL(128) ? vb_pool : rowoff[i] < 0 ? vb_new + (rowoff[i] & ~NEW_ROW) : vb_pool + rowoff[i];
-            if constexpr (NT) dma16nt(src, ldsV + buf + (uint32_t)i * 1024u);
-            else dma16(src, ldsV + buf + (uint32_t)i * 1024u);
+            if constexpr (NT) dma16nt(src, ldsV + (uint32_t)i * 1024u);
+            else dma16(src, ldsV + (uint32_t)i * 1024u);
         }
     };
     auto issue_q = [&]() {  // rows 8w .. 8w+7 of the shared Q buffer, offsets from aux slot 0
@@ -308,18 +298,8 @@ __global__ __launch_bounds__(256, DEEP ? 1 : 2) void stage1_np_kernel(NpParams n
         if (w == 0) dma4(rec_lead + PLAN_OROW + 4 * (l & 31), SM::OROW_OFF);
         issue_aux(0, 0);
     }
-    // ---- prologue: aux(0) -> Q, K(0), aux(1), V(0)        (DEEP: aux(0), aux(1) -> Q, K(0), V(0), aux(2) -> K(1), V(1): the order
-    //      of the steady state -- aux(i+1), K(i) | V(i) | aux(i+2), K(i+1) | V(i+1) -- which the counted waits below rely on)
-    if constexpr (DEEP) {
-        if (n > 1) {
-            issue_aux(1, 1);
-            wait_vm<2>();
-        } else {
-            wait_vm<0>();
-        }
-    } else {
-        wait_vm<0>();
-    }
+    // ---- prologue: aux(0) -> Q, K(0), aux(1), V(0) -----------------------------------------------------
+    wait_vm<0>();
     load_rowoff(0);
     // fused rotary embedding of Q: every wave rotates, in LDS, the 8 rows it stages itself -- lane (dpos, dkey) owns
     // position dpos of rows 8 w + dkey and 8 w + 4 + dkey, i.e. source chunk dpos ^ (row & 15), partner chunk at position
@@ -346,20 +326,8 @@ __global__ __launch_bounds__(256, DEEP ? 1 : 2) void stage1_np_kernel(NpParams n
 
     issue_q();
     issue_k();
-    if constexpr (DEEP) {
-        issue_v();
-        if (n > 2) issue_aux(2, 2);
-        if (n > 1) {  // aux(1) landed: younger are Q [2], K(0) [8], V(0) [8] and aux(2) [2]
-            if (n > 2) wait_vm<2 * LPT + 4>();
-            else wait_vm<2 * LPT + 2>();
-            load_rowoff(1);
-            issue_k(SM::BUF);
-            issue_v(SM::BUF);
-        }
-    } else {
-        if (n > 1) issue_aux(1, 1);
-        issue_v();
-    }
+    if (n > 1) issue_aux(1, 1);
+    issue_v();
 
     half8 qf[KS];
     float m_run[NH], l_run[NH];
@@ -400,14 +368,9 @@ __global__ __launch_bounds__(256, DEEP ? 1 : 2) void stage1_np_kernel(NpParams n
     }
     for (int i = 0; i < n; ++i) {
         const bool has1 = i + 1 < n, has2 = i + 2 < n;
-        const int slot = i & (SM::NSLOT - 1);
-        const uint32_t buf = DEEP ? (uint32_t)(i & 1) * SM::BUF : 0u;  // (uniform) this tile's K / V buffer
+        const int slot = i & 1;
         // ---- K(i) (and Q) landed: younger than it are aux(i+1) [2] and V(i) [8] -------------------------
-        if constexpr (DEEP) {  // younger: V(i) [8], aux(i+2) [2], K(i+1) [8], V(i+1) [8]
-            if (has2) wait_vm<3 * LPT + 2>();
-            else if (has1) wait_vm<3 * LPT>();
-            else wait_vm<LPT>();
-        } else if (ABL(2) && i > 0) {
+        if (ABL(2) && i > 0) {  // (experiments: 2 = no K / V waits after the first tile)
         } else if (has1) wait_vm<LPT + 2>();
         else wait_vm<LPT>();
         if (!ROPE && !PEEL && i == 0) {
@@ -464,7 +427,7 @@ __global__ __launch_bounds__(256, DEEP ? 1 : 2) void stage1_np_kernel(NpParams n
         if (!ABL(1)) {  // experiments build: 1 skip QK^T, 4 skip PV, 16 skip the epilogue, 32 skip the stores
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                const half8 a = *reinterpret_cast<const half8*>(smem + buf + krow_b + (kcol_b ^ (32 * ks)));
+                const half8 a = *reinterpret_cast<const half8*>(smem + krow_b + (kcol_b ^ (32 * ks)));
                 constexpr int HALF = KS / 2;
                 floatx16& dst = acc[HD2 ? (ks / HALF) : 0];
                 dst = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qf[ks], dst, 0, 0, 0);
@@ -485,14 +448,7 @@ __global__ __launch_bounds__(256, DEEP ? 1 : 2) void stage1_np_kernel(NpParams n
                 }
         }
         // ---- the K slice is free: next tile's row offsets -> K(i+1), aux(i+2) ---------------------------
-        if constexpr (DEEP) {
-            if (has2) {
-                wait_vm<2 * LPT>();  // aux(i+2) landed (younger: K(i+1), V(i+1))
-                if (i + 3 < n) issue_aux(i + 3, (i + 3) & (SM::NSLOT - 1));  // (slot of tile i-1: its masks are consumed)
-                load_rowoff((i + 2) & (SM::NSLOT - 1));
-                issue_k(buf);  // K(i+2) into the buffer QK^T(i) has just released
-            }
-        } else if (has1) {
+        if (has1) {
             wait_vm<LPT>();  // aux(i+1) landed (younger: V(i))
             load_rowoff(slot ^ 1);
             issue_k();
@@ -526,12 +482,7 @@ __global__ __launch_bounds__(256, DEEP ? 1 : 2) void stage1_np_kernel(NpParams n
             }
         }
         // ---- V(i) landed: younger are K(i+1) [8] and aux(i+2) [2] ---------------------------------------
-        if constexpr (DEEP) {  // younger than V(i): aux(i+2) [2], K(i+1) [8], V(i+1) [8], aux(i+3) [2], K(i+2) [8]
-            if (i + 3 < n) wait_vm<3 * LPT + 4>();
-            else if (has2) wait_vm<3 * LPT + 2>();
-            else if (has1) wait_vm<2 * LPT>();
-            else wait_vm<0>();
-        } else if (ABL(2)) {
+        if (ABL(2)) {
         } else if (has2) wait_vm<LPT + 2>();
         else if (has1) wait_vm<LPT>();
         else wait_vm<0>();
@@ -542,7 +493,7 @@ __global__ __launch_bounds__(256, DEEP ? 1 : 2) void stage1_np_kernel(NpParams n
 #pragma unroll
             for (int blk = 0; blk < 4; ++blk) {
                 typedef __attribute__((address_space(3))) short4v* lds_s4;
-                const int vb = (int)buf + vtr_row_b + vtr_col_b[blk] + (16 * t) * D * 2;
+                const int vb = vtr_row_b + vtr_col_b[blk] + (16 * t) * D * 2;
                 union {
                     short4v s4[2];
                     half8 h8;
@@ -552,11 +503,7 @@ __global__ __launch_bounds__(256, DEEP ? 1 : 2) void stage1_np_kernel(NpParams n
                 o[blk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av.h8, pb[HD2 ? (blk >> 1) : 0][t], o[blk], 0, 0, 0);
             }
         }
-        if constexpr (DEEP) {
-            if (has2) issue_v(buf);  // V(i+2); rowoff holds tile i+2's offsets
-        } else if (has1) {
-            issue_v();  // V(i+1); rowoff still holds tile i+1's offsets
-        }
+        if (has1) issue_v();  // V(i+1); rowoff still holds tile i+1's offsets
     }
 
     if (ABL(16)) {  // (experiments build: no epilogue at all)

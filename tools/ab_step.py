@@ -9,6 +9,7 @@ from deft_amd.utils.workloads import WORKLOADS, Workload, GEOMETRY
 ap = argparse.ArgumentParser()
 ap.add_argument("--workload", default="medusa64_node")
 ap.add_argument("--mode", default=None, help="override the workload's mode (flatten / node / seq)")
+ap.add_argument("--width", type=int, default=None, help="override the workload's branch count")
 ap.add_argument("--steps", type=int, default=60)
 ap.add_argument("--rounds", type=int, default=3)
 ap.add_argument("knobs", nargs="+")
@@ -16,6 +17,8 @@ a = ap.parse_args()
 w = WORKLOADS[a.workload]
 if a.mode:
     w = Workload(**{**w.__dict__, "mode": a.mode})
+if a.width:
+    w = Workload(**{**w.__dict__, "width": a.width})
 b = Bench(w, GEOMETRY[w.model][3], torch.device("cuda", 0))
 names = [k.split("=")[0] for k in a.knobs]
 vals = [k.split("=")[1].split(",") for k in a.knobs]
