@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
     const int h = l >> 5;
     const int bid = blockIdx.x;
     const int W = (int)gridDim.x;
-    unsigned long long t_start = 0, t_k0 = 0, t_epi = 0;
+    unsigned long long t_start = 0, t_k0 = 0, t_epi = 0, t_bar = 0;
     const int HP = HD2 ? p.Hkv / 2 : p.Hkv;                  // rows (heads, or head pairs) per token
     const int64_t kv_shp = HD2 ? 2 * p.kv_sh : p.kv_sh;      // elements between two of them
 
@@ -517,13 +517,13 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
     //      every wave parks its unscaled O (and m, l) in its own slices -- nobody else ever touched them -- and
     //      the readers rescale while they sum.  Rows of follower tiles are dead by construction: the plan gave
     //      them row_q = -1, so nothing is written for them.
-    float* xm = reinterpret_cast<float*>(smem + SM::X_OFF);  // [NH][4][32]
+    float* xm = reinterpret_cast<float*>(smem + SM::X_OFF);  // [NH][32 rows][4 waves]: a row's four values are one 16-byte read
     float* xl = xm + 2 * 4 * MQ;
     if (h == 0) {
 #pragma unroll
         for (int hh = 0; hh < NH; ++hh) {
-            xm[(hh * 4 + w) * MQ + c] = m_run[hh];
-            xl[(hh * 4 + w) * MQ + c] = l_run[hh];
+            xm[(hh * MQ + c) * 4 + w] = m_run[hh];
+            xl[(hh * MQ + c) * 4 + w] = l_run[hh];
         }
     }
     // query row c < 16 in the K slice, c >= 16 in the V slice; [row][128] floats, 16-byte chunk index XOR-ed by the row
@@ -539,46 +539,66 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
             }
     }
     if (!(ABL(64))) lds_barrier();
+    if (DBG) t_bar = wall_clock64();
     const int32_t* orow = reinterpret_cast<const int32_t*>(smem + SM::OROW_OFF);
     // wave w sums the 16-byte chunks 8w .. 8w+7 of every row: lane = (row within a group of 8, chunk).  HD2: chunks 0-15 are
     // head A's 64 floats (waves 0, 1), chunks 16-31 head B's (waves 2, 3): each with its own head's (m, l), its own output row.
     const int k4 = 8 * w + (l & 7);
     const int hh_out = HD2 ? (w >> 1) : 0;
     const int64_t head_rows = (int64_t)((HD2 ? 2 * kvh + hh_out : kvh)) * p.G * p.rows;
-    // (the four groups of eight rows are independent: unrolled, their LDS reads are in flight together -- a lone wave per SIMD,
-    //  the regime of the small trees, otherwise walks four dependent read -> exp2 -> sum chains one after the other)
-#pragma unroll 4
-    for (int q0 = 0; q0 < nv; q0 += 8) {
-        const int qr = q0 + (l >> 3);
-        if (qr < nv) {
-            float mw[4];
+    // The four groups of eight rows are independent, and they have to LOOK independent to the compiler: a loop over the live
+    // groups with `if (row < nv)` around each body compiles to four exec-masked blocks executed one after the other, each a
+    // chain of six dependent LDS round trips (round 3, seen in the ISA: 1.3 us of a lone wave's 1.75 us epilogue).  So every
+    // group's reads are issued unconditionally -- rows >= nv hold stale bytes, all of them valid LDS -- and only the stores are
+    // predicated; two groups at a time.  The arithmetic of a live row is unchanged.
+#pragma unroll 1
+    for (int g0 = 0; 8 * g0 < nv; g0 += 2) {  // two groups in flight (four cost 23-40 spilled registers)
+        floatx4 mw[2], lw[2], b[2][4], res[2];
+        float lse[2];
+        int orow_q[2];
 #pragma unroll
-            for (int ww = 0; ww < 4; ++ww) mw[ww] = xm[(hh_out * 4 + ww) * MQ + qr];
-            const float M = fmaxf(fmaxf(mw[0], mw[1]), fmaxf(mw[2], mw[3]));
+        for (int g = 0; g < 2; ++g) {
+            const int qr = 8 * (g0 + g) + (l >> 3);
+            const int off = (qr < 16 ? SM::K_OFF : SM::V_OFF) + (qr & 15) * (D * 4) + ((k4 ^ qr) & 31) * 16;
+            mw[g] = *reinterpret_cast<const floatx4*>(xm + (hh_out * MQ + qr) * 4);
+            lw[g] = *reinterpret_cast<const floatx4*>(xl + (hh_out * MQ + qr) * 4);
+#pragma unroll
+            for (int ww = 0; ww < 4; ++ww) b[g][ww] = *reinterpret_cast<const floatx4*>(smem + off + ww * SM::SLICE);
+            orow_q[g] = orow[qr];
+        }
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const float M = fmaxf(fmaxf(mw[g][0], mw[g][1]), fmaxf(mw[g][2], mw[g][3]));
             float L = 0.f;
             floatx4 a = {0.f, 0.f, 0.f, 0.f};
-            const int off = (qr < 16 ? SM::K_OFF : SM::V_OFF) + (qr & 15) * (D * 4) + ((k4 ^ qr) & 31) * 16;
 #pragma unroll
             for (int ww = 0; ww < 4; ++ww) {
-                const float f = (mw[ww] == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(mw[ww] - M);
-                L += f * xl[(hh_out * 4 + ww) * MQ + qr];
-                const floatx4 b = *reinterpret_cast<const floatx4*>(smem + off + ww * SM::SLICE);
-                a += b * f;
+                const float f = (mw[g][ww] == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(mw[g][ww] - M);
+                L += f * lw[g][ww];
+                a += b[g][ww] * f;
             }
             const float inv = L > 0.f ? 1.f / L : 0.f;
-            const int orow_q = orow[qr];
-            if (ABL(32)) continue;
-            const floatx4 res = a * inv;
-            const float lse = (L > 0.f) ? (M + __builtin_amdgcn_logf(L)) * LN2 : -INFINITY;
-            const int64_t row = head_rows + orow_q;
-            // (ordinary stores: non-temporal partial stores, and non-temporal loads of them in the merge, each cost the
-            //  north-star layer ~1 us and both ~2.3 -- profiles/r2n_nontemporal.txt)
-            if constexpr (HD2) {
-                *reinterpret_cast<floatx4*>(p.partial_o + row * (D / 2) + 4 * (k4 & 15)) = res;
-                if ((k4 & 15) == 0) p.partial_lse[row] = lse;
-            } else {
-                *reinterpret_cast<floatx4*>(p.partial_o + row * D + 4 * k4) = res;
-                if (k4 == 0) p.partial_lse[row] = lse;
+            res[g] = a * inv;
+            lse[g] = (L > 0.f) ? (M + __builtin_amdgcn_logf(L)) * LN2 : -INFINITY;
+            // (the values are pinned OUTSIDE the predicated stores: otherwise the compiler sinks the arithmetic and the reads
+            //  back into the exec-masked blocks)
+            asm volatile("" : "+v"(res[g]), "+v"(lse[g]));
+        }
+        if (ABL(32)) continue;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int qr = 8 * (g0 + g) + (l >> 3);
+            if (qr < nv) {
+                const int64_t row = head_rows + orow_q[g];
+                // (ordinary stores: non-temporal partial stores, and non-temporal loads of them in the merge, each cost the
+                //  north-star layer ~1 us and both ~2.3 -- profiles/r2n_nontemporal.txt)
+                if constexpr (HD2) {
+                    *reinterpret_cast<floatx4*>(p.partial_o + row * (D / 2) + 4 * (k4 & 15)) = res[g];
+                    if ((k4 & 15) == 0) p.partial_lse[row] = lse[g];
+                } else {
+                    *reinterpret_cast<floatx4*>(p.partial_o + row * D + 4 * k4) = res[g];
+                    if (k4 == 0) p.partial_lse[row] = lse[g];
+                }
             }
         }
     }
@@ -594,6 +614,7 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
         d[4] = (unsigned long long)n;
         d[5] = ((unsigned long long)xcc << 32) | hw;
         d[6] = (unsigned long long)kvh;
+        d[7] = t_bar;
     }
     // Next item of a capped grid: record capacity beyond the chunk leaders would otherwise be launched as workgroups
     // that only find out that they have nothing to do (tens of thousands for the sequential comparator's entries).

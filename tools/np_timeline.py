@@ -36,7 +36,7 @@ for rep in range(3):
     for nn in sorted(set(n.tolist())):
         m = n == nn
         print(f"  n={int(nn)}: {int(m.sum()):4d} WGs  start {pct(st[m])}  ramp(start->K0) {pct((k0 - st)[m])}  body {pct((ep - k0)[m])}  "
-              f"epilogue {pct((en - ep)[m])}  total {pct((en - st)[m])}  end {pct(en[m])}")
+              f"epilogue {pct((en - ep)[m])} (to barrier {pct(((d[:, 7] - t0) / 100.0 - ep)[m])})  total {pct((en - st)[m])}  end {pct(en[m])}")
     # single-launch decode: how long after its KV head's last stage-1 workgroup ended did a merge workgroup see the
     # counter complete, and how long did its merges take
     mg = n == 1000
