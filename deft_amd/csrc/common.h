@@ -81,7 +81,7 @@ inline PlanView plan_view(void* base, int64_t cap, int64_t rows) {
     v.records = p + off;
     off = align_up(off + 2048 * (size_t)(cap + 1), 256);
     v.units = reinterpret_cast<int32_t*>(p + off);
-    off = align_up(off + sizeof(int32_t) * 20 * (size_t)(cap > 0 ? cap : 1), 256);
+    off = align_up(off + sizeof(int32_t) * 17 * (size_t)(cap > 0 ? cap : 1), 256);
     v.row_q = reinterpret_cast<int32_t*>(p + off);
     off = align_up(off + sizeof(int32_t) * (size_t)(rows > 0 ? rows : 1), 256);
     v.qoff = reinterpret_cast<int32_t*>(p + off);

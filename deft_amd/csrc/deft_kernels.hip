@@ -292,7 +292,6 @@ __global__ __launch_bounds__(256, 2) void stage1_kernel(Stage1Params p) {
 #include "tree_plan.h"
 #include "merge.h"
 #include "stage1_np.h"
-#include "stage1_pp.h"
 #include "prefill.h"
 #ifdef DEFT_EXPERIMENTS
 #include "prefill_w4.h"    // 4 waves x 2 workgroups per CU: experiment
@@ -549,8 +548,7 @@ static int num_cus() {
     return d.cus;
 }
 enum : unsigned { ATTR_NP = 4,  // (bits 0-1, 8-11: the head_dim 64 / 32 / 16 kernels)
-                  ATTR_UNITS = 8, ATTR_NODE_UNITS = 16, ATTR_PREFILL = 32, ATTR_TREE = 64, ATTR_NP_ROPE = 128, ATTR_PREFILL_PIPE = 4096, ATTR_NP_T = 8192, ATTR_NP_ROPE_T = 16384, ATTR_NP_HD2 = 32768, ATTR_NP_HD2_T = 65536,
-                  ATTR_PP = 1u << 17, ATTR_PP_T = 1u << 18 };
+                  ATTR_UNITS = 8, ATTR_NODE_UNITS = 16, ATTR_PREFILL = 32, ATTR_TREE = 64, ATTR_NP_ROPE = 128, ATTR_PREFILL_PIPE = 4096, ATTR_NP_T = 8192, ATTR_NP_ROPE_T = 16384, ATTR_NP_HD2 = 32768, ATTR_NP_HD2_T = 65536 };
 static int raise_lds(const void* fn, int bytes, unsigned bit, const char* what) {  // idempotent; races are harmless
     DeviceState& d = dev_state();
     if (d.attrs & bit) return DEFT_OK;
@@ -612,9 +610,6 @@ static UnitList unit_list(const PlanView& pv) {
     ul.gn = pv.units + 8 * pv.cap;
     ul.gq = pv.units + 9 * pv.cap;
     ul.grow = pv.units + 13 * pv.cap;
-    ul.ch_x = pv.units + 17 * pv.cap;
-    ul.ch_g = pv.units + 18 * pv.cap;
-    ul.ch_f = pv.units + 19 * pv.cap;
     return ul;
 }
 
@@ -638,10 +633,6 @@ static int np_union_knob() { return knob("DEFT_NP_UNION", 0); }  // leaf tiles p
 // calls carry no head_dim; the q head stride does (64 elements = contiguous heads of 64).  Only the rules depend on it.
 // (head pairs are passed NEGATED: np_record_order)
 static int plan_items_per_leader(const Stage1Params& p) { return (p.q_sh == 64 && p.Hkv % 2 == 0) ? -(p.Hkv / 2) : p.Hkv; }
-
-// Pass groups in the plan's record order (plan_kernels.h `pp`; stage1_pp.h): GQA, head_dim 128.  The order also serves the
-// tile-parallel kernel, so the decision does not depend on which of the two a launch will take.
-static int plan_pass_groups(const Stage1Params& p) { return p.G > 1 && plan_items_per_leader(p) > 0 ? 1 : 0; }
 
 // Flatten plan: unit list (one workgroup) then one record per unit.
 static int launch_plan(const Stage1Params& p, int NB, const PlanView& pv, const AppendArgs& ap, hipStream_t stream,
@@ -674,7 +665,7 @@ static int launch_plan(const Stage1Params& p, int NB, const PlanView& pv, const 
     const UnitList ul = unit_list(pv);
     hipLaunchKernelGGL(flatten_units_kernel, dim3(1), dim3(1024), lds, stream, p.block_q, p.block_q_cnts, p.block_q_offset, NB,
                        p.G, (int)pv.cap, ul, pv.hdr, plan_items_per_leader(p), 2 * num_cus(), np_chunk_knob(), np_union_knob(), (int)run_cap, qtab,
-                       par, dims, pv.row_q, (int)pv.rows, plan_pass_groups(p));
+                       par, dims, pv.row_q, (int)pv.rows);
     rc = check_launch("flatten units launch");
     if (rc) return rc;
     hipLaunchKernelGGL(flatten_records_kernel, dim3((unsigned)(pv.cap + 1)), dim3(128), 0, stream, p.block_q, p.block_q_cnts,
@@ -692,34 +683,9 @@ static int launch_plan(const Stage1Params& p, int NB, const PlanView& pv, const 
 static bool hd2_geometry(int D, int Hkv, int64_t kv_sh) { return D == 64 && Hkv % 2 == 0 && kv_sh == 64; }
 
 static int launch_stage1_np(const Stage1Params& p, int64_t unit_cap, const PlanView& pv, const AppendArgs& ap,
-                            hipStream_t stream, int nq, bool reread = false, bool hd2 = false, bool flatten = false) {
+                            hipStream_t stream, int nq, bool reread = false, bool hd2 = false) {
     using SM = NpSmem<128>;
     const bool rope = ap.cos_sin != nullptr;
-    // GQA launches whose virtual query rows need more than one 32-row pass per tile: the pass-parallel kernel (stage1_pp.h)
-    const int pp_knob = knob("DEFT_NP_PP", -1);
-    const bool pp = flatten && !rope && !hd2 && !reread && p.G > 1 && (pp_knob < 0 ? (int64_t)nq * p.G > MQ : pp_knob != 0);
-    if (pp) {
-        const bool ntp = knob("DEFT_NP_NT", 1) != 0;
-        int rc = ntp ? raise_lds(reinterpret_cast<const void*>(&stage1_pp_kernel<true>), PpSmem::BYTES, ATTR_PP, "stage1_pp")
-                     : raise_lds(reinterpret_cast<const void*>(&stage1_pp_kernel<false>), PpSmem::BYTES, ATTR_PP_T, "stage1_pp_t");
-        if (rc) return rc;
-        if (unit_cap <= 0) return DEFT_OK;
-        int64_t grid = unit_cap * p.Hkv;  // record capacity; the work items are the pass-group leaders among them
-        const int64_t cap_wgs = (int64_t)knob("DEFT_PP_GRIDCAP", 2) * num_cus();
-        if (grid > cap_wgs) grid = cap_wgs;
-        NpParams npp{};
-        npp.s = p;
-        npp.hdr = pv.hdr;
-        npp.plan = pv.records;
-        npp.k_new = ap.k_new;
-        npp.v_new = ap.v_new;
-        npp.cache_loc = ap.cache_loc;
-        npp.new_st = ap.new_st;
-        npp.n_new = ap.k_new ? ap.n_new : 0;
-        if (ntp) hipLaunchKernelGGL((stage1_pp_kernel<true>), dim3((unsigned)grid), dim3(256), PpSmem::BYTES, stream, npp);
-        else hipLaunchKernelGGL((stage1_pp_kernel<false>), dim3((unsigned)grid), dim3(256), PpSmem::BYTES, stream, npp);
-        return check_launch("stage1 pp launch");
-    }
     const int HP = hd2 ? p.Hkv / 2 : p.Hkv;  // work items per chunk leader: KV heads, or head pairs
     // K / V rows by NON-TEMPORAL LDS-DMA wherever a row is read by the few 32-row passes of its tile and never again: the
     // tree modes.  Same box, stage 1 (tools/ab.py, experiments build DEFT_NP_NT=0/1): north-star tree 36.0 -> 32.3 us, 1k x 32
@@ -982,7 +948,7 @@ static int flatten_stage1_impl(const void* q, int64_t q_stride_tok, int64_t q_st
         }
         *row_q_out = pv.row_q;
         *pv_out = pv;
-        return launch_stage1_np(p, cap, pv, ap, st, nq, false, hd2, /*flatten=*/true);
+        return launch_stage1_np(p, cap, pv, ap, st, nq, false, hd2);
     }
     if (ap.k_new) {  // head_dim 64 (tile-per-workgroup form): separate append launch first
         rc = deft_kv_append_f16(const_cast<void*>(k_base), const_cast<void*>(v_base), kv_stride_slot, kv_stride_head,

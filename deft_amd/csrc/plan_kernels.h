@@ -70,11 +70,6 @@ struct UnitList {   // all int32, capacity `cap` each
     int32_t* perm;   // record -> unit
     int32_t* ch_n;   // tiles of the chunk this record leads (itself included); 0 = follower
     int32_t* ch_fb;  // record index of the chunk's first follower (followers are consecutive records)
-    // pass groups (GQA, stage1_pp.h): the 32-row passes of one run of tiles are folded by ONE workgroup, a wave per pass.
-    // Written for the leader record that leads a group (the chunk's leader in pass 0, 4, ...), 0 elsewhere:
-    int32_t* ch_x;   // leader record of the same chunk in the group's SECOND pass (the third is ch_s records later, ...)
-    int32_t* ch_g;   // passes in the group (1..4) | rows of its last pass << 3 | chunks of the run (leader stride) << 9
-    int32_t* ch_f;   // follower records of one pass of the run (the stride between the passes' follower lists)
     // union groups (Flatten, tile-parallel order), indexed by GROUP id = aux - 1: consecutive leaf tiles whose query
     // lists differ but are small are folded by ONE workgroup over the union of their queries
     int32_t* gn;    // queries in the union (<= UNION_CAP)
@@ -105,10 +100,8 @@ constexpr int LONG_CHUNK = 4;  // tiles per chunk from which a chunk's leader is
 // stage1_np.h HD2: half as many items as heads, each with two softmaxes' worth of arithmetic per tile, so its launches are
 // short of workgroups where the head_dim-128 launch of the same tree is not -- chunk lengths follow the GQA rule and then
 // shrink until the launch has 3/4 of a workgroup per resident slot).
-// `pp` (pass groups, GQA): the leaders that lead a group come first -- they are the work items of stage1_pp_kernel -- and carry
-// what its waves need to find the other passes' records (UnitList::ch_x / ch_g / ch_f); hdr[HDR_GROUPS] = their number.
 __device__ inline void np_record_order(const UnitList& ul, int R, int Hkv, int G, int slots, int chunk_c, int32_t* hdr,
-                                       RunTable rt, int pp = 0) {
+                                       RunTable rt) {
     const bool pairs = Hkv < 0;
     Hkv = pairs ? -Hkv : Hkv;
     if (rt.n > rt.cap) {  // rebuild the table is impossible: scan (slow path, huge trees only)
@@ -177,42 +170,21 @@ __device__ inline void np_record_order(const UnitList& ul, int R, int Hkv, int G
     // to: a capped grid hands item b + W to the workgroup that finishes item b, so with the leaders run by run a batch of
     // trees (prefix chunks, leaf tiles, prefix chunks, leaf tiles, ...) gave the workgroups that already held one
     // 8-tile chunk a second one (8 trees of 8k x 8 as one tree object: 71 -> 57 us per layer).  Longest first, as in prefill.
-    // classes of leaders, in this order: [leads a pass group: long, short] [other passes: long, short]; without `pp` every
-    // run leads (its own) group, i.e. long chunks, then short ones.  ul.pass = pass | virtual rows of this and the later passes << 8.
-    auto leads = [&](int r) { return !pp || (ul.pass[r] & 3) == 0; };
-    int ncls[4] = {0, 0, 0, 0}, NL = 0;
-    for_runs([&](int r, int nt, int uni) {
+    int NL = 0, NLong = 0;
+    for_runs([&](int, int nt, int uni) {
         const int S = uni ? 1 : (nt + C - 1) / C;
         NL += S;
-        ncls[(leads(r) ? 0 : 2) + ((!uni && nt / S >= LONG_CHUNK) ? 0 : 1)] += S;
+        if (!uni && nt / S >= LONG_CHUNK) NLong += S;
     });
-    int li4[4] = {0, ncls[0], ncls[0] + ncls[1], ncls[0] + ncls[1] + ncls[2]};
-    int fi = NL;
-    // (a group's later passes are the runs that follow it -- same tiles, pass + 1, ... -- so their leaders are consecutive
-    //  blocks of S records in the classes behind: the group's leaders point at the second pass's)
-    int pend_li = -1;
+    int liL = 0, liS = NLong, fi = NL;
     for_runs([&](int r, int nt, int uni) {
         const int S = uni ? 1 : (nt + C - 1) / C;  // a union group is one chunk
-        const bool lead = leads(r);
-        int& li = li4[(lead ? 0 : 2) + ((!uni && nt / S >= LONG_CHUNK) ? 0 : 1)];
-        int Pg = 0, nv_last = 0;
-        if (pp && lead) {
-            const int rows_left = max(ul.pass[r] >> 8, 1);
-            Pg = min(4, (rows_left + MQ - 1) / MQ);
-            nv_last = min(MQ, rows_left - MQ * (Pg - 1));
-            pend_li = Pg > 1 ? li : -1;
-        } else if (pp && (ul.pass[r] & 3) == 1 && pend_li >= 0) {
-            for (int p = 0; p < S; ++p) ul.ch_x[pend_li + p] = li + p;
-            pend_li = -1;
-        }
+        int& li = (!uni && nt / S >= LONG_CHUNK) ? liL : liS;
         for (int p = 0; p < S; ++p) {
             const int cnt = (nt - p + S - 1) / S;
             ul.perm[li] = r + p;
             ul.ch_n[li] = cnt;
             ul.ch_fb[li] = fi;
-            ul.ch_x[li] = 0;
-            ul.ch_g[li] = Pg ? (Pg | (nv_last << 3) | (S << 9)) : 0;
-            ul.ch_f[li] = nt - S;
             ++li;
             for (int j = 1; j < cnt; ++j, ++fi) {
                 ul.perm[fi] = r + p + j * S;
@@ -222,15 +194,13 @@ __device__ inline void np_record_order(const UnitList& ul, int R, int Hkv, int G
         }
     });
     hdr[1] = NL;
-    hdr[HDR_GROUPS] = pp ? ncls[0] + ncls[1] : 0;
 }
 
 // Record order of the tile-parallel stage 1, written by all waves of the unit kernel from its LDS run table (the
 // rules of np_record_order above, same result).  Called by every thread after the units are written; rT0 / rSp are
 // scratch arrays of run_cap words (the callers' run fields are dead by then), sMeta[2..3] two shared words.
-// `pp`: pass groups (np_record_order); rSp[k] comes in as block stride | pass << 8 | rows of this and the later passes << 16.
 __device__ inline void record_order_parallel(const UnitList& ul, const RunTable& rt, int NR, int* rT0, int* rSp, int* sMeta,
-                                             int32_t* hdr, int Hkv, int G, int slots, int chunk_c, int pp = 0) {
+                                             int32_t* hdr, int Hkv, int G, int slots, int chunk_c) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     const bool pairs = Hkv < 0;  // (np_record_order: head pairs)
     Hkv = pairs ? -Hkv : Hkv;
@@ -268,65 +238,36 @@ __device__ inline void record_order_parallel(const UnitList& ul, const RunTable&
                 if (2 * n0 * Hkv < slots && 2 * n1 * Hkv <= slots) --C;
             }
         }
-        // leaders in four classes (np_record_order): [leads a pass group: long, short] [other passes: long, short], each class in
-        // run order; followers in run order.  Per run: rT0 = position in its class | class << 28 (resolved below), rSp = first
-        // follower | passes of the group it leads << 24 | rows of the group's last pass << 27 (passes: 0 = leads none).
-        int lead4[4] = {0, 0, 0, 0}, foll = 0;
+        // leaders: long chunks first (np_record_order), each class in run order; followers in run order
+        int leadL = 0, leadS = 0, foll = 0;
         for (int base = 0; base < NR; base += 64) {
             const int k = base + lane;
             const int nt = k < NR ? rt.nt[k] : 0;
             const int S = k < NR ? (rt.uni[k] ? 1 : (nt + C - 1) / C) : 0;
             const bool lng = k < NR && !rt.uni[k] && S > 0 && nt / S >= LONG_CHUNK;
-            const int info = k < NR ? rSp[k] : 0;  // (read before this round's writes)
-            const int ps = (info >> 8) & 0xff, rows_left = max(info >> 16, 1);
-            const bool lead = !pp || (ps & 3) == 0;
-            const int cls = (lead ? 0 : 2) + (lng ? 0 : 1);
-            int Pg = 0, nv_last = 0;
-            if (pp && lead) {
-                Pg = min(4, (rows_left + MQ - 1) / MQ);
-                nv_last = min(MQ, rows_left - MQ * (Pg - 1));
-            }
-            int a[4], b = nt - S;  // inclusive scans over the lanes
-#pragma unroll
-            for (int q = 0; q < 4; ++q) a[q] = (k < NR && q == cls) ? S : 0;
+            int aL = lng ? S : 0, aS = lng ? 0 : S, b = nt - S;  // inclusive scans over the lanes
             for (int d = 1; d < 64; d <<= 1) {
-                int u[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) u[q] = __shfl_up(a[q], d, 64);
-                const int ub = __shfl_up(b, d, 64);
+                const int uL = __shfl_up(aL, d, 64), uS = __shfl_up(aS, d, 64), ub = __shfl_up(b, d, 64);
                 if (lane >= d) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) a[q] += u[q];
+                    aL += uL;
+                    aS += uS;
                     b += ub;
                 }
             }
             if (k < NR) {
-                int pos = 0;
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (q == cls) pos = lead4[q] + a[q] - S;
-                rT0[k] = pos | (cls << 28);
-                rSp[k] = (foll + b - (nt - S)) | (Pg << 24) | ((nv_last & 31) << 27);  // (32 rows read back as 0)
+                rT0[k] = lng ? leadL + aL - S : -(leadS + aS - S) - 1;  // short runs: position inside their class, resolved below
+                rSp[k] = foll + b - (nt - S);
             }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) lead4[q] += __shfl(a[q], 63, 64);
+            leadL += __shfl(aL, 63, 64);
+            leadS += __shfl(aS, 63, 64);
             foll += __shfl(b, 63, 64);
         }
-        const int base4[4] = {0, lead4[0], lead4[0] + lead4[1], lead4[0] + lead4[1] + lead4[2]};
-        for (int k = lane; k < NR; k += 64) {
-            const int v = rT0[k], cls = (v >> 28) & 3;
-            int bs = 0;
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (q == cls) bs = base4[q];
-            rT0[k] = bs + (v & 0x0fffffff);
-        }
+        for (int k = lane; k < NR; k += 64)
+            if (rT0[k] < 0) rT0[k] = leadL + (-rT0[k] - 1);
         if (lane == 0) {
-            const int NLall = lead4[0] + lead4[1] + lead4[2] + lead4[3];
             sMeta[2] = C;
-            sMeta[3] = NLall;
-            hdr[1] = NLall;
-            hdr[HDR_GROUPS] = pp ? lead4[0] + lead4[1] : 0;
+            sMeta[3] = leadL + leadS;
+            hdr[1] = leadL + leadS;
         }
     }
     __syncthreads();
@@ -335,10 +276,7 @@ __device__ inline void record_order_parallel(const UnitList& ul, const RunTable&
         for (int k = wave; k < NR; k += nwaves) {
             const int first = rt.r0[k], nt = rt.nt[k];
             const int S = rt.uni[k] ? 1 : (nt + C - 1) / C;  // a union group is one chunk
-            const int li = rT0[k], fi = NL + (rSp[k] & 0x00ffffff);
-            const int Pg = (rSp[k] >> 24) & 7;
-            const int nvl = (rSp[k] >> 27) & 31, nv_last = nvl ? nvl : MQ;
-            const int x = (Pg > 1 && k + 1 < NR) ? rT0[k + 1] : 0;  // the group's second pass is the next run
+            const int li = rT0[k], fi = NL + rSp[k];
             const int q = nt / S, rem = nt - q * S;  // chunk p folds units p, p + S, ...: q + 1 of them for p < rem, else q
             for (int u = lane; u < nt; u += 64) {
                 const int j = u / S, pc = u - j * S;
@@ -347,9 +285,6 @@ __device__ inline void record_order_parallel(const UnitList& ul, const RunTable&
                     ul.perm[li + pc] = first + pc;
                     ul.ch_n[li + pc] = q + (pc < rem ? 1 : 0);
                     ul.ch_fb[li + pc] = fb;
-                    ul.ch_x[li + pc] = Pg > 1 ? x + pc : 0;
-                    ul.ch_g[li + pc] = Pg ? (Pg | (nv_last << 3) | (S << 9)) : 0;
-                    ul.ch_f[li + pc] = nt - S;
                 } else {
                     ul.perm[fb + j - 1] = first + u;
                     ul.ch_n[fb + j - 1] = 0;
@@ -423,7 +358,7 @@ __global__ __launch_bounds__(1024) void flatten_units_kernel(const int64_t* bloc
                                                             const int64_t* block_q_offset, int NBc, int G, int cap,
                                                             UnitList ul, int32_t* hdr, int Hkv, int slots, int chunk_c,
                                                             int union_len, int run_cap, int qtab, int par,
-                                                            const int32_t* dims, int32_t* row_q, int rows, int pp) {
+                                                            const int32_t* dims, int32_t* row_q, int rows) {
     constexpr int np = 1;  // records in the tile-parallel order (leaders first); the only stage-1 form
     // NBc = block CAPACITY (sizes the tables); with `dims` (device-side metadata, tree_plan.h) the block count of this
     // step is read from the device, so that one captured launch serves every step of a structural epoch
@@ -536,7 +471,7 @@ __global__ __launch_bounds__(1024) void flatten_units_kernel(const int64_t* bloc
             return NB;
         };
         // units of one run: blocks t0, t0 + st, ... < te, pass ps, aux (0, or union group + 1)
-        auto emit_run = [&](int t0, int te, int st, int aux, int ps, int rows_left) {  // rows_left: virtual rows of pass ps and the later ones
+        auto emit_run = [&](int t0, int te, int st, int aux, int ps) {
             int n = st == 1 ? te - t0 : (te - t0 + st - 1) / st;
             if (n > cap - r) n = cap - r;
             if (n <= 0) return;
@@ -547,7 +482,7 @@ __global__ __launch_bounds__(1024) void flatten_units_kernel(const int64_t* bloc
                     rt.nt[rt.n] = n;
                     rt.uni[rt.n] = aux;
                     rT0[rt.n] = t0;
-                    rSp[rt.n] = st | (ps << 8) | (rows_left << 16);
+                    rSp[rt.n] = st | (ps << 8);
                 }
                 ++rt.n;
             } else {
@@ -556,7 +491,7 @@ __global__ __launch_bounds__(1024) void flatten_units_kernel(const int64_t* bloc
                         const int t = t0 + j * st;
                         ul.src[first + j] = t;
                         ul.aux[first + j] = aux;
-                        ul.pass[first + j] = ps | (rows_left << 8);
+                        ul.pass[first + j] = ps;
                         ul.flags[first + j] = (first << 1) | (j == 0 ? 1 : 0);
                         ul.prow[first + j] = sOff[t];
                     }
@@ -582,7 +517,7 @@ __global__ __launch_bounds__(1024) void flatten_units_kernel(const int64_t* bloc
                         ul.grow[j * cap + ng] = j < un ? urow[j] : 0;
                     }
                 }
-                emit_run(ta, ta + glen, 1, ng + 1, 0, MQ);
+                emit_run(ta, ta + glen, 1, ng + 1, 0);
                 ++ng;
                 ta += glen;
                 continue;
@@ -601,14 +536,14 @@ __global__ __launch_bounds__(1024) void flatten_units_kernel(const int64_t* bloc
                 if (P) {
                     const int te = find(ta + P, 1 << (P - 1));
                     for (int par_ = 0; par_ < P; ++par_) {
-                        const int npass = sPass[ta + par_];
-                        for (int ps = 0; ps < npass; ++ps) emit_run(ta + par_, te, P, 0, ps, sCnt[ta + par_] * G - MQ * ps);
+                        const int pp = sPass[ta + par_];
+                        for (int ps = 0; ps < pp; ++ps) emit_run(ta + par_, te, P, 0, ps);
                     }
                     ta = te;
                     continue;
                 }
             }
-            for (int ps = 0; ps < passes; ++ps) emit_run(ta, tb, 1, 0, ps, cnt_a * G - MQ * ps);
+            for (int ps = 0; ps < passes; ++ps) emit_run(ta, tb, 1, 0, ps);
             ta = tb;
         }
         if (lane == 0) {
@@ -616,14 +551,13 @@ __global__ __launch_bounds__(1024) void flatten_units_kernel(const int64_t* bloc
             hdr[1] = 0;
             hdr[HDR_ERR] = 0;
             hdr[HDR_QLISTS] = 0;
-            hdr[HDR_GROUPS] = 0;
             if (par && rt.n <= rt.cap) {
                 sMeta[0] = r;
                 sMeta[1] = rt.n;
                 sMeta[4] = 1;
             } else if (!par) {
                 sMeta[4] = 0;
-                if (np) np_record_order(ul, r, Hkv, G, slots, chunk_c, hdr, rt, pp);
+                if (np) np_record_order(ul, r, Hkv, G, slots, chunk_c, hdr, rt);
             }
         }
         if (!par || rt.n <= rt.cap) break;
@@ -635,7 +569,7 @@ __global__ __launch_bounds__(1024) void flatten_units_kernel(const int64_t* bloc
     const int NR = sMeta[1];
     const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     for (int k = wave; k < NR; k += nwaves) {
-        const int first = rt.r0[k], n = rt.nt[k], aux = rt.uni[k], t0 = rT0[k], st = rSp[k] & 0xff, ps = rSp[k] >> 8;  // (pass | rows << 8)
+        const int first = rt.r0[k], n = rt.nt[k], aux = rt.uni[k], t0 = rT0[k], st = rSp[k] & 0xff, ps = rSp[k] >> 8;
         if (aux > 0 && lane == 0) {  // a union group: its queries and the rows that carry their partials
             int uq[UNION_CAP], urow[UNION_CAP], un;
             union_group(t0, NB, sOpen[t0] >> 8, ucap, sCnt, sOff, qtab ? sQ : nullptr, block_q, uq, urow, un);
@@ -656,7 +590,7 @@ __global__ __launch_bounds__(1024) void flatten_units_kernel(const int64_t* bloc
     }
     if (!np) return;
     // Phase 4: record order of the tile-parallel stage 1
-    record_order_parallel(ul, rt, NR, rT0, rSp, sMeta, hdr, Hkv, G, slots, chunk_c, pp);
+    record_order_parallel(ul, rt, NR, rT0, rSp, sMeta, hdr, Hkv, G, slots, chunk_c);
 }
 
 // One workgroup of 128 threads per unit (+ the sentinel): pack its record.
@@ -694,7 +628,7 @@ __global__ __launch_bounds__(128) void flatten_records_kernel(const int64_t* blo
     const NewMap nm = newmap_build(sKeys, sVals, cache_loc, n_new);
     const int u = np ? ul.perm[r] : r;  // unit packed into this record
     const int t = ul.src[u];
-    const int ps = ul.pass[u] & 0xff;  // (| virtual rows of this and the later passes << 8: np_record_order)
+    const int ps = ul.pass[u];
     const int prow = ul.prow[u];
     const int len = (int)block_lens[t];
     const int cnt = (int)block_q_cnts[t];
@@ -730,15 +664,12 @@ __global__ __launch_bounds__(128) void flatten_records_kernel(const int64_t* blo
             }
         }
         if (k == 0) {
-            const bool leader = ul.ch_n[r] > 0;
             desc[0] = nvu;
             desc[1] = prow;
-            desc[2] = (ul.flags[u] & 1) | (leader ? ul.ch_f[r] << 1 : 0);
+            desc[2] = ul.flags[u] & 1;
             desc[3] = ul.flags[u] >> 1;
             desc[4] = ul.ch_n[r];
             desc[5] = ul.ch_fb[r];
-            desc[6] = leader ? ul.ch_x[r] : 0;
-            desc[7] = leader ? ul.ch_g[r] : 0;
         }
         return;
     }
@@ -766,15 +697,12 @@ __global__ __launch_bounds__(128) void flatten_records_kernel(const int64_t* blo
         }
     }
     if (k == 0) {
-        const bool leader = ul.ch_n[r] > 0;
         desc[0] = nv;
         desc[1] = prow;
-        desc[2] = (ul.flags[u] & 1) | (leader ? ul.ch_f[r] << 1 : 0);  // | followers of one pass of the run << 1 (pass groups)
+        desc[2] = ul.flags[u] & 1;
         desc[3] = ul.flags[u] >> 1;  // run id: tiles with equal ids share one query list and may fold
         desc[4] = np ? ul.ch_n[r] : 0;
         desc[5] = np ? ul.ch_fb[r] : 0;
-        desc[6] = leader ? ul.ch_x[r] : 0;  // pass groups (UnitList::ch_x / ch_g): what stage1_pp_kernel's waves need to
-        desc[7] = leader ? ul.ch_g[r] : 0;  // find the other passes' records from the group leader's descriptor alone
     }
 }
 
@@ -884,7 +812,6 @@ __global__ __launch_bounds__(1024) void node_units_kernel(const int64_t* node_kv
                 hdr[1] = 0;
                 if (!keep_err) hdr[HDR_ERR] = 0;  // (the sequential plan's slot-list kernel has already run and may have flagged)
                 hdr[HDR_QLISTS] = 0;
-            hdr[HDR_GROUPS] = 0;
                 if (par && rt.n <= rt.cap) {
                     sMeta[0] = r;
                     sMeta[1] = rt.n;
@@ -951,7 +878,6 @@ __global__ __launch_bounds__(128) void node_records_kernel(const int64_t* node_k
     if (k == 0) {
         desc[4] = np ? ul.ch_n[r] : 0;
         desc[5] = np ? ul.ch_fb[r] : 0;
-        desc[6] = desc[7] = 0;  // (no pass groups in Node plans)
     }
     const int e0 = ul.src[u], aux = ul.aux[u], ps = ul.pass[u], prow = ul.prow[u];
     if (aux < 0) {

@@ -16,8 +16,7 @@ typedef short short4v __attribute__((ext_vector_type(4)));
 constexpr int PLAN_BYTES = 2048;
 constexpr int PLAN_ROWOFF = 0;   // int64[128]  byte offset of each slot's row in the pool (pads alias slot 0)
 constexpr int PLAN_MASK = 1024;  // uint32[128] bit v set <=> virtual row v sees the slot (0 for pads)
-constexpr int PLAN_DESC = 1536;  // int32[8]    n_vrows, prow, opens_run | follower stride between passes << 1, run_id, chunk tiles (0 = follower), first follower record,
-                                 //             second pass's leader record, passes in the group | rows of the last << 3 | leader stride << 9  (pass groups: UnitList::ch_x / ch_g / ch_f)
+constexpr int PLAN_DESC = 1536;  // int32[8]    n_vrows, prow, opens_run, run_id, chunk tiles (0 = follower), first follower record, -, -
 constexpr int PLAN_QSRC = 1600;  // int32[32]   element offset of row v's Q vector from q + kvh*G*q_stride_head
 constexpr int PLAN_OROW = 1728;  // int32[32]   partial row of row v, relative to kvh*G*rows: g*rows + prow + qi
 
@@ -28,7 +27,6 @@ constexpr int PLAN_OROW = 1728;  // int32[32]   partial row of row v, relative t
 constexpr int PLAN_HDR = 4096;
 constexpr int HDR_ERR = 2;
 constexpr int HDR_QLISTS = 3;
-constexpr int HDR_GROUPS = 4;  // hdr[4]  NG  leaders that lead a pass group (they come first): the work items per KV head of stage1_pp_kernel; 0 = no groups in this plan
 
 // 64 lanes x 16 bytes, global (per-lane address) -> LDS (lds_dst + 16*lane).  M0 is not
 // otherwise used by the kernels (checked in the .s), so it is written, not saved.
