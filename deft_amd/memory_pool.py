@@ -74,6 +74,7 @@ class TokenToKVPool:
         self._lo = 0  # every slot below this index is in use: where the search for free slots starts
         # [layer][size, key/value, head_num, head_dim] — memory_pool.py:61-66
         self._storage = torch.empty((layer_num, size, 2, head_num, head_dim), dtype=dtype, device=device)
+        self.device = self._storage.device  # (WITH its index: torch.device("cuda") != torch.device("cuda:0"))
         self.kv_data = [self._storage[i] for i in range(layer_num)]
 
     def get_key_buffer(self, layer_id: int) -> torch.Tensor:

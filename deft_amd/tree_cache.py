@@ -802,6 +802,8 @@ class TreeMetadata:
         if max_block_len == -1:
             max_block_len = BLOCK_CONFIG["MAX_BLOCK_LEN"]
         dev = torch.device(device) if device is not None else tree.token_to_kv_pool.device
+        if dev.type == "cuda" and dev.index is None:  # ("cuda" and "cuda:0" must name the same device copy of the tree)
+            dev = torch.device("cuda", torch.cuda.current_device())
         if dev.type != "cpu" and (DEVICE_METADATA if device_build is None else device_build):
             if not tree._consistent():
                 raise RuntimeError("tree.nodes / tree.leaves were edited behind TreeCache's back")

@@ -19,6 +19,11 @@ dur, gap, n = defaultdict(float), defaultdict(float), defaultdict(int)
 for (s0, e0, _), (s1, e1, k1) in zip(rows, rows[1:]):
     k = k1.split("(")[0][-60:]
     dur[k] += e1 - s1; gap[k] += s1 - e0; n[k] += 1
+big = [(s1 - e0, k1.split("(")[0][-50:]) for (s0, e0, _), (s1, e1, k1) in zip(rows, rows[1:]) if s1 - e0 > 3000]
+by = defaultdict(list)
+for g, k in big: by[k].append(g)
+for k, v in by.items():
+    print(f"gaps > 3 us in front of {k}: {len(v)}, mean {sum(v) / len(v) / 1e3:.2f} us")
 tot = rows[-1][1] - rows[0][0]
 print(f"{len(rows)} kernels over {tot / 1e3:.1f} us")
 for k in sorted(n, key=lambda k: -dur[k]):
