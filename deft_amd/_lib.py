@@ -147,8 +147,6 @@ _TREE_FUNCS = {
     "deft_tree_dev_build_md": ([C.c_int, C.c_int, C.c_int] + [_vp] * 6 + [C.c_int] * 4 + [_vp, _sz] + [_vp] * 12 + [_vp, _vp], C.c_int),
     "deft_tree_dev_build_md_ops": ([C.c_int, C.c_int, C.c_int] + [_vp] * 6 + [C.c_int] * 4 + [_vp, _sz] + [_vp] * 12 + [_vp, _vp] +
                                    [_vp, _i64, _vp, _vp, _vp], C.c_int),
-    "deft_tree_dev_build_md_staged": ([C.c_int, C.c_int, C.c_int] + [_vp] * 6 + [C.c_int] * 4 + [_vp, _sz] + [_vp] * 12 + [_vp, _vp] +
-                                      [_vp, _i64, _vp, _vp] + [_vp, _i64, C.c_int, _vp, _vp, _i64] + [_vp], C.c_int),
     "deft_tree_dev_apply_ops": ([C.c_int, C.c_int, C.c_int] + [_vp] * 6 + [_vp, _vp, _vp], C.c_int),
     "deft_tree_journal_take": ([_i64, _vp, _i64], _i64),
 }

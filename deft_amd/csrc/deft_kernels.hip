@@ -1872,7 +1872,7 @@ static int tree_dev_build_md_impl(int n_nodes, int nq, int nqw, const int32_t* n
                            int64_t* node_q_len, int64_t* node_kv_len, int64_t* node_q_offset, int64_t* node_kv_offset,
                            int64_t* block_q, int64_t* block_q_cnts, int64_t* block_q_offset, int64_t* block_bitmasks,
                            int64_t* block_kv, int64_t* block_lens, const int32_t* advance_loc, const int32_t* ops, PageWrite pw,
-                           void* stream, Staging stg = Staging{nullptr, 0, 0, nullptr, nullptr, 0}) {
+                           void* stream) {
     if (n_nodes <= 0 || nq < 0 || nqw < 1 || nbp_cap < 0 || !node_start || !node_len || !node_cap || !refs || !leaf_node || !slots ||
         !scratch) {
         set_error("deft_tree_dev_build_md: bad arguments (nodes=%d nq=%d)", n_nodes, nq);
@@ -1910,7 +1910,7 @@ static int tree_dev_build_md_impl(int n_nodes, int nq, int nqw, const int32_t* n
     int rc = raise_lds(reinterpret_cast<const void*>(&tree_md_scan_kernel), 136 * 1024, ATTR_TREE, "tree_md_scan");
     if (rc) return rc;
     hipLaunchKernelGGL(tree_md_scan_kernel, dim3(1), dim3(1024), scan_lds, st, t, sc, max_q_len, block_len, max_block_len, nbp_cap,
-                       advance_loc, ops, pw, stg);
+                       advance_loc, ops, pw);
     rc = check_launch("tree scan launch");
     if (rc) return rc;
     if (nbp_cap > 0 && n_block_ptrs) {
@@ -1956,38 +1956,6 @@ int deft_tree_dev_build_md_ops(int n_nodes, int nq, int nqw, const int32_t* node
                                   max_block_len, nbp_cap, scratch, scratch_bytes, node_q, node_kv, node_q_len, node_kv_len,
                                   node_q_offset, node_kv_offset, block_q, block_q_cnts, block_q_offset, block_bitmasks, block_kv,
                                   block_lens, advance_loc, ops, PageWrite{page_table, page_stride, page_rows, page_cols}, stream);
-}
-
-// deft_tree_dev_build_md_ops whose per-step host inputs arrive WITHOUT a copy of their own: `staging_dev` (the device buffer
-// that advance_loc, ops, page_rows and page_cols point into) is filled by the step's first kernel from slot
-// (*step_counter % ring_slots) of `host_ring` -- pinned, device-accessible host memory -- and the kernel then advances the
-// counter.  The caller writes slot (launches so far % ring_slots) before every launch and must not overwrite a slot before the
-// launch that reads it has finished.
-int deft_tree_dev_build_md_staged(int n_nodes, int nq, int nqw, const int32_t* node_start, int32_t* node_len, const int32_t* node_cap,
-                                  const uint64_t* refs, const int32_t* leaf_node, int32_t* slots, int max_q_len, int block_len,
-                                  int max_block_len, int nbp_cap, void* scratch, size_t scratch_bytes, int64_t* node_q,
-                                  int64_t* node_kv, int64_t* node_q_len, int64_t* node_kv_len, int64_t* node_q_offset,
-                                  int64_t* node_kv_offset, int64_t* block_q, int64_t* block_q_cnts, int64_t* block_q_offset,
-                                  int64_t* block_bitmasks, int64_t* block_kv, int64_t* block_lens, const int32_t* advance_loc,
-                                  const int32_t* ops, int32_t* page_table, int64_t page_stride, const int64_t* page_rows,
-                                  const int64_t* page_cols, const void* host_ring, int64_t ring_slot_bytes, int ring_slots,
-                                  int32_t* step_counter, void* staging_dev, int64_t staging_bytes, void* stream) {
-    if (page_table && (!advance_loc || !page_rows || !page_cols || page_stride <= 0)) {
-        set_error("deft_tree_dev_build_md_staged: the page-table write needs advance_loc, rows, cols and a row stride");
-        return DEFT_EINVAL;
-    }
-    if (!host_ring || !step_counter || !staging_dev || ring_slots < 1 || staging_bytes < 0 || staging_bytes % 4 || ring_slot_bytes % 16 ||
-        staging_bytes > ring_slot_bytes) {
-        set_error("deft_tree_dev_build_md_staged: bad staging ring (slots=%d, slot bytes=%lld, bytes=%lld)", ring_slots,
-                  (long long)ring_slot_bytes, (long long)staging_bytes);
-        return DEFT_EINVAL;
-    }
-    return tree_dev_build_md_impl(n_nodes, nq, nqw, node_start, node_len, node_cap, refs, leaf_node, slots, max_q_len, block_len,
-                                  max_block_len, nbp_cap, scratch, scratch_bytes, node_q, node_kv, node_q_len, node_kv_len,
-                                  node_q_offset, node_kv_offset, block_q, block_q_cnts, block_q_offset, block_bitmasks, block_kv,
-                                  block_lens, advance_loc, ops, PageWrite{page_table, page_stride, page_rows, page_cols}, stream,
-                                  Staging{static_cast<const char*>(host_ring), ring_slot_bytes, ring_slots, step_counter,
-                                          static_cast<char*>(staging_dev), staging_bytes});
 }
 
 }  // extern "C"

@@ -227,21 +227,6 @@ struct PageWrite {
     const int64_t* cols;   // [nq] position of its new token
 };
 
-// What the host supplies per step (slot numbers, page-table coordinates, the journal of absorbed changes), read by the step's
-// first kernel STRAIGHT FROM PINNED HOST MEMORY: a ring of `slots` staging slots of `slot_bytes`, the slot of this launch =
-// *counter % slots (a device word the kernel itself advances, so a captured launch has the same arguments on every step), copied
-// to `dst` -- the fixed device buffer every later kernel of the step reads -- before anything else.  Round 3: the separate
-// host-to-device copy in front of every step cost a blit-kernel launch and a queue hand-over, ~15 us per step next to the 8 us
-// between two back-to-back step graphs (profiles/r3h_*).
-struct Staging {
-    const char* ring;    // pinned host memory, device-accessible (null = none)
-    int64_t slot_bytes;  // bytes between two slots (multiple of 16)
-    int slots;
-    int32_t* counter;    // device: launches so far
-    char* dst;           // device
-    int64_t bytes;       // bytes to copy (multiple of 4, <= slot_bytes)
-};
-
 // One workgroup.  `adv` (cache_loc != null): first append this step's slots to the leaves (tree_advance_kernel's work,
 // folded in: one launch fewer per step).  The scans run over tables in LDS when the tree fits (TREE_LDS_NODES nodes,
 // TREE_LDS_BLOCKS blocks: every tree but a pathological one) -- a scan whose input and output live in global memory pays
@@ -251,21 +236,12 @@ constexpr int TREE_LDS_BLOCKS = 8192;
 
 __global__ __launch_bounds__(1024) void tree_md_scan_kernel(TreeDev t, TreeScratch s, int max_q_len, int block_len,
                                                             int max_block_len, int nbp_cap, const int32_t* cache_loc,
-                                                            const int32_t* ops, PageWrite pw, Staging stg) {
+                                                            const int32_t* ops, PageWrite pw) {
     __shared__ int sWave[16];
     __shared__ int sCarry;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int n = t.n, nqw = t.nqw;
     const int tid = threadIdx.x;
-    if (stg.ring) {  // this step's staging slot -> the device buffer `cache_loc`, `ops` and the page-table coordinates point into
-        const int c = *stg.counter;
-        const int32_t* src = reinterpret_cast<const int32_t*>(stg.ring + (int64_t)(c % stg.slots) * stg.slot_bytes);
-        int32_t* dst = reinterpret_cast<int32_t*>(stg.dst);
-        for (int64_t i = tid; i < stg.bytes / 4; i += 1024) dst[i] = __builtin_nontemporal_load(src + i);
-        __threadfence();
-        __syncthreads();
-        if (tid == 0) *stg.counter = c + 1;
-    }
     if (ops && ops[0] > 0) {  // the journal of this step's absorbed changes first (uniform branch), then the step's new slots
         __shared__ int sNew[TREE_OPS_NEW], sPos[TREE_OPS_NEW], sMeta[4], sOps[TREE_OPS_LDS];
         tree_apply_ops(t, ops, s.dims + TREE_ERR, sNew, sPos, sMeta, sOps);

@@ -12,9 +12,9 @@ so the whole step is captured once and replayed:
     per-step plan                                                    flatten_units / _records, qrows_hist / _fill
     layers x (fused paged append + stage 1, merge)                   stage1_np_kernel, merge_kernel
 
-Per step the host picks the new slots (its allocator mirrors the pool), appends them to the native tree, writes
-nq slot numbers and page-table coordinates into a pinned staging slot -- which the step's first kernel reads directly -- and
-replays: ~0.1 ms of host time, nothing else crosses PCIe.  A branch / cut / merge (or a leaf outgrowing its room) starts a new epoch: upload the compact tree, capture again.
+Per step the host picks the new slots (its allocator mirrors the pool), appends them to the native tree, copies
+nq slot numbers and page-table coordinates from pinned memory, and replays: ~0.1 ms of host time, nothing else crosses
+PCIe.  A branch / cut / merge (or a leaf outgrowing its room) starts a new epoch: upload the compact tree, capture again.
 
 DeFT-Flatten and DeFT-Node, head_dim 128.  The eager path (`tree.alloc()` + `TreeMetadata.from_tree_cache` + `DeFTAttention`) gives the same
 results step for step (tests/test_session.py).
@@ -40,7 +40,8 @@ class DecodeSession:
         pool = tree.token_to_kv_pool
         assert pool.device.type == "cuda" and head_dim == 128 and mode in ("flatten", "node")
         self.mode = mode
-        # (the device WITH its index: "cuda" != "cuda:0" for torch.device, and the page-table fold below compares devices)
+        # (the device WITH its index: torch.device("cuda") != torch.device("cuda:0"), and the page-table fold below compares devices --
+        #  round 3: with the default "cuda" pool the fold never happened and every step carried an index_put)
         self.tree, self.pool, self.device = tree, pool, pool._storage.device
         self.Hq, self.Hkv, self.D, self.layers = num_heads, num_kv_heads, head_dim, layers
         self.qkv, self.max_q_len, self.use_graph = qkv, max_q_len, use_graph
@@ -48,13 +49,8 @@ class DecodeSession:
         self.graph_epoch = -1
         self.captures = 0
         self.out: List[torch.Tensor] = []
-        # per-step host inputs: a ring of pinned staging slots the step's first kernel reads directly (no copy of its own)
-        self._ring: Optional[torch.Tensor] = None  # uint8 [RING][slot bytes], pinned
-        self._ring_ev: list = [None] * self.RING  # event of the last launch that read the slot
-        self._launches = 0  # steps launched since the ring / counter were made: the device counter's mirror
-        self._step_ctr: Optional[torch.Tensor] = None  # device int32: the same number, advanced by the kernel
-
-    RING = 4
+        self._pin: list = []  # pinned staging buffers in rotation: [buffer, event of its last upload]
+        self._pin_k = -1
 
     # ---- per epoch ----------------------------------------------------------------------------------------
     def _epoch_setup(self) -> bool:
@@ -96,16 +92,6 @@ class DecodeSession:
         self.idx = self._small[cb:ob].view(torch.int64).view(2, nqm)
         self.ops = self._small[ob:].view(torch.int32)
         self._ops_off = ob
-        # (a new ring with every new staging size: nobody reads the old one once the stream has drained past its launches)
-        nb = self._small.numel()
-        self._slot_bytes = (nb + 15) // 16 * 16
-        if self._ring is None or self._ring.shape[1] != self._slot_bytes:
-            if self._ring is not None:
-                torch.cuda.current_stream(dev).synchronize()  # steps still in flight read the old ring (pinned memory is not stream-ordered)
-            self._ring = torch.zeros((self.RING, self._slot_bytes), dtype=torch.uint8).pin_memory()
-            self._ring_ev = [None] * self.RING
-            self._launches = 0
-            self._step_ctr = torch.zeros(1, dtype=torch.int32, device=dev)
         self.out = [torch.empty((self.nq, Hq * D), dtype=torch.float16, device=dev) for _ in range(self.layers)]
         order = sorted(tree.leaves)
         self.leaf_handles = [tree.leaves[i] for i in order]
@@ -123,22 +109,19 @@ class DecodeSession:
         # (page-table entries of this step's tokens: written by the step's first kernel when the table is what the kernel
         #  expects -- int32, contiguous rows, on this device --, by an index_put otherwise)
         fold = advance and table.dtype == torch.int32 and table.device == dev and table.dim() == 2 and table.stride(1) == 1
+        if not fold:
+            table[self.idx[0], self.idx[1]] = self.cache_loc
         mq, bl, mbl = dt.cfg
         # (the append of this step's slots to the device tree rides in the first metadata kernel)
         # (only the six arrays this mode's operator reads are written: the kernel of the other group is not launched)
         wanted = _FIELDS[6:] if self.mode == "flatten" else _FIELDS[:6]
         # (first the journal of changes the epoch absorbed since the last step -- {0} when there are none --, then the advance)
-        # (... and so does the upload of this step's host inputs: the kernel reads its staging slot from pinned memory)
-        check(lib.deft_tree_dev_build_md_staged(*dt._tree_args(), mq, bl, mbl, dt.nbp_cap, dt.scratch.data_ptr(), dt.scratch_bytes,
-                                                *[self.md_ptrs[k] if k in wanted else None for k in _FIELDS],
-                                                self.cache_loc.data_ptr() if advance else None, self.ops.data_ptr(),
-                                                table.data_ptr() if fold else None, table.stride(0) if fold else 0,
-                                                self.idx[0].data_ptr() if fold else None, self.idx[1].data_ptr() if fold else None,
-                                                self._ring.data_ptr(), self._slot_bytes, self.RING, self._step_ctr.data_ptr(),
-                                                self._small.data_ptr(), self._small.numel(), stream),
-              "deft_tree_dev_build_md_staged")
-        if not fold:  # (after the kernel that brings this step's inputs to the device)
-            table[self.idx[0], self.idx[1]] = self.cache_loc
+        check(lib.deft_tree_dev_build_md_ops(*dt._tree_args(), mq, bl, mbl, dt.nbp_cap, dt.scratch.data_ptr(), dt.scratch_bytes,
+                                             *[self.md_ptrs[k] if k in wanted else None for k in _FIELDS],
+                                             self.cache_loc.data_ptr() if advance else None, self.ops.data_ptr(),
+                                             table.data_ptr() if fold else None, table.stride(0) if fold else 0,
+                                             self.idx[0].data_ptr() if fold else None, self.idx[1].data_ptr() if fold else None, stream),
+              "deft_tree_dev_build_md_ops")
         Hq, Hkv, D = self.Hq, self.Hkv, self.D
         q0, k0, _ = self.qkv(0)
         kv0 = self.pool.kv_data[0]
@@ -191,44 +174,42 @@ class DecodeSession:
                     uploaded, jn = self._epoch_setup(), 0
             self._write_staging(loc, jn)
             self._launch_step(advance=not uploaded)
-            self._launched()
             return self.out
         self._write_staging(loc, jn)
         if not self.use_graph:
             self._launch_step()
-            self._launched()
             return self.out
         if self.graph is None:
             self._capture()
         self.graph.replay()
-        self._launched()
         return self.out
 
-    def _launched(self) -> None:
-        """One step is on the stream: its staging slot is busy until that work is done; the next step takes the next slot."""
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(self.device))
-        self._ring_ev[self._launches % self.RING] = ev
-        self._launches += 1
-
     def _write_staging(self, loc: np.ndarray, journal_words: int = 0) -> None:
-        """This step's slot numbers, page-table coordinates and journal into the staging slot the step's first kernel will read
-        (slot = steps launched so far % RING, what the device counter says at that launch); a slot is rewritten only when the
-        launch that last read it has finished, so the host runs up to RING - 1 steps ahead of the GPU."""
-        n = self.nq
-        k = self._launches % self.RING
-        if self._ring_ev[k] is not None:
-            self._ring_ev[k].synchronize()
-        h = self._ring[k].numpy()
+        """This step's slot numbers and page-table coordinates: pinned staging -> the fixed device tensors the graph reads, in
+        one copy.  Four pinned buffers in rotation, each guarded by the event of its last upload (a pageable source would make
+        the copy wait for the stream to drain -- the host would run in lock-step with the GPU)."""
+        n, nb = self.nq, self._small.numel()
+        self._pin_k = (self._pin_k + 1) % 4
+        while len(self._pin) <= self._pin_k:
+            self._pin.append(None)
+        ent = self._pin[self._pin_k]
+        if ent is None or ent[0].numel() != nb:
+            ent = self._pin[self._pin_k] = [torch.zeros(nb, dtype=torch.uint8).pin_memory(), None]
+        if ent[1] is not None:
+            ent[1].synchronize()
+        h = ent[0].numpy()
         nqm = max(n, 1)
         h[: 4 * n].view(np.int32)[:] = loc
         idx_h = h[self._ops_off - 16 * nqm : self._ops_off].view(np.int64).reshape(2, nqm)
         idx_h[0, :n] = self.leaf_reqs
         idx_h[1, :n] = [lf.positions[-1] for lf in self.leaf_handles]
-        ops_h = h[self._ops_off : self._small.numel()].view(np.int32)
+        ops_h = h[self._ops_off :].view(np.int32)
         ops_h[0] = journal_words
         if journal_words:
             ops_h[1 : 1 + journal_words] = self._journal[:journal_words]
+        self._small.copy_(ent[0], non_blocking=True)
+        ent[1] = torch.cuda.Event()
+        ent[1].record(torch.cuda.current_stream(self.device))
 
     def _capture(self) -> None:
         dev = self.device

@@ -439,22 +439,6 @@ int deft_tree_dev_build_md_ops(int n_nodes, int nq, int nqw, const int32_t* node
                                   page-table write of TreeCache.alloc (tree_cache.py:270-283) in the same kernel */
                                int32_t* page_table /* nullable */, int64_t page_stride, const int64_t* page_rows,
                                const int64_t* page_cols, void* stream);
-/* ... and with the step's host inputs read by that first kernel straight from PINNED host memory (no copy in front of the step):
- * `staging_dev` (device; advance_loc, ops, page_rows and page_cols point into it) is filled from slot (*step_counter % ring_slots)
- * of `host_ring` (device-accessible pinned memory, ring_slot_bytes apart), then *step_counter (a device word) is advanced by one.
- * The caller writes slot (launches so far % ring_slots) before each launch and keeps a slot untouched until the launch that
- * reads it has finished.  Same arguments on every step of an epoch, as above.  (DecodeSession: tree_cache.py:242-283, the
- * out_cache_loc upload of TreeCache.alloc, without its copy.) */
-int deft_tree_dev_build_md_staged(int n_nodes, int nq, int nqw, const int32_t* node_start, int32_t* node_len, const int32_t* node_cap,
-                                  const uint64_t* refs, const int32_t* leaf_node, int32_t* slots, int max_q_len, int block_len,
-                                  int max_block_len, int nbp_cap, void* scratch, size_t scratch_bytes, int64_t* node_q,
-                                  int64_t* node_kv, int64_t* node_q_len, int64_t* node_kv_len, int64_t* node_q_offset,
-                                  int64_t* node_kv_offset, int64_t* block_q, int64_t* block_q_cnts, int64_t* block_q_offset,
-                                  int64_t* block_bitmasks, int64_t* block_kv, int64_t* block_lens,
-                                  const int32_t* advance_loc /* nullable */, const int32_t* ops /* nullable */,
-                                  int32_t* page_table /* nullable */, int64_t page_stride, const int64_t* page_rows,
-                                  const int64_t* page_cols, const void* host_ring, int64_t ring_slot_bytes, int ring_slots,
-                                  int32_t* step_counter, void* staging_dev, int64_t staging_bytes, void* stream);
 
 #ifdef __cplusplus
 }
