@@ -212,7 +212,8 @@ class DecodeSession:
         if journal_words:
             ops_h[1 : 1 + journal_words] = self._journal[:journal_words]
         self._small.copy_(ent[0], non_blocking=True)
-        ent[1] = torch.cuda.Event()
+        if ent[1] is None:
+            ent[1] = torch.cuda.Event()  # (one event per staging buffer, re-recorded: not one hipEventCreate per step)
         ent[1].record(torch.cuda.current_stream(self.device))
 
     def _capture(self) -> None:
