@@ -113,6 +113,7 @@ class DecodeSession:
         # (page-table entries of this step's tokens: written by the step's first kernel when the table is what the kernel
         #  expects -- int32, contiguous rows, on this device --, by an index_put otherwise)
         fold = advance and table.dtype == torch.int32 and table.device == dev and table.dim() == 2 and table.stride(1) == 1
+        self.page_table_folded = fold  # (tests: the fold must really happen for the pools this package makes)
         if not fold:
             table[self.idx[0], self.idx[1]] = self.cache_loc
         mq, bl, mbl = dt.cfg

@@ -104,6 +104,8 @@ def test_session_after_device_built_metadata_of_the_same_tree(mode):
             nq_now[0] = n
             ref = [attn[l](q[l, :n], k[l, :n], v[l, :n], deft_amd.InputMetadata(fmode, upd, pe)) for l in range(layers)]
             out = sess.step()
+            if s > 0:  # (every step after an epoch's first writes its page-table entries in the step's first kernel, not by an index_put)
+                assert sess.page_table_folded
             torch.cuda.synchronize()
             for l in range(layers):
                 assert torch.equal(out[l][:n], ref[l]), (s, l)
