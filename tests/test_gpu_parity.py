@@ -538,10 +538,13 @@ def test_many_partial_rows_take_several_merge_passes(mode, shape):
 
 
 @pytest.mark.parametrize("mode", ["flatten", "node"])
-@pytest.mark.parametrize("shape", [(4, 4, 70), (8, 2, 100), (4, 4, 33)])
+@pytest.mark.parametrize("shape", [(4, 4, 70), (8, 2, 100), (4, 4, 33), (12, 4, 40), (6, 6, 17), (10, 2, 9), (24, 8, 35), (7, 1, 5)])
 def test_nodes_with_more_than_32_queries_fold_as_interleaved_runs(mode, shape):
     """A node shared by 33 / 70 / 100 leaves is cut by the reference's builder into alternating blocks of at most 32
-    queries (period 2, 3, 4): the plan folds each query chunk's blocks as one run.  Against fp64 attention per leaf."""
+    queries (period 2, 3, 4): the plan folds each query chunk's blocks as one run.  Against fp64 attention per leaf.
+    The later shapes: head counts and group sizes that are not powers of two (3, 5 and 7 query heads per KV head, six MHA
+    heads) and query counts that do not fill the merge's four-query workgroups -- its head-to-workgroup permutation
+    (a head is merged on the XCD that wrote its rows) must stay a bijection for all of them."""
     from deft_amd.memory_pool import ReqToTokenPool, TokenToKVPool
     from deft_amd.tree_cache import TreeCache
 
