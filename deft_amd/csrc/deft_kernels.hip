@@ -617,6 +617,10 @@ static UnitList unit_list(const PlanView& pv) {
 static int launch_qrows(const PlanView& pv, hipStream_t stream) {
     const int64_t rows = pv.rows;
     if (rows <= 0 || rows > QROWS_MAX) return DEFT_OK;  // hdr[HDR_QLISTS] stays 0: the merge scans row_q itself
+    if (rows <= QROWS_FUSED_MAX) {  // one launch for the usual sizes
+        hipLaunchKernelGGL(qrows_fused_kernel, dim3(1), dim3(1024), 0, stream, pv.row_q, (int)rows, pv.qoff, pv.qlist, pv.qinl, pv.hdr);
+        return check_launch("qrows launch");
+    }
     hipLaunchKernelGGL(qrows_hist_kernel, dim3(1), dim3(1024), sizeof(int) * (size_t)rows, stream, pv.row_q, (int)rows, pv.qoff, pv.hdr);
     int rc = check_launch("qrows hist launch");
     if (rc) return rc;

@@ -1050,4 +1050,73 @@ __global__ __launch_bounds__(256) void qrows_fill_kernel(const int32_t* row_q, i
     }
 }
 
+// Both steps in ONE workgroup for the usual row counts (<= QROWS_FUSED_MAX partial rows: every single tree of BASELINE.json; a
+// launch boundary alone costs ~2.5 us, and the row lists are one of six launches in front of every decode step's first layer):
+// row_q is staged in LDS once, counted, scanned, and every wave then fills the lists of the queries q = wave, wave + 16, ...
+// up to the largest query that has a row.  Same qoff / qlist / qinl as the two kernels above, word for word.
+constexpr int QROWS_FUSED_MAX = 4096;
+__global__ __launch_bounds__(1024) void qrows_fused_kernel(const int32_t* row_q, int rows, int32_t* qoff, int32_t* qlist, int32_t* qinl,
+                                                           int32_t* hdr) {
+    __shared__ int sRow[QROWS_FUSED_MAX], sCnt[QROWS_FUSED_MAX + 1];
+    __shared__ int sWave[16], sQmax;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) sQmax = -1;
+    for (int i = tid; i < rows; i += 1024) sCnt[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < rows; i += 1024) {
+        const int q = row_q[i];
+        sRow[i] = q;
+        if (q >= 0 && q < rows) {
+            atomicAdd(&sCnt[q], 1);  // LDS integer adds: the counts do not depend on the order
+            atomicMax(&sQmax, q);
+        }
+    }
+    __syncthreads();
+    // exclusive scan of sCnt[0 .. rows) in place (qrows_hist_kernel's), offsets also to qoff
+    const int per = (rows + 1023) / 1024;
+    const int lo = tid * per, hi = min(rows, lo + per);
+    int sum = 0;
+    for (int i = lo; i < hi; ++i) sum += sCnt[i];
+    int inc = sum;
+    for (int d = 1; d < 64; d <<= 1) {
+        const int u = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += u;
+    }
+    if (lane == 63) sWave[wave] = inc;
+    __syncthreads();
+    int base = 0;
+    for (int k = 0; k < wave; ++k) base += sWave[k];
+    int run = base + inc - sum;
+    for (int i = lo; i < hi; ++i) {
+        const int c = sCnt[i];
+        sCnt[i] = run;
+        qoff[i] = run;
+        qinl[i * 16] = c;  // {count, first 15 rows} of query i (qrows_fill_kernel)
+        run += c;
+    }
+    if (tid == 1023) {
+        sCnt[rows] = run;
+        qoff[rows] = run;
+        hdr[HDR_QLISTS] = 1;
+    }
+    __syncthreads();
+    const int qmax = sQmax;
+    for (int q = wave; q <= qmax; q += 16) {
+        const int o = sCnt[q], n = sCnt[q + 1] - o;
+        if (n <= 0) continue;  // (wave-uniform)
+        int found = 0;
+        for (int b0 = 0; b0 < rows && found < n; b0 += 64) {
+            const int i = b0 + lane;
+            const bool hit = i < rows && sRow[i] == q;
+            const unsigned long long mask = __ballot(hit);
+            if (hit) {
+                const int pos = found + __popcll(mask & ((1ull << lane) - 1ull));
+                qlist[o + pos] = i;
+                if (pos < 15) qinl[q * 16 + 1 + pos] = i;
+            }
+            found += __popcll(mask);
+        }
+    }
+}
+
 }  // namespace deft
