@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Fill the TAG_* placeholders of DESIGN.md's end-of-round paragraph from the files tools/end_of_round.sh wrote:
-   tools/fill_round_numbers.py r3z [dir = gpurun_out/r3z]     (placeholders are R3Z_*; prints what it filled)"""
+"""(Re)write DESIGN.md's end-of-round paragraph from its template (tools/end_of_round_paragraph.md, placeholders R3Z_*) and the
+files tools/end_of_round.sh wrote:   tools/fill_round_numbers.py r3z [dir = gpurun_out/r3z]     (prints what it filled)"""
 import json, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
@@ -57,6 +57,13 @@ vals = {
 vals["TOTR"] = per_step(replay("reasoning_tot50", "flatten"))
 path = os.path.join(ROOT, "DESIGN.md")
 txt = open(path).read()
+tpl = os.path.join(ROOT, "tools", "end_of_round_paragraph.md")
+if os.path.exists(tpl):  # the paragraph between the two headings is replaced by the template, then filled
+    t = open(tpl).read()
+    head = t.split("**", 2)[1]  # "End of round N"
+    a = txt.index("**" + head + "**")
+    b = txt.index("**End of round", a + 4)
+    txt = txt[:a] + t + txt[b:]
 # longest keys first: R3Z_E2EE before R3Z_E2E, R3Z_S1RP before R3Z_S1, R3Z_TOTR before R3Z_TOT, R3Z_CFG5E2E before R3Z_CFG5, ...
 for k in sorted(vals, key=len, reverse=True):
     n = txt.count(P + k)
