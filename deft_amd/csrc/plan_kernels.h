@@ -1063,14 +1063,17 @@ __global__ __launch_bounds__(1024) void qrows_fused_kernel(const int32_t* row_q,
     if (tid == 0) sQmax = -1;
     for (int i = tid; i < rows; i += 1024) sCnt[i] = 0;
     __syncthreads();
+    int my_max = -1;
     for (int i = tid; i < rows; i += 1024) {
         const int q = row_q[i];
         sRow[i] = q;
         if (q >= 0 && q < rows) {
             atomicAdd(&sCnt[q], 1);  // LDS integer adds: the counts do not depend on the order
-            atomicMax(&sQmax, q);
+            my_max = max(my_max, q);
         }
     }
+    for (int sft = 32; sft > 0; sft >>= 1) my_max = max(my_max, __shfl_xor(my_max, sft));
+    if (lane == 0 && my_max >= 0) atomicMax(&sQmax, my_max);  // (one atomic per wave: 1024 of them on one word serialise)
     __syncthreads();
     // exclusive scan of sCnt[0 .. rows) in place (qrows_hist_kernel's), offsets also to qoff
     const int per = (rows + 1023) / 1024;
