@@ -644,6 +644,11 @@ int deft_tree_layout_fetch(int64_t tree, int32_t* node_start, int32_t* node_len,
         }
         ++r;
     }
+    // The image holds every change made so far, journalled or not: whoever uploads it must not replay the journal on top of
+    // it (a second device copy made inside one epoch -- another max_q_len / BLOCK_CONFIG / device -- would otherwise see the
+    // pending EXTENDs twice).
+    t->journal.clear();
+    t->last_ext = -1;
     return DEFT_OK;
 }
 

@@ -97,7 +97,8 @@ __device__ inline void tree_apply_ops(const TreeDev& t, const int32_t* ops_g, in
     }
     for (int at = 1; at + 2 < words + 1;) {  // (uniform: every thread reads the same words)
         const int op = ops[at], node = ops[at + 1], k = ops[at + 2];
-        if (node < 0 || node >= t.n || k < 0 || at + 3 + k > words + 1 || k > TREE_OPS_NEW) {
+        // (a RESET carries no slots: one with k != 0 would pass for "not a reset" below and the walk would never advance)
+        if (node < 0 || node >= t.n || k < 0 || at + 3 + k > words + 1 || k > TREE_OPS_NEW || (op == 2 && k != 0)) {
             if (tid == 0) atomicOr(err, 4);
             break;
         }

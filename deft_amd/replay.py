@@ -33,8 +33,9 @@ import torch
 
 from .forward_mode import ForwardMode, InputMetadata, forward_mode_from_cli
 from .memory_pool import ReqToTokenPool, TokenToKVPool
-from .templates import (TreeTemplate, fit_accept_lengths, read_reasoning_file, read_speculative_file,  # noqa: F401
-                        synthetic_few_shot_template, synthetic_reasoning_template, synthetic_speculative_template)
+from .templates import (TreeTemplate, default_prompt_len, fit_accept_lengths, read_reasoning_file,  # noqa: F401
+                        read_speculative_file, synthetic_few_shot_template, synthetic_reasoning_template,
+                        synthetic_speculative_template)
 from .tree_cache import TreeCache, TreeMetadata, register_tree_metadata
 
 __all__ = [
@@ -248,7 +249,7 @@ class TemplateReplay:
         sess = None
         nq_now = [1]
         if self.session:
-            from ._lib import lib
+            from ._lib import check, lib
             from .session import DecodeSession
             from .tree_cache import _ptr
 
@@ -288,7 +289,8 @@ class TemplateReplay:
                     e1.synchronize()
                     t_attn = e0.elapsed_time(e1)
                 # sizes for the reference's IO counters, from node lengths on the host (no device read)
-                lib.deft_tree_md_sizes(tree._native, 32, 128, -1, 0, _ptr(sizes))
+                mq, bl, mbl = sess.dt.cfg
+                check(lib.deft_tree_md_sizes(tree._native, mq, bl, mbl, 0, _ptr(sizes)), "deft_tree_md_sizes")
                 kv_tokens, node_kv_n = int(sizes[2]), int(sizes[4])
                 t1 = time.perf_counter()
                 logits = self._scores(nq)

@@ -27,7 +27,7 @@ from typing import Any, Dict, Iterable, List, Mapping, Optional, Sequence, Tuple
 import numpy as np
 
 __all__ = ["TreeTemplate", "read_reasoning_file", "read_speculative_file", "fit_accept_lengths", "synthetic_reasoning_template",
-           "synthetic_speculative_template", "synthetic_few_shot_template"]
+           "synthetic_speculative_template", "synthetic_few_shot_template", "default_prompt_len"]
 
 OPEN_ENDED = 1 << 30  # `value` / `end` of a node that generates until the replay's own limit (few-shot leaves)
 
@@ -229,3 +229,13 @@ def synthetic_few_shot_template(width: int = 32) -> TreeTemplate:
     n = width + 1
     return TreeTemplate([0] + [OPEN_ENDED] * width, [0] + [1] * width, [0] + [OPEN_ENDED] * width,
                         [list(range(1, n))] + [[] for _ in range(width)])
+
+
+def default_prompt_len(tpl: TreeTemplate, task: str, from_file: bool = False) -> int:
+    """Prompt length of a replay that was given none: a reasoning template READ FROM A FILE carries it as the root's token count
+    (data_loader.py:31-49: the root node of a Reasoning tree is the prompt); otherwise BASELINE's shapes -- a ~1k-token root under a
+    speculative-decoding tree, a 4k prompt under everything else."""
+    root_tokens = int(tpl.value[0])
+    if from_file and task == "reasoning" and 0 < root_tokens < OPEN_ENDED:
+        return root_tokens
+    return 1016 if task == "speculative_decoding" else 4096

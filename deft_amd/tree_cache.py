@@ -436,8 +436,11 @@ class TreeCache:
             idx = torch.from_numpy(np.asarray([[self.leaf_to_req[i] for i in order],
                                                [self.leaves[i].positions[-1] for i in order]], dtype=np.int64)).to(table.device)
         if synced and dev.epoch == self._epoch():
-            dev.apply_journal()  # (absorbed changes since the last step -- merge_nodes / reset_node_KV -- come first)
-            dev.advance(cache_loc)  # the device copy of the tree appends the same slots itself
+            # absorbed changes since the last step -- merge_nodes / reset_node_KV -- come first; then the device copy of the tree
+            # appends the same slots itself, UNLESS the journal was too long to replay and the copy was uploaded afresh: that image
+            # was made after deft_tree_alloc_step and already ends in this step's slots
+            if dev.apply_journal() >= 0:
+                dev.advance(cache_loc)
         table[idx[0], idx[1]] = cache_loc.to(table.device)  # one batched page-table write
         return KVCacheUpdater(True, self.token_to_kv_pool, cache_loc, None, False)
 
@@ -696,18 +699,19 @@ class _DeviceTree:
         if self.epoch != self.tree._epoch():
             self._upload()
             return True
-        self.apply_journal()
-        return False
+        return self.apply_journal() < 0
 
     def apply_journal(self) -> int:
         """Hand the native tree's journal of absorbed changes to the device copy (eager: one small upload + one kernel); returns
-        the words replayed.  A captured session does the same inside its step graph (deft_tree_dev_build_md_ops)."""
+        the words replayed, or -1 when the journal was too long for one replay and the whole tree was UPLOADED instead (the image
+        then holds every slot the native tree holds now, this step's included: the caller must not advance it again).  A captured
+        session does the same inside its step graph (deft_tree_dev_build_md_ops)."""
         cap = 64 + 8 * max(self.nq, 1) + 4 * self.n
         buf = np.zeros(cap + 1, dtype=np.int32)
         nw = int(lib.deft_tree_journal_take(self.tree._native, _ptr(buf[1:]), cap))
         if nw == -5:  # too long for one replay: the call started a new epoch
             self._upload()
-            return 0
+            return -1
         if nw < 0:
             check(nw, "deft_tree_journal_take")
         if nw == 0:

@@ -230,7 +230,7 @@ def test_journal_path_reproduces_the_reference_golden(golden):
     def counting_j(self):
         nonlocal replayed
         n = orig_j(self)
-        replayed += n
+        replayed += max(n, 0)
         return n
 
     tc._DeviceTree._upload, tc._DeviceTree.apply_journal = counting_up, counting_j
@@ -261,3 +261,70 @@ def test_journal_path_reproduces_the_reference_golden(golden):
         assert np.array_equal(got[k], g[k]), k
     assert [md.query_num, md.node_num, md.total_kv_len, md.block_len] == g["scalars"].tolist()
     assert np.array_equal(pool.mem_state, g["pool_refcounts"])
+
+
+def _two_leaf_tree(prompt=50, slots=4096):
+    req = deft_amd.ReqToTokenPool(16, slots, device="cuda")
+    pool = deft_amd.TokenToKVPool(slots, torch.float16, 1, 128, 1, device="cuda")
+    tree = deft_amd.TreeCache(torch.float16, 1, 128, 1, req, pool, None, True, False)
+    tree.init_prompt(torch.arange(1, prompt + 1, dtype=torch.int32))
+    tree.branch(tree.root, 2)
+    return tree
+
+
+def _step(tree):
+    for leaf in list(tree.leaves.values()):
+        leaf.append_token(7)
+    tree.alloc()
+
+
+def test_journal_too_long_for_one_replay_uploads_and_does_not_advance_twice():
+    """A journal longer than one eager replay holds (64 + 8 nq + 4 n words: a 100-slot extend of a leaf on a 2-leaf tree) makes
+    `alloc()` upload the tree instead -- AFTER the step's slots went into the native tree, so the image already ends in them and the
+    device copy must not append them a second time (round 3 did: a duplicate slot per leaf from then on)."""
+    tree = _two_leaf_tree()
+    _step(tree)
+    _assert_same(*_both(tree))  # the device copy exists and is current
+    leaf = sorted(tree.leaves.values(), key=lambda n: n.id)[0]
+    tree.extend_leaf(leaf, torch.arange(100, dtype=torch.int32))  # absorbed: the leaf has room for 256; journalled, 103 words
+    epoch = tree._epoch()
+    _step(tree)  # journal_take -> too long -> new epoch + upload inside alloc()
+    assert tree._epoch() == epoch + 1
+    _assert_same(*_both(tree))
+    for _ in range(3):
+        _step(tree)
+        _assert_same(*_both(tree))
+    assert tree._device_tree.dims()[9] == 0
+
+
+def test_second_device_copy_inside_an_epoch_does_not_replay_a_stale_journal():
+    """A pending journal and a NEW device copy in the same epoch (another max_q_len): the fresh image carries the journalled slots,
+    the journal must not be replayed on top of it."""
+    tree = _two_leaf_tree()
+    _step(tree)
+    _assert_same(*_both(tree))
+    leaf = sorted(tree.leaves.values(), key=lambda n: n.id)[1]
+    tree.extend_leaf(leaf, torch.arange(5, dtype=torch.int32))  # journalled EXTEND, not yet taken
+    first = tree._device_tree
+    _assert_same(*_both(tree, max_q_len=16))  # different cfg: a new _DeviceTree, uploaded with the extend inside
+    assert tree._device_tree is not first
+    _step(tree)  # must find an empty journal
+    _assert_same(*_both(tree, max_q_len=16))
+    _step(tree)
+    _assert_same(*_both(tree, max_q_len=16))
+
+
+def test_malformed_journal_words_raise_the_error_flag_instead_of_spinning():
+    """The replay kernel reads its word count at run time from a reused staging buffer: a RESET word that carries slots (k != 0)
+    must be rejected like any other malformed op -- it used to pass validation, match no branch and never advance the walk."""
+    from deft_amd._lib import check, lib
+
+    tree = _two_leaf_tree()
+    _step(tree)
+    _assert_same(*_both(tree))
+    dt = tree._device_tree
+    ops = torch.tensor([5, 2, 1, 2, 99, 98], dtype=torch.int32, device="cuda")  # {RESET, node 1, k = 2, two stray words}
+    stream = torch.cuda.current_stream().cuda_stream
+    check(lib.deft_tree_dev_apply_ops(*dt._tree_args(), ops.data_ptr(), dt.scratch.data_ptr(), stream), "deft_tree_dev_apply_ops")
+    torch.cuda.synchronize()
+    assert dt.dims()[9] & 4

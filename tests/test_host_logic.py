@@ -386,3 +386,29 @@ def test_absorbed_changes_are_journalled_not_new_epochs():
     held = sorted(s for nd in tree.nodes.values() for s in nd.kv_indices)
     assert sorted(np.nonzero(tree.token_to_kv_pool.mem_state)[0].tolist()) == held
     assert set(np.asarray(tree.token_to_kv_pool.mem_state)[held].tolist()) == {1}
+
+
+def test_layout_fetch_hands_over_the_journal_with_the_image():
+    """deft_tree_layout_fetch writes the tree as it is NOW -- journalled changes included -- so the journal is empty afterwards:
+    a second device copy made inside one epoch must not replay an EXTEND its image already holds."""
+    from deft_amd._lib import check, lib
+    from deft_amd.tree_cache import _ptr
+
+    tree = _small_tree(prefix=8, size=256)
+    leaves = tree.branch(tree.root, 2)
+    for lf in tree.leaves.values():
+        lf.append_token(5)
+    tree.alloc()
+    sizes = np.zeros(5, dtype=np.int64)
+    check(lib.deft_tree_layout(tree._native, 256, _ptr(sizes)), "layout")
+    e = int(sizes[4])
+    tree.extend_leaf(leaves[0], torch.arange(3, dtype=torch.int32))
+    assert tree._epoch() == e  # absorbed by the layout, journalled
+    n, nq, nqw, total_cap = (int(x) for x in sizes[:4])
+    start, ln, cap = (np.zeros(n, dtype=np.int32) for _ in range(3))
+    refs, leaf_node, slots = np.zeros(n * nqw, dtype=np.uint64), np.zeros(nq, dtype=np.int32), np.zeros(total_cap, dtype=np.int32)
+    check(lib.deft_tree_layout_fetch(tree._native, _ptr(start), _ptr(ln), _ptr(cap), _ptr(refs), _ptr(leaf_node), _ptr(slots)), "fetch")
+    assert ln.tolist() == [8, 1 + 3, 1]  # the image has the extend
+    buf = np.zeros(64, dtype=np.int32)
+    assert lib.deft_tree_journal_take(tree._native, _ptr(buf), 64) == 0  # ... and took the journal with it
+    assert tree._epoch() == e

@@ -42,6 +42,13 @@ def test_load_trees_and_prompts_from_files(tmp_path):
     assert sum(t.accept_lengths) == 50 and t.accept_lengths[:3] == sd["Accept_length_0"][:3]
     with pytest.raises(NotImplementedError):
         rp.read_reasoning_file("x.csv")
+    # what tools/replay.py does when it is given a template file and no --prompt-len (it read a `.root` that
+    # TreeTemplate does not have): the root's token count of a reasoning FILE; BASELINE's shapes otherwise
+    root_tokens = int(trees[0].value[0])
+    assert rp.default_prompt_len(trees[0], "reasoning", from_file=True) == (root_tokens if root_tokens > 0 else 4096)
+    assert rp.default_prompt_len(trees[0], "reasoning", from_file=False) == 4096
+    assert rp.default_prompt_len(t, "speculative_decoding", from_file=True) == 1016
+    assert rp.default_prompt_len(rp.synthetic_few_shot_template(4), "few_shot") == 4096
 
 
 def _cpu_replay(task, template, prompt_len, max_gen_len, mode="flatten"):

@@ -60,8 +60,7 @@ else:
     a_modes = list(a.modes)
 for idx, mode in enumerate(a_modes):
     tpl = template()
-    prompt_len = a.prompt_len or (tpl.root.value if a.template and a.task == "reasoning" and tpl.root.value > 0 else
-                                  (1016 if a.task == "speculative_decoding" else 4096))
+    prompt_len = a.prompt_len or rp.default_prompt_len(tpl, a.task, from_file=bool(a.template))
     r = rp.TemplateReplay(Hq, Hkv, D, L, mode=mode, device="cuda", attention=True, session=False if a.eager else None)
     rep = r.run(tpl, a.task, prompt_len, a.max_gen_len, max_rows=max(512, a.width, a.tree_size), pipelined=a.pipelined)
     s = rep.summary(); s["model"] = a.model; s["layers"] = L
