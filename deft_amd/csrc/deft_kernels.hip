@@ -293,10 +293,6 @@ __global__ __launch_bounds__(256, 2) void stage1_kernel(Stage1Params p) {
 #include "merge.h"
 #include "stage1_np.h"
 #include "prefill.h"
-#ifdef DEFT_EXPERIMENTS
-#include "prefill_w4.h"    // 4 waves x 2 workgroups per CU: experiment
-#include "prefill_pipe.h"  // software-pipelined form: parity-green, 15-20 % slower; experiments build only
-#endif
 namespace deft {
 
 // ---------------------------------------------------------------------------
@@ -548,7 +544,7 @@ static int num_cus() {
     return d.cus;
 }
 enum : unsigned { ATTR_NP = 4,  // (bits 0-1, 8-11: the head_dim 64 / 32 / 16 kernels)
-                  ATTR_UNITS = 8, ATTR_NODE_UNITS = 16, ATTR_PREFILL = 32, ATTR_TREE = 64, ATTR_NP_ROPE = 128, ATTR_PREFILL_PIPE = 4096, ATTR_NP_T = 8192, ATTR_NP_ROPE_T = 16384, ATTR_NP_HD2 = 32768, ATTR_NP_HD2_T = 65536 };
+                  ATTR_UNITS = 8, ATTR_NODE_UNITS = 16, ATTR_PREFILL = 32, ATTR_TREE = 64, ATTR_NP_ROPE = 128, ATTR_NP_T = 8192, ATTR_NP_ROPE_T = 16384, ATTR_NP_HD2 = 32768, ATTR_NP_HD2_T = 65536 };
 static int raise_lds(const void* fn, int bytes, unsigned bit, const char* what) {  // idempotent; races are harmless
     DeviceState& d = dev_state();
     if (d.attrs & bit) return DEFT_OK;
@@ -830,11 +826,11 @@ int deft_plan_variant(void) {
 // the plan; runcap > 0: a run table of that many entries).  deft_debug_set_buffer: device buffer of 8192 x 8 u64 receiving
 // per-workgroup time stamps of stage 1.
 #ifdef DEFT_EXPERIMENTS
-void deft_debug_plan_form(int serial, int runcap) {
+__attribute__((visibility("default"))) void deft_debug_plan_form(int serial, int runcap) {
     g_plan_serial = serial;
     g_plan_runcap = runcap;
 }
-void deft_debug_set_buffer(void* dev_ptr) { g_dbg = static_cast<unsigned long long*>(dev_ptr); }
+__attribute__((visibility("default"))) void deft_debug_set_buffer(void* dev_ptr) { g_dbg = static_cast<unsigned long long*>(dev_ptr); }
 #endif
 
 int deft_supported(int Hq, int Hkv, int D) {
@@ -1739,14 +1735,6 @@ extern "C" int deft_prefill_f16(const void* q, int64_t q_stride_tok, int64_t q_s
         set_error("prefill: q/k/v rows must be 16-byte aligned, out rows 8-byte aligned");
         return DEFT_EINVAL;
     }
-#ifdef DEFT_EXPERIMENTS
-    const bool pipe = knob("DEFT_PREFILL_PIPE", 0) != 0;
-    if (pipe) {
-        const int rc = raise_lds(reinterpret_cast<const void*>(&prefill_pipe_kernel<128>), PrefillPipeSmem<128>::BYTES,
-                                 ATTR_PREFILL_PIPE, "prefill_pipe");
-        if (rc) return rc;
-    }
-#endif
     {
         const int rc = raise_lds(reinterpret_cast<const void*>(&prefill_kernel<128>), PrefillSmem<128>::BYTES, ATTR_PREFILL, "prefill");
         if (rc) return rc;
@@ -1777,23 +1765,6 @@ extern "C" int deft_prefill_f16(const void* q, int64_t q_stride_tok, int64_t q_s
         return DEFT_EINVAL;
     }
     const dim3 grid((unsigned)((int64_t)p.nblk * Hq * batch));
-#ifdef DEFT_EXPERIMENTS
-    if (pipe) {
-        hipLaunchKernelGGL((prefill_pipe_kernel<128>), grid, dim3(512), PrefillPipeSmem<128>::BYTES, static_cast<hipStream_t>(stream), p);
-        return check_launch("prefill (pipelined) launch");
-    }
-    if (knob("DEFT_PREFILL_W4", 0)) {
-        static bool once = false;
-        if (!once) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&prefill_w4_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, PrefillW4Smem<128>::BYTES);
-            once = true;
-        }
-        p.nblk = (max_input_len + 127) / 128;
-        hipLaunchKernelGGL((prefill_w4_kernel<128>), dim3((unsigned)((int64_t)p.nblk * Hq * batch)), dim3(256), PrefillW4Smem<128>::BYTES,
-                           static_cast<hipStream_t>(stream), p);
-        return check_launch("prefill (4-wave) launch");
-    }
-#endif
     hipLaunchKernelGGL((prefill_kernel<128>), grid, dim3(512), PrefillSmem<128>::BYTES, static_cast<hipStream_t>(stream), p);
     return check_launch("prefill launch");
 }

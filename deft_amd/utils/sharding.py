@@ -44,11 +44,15 @@ def all_gather_outputs(o_local: torch.Tensor) -> List[torch.Tensor]:
     (RCCL all-gather on GPUs, gloo on CPU).  Shapes may differ per rank (ragged forests)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return [o_local]
-    world = dist.get_world_size()
+    world, rank = dist.get_world_size(), dist.get_rank()
     shapes = [None] * world
     dist.all_gather_object(shapes, tuple(o_local.shape))
     outs = [torch.empty(s, dtype=o_local.dtype, device=o_local.device) for s in shapes]
-    dist.all_gather(outs, o_local.contiguous()) if len(set(shapes)) == 1 else [
-        dist.broadcast(outs[r] if r != dist.get_rank() else outs[r].copy_(o_local), src=r) for r in range(world)
-    ]
+    if len(set(shapes)) == 1:
+        dist.all_gather(outs, o_local.contiguous())
+        return outs
+    # ragged: one broadcast per rank (all_gather wants equal shapes); a rank with no rows takes part with an empty tensor
+    outs[rank].copy_(o_local)
+    for src in range(world):
+        dist.broadcast(outs[src], src=src)
     return outs

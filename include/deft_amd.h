@@ -44,6 +44,12 @@
 extern "C" {
 #endif
 
+/* The library is built with -fvisibility=hidden: the functions declared in this header -- and nothing else -- are its
+ * dynamic symbols (tests/test_abi.py compares `nm -D` with the declarations). */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
+
 #define DEFT_OK 0
 #define DEFT_EINVAL (-1)       /* bad argument (null pointer, negative size, misalignment) */
 #define DEFT_EUNSUPPORTED (-2) /* geometry the kernels do not cover (see deft_supported) */
@@ -439,6 +445,10 @@ int deft_tree_dev_build_md_ops(int n_nodes, int nq, int nqw, const int32_t* node
                                   page-table write of TreeCache.alloc (tree_cache.py:270-283) in the same kernel */
                                int32_t* page_table /* nullable */, int64_t page_stride, const int64_t* page_rows,
                                const int64_t* page_cols, void* stream);
+
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 
 #ifdef __cplusplus
 }

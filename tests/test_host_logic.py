@@ -27,6 +27,20 @@ def test_library_exports_every_declared_symbol():
     assert so.deft_abi_version() == 1
 
 
+def test_library_exports_nothing_but_the_declared_symbols():
+    """`nm -D`: the dynamic symbol table of the shipped library is the header's list -- no kernel handles, no C++ helpers, no
+    libstdc++ instantiations (-fvisibility=hidden + deft_amd/csrc/exports.map)."""
+    import shutil
+    import subprocess
+
+    nm = shutil.which("nm") or "/opt/rocm/lib/llvm/bin/llvm-nm"
+    out = subprocess.run([nm, "-D", "--defined-only", LIB_PATH], check=True, capture_output=True, text=True).stdout
+    defined = {line.split()[-1] for line in out.splitlines() if line.strip()}
+    header = open(os.path.join(ROOT, "include", "deft_amd.h")).read()
+    declared = set(re.findall(r"\b(deft_[a-z0-9_]+)\s*\(", header))
+    assert defined == declared, sorted(defined ^ declared)
+
+
 def test_supported_geometries():
     lib = deft_amd.lib
     assert lib.deft_supported(32, 32, 128) == 1 and lib.deft_supported(32, 8, 128) == 1

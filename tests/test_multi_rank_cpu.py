@@ -54,6 +54,12 @@ def _worker(rank, world, port, ret):
             digest += int(sum(int(v.sum()) for v in md_numpy(md).values()))
         slow = max_over_ranks(0.001 * (rank + 1), torch.device("cpu"))
         outs = all_gather_outputs(torch.full((len(mine), 4), float(rank)))
+        # ragged forests: rank r holds r + 2 rows (the per-rank broadcast branch), and one of the ranks may hold none
+        ragged = all_gather_outputs(torch.full((rank + 2, 3), 10.0 + rank))
+        assert [tuple(o.shape) for o in ragged] == [(r + 2, 3) for r in range(world)]
+        assert all(bool((o == 10.0 + r).all()) for r, o in enumerate(ragged))
+        empty = all_gather_outputs(torch.full((0 if rank == 0 else 5, 2), 7.0))
+        assert [tuple(o.shape) for o in empty] == [(0, 2)] + [(5, 2)] * (world - 1) and bool((empty[1] == 7.0).all())
         # bench.py's multi-GPU selection (BASELINE configs[4]): 8 trees per rank, disjoint, every tree once
         share = cfg5_shard(world, rank)
         both = [None] * world
