@@ -292,7 +292,6 @@ __global__ __launch_bounds__(256, 2) void stage1_kernel(Stage1Params p) {
 #include "tree_plan.h"
 #include "merge.h"
 #include "stage1_np.h"
-#include "stage1_pair.h"
 #include "prefill.h"
 namespace deft {
 
@@ -545,7 +544,7 @@ static int num_cus() {
     return d.cus;
 }
 enum : unsigned { ATTR_NP = 4,  // (bits 0-1, 8-11: the head_dim 64 / 32 / 16 kernels)
-                  ATTR_UNITS = 8, ATTR_NODE_UNITS = 16, ATTR_PREFILL = 32, ATTR_TREE = 64, ATTR_NP_ROPE = 128, ATTR_NP_T = 8192, ATTR_NP_ROPE_T = 16384, ATTR_NP_HD2 = 32768, ATTR_NP_HD2_T = 65536, ATTR_PAIR = 1u << 17, ATTR_PAIR_T = 1u << 18 };
+                  ATTR_UNITS = 8, ATTR_NODE_UNITS = 16, ATTR_PREFILL = 32, ATTR_TREE = 64, ATTR_NP_ROPE = 128, ATTR_NP_T = 8192, ATTR_NP_ROPE_T = 16384, ATTR_NP_HD2 = 32768, ATTR_NP_HD2_T = 65536 };
 static int raise_lds(const void* fn, int bytes, unsigned bit, const char* what) {  // idempotent; races are harmless
     DeviceState& d = dev_state();
     if (d.attrs & bit) return DEFT_OK;
@@ -627,11 +626,6 @@ static int launch_qrows(const PlanView& pv, hipStream_t stream) {
 }
 
 static int np_chunk_knob() { return knob("DEFT_NP_CHUNK", 0); }  // tiles per chunk (0 = the plan kernel's rule)
-// Pairs of 32-row passes over the same tiles (plan_kernels.h np_record_order, stage1_pair.h): flagged and ordered by the plan
-// kernels whenever they exist -- a plan without any is the round-3 plan bit for bit -- and folded from ONE staging of their tiles
-// by the 8-wave stage 1.  (experiments build: DEFT_NP_PAIR = 0 no pairs in the plan and the 4-wave kernel everywhere, 2 = the
-// 8-wave kernel for every head_dim-128 launch, whatever its shape)
-static int np_pair_knob() { return knob("DEFT_NP_PAIR", 1); }
 static int np_union_knob() { return knob("DEFT_NP_UNION", 0); }  // leaf tiles per union group (1 = off, 0 = rule)
 
 // Work items of stage 1 per chunk leader, for the plan's chunk-length rules (they weigh the number of workgroups against the
@@ -671,7 +665,7 @@ static int launch_plan(const Stage1Params& p, int NB, const PlanView& pv, const 
     const UnitList ul = unit_list(pv);
     hipLaunchKernelGGL(flatten_units_kernel, dim3(1), dim3(1024), lds, stream, p.block_q, p.block_q_cnts, p.block_q_offset, NB,
                        p.G, (int)pv.cap, ul, pv.hdr, plan_items_per_leader(p), 2 * num_cus(), np_chunk_knob(), np_union_knob(), (int)run_cap, qtab,
-                       par, dims, pv.row_q, (int)pv.rows, np_pair_knob() != 0);
+                       par, dims, pv.row_q, (int)pv.rows);
     rc = check_launch("flatten units launch");
     if (rc) return rc;
     hipLaunchKernelGGL(flatten_records_kernel, dim3((unsigned)(pv.cap + 1)), dim3(128), 0, stream, p.block_q, p.block_q_cnts,
@@ -699,42 +693,6 @@ static int launch_stage1_np(const Stage1Params& p, int64_t unit_cap, const PlanV
     // 22.8, Medusa-64 18.7 -> 18.0, ToT-50 (six passes per root tile) 24.0 -> 24.3.  NOT the sequential comparator, where every
     // leaf re-reads the shared prefix through the caches: 216 -> 298 us per layer (`reread`).
     const bool nt = knob("DEFT_NP_NT", 1) != 0 && !reread && (int64_t)nq * p.G <= 1024;
-    // The 8-wave kernel (stage1_pair.h) wherever a tile can have more than one 32-row pass -- more than 32 virtual rows in all:
-    // GQA trees, nodes of more than 32 queries -- and the plan may therefore hold pairs.  A function of the call's arguments alone
-    // (the plan lives on the device); a plan without pairs runs through it as independent items.
-    const int pair_knob = np_pair_knob();
-    const bool pair8 = !hd2 && !rope && !reread && (pair_knob == 2 || (pair_knob == 1 && (int64_t)nq * p.G > MQ));
-    if (pair8) {
-        using SP = PairSmem<128>;
-        int rcp = nt ? raise_lds(reinterpret_cast<const void*>(&stage1_pair_kernel<128, true>), SP::BYTES, ATTR_PAIR, "stage1_pair")
-                     : raise_lds(reinterpret_cast<const void*>(&stage1_pair_kernel<128, false>), SP::BYTES, ATTR_PAIR_T, "stage1_pair_t");
-        if (rcp) return rcp;
-        if (unit_cap <= 0) return DEFT_OK;
-        int64_t grid = ((unit_cap + 1) / 2) * HP;  // record pairs x heads
-        if (grid > 0x7fffffffLL) {
-            set_error("stage1 grid too large: %lld", (long long)grid);
-            return DEFT_EINVAL;
-        }
-        const bool small_gqa = unit_cap * HP <= 16LL * num_cus();
-        const int capx = knob("DEFT_NP_GRIDCAP", p.G > 1 ? (small_gqa ? 2 : 1) : 3);
-        const int64_t cap_wgs = (int64_t)capx * num_cus();  // one workgroup per CU
-        if (cap_wgs > 0 && grid > cap_wgs) grid = cap_wgs;
-        NpParams npp{};
-        npp.s = p;
-        npp.hdr = pv.hdr;
-        npp.fast_n = knob("DEFT_NP_FAST", num_cus());
-        npp.s.ablate = knob("DEFT_STAGE1_ABLATE", 0);
-        npp.plan = pv.records;
-        npp.k_new = ap.k_new;
-        npp.v_new = ap.v_new;
-        npp.cache_loc = ap.cache_loc;
-        npp.new_st = ap.new_st;
-        npp.n_new = ap.k_new ? ap.n_new : 0;
-        npp.dbg = g_dbg;
-        if (nt) hipLaunchKernelGGL((stage1_pair_kernel<128, true>), dim3((unsigned)grid), dim3(512), SP::BYTES, stream, npp);
-        else hipLaunchKernelGGL((stage1_pair_kernel<128, false>), dim3((unsigned)grid), dim3(512), SP::BYTES, stream, npp);
-        return check_launch("stage1 pair launch");
-    }
     int rc;
     if (hd2) rc = nt ? raise_lds(reinterpret_cast<const void*>(&stage1_np_kernel<128, false, true, false, true>), SM::BYTES, ATTR_NP_HD2, "stage1_np_hd2")
                      : raise_lds(reinterpret_cast<const void*>(&stage1_np_kernel<128, false, false, false, true>), SM::BYTES, ATTR_NP_HD2_T, "stage1_np_hd2_t");
@@ -859,7 +817,7 @@ int deft_abi_version(void) { return 1; }
 // Everything a plan's layout depends on besides the caller's arguments.  The shipped library has no such thing (0);
 // the experiments build folds its plan knobs into the value, so that callers which cache plans key them by it.
 int deft_plan_variant(void) {
-    return ((np_chunk_knob() & 0xff) << 4) | ((np_union_knob() & 0xff) << 12) | ((np_pair_knob() & 3) << 20) | ((g_plan_serial ? 1 : 0) << 24) |
+    return ((np_chunk_knob() & 0xff) << 4) | ((np_union_knob() & 0xff) << 12) | ((g_plan_serial ? 1 : 0) << 24) |
            ((g_plan_runcap & 0x3f) << 25);
 }
 
@@ -1202,7 +1160,7 @@ static int launch_node_plan(const Stage1Params& p, int NE, int64_t rows_cap, con
         while (sizeof(int) * (3 * (size_t)run_cap + 8) > UNIT_LDS && run_cap > 1) run_cap /= 2;
     hipLaunchKernelGGL(node_units_kernel, dim3(1), dim3(1024), sizeof(int) * ((par ? 8 : 3) * (size_t)run_cap + 8), stream,
                        p.node_kv_len, p.node_q_len, NE, p.G, (int)pv.cap, rows_cap, ul, pv.hdr, pv.row_q, plan_items_per_leader(p),
-                       2 * num_cus(), np_chunk_knob(), (int)run_cap, par, keep_err, dims, np_pair_knob() != 0);
+                       2 * num_cus(), np_chunk_knob(), (int)run_cap, par, keep_err, dims);
     rc = check_launch("node units launch");
     if (rc) return rc;
     hipLaunchKernelGGL(node_records_kernel, dim3((unsigned)(pv.cap + 1)), dim3(128), 0, stream, p.node_kv, p.node_kv_offset,

@@ -63,7 +63,7 @@ __device__ __forceinline__ int64_t plan_rowoff(int64_t slot, int64_t kv_stride_s
 struct UnitList {   // all int32, capacity `cap` each
     int32_t* src;   // Flatten: block index; Node: entry index
     int32_t* aux;   // Flatten: 0;           Node: 128-slot tile index within the entry
-    int32_t* pass;  // bits 0-15: 32-row pass of the unit's virtual query rows; bits 16-17: the run's PAIR flag (np_record_order)
+    int32_t* pass;  // 32-row pass of the unit's virtual query rows
     int32_t* flags; // bit 0: opens a run (query list differs from the previous unit's); bits 1..: unit index of the run's first unit
     int32_t* prow;  // first partial row of the unit's tile
     // tile-parallel record order (stage1_np.h), indexed by RECORD: which unit the record packs, and its chunk
@@ -89,21 +89,12 @@ constexpr int UNION_CAP = 4;
 struct RunTable {
     int* r0;   // first unit of the run
     int* nt;   // units (tiles) in the run
-    int* uni;  // > 0: a union group = one chunk whatever its length (the Flatten kernel keeps the group id + 1 here);
-               // -1 / -2: first / second run of a PAIR (see np_record_order)
+    int* uni;  // non-zero: a union group = one chunk whatever its length (the Flatten kernel keeps the group id + 1 here)
     int n;    // runs recorded
     int cap;  // capacity; n > cap = overflow, fall back to scanning the unit arrays
 };
 
 constexpr int LONG_CHUNK = 4;  // tiles per chunk from which a chunk's leader is dispatched ahead of the short ones
-
-// PAIRS (round 4).  Two consecutive runs over the SAME tiles -- the 32-row passes 2j, 2j+1 of a shared node under GQA or under more
-// than 32 queries: same slots, same chunking, different virtual rows -- are a pair: the 8-wave stage 1 (stage1_pair.h) stages each
-// of their tiles ONCE and folds both passes from it, one on each half of the workgroup.  The unit kernels flag the runs (1 = first,
-// 2 = second of a pair); the record order puts the leaders of paired runs FIRST and interleaved -- chunk p of the first run at an
-// even record 2m, chunk p of the second at 2m + 1 -- so that leader records (2m, 2m + 1) are what one 8-wave workgroup takes, with
-// nothing to look up.  Behind them the unpaired leaders as before (long chunks first); they are taken two by two as well, as two
-// independent items.  Without pairs (every MHA tree of up to 32 queries) the order is exactly the round-3 order.
 
 // `Hkv` = stage-1 work items per chunk leader: KV heads -- or, NEGATED, head PAIRS (head_dim 64 runs two heads to a pool row,
 // stage1_np.h HD2: half as many items as heads, each with two softmaxes' worth of arithmetic per tile, so its launches are
@@ -127,7 +118,7 @@ __device__ inline void np_record_order(const UnitList& ul, int R, int Hkv, int G
                 const int id = ul.flags[r] >> 1;
                 int e = r + 1;
                 while (e < R && (ul.flags[e] >> 1) == id) ++e;
-                fn(r, e - r, ul.aux[r] > 0 ? 1 : -(ul.pass[r] >> 16));
+                fn(r, e - r, ul.aux[r] > 0 ? 1 : 0);
                 r = e;
             }
         }
@@ -139,7 +130,7 @@ __device__ inline void np_record_order(const UnitList& ul, int R, int Hkv, int G
         // prefixes, 4 from 8 tiles on, halved while fewer than ~0.3 workgroups per slot would be left.
         int lmax = 0;
         for_runs([&](int, int nt, int uni) {
-            if (uni <= 0 && nt > lmax) lmax = nt;
+            if (!uni && nt > lmax) lmax = nt;
         });
         C = lmax >= 32 ? 8 : (lmax >= 8 ? 4 : (lmax >= 4 ? 2 : 1));
         // ... and with GQA a chunk should not outlast the launch: the passes of a shared tile are separate chunks that
@@ -156,7 +147,7 @@ __device__ inline void np_record_order(const UnitList& ul, int R, int Hkv, int G
         }
         for (; C > 1; C >>= 1) {
             int64_t n = 0;
-            for_runs([&](int, int nt, int uni) { n += uni > 0 ? 1 : (nt + C - 1) / C; });
+            for_runs([&](int, int nt, int uni) { n += uni ? 1 : (nt + C - 1) / C; });
             if ((pairs ? 4 : 10) * n * Hkv >= 3LL * slots) break;
         }
         // ... but no run is cut into more than 16 chunks while chunks may still grow (<= 8 tiles): every chunk of a
@@ -169,8 +160,8 @@ __device__ inline void np_record_order(const UnitList& ul, int R, int Hkv, int G
         if (C > 2 && lmax <= 16 * (C - 1)) {
             int64_t n0 = 0, n1 = 0;
             for_runs([&](int, int nt, int uni) {
-                n0 += uni > 0 ? 1 : (nt + C - 1) / C;
-                n1 += uni > 0 ? 1 : (nt + C - 2) / (C - 1);
+                n0 += uni ? 1 : (nt + C - 1) / C;
+                n1 += uni ? 1 : (nt + C - 2) / (C - 1);
             });
             if (2 * n0 * Hkv < slots && 2 * n1 * Hkv <= slots) --C;
         }
@@ -179,33 +170,22 @@ __device__ inline void np_record_order(const UnitList& ul, int R, int Hkv, int G
     // to: a capped grid hands item b + W to the workgroup that finishes item b, so with the leaders run by run a batch of
     // trees (prefix chunks, leaf tiles, prefix chunks, leaf tiles, ...) gave the workgroups that already held one
     // 8-tile chunk a second one (8 trees of 8k x 8 as one tree object: 71 -> 57 us per layer).  Longest first, as in prefill.
-    // leader classes: 0 = paired long, 1 = paired short, 2 = long, 3 = short; the first run of a pair takes 2 S positions (its own
-    // chunks at the even ones, its partner's at the odd ones), the second none of its own
-    int tot[4] = {0, 0, 0, 0};
+    int NL = 0, NLong = 0;
     for_runs([&](int, int nt, int uni) {
-        const int S = uni > 0 ? 1 : (nt + C - 1) / C;
-        const bool lng = uni <= 0 && nt / S >= LONG_CHUNK;
-        const int pf = uni < 0 ? -uni : 0;
-        tot[pf ? (lng ? 0 : 1) : (lng ? 2 : 3)] += pf == 1 ? 2 * S : (pf == 2 ? 0 : S);
+        const int S = uni ? 1 : (nt + C - 1) / C;
+        NL += S;
+        if (!uni && nt / S >= LONG_CHUNK) NLong += S;
     });
-    const int NL = tot[0] + tot[1] + tot[2] + tot[3];
-    int li4[4] = {0, tot[0], tot[0] + tot[1], tot[0] + tot[1] + tot[2]};
-    int fi = NL, pair_li = 0;
+    int liL = 0, liS = NLong, fi = NL;
     for_runs([&](int r, int nt, int uni) {
-        const int S = uni > 0 ? 1 : (nt + C - 1) / C;  // a union group is one chunk
-        const bool lng = uni <= 0 && nt / S >= LONG_CHUNK;
-        const int pf = uni < 0 ? -uni : 0;
-        int& cls = li4[pf ? (lng ? 0 : 1) : (lng ? 2 : 3)];
-        int li = cls;
-        if (pf == 1) pair_li = li, cls += 2 * S;
-        else if (pf == 2) li = pair_li + 1;
-        else cls += S;
-        const int lst = pf ? 2 : 1;
+        const int S = uni ? 1 : (nt + C - 1) / C;  // a union group is one chunk
+        int& li = (!uni && nt / S >= LONG_CHUNK) ? liL : liS;
         for (int p = 0; p < S; ++p) {
             const int cnt = (nt - p + S - 1) / S;
-            ul.perm[li + lst * p] = r + p;
-            ul.ch_n[li + lst * p] = cnt;
-            ul.ch_fb[li + lst * p] = fi;
+            ul.perm[li] = r + p;
+            ul.ch_n[li] = cnt;
+            ul.ch_fb[li] = fi;
+            ++li;
             for (int j = 1; j < cnt; ++j, ++fi) {
                 ul.perm[fi] = r + p + j * S;
                 ul.ch_n[fi] = 0;
@@ -238,7 +218,7 @@ __device__ inline void record_order_parallel(const UnitList& ul, const RunTable&
         if (C <= 0) {
             int lmax = 0;
             for (int k = lane; k < NR; k += 64)
-                if (rt.uni[k] <= 0 && rt.nt[k] > lmax) lmax = rt.nt[k];
+                if (!rt.uni[k] && rt.nt[k] > lmax) lmax = rt.nt[k];
             for (int m = 32; m > 0; m >>= 1) lmax = max(lmax, __shfl_xor(lmax, m, 64));
             C = lmax >= 32 ? 8 : (lmax >= 8 ? 4 : (lmax >= 4 ? 2 : 1));
             if (G > 1 || pairs) {
@@ -248,83 +228,63 @@ __device__ inline void record_order_parallel(const UnitList& ul, const RunTable&
                 if (C > cmax) C = cmax;
             }
             for (; C > 1; C >>= 1) {
-                const int64_t n = wave_sum([C](int nt, int uni) { return uni > 0 ? 1 : (nt + C - 1) / C; });
+                const int64_t n = wave_sum([C](int nt, int uni) { return uni ? 1 : (nt + C - 1) / C; });
                 if ((pairs ? 4 : 10) * n * Hkv >= 3LL * slots) break;
             }
             while (C < 8 && lmax > 16 * C) C <<= 1;  // (np_record_order: at most 16 chunks per run while C < 8)
             if (C > 2 && lmax <= 16 * (C - 1)) {       // (np_record_order: fill the CUs of a launch that leaves some empty)
-                const int64_t n0 = wave_sum([C](int nt, int uni) { return uni > 0 ? 1 : (nt + C - 1) / C; });
-                const int64_t n1 = wave_sum([C](int nt, int uni) { return uni > 0 ? 1 : (nt + C - 2) / (C - 1); });
+                const int64_t n0 = wave_sum([C](int nt, int uni) { return uni ? 1 : (nt + C - 1) / C; });
+                const int64_t n1 = wave_sum([C](int nt, int uni) { return uni ? 1 : (nt + C - 2) / (C - 1); });
                 if (2 * n0 * Hkv < slots && 2 * n1 * Hkv <= slots) --C;
             }
         }
-        // leaders by class (np_record_order: paired long, paired short, long, short), each class in run order; followers in run
-        // order.  rT0[k] = the run's first leader record (the second run of a pair: resolved from its partner below).
-        int tot[4] = {0, 0, 0, 0}, foll = 0;
+        // leaders: long chunks first (np_record_order), each class in run order; followers in run order
+        int leadL = 0, leadS = 0, foll = 0;
         for (int base = 0; base < NR; base += 64) {
             const int k = base + lane;
             const int nt = k < NR ? rt.nt[k] : 0;
-            const int uni = k < NR ? rt.uni[k] : 0;
-            const int S = k < NR ? (uni > 0 ? 1 : (nt + C - 1) / C) : 0;
-            const bool lng = k < NR && uni <= 0 && S > 0 && nt / S >= LONG_CHUNK;
-            const int pf = uni < 0 ? -uni : 0;
-            const int cls = pf ? (lng ? 0 : 1) : (lng ? 2 : 3);
-            const int take = pf == 1 ? 2 * S : (pf == 2 ? 0 : S);
-            int a[4], b = nt - S;  // inclusive scans over the lanes
-#pragma unroll
-            for (int c4 = 0; c4 < 4; ++c4) a[c4] = cls == c4 ? take : 0;
+            const int S = k < NR ? (rt.uni[k] ? 1 : (nt + C - 1) / C) : 0;
+            const bool lng = k < NR && !rt.uni[k] && S > 0 && nt / S >= LONG_CHUNK;
+            int aL = lng ? S : 0, aS = lng ? 0 : S, b = nt - S;  // inclusive scans over the lanes
             for (int d = 1; d < 64; d <<= 1) {
-                int u[4];
-#pragma unroll
-                for (int c4 = 0; c4 < 4; ++c4) u[c4] = __shfl_up(a[c4], d, 64);
-                const int ub = __shfl_up(b, d, 64);
+                const int uL = __shfl_up(aL, d, 64), uS = __shfl_up(aS, d, 64), ub = __shfl_up(b, d, 64);
                 if (lane >= d) {
-#pragma unroll
-                    for (int c4 = 0; c4 < 4; ++c4) a[c4] += u[c4];
+                    aL += uL;
+                    aS += uS;
                     b += ub;
                 }
             }
             if (k < NR) {
-                int pos = 0;
-#pragma unroll
-                for (int c4 = 0; c4 < 4; ++c4) pos = cls == c4 ? tot[c4] + a[c4] - take : pos;
-                rT0[k] = pos | (cls << 28);  // position inside its class; the class bases are known after the last batch
+                rT0[k] = lng ? leadL + aL - S : -(leadS + aS - S) - 1;  // short runs: position inside their class, resolved below
                 rSp[k] = foll + b - (nt - S);
             }
-#pragma unroll
-            for (int c4 = 0; c4 < 4; ++c4) tot[c4] += __shfl(a[c4], 63, 64);
+            leadL += __shfl(aL, 63, 64);
+            leadS += __shfl(aS, 63, 64);
             foll += __shfl(b, 63, 64);
         }
-        const int cbase[4] = {0, tot[0], tot[0] + tot[1], tot[0] + tot[1] + tot[2]};
-        for (int k = lane; k < NR; k += 64) {
-            const int v = rT0[k], cls = v >> 28;
-            int base = 0;
-#pragma unroll
-            for (int c4 = 0; c4 < 4; ++c4) base = cls == c4 ? cbase[c4] : base;
-            rT0[k] = base + (v & 0x0fffffff);
-        }
+        for (int k = lane; k < NR; k += 64)
+            if (rT0[k] < 0) rT0[k] = leadL + (-rT0[k] - 1);
         if (lane == 0) {
             sMeta[2] = C;
-            sMeta[3] = tot[0] + tot[1] + tot[2] + tot[3];
-            hdr[1] = tot[0] + tot[1] + tot[2] + tot[3];
+            sMeta[3] = leadL + leadS;
+            hdr[1] = leadL + leadS;
         }
     }
     __syncthreads();
     {
         const int C = sMeta[2], NL = sMeta[3];
         for (int k = wave; k < NR; k += nwaves) {
-            const int first = rt.r0[k], nt = rt.nt[k], uni = rt.uni[k];
-            const int S = uni > 0 ? 1 : (nt + C - 1) / C;  // a union group is one chunk
-            // (pairs: the first run's chunks at even records from its base, the second run's at the odd ones between them)
-            const int li = uni == -2 ? rT0[k - 1] + 1 : rT0[k], lst = uni < 0 ? 2 : 1, fi = NL + rSp[k];
+            const int first = rt.r0[k], nt = rt.nt[k];
+            const int S = rt.uni[k] ? 1 : (nt + C - 1) / C;  // a union group is one chunk
+            const int li = rT0[k], fi = NL + rSp[k];
             const int q = nt / S, rem = nt - q * S;  // chunk p folds units p, p + S, ...: q + 1 of them for p < rem, else q
             for (int u = lane; u < nt; u += 64) {
                 const int j = u / S, pc = u - j * S;
                 const int fb = fi + pc * (q - 1) + min(pc, rem);  // followers of the chunks before pc
                 if (j == 0) {
-                    ul.perm[li + lst * pc] = first + pc;
-                    ul.ch_n[li + lst * pc] = q + (pc < rem ? 1 : 0);
-                    ul.ch_fb[li + lst * pc] = fb;
+                    ul.perm[li + pc] = first + pc;
+                    ul.ch_n[li + pc] = q + (pc < rem ? 1 : 0);
+                    ul.ch_fb[li + pc] = fb;
                 } else {
                     ul.perm[fb + j - 1] = first + u;
                     ul.ch_n[fb + j - 1] = 0;
@@ -398,7 +358,7 @@ __global__ __launch_bounds__(1024) void flatten_units_kernel(const int64_t* bloc
                                                             const int64_t* block_q_offset, int NBc, int G, int cap,
                                                             UnitList ul, int32_t* hdr, int Hkv, int slots, int chunk_c,
                                                             int union_len, int run_cap, int qtab, int par,
-                                                            const int32_t* dims, int32_t* row_q, int rows, int pair_runs) {
+                                                            const int32_t* dims, int32_t* row_q, int rows) {
     constexpr int np = 1;  // records in the tile-parallel order (leaders first); the only stage-1 form
     // NBc = block CAPACITY (sizes the tables); with `dims` (device-side metadata, tree_plan.h) the block count of this
     // step is read from the device, so that one captured launch serves every step of a structural epoch
@@ -511,8 +471,7 @@ __global__ __launch_bounds__(1024) void flatten_units_kernel(const int64_t* bloc
             return NB;
         };
         // units of one run: blocks t0, t0 + st, ... < te, pass ps, aux (0, or union group + 1)
-        // (pf: 1 / 2 = first / second run of a pair, np_record_order; kept as -pf in the run table, in bits 16.. of ul.pass)
-        auto emit_run = [&](int t0, int te, int st, int aux, int ps, int pf = 0) {
+        auto emit_run = [&](int t0, int te, int st, int aux, int ps) {
             int n = st == 1 ? te - t0 : (te - t0 + st - 1) / st;
             if (n > cap - r) n = cap - r;
             if (n <= 0) return;
@@ -521,7 +480,7 @@ __global__ __launch_bounds__(1024) void flatten_units_kernel(const int64_t* bloc
                 if (lane == 0 && rt.n < rt.cap) {
                     rt.r0[rt.n] = first;
                     rt.nt[rt.n] = n;
-                    rt.uni[rt.n] = aux > 0 ? aux : -pf;
+                    rt.uni[rt.n] = aux;
                     rT0[rt.n] = t0;
                     rSp[rt.n] = st | (ps << 8);
                 }
@@ -532,37 +491,18 @@ __global__ __launch_bounds__(1024) void flatten_units_kernel(const int64_t* bloc
                         const int t = t0 + j * st;
                         ul.src[first + j] = t;
                         ul.aux[first + j] = aux;
-                        ul.pass[first + j] = ps | (pf << 16);
+                        ul.pass[first + j] = ps;
                         ul.flags[first + j] = (first << 1) | (j == 0 ? 1 : 0);
                         ul.prow[first + j] = sOff[t];
                     }
                 if (rt.n < rt.cap && lane == 0) {
                     rt.r0[rt.n] = first;
                     rt.nt[rt.n] = n;
-                    rt.uni[rt.n] = aux > 0 ? aux : -pf;
+                    rt.uni[rt.n] = aux;
                 }
                 ++rt.n;
             }
             r += n;
-        };
-        // The runs over ONE range of tiles -- the 32-row passes of a shared node, and for a node of more than 32 queries its
-        // alternating query chunks, which hold the same slots -- come one after the other: two consecutive ones of equal length
-        // are a pair (np_record_order).  One run is held back until its successor is known.
-        int pd_t0 = -1, pd_te = 0, pd_st = 0, pd_ps = 0, pd_n = 0;
-        auto group_end = [&]() {
-            if (pd_t0 >= 0) emit_run(pd_t0, pd_te, pd_st, 0, pd_ps, 0);
-            pd_t0 = -1;
-        };
-        auto group_add = [&](int t0, int te, int st, int ps) {
-            const int n = st == 1 ? te - t0 : (te - t0 + st - 1) / st;
-            if (pair_runs && pd_t0 >= 0 && pd_n == n && 2 * n <= cap - r) {
-                emit_run(pd_t0, pd_te, pd_st, 0, pd_ps, 1);
-                emit_run(t0, te, st, 0, ps, 2);
-                pd_t0 = -1;
-                return;
-            }
-            group_end();
-            pd_t0 = t0, pd_te = te, pd_st = st, pd_ps = ps, pd_n = n;
         };
         for (int ta = 0; ta < NB;) {
             // ---- union group starting at ta (phase 1b) ------------------------------------------------------
@@ -597,15 +537,13 @@ __global__ __launch_bounds__(1024) void flatten_units_kernel(const int64_t* bloc
                     const int te = find(ta + P, 1 << (P - 1));
                     for (int par_ = 0; par_ < P; ++par_) {
                         const int pp = sPass[ta + par_];
-                        for (int ps = 0; ps < pp; ++ps) group_add(ta + par_, te, P, ps);
+                        for (int ps = 0; ps < pp; ++ps) emit_run(ta + par_, te, P, 0, ps);
                     }
-                    group_end();
                     ta = te;
                     continue;
                 }
             }
-            for (int ps = 0; ps < passes; ++ps) group_add(ta, tb, 1, ps);
-            group_end();
+            for (int ps = 0; ps < passes; ++ps) emit_run(ta, tb, 1, 0, ps);
             ta = tb;
         }
         if (lane == 0) {
@@ -631,8 +569,7 @@ __global__ __launch_bounds__(1024) void flatten_units_kernel(const int64_t* bloc
     const int NR = sMeta[1];
     const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     for (int k = wave; k < NR; k += nwaves) {
-        const int first = rt.r0[k], n = rt.nt[k], uni = rt.uni[k], t0 = rT0[k], st = rSp[k] & 0xff, ps = rSp[k] >> 8;
-        const int aux = uni > 0 ? uni : 0, pf = uni < 0 ? -uni : 0;
+        const int first = rt.r0[k], n = rt.nt[k], aux = rt.uni[k], t0 = rT0[k], st = rSp[k] & 0xff, ps = rSp[k] >> 8;
         if (aux > 0 && lane == 0) {  // a union group: its queries and the rows that carry their partials
             int uq[UNION_CAP], urow[UNION_CAP], un;
             union_group(t0, NB, sOpen[t0] >> 8, ucap, sCnt, sOff, qtab ? sQ : nullptr, block_q, uq, urow, un);
@@ -646,7 +583,7 @@ __global__ __launch_bounds__(1024) void flatten_units_kernel(const int64_t* bloc
             const int t = t0 + j * st;
             ul.src[first + j] = t;
             ul.aux[first + j] = aux;
-            ul.pass[first + j] = ps | (pf << 16);
+            ul.pass[first + j] = ps;
             ul.flags[first + j] = (first << 1) | (j == 0 ? 1 : 0);
             ul.prow[first + j] = sOff[t];
         }
@@ -654,17 +591,6 @@ __global__ __launch_bounds__(1024) void flatten_units_kernel(const int64_t* bloc
     if (!np) return;
     // Phase 4: record order of the tile-parallel stage 1
     record_order_parallel(ul, rt, NR, rT0, rSp, sMeta, hdr, Hkv, G, slots, chunk_c);
-}
-
-// desc[6] of record r: 1 / 2 = this LEADER and the one after / before it are the two runs of a pair over the same tiles (an even
-// record and the odd one behind it, chunks of equal length -- checked here, so that the 8-wave stage 1 never sees half a pair),
-// 0 = an item of its own (or a follower).
-__device__ inline int pair_flag(const UnitList& ul, int r, int R) {
-    if (ul.ch_n[r] <= 0) return 0;
-    const int pf = ul.pass[ul.perm[r]] >> 16;
-    if (pf == 1 && !(r & 1) && r + 1 < R && ul.ch_n[r + 1] == ul.ch_n[r] && (ul.pass[ul.perm[r + 1]] >> 16) == 2) return 1;
-    if (pf == 2 && (r & 1) && ul.ch_n[r - 1] == ul.ch_n[r] && (ul.pass[ul.perm[r - 1]] >> 16) == 1) return 2;
-    return 0;
 }
 
 // One workgroup of 128 threads per unit (+ the sentinel): pack its record.
@@ -696,16 +622,14 @@ __global__ __launch_bounds__(128) void flatten_records_kernel(const int64_t* blo
             desc[2] = 1;
             desc[3] = -1;
             desc[4] = 0;
-            desc[6] = 0;
         }
         return;
     }
     const NewMap nm = newmap_build(sKeys, sVals, cache_loc, n_new);
     const int u = np ? ul.perm[r] : r;  // unit packed into this record
     const int t = ul.src[u];
-    const int ps = ul.pass[u] & 0xffff;
+    const int ps = ul.pass[u];
     const int prow = ul.prow[u];
-    if (k == 0) desc[6] = pair_flag(ul, r, R);
     const int len = (int)block_lens[t];
     const int cnt = (int)block_q_cnts[t];
     const bool live = k < len;
@@ -793,7 +717,7 @@ __global__ __launch_bounds__(128) void flatten_records_kernel(const int64_t* blo
 __global__ __launch_bounds__(1024) void node_units_kernel(const int64_t* node_kv_len, const int64_t* node_q_len, int NEc, int G,
                                                           int cap, int64_t rows_cap, UnitList ul, int32_t* hdr,
                                                           int32_t* row_q, int Hkv, int slots, int chunk_c, int run_cap,
-                                                          int par, int keep_err, const int32_t* dims, int pair_runs) {
+                                                          int par, int keep_err, const int32_t* dims) {
     constexpr int np = 1;
     const int NE = dims ? min(dims[1], NEc) : NEc;  // (device-side metadata: this step's entry count, see flatten_units_kernel)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -814,7 +738,7 @@ __global__ __launch_bounds__(1024) void node_units_kernel(const int64_t* node_kv
             rt.n = 0;
             int r = 0, rowbase = 0;
             int pack_r = -1, pack_k = -1, pack_n = 0, pack_keys = 0, pack_rows = 0;  // open pack: unit, run, entries, slots, virtual rows
-            auto emit_run = [&](int e, int n, int ps, int prow0, int ql, int aux, int pf = 0) {
+            auto emit_run = [&](int e, int n, int ps, int prow0, int ql, int aux) {
                 if (n > cap - r) n = cap - r;
                 if (n <= 0) return;
                 const int first = r;
@@ -822,7 +746,7 @@ __global__ __launch_bounds__(1024) void node_units_kernel(const int64_t* node_kv
                     if (lane == 0 && rt.n < rt.cap) {
                         rt.r0[rt.n] = first;
                         rt.nt[rt.n] = n;
-                        rt.uni[rt.n] = -pf;
+                        rt.uni[rt.n] = 0;
                         rT0[rt.n] = e;
                         rSp[rt.n] = ps;
                         rProw[rt.n] = prow0;
@@ -833,14 +757,14 @@ __global__ __launch_bounds__(1024) void node_units_kernel(const int64_t* node_kv
                     for (int j = 0; j < n; ++j) {
                         ul.src[first + j] = e;
                         ul.aux[first + j] = aux > 0 ? j : aux;
-                        ul.pass[first + j] = ps | (pf << 16);
+                        ul.pass[first + j] = ps;
                         ul.flags[first + j] = (first << 1) | (j == 0 ? 1 : 0);
                         ul.prow[first + j] = prow0 + j * ql;
                     }
                     if (rt.n < rt.cap) {
                         rt.r0[rt.n] = first;
                         rt.nt[rt.n] = n;
-                        rt.uni[rt.n] = -pf;
+                        rt.uni[rt.n] = 0;
                     }
                 }
                 ++rt.n;
@@ -878,12 +802,7 @@ __global__ __launch_bounds__(1024) void node_units_kernel(const int64_t* node_kv
                     }
                 } else {
                     pack_r = -1;
-                    // (the 32-row passes of one entry walk the same tiles: two by two they are pairs, np_record_order)
-                    bool paired = false;  // (decided at the even pass, for both)
-                    for (int ps = 0; ps < npass; ++ps) {
-                        if (!(ps & 1)) paired = pair_runs && ps + 1 < npass && 2 * nt <= cap - r;
-                        emit_run(e, nt, ps, rowbase, ql, 1, paired ? ((ps & 1) ? 2 : 1) : 0);
-                    }
+                    for (int ps = 0; ps < npass; ++ps) emit_run(e, nt, ps, rowbase, ql, 1);
                 }
                 rowbase += nt * ql;
               }
@@ -911,11 +830,10 @@ __global__ __launch_bounds__(1024) void node_units_kernel(const int64_t* node_kv
     const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     for (int k = wave; k < NR; k += nwaves) {
         const int first = rt.r0[k], n = rt.nt[k], e = rT0[k], ps = rSp[k], prow0 = rProw[k], ql = rQl[k], aux = rAux[k];
-        const int pf = rt.uni[k] < 0 ? -rt.uni[k] : 0;
         for (int j = lane; j < n; j += 64) {
             ul.src[first + j] = e;
             ul.aux[first + j] = aux > 0 ? j : aux;
-            ul.pass[first + j] = ps | (pf << 16);
+            ul.pass[first + j] = ps;
             ul.flags[first + j] = (first << 1) | (j == 0 ? 1 : 0);
             ul.prow[first + j] = prow0 + j * ql;
         }
@@ -952,7 +870,6 @@ __global__ __launch_bounds__(128) void node_records_kernel(const int64_t* node_k
             desc[2] = 1;
             desc[3] = -1;
             desc[4] = 0;
-            desc[6] = 0;
         }
         return;
     }
@@ -961,9 +878,8 @@ __global__ __launch_bounds__(128) void node_records_kernel(const int64_t* node_k
     if (k == 0) {
         desc[4] = np ? ul.ch_n[r] : 0;
         desc[5] = np ? ul.ch_fb[r] : 0;
-        desc[6] = pair_flag(ul, r, R);
     }
-    const int e0 = ul.src[u], aux = ul.aux[u], ps = ul.pass[u] & 0xffff, prow = ul.prow[u];
+    const int e0 = ul.src[u], aux = ul.aux[u], ps = ul.pass[u], prow = ul.prow[u];
     if (aux < 0) {
         // ---- packed unit: entries e0 .. e0 - aux - 1, each one tile and one pass -------------------------
         const int cnt = -aux;
