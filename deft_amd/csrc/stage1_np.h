@@ -80,6 +80,17 @@ __device__ __forceinline__ uintx4 rope_chunk(uintx4 own_u, uintx4 par_u, bool fi
     return res.u;
 }
 
+// x combined with the value 32 lanes away (lane l with lane l ^ 32) -- gfx950's v_permlane32_swap instead of a ds_bpermute round
+// trip through the LDS: the row maximum and the row sum of the wave-private softmax sit on the tile's dependent chain.
+__device__ __forceinline__ float max_xor32(float x) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float sum_xor32(float x) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 template <int D>
 struct NpSmem {
     static constexpr int SLICE = 32 * D * 2;            // one wave's 32 keys of K (or V)
@@ -132,6 +143,22 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
     const int bid = blockIdx.x;
     const int W = (int)gridDim.x;
     unsigned long long t_start = 0, t_k0 = 0, t_epi = 0, t_bar = 0;
+#ifdef DEFT_EXPERIMENTS
+    // per-phase wall-clock sums over the tiles of an item (wave 0; written behind the per-item stamps, tools/np_phases.py):
+    // 0 wait K(i) | 1 masks + QK^T + maxima | 2 offsets of tile i+1, K(i+1) / aux(i+2) requests | 3 softmax | 4 wait V(i) | 5 PV, V(i+1) request
+    unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, ph_t = 0;
+#define PHASE(k)                                         \
+    if (DBG) {                                           \
+        const unsigned long long now_ = wall_clock64(); \
+        ph[k] += now_ - ph_t;                            \
+        ph_t = now_;                                     \
+    }
+#define PHASE_START() \
+    if (DBG) ph_t = wall_clock64();
+#else
+#define PHASE(k)
+#define PHASE_START()
+#endif
     const int HP = HD2 ? p.Hkv / 2 : p.Hkv;                  // rows (heads, or head pairs) per token
     const int64_t kv_shp = HD2 ? 2 * p.kv_sh : p.kv_sh;      // elements between two of them
 
@@ -204,22 +231,40 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
     const char *kb_pool = nullptr, *vb_pool = nullptr, *kb_new = nullptr, *vb_new = nullptr;  // per work item (KV head)
 
     int64_t rowoff[LPT];
+    bool has_new = true;  // (wave-uniform) some row of the slice whose offsets `rowoff` holds is one of this step's new rows
     auto issue_aux = [&](int i, int slot) {  // 2 DMA: this wave's 32 row offsets; its 32 key masks | the 32 q offsets
         const char* rec = rec_of(i);
         dma4(rec + PLAN_ROWOFF + 32 * w * 8 + 4 * l, aux0 + (uint32_t)slot * SM::AUX_SLOT);
         const char* src2 = (l < 32) ? rec + PLAN_MASK + (32 * w + l) * 4 : rec + PLAN_QSRC + (l - 32) * 4;
         dma4(src2, aux0 + (uint32_t)slot * SM::AUX_SLOT + 256u);
     };
+    // (round 4: the instruction stream of a tile, not its memory traffic, is what a CU spends most of a small launch on --
+    //  profiles/r4_pair_kernel_negative.txt: 1.44 us per tile with no K / V request at all, ~350 VALU instructions per wave at 4
+    //  cycles each.  A tile's slice almost never holds one of this step's new rows, so the per-request select between the pool and
+    //  k_new / v_new -- compare, two selects, a mask, 16 times per tile -- is decided once per slice: lane k looks at the sign of
+    //  row k's offset, one ballot.)
     auto load_rowoff = [&](int slot) {
         const int64_t* ro = reinterpret_cast<const int64_t*>(smem + aux0 + slot * SM::AUX_SLOT);
 #pragma unroll
         for (int i = 0; i < LPT; ++i) rowoff[i] = ro[4 * i + dkey];
+        const int32_t hi = reinterpret_cast<const int32_t*>(ro)[2 * (l & 31) + 1];
+        has_new = ABL(1024) || __builtin_amdgcn_ballot_w64(hi < 0) != 0ull;
     };
     auto issue_k = [&]() {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of the slice being overwritten
+        if (!has_new) {
+#pragma unroll
+            for (int i = 0; i < LPT; ++i) {
+                if (ABL(8)) continue;  // (experiments: 8 no K / V requests at all; 128 every row is the pool's first -- cache hits)
+                const char* src = ABL(128) ? kb_pool : kb_pool + rowoff[i];
+                if constexpr (NT) dma16nt(src + kchunk_b[i & 3], ldsK + (uint32_t)i * 1024u);
+                else dma16(src + kchunk_b[i & 3], ldsK + (uint32_t)i * 1024u);
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < LPT; ++i) {
-            if (ABL(8)) continue;  // (experiments: 8 no K / V requests at all; 128 every row is the pool's first -- cache hits)
+            if (ABL(8)) continue;
             const char* src = ABL(128) ? kb_pool : rowoff[i] < 0 ? kb_new + (rowoff[i] & ~NEW_ROW) : kb_pool + rowoff[i];
             if constexpr (NT) dma16nt(src + kchunk_b[i & 3], ldsK + (uint32_t)i * 1024u);
             else dma16(src + kchunk_b[i & 3], ldsK + (uint32_t)i * 1024u);
@@ -227,6 +272,16 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
     };
     auto issue_v = [&]() {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (!has_new) {
+#pragma unroll
+            for (int i = 0; i < LPT; ++i) {
+                if (ABL(8)) continue;
+                const char* src = ABL(128) ? vb_pool : vb_pool + rowoff[i];
+                if constexpr (NT) dma16nt(src, ldsV + (uint32_t)i * 1024u);
+                else dma16(src, ldsV + (uint32_t)i * 1024u);
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < LPT; ++i) {
             if (ABL(8)) continue;
@@ -289,6 +344,10 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
     const int n = sd4;  // tiles of this chunk (> 0: items only name leaders)
     const int nv = sd0;
     fb = sd5;
+    const uint32_t rowbits = nv >= 32 ? 0xffffffffu : ((1u << nv) - 1u);  // the chunk's live virtual rows
+    // the scale enters as |scale| inside the exp2 argument (one fma per score instead of a multiply and a subtract); a negative one
+    // -- nobody passes it, the C ABI takes any float -- flips the sign of the Q fragments instead
+    const float sc = fmaxf(fabsf(p.scale_log2e), 1e-30f);  // (never 0: a masked score is -inf, and -inf * 0 is not)
     kb_pool = reinterpret_cast<const char*>(p.k) + (int64_t)kvh * kv_shp * 2;
     vb_pool = reinterpret_cast<const char*>(p.v) + (int64_t)kvh * kv_shp * 2 + vchunk_b;
     kb_new = reinterpret_cast<const char*>(np.k_new) + (int64_t)kvh * D * 2;
@@ -329,7 +388,8 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
     if (n > 1) issue_aux(1, 1);
     issue_v();
 
-    half8 qf[KS];
+    constexpr bool QF_LDS = HD2;  // Q fragments re-read from LDS every tile instead of living in 32 registers (with ROPE too it measured slower than three spilled registers: gqa_4kx32 fused 23.0 -> 24.3 us per layer)
+    half8 qf[QF_LDS ? 1 : KS];
     float m_run[NH], l_run[NH];
 #pragma unroll
     for (int hh = 0; hh < NH; ++hh) m_run[hh] = -INFINITY, l_run[hh] = 0.f;
@@ -362,13 +422,19 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
             }
         }
         lds_barrier();  // rotated Q rows of all four waves visible
+        if constexpr (!QF_LDS) {
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-            qf[ks] = *reinterpret_cast<const half8*>(smem + SM::Q_OFF + c * D * 2 + (((2 * ks + h) ^ (c & 15)) * 16));
+            for (int ks = 0; ks < KS; ++ks)
+                qf[ks] = *reinterpret_cast<const half8*>(smem + SM::Q_OFF + c * D * 2 + (((2 * ks + h) ^ (c & 15)) * 16));
+            if (p.scale_log2e < 0.f)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) qf[ks] = -qf[ks];
+        }
     }
     for (int i = 0; i < n; ++i) {
         const bool has1 = i + 1 < n, has2 = i + 2 < n;
         const int slot = i & 1;
+        PHASE_START();
         // ---- K(i) (and Q) landed: younger than it are aux(i+1) [2] and V(i) [8] -------------------------
         if (ABL(2) && i > 0) {  // (experiments: 2 = no K / V waits after the first tile)
         } else if (has1) wait_vm<LPT + 2>();
@@ -376,9 +442,14 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
         if (!ROPE && !PEEL && i == 0) {
             if (DBG) t_k0 = wall_clock64();
             lds_barrier();  // Q rows of all four waves visible
+            if constexpr (!QF_LDS) {
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
-                qf[ks] = *reinterpret_cast<const half8*>(smem + SM::Q_OFF + c * D * 2 + (((2 * ks + h) ^ (c & 15)) * 16));
+                for (int ks = 0; ks < KS; ++ks)
+                    qf[ks] = *reinterpret_cast<const half8*>(smem + SM::Q_OFF + c * D * 2 + (((2 * ks + h) ^ (c & 15)) * 16));
+                if (p.scale_log2e < 0.f)
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) qf[ks] = -qf[ks];
+            }
         }
         if constexpr (ROPE) {
             // rows of this wave's K slice that came from k_new (this step's tokens) are rotated in LDS before QK^T:
@@ -411,13 +482,12 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
                 }
             }
         }
-        // key masks of this lane's 16 keys (keys 8 g4 + 4 h + j of the wave's 32)
-        uintx4 m4[4];
-        {
-            const uint32_t* masks = reinterpret_cast<const uint32_t*>(smem + aux0 + slot * SM::AUX_SLOT + 256);
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) m4[g4] = *reinterpret_cast<const uintx4*>(masks + 8 * g4 + 4 * h);
-        }
+        PHASE(0);
+        // Does every live row see every one of this wave's 32 keys -- a shared-prefix tile: no pads, no query that is not on the
+        // slots' path?  Then no score needs its mask bit tested (three instructions a score): lane k looks at key k's mask word,
+        // one ballot.  (wave-uniform; the last tile of a node, a union group's tiles, the leaf tiles take the general path)
+        const uint32_t* masks = reinterpret_cast<const uint32_t*>(smem + aux0 + slot * SM::AUX_SLOT + 256);
+        const bool full = !ABL(512) && __builtin_amdgcn_ballot_w64((masks[l & 31] & rowbits) != rowbits) == 0ull;
         // ---- S^T for this wave's 32 keys (HD2: k-steps 0-3 = head A, 4-7 = head B) ---------------------------
         floatx16 acc[NH];
 #pragma unroll
@@ -430,23 +500,38 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
                 const half8 a = *reinterpret_cast<const half8*>(smem + krow_b + (kcol_b ^ (32 * ks)));
                 constexpr int HALF = KS / 2;
                 floatx16& dst = acc[HD2 ? (ks / HALF) : 0];
-                dst = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qf[ks], dst, 0, 0, 0);
+                if constexpr (QF_LDS) {  // (the variants that are short of registers re-read the Q fragment: 32 VGPRs for 8 LDS reads a tile)
+                    half8 qk = *reinterpret_cast<const half8*>(smem + SM::Q_OFF + c * D * 2 + (((2 * ks + h) ^ (c & 15)) * 16));
+                    if (p.scale_log2e < 0.f) qk = -qk;
+                    dst = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qk, dst, 0, 0, 0);
+                } else {
+                    dst = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qf[ks], dst, 0, 0, 0);
+                }
             }
         }
-        float s[NH][16];
+        if (!full) {  // key masks of this lane's 16 keys (keys 8 g4 + 4 h + j of the wave's 32): masked scores become -inf
+            uintx4 m4[4];
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) m4[g4] = *reinterpret_cast<const uintx4*>(masks + 8 * g4 + 4 * h);
+#pragma unroll
+            for (int hh = 0; hh < NH; ++hh)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int r = 4 * g4 + j;
+                        acc[hh][r] = ((m4[g4][j] >> c) & 1u) ? acc[hh][r] : -INFINITY;
+                    }
+        }
+        // row maxima over the UNSCALED scores (the scale is positive: it commutes with the maximum)
         float mx[NH];
 #pragma unroll
         for (int hh = 0; hh < NH; ++hh) {
             mx[hh] = -INFINITY;
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int r = 4 * g4 + j;
-                    s[hh][r] = ((m4[g4][j] >> c) & 1u) ? acc[hh][r] * p.scale_log2e : -INFINITY;
-                    mx[hh] = fmaxf(mx[hh], s[hh][r]);
-                }
+            for (int r = 0; r < 16; ++r) mx[hh] = fmaxf(mx[hh], acc[hh][r]);
         }
+        PHASE(1);
         // ---- the K slice is free: next tile's row offsets -> K(i+1), aux(i+2) ---------------------------
         if (has1) {
             wait_vm<LPT>();  // aux(i+1) landed (younger: V(i))
@@ -454,22 +539,23 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
             issue_k();
             if (has2) issue_aux(i + 2, slot);
         }
+        PHASE(2);
         // ---- wave-private online softmax (per head of the row) ------------------------------------------------
         half8 pb[NH][2];
 #pragma unroll
         for (int hh = 0; hh < NH; ++hh) {
-            const float mxx = fmaxf(mx[hh], __shfl_xor(mx[hh], 32));
+            const float mxx = max_xor32(mx[hh]) * sc;  // (rounded once, like every scaled score was: the same maximum as before)
             const float m_new = fmaxf(m_run[hh], mxx);
             const float msafe = (m_new == -INFINITY) ? 0.f : m_new;
             const float alpha = (m_run[hh] == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run[hh] - msafe);
             float sum = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const _Float16 ph = (_Float16)__builtin_amdgcn_exp2f(s[hh][r] - msafe);
+                const _Float16 ph = (_Float16)__builtin_amdgcn_exp2f(__builtin_fmaf(acc[hh][r], sc, -msafe));
                 pb[hh][r >> 3][r & 7] = ph;
                 sum += (float)ph;  // row sums over the ROUNDED probabilities: the weights sum to 1 exactly
             }
-            sum += __shfl_xor(sum, 32);
+            sum = sum_xor32(sum);
             l_run[hh] = l_run[hh] * alpha + sum;
             m_run[hh] = m_new;
             if (i > 0 && __builtin_amdgcn_ballot_w64(alpha != 1.f) != 0ull) {
@@ -481,11 +567,13 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
                 }
             }
         }
+        PHASE(3);
         // ---- V(i) landed: younger are K(i+1) [8] and aux(i+2) [2] ---------------------------------------
         if (ABL(2)) {
         } else if (has2) wait_vm<LPT + 2>();
         else if (has1) wait_vm<LPT>();
         else wait_vm<0>();
+        PHASE(4);
         // ---- O^T += V^T P^T: four 32-column blocks x two 16-key steps ------------------------------------
         if (!ABL(4))
 #pragma unroll
@@ -504,6 +592,7 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
             }
         }
         if (has1) issue_v();  // V(i+1); rowoff still holds tile i+1's offsets
+        PHASE(5);
     }
 
     if (ABL(16)) {  // (experiments build: no epilogue at all)
@@ -615,7 +704,16 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
         d[5] = ((unsigned long long)xcc << 32) | hw;
         d[6] = (unsigned long long)kvh;
         d[7] = t_bar;
+#ifdef DEFT_EXPERIMENTS
+        unsigned long long* d2 = DBG + (int64_t)(8192 + item) * 8;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) d2[k] = ph[k];
+#endif
     }
+#ifdef DEFT_EXPERIMENTS
+#pragma unroll
+    for (int k = 0; k < 6; ++k) ph[k] = 0;
+#endif
     // Next item of a capped grid: record capacity beyond the chunk leaders would otherwise be launched as workgroups
     // that only find out that they have nothing to do (tens of thousands for the sequential comparator's entries).
     if (item + W >= NI) break;
@@ -626,5 +724,7 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
 
 #undef ABL
 #undef DBG
+#undef PHASE
+#undef PHASE_START
 
 }  // namespace deft
