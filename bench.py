@@ -120,6 +120,13 @@ class Bench:
         else:
             self.step_eager()
 
+    def release(self):
+        """Drop the pools and the per-layer inputs (the scalars and the metadata stay): under a shared GPU -- eight gloo ranks on
+        one device -- the headline's 6.7 GB must not sit beside the sharded forest's."""
+        self.graph = None
+        self.forest = self.pool = self.q = self.k_new = self.v_new = self.updater = self.meta = self.attn = self.out = None
+        torch.cuda.empty_cache()
+
     def algorithmic_bytes_per_layer(self) -> int:
         return algorithmic_bytes(self.n_kv, self.nq, self.Hq, self.Hkv, self.D)
 
@@ -186,6 +193,51 @@ class Bench:
         sweeps.sort()
         return {"mean_us": sum(sweeps) / len(sweeps), "median_us": sweeps[len(sweeps) // 2],
                 "launches": len(sweeps) * 4 * self.layers, "launch": "hipgraph" if graph is not None else "eager"}
+
+    def ceiling_us(self, reps: int = 3):
+        """What ONE cold launch that only READS this tree's K/V bytes takes on this GPU (deft_probe_stream_read: coalesced 16-byte
+        loads, nothing else), over the same rotating layer pools, captured and timed like `time_stage1`: the hardware ceiling a
+        stage-1 launch of this size is judged against.  The tree's tokens sit in the pool's lowest slots
+        (prompt contiguous, leaf tokens interleaved step by step), so the byte range is the K/V the kernel reads.  Best of
+        256 / 512 / 1024 workgroups."""
+        slot_bytes = self.pool.kv_data[0].stride(0) * 2
+        nbytes = int(self.n_kv) * slot_bytes
+        stream = torch.cuda.current_stream(self.device)
+        best = None
+        for wgs in (256, 512, 1024):
+            def launch_all():
+                for l in range(self.layers):
+                    check(lib.deft_probe_stream_read(self.pool.kv_data[l].data_ptr(), nbytes, wgs,
+                                                     torch.cuda.current_stream(self.device).cuda_stream), "deft_probe_stream_read")
+            launch_all()
+            torch.cuda.synchronize(self.device)
+            graph = None
+            try:
+                graph = torch.cuda.CUDAGraph()
+                side = torch.cuda.Stream(device=self.device)
+                side.wait_stream(stream)
+                with torch.cuda.stream(side):
+                    with torch.cuda.graph(graph, stream=side):
+                        launch_all()
+                stream.wait_stream(side)
+            except Exception:
+                graph = None
+            sweep = graph.replay if graph is not None else launch_all
+            for _ in range(3):
+                sweep()
+            ts = []
+            for _ in range(reps):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                for _ in range(4):
+                    sweep()
+                e1.record(stream)
+                torch.cuda.synchronize(self.device)
+                ts.append(e0.elapsed_time(e1) * 1e3 / (4 * self.layers))
+            us = sorted(ts)[len(ts) // 2]
+            if best is None or us < best[0]:
+                best = (us, wgs)
+        return {"us": round(best[0], 2), "workgroups": best[1], "kv_bytes": nbytes}
 
     def time_plan(self, reps: int = 7):
         """Median duration (us) of the per-step plan kernels -- the device-side repack of the metadata every layer of
@@ -542,6 +594,10 @@ def main():
                     help="process-group backend of the N > 1 bracket (barrier + MAX of the step time; the data path has no "
                          "collective).  nccl = RCCL, one rank per GPU.  gloo: control plane over TCP, and ranks beyond the visible "
                          "GPUs share them round-robin -- rehearses every line of the N > 1 path on a ONE-GPU box")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="set the process group up even at world size 1 (under a launcher: torch.distributed.run --nproc-per-node 1): "
+                         "the N > 1 bracket -- init_process_group, barrier, MAX all-reduce on the control device -- on ONE GPU, which "
+                         "is how RCCL itself gets exercised where no multi-GPU box is at hand")
     ap.add_argument("--child", action="store_true", help=argparse.SUPPRESS)  # the PMC child: timed steps only
     args = ap.parse_args()
 
@@ -560,7 +616,7 @@ def main():
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr",
                "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         raise SystemExit(subprocess.run(cmd).returncode)
-    dist_on = world > 1
+    dist_on = world > 1 or (args.force_dist and "RANK" in os.environ)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: deft_amd has no CPU path")
     shared_gpus = args.dist_backend == "gloo" and world > torch.cuda.device_count()
@@ -622,13 +678,20 @@ def main():
                     traffic_source = "profiles/r2a_pmc_fetch_size_northstar_4kx32.json (committed pass, NOT this run)" if traffic else None
             except Exception:
                 traffic = None
+        ceil = b.ceiling_us()
         roofline = {"bound": "hbm", "kernel": f"deft::{kind}<128> (Flatten stage 1)",
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_source,
                     "algorithmic_bytes_per_launch": algo, "avg_launch_us": round(s1["mean_us"], 2),
                     "median_launch_us": round(s1["median_us"], 2), "launches_timed": s1["launches"],
-                    "timing": "HIP events around a hipGraph of one launch per layer pool" if s1.get("launch") == "hipgraph"
-                              else "HIP events around eager launches"}
+                    "timing": ("HIP events around a hipGraph of one launch per layer pool" if s1.get("launch") == "hipgraph"
+                               else "HIP events around eager launches") +
+                              "; the launches timed are deft_flatten_stage1_f16 = stage1_np_kernel<128, false, NT> WITHOUT the fused "
+                              "append -- the step's own launches (deft_flatten_decode_append_f16) are the same template "
+                              "instantiation with n_new = nq new rows copied into the pool by its first workgroups",
+                    # the hardware ceiling of a launch of this size: a bare read of the same K/V bytes (deft_probe_stream_read)
+                    "ceiling_us": ceil["us"], "ceiling_workgroups": ceil["workgroups"],
+                    "launch_over_ceiling": round(s1["mean_us"] / ceil["us"], 3)}
     step_achieved = algo * layers / (dt / args.steps) / 1e9
     e2e = None
     if rank == 0 and not dist_on and not args.no_e2e and w.trees == 1 and w.mode == "flatten":
@@ -682,6 +745,7 @@ def main():
                 n = max(100, args.steps // 2)  # >= 100 timed steps
                 dtv = run_timed(bv, n, max(5, args.warmup // 2), False)
                 s1v = bv.time_stage1(reps=1)
+                cv = bv.ceiling_us(reps=1)
                 av = bv.algorithmic_bytes_per_layer()
                 extras[name] = {
                     "model": wv.model, "mode": wv.mode, "trees": wv.trees, "nq": bv.nq, "kv_tokens": bv.n_kv, "steps": n,
@@ -691,6 +755,7 @@ def main():
                     "step_hbm_frac": round(av * bv.layers / (dtv / n) / 1e9 / HBM_PEAK_GBPS, 4),
                     "stage1_us": round(s1v["mean_us"], 2) if s1v else None,
                     "stage1_hbm_frac": round(av / (s1v["mean_us"] * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4) if s1v else None,
+                    "algorithmic_MB": round(av / 1e6, 2), "ceiling_us": cv["us"], "ceiling_workgroups": cv["workgroups"],
                     "metadata_build_ms": round(bv.metadata_build_ms, 3), "launch": bv.launch,
                     "plan_build_us_per_step": round(pv, 1) if (pv := bv.time_plan(5)) is not None else None,
                 }
@@ -712,6 +777,8 @@ def main():
         try:
             del b.graph
             b.graph = None
+            if dist_on:
+                b.release()  # (nothing below reads the headline's pools when ranks > 1: no CPU baseline, no extras)
             torch.cuda.empty_cache()
             cfg5 = cfg5_line(device, w.model, n_gpus, rank, dist_on, max(50, args.steps // 4), max(5, args.warmup // 4),
                              not args.no_graph)

@@ -61,6 +61,8 @@ lib.deft_flatten_decode_append_f16.argtypes = (_QKV + _OUT + _MD6 + [_i32] * 6 +
 lib.deft_flatten_decode_append_f16.restype = C.c_int
 lib.deft_flatten_stage1_f16.argtypes = _QKV + _MD6 + [_i32] * 6 + [_f32, _vp, _vp, _sz, _vp]
 lib.deft_flatten_stage1_f16.restype = C.c_int
+lib.deft_probe_stream_read.argtypes = [_vp, _sz, _i32, _vp]
+lib.deft_probe_stream_read.restype = C.c_int
 lib.deft_flatten_plan_bytes.argtypes = [_i32, _i32, _i32, _i32]
 lib.deft_flatten_plan_bytes.restype = _sz
 lib.deft_flatten_build_plan.argtypes = _MD6 + [_i32, _i32, _i32, _i32, _i64, _i64, _i64, _vp, _i32, _i64, _vp, _sz, _vp]
@@ -161,7 +163,7 @@ EXPORTED = (
     "deft_flatten_read_partials", "deft_node_workspace_bytes", "deft_node_plan_bytes", "deft_node_build_plan", "deft_node_build_plan_dims",
     "deft_node_decode_f16", "deft_node_decode_append_f16", "deft_flatten_decode_rope_append_f16", "deft_node_decode_rope_append_f16", "deft_rope_gather_rows",
     "deft_prefill_f16", "deft_rope_qk_f16", "deft_seq_plan_bytes", "deft_seq_workspace_bytes", "deft_seq_build_plan", "deft_seq_decode_f16", "deft_seq_decode_append_f16",
-    "deft_kv_append_f16", "deft_md_build", "deft_md_sizes", "deft_md_fetch", "deft_md_free",
+    "deft_kv_append_f16", "deft_probe_stream_read", "deft_md_build", "deft_md_sizes", "deft_md_fetch", "deft_md_free",
     "deft_tree_create",
 ) + tuple(_TREE_FUNCS)
 

@@ -833,6 +833,31 @@ __attribute__((visibility("default"))) void deft_debug_plan_form(int serial, int
 __attribute__((visibility("default"))) void deft_debug_set_buffer(void* dev_ptr) { g_dbg = static_cast<unsigned long long*>(dev_ptr); }
 #endif
 
+// Measurement aid (include/deft_amd.h): a bare coalesced read of a byte range, the ceiling of a launch of that size.
+namespace deft {
+__global__ __launch_bounds__(256) void probe_stream_read_kernel(const uintx4* p, size_t n, uint32_t* sink) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * 256;
+    uint32_t acc = 0;
+    for (; i + 3 * stride < n; i += 4 * stride) {
+        const uintx4 a = p[i], b = p[i + stride], c = p[i + 2 * stride], d = p[i + 3 * stride];
+        acc += a.x ^ b.y ^ c.z ^ d.w;
+    }
+    for (; i < n; i += stride) acc += p[i].x;
+    if (acc == 0x9e3779b9u && sink) sink[0] = acc;  // (keeps the loads alive; practically never taken)
+}
+}  // namespace deft
+int deft_probe_stream_read(const void* base, size_t bytes, int workgroups, void* stream) {
+    if (!base || !aligned16(base) || workgroups <= 0) {
+        set_error("deft_probe_stream_read: null / misaligned base or no workgroups");
+        return DEFT_EINVAL;
+    }
+    if (bytes < 16) return DEFT_OK;
+    hipLaunchKernelGGL(probe_stream_read_kernel, dim3((unsigned)workgroups), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const uintx4*>(base), bytes / 16, static_cast<uint32_t*>(nullptr));
+    return check_launch("probe launch");
+}
+
 int deft_supported(int Hq, int Hkv, int D) {
     return (Hq > 0 && Hkv > 0 && Hq % Hkv == 0 && (D == 16 || D == 32 || D == 64 || D == 128)) ? 1 : 0;
 }

@@ -34,13 +34,13 @@ import torch
 from .forward_mode import ForwardMode, InputMetadata, forward_mode_from_cli
 from .memory_pool import ReqToTokenPool, TokenToKVPool
 from .templates import (TreeTemplate, default_prompt_len, fit_accept_lengths, read_reasoning_file,  # noqa: F401
-                        read_speculative_file, synthetic_few_shot_template, synthetic_reasoning_template,
-                        synthetic_speculative_template)
+                        read_speculative_file, synthetic_beam_template, synthetic_few_shot_template,
+                        synthetic_reasoning_template, synthetic_speculative_template)
 from .tree_cache import TreeCache, TreeMetadata, register_tree_metadata
 
 __all__ = [
     "TreeTemplate", "read_reasoning_file", "read_speculative_file", "fit_accept_lengths", "synthetic_reasoning_template",
-    "synthetic_speculative_template", "synthetic_few_shot_template", "branch_from_tree_template",
+    "synthetic_speculative_template", "synthetic_few_shot_template", "synthetic_beam_template", "branch_from_tree_template",
     "branch_speculative_decoding", "branch_few_shot", "ReplayReport", "TemplateReplay",
 ]
 
@@ -179,11 +179,14 @@ class TemplateReplay:
     layers would call it (llama2.py:108-113)."""
 
     def __init__(self, num_heads: int, num_kv_heads: int, head_dim: int, layers: int, mode: str = "flatten",
-                 device: str = "cuda", attention: bool = True, seed: int = 0, vocab: int = 4096, session: Optional[bool] = None) -> None:
+                 device: str = "cuda", attention: bool = True, seed: int = 0, vocab: int = 4096, session: Optional[bool] = None,
+                 capture_after="auto") -> None:
         """`session`: drive the attention path through `deft_amd.DecodeSession` -- the whole decode step (tree advance,
         TreeMetadata, plan, every layer's append + attention) as ONE captured hipGraph per structural epoch of the tree -- instead
         of the reference-shaped eager calls (`tree.alloc()`, `TreeMetadata.from_tree_cache`, `DeFTAttention.forward` per layer).
-        None = wherever a session exists (DeFT-Flatten / DeFT-Node, head_dim 128, attention on)."""
+        None = wherever a session exists (DeFT-Flatten / DeFT-Node, head_dim 128 or 64 as head pairs, attention on).
+        `capture_after`: DecodeSession's -- how many steps of an epoch run eagerly before its step is captured."""
+        self.capture_after = capture_after
         self.Hq, self.Hkv, self.D, self.layers = num_heads, num_kv_heads, head_dim, layers
         self.mode = mode
         self.forward_mode: ForwardMode = forward_mode_from_cli(mode)
@@ -195,7 +198,7 @@ class TemplateReplay:
         # rolling window -- drawing nq x vocab fresh numbers per decode step cost more host time than the step itself
         self._score_table = self.rng.random((1024 + 257, vocab), dtype=np.float32)
         self._score_at = 0
-        can = attention and mode in ("flatten", "node") and head_dim == 128
+        can = attention and mode in ("flatten", "node") and (head_dim == 128 or (head_dim == 64 and num_kv_heads % 2 == 0))
         self.session = can if session is None else (bool(session) and can)
         # test hook: called after every step's attention with (tree, layer-0 q rows [nq, Hq*D], layer-0 output [nq, Hq*D])
         self.step_hook: Optional[Callable[[TreeCache, torch.Tensor, torch.Tensor], None]] = None
@@ -254,7 +257,8 @@ class TemplateReplay:
             from .tree_cache import _ptr
 
             sess = DecodeSession(tree, self.Hq, self.Hkv, self.D, self.layers,
-                                 lambda l: (q_all[l, : nq_now[0]], k_all[l, : nq_now[0]], v_all[l, : nq_now[0]]), mode=self.mode)
+                                 lambda l: (q_all[l, : nq_now[0]], k_all[l, : nq_now[0]], v_all[l, : nq_now[0]]), mode=self.mode,
+                                 capture_after=self.capture_after)
             sizes = np.zeros(9, dtype=np.int64)
         t_wall = time.perf_counter()
         tree.init_prompt(torch.arange(1, prompt_len + 1, dtype=torch.int32))

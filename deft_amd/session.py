@@ -16,7 +16,7 @@ Per step the host picks the new slots (its allocator mirrors the pool), appends 
 nq slot numbers and page-table coordinates from pinned memory, and replays: ~0.1 ms of host time, nothing else crosses
 PCIe.  A branch / cut / merge (or a leaf outgrowing its room) starts a new epoch: upload the compact tree, capture again.
 
-DeFT-Flatten and DeFT-Node, head_dim 128.  The eager path (`tree.alloc()` + `TreeMetadata.from_tree_cache` + `DeFTAttention`) gives the same
+DeFT-Flatten and DeFT-Node; head_dim 128, and 64 as head pairs.  The eager path (`tree.alloc()` + `TreeMetadata.from_tree_cache` + `DeFTAttention`) gives the same
 results step for step (tests/test_session.py).
 """
 from __future__ import annotations
@@ -34,11 +34,27 @@ __all__ = ["DecodeSession", "FlattenDecodeSession"]
 
 class DecodeSession:
     def __init__(self, tree: TreeCache, num_heads: int, num_kv_heads: int, head_dim: int, layers: int,
-                 qkv: Callable[[int], tuple], max_q_len: int = 32, use_graph: bool = True, mode: str = "flatten") -> None:
+                 qkv: Callable[[int], tuple], max_q_len: int = 32, use_graph: bool = True, mode: str = "flatten",
+                 capture_after="auto") -> None:
         """`qkv(layer)` -> (q [nq, Hq*D], k_new [nq, Hkv*D], v_new [nq, Hkv*D]) fp16 CUDA tensors at FIXED addresses (the
-        model writes this step's projections there); outputs are in `self.out[layer]` ([nq, Hq*D])."""
+        model writes this step's projections there); outputs are in `self.out[layer]` ([nq, Hq*D]).
+
+        head_dim 128, or 64 with an even number of KV heads (the pool's contiguous heads: two heads of 64 to a 256-byte row, the
+        tile-parallel kernel's head-pair form) -- the geometries whose stage 1 reads a per-step PLAN, which is what lets one captured
+        launch serve every step of an epoch; head_dim 32 / 16 take the eager operators.
+
+        `capture_after`: an epoch's step is captured once the epoch has lasted that many steps (its first step always runs
+        eagerly: it follows an upload).  1 = at the second step, the round-3 behaviour: a capture costs ~0.65 ms of host time and
+        a replayed step ~0.07 ms against ~0.55 ms for an eager one, so it pays from the third step of an epoch on.  "auto": 1,
+        unless the LAST epoch ended within three steps -- trees that change shape every step or two (a controller that prunes after
+        every token) then stay eager instead of paying a capture per step, and go back to capturing as soon as an epoch lasts."""
         pool = tree.token_to_kv_pool
-        assert pool.device.type == "cuda" and head_dim == 128 and mode in ("flatten", "node")
+        assert pool.device.type == "cuda" and mode in ("flatten", "node")
+        assert head_dim == 128 or (head_dim == 64 and num_kv_heads % 2 == 0), "DecodeSession: head_dim 128, or 64 with an even number of KV heads"
+        assert capture_after == "auto" or int(capture_after) >= 1
+        self.capture_after = capture_after
+        self._epoch_steps = 0       # steps of the current epoch so far (its eager first one included)
+        self._last_epoch_steps = 1 << 30
         self.mode = mode
         # (the device WITH its index: torch.device("cuda") != torch.device("cuda:0"), and the page-table fold below compares devices --
         #  round 3: with the default "cuda" pool the fold never happened and every step carried an index_put)
@@ -171,6 +187,7 @@ class DecodeSession:
             # a new structural epoch (branch / cut / merge since the last step, or a leaf outgrew its room): an upload made
             # now already contains this step's slots, so this step runs eagerly without the advance; a device copy that was
             # current BEFORE this step's alloc_step (and stayed in its epoch) appends them itself.  The next step captures.
+            self._last_epoch_steps, self._epoch_steps = (self._epoch_steps if self.graph_epoch >= 0 else 1 << 30), 1
             uploaded = self._epoch_setup()
             jn = 0
             if not uploaded:  # (a device copy that stays may still owe the journal)
@@ -181,10 +198,12 @@ class DecodeSession:
             self._launch_step(advance=not uploaded)
             return self.out
         self._write_staging(loc, jn)
-        if not self.use_graph:
-            self._launch_step()
-            return self.out
+        self._epoch_steps += 1
         if self.graph is None:
+            wait = (1 if self._last_epoch_steps > 3 else 4) if self.capture_after == "auto" else int(self.capture_after)
+            if not self.use_graph or self._epoch_steps <= wait:  # (this is step `_epoch_steps` of the epoch; `wait` of them run eagerly)
+                self._launch_step()
+                return self.out
             self._capture()
         self.graph.replay()
         return self.out

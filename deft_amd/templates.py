@@ -27,7 +27,7 @@ from typing import Any, Dict, Iterable, List, Mapping, Optional, Sequence, Tuple
 import numpy as np
 
 __all__ = ["TreeTemplate", "read_reasoning_file", "read_speculative_file", "fit_accept_lengths", "synthetic_reasoning_template",
-           "synthetic_speculative_template", "synthetic_few_shot_template", "default_prompt_len"]
+           "synthetic_speculative_template", "synthetic_few_shot_template", "synthetic_beam_template", "default_prompt_len"]
 
 OPEN_ENDED = 1 << 30  # `value` / `end` of a node that generates until the replay's own limit (few-shot leaves)
 
@@ -216,6 +216,27 @@ def synthetic_reasoning_template(widths=(7, 6), lens=(128, 64)) -> TreeTemplate:
                 children[parent].append(nid)
                 nxt.append(nid)
         frontier = nxt
+    return TreeTemplate(value, start, end, children)
+
+
+def synthetic_beam_template(width: int = 10, depth: int = 10, seg_len: int = 8) -> TreeTemplate:
+    """The shape of the reference's shipped Reasoning templates (dataset/generation/Reasoning/*: 31 / 61 / 91 / 101 lifetime nodes,
+    width 10 per level): at every level the kept node branches into `width` candidates, each generates `seg_len` tokens, all but
+    the first are pruned and the first branches again -- 1 + width x depth nodes, a branch (and width - 1 prunes) every `seg_len`
+    decode steps: the workload whose tree changes shape every few steps."""
+    value, start, end, children = [0], [0], [0], [[]]
+    parent = 0
+    for _ in range(depth):
+        kids = []
+        for _ in range(width):
+            nid = len(value)
+            value.append(seg_len)
+            start.append(end[parent] + 1)
+            end.append(end[parent] + seg_len)
+            children.append([])
+            children[parent].append(nid)
+            kids.append(nid)
+        parent = kids[0]
     return TreeTemplate(value, start, end, children)
 
 

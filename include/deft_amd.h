@@ -305,6 +305,12 @@ int deft_kv_append_f16(
 
 /* ---- stage-level entry points (benchmarks / profiling) ------------------- */
 
+/* Measurement aid, not on the product path: ONE launch of `workgroups` x 256 threads that reads `bytes` bytes at `base` (16-byte
+ * aligned) with coalesced 16-byte loads, four in flight per thread, and does nothing else.  What a cold launch of that size can
+ * draw from HBM on this part: the ceiling a stage-1 launch over the same K/V bytes is judged against (bench.py `ceiling_us`;
+ * tools/probes/launch_ceiling.hip is the stand-alone form). */
+int deft_probe_stream_read(const void* base, size_t bytes, int workgroups, void* stream);
+
 /* Flatten stage 1 only: writes normalised fp32 partials + LSE into the workspace
  * (same layout deft_flatten_decode_f16 uses).  For roofline timing of the dominant
  * kernel in isolation. */

@@ -131,6 +131,12 @@ def s_fewshot_1k(tree, ids):  # BASELINE config 2 at branch length 1
     _step(tree, 1)
 
 
+def s_fewshot_1k_len200(tree, ids):  # BASELINE config 2 at the branch length bench.py measures it at
+    tree.init_prompt(ids(1024))
+    tree.branch(tree.root, 32)
+    _step(tree, 200)
+
+
 def s_fewshot_4k(tree, ids):  # north-star tree at branch length 1
     tree.init_prompt(ids(4096))
     tree.branch(tree.root, 32)
@@ -172,6 +178,7 @@ SCENARIOS: Dict[str, Scenario] = {
     "medusa64": Scenario(s_medusa64, pool_size=2048, kernels=False),
     "tot50": Scenario(s_tot50, pool_size=8192, kernels=False),
     "fewshot_1k": Scenario(s_fewshot_1k, pool_size=2048, kernels=False),
+    "fewshot_1k_len200": Scenario(s_fewshot_1k_len200, pool_size=7680, kernels=False),
     "fewshot_4k": Scenario(s_fewshot_4k, pool_size=8192, kernels=False),
     "fewshot_4k_len200": Scenario(s_fewshot_4k_len200, pool_size=10752, kernels=False),
     "forest_tree_8kx8": Scenario(s_forest_tree_8kx8, pool_size=8832, kernels=False),
@@ -182,7 +189,7 @@ SMALL_GEOMETRIES = ((4, 4, 128), (8, 2, 128), (4, 4, 64))
 # full Llama-2-7B geometry goldens (F3): scenario -> (Hq, Hkv, D).  BASELINE configs[1] (1k x 32), the north-star tree
 # at branch length 1 and at the benchmarked length 200, configs[2] (Medusa-64) at the model BASELINE names for it
 # (and configs[0], the 256-prefix x 2-branch plumbing case, at its own model's geometry too)
-FULL_GEOMETRY = {"cfgA_256x2": (32, 32, 128), "fewshot_1k": (32, 32, 128), "fewshot_4k": (32, 32, 128),
+FULL_GEOMETRY = {"cfgA_256x2": (32, 32, 128), "fewshot_1k": (32, 32, 128), "fewshot_1k_len200": (32, 32, 128), "fewshot_4k": (32, 32, 128),
                  "fewshot_4k_len200": (32, 32, 128), "medusa64": (32, 32, 128)}
 # Llama-3-8B GQA geometry: the Medusa tree, configs[3] (ToT-50) and one tree of configs[4] (8k x 8 x 64)
 GQA_GEOMETRY = {"medusa64": (32, 8, 128), "tot50": (32, 8, 128), "forest_tree_8kx8": (32, 8, 128)}

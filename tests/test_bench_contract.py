@@ -58,3 +58,40 @@ def test_two_ranks_over_gloo_on_one_gpu():
     assert len(a) == len(b) == 8 and not set(a) & set(b) and sorted(a + b) == list(range(16))
     assert c5["collectives_in_data_path"] == 0 and c5["end_to_end"] and "error" not in c5["end_to_end"]
     assert d["value"] > 0 and c5["tokens_per_s"] > 0
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def test_rccl_bracket_at_world_size_one():
+    """RCCL itself (backend "nccl"), one rank on the one GPU: `init_process_group("nccl", device_id=...)`, the rehearsed barrier /
+    MAX all-reduce with the control tensors ON THE GPU (`_ctl_device`), the distributed bracket around the timed region and around
+    the sharded forest's loop, `destroy_process_group` -- everything of the N > 1 path except a second GPU."""
+    d = _line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), "bench.py", "--gpus", "1", "--force-dist", "--dist-backend", "nccl", "--steps", "20",
+               "--warmup", "5", *FAST])
+    assert d["n_gpus"] == 1 and d["dist"]["backend"] == "nccl" and d["dist"]["world_size"] == 1 and not d["dist"]["ranks_share_gpus"]
+    c5 = d["cfg5_sharded_forest"]
+    assert c5["dist_backend"] == "nccl" and c5["trees_by_rank"] == [list(range(8))] and c5["collectives_in_data_path"] == 0
+    assert d["value"] > 0 and "error" not in (c5["end_to_end"] or {})
+
+
+@pytest.mark.timeout(1500)
+def test_eight_ranks_over_gloo_on_one_gpu():
+    """BASELINE configs[4] at its full rank count -- 64 trees, 8 per rank -- with all eight ranks sharing this GPU over gloo: the
+    launcher, the process group, `cfg5_shard` at world size 8 and the bracket as the driver's 8-GPU run will execute them."""
+    d = _line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), "bench.py", "--gpus", "8", "--dist-backend", "gloo", "--steps", "8", "--warmup", "2",
+               *FAST], timeout=1400)
+    assert d["n_gpus"] == 8 and d["dist"]["world_size"] == 8 and d["dist"]["ranks_share_gpus"]
+    c5 = d["cfg5_sharded_forest"]
+    shares = c5["trees_by_rank"]
+    assert len(shares) == 8 and all(len(sh) == 8 for sh in shares)
+    assert sorted(t for sh in shares for t in sh) == list(range(64))  # every tree once
+    assert c5["collectives_in_data_path"] == 0 and "error" not in (c5["end_to_end"] or {})
+    assert d["value"] > 0 and c5["tokens_per_s"] > 0

@@ -67,6 +67,15 @@ def test_reasoning_replay_follows_the_template_and_frees_everything():
     assert int((r.pool.mem_state != 0).sum()) == 0  # all KV slots back in the pool
 
 
+def test_beam_template_has_the_shipped_files_shape():
+    """width 10 per level, the kept node branching again (dataset/generation/Reasoning/*: 31 / 61 / 91 / 101 lifetime nodes)."""
+    tpl = rp.synthetic_beam_template(width=10, depth=6, seg_len=8)
+    assert tpl.node_num == 61 and tpl.max_width == 10 and tpl.max_depth == 6
+    assert sorted(tpl.branch_record) == [0, 8, 16, 24, 32, 40]  # a branch every 8 steps
+    r, rep = _cpu_replay("reasoning", tpl, prompt_len=30, max_gen_len=1000)
+    assert rep.steps == 6 * 8
+
+
 def test_reference_template_replay_runs_to_completion():
     g = GOLD["reasoning"]["docmergeToT"]
     tpl = rp.TreeTemplate.from_node_table(g["data"])

@@ -177,3 +177,56 @@ def test_session_speculative_decoding_steps_replay_one_graph(mode):
             tree.reset_nodes_KV(lv, len(tree.root.kv_indices) - before)
     # epochs: the first step; the first merge into a root without room.  Everything after replays the second epoch's graph.
     assert sess.captures <= 2, sess.captures
+
+
+@pytest.mark.parametrize("capture_after", [1, 3, "auto"])
+def test_session_head_dim_64_and_lazy_capture(capture_after):
+    """head_dim 64 through the captured loop (two KV heads to a 256-byte pool row: the tile-parallel kernel's head pairs read a
+    per-step plan, so one captured launch serves the epoch), and `capture_after`: the epoch's first steps run eagerly, the graph
+    is captured once the epoch has lasted -- bit-identical to the eager operators either way."""
+    Hq, Hkv, D, layers, prefix, width = 8, 4, 64, 2, 500, 5
+    g = torch.Generator(device="cuda").manual_seed(23)
+    kv_init = torch.randn((layers, 2048, 2, Hkv, D), dtype=torch.float16, device="cuda", generator=g)
+    (te, pe), (ts, ps) = [_mk(Hkv, D, layers, prefix, width, 2048) for _ in range(2)]
+    for p in (pe, ps):
+        p._storage.copy_(kv_init)
+    cap = 16
+    q = torch.randn((layers, cap, Hq * D), dtype=torch.float16, device="cuda", generator=g)
+    k = torch.randn((layers, cap, Hkv * D), dtype=torch.float16, device="cuda", generator=g)
+    v = torch.randn((layers, cap, Hkv * D), dtype=torch.float16, device="cuda", generator=g)
+    nq_now = [width]
+    sess = deft_amd.DecodeSession(ts, Hq, Hkv, D, layers, lambda l: (q[l, : nq_now[0]], k[l, : nq_now[0]], v[l, : nq_now[0]]),
+                                  capture_after=capture_after)
+    attn = [deft_amd.DeFTAttention(Hq, D, D ** -0.5, Hkv, l) for l in range(layers)]
+    fmode = deft_amd.forward_mode_from_cli("flatten")
+
+    def both_steps(steps):
+        for _ in range(steps):
+            for tree in (te, ts):
+                for leaf in tree.leaves.values():
+                    leaf.append_token(7)
+            upd = te.alloc()
+            md = deft_amd.TreeMetadata.from_tree_cache(te)
+            deft_amd.register_tree_metadata(md)
+            n = md.query_num
+            nq_now[0] = n
+            ref = [attn[l](q[l, :n], k[l, :n], v[l, :n], deft_amd.InputMetadata(fmode, upd, pe)) for l in range(layers)]
+            out = sess.step()
+            torch.cuda.synchronize()
+            for l in range(layers):
+                assert torch.equal(out[l][:n], ref[l]), l
+            assert torch.equal(pe._storage, ps._storage)
+
+    both_steps(2)
+    assert sess.captures == (1 if capture_after in (1, "auto") else 0)  # the second step of an epoch is captured at once, or not yet
+    both_steps(8)
+    assert sess.captures == 1
+    for rounds in range(3):  # epochs of two steps each: `auto` stops capturing after the first short one
+        for tree in (te, ts):
+            lv = sorted(tree.leaves.values(), key=lambda n: n.id)
+            tree.cut(lv[-1])
+            tree.branch(lv[0], 2)
+        both_steps(2)
+    assert sess.captures == {1: 4, 3: 1, "auto": 2}[capture_after]
+    both_steps(6)  # ... and the last epoch lasts: everyone captures it
+    assert sess.captures == {1: 4, 3: 2, "auto": 3}[capture_after]

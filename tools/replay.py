@@ -29,6 +29,10 @@ ap.add_argument("--pipelined", action="store_true", help="no per-step sync: host
 ap.add_argument("--no-warmup", action="store_true", help="do not run the first mode once untimed before the table")
 ap.add_argument("--host-metadata", action="store_true", help="TreeMetadata by the host builder + one upload per step (round-1 path)")
 ap.add_argument("--eager", action="store_true", help="the reference-shaped eager calls per step instead of deft_amd.DecodeSession (one hipGraph per structural epoch)")
+ap.add_argument("--beam", default=None, metavar="WIDTH,DEPTH,LEN",
+                help="reasoning: the shipped templates' shape instead of the ToT-50 tree -- the kept node branches into WIDTH candidates "
+                     "every LEN steps, DEPTH levels (deft_amd.templates.synthetic_beam_template)")
+ap.add_argument("--capture-after", default="auto", help="DecodeSession(capture_after=): 1, 2, ... or auto")
 ap.add_argument("--out", default=None)
 a = ap.parse_args()
 if a.host_metadata:
@@ -42,6 +46,8 @@ def template():
     if a.task == "reasoning":
         if a.template:
             return rp.read_reasoning_file(a.template)[a.tree_index]
+        if a.beam:
+            return rp.synthetic_beam_template(*[int(x) for x in a.beam.split(",")])
         return rp.synthetic_reasoning_template()
     if a.task == "speculative_decoding":
         if a.template:
@@ -61,11 +67,12 @@ else:
 for idx, mode in enumerate(a_modes):
     tpl = template()
     prompt_len = a.prompt_len or rp.default_prompt_len(tpl, a.task, from_file=bool(a.template))
-    r = rp.TemplateReplay(Hq, Hkv, D, L, mode=mode, device="cuda", attention=True, session=False if a.eager else None)
+    r = rp.TemplateReplay(Hq, Hkv, D, L, mode=mode, device="cuda", attention=True, session=False if a.eager else None,
+                          capture_after=a.capture_after if a.capture_after == "auto" else int(a.capture_after))
     rep = r.run(tpl, a.task, prompt_len, a.max_gen_len, max_rows=max(512, a.width, a.tree_size), pipelined=a.pipelined)
     s = rep.summary(); s["model"] = a.model; s["layers"] = L
     s["path"] = "session (one hipGraph per structural epoch)" if r.session else "eager calls"
-    s["graph_captures"] = r.graph_captures; s["pipelined"] = bool(a.pipelined)
+    s["graph_captures"] = r.graph_captures; s["pipelined"] = bool(a.pipelined); s["capture_after"] = a.capture_after
     s["wall_over_attention"] = round(s["wall_ms"] / max(s["attention_latency_ms"], 1e-9), 3)
     if not a.no_warmup and idx == 0:
         del r
