@@ -3,7 +3,7 @@
 # bench line, the rocprofv3 kernel-trace summary of the STEP graph alone and the two PMC passes (own runs, --kernel-trace
 # only), the two-rank rehearsal of the N > 1 path over gloo, the fuzzers.  Writes gpurun_out/<tag>/<tag>_*; the files judged are
 # copied from there into profiles/ (see profiles/README.md).
-TAG=${1:-r3z}
+TAG=${1:-r4z}
 R=$GRAFT_REPO_ROOT; export PYTHONPATH=$R; O=$R/gpurun_out/$TAG; mkdir -p $O
 cd $R
 # replays: through the captured session (default) -- per-step synchronised (per-step attention times) and pipelined (the loop as a
@@ -16,13 +16,29 @@ timeout 300 python tools/replay.py --task reasoning --model llama3-8b --out $O/$
 timeout 300 python tools/replay.py --task speculative_decoding --modes node flatten seq --tree-size 64 --out $O/${TAG}_replay_speculative_64.json > $O/replay_sd.log 2>&1
 timeout 300 python tools/replay.py --task speculative_decoding --modes node flatten --tree-size 64 --pipelined --out $O/${TAG}_replay_speculative_64_pipelined.json > $O/replay_sdp.log 2>&1
 timeout 300 python tools/replay.py --task speculative_decoding --modes node flatten --tree-size 64 --eager --out $O/${TAG}_replay_speculative_64_eager.json > $O/replay_sde.log 2>&1
+# the shipped reasoning templates' shape: width 10 per level, a branch (and nine prunes) every 8 steps -- synchronised per step and pipelined
+timeout 300 python tools/replay.py --task reasoning --beam 10,12,8 --prompt-len 4096 --modes flatten --out $O/${TAG}_replay_reasoning_beam10x8.json > $O/replay_beam.log 2>&1
+timeout 300 python tools/replay.py --task reasoning --beam 10,12,8 --prompt-len 4096 --modes flatten --pipelined --out $O/${TAG}_replay_reasoning_beam10x8_pipelined.json > $O/replay_beamp.log 2>&1
 timeout 900 python bench.py > $O/${TAG}_bench_default.json 2> $O/bench.err
 # the N > 1 path on one GPU: two ranks over gloo (RCCL needs a GPU per rank; the driver's 8-GPU run uses it)
 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --dist-backend gloo --steps 50 --warmup 10 --no-extras --no-cpu-baseline --no-traffic 2> $O/bench_2rank.err | grep '^{' > $O/${TAG}_bench_2rank_gloo_one_gpu.json
+# ... BASELINE configs[4] at its full rank count: eight ranks, 64 trees, all sharing this GPU over gloo; and RCCL itself at world size 1
+timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29518 bench.py --gpus 8 --dist-backend gloo --steps 10 --warmup 2 --no-extras --no-cpu-baseline --no-traffic --no-e2e 2> $O/bench_8rank.err | grep '^{' > $O/${TAG}_bench_8rank_gloo_one_gpu.json
+timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29519 bench.py --gpus 1 --force-dist --dist-backend nccl --steps 50 --warmup 10 --no-extras --no-cpu-baseline --no-traffic --no-e2e 2> $O/bench_rccl1.err | grep '^{' > $O/${TAG}_bench_rccl_world_size_1.json
+# what one cold launch of each BASELINE size can read (stand-alone probe; bench.py measures the same per workload as `ceiling_us`), and
+# the per-CU L2 -> LDS rate
+(cd tools/probes && make -s launch_ceiling l2_to_lds_bw) > /dev/null 2>&1
+timeout 200 tools/probes/launch_ceiling > $O/${TAG}_launch_ceiling.txt 2>&1
+timeout 120 tools/probes/l2_to_lds_bw > $O/${TAG}_l2_to_lds_bw.txt 2>&1
+# where a stage-1 work item's tile loop spends its time (experiments build)
+for wl in northstar_4kx32 gqa_4kx32 medusa64_node; do echo "== $wl"; WL=$wl DEFT_AMD_LIB=$R/deft_amd/lib/libdeft_amd_exp.so timeout 100 python tools/np_phases.py 2>&1 | grep "^rep 2\|^  n="; done > $O/${TAG}_stage1_phases.txt
 cd /tmp && export TMPDIR=/tmp
 # per-kernel averages of the STEP graph alone (no stage-1-only sweeps, no eager percentiles): sum of the two averages <= step time / layers
 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_$TAG -- python $R/bench.py --steps 100 --warmup 10 --step-only > $O/${TAG}_bench_under_rocprof_stats.json 2> $O/rocprof.err
 python $R/tools/prof_summary.py /tmp/prof_$TAG > $O/${TAG}_kernel_stats.txt 2>&1
+# the same command's kernel trace as CSV: durations AND the gaps between consecutive kernels, next to the step time the traced run printed
+timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/kt_$TAG -- python $R/bench.py --steps 100 --warmup 10 --step-only > $O/${TAG}_bench_under_rocprof_trace.json 2>/dev/null
+python $R/tools/kernel_gaps.py /tmp/kt_$TAG 0.4 > $O/${TAG}_kernel_gaps.txt 2>&1
 tail -c 600 $O/${TAG}_bench_default.json | head -c 300; echo; head -8 $O/${TAG}_kernel_stats.txt | cut -c1-160
 # the small BASELINE configurations under the kernel trace (configs[2], configs[3]) and head_dim 64
 for wl in medusa64_node tot50_4k gqa_4kx32 northstar_4kx32_d64; do
