@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""(Re)write DESIGN.md's end-of-round paragraph from its template (tools/end_of_round_paragraph.md, placeholders R3Z_*) and the
-files tools/end_of_round.sh wrote:   tools/fill_round_numbers.py r3z [dir = gpurun_out/r3z]     (prints what it filled)"""
+"""(Re)write DESIGN.md's end-of-round paragraph from its template (tools/end_of_round_paragraph.md, placeholders <TAG>_*) and the
+files tools/end_of_round.sh wrote:   tools/fill_round_numbers.py r4z [dir = gpurun_out/r4z]     (prints what it filled).
+DESIGN.md holds either the markers <TAG>_PARAGRAPH / <TAG>_CEILTABLE (first fill) or an earlier fill of them between the
+<!-- ... --> comments this tool leaves behind (refill)."""
 import json, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
@@ -38,6 +40,16 @@ def per_step(r):
 
 
 two = last_json(os.path.join(d, f"{tag}_bench_2rank_gloo_one_gpu.json"))
+
+
+def opt_json(name):
+    try:
+        return last_json(os.path.join(d, f"{tag}_{name}.json"))
+    except Exception:
+        return None
+
+
+eight, rccl = opt_json("bench_8rank_gloo_one_gpu"), opt_json("bench_rccl_world_size_1")
 vals = {
     "VALUE": f"{b['value'] / 1e3:.2f}", "MS": b["ms_per_step"], "LAYER": b["attention_latency_us_per_layer"],
     "S1RP": avg("stage1_np_kernel"), "S1": b["roofline"]["avg_launch_us"], "MG": avg("merge_kernel"), "FRAC": b["roofline"]["frac"],
@@ -55,15 +67,42 @@ vals = {
     "FS": per_step(replay("few_shot_4kx32", "flatten")), "2R": two["ms_per_step"],
 }
 vals["TOTR"] = per_step(replay("reasoning_tot50", "flatten"))
+rf = b["roofline"]
+vals.update({"CEIL": rf.get("ceiling_us", "n/a"), "OVERCEIL": rf.get("launch_over_ceiling", "n/a"),
+             "8R": eight["ms_per_step"] if eight else "n/a", "RCCL": rccl["ms_per_step"] if rccl else "n/a"})
+try:
+    bm, bmp = replay("reasoning_beam10x8", "flatten"), replay("reasoning_beam10x8_pipelined", "flatten")
+    vals.update({"BEAM": per_step(bm), "BEAMR": bm["wall_over_attention"], "BEAMP": per_step(bmp), "BEAMPR": bmp["wall_over_attention"]})
+except Exception:
+    vals.update({"BEAM": "n/a", "BEAMR": "n/a", "BEAMP": "n/a", "BEAMPR": "n/a"})
+# the small-launch table of section 4b: B_algo, ceiling, stage 1, layer
+rows = []
+names = [("medusa64_node", "Medusa-64, DeFT-Node (configs[2])"), ("tot50_4k", "ToT-50, Llama-3-8B (configs[3])"),
+         ("forest_8kx8_single", "one 8k x 8 tree of configs[4]"), ("gqa_4kx32", "north-star tree on Llama-3-8B (GQA 4k x 32)"),
+         ("northstar_4kx32_len1", "north-star tree at branch length 1"), ("fewshot_1kx32", "1k x 32 x 200 (configs[1])")]
+for key, label in names:
+    o = ow.get(key) or {}
+    rows.append(f"| {label} | {o.get('algorithmic_MB', '?')} | {o.get('ceiling_us', '?')} | {o.get('stage1_us') or '(Node plan: no stage-1-only entry point)'} | {o.get('us_per_layer', '?')} |")
+rows.append(f"| north-star 4k x 32 x 200 (headline) | {rf['algorithmic_bytes_per_launch'] / 1e6:.2f} | {rf.get('ceiling_us', '?')} | {rf['avg_launch_us']} | {b['attention_latency_us_per_layer']} |")
+ceil_table = "\n".join(rows)
 path = os.path.join(ROOT, "DESIGN.md")
 txt = open(path).read()
 tpl = os.path.join(ROOT, "tools", "end_of_round_paragraph.md")
-if os.path.exists(tpl):  # the paragraph between the two headings is replaced by the template, then filled
-    t = open(tpl).read()
-    head = t.split("**", 2)[1]  # "End of round N"
-    a = txt.index("**" + head + "**")
-    b = txt.index("**End of round", a + 4)
-    txt = txt[:a] + t + txt[b:]
+def put(marker, body):
+    """Replace `marker` -- or what an earlier run put in its place, between the comment pair -- with body."""
+    global txt
+    open_, close_ = f"<!-- {marker} -->", f"<!-- /{marker} -->"
+    block = f"{open_}\n{body.rstrip()}\n{close_}"
+    if open_ in txt:
+        a, z = txt.index(open_), txt.index(close_) + len(close_)
+        txt = txt[:a] + block + txt[z:]
+    else:
+        txt = txt.replace(marker, block, 1)
+
+
+put(P + "CEILTABLE", ceil_table)
+if os.path.exists(tpl):
+    put(P + "PARAGRAPH", open(tpl).read())
 # longest keys first: R3Z_E2EE before R3Z_E2E, R3Z_S1RP before R3Z_S1, R3Z_TOTR before R3Z_TOT, R3Z_CFG5E2E before R3Z_CFG5, ...
 for k in sorted(vals, key=len, reverse=True):
     n = txt.count(P + k)
