@@ -150,11 +150,6 @@ _TREE_FUNCS = {
     "deft_tree_dev_build_md_ops": ([C.c_int, C.c_int, C.c_int] + [_vp] * 6 + [C.c_int] * 4 + [_vp, _sz] + [_vp] * 12 + [_vp, _vp] +
                                    [_vp, _i64, _vp, _vp, _vp], C.c_int),
     "deft_tree_dev_apply_ops": ([C.c_int, C.c_int, C.c_int] + [_vp] * 6 + [_vp, _vp, _vp], C.c_int),
-    # tree (3 ints, 6 ptrs), config (4 ints), scratch, the six block arrays, advance_loc, ops, page table (ptr, stride, rows, cols),
-    # NB, P, Hq, Hkv, q strides + pool stride, cache_loc, n_new, new stride, plan, plan bytes, stream
-    "deft_tree_dev_build_flatten_step": ([C.c_int, C.c_int, C.c_int] + [_vp] * 6 + [C.c_int] * 4 + [_vp, _sz] + [_vp] * 6 + [_vp, _vp] +
-                                         [_vp, _i64, _vp, _vp] + [C.c_int] * 4 + [_i64, _i64, _i64] + [_vp, C.c_int, _i64] +
-                                         [_vp, _sz, _vp], C.c_int),
     "deft_tree_journal_take": ([_i64, _vp, _i64], _i64),
 }
 for _f, (_a, _r) in _TREE_FUNCS.items():

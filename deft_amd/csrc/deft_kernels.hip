@@ -290,7 +290,6 @@ __global__ __launch_bounds__(256, 2) void stage1_kernel(Stage1Params p) {
 #include "plan_records.h"
 #include "plan_kernels.h"
 #include "tree_plan.h"
-#include "step_head.h"
 #include "merge.h"
 #include "stage1_np.h"
 #include "prefill.h"
@@ -545,7 +544,7 @@ static int num_cus() {
     return d.cus;
 }
 enum : unsigned { ATTR_NP = 4,  // (bits 0-1, 8-11: the head_dim 64 / 32 / 16 kernels)
-                  ATTR_UNITS = 8, ATTR_NODE_UNITS = 16, ATTR_PREFILL = 32, ATTR_TREE = 64, ATTR_STEP_HEAD = 1u << 19, ATTR_NP_ROPE = 128, ATTR_NP_T = 8192, ATTR_NP_ROPE_T = 16384, ATTR_NP_HD2 = 32768, ATTR_NP_HD2_T = 65536 };
+                  ATTR_UNITS = 8, ATTR_NODE_UNITS = 16, ATTR_PREFILL = 32, ATTR_TREE = 64, ATTR_NP_ROPE = 128, ATTR_NP_T = 8192, ATTR_NP_ROPE_T = 16384, ATTR_NP_HD2 = 32768, ATTR_NP_HD2_T = 65536 };
 static int raise_lds(const void* fn, int bytes, unsigned bit, const char* what) {  // idempotent; races are harmless
     DeviceState& d = dev_state();
     if (d.attrs & bit) return DEFT_OK;
@@ -636,36 +635,6 @@ static int np_union_knob() { return knob("DEFT_NP_UNION", 0); }  // leaf tiles p
 static int plan_items_per_leader(const Stage1Params& p) { return (p.q_sh == 64 && p.Hkv % 2 == 0) ? -(p.Hkv / 2) : p.Hkv; }
 
 // Flatten plan: unit list (one workgroup) then one record per unit.
-// What the unit kernel's launch needs besides the arrays: LDS bytes, run-table capacity, forms (shared by launch_plan and the
-// fused step head, which runs the same code as a phase)
-struct UnitLaunch {
-    size_t lds;
-    int run_cap, qtab, par;
-};
-static int unit_launch_config(int NB, const PlanView& pv, UnitLaunch* out) {
-    constexpr size_t UNIT_LDS = 156 * 1024;
-    if (sizeof(int) * 4 * (size_t)NB > 144 * 1024) {
-        set_error("plan: %d blocks exceed the unit kernel's LDS", NB);
-        return DEFT_EUNSUPPORTED;
-    }
-    const int qtab = sizeof(int) * 8 * (size_t)NB <= 100 * 1024;
-    const size_t blk = (qtab ? 8 : 4) * (size_t)NB;
-    int64_t run_cap = pv.cap;
-    int par = !g_plan_serial;
-    if (par && sizeof(int) * (blk + 5 * (size_t)run_cap + 8) > UNIT_LDS) {
-        run_cap = ((int64_t)(UNIT_LDS / sizeof(int)) - (int64_t)blk - 8) / 5;
-        if (run_cap < 256) par = 0, run_cap = pv.cap;
-    }
-    if (par && g_plan_runcap > 0) run_cap = std::max(1, std::min((int)run_cap, g_plan_runcap));
-    if (!par)
-        while (sizeof(int) * (blk + 3 * (size_t)run_cap + 8) > UNIT_LDS && run_cap > 0) run_cap /= 2;
-    out->lds = sizeof(int) * (blk + (par ? 5 : 3) * (size_t)run_cap + 8);
-    out->run_cap = (int)run_cap;
-    out->qtab = qtab;
-    out->par = par;
-    return DEFT_OK;
-}
-
 static int launch_plan(const Stage1Params& p, int NB, const PlanView& pv, const AppendArgs& ap, hipStream_t stream,
                        const int32_t* dims = nullptr) {
     if (NB <= 0) return DEFT_OK;
@@ -1987,102 +1956,6 @@ int deft_tree_dev_build_md_ops(int n_nodes, int nq, int nqw, const int32_t* node
                                   max_block_len, nbp_cap, scratch, scratch_bytes, node_q, node_kv, node_q_len, node_kv_len,
                                   node_q_offset, node_kv_offset, block_q, block_q_cnts, block_q_offset, block_bitmasks, block_kv,
                                   block_lens, advance_loc, ops, PageWrite{page_table, page_stride, page_rows, page_cols}, stream);
-}
-
-
-// One decode step of a DeFT-Flatten session in front of its first layer: deft_tree_dev_build_md_ops (the block arrays) followed by
-// deft_flatten_build_plan_dims -- in THREE launches instead of five (step_head.h: the scan, the unit list, the record order and
-// the merge's row lists by one workgroup in one kernel; then the blocks' slots + masks and the records as before).  Same
-// arguments as the two calls, same bytes in every output.  Falls back to the two calls when the fused kernel's tables do not
-// fit its LDS (trees of thousands of blocks) or the plan has more than 4096 partial rows.
-int deft_tree_dev_build_flatten_step(int n_nodes, int nq, int nqw, const int32_t* node_start, int32_t* node_len, const int32_t* node_cap,
-                                     const uint64_t* refs, const int32_t* leaf_node, int32_t* slots, int max_q_len, int block_len,
-                                     int max_block_len, int nbp_cap, void* scratch, size_t scratch_bytes, int64_t* block_q,
-                                     int64_t* block_q_cnts, int64_t* block_q_offset, int64_t* block_bitmasks, int64_t* block_kv,
-                                     int64_t* block_lens, const int32_t* advance_loc, const int32_t* ops, int32_t* page_table,
-                                     int64_t page_stride, const int64_t* page_rows, const int64_t* page_cols, int NB, int P, int Hq,
-                                     int Hkv, int64_t q_stride_tok, int64_t q_stride_head, int64_t kv_stride_slot,
-                                     const int32_t* cache_loc, int n_new, int64_t new_stride_tok, void* plan, size_t plan_bytes,
-                                     void* stream) {
-    auto two_calls = [&]() {
-        int rc = deft_tree_dev_build_md_ops(n_nodes, nq, nqw, node_start, node_len, node_cap, refs, leaf_node, slots, max_q_len, block_len,
-                                            max_block_len, nbp_cap, scratch, scratch_bytes, nullptr, nullptr, nullptr, nullptr, nullptr,
-                                            nullptr, block_q, block_q_cnts, block_q_offset, block_bitmasks, block_kv, block_lens,
-                                            advance_loc, ops, page_table, page_stride, page_rows, page_cols, stream);
-        if (rc) return rc;
-        return deft_flatten_build_plan_dims(block_q, block_q_cnts, block_q_offset, block_bitmasks, block_kv, block_lens, NB, P,
-                                            static_cast<const int32_t*>(scratch), Hq, Hkv, q_stride_tok, q_stride_head, kv_stride_slot,
-                                            cache_loc, n_new, new_stride_tok, plan, plan_bytes, stream);
-    };
-    if (n_nodes <= 0 || nq < 0 || nqw < 1 || nbp_cap <= 0 || NB <= 0 || P <= 0 || !node_start || !node_len || !node_cap || !refs ||
-        !leaf_node || !slots || !scratch || !plan || !block_q || !block_q_cnts || !block_q_offset || !block_bitmasks || !block_kv ||
-        !block_lens || Hq <= 0 || Hkv <= 0 || Hq % Hkv || n_new < 0 ||
-        (page_table && (!advance_loc || !page_rows || !page_cols || page_stride <= 0)) || max_q_len < 1 || max_q_len > 63 ||
-        block_len < 1 || block_len > 1024 || (max_block_len < 1 && max_block_len != -1))
-        return two_calls();  // (they report what is wrong)
-    const PlanView pv = plan_view(plan, flatten_unit_cap(NB, Hq / Hkv), P);
-    size_t need = 0;
-    const TreeScratch sc = tree_scratch_view(scratch, n_nodes, nqw, nbp_cap, &need);
-    UnitLaunch ucfg;
-    if (plan_bytes < pv.bytes || scratch_bytes < need || P > QROWS_FUSED_MAX || unit_launch_config(NB, pv, &ucfg) != DEFT_OK)
-        return two_calls();
-    size_t scan_lds = 0;
-    if (n_nodes <= TREE_LDS_NODES) {
-        scan_lds = sizeof(int32_t) * 6 * ((size_t)n_nodes + 1);
-        if (nbp_cap <= TREE_LDS_BLOCKS) scan_lds += sizeof(int32_t) * ((size_t)nbp_cap + 1);
-    }
-    const size_t rows_lds = sizeof(int) * (2 * (size_t)QROWS_FUSED_MAX + 1);
-    const size_t dyn = std::max(std::max(scan_lds, ucfg.lds), rows_lds);
-    constexpr size_t HEAD_LDS = 142 * 1024;  // (next to ~17 KB of static LDS: the journal replay's tables)
-    if (dyn > HEAD_LDS) return two_calls();
-    int rc = raise_lds(reinterpret_cast<const void*>(&flatten_step_head_kernel), (int)HEAD_LDS, ATTR_STEP_HEAD, "flatten_step_head");
-    if (rc) return rc;
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    TreeDev t{n_nodes, nq, nqw, node_start, node_len, node_cap, reinterpret_cast<const unsigned long long*>(refs), leaf_node, slots};
-    TreeMdOut o{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, block_q, block_q_cnts, block_q_offset, block_bitmasks, block_kv, block_lens};
-    Stage1Params p{};
-    p.block_q = block_q;
-    p.block_q_cnts = block_q_cnts;
-    p.block_q_offset = block_q_offset;
-    p.block_bitmasks = block_bitmasks;
-    p.block_kv = block_kv;
-    p.block_lens = block_lens;
-    p.rows = P;
-    p.G = Hq / Hkv;
-    p.Hkv = Hkv;
-    p.q_st = q_stride_tok;
-    p.q_sh = q_stride_head;
-    p.kv_ss = kv_stride_slot;
-    const UnitList ul = unit_list(pv);
-    StepHeadArgs a{};
-    a.max_q_len = max_q_len;
-    a.block_len = block_len;
-    a.max_block_len = max_block_len;
-    a.nbp_cap = nbp_cap;
-    a.cache_loc = advance_loc;
-    a.ops = ops;
-    a.pw = PageWrite{page_table, page_stride, page_rows, page_cols};
-    a.NBc = NB;
-    a.G = p.G;
-    a.cap = (int)pv.cap;
-    a.Hkv_items = plan_items_per_leader(p);
-    a.slots = 2 * num_cus();
-    a.chunk_c = np_chunk_knob();
-    a.union_len = np_union_knob();
-    a.run_cap = ucfg.run_cap;
-    a.qtab = ucfg.qtab;
-    a.par = ucfg.par;
-    a.rows = (int)pv.rows;
-    hipLaunchKernelGGL(flatten_step_head_kernel, dim3(1), dim3(1024), dyn, st, t, sc, o, ul, pv.hdr, pv.row_q, pv.qoff, pv.qlist, pv.qinl, a);
-    rc = check_launch("flatten step head launch");
-    if (rc) return rc;
-    hipLaunchKernelGGL(tree_md_blocks_kernel, dim3((unsigned)nbp_cap), dim3(128), 0, st, t, sc, o, max_q_len, block_len);
-    rc = check_launch("tree blocks launch");
-    if (rc) return rc;
-    hipLaunchKernelGGL(flatten_records_kernel, dim3((unsigned)(pv.cap + 1)), dim3(128), 0, st, block_q, block_q_cnts, block_bitmasks,
-                       block_kv, block_lens, p.G, (int)p.rows, p.q_st, p.q_sh, p.kv_ss, ul, pv.hdr, pv.records, pv.row_q, cache_loc,
-                       cache_loc ? n_new : 0, new_stride_tok * 2);
-    return check_launch("flatten records launch");
 }
 
 }  // extern "C"

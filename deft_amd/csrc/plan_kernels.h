@@ -354,18 +354,18 @@ __device__ inline int union_group(int t, int NB, int ulen, int ucap, const int* 
 // tail shares a block with the next branch's head, so their lists go {a}, {a,b}, {b}, {b,c} ... -- are grouped, up
 // to union_len tiles and UNION_CAP queries, into ONE run over the union of their queries (per-slot masks keep a
 // query away from keys that are not on its path), so that one workgroup folds them and writes one partial per query.
-// (a device function: flatten_units_kernel is its launch of its own, flatten_step_head_kernel -- step_head.h -- runs it behind the
-//  metadata scan in the same workgroup; `smem` = the dynamic LDS)
-__device__ inline void flatten_units_body(const int64_t* block_q, const int64_t* block_q_cnts, const int64_t* block_q_offset,
-                                          int NBc, int G, int cap, const UnitList& ul, int32_t* hdr, int Hkv, int slots,
-                                          int chunk_c, int union_len, int run_cap, int qtab, int par, const int32_t* dims,
-                                          int32_t* row_q, int rows, char* smem) {
+__global__ __launch_bounds__(1024) void flatten_units_kernel(const int64_t* block_q, const int64_t* block_q_cnts,
+                                                            const int64_t* block_q_offset, int NBc, int G, int cap,
+                                                            UnitList ul, int32_t* hdr, int Hkv, int slots, int chunk_c,
+                                                            int union_len, int run_cap, int qtab, int par,
+                                                            const int32_t* dims, int32_t* row_q, int rows) {
     constexpr int np = 1;  // records in the tile-parallel order (leaders first); the only stage-1 form
     // NBc = block CAPACITY (sizes the tables); with `dims` (device-side metadata, tree_plan.h) the block count of this
     // step is read from the device, so that one captured launch serves every step of a structural epoch
     const int NB = dims ? min(dims[5], NBc) : NBc;
     if (dims)  // rows beyond this step's partial rows must read "dead" (the row lists are built over the capacity)
         for (int i = threadIdx.x; i < rows; i += blockDim.x) row_q[i] = -1;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
     int* sOpen = reinterpret_cast<int*>(smem);  // [NBc]
     int* sPass = sOpen + NBc;                   // [NBc]
     int* sCnt = sPass + NBc;                    // [NBc] block_q_cnts
@@ -591,63 +591,6 @@ __device__ inline void flatten_units_body(const int64_t* block_q, const int64_t*
     if (!np) return;
     // Phase 4: record order of the tile-parallel stage 1
     record_order_parallel(ul, rt, NR, rT0, rSp, sMeta, hdr, Hkv, G, slots, chunk_c);
-}
-
-__global__ __launch_bounds__(1024) void flatten_units_kernel(const int64_t* block_q, const int64_t* block_q_cnts,
-                                                            const int64_t* block_q_offset, int NBc, int G, int cap,
-                                                            UnitList ul, int32_t* hdr, int Hkv, int slots, int chunk_c,
-                                                            int union_len, int run_cap, int qtab, int par,
-                                                            const int32_t* dims, int32_t* row_q, int rows) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    flatten_units_body(block_q, block_q_cnts, block_q_offset, NBc, G, cap, ul, hdr, Hkv, slots, chunk_c, union_len, run_cap, qtab, par,
-                       dims, row_q, rows, smem);
-}
-
-// row_q of a Flatten plan from the UNIT list alone -- which partial rows are live, and whose: exactly what
-// flatten_records_kernel writes record by record (a chunk leader's rows carry their queries, follower tiles' rows are dead, a
-// union group parks each of its queries in the row of its first occurrence) -- so that the per-query row lists can be built by
-// the workgroup that made the units, without waiting for the records.  A thread per record.
-__device__ inline void flatten_rowq_body(const int64_t* block_q, const int64_t* block_q_cnts, int G, const UnitList& ul,
-                                         const int32_t* hdr, int32_t* row_q) {
-    // (the unit phase has just set every row to -1, so only records with LIVE rows write: chunk leaders, and the members of union
-    //  groups; a record's values are loaded together before any is stored -- a load behind a store that might alias it is a
-    //  dependent round trip, thirty-two of them per record otherwise)
-    const int R = hdr[0];
-    const int cap = (int)(ul.gq - ul.gn);  // arrays are `cap` apart
-    for (int r = threadIdx.x; r < R; r += blockDim.x) {
-        const int u = ul.perm[r];
-        const int aux = ul.aux[u];
-        const bool leader = ul.ch_n[r] > 0;
-        if (aux <= 0 && !leader) continue;
-        const int t = ul.src[u], ps = ul.pass[u], prow = ul.prow[u];
-        const int cnt = (int)block_q_cnts[t];
-        if (aux > 0) {
-            const int gid = aux - 1, un = ul.gn[gid];
-            int gr[UNION_CAP], gqv[UNION_CAP];
-#pragma unroll
-            for (int j2 = 0; j2 < UNION_CAP; ++j2) {
-                gr[j2] = j2 < un ? ul.grow[j2 * cap + gid] : -1;
-                gqv[j2] = j2 < un ? ul.gq[j2 * cap + gid] : -1;
-            }
-            for (int k = 0; k < cnt && k < MQ; ++k) {
-                int qlive = -1;
-#pragma unroll
-                for (int j2 = 0; j2 < UNION_CAP; ++j2)
-                    if (gr[j2] == prow + k) qlive = gqv[j2];
-                row_q[prow + k] = qlive;
-            }
-            continue;
-        }
-        // rows of this pass: queries qi with MQ ps <= qi G < MQ ps + nv
-        const int nv = min(MQ, cnt * G - MQ * ps);
-        const int lo = (MQ * ps + G - 1) / G, hi = (MQ * ps + nv - 1) / G;  // inclusive
-        int32_t vals[MQ];
-#pragma unroll
-        for (int i = 0; i < MQ; ++i) vals[i] = lo + i <= hi ? (int32_t)block_q[prow + lo + i] : -1;
-#pragma unroll
-        for (int i = 0; i < MQ; ++i)
-            if (lo + i <= hi) row_q[prow + lo + i] = vals[i];
-    }
 }
 
 // One workgroup of 128 threads per unit (+ the sentinel): pack its record.
@@ -1112,10 +1055,9 @@ __global__ __launch_bounds__(256) void qrows_fill_kernel(const int32_t* row_q, i
 // row_q is staged in LDS once, counted, scanned, and every wave then fills the lists of the queries q = wave, wave + 16, ...
 // up to the largest query that has a row.  Same qoff / qlist / qinl as the two kernels above, word for word.
 constexpr int QROWS_FUSED_MAX = 4096;
-// (a device function over LDS arrays the caller provides -- sRow[rows], sCnt[rows + 1] --: qrows_fused_kernel is its launch of its
-//  own, flatten_step_head_kernel, step_head.h, runs it as the last phase of a decode step's single-workgroup work)
-__device__ inline void qrows_fused_body(const int32_t* row_q, int rows, int32_t* qoff, int32_t* qlist, int32_t* qinl, int32_t* hdr,
-                                        int* sRow, int* sCnt) {
+__global__ __launch_bounds__(1024) void qrows_fused_kernel(const int32_t* row_q, int rows, int32_t* qoff, int32_t* qlist, int32_t* qinl,
+                                                           int32_t* hdr) {
+    __shared__ int sRow[QROWS_FUSED_MAX], sCnt[QROWS_FUSED_MAX + 1];
     __shared__ int sWave[16], sQmax;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) sQmax = -1;
@@ -1178,12 +1120,6 @@ __device__ inline void qrows_fused_body(const int32_t* row_q, int rows, int32_t*
             found += __popcll(mask);
         }
     }
-}
-
-__global__ __launch_bounds__(1024) void qrows_fused_kernel(const int32_t* row_q, int rows, int32_t* qoff, int32_t* qlist, int32_t* qinl,
-                                                           int32_t* hdr) {
-    __shared__ int sRow[QROWS_FUSED_MAX], sCnt[QROWS_FUSED_MAX + 1];
-    qrows_fused_body(row_q, rows, qoff, qlist, qinl, hdr, sRow, sCnt);
 }
 
 }  // namespace deft

@@ -219,26 +219,6 @@ __device__ inline int refs_count(const unsigned long long* r, int nqw) {
     return c;
 }
 
-// k-th (0-based) set bit of a bit set, or -1
-__device__ inline int nth_set_bit(const unsigned long long* u, int nqw, int k) {
-    for (int w = 0; w < nqw; ++w) {
-        const int c = __popcll(u[w]);
-        if (k < c) {
-            unsigned long long x = u[w];
-            for (int j = 0; j < k; ++j) x &= x - 1;
-            return 64 * w + __ffsll((long long)x) - 1;
-        }
-        k -= c;
-    }
-    return -1;
-}
-// number of set bits of u below position q
-__device__ inline int rank_below(const unsigned long long* u, int q) {
-    int c = 0;
-    for (int w = 0; w < (q >> 6); ++w) c += __popcll(u[w]);
-    return c + __popcll(u[q >> 6] & ((1ull << (q & 63)) - 1ull));
-}
-
 // The page-table rows of a step's new tokens (ReqToTokenPool.req_to_token[row[r], col[r]] = cache_loc[r], what TreeCache.alloc
 // writes with one index_put, tree_cache.py:270-283): folded into the advance -- one launch fewer per captured step.
 struct PageWrite {
@@ -255,13 +235,12 @@ struct PageWrite {
 constexpr int TREE_LDS_NODES = 4096;
 constexpr int TREE_LDS_BLOCKS = 8192;
 
-// (a device function: tree_md_scan_kernel below is its launch of its own, flatten_step_head_kernel -- step_head.h -- runs it as the
-//  first phase of a decode step's single-workgroup work; `smem` = the dynamic LDS, `blkq` (nullable) = see the end)
-__device__ inline void tree_md_scan_body(const TreeDev& t, const TreeScratch& s, int max_q_len, int block_len, int max_block_len,
-                                         int nbp_cap, const int32_t* cache_loc, const int32_t* ops, const PageWrite& pw, char* smem,
-                                         const TreeMdOut* blkq) {
+__global__ __launch_bounds__(1024) void tree_md_scan_kernel(TreeDev t, TreeScratch s, int max_q_len, int block_len,
+                                                            int max_block_len, int nbp_cap, const int32_t* cache_loc,
+                                                            const int32_t* ops, PageWrite pw) {
     __shared__ int sWave[16];
     __shared__ int sCarry;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int n = t.n, nqw = t.nqw;
     const int tid = threadIdx.x;
     if (ops && ops[0] > 0) {  // the journal of this step's absorbed changes first (uniform branch), then the step's new slots
@@ -388,31 +367,26 @@ __device__ inline void tree_md_scan_body(const TreeDev& t, const TreeScratch& s,
         s.dims[7] = s.b_eoff[nbp] * block_len;
         s.dims[8] = nbp;
     }
-    // The query lists of the emitted blocks -- block_q, block_q_cnts, block_q_offset, block_lens: what the per-step plan's unit
-    // phase reads -- written HERE when the caller goes on in the same workgroup (tree_md_blocks_kernel writes the same values once
-    // more, with the slots and masks): a wave per physical block, lane k takes the k-th query of the block's union.
-    if (blkq) {
-        const int lane = tid & 63, wave = tid >> 6;
-        for (int b = wave; b < nbp; b += 16) {
-            const unsigned long long* uni = s.b_union + (size_t)b * nqw;
-            const int nqs = bcount(b), e0 = s.b_eoff[b], p0 = s.b_poff[b];
-            const int cur_len = min(block_len, total - b * block_len);
-            for (int k = lane; k < nqs; k += 64) blkq->block_q[p0 + k] = nth_set_bit(uni, nqw, k);
-            const int chunks = (nqs + max_q_len - 1) / max_q_len;
-            for (int c = lane; c < chunks; c += 64) {
-                blkq->block_q_cnts[e0 + c] = min(max_q_len, nqs - c * max_q_len);
-                blkq->block_q_offset[e0 + c] = p0 + c * max_q_len;
-                blkq->block_lens[e0 + c] = cur_len;
-            }
-        }
-    }
 }
 
-__global__ __launch_bounds__(1024) void tree_md_scan_kernel(TreeDev t, TreeScratch s, int max_q_len, int block_len,
-                                                            int max_block_len, int nbp_cap, const int32_t* cache_loc,
-                                                            const int32_t* ops, PageWrite pw) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    tree_md_scan_body(t, s, max_q_len, block_len, max_block_len, nbp_cap, cache_loc, ops, pw, smem, nullptr);
+// k-th (0-based) set bit of a bit set, or -1
+__device__ inline int nth_set_bit(const unsigned long long* u, int nqw, int k) {
+    for (int w = 0; w < nqw; ++w) {
+        const int c = __popcll(u[w]);
+        if (k < c) {
+            unsigned long long x = u[w];
+            for (int j = 0; j < k; ++j) x &= x - 1;
+            return 64 * w + __ffsll((long long)x) - 1;
+        }
+        k -= c;
+    }
+    return -1;
+}
+// number of set bits of u below position q
+__device__ inline int rank_below(const unsigned long long* u, int q) {
+    int c = 0;
+    for (int w = 0; w < (q >> 6); ++w) c += __popcll(u[w]);
+    return c + __popcll(u[q >> 6] & ((1ull << (q & 63)) - 1ull));
 }
 
 // The masks of a block's positions depend on the position's NODE only (bit = rank of a leaf of the node among the block's

@@ -31,9 +31,6 @@ from .tree_cache import BLOCK_CONFIG, TreeCache, _DeviceTree, _FIELDS, _ptr
 
 __all__ = ["DecodeSession", "FlattenDecodeSession"]
 
-# A/B switch (tests, tools): False = a DeFT-Flatten step's metadata and plan by the two calls of five launches, as in round 3
-FUSED_STEP_HEAD = True
-
 
 class DecodeSession:
     def __init__(self, tree: TreeCache, num_heads: int, num_kv_heads: int, head_dim: int, layers: int,
@@ -139,30 +136,18 @@ class DecodeSession:
         # (the append of this step's slots to the device tree rides in the first metadata kernel)
         # (only the six arrays this mode's operator reads are written: the kernel of the other group is not launched)
         wanted = _FIELDS[6:] if self.mode == "flatten" else _FIELDS[:6]
+        # (first the journal of changes the epoch absorbed since the last step -- {0} when there are none --, then the advance)
+        check(lib.deft_tree_dev_build_md_ops(*dt._tree_args(), mq, bl, mbl, dt.nbp_cap, dt.scratch.data_ptr(), dt.scratch_bytes,
+                                             *[self.md_ptrs[k] if k in wanted else None for k in _FIELDS],
+                                             self.cache_loc.data_ptr() if advance else None, self.ops.data_ptr(),
+                                             table.data_ptr() if fold else None, table.stride(0) if fold else 0,
+                                             self.idx[0].data_ptr() if fold else None, self.idx[1].data_ptr() if fold else None, stream),
+              "deft_tree_dev_build_md_ops")
         Hq, Hkv, D = self.Hq, self.Hkv, self.D
         q0, k0, _ = self.qkv(0)
         kv0 = self.pool.kv_data[0]
         v_off = kv0.stride(1) * 2
-        adv = self.cache_loc.data_ptr() if advance else None
-        page = (table.data_ptr() if fold else None, table.stride(0) if fold else 0,
-                self.idx[0].data_ptr() if fold else None, self.idx[1].data_ptr() if fold else None)
-        if self.mode == "flatten" and FUSED_STEP_HEAD:
-            # metadata + plan in three launches: scan / units / record order / row lists by ONE single-workgroup kernel, then the
-            # blocks' slots + masks and the records (deft_amd/csrc/step_head.h)
-            mdl = [self.md_ptrs[k] for k in ("block_q", "block_q_cnts", "block_q_offset", "block_bitmasks", "block_kv", "block_lens")]
-            check(lib.deft_tree_dev_build_flatten_step(*dt._tree_args(), mq, bl, mbl, dt.nbp_cap, dt.scratch.data_ptr(), dt.scratch_bytes,
-                                                       *mdl, adv, self.ops.data_ptr(), *page, self.NB, self.P, Hq, Hkv, q0.stride(0), D,
-                                                       kv0.stride(0), self.cache_loc.data_ptr(), self.nq, k0.stride(0),
-                                                       self.plan.data_ptr(), self.plan_bytes, stream), "deft_tree_dev_build_flatten_step")
-            fn, tail = lib.deft_flatten_decode_append_f16, (self.NB, self.P, self.nq, Hq, Hkv, D, 1.0 / (D ** 0.5))
-        else:
-            # (first the journal of changes the epoch absorbed since the last step -- {0} when there are none --, then the advance)
-            check(lib.deft_tree_dev_build_md_ops(*dt._tree_args(), mq, bl, mbl, dt.nbp_cap, dt.scratch.data_ptr(), dt.scratch_bytes,
-                                                 *[self.md_ptrs[k] if k in wanted else None for k in _FIELDS],
-                                                 adv, self.ops.data_ptr(), *page, stream), "deft_tree_dev_build_md_ops")
-        if self.mode == "flatten" and FUSED_STEP_HEAD:
-            pass
-        elif self.mode == "flatten":
+        if self.mode == "flatten":
             mdl = [self.md_ptrs[k] for k in ("block_q", "block_q_cnts", "block_q_offset", "block_bitmasks", "block_kv", "block_lens")]
             check(lib.deft_flatten_build_plan_dims(*mdl, self.NB, self.P, dt.scratch.data_ptr(), Hq, Hkv, q0.stride(0), D,
                                                    kv0.stride(0), self.cache_loc.data_ptr(), self.nq, k0.stride(0),

@@ -452,22 +452,6 @@ int deft_tree_dev_build_md_ops(int n_nodes, int nq, int nqw, const int32_t* node
                                int32_t* page_table /* nullable */, int64_t page_stride, const int64_t* page_rows,
                                const int64_t* page_cols, void* stream);
 
-/* deft_tree_dev_build_md_ops (block arrays only) + deft_flatten_build_plan_dims as ONE call of three launches instead of five: what a
- * captured DeFT-Flatten decode step runs in front of its first layer.  The scan, the plan's unit list and record order and the
- * merge's per-query row lists are ONE single-workgroup kernel (they never needed the two wide kernels in between: csrc/step_head.h),
- * followed by the blocks' slots / masks and the plan records.  Arguments = those of the two calls (`advance_loc`: the slots the device
- * tree appends, null when its image already holds them; `cache_loc` / `n_new`: the step's new rows as the plan flags them); every
- * output holds the same bytes.  Falls back to the two calls by itself where the fused kernel does not fit. */
-int deft_tree_dev_build_flatten_step(int n_nodes, int nq, int nqw, const int32_t* node_start, int32_t* node_len, const int32_t* node_cap,
-                                     const uint64_t* refs, const int32_t* leaf_node, int32_t* slots, int max_q_len, int block_len,
-                                     int max_block_len, int nbp_cap, void* scratch, size_t scratch_bytes, int64_t* block_q,
-                                     int64_t* block_q_cnts, int64_t* block_q_offset, int64_t* block_bitmasks, int64_t* block_kv,
-                                     int64_t* block_lens, const int32_t* advance_loc /* nullable */, const int32_t* ops /* nullable */,
-                                     int32_t* page_table /* nullable */, int64_t page_stride, const int64_t* page_rows,
-                                     const int64_t* page_cols, int NB, int P, int Hq, int Hkv, int64_t q_stride_tok,
-                                     int64_t q_stride_head, int64_t kv_stride_slot, const int32_t* cache_loc /* nullable */, int n_new,
-                                     int64_t new_stride_tok, void* plan, size_t plan_bytes, void* stream);
-
 #if defined(__GNUC__) || defined(__clang__)
 #pragma GCC visibility pop
 #endif

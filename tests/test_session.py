@@ -230,71 +230,3 @@ def test_session_head_dim_64_and_lazy_capture(capture_after):
     assert sess.captures == {1: 4, 3: 1, "auto": 2}[capture_after]
     both_steps(6)  # ... and the last epoch lasts: everyone captures it
     assert sess.captures == {1: 4, 3: 2, "auto": 3}[capture_after]
-
-
-@pytest.mark.parametrize("geom,width", [((8, 2, 128), 6), ((4, 4, 128), 40), ((8, 8, 128), 9)])
-def test_fused_step_head_builds_the_same_plan(geom, width):
-    """A DeFT-Flatten step's metadata + plan in three launches (deft_tree_dev_build_flatten_step: scan, units, record order and the
-    merge's row lists by one single-workgroup kernel) against the five launches of deft_tree_dev_build_md_ops +
-    deft_flatten_build_plan_dims: every byte of the TreeMetadata buffer and of the plan, and the outputs, equal at every step --
-    GQA passes, a node of more than 32 queries, union groups of leaf tiles; through a cut / branch and speculative-decoding merges."""
-    import deft_amd.session as sm
-
-    Hq, Hkv, D = geom
-    layers, prefix = 2, 600
-
-    class Zeroed(deft_amd.DecodeSession):  # buffers start from zeros, so that bytes no kernel writes compare equal too
-        def _epoch_setup(self):
-            up = super()._epoch_setup()
-            self.plan.zero_()
-            self.dt.out.zero_()
-            return up
-
-    g = torch.Generator(device="cuda").manual_seed(29)
-    kv_init = torch.randn((layers, 4096, 2, Hkv, D), dtype=torch.float16, device="cuda", generator=g)
-    (ta, pa), (tb, pb) = [_mk(Hkv, D, layers, prefix, width, 4096) for _ in range(2)]
-    for p in (pa, pb):
-        p._storage.copy_(kv_init)
-    cap = 64
-    q = torch.randn((layers, cap, Hq * D), dtype=torch.float16, device="cuda", generator=g)
-    k = torch.randn((layers, cap, Hkv * D), dtype=torch.float16, device="cuda", generator=g)
-    v = torch.randn((layers, cap, Hkv * D), dtype=torch.float16, device="cuda", generator=g)
-    nq_now = [width]
-    mk = lambda t: Zeroed(t, Hq, Hkv, D, layers, lambda l: (q[l, : nq_now[0]], k[l, : nq_now[0]], v[l, : nq_now[0]]), use_graph=False)
-    sa, sb = mk(ta), mk(tb)
-
-    def step():
-        for tree in (ta, tb):
-            for leaf in tree.leaves.values():
-                leaf.append_token(7)
-        nq_now[0] = len(ta.leaves)
-        outs = []
-        for fused, sess in ((True, sa), (False, sb)):
-            sm.FUSED_STEP_HEAD = fused
-            try:
-                outs.append([o.clone() for o in sess.step()])
-            finally:
-                sm.FUSED_STEP_HEAD = True
-        torch.cuda.synchronize()
-        assert sa.dt.dims()[9] == 0 and sb.dt.dims()[9] == 0
-        assert torch.equal(sa.dt.out, sb.dt.out), "TreeMetadata bytes differ"
-        assert torch.equal(sa.plan, sb.plan), "plan bytes differ"
-        for l in range(layers):
-            assert torch.equal(outs[0][l], outs[1][l])
-
-    for _ in range(12):
-        step()
-    for tree in (ta, tb):
-        lv = sorted(tree.leaves.values(), key=lambda n: n.id)
-        tree.cut(lv[1])
-        tree.branch(lv[0], 3)
-    for _ in range(6):
-        step()
-    for _ in range(4):  # speculative-decoding steps: merges into the root and resets ride in the journal of the fused kernel too
-        for tree in (ta, tb):
-            lv = sorted(tree.leaves.values(), key=lambda n: n.id)
-            before = len(tree.root.kv_indices)
-            for lf in lv[:2]:
-                tree.merge_nodes(tree.root, lf, pruneB_flag=False)
-            tree.reset_nodes_KV(lv, len(tree.root.kv_indices) - before)
-        step()

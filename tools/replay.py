@@ -33,12 +33,8 @@ ap.add_argument("--beam", default=None, metavar="WIDTH,DEPTH,LEN",
                 help="reasoning: the shipped templates' shape instead of the ToT-50 tree -- the kept node branches into WIDTH candidates "
                      "every LEN steps, DEPTH levels (deft_amd.templates.synthetic_beam_template)")
 ap.add_argument("--capture-after", default="auto", help="DecodeSession(capture_after=): 1, 2, ... or auto")
-ap.add_argument("--unfused-head", action="store_true", help="A/B: the session's metadata + plan by five launches (round 3) instead of three")
 ap.add_argument("--out", default=None)
 a = ap.parse_args()
-if a.unfused_head:
-    import deft_amd.session as _sm
-    _sm.FUSED_STEP_HEAD = False
 if a.host_metadata:
     import deft_amd.tree_cache as _tc
     _tc.DEVICE_METADATA = False
