@@ -293,7 +293,6 @@ __global__ __launch_bounds__(256, 2) void stage1_kernel(Stage1Params p) {
 #include "merge.h"
 #include "stage1_np.h"
 #include "prefill.h"
-#include "prefill_pp.h"
 namespace deft {
 
 // ---------------------------------------------------------------------------
@@ -545,8 +544,7 @@ static int num_cus() {
     return d.cus;
 }
 enum : unsigned { ATTR_NP = 4,  // (bits 0-1, 8-11: the head_dim 64 / 32 / 16 kernels)
-                  ATTR_UNITS = 8, ATTR_NODE_UNITS = 16, ATTR_PREFILL = 32, ATTR_TREE = 64, ATTR_NP_ROPE = 128, ATTR_NP_T = 8192, ATTR_NP_ROPE_T = 16384, ATTR_NP_HD2 = 32768, ATTR_NP_HD2_T = 65536, ATTR_PREFILL_PP = 1u << 17 };
-constexpr int PREFILL_PP_DEFAULT = 0;  // (which prefill kernel the shipped library launches)
+                  ATTR_UNITS = 8, ATTR_NODE_UNITS = 16, ATTR_PREFILL = 32, ATTR_TREE = 64, ATTR_NP_ROPE = 128, ATTR_NP_T = 8192, ATTR_NP_ROPE_T = 16384, ATTR_NP_HD2 = 32768, ATTR_NP_HD2_T = 65536 };
 static int raise_lds(const void* fn, int bytes, unsigned bit, const char* what) {  // idempotent; races are harmless
     DeviceState& d = dev_state();
     if (d.attrs & bit) return DEFT_OK;
@@ -1792,14 +1790,6 @@ extern "C" int deft_prefill_f16(const void* q, int64_t q_stride_tok, int64_t q_s
         return DEFT_EINVAL;
     }
     const dim3 grid((unsigned)((int64_t)p.nblk * Hq * batch));
-    // The ping-pong form (prefill_pp.h: the two waves of a SIMD half a tile out of phase) -- experiments build: DEFT_PREFILL_PP=0 the
-    // in-phase kernel
-    if (knob("DEFT_PREFILL_PP", PREFILL_PP_DEFAULT)) {
-        const int rc = raise_lds(reinterpret_cast<const void*>(&prefill_pp_kernel<128>), PrefillSmem<128>::BYTES, ATTR_PREFILL_PP, "prefill_pp");
-        if (rc) return rc;
-        hipLaunchKernelGGL((prefill_pp_kernel<128>), grid, dim3(512), PrefillSmem<128>::BYTES, static_cast<hipStream_t>(stream), p);
-        return check_launch("prefill (ping-pong) launch");
-    }
     hipLaunchKernelGGL((prefill_kernel<128>), grid, dim3(512), PrefillSmem<128>::BYTES, static_cast<hipStream_t>(stream), p);
     return check_launch("prefill launch");
 }
