@@ -98,6 +98,10 @@ __global__ __launch_bounds__(512, 1) void prefill_kernel(PrefillParams p) {
 
     const char* kbase = reinterpret_cast<const char*>(p.k + start * p.k_st + (int64_t)kvh * p.k_sh);
     const char* vbase = reinterpret_cast<const char*>(p.v + start * p.v_st + (int64_t)kvh * p.v_sh);
+    // (round 4, tools/prefill_phases.py: the CU's request path takes the workgroup's 64 request instructions one wave at a time and
+    //  the older half of the workgroup wins the arbitration -- waves 0-3 are through their eight in 0.43 us, waves 4-7 in 1.13 us,
+    //  and the older half then waits 1.24 us per tile at the barrier.  Dealing the older half 5 .. 8 of every 8 pieces instead of 4
+    //  moves that wait to the other half and changes nothing: 979 / 969 / 960 / 966 / 967 TFLOP/s at 16k tokens for 4 .. 8.)
     auto issue_tile = [&](int t, int stg) {  // 4 K + 4 V instructions per wave: keys 16w + 4i + dkey of tile t
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -141,12 +145,29 @@ __global__ __launch_bounds__(512, 1) void prefill_kernel(PrefillParams p) {
 
 #ifdef DEFT_EXPERIMENTS
     if (p.dbg) t_loop = wall_clock64();
+    // per-phase wall-clock sums of this wave over its tiles (tools/prefill_phases.py): 0 wait + barrier | 1 next tile's requests |
+    // 2 QK^T | 3 softmax | 4 PV
+    unsigned long long ph[5] = {0, 0, 0, 0, 0}, ph_t = 0;
+    int ph_tiles = 0;
+#define PF_PHASE(k)                                      \
+    if (p.dbg) {                                         \
+        const unsigned long long now_ = wall_clock64(); \
+        ph[k] += now_ - ph_t;                            \
+        ph_t = now_;                                     \
+    }
+#else
+#define PF_PHASE(k)
 #endif
     for (int t = 0; t < ntiles; ++t) {
         const int stg = t & 1;
+#ifdef DEFT_EXPERIMENTS
+        if (p.dbg) ph_t = wall_clock64();
+#endif
         wait_vm<0>();   // tile t landed (this wave's part)
         lds_barrier();  // ... everyone's part; and every wave is done with tile t-1's stage
+        PF_PHASE(0);
         if (t + 1 < ntiles) issue_tile(t + 1, stg ^ 1);
+        PF_PHASE(1);
         const int key0 = TILE * t;
         if (key0 > q_lo + 31) continue;  // the whole tile lies above this wave's queries (wave-uniform)
         const bool diag = key0 + TILE - 1 > q_lo;  // some key of the tile is beyond some query of the wave
@@ -175,6 +196,10 @@ __global__ __launch_bounds__(512, 1) void prefill_kernel(PrefillParams p) {
             for (int kb = 0; kb < 4; ++kb) acc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks & 1][kb], qf[ks], acc[kb], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
+        PF_PHASE(2);
+#ifdef DEFT_EXPERIMENTS
+        ++ph_tiles;
+#endif
         // ---- one online-softmax step per tile (one rescale of O per 128 keys) ----------------------------------
         // (VALU-bound: per score one max, one fma feeding exp2, one conversion and half a dot2 -- the scale rides in the
         //  fma; the row sum is a chain of fp32 adds, see below)
@@ -225,6 +250,7 @@ __global__ __launch_bounds__(512, 1) void prefill_kernel(PrefillParams p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[bk][r] *= alpha;  // (packed by the compiler; 64 single multiplies measured the same)
         }
+        PF_PHASE(3);
         // ---- O^T += V^T P^T: 32 MFMAs on four independent accumulators -------------------------------------------
         const int vstage = SM::V_OFF + stg * SM::STAGE;
         int vfrag[4];
@@ -257,10 +283,18 @@ __global__ __launch_bounds__(512, 1) void prefill_kernel(PrefillParams p) {
                 o[bk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[g & 1][bk].h8, pb[g >> 1][g & 1], o[bk], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
+        PF_PHASE(4);
     }
     wait_vm<0>();
 #ifdef DEFT_EXPERIMENTS
     if (p.dbg) t_epi = wall_clock64();
+    if (p.dbg && l == 0 && L < 1024) {  // [8192 x 8 workgroup stamps][1024 workgroups][8 waves][8]
+        unsigned long long* d2 = p.dbg + (int64_t)8192 * 8 + ((int64_t)L * 8 + w) * 8;
+#pragma unroll
+        for (int k2 = 0; k2 < 5; ++k2) d2[k2] = ph[k2];
+        d2[5] = (unsigned long long)ph_tiles;
+        d2[6] = (unsigned long long)ntiles;
+    }
 #endif
     // ---- normalise and store: lane (c, h) holds d = 32 bk + 8 j + 4 h + (0..3) of query c ---------------------
     if (qi < len) {
@@ -289,5 +323,6 @@ __global__ __launch_bounds__(512, 1) void prefill_kernel(PrefillParams p) {
     }
 #endif
 }
+#undef PF_PHASE
 
 }  // namespace deft
