@@ -220,6 +220,47 @@ def test_unsupported_head_dim_fails_loudly():
     assert rc == -2  # DEFT_EUNSUPPORTED
 
 
+@pytest.mark.parametrize("geom", [(8, 2, 128), (4, 4, 64)])
+def test_any_scale_through_the_c_abi(geom):
+    """The C ABI takes `scale` as a plain float.  The kernels apply |scale| inside the exp2 argument and flip the sign of the Q
+    fragments for a negative one: attention(q, scale = -s) must equal attention(-q, scale = +s) bit for bit (negating fp16 is exact),
+    and scale = 0 must give the uniform average of the values each query sees -- not NaN from -inf x 0."""
+    Hq, Hkv, D = geom
+    name = "multilevel"
+    tree = product_tree(name, device="cuda", heads=(Hkv, D))
+    md = product_metadata(name, tree)
+    q_np, kv_np = seeded_inputs(name, geom, md.query_num)
+    tree.token_to_kv_pool.kv_data[0].copy_(torch.from_numpy(kv_np))
+    pool = tree.token_to_kv_pool
+    kb, vb = pool.get_key_buffer(0), pool.get_value_buffer(0)
+    q = torch.from_numpy(q_np).cuda()
+    nq = md.query_num
+    NB, P = md.block_q_cnts.shape[0], md.block_q.shape[0]
+    ws = torch.empty(deft_amd.lib.deft_flatten_workspace_bytes(NB, P, nq, Hq, Hkv, D), dtype=torch.uint8, device="cuda")
+
+    def run(qt, scale):
+        o = torch.full((nq, Hq, D), float("nan"), dtype=torch.float16, device="cuda")
+        rc = deft_amd.lib.deft_flatten_decode_f16(
+            qt.data_ptr(), qt.stride(0), qt.stride(1), kb.data_ptr(), vb.data_ptr(), kb.stride(0), kb.stride(1), o.data_ptr(), o.stride(0),
+            o.stride(1), md.block_q.data_ptr(), md.block_q_cnts.data_ptr(), md.block_q_offset.data_ptr(), md.block_bitmasks.data_ptr(),
+            md.block_kv.data_ptr(), md.block_lens.data_ptr(), NB, P, nq, Hq, Hkv, D, scale, None, ws.data_ptr(), ws.numel(),
+            torch.cuda.current_stream().cuda_stream)
+        assert rc == 0, deft_amd.lib.deft_last_error()
+        torch.cuda.synchronize()
+        return o
+
+    s = D ** -0.5
+    assert torch.equal(run(q, -s), run(-q, s))
+    o0 = run(q, 0.0)
+    assert torch.isfinite(o0).all()
+    paths = leaf_paths(oracle_tree(name))
+    kv = torch.from_numpy(kv_np).float()
+    for qi in (0, nq - 1):
+        want = kv[paths[qi], 1].mean(dim=0)  # [Hkv, D]: every key of the path weighs the same
+        got = o0[qi].float().cpu().view(Hkv, Hq // Hkv, D)
+        assert (got - want[:, None, :]).abs().max() < 2e-3
+
+
 def _flatten_args(md):
     return (md.block_len, md.block_q, md.block_q_cnts, md.block_q_offset, md.block_bitmasks, md.block_kv, md.block_lens)
 
