@@ -180,7 +180,26 @@ static constexpr SoftmaxOps SM_OPS = make_softmax_ops();
 // maxima from piece p_max (three pieces), the chain one link a piece behind them, exponentials spread over [p_exp, p_end]; a
 // conversion of 16-key step st's scores not before piece 32 + 10 (st + 1); 72 = behind the step.  arg = pair.
 constexpr int FS_PIECES = 72;
-constexpr SoftmaxOps make_block_ops(int p_max, int p_exp, int p_end) {
+constexpr void add_exp_ops(SoftmaxOps& o, int pair_lo, int pair_hi, int p0, int p1, bool rolling) {
+    const int np = pair_hi - pair_lo;
+    for (int g = 0; g < np + 3; ++g) {
+        const int pc = p0 + g * (p1 - p0) / (np + 2);
+        if (g < np) {
+            o.add(3, pair_lo + g), o.piece[o.n - 1] = pc;
+            o.add(4, pair_lo + g), o.piece[o.n - 1] = pc;
+        }
+        if (g >= 1 && g - 1 < np) {
+            o.add(5, pair_lo + g - 1), o.piece[o.n - 1] = pc;
+            o.add(6, pair_lo + g - 1), o.piece[o.n - 1] = pc;
+        }
+        if (g >= 3) {
+            const int pair = pair_lo + g - 3, st = pair >> 2, lo = rolling ? 32 + 10 * (st + 1) : 0;
+            o.add(7, pair);
+            o.piece[o.n - 1] = pc < lo ? lo : pc;
+        }
+    }
+}
+constexpr SoftmaxOps make_block_ops(int p_max, int pair_hi, int p_exp, int p_end) {
     SoftmaxOps o;
     for (int q = 0; q < 16; ++q) {
         o.add(0, q);
@@ -190,26 +209,20 @@ constexpr SoftmaxOps make_block_ops(int p_max, int p_exp, int p_end) {
         o.add(t, 0);
         o.piece[o.n - 1] = p_max + 3 + (t - 10);
     }
-    for (int g = 0; g < 19; ++g) {
-        const int pc = p_exp + g * (p_end - p_exp) / 18;
-        if (g < 16) {
-            o.add(3, g), o.piece[o.n - 1] = pc;
-            o.add(4, g), o.piece[o.n - 1] = pc;
-        }
-        if (g >= 1 && g - 1 < 16) {
-            o.add(5, g - 1), o.piece[o.n - 1] = pc;
-            o.add(6, g - 1), o.piece[o.n - 1] = pc;
-        }
-        if (g >= 3) {
-            const int pair = g - 3, st = pair >> 2, lo = 32 + 10 * (st + 1);
-            o.add(7, pair);
-            o.piece[o.n - 1] = pc < lo ? lo : pc;
-        }
-    }
+    add_exp_ops(o, 0, pair_hi, p_exp, p_end, true);
     return o;
 }
-static constexpr SoftmaxOps FS_OPS_A = make_block_ops(17, 27, 60);
-static constexpr SoftmaxOps FS_OPS_B = make_block_ops(33, 43, 71);
+constexpr SoftmaxOps make_tail_ops(int pair_lo, int p0, int p1) {
+    SoftmaxOps o;
+    add_exp_ops(o, pair_lo, 16, p0, p1, false);
+    return o;
+}
+// Block B's last four pairs (the scores of its last 16 keys) are exponentiated in the NEXT step's pieces 0-15 -- S^T of block B is
+// only overwritten from piece 16 on, their conversions could not be placed before piece 72 anyway, and those pieces carry little else
+constexpr int FS_TAIL_PAIR = 12;
+static constexpr SoftmaxOps FS_OPS_A = make_block_ops(17, 16, 27, 60);
+static constexpr SoftmaxOps FS_OPS_B = make_block_ops(33, FS_TAIL_PAIR, 43, 71);
+static constexpr SoftmaxOps FS_OPS_BT = make_tail_ops(FS_TAIL_PAIR, 0, 15);
 
 }  // namespace pf64
 
@@ -526,7 +539,8 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(PrefillParams p) {
     //      soon as its S^T is complete, block B's behind piece 32: the ~210 softmax instructions are spread over 56 MFMAs instead of
     //      40 (half Q's MFMAs had nothing beside them, half P's pieces took 49 cycles).  The K fragments are read twice for that (once
     //      per block), the V^T fragments once.
-    auto full_step = [&](int u, float (&alpha)[2]) __attribute__((always_inline)) {
+    auto full_step = [&](auto tail_in, int u, float (&alpha)[2]) __attribute__((always_inline)) {
+        constexpr bool TAIL_IN = decltype(tail_in)::value;  // the previous step was a full step: block B's last pairs are still to do
         const int kstage = SM::K_OFF + (u & (SM::NS - 1)) * SM::STAGE;
         const int vstage = SM::V_OFF + ((u - 1) & (SM::NS - 1)) * SM::STAGE;
         constexpr int PDK = 5, PDV = 3;
@@ -545,60 +559,47 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(PrefillParams p) {
         };
         float mx2[2][2] = {{-INFINITY, -INFINITY}, {-INFINITY, -INFINITY}}, m_new[2] = {mref[0], mref[1]};
         float tv[2][32], ev[2][32], ch0[2] = {0.f, 0.f}, ch1[2] = {0.f, 0.f};
+        // Every softmax instruction is its own asm volatile statement: the statements keep their source order among themselves and
+        // among the MFMAs, which is the whole point -- plain arithmetic is placed by the selection DAG wherever it likes between its
+        // operands and its users (fences do not bind it), and what came out had five MFMAs back to back here and twenty VALU
+        // instructions there: SQ_VALU_MFMA_COEXEC_CYCLES 35 % of the MFMA time.  The registers are still the compiler's.  (An asm
+        // statement that reads what the asm statement right in front of it wrote gets an s_nop 0 from the hazard recogniser; the
+        // order below never does that.)
+        float negm[2] = {-mref[0], -mref[1]};
         auto sm_op = [&](auto xc, auto tc, auto ac) __attribute__((always_inline)) {
             constexpr int x = decltype(xc)::value, type = decltype(tc)::value, a = decltype(ac)::value;
             constexpr int e0 = 2 * a, e1 = 2 * a + 1;  // the pair's scores: sc[x][e >> 4][e & 15]
-            if constexpr (type == 0) mx2[x][a & 1] = fmaxf(fmaxf(mx2[x][a & 1], sc[x][e0 >> 4][e0 & 15]), sc[x][e1 >> 4][e1 & 15]);
-            else if constexpr (type == 10) {
-                asm volatile("" : "+v"(mx2[x][0]), "+v"(mx2[x][1]));
-                ch0[x] = fmaxf(mx2[x][0], mx2[x][1]);
-            } else if constexpr (type == 11) {
-                asm volatile("" : "+v"(ch0[x]));
-                const auto r2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(ch0[x]), __float_as_uint(ch0[x]), false, false);
-                ch0[x] = __uint_as_float(r2[0]), ch1[x] = __uint_as_float(r2[1]);
-            } else if constexpr (type == 12) {
-                asm volatile("" : "+v"(ch0[x]), "+v"(ch1[x]));
-                ch0[x] = fmaxf(ch0[x], ch1[x]);
-            } else if constexpr (type == 13) {
-                asm volatile("" : "+v"(ch0[x]));
-                ch0[x] = ch0[x] * scale;
-            } else if constexpr (type == 14) {
+            if constexpr (type == 0) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(mx2[x][a & 1]) : "v"(sc[x][e0 >> 4][e0 & 15]), "v"(sc[x][e1 >> 4][e1 & 15]));
+            else if constexpr (type == 10) asm volatile("v_max_f32 %0, %1, %2" : "=v"(ch0[x]) : "v"(mx2[x][0]), "v"(mx2[x][1]));
+            else if constexpr (type == 11) asm volatile("v_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(ch0[x]), "=&v"(ch1[x]));
+            else if constexpr (type == 12) asm volatile("v_max_f32 %0, %0, %1" : "+v"(ch0[x]) : "v"(ch1[x]));
+            else if constexpr (type == 13) asm volatile("v_mul_f32 %0, %1, %0" : "+v"(ch0[x]) : "s"(scale));
+            else if constexpr (type == 14) {
                 asm volatile("" : "+v"(ch0[x]));
                 const bool move = __builtin_amdgcn_ballot_w64(ch0[x] > mref[x] + THR) != 0ull;  // wave-uniform
                 m_new[x] = move ? fmaxf(mref[x], ch0[x]) : mref[x];
-            } else if constexpr (type == 15) {
-                asm volatile("" : "+v"(m_new[x]));
-                ch0[x] = mref[x] - m_new[x];
-            } else if constexpr (type == 16) {
-                asm volatile("" : "+v"(ch0[x]));
-                alpha[x] = __builtin_amdgcn_exp2f(ch0[x]);
+                negm[x] = -m_new[x];
+                asm volatile("" : "+v"(negm[x]));
+            } else if constexpr (type == 15) asm volatile("v_add_f32 %0, %1, %2" : "=v"(ch0[x]) : "v"(mref[x]), "v"(negm[x]));
+            else if constexpr (type == 16) {
+                asm volatile("v_exp_f32 %0, %1" : "=v"(alpha[x]) : "v"(ch0[x]));  // (exp2(-inf) = 0: a row's first sub-tile)
                 mref[x] = m_new[x];
-            } else if constexpr (type == 3) tv[x][e0] = __builtin_fmaf(sc[x][e0 >> 4][e0 & 15], scale, -m_new[x]);
-            else if constexpr (type == 4) tv[x][e1] = __builtin_fmaf(sc[x][e1 >> 4][e1 & 15], scale, -m_new[x]);
-            else if constexpr (type == 5) ev[x][e0] = __builtin_amdgcn_exp2f(tv[x][e0]);
-            else if constexpr (type == 6) ev[x][e1] = __builtin_amdgcn_exp2f(tv[x][e1]);
+            } else if constexpr (type == 3) asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(tv[x][e0]) : "v"(sc[x][e0 >> 4][e0 & 15]), "s"(scale), "v"(negm[x]));
+            else if constexpr (type == 4) asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(tv[x][e1]) : "v"(sc[x][e1 >> 4][e1 & 15]), "s"(scale), "v"(negm[x]));
+            else if constexpr (type == 5) asm volatile("v_exp_f32 %0, %1" : "=v"(ev[x][e0]) : "v"(tv[x][e0]));
+            else if constexpr (type == 6) asm volatile("v_exp_f32 %0, %1" : "=v"(ev[x][e1]) : "v"(tv[x][e1]));
             else {
-                asm volatile("" : "+v"(ev[x][e0]), "+v"(ev[x][e1]));
-                typedef _Float16 half2v __attribute__((ext_vector_type(2)));
-                union {
-                    half2v h2;
-                    uint32_t u;
-                } cv;
-                cv.h2 = half2v{(_Float16)ev[x][e0], (_Float16)ev[x][e1]};
-                asm volatile("" : "+v"(cv.u));
                 union {
                     half8 h8;
                     uint32_t u[4];
                 } pv;
                 pv.h8 = pp[x][e0 >> 4][(e0 & 15) >> 3];
-                pv.u[(e0 & 7) >> 1] = cv.u;
+                asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(pv.u[(e0 & 7) >> 1]) : "v"(ev[x][e0]), "v"(ev[x][e1]));
                 pp[x][e0 >> 4][(e0 & 15) >> 3] = pv.h8;
             }
         };
         auto sm_piece = [&](auto ic) __attribute__((always_inline)) {  // the softmax instructions behind MFMA i (72: the rest)
             constexpr int i = decltype(ic)::value;
-            if constexpr (i > 26 && i < FS_PIECES) asm volatile("" : "+v"(m_new[0]));
-            if constexpr (i > 42 && i < FS_PIECES) asm volatile("" : "+v"(m_new[1]));
             unroll<FS_OPS_A.n>([&](auto kc) __attribute__((always_inline)) {
                 constexpr int k = decltype(kc)::value;
                 if constexpr (FS_OPS_A.piece[k] == i)
@@ -609,6 +610,12 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(PrefillParams p) {
                 if constexpr (FS_OPS_B.piece[k] == i)
                     sm_op(std::integral_constant<int, 1>{}, std::integral_constant<int, FS_OPS_B.type[k]>{}, std::integral_constant<int, FS_OPS_B.arg[k]>{});
             });
+            if constexpr (TAIL_IN)
+                unroll<FS_OPS_BT.n>([&](auto kc) __attribute__((always_inline)) {
+                    constexpr int k = decltype(kc)::value;
+                    if constexpr (FS_OPS_BT.piece[k] == i)
+                        sm_op(std::integral_constant<int, 1>{}, std::integral_constant<int, FS_OPS_BT.type[k]>{}, std::integral_constant<int, FS_OPS_BT.arg[k]>{});
+                });
         };
         unroll<PDK>([&](auto jc) __attribute__((always_inline)) { fk[decltype(jc)::value] = load_k(jc); });
         unroll<(PF64_CUT < FS_PIECES ? PF64_CUT : FS_PIECES)>([&](auto ic) __attribute__((always_inline)) {
@@ -641,6 +648,17 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(PrefillParams p) {
         else alpha[0] = alpha[1] = 1.f;
         __builtin_amdgcn_sched_barrier(0);
     };
+    // block B's deferred pairs, all at once (the step after a full step is not a full step)
+    auto flush_tail = [&]() __attribute__((always_inline)) {
+        typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+        unroll<16 - FS_TAIL_PAIR>([&](auto ac) __attribute__((always_inline)) {
+            constexpr int a = FS_TAIL_PAIR + decltype(ac)::value, e0 = 2 * a, e1 = 2 * a + 1;
+            const float x0 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[1][e0 >> 4][e0 & 15], scale, -mref[1]));
+            const float x1 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[1][e1 >> 4][e1 & 15], scale, -mref[1]));
+            pp[1][e0 >> 4][(e0 & 15) >> 3][e0 & 7] = (_Float16)x0;
+            pp[1][e0 >> 4][(e0 & 15) >> 3][(e0 & 7) + 1] = (_Float16)x1;
+        });
+    };
     auto rescale = [&](const float (&alpha)[2]) __attribute__((always_inline)) {
         if (__builtin_amdgcn_ballot_w64(alpha[0] != 1.f) != 0ull) {
             acc_scale<ACC_O, 64>(alpha[0]);
@@ -660,6 +678,7 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(PrefillParams p) {
     const unsigned long long c_loop = __builtin_readcyclecounter();
 #endif
     // step u of this wave: half Q for sub-tile u (u < nt_w), half P with sub-tile u-1's PV (u >= 1) and sub-tile u's softmax (u < nt_w)
+    bool tail_pending = false;  // (wave-uniform) block B's last pairs of the previous step are still to be exponentiated
     for (int u = 0; u <= nt_all; ++u) {
         const bool has_q = u < nt_w;  // (wave-uniform)
 #ifdef DEFT_EXPERIMENTS
@@ -687,10 +706,18 @@ __global__ __launch_bounds__(256, 1) void prefill64_kernel(PrefillParams p) {
                 for (int kb = 0; kb < 2; ++kb) asm volatile("" : "=v"(sc[x][kb]));
         };
         if (u >= 1 && u < nt_w - 1) {  // the full step, one straight-line block
-            full_step(u, alpha);
+            if (tail_pending) full_step(T{}, u, alpha);
+            else full_step(F{}, u, alpha);
+            tail_pending = true;
             rescale(alpha);
-            kill_s();
+            // (S^T of block B lives on into the next step's first pieces; block A's is dead)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) asm volatile("" : "=v"(sc[0][kb]));
             continue;
+        }
+        if (tail_pending) {
+            flush_tail();
+            tail_pending = false;
         }
         if (has_q) half_q(u);
         if (u == 0) {

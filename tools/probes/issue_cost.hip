@@ -75,6 +75,21 @@ __global__ __launch_bounds__(256, 1) void probe(unsigned long long* out, const c
         if (MODE == 23) asm volatile(REP64("v_cvt_pk_f16_f32 %0, %2, %3\n v_cvt_pk_f16_f32 %1, %2, %3\n") : "+v"(x0), "+v"(x1) : "v"(x2), "v"(x3));
         if (MODE == 24) asm volatile(REP64("v_exp_f32 %0, %2\n v_exp_f32 %1, %3\n") : "+v"(x0), "+v"(x1) : "v"(x2), "v"(x3));
         if (MODE == 25) asm volatile(REP64("v_fma_f32 %0, %2, %3, %2\n v_fma_f32 %1, %3, %2, %3\n") : "+v"(x0), "+v"(x1) : "v"(x2), "v"(x3));
+        // one PV piece of the one-wave-per-SIMD attention loop as it is issued there: counted wait, MFMA on a fragment read three pieces
+        // earlier (ring of four), two transpose reads for the piece three ahead, a softmax pair (2 fma, 2 exp2, 1 cvt, staggered)
+#define PCE(acc, fr, nx, a0, a1, b0, b1, c0, c1, d)                                                                                 \
+    "s_waitcnt lgkmcnt(4)\n v_mfma_f32_32x32x16_f16 " acc ", " fr ", v[60:63], " acc "\n ds_read_b64_tr_b16 " nx "\n"                 \
+    "v_fma_f32 " a0 ", v40, v41, v42\n v_fma_f32 " a1 ", v43, v41, v42\n v_exp_f32 " b0 ", " b0 "\n v_exp_f32 " b1 ", " b1 "\n v_cvt_pk_f16_f32 " d ", " c0 ", " c1 "\n"
+        if (MODE == 40 || MODE == 41 || MODE == 42) {
+            asm volatile("ds_read_b64_tr_b16 v[44:45], %0\n ds_read_b64_tr_b16 v[46:47], %0 offset:2048\n ds_read_b64_tr_b16 v[48:49], %0 offset:4096\n ds_read_b64_tr_b16 v[50:51], %0 offset:6144\n"
+                         "ds_read_b64_tr_b16 v[52:53], %0 offset:8192\n ds_read_b64_tr_b16 v[54:55], %0 offset:10240\n" ::"v"(addr) : "v44","v45","v46","v47","v48","v49","v50","v51","v52","v53","v54","v55");
+            if (MODE == 40)
+                asm volatile(REP16(PCE("a[0:15]", "v[44:47]", "v[56:57], %0 offset:12288\n ds_read_b64_tr_b16 v[58:59], %0 offset:14336", "v30", "v31", "v32", "v33", "v34", "v35", "v36")
+                                   PCE("a[16:31]", "v[48:51]", "v[44:45], %0\n ds_read_b64_tr_b16 v[46:47], %0 offset:2048", "v34", "v35", "v30", "v31", "v32", "v33", "v37")
+                                   PCE("a[32:47]", "v[52:55]", "v[48:49], %0 offset:4096\n ds_read_b64_tr_b16 v[50:51], %0 offset:6144", "v32", "v33", "v34", "v35", "v30", "v31", "v38")
+                                   PCE("a[48:63]", "v[56:59]", "v[52:53], %0 offset:8192\n ds_read_b64_tr_b16 v[54:55], %0 offset:10240", "v30", "v31", "v32", "v33", "v34", "v35", "v36"))
+                             "s_waitcnt lgkmcnt(0)\n" ::"v"(addr) : "v30","v31","v32","v33","v34","v35","v36","v37","v38","v40","v41","v42","v43","v44","v45","v46","v47","v48","v49","v50","v51","v52","v53","v54","v55","v56","v57","v58","v59","v60","v61","v62","v63");
+        }
 #define F4 "v_fma_f32 %0, %0, %0, %0\n v_fma_f32 %1, %1, %1, %1\n v_fma_f32 %2, %2, %2, %2\n v_fma_f32 %3, %3, %3, %3\n"
 #define CLB "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31"
         // four rotating accumulation-register accumulators, 4 fma behind each MFMA
@@ -145,6 +160,7 @@ int main() {
     run<32>("MFMA + 4 v_fma_f32, ordinary accumulators, B operand in acc registers", 64, d_out, g);
     run<33>("MFMA + 4 v_fma_f32, A operand from the LDS two MFMAs ahead", 64, d_out, g);
     run<34>("MFMA + 2 cvt_pk + 2 v_fma_f32, B operand written by the cvt", 64, d_out, g);
+    run<40>("PV piece: wait + MFMA + 2 tr reads (3 ahead) + softmax pair", 64, d_out, g);
     run<25>("2 v_fma_f32 (no dependencies at all)", 64, d_out, g);
     run<24>("2 v_exp_f32 (no dependencies at all)", 64, d_out, g);
     run<23>("2 v_cvt_pk_f16_f32 (no dependencies)", 64, d_out, g);
