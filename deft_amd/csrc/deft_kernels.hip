@@ -293,7 +293,6 @@ __global__ __launch_bounds__(256, 2) void stage1_kernel(Stage1Params p) {
 #include "merge.h"
 #include "stage1_np.h"
 #include "prefill.h"
-#include "prefill64.h"
 namespace deft {
 
 // ---------------------------------------------------------------------------
@@ -545,7 +544,7 @@ static int num_cus() {
     return d.cus;
 }
 enum : unsigned { ATTR_NP = 4,  // (bits 0-1, 8-11: the head_dim 64 / 32 / 16 kernels)
-                  ATTR_UNITS = 8, ATTR_NODE_UNITS = 16, ATTR_PREFILL = 32, ATTR_TREE = 64, ATTR_NP_ROPE = 128, ATTR_NP_T = 8192, ATTR_NP_ROPE_T = 16384, ATTR_NP_HD2 = 32768, ATTR_NP_HD2_T = 65536, ATTR_PREFILL_S1 = 1u << 17, ATTR_PREFILL_S2 = 1u << 18, ATTR_PREFILL_64 = 1u << 19 };
+                  ATTR_UNITS = 8, ATTR_NODE_UNITS = 16, ATTR_PREFILL = 32, ATTR_TREE = 64, ATTR_NP_ROPE = 128, ATTR_NP_T = 8192, ATTR_NP_ROPE_T = 16384, ATTR_NP_HD2 = 32768, ATTR_NP_HD2_T = 65536 };
 static int raise_lds(const void* fn, int bytes, unsigned bit, const char* what) {  // idempotent; races are harmless
     DeviceState& d = dev_state();
     if (d.attrs & bit) return DEFT_OK;
@@ -1791,22 +1790,6 @@ extern "C" int deft_prefill_f16(const void* q, int64_t q_stride_tok, int64_t q_s
         return DEFT_EINVAL;
     }
     const dim3 grid((unsigned)((int64_t)p.nblk * Hq * batch));
-    if (knob("DEFT_PREFILL_64", 0) && prefill64_fits(max_input_len, k_stride_tok, v_stride_tok)) {
-        const int rc = raise_lds(reinterpret_cast<const void*>(&prefill64_kernel<128>), Prefill64Smem<128>::BYTES, ATTR_PREFILL_64, "prefill64");
-        if (rc) return rc;
-        hipLaunchKernelGGL((prefill64_kernel<128>), grid, dim3(256), Prefill64Smem<128>::BYTES, static_cast<hipStream_t>(stream), p);
-        return check_launch("prefill64 launch");
-    }
-    const int spread = knob("DEFT_PREFILL_SPREAD", 0);
-    if (spread == 1) {
-        const int rc = raise_lds(reinterpret_cast<const void*>(&prefill_kernel<128, 1>), PrefillSmem<128>::BYTES, ATTR_PREFILL_S1, "prefill s1");
-        if (rc) return rc;
-        hipLaunchKernelGGL((prefill_kernel<128, 1>), grid, dim3(512), PrefillSmem<128>::BYTES, static_cast<hipStream_t>(stream), p);
-    } else if (spread == 2) {
-        const int rc = raise_lds(reinterpret_cast<const void*>(&prefill_kernel<128, 2>), PrefillSmem<128>::BYTES, ATTR_PREFILL_S2, "prefill s2");
-        if (rc) return rc;
-        hipLaunchKernelGGL((prefill_kernel<128, 2>), grid, dim3(512), PrefillSmem<128>::BYTES, static_cast<hipStream_t>(stream), p);
-    } else
     hipLaunchKernelGGL((prefill_kernel<128>), grid, dim3(512), PrefillSmem<128>::BYTES, static_cast<hipStream_t>(stream), p);
     return check_launch("prefill launch");
 }

@@ -46,7 +46,7 @@ struct PrefillSmem {
     static_assert(BYTES <= 160 * 1024, "LDS budget");
 };
 
-template <int D, int SPREAD = 0>
+template <int D>
 __global__ __launch_bounds__(512, 1) void prefill_kernel(PrefillParams p) {
     constexpr int KS = D / 16;
     constexpr int QB = 256;  // queries per workgroup
@@ -102,6 +102,8 @@ __global__ __launch_bounds__(512, 1) void prefill_kernel(PrefillParams p) {
     //  the older half of the workgroup wins the arbitration -- waves 0-3 are through their eight in 0.43 us, waves 4-7 in 1.13 us,
     //  and the older half then waits 1.24 us per tile at the barrier.  Dealing the older half 5 .. 8 of every 8 pieces instead of 4
     //  moves that wait to the other half and changes nothing: 979 / 969 / 960 / 966 / 967 TFLOP/s at 16k tokens for 4 .. 8.)
+    // (spreading a tile's eight request instructions over the k-steps' MFMAs instead -- one behind every four, or K among QK^T and V
+    //  among PV -- measured 0.98x / 1.003x: the time moves from one phase into the other, profiles/r4_prefill64_negative.txt)
     auto issue_tile = [&](int t, int stg) {  // 4 K + 4 V instructions per wave: keys 16w + 4i + dkey of tile t
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -113,16 +115,6 @@ __global__ __launch_bounds__(512, 1) void prefill_kernel(PrefillParams p) {
             dma16(kbase + (int64_t)tok * p.k_st * 2 + kc, SM::K_OFF + (uint32_t)stg * SM::STAGE + (uint32_t)(16 * w + 4 * i) * 256u);
             dma16(vbase + (int64_t)tok * p.v_st * 2 + vc, SM::V_OFF + (uint32_t)stg * SM::STAGE + (uint32_t)(16 * w + 4 * i) * 256u);
         }
-    };
-
-    // one of a tile's eight request instructions: piece j < 4 = K keys 16w + 4j + dkey, j >= 4 = the V rows of piece j - 4
-    auto issue_piece = [&](int t, int stg, int j) {
-        const int i = j & 3;
-        const int key = 16 * w + 4 * i + dkey;
-        int tok = TILE * t + key;
-        tok = tok < len ? tok : len - 1;
-        if (j < 4) dma16(kbase + (int64_t)tok * p.k_st * 2 + (dpos ^ (key & 15)) * 16, SM::K_OFF + (uint32_t)stg * SM::STAGE + (uint32_t)(16 * w + 4 * i) * 256u);
-        else dma16(vbase + (int64_t)tok * p.v_st * 2 + (dpos ^ (4 * (key & 3))) * 16, SM::V_OFF + (uint32_t)stg * SM::STAGE + (uint32_t)(16 * w + 4 * i) * 256u);
     };
 
     const int ntiles = min(2 * m + 2, (len + TILE - 1) / TILE);
@@ -176,12 +168,10 @@ __global__ __launch_bounds__(512, 1) void prefill_kernel(PrefillParams p) {
         wait_vm<0>();   // tile t landed (this wave's part)
         lds_barrier();  // ... everyone's part; and every wave is done with tile t-1's stage
         PF_PHASE(0);
-        const int key0 = TILE * t;
-        const bool above = key0 > q_lo + 31;  // the whole tile lies above this wave's queries (wave-uniform)
-        const bool more = t + 1 < ntiles;
-        if (more && (SPREAD == 0 || above)) issue_tile(t + 1, stg ^ 1);
+        if (t + 1 < ntiles) issue_tile(t + 1, stg ^ 1);
         PF_PHASE(1);
-        if (above) continue;
+        const int key0 = TILE * t;
+        if (key0 > q_lo + 31) continue;  // the whole tile lies above this wave's queries (wave-uniform)
         const bool diag = key0 + TILE - 1 > q_lo;  // some key of the tile is beyond some query of the wave
         // ---- S^T for all 128 keys of the tile: four independent accumulator chains (32 keys each) -----------
         floatx16 acc[4];
@@ -206,8 +196,6 @@ __global__ __launch_bounds__(512, 1) void prefill_kernel(PrefillParams p) {
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb) acc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks & 1][kb], qf[ks], acc[kb], 0, 0, 0);
-            if (SPREAD == 1 && more) issue_piece(t + 1, stg ^ 1, ks);  // one request in the shadow of each k-step's MFMAs
-            if (SPREAD == 2 && more && !(ks & 1)) issue_piece(t + 1, stg ^ 1, ks >> 1);  // K here, V among the PV groups
             __builtin_amdgcn_sched_barrier(0);
         }
         PF_PHASE(2);
@@ -295,7 +283,6 @@ __global__ __launch_bounds__(512, 1) void prefill_kernel(PrefillParams p) {
 #pragma unroll
             for (int bk = 0; bk < 4; ++bk)
                 o[bk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[g & 1][bk].h8, pb[g >> 1][g & 1], o[bk], 0, 0, 0);
-            if (SPREAD == 2 && more && !(g & 1)) issue_piece(t + 1, stg ^ 1, 4 + (g >> 1));
             __builtin_amdgcn_sched_barrier(0);
         }
         PF_PHASE(4);
