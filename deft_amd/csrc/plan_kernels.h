@@ -156,8 +156,10 @@ __device__ inline void np_record_order(const UnitList& ul, int R, int Hkv, int G
         while (C < 8 && lmax > 16 * C) C <<= 1;
         // A launch that leaves CUs empty (fewer chunks than CUs = slots / 2) takes the next shorter chunk length -- powers
         // of two or not -- as long as that still fits one workgroup per CU: Medusa-64 (an 8-tile root under two query
-        // chunks, 32 KV heads) 192 workgroups of 4 tiles -> 256 of 3: 15.8 -> 14.9 us per layer.
-        if (C > 2 && lmax <= 16 * (C - 1)) {
+        // chunks, 32 KV heads) 192 workgroups of 4 tiles -> 256 of 3: 15.8 -> 14.9 us per layer.  Such a launch may also cut its
+        // longest run into up to 24 chunks (round 4: one 8192-token prefix under 8 branches, Llama-3-8B, 192 workgroups of 4
+        // tiles -> 240 of 3: 15.4 -> 14.35 us per layer, stage 1 12.4 -> 11.5; tools/ab.py DEFT_NP_CHUNK=1..8: 14.7 12.6 11.3 12.4 - 15.2 - 18.0).
+        if (C > 2 && lmax <= 24 * (C - 1)) {
             int64_t n0 = 0, n1 = 0;
             for_runs([&](int, int nt, int uni) {
                 n0 += uni ? 1 : (nt + C - 1) / C;
@@ -232,7 +234,7 @@ __device__ inline void record_order_parallel(const UnitList& ul, const RunTable&
                 if ((pairs ? 4 : 10) * n * Hkv >= 3LL * slots) break;
             }
             while (C < 8 && lmax > 16 * C) C <<= 1;  // (np_record_order: at most 16 chunks per run while C < 8)
-            if (C > 2 && lmax <= 16 * (C - 1)) {       // (np_record_order: fill the CUs of a launch that leaves some empty)
+            if (C > 2 && lmax <= 24 * (C - 1)) {       // (np_record_order: fill the CUs of a launch that leaves some empty)
                 const int64_t n0 = wave_sum([C](int nt, int uni) { return uni ? 1 : (nt + C - 1) / C; });
                 const int64_t n1 = wave_sum([C](int nt, int uni) { return uni ? 1 : (nt + C - 2) / (C - 1); });
                 if (2 * n0 * Hkv < slots && 2 * n1 * Hkv <= slots) --C;
