@@ -3,8 +3,8 @@
 Same name, positional signature and in-place output as
 DeFT/deft/layers/attention/context_flashattention_nopad.py:130-195, the operator behind
 `DeFTAttention.prefill_forward_triton` (deft_attention.py:50-70): sequences packed without padding, token i of a
-sequence attends to tokens 0..i of it.  Backed by libdeft_amd.so (deft_prefill_f16, head_dim 128); no PyTorch or CPU
-fallback.
+sequence attends to tokens 0..i of it.  Backed by libdeft_amd.so (deft_prefill_f16; head_dim 128 and 64 on the MFMA
+kernel, 32 and 16 on a plain one); no PyTorch or CPU fallback.
 """
 from __future__ import annotations
 

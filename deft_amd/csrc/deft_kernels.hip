@@ -544,7 +544,7 @@ static int num_cus() {
     return d.cus;
 }
 enum : unsigned { ATTR_NP = 4,  // (bits 0-1, 8-11: the head_dim 64 / 32 / 16 kernels)
-                  ATTR_UNITS = 8, ATTR_NODE_UNITS = 16, ATTR_PREFILL = 32, ATTR_TREE = 64, ATTR_NP_ROPE = 128, ATTR_NP_T = 8192, ATTR_NP_ROPE_T = 16384, ATTR_NP_HD2 = 32768, ATTR_NP_HD2_T = 65536 };
+                  ATTR_UNITS = 8, ATTR_NODE_UNITS = 16, ATTR_PREFILL = 32, ATTR_TREE = 64, ATTR_NP_ROPE = 128, ATTR_NP_T = 8192, ATTR_NP_ROPE_T = 16384, ATTR_NP_HD2 = 32768, ATTR_NP_HD2_T = 65536, ATTR_PREFILL_64 = 1u << 17 };
 static int raise_lds(const void* fn, int bytes, unsigned bit, const char* what) {  // idempotent; races are harmless
     DeviceState& d = dev_state();
     if (d.attrs & bit) return DEFT_OK;
@@ -1750,8 +1750,8 @@ extern "C" int deft_prefill_f16(const void* q, int64_t q_stride_tok, int64_t q_s
         set_error("bad prefill arguments (batch=%d max_input_len=%d Hq=%d Hkv=%d)", batch, max_input_len, Hq, Hkv);
         return DEFT_EINVAL;
     }
-    if (D != 128) {
-        set_error("prefill: unsupported head_dim %d (supported: 128)", D);
+    if (D != 128 && D != 64 && D != 32 && D != 16) {
+        set_error("prefill: unsupported head_dim %d (supported: 16, 32, 64, 128)", D);
         return DEFT_EUNSUPPORTED;
     }
     if (!aligned16(q) || !aligned16(k) || !aligned16(v) || (reinterpret_cast<uintptr_t>(out) & 7u) || (q_stride_tok % 8) ||
@@ -1760,8 +1760,11 @@ extern "C" int deft_prefill_f16(const void* q, int64_t q_stride_tok, int64_t q_s
         set_error("prefill: q/k/v rows must be 16-byte aligned, out rows 8-byte aligned");
         return DEFT_EINVAL;
     }
-    {
+    if (D == 128) {
         const int rc = raise_lds(reinterpret_cast<const void*>(&prefill_kernel<128>), PrefillSmem<128>::BYTES, ATTR_PREFILL, "prefill");
+        if (rc) return rc;
+    } else if (D == 64) {
+        const int rc = raise_lds(reinterpret_cast<const void*>(&prefill_kernel<64>), PrefillSmem<64>::BYTES, ATTR_PREFILL_64, "prefill (head_dim 64)");
         if (rc) return rc;
     }
     PrefillParams p{};
@@ -1790,7 +1793,13 @@ extern "C" int deft_prefill_f16(const void* q, int64_t q_stride_tok, int64_t q_s
         return DEFT_EINVAL;
     }
     const dim3 grid((unsigned)((int64_t)p.nblk * Hq * batch));
-    hipLaunchKernelGGL((prefill_kernel<128>), grid, dim3(512), PrefillSmem<128>::BYTES, static_cast<hipStream_t>(stream), p);
+    if (D == 128) hipLaunchKernelGGL((prefill_kernel<128>), grid, dim3(512), PrefillSmem<128>::BYTES, static_cast<hipStream_t>(stream), p);
+    else if (D == 64) hipLaunchKernelGGL((prefill_kernel<64>), grid, dim3(512), PrefillSmem<64>::BYTES, static_cast<hipStream_t>(stream), p);
+    else {  // head_dim 32 / 16: a wave per (token, head)
+        const dim3 g2((unsigned)((((int64_t)p.nblk * 256 + 3) / 4) * batch), (unsigned)Hq);
+        if (D == 32) hipLaunchKernelGGL((prefill_small_kernel<32>), g2, dim3(256), 0, static_cast<hipStream_t>(stream), p);
+        else hipLaunchKernelGGL((prefill_small_kernel<16>), g2, dim3(256), 0, static_cast<hipStream_t>(stream), p);
+    }
     return check_launch("prefill launch");
 }
 

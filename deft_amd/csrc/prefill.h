@@ -17,7 +17,10 @@
 //   * one online-softmax step per 128-key tile: 32 QK^T MFMAs on four independent accumulators, one max / rescale,
 //     32 PV MFMAs;
 //   * causal structure: query block m needs key tiles 0 .. 2m+1; only the last two touch the diagonal and are masked,
-//     a wave skips tiles that lie entirely above its queries; workgroups are launched longest first over the whole grid.
+//     a wave skips tiles that lie entirely above its queries; workgroups are launched longest first over the whole grid;
+//   * head_dim 128 and 64 (the reference takes 16 / 32 / 64 / 128, context_flashattention_nopad.py:134; 32 and 16 go through
+//     prefill_small_kernel below): a row is D / 8 16-byte chunks, O^T has D / 32 column blocks, QK^T D / 16 k-steps; the LDS
+//     swizzles keep their form with the chunk count as modulus.
 #pragma once
 
 namespace deft {
@@ -48,9 +51,13 @@ struct PrefillSmem {
 
 template <int D>
 __global__ __launch_bounds__(512, 1) void prefill_kernel(PrefillParams p) {
-    constexpr int KS = D / 16;
+    constexpr int KS = D / 16;   // k-steps of QK^T
+    constexpr int CH = D / 8;    // 16-byte chunks per row
+    constexpr int NB = D / 32;   // 32-wide column blocks of O^T
+    constexpr int RPI = 64 / CH; // rows one 64-lane request instruction covers (4 at head_dim 128, 8 at 64)
+    constexpr int NREQ = TILE / (8 * RPI);  // request instructions per wave for a K (or V) tile: 4 / 2
     constexpr int QB = 256;  // queries per workgroup
-    static_assert(D == 128, "prefill is instantiated for head_dim 128");
+    static_assert(D == 128 || D == 64, "prefill_kernel is instantiated for head_dim 128 and 64");
     using SM = PrefillSmem<D>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -81,20 +88,20 @@ __global__ __launch_bounds__(512, 1) void prefill_kernel(PrefillParams p) {
 #endif
     const int kvh = head / p.G;
 
-    // ---- lane constants (LDS layouts of stage1_np.h: K chunks XOR-ed by key & 15, V chunks by 4*(key & 3)) ----------
-    const int dpos = l & 15, dkey = l >> 4;
+    // ---- lane constants (LDS layouts of stage1_np.h: K chunks XOR-ed by key & (CH - 1), V chunks by 4*(key & (NB - 1))) ------
+    const int dpos = l & (CH - 1), dkey = l / CH;
     const int tg = l >> 4, tx = l & 15;
-    int vtr_col_b[4];
+    int vtr_col_b[NB];
 #pragma unroll
-    for (int blk = 0; blk < 4; ++blk) vtr_col_b[blk] = (4 * (blk ^ (tx >> 2)) + 2 * (tg & 1) + ((tx & 3) >> 1)) * 16;
+    for (int blk = 0; blk < NB; ++blk) vtr_col_b[blk] = (4 * (blk ^ ((tx >> 2) & (NB - 1))) + 2 * (tg & 1) + ((tx & 3) >> 1)) * 16;
     const int vtr_row_b = (4 * (tg >> 1) + (tx >> 2)) * D * 2 + (tx & 1) * 8;
     const int krow_b = c * D * 2;
-    const int kcol_b = ((h ^ c) & 15) * 16;
-    int kfrag_b[KS], vfrag_b[4];  // per-lane fragment bases inside a stage
+    const int kcol_b = ((h ^ c) & (CH - 1)) * 16;
+    int kfrag_b[KS], vfrag_b[NB];  // per-lane fragment bases inside a stage
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) kfrag_b[ks] = krow_b + (kcol_b ^ (32 * ks));
 #pragma unroll
-    for (int blk = 0; blk < 4; ++blk) vfrag_b[blk] = vtr_row_b + vtr_col_b[blk];
+    for (int blk = 0; blk < NB; ++blk) vfrag_b[blk] = vtr_row_b + vtr_col_b[blk];
 
     const char* kbase = reinterpret_cast<const char*>(p.k + start * p.k_st + (int64_t)kvh * p.k_sh);
     const char* vbase = reinterpret_cast<const char*>(p.v + start * p.v_st + (int64_t)kvh * p.v_sh);
@@ -104,16 +111,16 @@ __global__ __launch_bounds__(512, 1) void prefill_kernel(PrefillParams p) {
     //  moves that wait to the other half and changes nothing: 979 / 969 / 960 / 966 / 967 TFLOP/s at 16k tokens for 4 .. 8.)
     // (spreading a tile's eight request instructions over the k-steps' MFMAs instead -- one behind every four, or K among QK^T and V
     //  among PV -- measured 0.98x / 1.003x: the time moves from one phase into the other, profiles/r4_prefill64_negative.txt)
-    auto issue_tile = [&](int t, int stg) {  // 4 K + 4 V instructions per wave: keys 16w + 4i + dkey of tile t
+    auto issue_tile = [&](int t, int stg) {  // NREQ K + NREQ V instructions per wave: keys 16w + RPI i + dkey of tile t
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int key = 16 * w + 4 * i + dkey;
+        for (int i = 0; i < NREQ; ++i) {
+            const int key = 16 * w + RPI * i + dkey;
             int tok = TILE * t + key;
             tok = tok < len ? tok : len - 1;  // padding aliases the last token; masked by the causal test
-            const int kc = (dpos ^ (key & 15)) * 16;
-            const int vc = (dpos ^ (4 * (key & 3))) * 16;
-            dma16(kbase + (int64_t)tok * p.k_st * 2 + kc, SM::K_OFF + (uint32_t)stg * SM::STAGE + (uint32_t)(16 * w + 4 * i) * 256u);
-            dma16(vbase + (int64_t)tok * p.v_st * 2 + vc, SM::V_OFF + (uint32_t)stg * SM::STAGE + (uint32_t)(16 * w + 4 * i) * 256u);
+            const int kc = (dpos ^ (key & (CH - 1))) * 16;
+            const int vc = (dpos ^ (4 * (key & (NB - 1)))) * 16;
+            dma16(kbase + (int64_t)tok * p.k_st * 2 + kc, SM::K_OFF + (uint32_t)stg * SM::STAGE + (uint32_t)(16 * w + RPI * i) * (uint32_t)(D * 2));
+            dma16(vbase + (int64_t)tok * p.v_st * 2 + vc, SM::V_OFF + (uint32_t)stg * SM::STAGE + (uint32_t)(16 * w + RPI * i) * (uint32_t)(D * 2));
         }
     };
 
@@ -138,9 +145,9 @@ __global__ __launch_bounds__(512, 1) void prefill_kernel(PrefillParams p) {
     for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]));
 
     float m_run = -INFINITY, l_run = 0.f;
-    floatx16 o[4];
+    floatx16 o[NB];
 #pragma unroll
-    for (int bk = 0; bk < 4; ++bk)
+    for (int bk = 0; bk < NB; ++bk)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[bk][r] = 0.f;
     const int q_lo = m * QB + 32 * w;  // first query of this wave
@@ -248,28 +255,28 @@ __global__ __launch_bounds__(512, 1) void prefill_kernel(PrefillParams p) {
         m_run = m_new;
         if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0ull) {
 #pragma unroll
-            for (int bk = 0; bk < 4; ++bk)
+            for (int bk = 0; bk < NB; ++bk)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[bk][r] *= alpha;  // (packed by the compiler; 64 single multiplies measured the same)
         }
         PF_PHASE(3);
         // ---- O^T += V^T P^T: 32 MFMAs on four independent accumulators -------------------------------------------
         const int vstage = SM::V_OFF + stg * SM::STAGE;
-        int vfrag[4];
+        int vfrag[NB];
 #pragma unroll
-        for (int bk = 0; bk < 4; ++bk) vfrag[bk] = vfrag_b[bk] + vstage;
-        // V^T fragments double-buffered by (key block, k-step) group: the eight transpose reads of group g + 1 go out before the
-        // four MFMAs of group g
+        for (int bk = 0; bk < NB; ++bk) vfrag[bk] = vfrag_b[bk] + vstage;
+        // V^T fragments double-buffered by (key block, k-step) group: the transpose reads of group g + 1 go out before the
+        // MFMAs of group g
         typedef __attribute__((address_space(3))) short4v* lds_s4;
         union VFrag {
             short4v s4[2];
             half8 h8;
         };
-        VFrag vf[2][4];
-        auto load_group = [&](int g, VFrag (&dst)[4]) {
+        VFrag vf[2][NB];
+        auto load_group = [&](int g, VFrag (&dst)[NB]) {
             const int kb = g >> 1, tt = g & 1;
 #pragma unroll
-            for (int bk = 0; bk < 4; ++bk) {
+            for (int bk = 0; bk < NB; ++bk) {
                 const int vb = vfrag[bk] + (32 * kb * D * 2 + (16 * tt) * D * 2);
                 dst[bk].s4[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(uintptr_t)(vb));
                 dst[bk].s4[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(uintptr_t)(vb + 8 * D * 2));
@@ -281,7 +288,7 @@ __global__ __launch_bounds__(512, 1) void prefill_kernel(PrefillParams p) {
             if (g + 1 < 8) load_group(g + 1, vf[(g + 1) & 1]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int bk = 0; bk < 4; ++bk)
+            for (int bk = 0; bk < NB; ++bk)
                 o[bk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[g & 1][bk].h8, pb[g >> 1][g & 1], o[bk], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -303,7 +310,7 @@ __global__ __launch_bounds__(512, 1) void prefill_kernel(PrefillParams p) {
         const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
         _Float16* op = p.o + (start + qi) * p.o_st + (int64_t)head * p.o_sh + 4 * h;
 #pragma unroll
-        for (int bk = 0; bk < 4; ++bk)
+        for (int bk = 0; bk < NB; ++bk)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 half4 v4 = {(_Float16)(o[bk][4 * j] * inv), (_Float16)(o[bk][4 * j + 1] * inv),
@@ -326,5 +333,59 @@ __global__ __launch_bounds__(512, 1) void prefill_kernel(PrefillParams p) {
 #endif
 }
 #undef PF_PHASE
+
+// head_dim 32 and 16 (context_flashattention_nopad.py:134 takes them; no model the reference ships has them): one wave per
+// (query token, query head), the lanes stride over the keys 0 .. i with a private online softmax in fp32 and merge at the end.
+// Correctness path, not a tuned one.  Grid: (ceil(max_input_len / 4) * batch, Hq), 256 threads.
+template <int D>
+__global__ __launch_bounds__(256) void prefill_small_kernel(PrefillParams p) {
+    static_assert(D == 32 || D == 16, "small head dimensions");
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int per_seq = (p.nblk * 256 + 3) / 4;  // (nblk * 256 >= max_input_len)
+    const int b = (int)blockIdx.x / per_seq;
+    const int qi = ((int)blockIdx.x - b * per_seq) * 4 + w;
+    const int head = (int)blockIdx.y;
+    const int len = p.b_seq_len[b];
+    if (b >= p.batch || qi >= len) return;
+    const int64_t start = p.b_start_loc[b];
+    const int kvh = head / p.G;
+    float q[D];
+    const _Float16* qp = p.q + (start + qi) * p.q_st + (int64_t)head * p.q_sh;
+#pragma unroll
+    for (int d = 0; d < D; ++d) q[d] = (float)qp[d];
+    float m = -INFINITY, s = 0.f, acc[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) acc[d] = 0.f;
+    for (int j = l; j <= qi; j += 64) {
+        const _Float16* kp = p.k + (start + j) * p.k_st + (int64_t)kvh * p.k_sh;
+        const _Float16* vp = p.v + (start + j) * p.v_st + (int64_t)kvh * p.v_sh;
+        float dot = 0.f;
+#pragma unroll
+        for (int d = 0; d < D; ++d) dot += q[d] * (float)kp[d];
+        const float x = dot * p.scale_log2e;
+        const float mn = fmaxf(m, x);
+        const float a = __builtin_amdgcn_exp2f(m - mn), e = __builtin_amdgcn_exp2f(x - mn);  // (exp2(-inf) = 0 the first time)
+        s = s * a + e;
+#pragma unroll
+        for (int d = 0; d < D; ++d) acc[d] = acc[d] * a + e * (float)vp[d];
+        m = mn;
+    }
+    // merge the 64 lanes' states (lanes beyond the keys hold m = -inf, s = 0)
+    for (int off = 32; off > 0; off >>= 1) {
+        const float mo = __shfl_xor(m, off, 64), so = __shfl_xor(s, off, 64);
+        const float mn = fmaxf(m, mo);
+        const float a = (m == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m - mn), bfac = (mo == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(mo - mn);
+        s = s * a + so * bfac;
+#pragma unroll
+        for (int d = 0; d < D; ++d) acc[d] = acc[d] * a + __shfl_xor(acc[d], off, 64) * bfac;
+        m = mn;
+    }
+    if (l == 0) {
+        const float inv = s > 0.f ? 1.f / s : 0.f;
+        _Float16* op = p.o + (start + qi) * p.o_st + (int64_t)head * p.o_sh;
+#pragma unroll
+        for (int d = 0; d < D; ++d) op[d] = (_Float16)(acc[d] * inv);
+    }
+}
 
 }  // namespace deft

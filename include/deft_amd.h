@@ -240,7 +240,8 @@ int deft_node_decode_rope_append_f16(
  * Replaces context_attention_fwd (DeFT/deft/layers/attention/context_flashattention_nopad.py:130-195) behind
  * DeFTAttention.prefill_forward_triton (deft_attention.py:50-70): sequences packed without padding,
  * q[T][Hq][D], k / v[T][Hkv][D] fp16, token i of sequence b attends to tokens 0..i of b;
- * b_start_loc / b_seq_len int32 [batch] (model_runner.py:110-114).  head_dim 128.
+ * b_start_loc / b_seq_len int32 [batch] (model_runner.py:110-114).  head_dim 16 / 32 / 64 / 128 as upstream
+ * (context_flashattention_nopad.py:134): 128 and 64 on the MFMA kernel, 32 and 16 on a plain one.
  */
 int deft_prefill_f16(const void* q, int64_t q_stride_tok, int64_t q_stride_head,
                      const void* k, int64_t k_stride_tok, int64_t k_stride_head,

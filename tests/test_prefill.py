@@ -22,7 +22,7 @@ def _close_to_truth(out, truth):
 
 
 GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "prefill.npz"))
-CASES = ("single_300", "single_513_gqa", "batch_ragged")
+CASES = ("single_300", "single_513_gqa", "batch_ragged", "d64_gqa_385", "d64_batch_ragged", "d32_gqa_200", "d16_150")
 
 
 def _inputs(name):
@@ -66,7 +66,8 @@ def test_gpu_prefill_matches_reference_and_truth(name):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("lens,geom", [([1], (4, 4, 128)), ([255, 256, 257], (8, 2, 128)), ([1000], (32, 32, 128)),
-                                       ([640, 3], (32, 8, 128))])
+                                       ([640, 3], (32, 8, 128)), ([1], (4, 4, 64)), ([255, 256, 257], (8, 2, 64)),
+                                       ([1000, 130], (32, 8, 64)), ([257, 1, 64], (4, 2, 32)), ([300], (2, 1, 16))])
 def test_gpu_prefill_edges_and_strided_views(lens, geom):
     """Block edges (255/256/257), a single token, GQA, and q/k/v as strided views of the fused qkv (llama2.py:108-109)."""
     Hq, Hkv, D = geom

@@ -25,7 +25,10 @@ torch.cuda.get_device_capability = lambda *a, **k: (8, 0)  # type: ignore[assign
 import deft.layers.attention.context_flashattention_nopad as ref  # noqa: E402
 from deft_amd.utils.synthetic import dyadic_normal  # noqa: E402
 
-CASES = {"single_300": ([300], (4, 4, 128)), "single_513_gqa": ([513], (8, 2, 128)), "batch_ragged": ([130, 77, 256, 1], (4, 4, 128))}
+CASES = {"single_300": ([300], (4, 4, 128)), "single_513_gqa": ([513], (8, 2, 128)), "batch_ragged": ([130, 77, 256, 1], (4, 4, 128)),
+         # the other head dimensions the reference takes (:134): 64 on the MFMA kernel, 32 / 16 on the small-head-dim kernel
+         "d64_gqa_385": ([385], (4, 2, 64)), "d64_batch_ragged": ([130, 77, 256, 1], (4, 4, 64)), "d32_gqa_200": ([200, 3], (4, 2, 32)),
+         "d16_150": ([150], (2, 2, 16))}
 out = {}
 for name, (lens, (Hq, Hkv, D)) in CASES.items():
     t0 = time.time()
