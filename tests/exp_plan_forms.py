@@ -73,6 +73,7 @@ def run(shape):
         assert torch.equal(o, outs[0])
         assert torch.equal(hd, plans[0][0])
         assert torch.equal(rec, plans[0][1])
+    print("flatten units", int(plans[0][0][:4].view(torch.int32).item()), "leaders", int(plans[0][0][4:8].view(torch.int32).item()))
     # the Node plan (entries cut into tiles, small entries packed) has the same three forms
     nd = [md.node_kv, md.node_kv_offset, md.node_kv_len, md.node_q, md.node_q_offset, md.node_q_len]
     NE, Pn, total_kv = md.node_kv_offset.shape[0], md.node_q.shape[0], md.node_kv.shape[0]

@@ -623,7 +623,8 @@ def test_nodes_with_more_than_32_queries_fold_as_interleaved_runs(mode, shape):
         assert (o[r].double() - ref).abs().max().item() < TOL_EXACT, r
 
 
-@pytest.mark.parametrize("shape", [(32, 32, 1024, 32, 200), (8, 2, 1500, 70, 3), (4, 4, 300, 5, 40), (4, 4, 5, 40, 1)])
+@pytest.mark.parametrize("shape", [(32, 32, 1024, 32, 200), (8, 2, 1500, 70, 3), (4, 4, 300, 5, 40), (4, 4, 5, 40, 1),
+                                   (32, 8, 8192, 8, 40)])
 def test_plan_build_forms_give_identical_plans(shape):
     """The plan kernels' three forms (tests/exp_plan_forms.py) produce identical plan bytes and output bits.  The hook that
     forces the fallback forms exists in the EXPERIMENTS build only (`deft_debug_plan_form`, libdeft_amd_exp.so: the shipped
@@ -638,6 +639,11 @@ def test_plan_build_forms_give_identical_plans(shape):
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "forms identical" in r.stdout
+    if shape == (32, 8, 8192, 8, 40):
+        # one 8192-token prefix under 8 branches, Llama-3-8B heads: with 4-tile chunks the launch would leave CUs empty (16 + 3
+        # leaders x 8 KV heads = 152 workgroups), so the 64-tile run is cut into 22 chunks of 3 (round 4's rule); the leaves'
+        # 320 tokens share 3 blocks: 25 leaders, in the serial and the parallel form of the rule alike
+        assert "flatten units 67 leaders 25" in r.stdout, r.stdout[-500:]
 
 
 def test_decode_step_inside_inference_mode():
