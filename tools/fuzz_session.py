@@ -46,6 +46,34 @@ while time.time() < t_end:
 
     def both(nsteps):
         global steps
+        # Half of the runs WITHOUT a synchronisation between the session's steps: the host runs ahead of the GPU, and the session's
+        # step t+1 head (its own stream) overlaps step t's layers -- the outputs of every step are cloned in stream order and
+        # compared at the end of the run, pool bytes and page tables then too.
+        if nsteps > 1 and rng.random() < 0.5:
+            refs, outs, n = [], [], 0
+            for _ in range(nsteps):
+                for leaf in te.leaves.values():
+                    leaf.append_token(7)
+                upd = te.alloc()
+                md = deft_amd.TreeMetadata.from_tree_cache(te)
+                deft_amd.register_tree_metadata(md)
+                n = md.query_num
+                refs.append([attn[l](q[l, :n], k[l, :n], v[l, :n], deft_amd.InputMetadata(fmode, upd, pe)).clone() for l in range(layers)])
+            torch.cuda.synchronize()
+            nq_now[0] = n
+            for _ in range(nsteps):
+                for leaf in ts.leaves.values():
+                    leaf.append_token(7)
+                out = sess.step()
+                outs.append([out[l][:n].clone() for l in range(layers)])
+            torch.cuda.synchronize()
+            for i in range(nsteps):
+                for l in range(layers):
+                    assert torch.equal(outs[i][l], refs[i][l]), ("lagged", runs, steps + i, l, mode, Hq, Hkv, prompts, widths, lens)
+            assert torch.equal(pe._storage, ps._storage), ("lagged", runs, steps)
+            assert torch.equal(te.req_to_token_pool.req_to_token, ts.req_to_token_pool.req_to_token), ("lagged", runs, steps)
+            steps += nsteps
+            return
         for _ in range(nsteps):
             for tree in (te, ts):
                 for leaf in tree.leaves.values():
