@@ -787,3 +787,16 @@ def test_head_dim_64_head_pairs_against_truth(name, geom, mode):
                 ref = torch.einsum("hs,hsd->hd", torch.softmax(s, dim=-1), vv)
                 assert (o[i].double() - ref).abs().max().item() < TOL_EXACT, (i, geom, mode)
     assert torch.equal(outs[0], outs[1])
+
+
+def test_c_program_through_the_c_abi(tmp_path):
+    """tests/c_abi/decode_from_c.c: hipMalloc / hipMemcpy from C, a TreeMetadata written by hand, deft_flatten_decode_f16, and a
+    double-precision restatement inside the program -- no Python and no torch anywhere between the caller and the kernels."""
+    import subprocess
+
+    from test_host_logic import _build_c_program
+
+    exe = _build_c_program(str(tmp_path / "decode_from_c"))
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-2000:]
+    assert "worst |err| vs double" in r.stdout

@@ -426,3 +426,27 @@ def test_layout_fetch_hands_over_the_journal_with_the_image():
     buf = np.zeros(64, dtype=np.int32)
     assert lib.deft_tree_journal_take(tree._native, _ptr(buf), 64) == 0  # ... and took the journal with it
     assert tree._epoch() == e
+
+
+def _build_c_program(out_path):
+    """The plain-C program of tests/c_abi against include/deft_amd.h and libdeft_amd.so, with gcc as a C11 compiler."""
+    import shutil
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib_dir = os.path.join(root, "deft_amd", "lib")
+    if shutil.which("gcc") is None or not os.path.exists("/opt/rocm/include/hip/hip_runtime_api.h"):
+        pytest.skip("no gcc / no ROCm headers")
+    cmd = ["gcc", "-std=c11", "-O1", "-Wall", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(root, "include"), "-I", "/opt/rocm/include",
+           os.path.join(root, "tests", "c_abi", "decode_from_c.c"), "-L", lib_dir, "-ldeft_amd", "-L", "/opt/rocm/lib", "-lamdhip64", "-lm",
+           "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib", "-o", out_path]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return out_path
+
+
+def test_header_and_library_serve_a_plain_c_program(tmp_path):
+    """include/deft_amd.h is a C header (no C++ in the boundary), and a C11 program links against the shared library with gcc alone;
+    running it needs a GPU (tests/test_gpu_parity.py::test_c_program_through_the_c_abi)."""
+    exe = _build_c_program(str(tmp_path / "decode_from_c"))
+    assert os.path.getsize(exe) > 0
