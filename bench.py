@@ -549,7 +549,8 @@ def prefill_lines(device, model: str):
     a fused qkv projection; TFLOP/s counts the causal half against the dense fp16 MFMA peak (2.5 PFLOP/s)."""
     Hq, Hkv, D, _ = GEOMETRY[model]
     out = {"kernel": "deft::prefill_kernel<128>", "bound": "mfma", "peak_TFLOPs": 2500.0, "prompts": {}}
-    for S in (4096, 16384):
+    # (the same prompt lengths with twice the heads of half the width -- head_dim 64, prefill_kernel<64> -- as "<S>_head_dim_64")
+    for S, (Hq, Hkv, D) in [(4096, (Hq, Hkv, D)), (16384, (Hq, Hkv, D)), (4096, (2 * Hq, 2 * Hkv, D // 2)), (16384, (2 * Hq, 2 * Hkv, D // 2))]:
         qkv = torch.randn((S, (Hq + 2 * Hkv) * D), dtype=torch.float16, device=device)
         q, k, v = (t.view(S, -1, D) for t in qkv.split([Hq * D, Hkv * D, Hkv * D], dim=-1))
         o = torch.empty((S, Hq, D), dtype=torch.float16, device=device)
@@ -566,8 +567,8 @@ def prefill_lines(device, model: str):
         e1.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / n
         flops = 2.0 * 2.0 * (S * (S + 1) / 2) * D * Hq
-        out["prompts"][str(S)] = {"us_per_layer": round(us, 1), "TFLOPs": round(flops / us / 1e6, 1),
-                                  "frac": round(flops / us / 1e6 / 2500.0, 4)}
+        out["prompts"][str(S) if D == GEOMETRY[model][2] else f"{S}_head_dim_{D}"] = {
+            "us_per_layer": round(us, 1), "TFLOPs": round(flops / us / 1e6, 1), "frac": round(flops / us / 1e6 / 2500.0, 4)}
         del qkv, o
     return out
 

@@ -61,6 +61,7 @@ vals = {
     "CFG5E2E": c5["end_to_end"]["ms_per_step"], "CFG5": f"{c5['us_per_layer']} ({c5.get('stage1_hbm_frac')})",
     "NODE": wl("northstar_4kx32_node"), "SEQ": wl("northstar_4kx32_seq"), "D64": wl("northstar_4kx32_d64"),
     "PF4": pf["4096"]["TFLOPs"], "PF16": pf["16384"]["TFLOPs"],
+    "PFD4": (pf.get("4096_head_dim_64") or {}).get("TFLOPs", "?"), "PFD16": (pf.get("16384_head_dim_64") or {}).get("TFLOPs", "?"),
     "CPU16": b["cpu_baseline"]["fp16"]["value"], "CPU": b["cpu_baseline"]["value"],
     "SDS": per_step(replay("speculative_64", "flatten")), "SDE": per_step(replay("speculative_64_eager", "flatten")),
     "SD": per_step(replay("speculative_64_pipelined", "flatten")),
