@@ -692,7 +692,10 @@ static int launch_stage1_np(const Stage1Params& p, int64_t unit_cap, const PlanV
     // 26.5 -> 24.1, 400-token branches 54.0 -> 48.4; whole layer: 8-tree forest 64.7 -> 60.0, Llama-3 north-star tree 23.5 ->
     // 22.8, Medusa-64 18.7 -> 18.0, ToT-50 (six passes per root tile) 24.0 -> 24.3.  NOT the sequential comparator, where every
     // leaf re-reads the shared prefix through the caches: 216 -> 298 us per layer (`reread`).
-    const bool nt = knob("DEFT_NP_NT", 1) != 0 && !reread && (int64_t)nq * p.G <= 1024;
+    // ... and not where a tile is folded by more than five 32-row passes (ToT-50 on Llama-3-8B: 50 queries x 4 = seven passes over every
+    // root tile; round 4, tools/ab.py DEFT_NP_NT=0,1: stage 1 17.99 vs 18.50 us without / with, while four passes -- the north-star tree
+    // on Llama-3-8B -- still gain: 18.29 -> 16.93): the later passes find the rows in L2 only if the first ones left them there.
+    const bool nt = knob("DEFT_NP_NT", (int64_t)nq * p.G <= 160 ? 1 : 0) != 0 && !reread && (int64_t)nq * p.G <= 1024;
     int rc;
     if (hd2) rc = nt ? raise_lds(reinterpret_cast<const void*>(&stage1_np_kernel<128, false, true, false, true>), SM::BYTES, ATTR_NP_HD2, "stage1_np_hd2")
                      : raise_lds(reinterpret_cast<const void*>(&stage1_np_kernel<128, false, false, false, true>), SM::BYTES, ATTR_NP_HD2_T, "stage1_np_hd2_t");
