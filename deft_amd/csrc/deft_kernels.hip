@@ -626,6 +626,9 @@ static int launch_qrows(const PlanView& pv, hipStream_t stream) {
 }
 
 static int np_chunk_knob() { return knob("DEFT_NP_CHUNK", 0); }  // tiles per chunk (0 = the plan kernel's rule)
+// a chunk whose tiles are folded by more 32-row passes than this asks for its K / V rows with the temporal cache policy
+// (launch_stage1_np; the record kernels write the flag)
+static int np_nt_passes_knob() { return knob("DEFT_NP_NT_PASSES", 5); }
 static int np_union_knob() { return knob("DEFT_NP_UNION", 0); }  // leaf tiles per union group (1 = off, 0 = rule)
 
 // Work items of stage 1 per chunk leader, for the plan's chunk-length rules (they weigh the number of workgroups against the
@@ -670,7 +673,7 @@ static int launch_plan(const Stage1Params& p, int NB, const PlanView& pv, const 
     if (rc) return rc;
     hipLaunchKernelGGL(flatten_records_kernel, dim3((unsigned)(pv.cap + 1)), dim3(128), 0, stream, p.block_q, p.block_q_cnts,
                        p.block_bitmasks, p.block_kv, p.block_lens, p.G, (int)p.rows, p.q_st, p.q_sh, p.kv_ss, ul, pv.hdr,
-                       pv.records, pv.row_q, ap.cache_loc, ap.n_new, ap.new_st * 2);
+                       pv.records, pv.row_q, ap.cache_loc, ap.n_new, ap.new_st * 2, np_nt_passes_knob(), NB, dims);
     rc = check_launch("flatten records launch");
     if (rc) return rc;
     return launch_qrows(pv, stream);
@@ -692,10 +695,13 @@ static int launch_stage1_np(const Stage1Params& p, int64_t unit_cap, const PlanV
     // 26.5 -> 24.1, 400-token branches 54.0 -> 48.4; whole layer: 8-tree forest 64.7 -> 60.0, Llama-3 north-star tree 23.5 ->
     // 22.8, Medusa-64 18.7 -> 18.0, ToT-50 (six passes per root tile) 24.0 -> 24.3.  NOT the sequential comparator, where every
     // leaf re-reads the shared prefix through the caches: 216 -> 298 us per layer (`reread`).
-    // ... and not where a tile is folded by more than five 32-row passes (ToT-50 on Llama-3-8B: 50 queries x 4 = seven passes over every
-    // root tile; round 4, tools/ab.py DEFT_NP_NT=0,1: stage 1 17.99 vs 18.50 us without / with, while four passes -- the north-star tree
-    // on Llama-3-8B -- still gain: 18.29 -> 16.93): the later passes find the rows in L2 only if the first ones left them there.
-    const bool nt = knob("DEFT_NP_NT", (int64_t)nq * p.G <= 160 ? 1 : 0) != 0 && !reread && (int64_t)nq * p.G <= 1024;
+    // ... and not for the chunks whose tiles are folded by more than five 32-row passes (ToT-50 on Llama-3-8B: 50 queries x 4 = seven
+    // passes over every root tile; round 4, tools/ab.py DEFT_NP_NT=0,1 on the whole launch: stage 1 17.99 vs 18.50 us without /
+    // with, while four passes -- the north-star tree on Llama-3-8B -- still gain: 18.29 -> 16.93): the later passes find the rows in
+    // L2 only if the first ones left them there.  That is a property of a RUN of tiles, not of the launch (an 8-tree forest has 64
+    // queries and one pass per tile), so the plan's record kernels flag it per chunk leader (desc[6]) and the kernel picks the
+    // policy per work item.
+    const bool nt = knob("DEFT_NP_NT", 1) != 0 && !reread;
     int rc;
     if (hd2) rc = nt ? raise_lds(reinterpret_cast<const void*>(&stage1_np_kernel<128, false, true, false, true>), SM::BYTES, ATTR_NP_HD2, "stage1_np_hd2")
                      : raise_lds(reinterpret_cast<const void*>(&stage1_np_kernel<128, false, false, false, true>), SM::BYTES, ATTR_NP_HD2_T, "stage1_np_hd2_t");
@@ -821,7 +827,7 @@ int deft_abi_version(void) { return 1; }
 // the experiments build folds its plan knobs into the value, so that callers which cache plans key them by it.
 int deft_plan_variant(void) {
     return ((np_chunk_knob() & 0xff) << 4) | ((np_union_knob() & 0xff) << 12) | ((g_plan_serial ? 1 : 0) << 24) |
-           ((g_plan_runcap & 0x3f) << 25);
+           (((g_plan_runcap & 0x3f) << 25) ^ ((np_nt_passes_knob() - 5) & 0xf));
 }
 
 // Internal hooks of the EXPERIMENTS build only (libdeft_amd_exp.so; the shipped library exports exactly what
@@ -1193,7 +1199,7 @@ static int launch_node_plan(const Stage1Params& p, int NE, int64_t rows_cap, con
     if (rc) return rc;
     hipLaunchKernelGGL(node_records_kernel, dim3((unsigned)(pv.cap + 1)), dim3(128), 0, stream, p.node_kv, p.node_kv_offset,
                        p.node_kv_len, p.node_q, p.node_q_offset, p.node_q_len, p.G, (int)p.rows, p.q_st, p.q_sh, p.kv_ss, ul,
-                       pv.hdr, pv.records, pv.row_q, ap.cache_loc, ap.n_new, ap.new_st * 2);
+                       pv.hdr, pv.records, pv.row_q, ap.cache_loc, ap.n_new, ap.new_st * 2, np_nt_passes_knob(), NE, dims);
     rc = check_launch("node records launch");
     if (rc) return rc;
     return launch_qrows(pv, stream);

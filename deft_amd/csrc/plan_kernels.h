@@ -601,8 +601,10 @@ __global__ __launch_bounds__(128) void flatten_records_kernel(const int64_t* blo
                                                               const int64_t* block_lens, int G, int rows, int64_t q_st,
                                                               int64_t q_sh, int64_t kv_stride_slot, UnitList ul,
                                                               const int32_t* hdr, char* plan, int32_t* row_q,
-                                                              const int32_t* cache_loc, int n_new, int64_t new_row_bytes) {
+                                                              const int32_t* cache_loc, int n_new, int64_t new_row_bytes,
+                                                              int nt_passes, int NBc, const int32_t* dims) {
     constexpr int np = 1;
+    const int NB = dims ? min(dims[5], NBc) : NBc;  // (device-side metadata: this step's block count, see flatten_units_kernel)
     __shared__ int sKeys[NEWMAP_SIZE], sVals[NEWMAP_SIZE];
     const int r = blockIdx.x;
     const int k = threadIdx.x;
@@ -672,6 +674,7 @@ __global__ __launch_bounds__(128) void flatten_records_kernel(const int64_t* blo
             desc[3] = ul.flags[u] >> 1;
             desc[4] = ul.ch_n[r];
             desc[5] = ul.ch_fb[r];
+            desc[6] = 0;  // one pass over the group's tiles: non-temporal
         }
         return;
     }
@@ -705,6 +708,16 @@ __global__ __launch_bounds__(128) void flatten_records_kernel(const int64_t* blo
         desc[3] = ul.flags[u] >> 1;  // run id: tiles with equal ids share one query list and may fold
         desc[4] = np ? ul.ch_n[r] : 0;
         desc[5] = np ? ul.ch_fb[r] : 0;
+        // How many 32-row passes fold this tile's rows in the whole launch: its own, plus those of the neighbouring blocks over the
+        // same slots (the query chunks of a node of more than max_q_len queries alternate over its tiles).  Many: the later ones
+        // want the rows in L2, so the chunk asks for them with the temporal policy (launch_stage1_np).
+        int passes = (cnt * G + MQ - 1) / MQ;
+        const int64_t slot0 = block_kv[(int64_t)t * TILE];
+        for (int o = t - 1; o >= 0 && passes <= nt_passes && block_kv[(int64_t)o * TILE] == slot0; --o)
+            passes += ((int)block_q_cnts[o] * G + MQ - 1) / MQ;
+        for (int o = t + 1; o < NB && passes <= nt_passes && block_kv[(int64_t)o * TILE] == slot0; ++o)
+            passes += ((int)block_q_cnts[o] * G + MQ - 1) / MQ;
+        desc[6] = passes > nt_passes;
     }
 }
 
@@ -849,7 +862,10 @@ __global__ __launch_bounds__(128) void node_records_kernel(const int64_t* node_k
                                                            const int64_t* node_q_offset, const int64_t* node_q_len, int G,
                                                            int rows, int64_t q_st, int64_t q_sh, int64_t kv_stride_slot,
                                                            UnitList ul, const int32_t* hdr, char* plan, int32_t* row_q,
-                                                           const int32_t* cache_loc, int n_new, int64_t new_row_bytes) {
+                                                           const int32_t* cache_loc, int n_new, int64_t new_row_bytes,
+                                                           int nt_passes, int NEc, const int32_t* dims) {
+    const int NE = dims ? min(dims[1], NEc) : NEc;
+    __shared__ int sPasses;
     constexpr int np = 1;
     __shared__ int sKeys[NEWMAP_SIZE], sVals[NEWMAP_SIZE];
     const int r = blockIdx.x;
@@ -932,11 +948,22 @@ __global__ __launch_bounds__(128) void node_records_kernel(const int64_t* node_k
             desc[1] = prow;
             desc[2] = 1;
             desc[3] = ul.flags[u] >> 1;
+            desc[6] = 0;
         }
         return;
     }
     const int e = e0, tt = aux;
     const int64_t kv0 = node_kv_offset[e] + (int64_t)tt * TILE;
+    {   // How many 32-row passes fold this node's rows in the whole launch (see flatten_records_kernel): the entries of one node --
+        // up to 32 of its queries over one stretch of its slots each (tree_cache.py:744-760) -- repeat the slots; thread k looks at
+        // entry e - 64 + k.
+        if (k == 0) sPasses = 0;
+        __syncthreads();
+        const int o = e - 64 + k;
+        if (o >= 0 && o < NE && node_kv_len[o] == node_kv_len[e] && node_kv[node_kv_offset[o]] == node_kv[node_kv_offset[e]])
+            atomicAdd(&sPasses, ((int)node_q_len[o] * G + MQ - 1) / MQ);
+        __syncthreads();
+    }
     const int len = (int)min((int64_t)TILE, node_kv_len[e] - (int64_t)tt * TILE);
     const int64_t q0 = node_q_offset[e];
     const int ql = (int)node_q_len[e];
@@ -967,6 +994,7 @@ __global__ __launch_bounds__(128) void node_records_kernel(const int64_t* node_k
         desc[1] = prow;
         desc[2] = ul.flags[u] & 1;
         desc[3] = ul.flags[u] >> 1;
+        desc[6] = sPasses > nt_passes;
     }
 }
 

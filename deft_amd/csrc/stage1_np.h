@@ -250,14 +250,16 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
         const int32_t hi = reinterpret_cast<const int32_t*>(ro)[2 * (l & 31) + 1];
         has_new = ABL(1024) || __builtin_amdgcn_ballot_w64(hi < 0) != 0ull;
     };
-    auto issue_k = [&]() {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of the slice being overwritten
+    // NT kernels: a chunk whose tiles are folded by many passes (the plan's desc[6]) asks for its rows with the ordinary policy
+    bool temporal = false;  // (wave-uniform, per work item)
+    auto issue_k_as = [&](auto ntc) __attribute__((always_inline)) {
+        constexpr bool nt = decltype(ntc)::value;
         if (!has_new) {
 #pragma unroll
             for (int i = 0; i < LPT; ++i) {
                 if (ABL(8)) continue;  // (experiments: 8 no K / V requests at all; 128 every row is the pool's first -- cache hits)
                 const char* src = ABL(128) ? kb_pool : kb_pool + rowoff[i];
-                if constexpr (NT) dma16nt(src + kchunk_b[i & 3], ldsK + (uint32_t)i * 1024u);
+                if constexpr (nt) dma16nt(src + kchunk_b[i & 3], ldsK + (uint32_t)i * 1024u);
                 else dma16(src + kchunk_b[i & 3], ldsK + (uint32_t)i * 1024u);
             }
             return;
@@ -266,18 +268,18 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
         for (int i = 0; i < LPT; ++i) {
             if (ABL(8)) continue;
             const char* src = ABL(128) ? kb_pool : rowoff[i] < 0 ? kb_new + (rowoff[i] & ~NEW_ROW) : kb_pool + rowoff[i];
-            if constexpr (NT) dma16nt(src + kchunk_b[i & 3], ldsK + (uint32_t)i * 1024u);
+            if constexpr (nt) dma16nt(src + kchunk_b[i & 3], ldsK + (uint32_t)i * 1024u);
             else dma16(src + kchunk_b[i & 3], ldsK + (uint32_t)i * 1024u);
         }
     };
-    auto issue_v = [&]() {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    auto issue_v_as = [&](auto ntc) __attribute__((always_inline)) {
+        constexpr bool nt = decltype(ntc)::value;
         if (!has_new) {
 #pragma unroll
             for (int i = 0; i < LPT; ++i) {
                 if (ABL(8)) continue;
                 const char* src = ABL(128) ? vb_pool : vb_pool + rowoff[i];
-                if constexpr (NT) dma16nt(src, ldsV + (uint32_t)i * 1024u);
+                if constexpr (nt) dma16nt(src, ldsV + (uint32_t)i * 1024u);
                 else dma16(src, ldsV + (uint32_t)i * 1024u);
             }
             return;
@@ -286,9 +288,19 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
         for (int i = 0; i < LPT; ++i) {
             if (ABL(8)) continue;
             const char* src = ABL(128) ? vb_pool : rowoff[i] < 0 ? vb_new + (rowoff[i] & ~NEW_ROW) : vb_pool + rowoff[i];
-            if constexpr (NT) dma16nt(src, ldsV + (uint32_t)i * 1024u);
+            if constexpr (nt) dma16nt(src, ldsV + (uint32_t)i * 1024u);
             else dma16(src, ldsV + (uint32_t)i * 1024u);
         }
+    };
+    auto issue_k = [&]() __attribute__((always_inline)) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of the slice being overwritten
+        if (NT && !temporal) issue_k_as(std::true_type{});
+        else issue_k_as(std::false_type{});
+    };
+    auto issue_v = [&]() __attribute__((always_inline)) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (NT && !temporal) issue_v_as(std::true_type{});
+        else issue_v_as(std::false_type{});
     };
     auto issue_q = [&]() {  // rows 8w .. 8w+7 of the shared Q buffer, offsets from aux slot 0
         const int32_t* qs = reinterpret_cast<const int32_t*>(smem + aux0 + 256 + 128);
@@ -341,6 +353,7 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
     sd4 = dsc[4];
     sd0 = dsc[0];
     sd5 = dsc[5];
+    temporal = NT && __builtin_amdgcn_readfirstlane(dsc[6]) != 0;
     const int n = sd4;  // tiles of this chunk (> 0: items only name leaders)
     const int nv = sd0;
     fb = sd5;

@@ -74,6 +74,12 @@ def run(shape):
         assert torch.equal(hd, plans[0][0])
         assert torch.equal(rec, plans[0][1])
     print("flatten units", int(plans[0][0][:4].view(torch.int32).item()), "leaders", int(plans[0][0][4:8].view(torch.int32).item()))
+
+    def temporal_leaders(rec):  # chunk leaders (desc[4] > 0) whose rows are asked for with the temporal cache policy (desc[6])
+        d = rec.view(-1, 2048)[:, 1536:1568].contiguous().view(torch.int32).view(-1, 8)
+        return int(((d[:, 4] > 0) & (d[:, 6] != 0)).sum().item())
+
+    print("flatten temporal leaders", temporal_leaders(plans[0][1]))
     # the Node plan (entries cut into tiles, small entries packed) has the same three forms
     nd = [md.node_kv, md.node_kv_offset, md.node_kv_len, md.node_q, md.node_q_offset, md.node_q_len]
     NE, Pn, total_kv = md.node_kv_offset.shape[0], md.node_q.shape[0], md.node_kv.shape[0]
@@ -100,6 +106,7 @@ def run(shape):
         assert torch.equal(o, outs[0])
         assert torch.equal(hd, plans[0][0])
         assert torch.equal(rec, plans[0][1])
+    print("node temporal leaders", temporal_leaders(plans[0][1]))
 
 
 if __name__ == "__main__":

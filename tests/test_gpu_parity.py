@@ -644,6 +644,17 @@ def test_plan_build_forms_give_identical_plans(shape):
         # leaders x 8 KV heads = 152 workgroups), so the 64-tile run is cut into 22 chunks of 3 (round 4's rule); the leaves'
         # 320 tokens share 3 blocks: 25 leaders, in the serial and the parallel form of the rule alike
         assert "flatten units 67 leaders 25" in r.stdout, r.stdout[-500:]
+        # 8 queries x 4 heads of a group = one 32-row pass over every tile: every chunk reads its rows non-temporally
+        assert "flatten temporal leaders 0\n" in r.stdout and "node temporal leaders 0\n" in r.stdout, r.stdout[-500:]
+    if shape == (8, 2, 1500, 70, 3):
+        # 70 queries x 4 heads of a group over the 1500-token prefix = 4 + 4 + 1 passes (three query chunks of <= 32) over each of
+        # its tiles: more than five, so the chunks over the prefix ask for their rows with the temporal policy (desc[6]) and the
+        # later passes find them in L2; the leaves' tiles (one pass) do not.  Flatten: 12 prefix tiles x 9 passes in 4-tile chunks.
+        import re
+        fl = int(re.search(r"flatten temporal leaders (\d+)", r.stdout).group(1))
+        nd = int(re.search(r"node temporal leaders (\d+)", r.stdout).group(1))
+        leaders = int(re.search(r"flatten units \d+ leaders (\d+)", r.stdout).group(1))
+        assert 0 < fl < leaders and nd > 0, r.stdout[-500:]
 
 
 def test_decode_step_inside_inference_mode():
