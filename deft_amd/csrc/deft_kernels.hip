@@ -735,6 +735,7 @@ static int launch_stage1_np(const Stage1Params& p, int64_t unit_cap, const PlanV
     npp.s = p;
     npp.hdr = pv.hdr;
     npp.fast_n = knob("DEFT_NP_FAST", 2 * num_cus());
+    npp.mirror = knob("DEFT_NP_MIRROR", 0);
     npp.s.ablate = knob("DEFT_STAGE1_ABLATE", 0);
     npp.plan = pv.records;
     npp.k_new = ap.k_new;

@@ -37,6 +37,7 @@ struct NpParams {
     Stage1Params s;
     const char* plan;  // [cap+1][PLAN_BYTES], leaders first (np_record_order)
     const int32_t* hdr;  // plan header (plan_records.h): hdr[1] = number of chunk leaders
+    int mirror;        // capped grids: workgroup b takes items b, 2W-1-b, 2W+b, 4W-1-b, ... (the SHORT first items get the extra ones)
     int fast_n;        // workgroups < fast_n (the ones resident at launch) request tile 0's offsets before anything else
     // fused paged append (optional): rows whose plan offset has bit 63 set are read from k_new / v_new
     const _Float16* k_new;
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
     // long shared-prefix chunks come first.  Item `bid` is this workgroup's first; a workgroup whose index has
     // further items (capped grids) takes item + W, item + 2 W, ... in a loop.
     int NI = 0x7fffffff;  // leaders x heads, read with the first item's descriptor
-    int item = bid;
+    int item = bid, round = 0;
     int rec0 = 0, kvh = 0, fb = 0, sd4 = 0, sd0 = 0, sd5 = 0;
     auto rec_of = [&](int i) { return np.plan + (int64_t)(i == 0 ? rec0 : fb + i - 1) * PLAN_BYTES; };
 
@@ -609,9 +610,10 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
     }
 
     if (ABL(16)) {  // (experiments build: no epilogue at all)
-        if (item + W >= NI) break;
+        const int next = np.mirror ? ((++round & 1) ? (round + 1) * W - 1 - bid : round * W + bid) : item + W;
+        if (next >= NI) break;
         lds_barrier();
-        item += W;
+        item = next;
         continue;
     }
     if (DBG) t_epi = wall_clock64();
@@ -729,9 +731,12 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
 #endif
     // Next item of a capped grid: record capacity beyond the chunk leaders would otherwise be launched as workgroups
     // that only find out that they have nothing to do (tens of thousands for the sequential comparator's entries).
-    if (item + W >= NI) break;
-    lds_barrier();  // every wave is done reading the others' slices
-    item += W;
+    {
+        const int next = np.mirror ? ((++round & 1) ? (round + 1) * W - 1 - bid : round * W + bid) : item + W;
+        if (next >= NI) break;
+        lds_barrier();  // every wave is done reading the others' slices
+        item = next;
+    }
     }  // work items
 }
 
