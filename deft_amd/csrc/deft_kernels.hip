@@ -723,19 +723,28 @@ static int launch_stage1_np(const Stage1Params& p, int64_t unit_cap, const PlanV
     // build): 3 x slots is never worse and up to 22 % better for MHA (sequential north-star tree 261 -> 204 us,
     // 400-token branches 56.8 -> 54.2); GQA, where every workgroup's tiles come from L2 after the first pass, prefers
     // resident workgroups only (ToT-50 28.1 -> 24.0 us, 8-tree forest 65.5 -> 60.9).
+    bool mirror;
     {
         // GQA launches whose whole record capacity is within 8 x the resident slots (a single tree: the Llama-3
-        // north-star tree, ToT-50) have about one item per workgroup anyway and gain 2 us from 2 x slots.
+        // north-star tree, ToT-50) have about one item per workgroup anyway and gain 2 us from 2 x slots -- or (late round 4) from
+        // the resident workgroups alone taking their further items in MIRRORED order (b, 2W-1-b, 2W+b, ...): the items are sorted
+        // long chunks first, so the extra ones go to the workgroups whose first item was a short leaf tile, and start without a
+        // dispatch (tools/knob_layer.sh, us per layer: GQA 4k x 32 20.7 hardware-dispatched at 2 x slots / 22.7 resident in plain
+        // order / 20.4 mirrored; ToT-50 21.8 / 23.3 / 21.6; one 8k x 8 tree equal; NOT the large launches: north-star 36.2 / 41.4 /
+        // 39.8, the 8-tree forest 54.8 / 55.0 / 56.6).
         const bool small_gqa = unit_cap * HP <= 16LL * num_cus();
-        const int capx = knob("DEFT_NP_GRIDCAP", p.G > 1 ? (small_gqa ? 2 : 1) : 3);
+        mirror = knob("DEFT_NP_MIRROR", p.G > 1 && small_gqa ? 1 : 0) != 0;
+        const int capx = knob("DEFT_NP_GRIDCAP", p.G > 1 ? 1 : 3);
         const int64_t cap_wgs = (int64_t)capx * 2LL * num_cus();
         if (cap_wgs > 0 && grid > cap_wgs) grid = cap_wgs;
+        const int gx = knob("DEFT_NP_GRID", 0);  // (experiments build, tests: a tiny grid = many rounds of the item loop)
+        if (gx > 0 && grid > gx) grid = gx;
     }
     NpParams npp{};
     npp.s = p;
     npp.hdr = pv.hdr;
     npp.fast_n = knob("DEFT_NP_FAST", 2 * num_cus());
-    npp.mirror = knob("DEFT_NP_MIRROR", 0);
+    npp.mirror = mirror ? 1 : 0;
     npp.s.ablate = knob("DEFT_STAGE1_ABLATE", 0);
     npp.plan = pv.records;
     npp.k_new = ap.k_new;

@@ -74,6 +74,18 @@ def run(shape):
         assert torch.equal(hd, plans[0][0])
         assert torch.equal(rec, plans[0][1])
     print("flatten units", int(plans[0][0][:4].view(torch.int32).item()), "leaders", int(plans[0][0][4:8].view(torch.int32).item()))
+    # the item loop of a capped grid (a workgroup takes several chunk leaders), in plain (b, b + W, ...) and in mirrored order
+    # (b, 2W - 1 - b, 2W + b, ...: GQA launches of one tree): forced to many rounds by a tiny grid, every item exactly once --
+    # the same bits as one workgroup per item
+    for grid, mirror in ((37, 1), (37, 0), (5, 1), (1, 1)):
+        os.environ["DEFT_NP_GRID"], os.environ["DEFT_NP_MIRROR"] = str(grid), str(mirror)
+        try:
+            o = torch.full_like(q, float("nan"))
+            deft_amd.tree_attention_subtree_fwd(q, kb, vb, o, *_flatten_args(md))
+            torch.cuda.synchronize()
+        finally:
+            del os.environ["DEFT_NP_GRID"], os.environ["DEFT_NP_MIRROR"]
+        assert torch.equal(o, outs[0]), (grid, mirror)
 
     def temporal_leaders(rec):  # chunk leaders (desc[4] > 0) whose rows are asked for with the temporal cache policy (desc[6])
         d = rec.view(-1, 2048)[:, 1536:1568].contiguous().view(torch.int32).view(-1, 8)
