@@ -423,12 +423,18 @@ __global__ __launch_bounds__(1024) void flatten_units_kernel(const int64_t* bloc
     __syncthreads();
     // Phase 1b (tile-parallel order): for every block, how many blocks a union group starting there would take
     // (0 = none), one thread per block, into bits 8.. of sOpen -- the walk below then only looks the answer up.
-    const int ucap = (UNION_CAP * G <= MQ) ? UNION_CAP : MQ / G;  // union queries whose virtual rows fit one pass
+    int ucap = (UNION_CAP * G <= MQ) ? UNION_CAP : MQ / G;  // union queries whose virtual rows fit one pass
+    // GQA (late round 4, tools/knob_layer.sh DEFT_NP_UNION=2 | cap << 8, us per layer): pairs of tiles with at most THREE queries
+    // between them -- a branch end straddling a block boundary, [a, b] + [b, c] -- fold as one group: the north-star tree on
+    // Llama-3-8B 20.4 -> 19.5 (400 one-tile leaf workgroups become 200); pairs of four queries (ToT-50's [l1, l2] + [l3, l4]) cost
+    // 1.7 us there and 1-2 on the 8-tree forest, so the cap is three.
+    if (G > 1) ucap = min(ucap, 3);
+    if ((union_len >> 8) > 0) ucap = min(ucap, union_len >> 8);  // (experiments: bits 8.. of the knob cap the union's queries)
     auto union_len_at = [&](int t) {
         (void)t;
-        int ulen = union_len;
+        int ulen = union_len & 0xff;
         // (head pairs, Hkv < 0: groups of two -- their launches want workgroups, tools/ab_step.py on the head_dim-64 north-star tree)
-        if (ulen <= 0) ulen = G > 1 ? 1 : (Hkv < 0 ? 2 : ((int64_t)NB * Hkv < 2048 ? 4 : 3));  // measured, tools/np_sweep.sh / tools/ab.py
+        if (ulen <= 0) ulen = G > 1 || Hkv < 0 ? 2 : ((int64_t)NB * Hkv < 2048 ? 4 : 3);  // measured, tools/np_sweep.sh / tools/ab.py
         return ulen;
     };
     if (np && ucap >= 2)
