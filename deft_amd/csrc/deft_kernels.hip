@@ -506,7 +506,20 @@ static unsigned long long* g_dbg = nullptr;  // per-workgroup time stamps, see d
 // reached only by trees whose run tables exceed the LDS.
 static int g_plan_serial = 0, g_plan_runcap = 0;
 #else
+#ifdef DEFT_FIXED_KNOBS
+// Rule variants of the SHIPPED code (`make rules KNOBS="DEFT_NP_CHUNK=5;DEFT_NP_UNION=2" NAME=x` -> libdeft_amd_rules_x.so): the
+// knobs named in the compile-time string take its values, everything else is the shipped build -- no environment, no time stamps,
+// no ablation branches.  tools/ab_rules.sh compares such builds on one box: the experiments build is 1.5-2 us per layer slower
+// than the shipped one and does not always rank rules the same way (head_dim-64 union groups of 3: -0.9 us there, +0.4 here).
+static int knob(const char* name, int dflt) {
+    const size_t n = strlen(name);
+    for (const char* p = DEFT_FIXED_KNOBS; p && *p; p = strchr(p, ';') ? strchr(p, ';') + 1 : nullptr)
+        if (!strncmp(p, name, n) && p[n] == '=') return atoi(p + n + 1);
+    return dflt;
+}
+#else
 static inline int knob(const char*, int dflt) { return dflt; }
+#endif
 static constexpr unsigned long long* g_dbg = nullptr;
 static constexpr int g_plan_serial = 0, g_plan_runcap = 0;
 #endif

@@ -167,6 +167,20 @@ __device__ inline void np_record_order(const UnitList& ul, int R, int Hkv, int G
             });
             if (2 * n0 * Hkv < slots && 2 * n1 * Hkv <= slots) --C;
         }
+        // GQA: the launch should fit the resident slots -- chunks grow (up to 8 tiles) until there are fewer workgroups than slots:
+        // a second round of workgroups, every one with its ramp and its epilogue, costs more than longer chunks do (late round 4,
+        // rule variants of the shipped build, tools/ab_rules.sh: ToT-50 on Llama-3-8B, 6 passes over 32 root tiles + 28 leaf
+        // tiles, 8 KV heads: 608 workgroups of 4 tiles 20.5 us per layer, 560 of 5 21.0, 512 of 6 20.9, 464 of 7 19.65, 416 of 8 20.0).
+        // (Only if some length up to 8 does fit: a launch with more leaf tiles than slots keeps its short chunks.)
+        if (G > 1 && !pairs)
+            for (int c2 = C; c2 <= 8; ++c2) {
+                int64_t n = 0;
+                for_runs([&](int, int nt, int uni) { n += uni ? 1 : (nt + c2 - 1) / c2; });
+                if (n * Hkv < slots) {
+                    C = c2;
+                    break;
+                }
+            }
     }
     // Leaders of LONG chunks (>= LONG_CHUNK tiles: the shared prefixes) come before all others, whatever run they belong
     // to: a capped grid hands item b + W to the workgroup that finishes item b, so with the leaders run by run a batch of
@@ -239,6 +253,14 @@ __device__ inline void record_order_parallel(const UnitList& ul, const RunTable&
                 const int64_t n1 = wave_sum([C](int nt, int uni) { return uni ? 1 : (nt + C - 2) / (C - 1); });
                 if (2 * n0 * Hkv < slots && 2 * n1 * Hkv <= slots) --C;
             }
+            if (G > 1 && !pairs)  // (np_record_order: a GQA launch should fit the resident slots)
+                for (int c2 = C; c2 <= 8; ++c2) {
+                    const int64_t n = wave_sum([c2](int nt, int uni) { return uni ? 1 : (nt + c2 - 1) / c2; });
+                    if (n * Hkv < slots) {
+                        C = c2;
+                        break;
+                    }
+                }
         }
         // leaders: long chunks first (np_record_order), each class in run order; followers in run order
         int leadL = 0, leadS = 0, foll = 0;
@@ -433,7 +455,8 @@ __global__ __launch_bounds__(1024) void flatten_units_kernel(const int64_t* bloc
     auto union_len_at = [&](int t) {
         (void)t;
         int ulen = union_len & 0xff;
-        // (head pairs, Hkv < 0: groups of two -- their launches want workgroups, tools/ab_step.py on the head_dim-64 north-star tree)
+        // (head pairs, Hkv < 0: groups of two -- their launches want workgroups, tools/ab_step.py on the head_dim-64 north-star tree;
+        //  three measured 0.9 us per layer faster in the experiments build and 0.4 slower in the shipped one, tools/ab_lib.sh)
         if (ulen <= 0) ulen = G > 1 || Hkv < 0 ? 2 : ((int64_t)NB * Hkv < 2048 ? 4 : 3);  // measured, tools/np_sweep.sh / tools/ab.py
         return ulen;
     };
