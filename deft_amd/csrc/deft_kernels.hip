@@ -756,7 +756,11 @@ static int launch_stage1_np(const Stage1Params& p, int64_t unit_cap, const PlanV
     NpParams npp{};
     npp.s = p;
     npp.hdr = pv.hdr;
-    npp.fast_n = knob("DEFT_NP_FAST", 2 * num_cus());
+    // The speculative ramp (stage1_np.h: tile 0's offsets requested before the descriptor is known) for the workgroups resident at
+    // launch.  MHA: the first CUs-many only -- a workgroup of the second half that turns out to have no item (Medusa-64: 256 items
+    // on 512 slots) waits for its speculative requests before it may exit (rule variants of the shipped build, tools/ab_rules.sh:
+    // Medusa-64 12.8 -> 12.5 us per layer, the north-star tree / 1k x 32 / head_dim 64 unchanged; ToT-50, GQA, loses 0.5 with it).
+    npp.fast_n = knob("DEFT_NP_FAST", (p.G > 1 ? 2 : 1) * num_cus());
     npp.mirror = mirror ? 1 : 0;
     npp.s.ablate = knob("DEFT_STAGE1_ABLATE", 0);
     npp.plan = pv.records;
