@@ -399,6 +399,8 @@ __global__ __launch_bounds__(1024) void flatten_units_kernel(const int64_t* bloc
     int* sQ = sOff + NBc;
     int* sRun = sQ + (qtab ? UNION_CAP * NBc : 0);
     RunTable rt{sRun, sRun + run_cap, sRun + 2 * run_cap, 0, run_cap};
+    __shared__ int sEst[2];  // GQA: leaf-like blocks (at most three queries); 32-row passes of all other blocks
+    if (threadIdx.x == 0) sEst[0] = sEst[1] = 0;
     for (int t = threadIdx.x; t < NB; t += blockDim.x) {
         const int cnt = (int)block_q_cnts[t];
         sCnt[t] = cnt;
@@ -406,6 +408,21 @@ __global__ __launch_bounds__(1024) void flatten_units_kernel(const int64_t* bloc
         sPass[t] = (cnt * G + MQ - 1) / MQ;
     }
     __syncthreads();
+    if (G > 1) {
+        int small = 0, passes = 0;
+        for (int t = threadIdx.x; t < NB; t += blockDim.x) {
+            if (sCnt[t] <= 3) ++small;
+            else passes += sPass[t];
+        }
+        for (int m = 32; m > 0; m >>= 1) {
+            small += __shfl_xor(small, m, 64);
+            passes += __shfl_xor(passes, m, 64);
+        }
+        if ((threadIdx.x & 63) == 0 && (small | passes)) {
+            atomicAdd(&sEst[0], small);
+            atomicAdd(&sEst[1], passes);
+        }
+    }
     // Does block t's query list differ from the one 1 / 2 / 3 / 4 blocks back?  Half a wave per block, lane i on
     // list entry i (and i + 32, ... for longer lists), the five loads of an entry independent of each other: one
     // round trip per block instead of one per list entry (a shared-prefix block has 32 entries, and a thread walking
@@ -450,14 +467,25 @@ __global__ __launch_bounds__(1024) void flatten_units_kernel(const int64_t* bloc
     // between them -- a branch end straddling a block boundary, [a, b] + [b, c] -- fold as one group: the north-star tree on
     // Llama-3-8B 20.4 -> 19.5 (400 one-tile leaf workgroups become 200); pairs of four queries (ToT-50's [l1, l2] + [l3, l4]) cost
     // 1.7 us there and 1-2 on the 8-tree forest, so the cap is three.
-    if (G > 1) ucap = min(ucap, 3);
+    // ... and only where pairing is what makes the launch FIT the resident slots (rule variants of the shipped build at other
+    // branch lengths, tools/ab_rules.sh BENCH_EXTRA="--branch-len N", us per layer with / without pairs: 100 tokens 17.75 / 16.15 --
+    // 456 workgroups fit anyway, pairs only make them longer; 200 tokens 18.77 / 19.75 -- 656 become 456; 400 tokens 25.0 / 25.05 and
+    // 1000 tokens 38.3 / 37.55 -- far more leaf tiles than slots either way).  Estimated per KV head from the blocks alone: the
+    // leaf-like blocks (at most three queries) are a workgroup each, everything else a workgroup per four passes.
+    bool gqa_pairs = false;
+    if (G > 1) {
+        ucap = min(ucap, 3);
+        const int hk = Hkv < 0 ? -Hkv : Hkv;
+        const int64_t rest = (sEst[1] + 3) / 4;
+        gqa_pairs = (rest + sEst[0]) * hk > slots && (rest + (sEst[0] + 1) / 2) * hk <= slots;
+    }
     if ((union_len >> 8) > 0) ucap = min(ucap, union_len >> 8);  // (experiments: bits 8.. of the knob cap the union's queries)
     auto union_len_at = [&](int t) {
         (void)t;
         int ulen = union_len & 0xff;
         // (head pairs, Hkv < 0: groups of two -- their launches want workgroups, tools/ab_step.py on the head_dim-64 north-star tree;
         //  three measured 0.9 us per layer faster in the experiments build and 0.4 slower in the shipped one, tools/ab_lib.sh)
-        if (ulen <= 0) ulen = G > 1 || Hkv < 0 ? 2 : ((int64_t)NB * Hkv < 2048 ? 4 : 3);  // measured, tools/np_sweep.sh / tools/ab.py
+        if (ulen <= 0) ulen = G > 1 ? (gqa_pairs ? 2 : 1) : (Hkv < 0 ? 2 : ((int64_t)NB * Hkv < 2048 ? 4 : 3));  // measured, tools/np_sweep.sh / tools/ab.py
         return ulen;
     };
     if (np && ucap >= 2)
