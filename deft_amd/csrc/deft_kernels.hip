@@ -557,7 +557,7 @@ static int num_cus() {
     return d.cus;
 }
 enum : unsigned { ATTR_NP = 4,  // (bits 0-1, 8-11: the head_dim 64 / 32 / 16 kernels)
-                  ATTR_UNITS = 8, ATTR_NODE_UNITS = 16, ATTR_PREFILL = 32, ATTR_TREE = 64, ATTR_NP_ROPE = 128, ATTR_NP_T = 8192, ATTR_NP_ROPE_T = 16384, ATTR_NP_HD2 = 32768, ATTR_NP_HD2_T = 65536, ATTR_PREFILL_64 = 1u << 17 };
+                  ATTR_UNITS = 8, ATTR_NODE_UNITS = 16, ATTR_PREFILL = 32, ATTR_TREE = 64, ATTR_NP_ROPE = 128, ATTR_NP_T = 8192, ATTR_NP_ROPE_T = 16384, ATTR_NP_HD2 = 32768, ATTR_NP_HD2_T = 65536, ATTR_PREFILL_64 = 1u << 17, ATTR_NP_DYN = 1u << 18, ATTR_NP_ROPE_DYN = 1u << 19, ATTR_NP_HD2_DYN = 1u << 20 };
 static int raise_lds(const void* fn, int bytes, unsigned bit, const char* what) {  // idempotent; races are harmless
     DeviceState& d = dev_state();
     if (d.attrs & bit) return DEFT_OK;
@@ -715,13 +715,19 @@ static int launch_stage1_np(const Stage1Params& p, int64_t unit_cap, const PlanV
     // queries and one pass per tile), so the plan's record kernels flag it per chunk leader (desc[6]) and the kernel picks the
     // policy per work item.
     const bool nt = knob("DEFT_NP_NT", 1) != 0 && !reread;
+    // DYN instantiations (stage1_np.h): per-chunk cache policy and the mirrored item order -- GQA launches, and launches with so
+    // many queries that some node may be folded by more than five passes
+    const bool dyn = nt && (p.G > 1 || (int64_t)nq * p.G > 160);
     int rc;
-    if (hd2) rc = nt ? raise_lds(reinterpret_cast<const void*>(&stage1_np_kernel<128, false, true, false, true>), SM::BYTES, ATTR_NP_HD2, "stage1_np_hd2")
-                     : raise_lds(reinterpret_cast<const void*>(&stage1_np_kernel<128, false, false, false, true>), SM::BYTES, ATTR_NP_HD2_T, "stage1_np_hd2_t");
-    else if (rope) rc = nt ? raise_lds(reinterpret_cast<const void*>(&stage1_np_kernel<128, true, true>), SM::BYTES, ATTR_NP_ROPE, "stage1_np_rope")
-                      : raise_lds(reinterpret_cast<const void*>(&stage1_np_kernel<128, true, false>), SM::BYTES, ATTR_NP_ROPE_T, "stage1_np_rope_t");
-    else rc = nt ? raise_lds(reinterpret_cast<const void*>(&stage1_np_kernel<128, false, true>), SM::BYTES, ATTR_NP, "stage1_np")
-                 : raise_lds(reinterpret_cast<const void*>(&stage1_np_kernel<128, false, false>), SM::BYTES, ATTR_NP_T, "stage1_np_t");
+    if (hd2) rc = dyn  ? raise_lds(reinterpret_cast<const void*>(&stage1_np_kernel<128, false, true, false, true, true>), SM::BYTES, ATTR_NP_HD2_DYN, "stage1_np_hd2_dyn")
+                 : nt ? raise_lds(reinterpret_cast<const void*>(&stage1_np_kernel<128, false, true, false, true>), SM::BYTES, ATTR_NP_HD2, "stage1_np_hd2")
+                      : raise_lds(reinterpret_cast<const void*>(&stage1_np_kernel<128, false, false, false, true>), SM::BYTES, ATTR_NP_HD2_T, "stage1_np_hd2_t");
+    else if (rope) rc = dyn  ? raise_lds(reinterpret_cast<const void*>(&stage1_np_kernel<128, true, true, true, false, true>), SM::BYTES, ATTR_NP_ROPE_DYN, "stage1_np_rope_dyn")
+                       : nt ? raise_lds(reinterpret_cast<const void*>(&stage1_np_kernel<128, true, true>), SM::BYTES, ATTR_NP_ROPE, "stage1_np_rope")
+                            : raise_lds(reinterpret_cast<const void*>(&stage1_np_kernel<128, true, false>), SM::BYTES, ATTR_NP_ROPE_T, "stage1_np_rope_t");
+    else rc = dyn  ? raise_lds(reinterpret_cast<const void*>(&stage1_np_kernel<128, false, true, false, false, true>), SM::BYTES, ATTR_NP_DYN, "stage1_np_dyn")
+             : nt ? raise_lds(reinterpret_cast<const void*>(&stage1_np_kernel<128, false, true>), SM::BYTES, ATTR_NP, "stage1_np")
+                  : raise_lds(reinterpret_cast<const void*>(&stage1_np_kernel<128, false, false>), SM::BYTES, ATTR_NP_T, "stage1_np_t");
     if (rc) return rc;
     if (unit_cap <= 0) return DEFT_OK;
     int64_t grid = unit_cap * HP;
@@ -772,7 +778,10 @@ static int launch_stage1_np(const Stage1Params& p, int64_t unit_cap, const PlanV
     npp.dbg = g_dbg;
     npp.cos_sin = ap.cos_sin;
     const dim3 g((unsigned)grid), b(256);
-    if (hd2 && nt) hipLaunchKernelGGL((stage1_np_kernel<128, false, true, false, true>), g, b, SM::BYTES, stream, npp);
+    if (hd2 && dyn) hipLaunchKernelGGL((stage1_np_kernel<128, false, true, false, true, true>), g, b, SM::BYTES, stream, npp);
+    else if (rope && dyn) hipLaunchKernelGGL((stage1_np_kernel<128, true, true, true, false, true>), g, b, SM::BYTES, stream, npp);
+    else if (dyn) hipLaunchKernelGGL((stage1_np_kernel<128, false, true, false, false, true>), g, b, SM::BYTES, stream, npp);
+    else if (hd2 && nt) hipLaunchKernelGGL((stage1_np_kernel<128, false, true, false, true>), g, b, SM::BYTES, stream, npp);
     else if (hd2) hipLaunchKernelGGL((stage1_np_kernel<128, false, false, false, true>), g, b, SM::BYTES, stream, npp);
     else if (rope && nt) hipLaunchKernelGGL((stage1_np_kernel<128, true, true>), g, b, SM::BYTES, stream, npp);
     else if (rope) hipLaunchKernelGGL((stage1_np_kernel<128, true, false>), g, b, SM::BYTES, stream, npp);

@@ -120,12 +120,15 @@ struct NpSmem {
 // PEEL: Q fragments built in front of the tile loop (what ROPE needs; for the plain kernel measured neutral, tools/ab.py:
 // north-star 35.96 / 36.10 us, ToT-50 18.41 / 18.20, Llama-3 north-star tree 17.93 / 17.66 -- the loop form stays)
 // NT: K / V rows arrive by non-temporal LDS-DMA (tree modes: a row is read by the few passes of its tile and never again)
+// DYN (with NT; GQA launches and nodes of very many queries): the cache policy is the chunk leader's (desc[6]: a tile folded by many
+//      passes wants its rows in L2) and a capped grid may take its further items in mirrored order.  Kept out of the plain
+//      instantiation: the two wave-uniform branches cost the north-star launch 0.2-0.4 us (tools/ab_rules.sh, late round 4).
 // HD2: head_dim 64 (the reference also takes 16 / 32 / 64, tree_attention.py:100, :582).  Two ADJACENT KV heads share one 256-byte
 //      pool row -- [slot][K|V][Hkv][64] with heads contiguous -- so a work item is a head PAIR and everything that moves data is
 //      the head_dim-128 kernel unchanged: the same DMA granules, the same LDS slices, the same fragment reads.  Only the
 //      arithmetic splits: k-steps 0-3 are head A's S^T, 4-7 head B's (two accumulators, two softmaxes), column blocks 0-1 of O^T
 //      take head A's probabilities, 2-3 head B's, and the epilogue writes two 64-float partial rows per virtual row.
-template <int D, bool ROPE, bool NT, bool PEEL = ROPE, bool HD2 = false>
+template <int D, bool ROPE, bool NT, bool PEEL = ROPE, bool HD2 = false, bool DYN = false>
 __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
     constexpr int KS = D / 16;
     constexpr int LPT = 32 * (D / 8) / 64;  // DMA instructions per wave per K (or V) slice
@@ -203,6 +206,12 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
     // further items (capped grids) takes item + W, item + 2 W, ... in a loop.
     int NI = 0x7fffffff;  // leaders x heads, read with the first item's descriptor
     int item = bid, round = 0;
+    auto next_item = [&](int it) __attribute__((always_inline)) {
+        if constexpr (DYN) {
+            if (np.mirror) return (++round & 1) ? (round + 1) * W - 1 - bid : round * W + bid;  // b, 2W-1-b, 2W+b, 4W-1-b, ...
+        }
+        return it + W;
+    };
     int rec0 = 0, kvh = 0, fb = 0, sd4 = 0, sd0 = 0, sd5 = 0;
     auto rec_of = [&](int i) { return np.plan + (int64_t)(i == 0 ? rec0 : fb + i - 1) * PLAN_BYTES; };
 
@@ -295,12 +304,12 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
     };
     auto issue_k = [&]() __attribute__((always_inline)) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of the slice being overwritten
-        if (NT && !temporal) issue_k_as(std::true_type{});
+        if (NT && !(DYN && temporal)) issue_k_as(std::true_type{});
         else issue_k_as(std::false_type{});
     };
     auto issue_v = [&]() __attribute__((always_inline)) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (NT && !temporal) issue_v_as(std::true_type{});
+        if (NT && !(DYN && temporal)) issue_v_as(std::true_type{});
         else issue_v_as(std::false_type{});
     };
     auto issue_q = [&]() {  // rows 8w .. 8w+7 of the shared Q buffer, offsets from aux slot 0
@@ -354,7 +363,7 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
     sd4 = dsc[4];
     sd0 = dsc[0];
     sd5 = dsc[5];
-    temporal = NT && __builtin_amdgcn_readfirstlane(dsc[6]) != 0;
+    if constexpr (DYN) temporal = NT && __builtin_amdgcn_readfirstlane(dsc[6]) != 0;
     const int n = sd4;  // tiles of this chunk (> 0: items only name leaders)
     const int nv = sd0;
     fb = sd5;
@@ -610,7 +619,7 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
     }
 
     if (ABL(16)) {  // (experiments build: no epilogue at all)
-        const int next = np.mirror ? ((++round & 1) ? (round + 1) * W - 1 - bid : round * W + bid) : item + W;
+        const int next = next_item(item);
         if (next >= NI) break;
         lds_barrier();
         item = next;
@@ -732,7 +741,7 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
     // Next item of a capped grid: record capacity beyond the chunk leaders would otherwise be launched as workgroups
     // that only find out that they have nothing to do (tens of thousands for the sequential comparator's entries).
     {
-        const int next = np.mirror ? ((++round & 1) ? (round + 1) * W - 1 - bid : round * W + bid) : item + W;
+        const int next = next_item(item);
         if (next >= NI) break;
         lds_barrier();  // every wave is done reading the others' slices
         item = next;
