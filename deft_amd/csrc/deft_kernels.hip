@@ -714,10 +714,14 @@ static int launch_stage1_np(const Stage1Params& p, int64_t unit_cap, const PlanV
     // L2 only if the first ones left them there.  That is a property of a RUN of tiles, not of the launch (an 8-tree forest has 64
     // queries and one pass per tile), so the plan's record kernels flag it per chunk leader (desc[6]) and the kernel picks the
     // policy per work item.
-    const bool nt = knob("DEFT_NP_NT", 1) != 0 && !reread;
-    // DYN instantiations (stage1_np.h): per-chunk cache policy and the mirrored item order -- GQA launches, and launches with so
-    // many queries that some node may be folded by more than five passes
-    const bool dyn = nt && (p.G > 1 || (int64_t)nq * p.G > 160);
+    // (MHA keeps its launch-level rule: more than 1024 virtual rows read temporally.  Medusa with 256 queries -- eight passes over
+    //  the root, 32 KV heads -- measured 0.4 us per layer SLOWER with its root chunks temporal: the per-chunk flag is GQA's.)
+    const bool nt = knob("DEFT_NP_NT", 1) != 0 && !reread && (p.G > 1 || (int64_t)nq <= 1024);
+    // DYN instantiations (stage1_np.h): per-chunk cache policy and the mirrored item order -- GQA launches
+    // ... that can use either: launches small enough for the mirrored order (below), or with enough virtual rows (> 160) for a
+    // node to be folded by more than five passes.  The rest (a 64k-token prefix under 8 branches: +0.45 us of 54 with the branches
+    // in) run the plain instantiation.
+    const bool dyn = nt && p.G > 1 && (unit_cap * HP <= 16LL * num_cus() || (int64_t)nq * p.G > 160);
     int rc;
     if (hd2) rc = dyn  ? raise_lds(reinterpret_cast<const void*>(&stage1_np_kernel<128, false, true, false, true, true>), SM::BYTES, ATTR_NP_HD2_DYN, "stage1_np_hd2_dyn")
                  : nt ? raise_lds(reinterpret_cast<const void*>(&stage1_np_kernel<128, false, true, false, true>), SM::BYTES, ATTR_NP_HD2, "stage1_np_hd2")
@@ -763,10 +767,11 @@ static int launch_stage1_np(const Stage1Params& p, int64_t unit_cap, const PlanV
     npp.s = p;
     npp.hdr = pv.hdr;
     // The speculative ramp (stage1_np.h: tile 0's offsets requested before the descriptor is known) for the workgroups resident at
-    // launch.  MHA: the first CUs-many only -- a workgroup of the second half that turns out to have no item (Medusa-64: 256 items
-    // on 512 slots) waits for its speculative requests before it may exit (rule variants of the shipped build, tools/ab_rules.sh:
-    // Medusa-64 12.8 -> 12.5 us per layer, the north-star tree / 1k x 32 / head_dim 64 unchanged; ToT-50, GQA, loses 0.5 with it).
-    npp.fast_n = knob("DEFT_NP_FAST", (p.G > 1 ? 2 : 1) * num_cus());
+    // launch.  (Half of them -- fast256 -- gains Medusa-64 0.3 us per layer: its 256 items leave the second half of the resident
+    // workgroups without one, and those wait for their speculative requests before they may exit.  But it costs launches with more
+    // items than that: the north-star tree through DeFT-Node +0.8 us, a 4k x 8 tree +0.2 (tools/shape_ab.sh) -- and the host does not
+    // know the item count.  Not adopted.)
+    npp.fast_n = knob("DEFT_NP_FAST", 2 * num_cus());
     npp.mirror = mirror ? 1 : 0;
     npp.s.ablate = knob("DEFT_STAGE1_ABLATE", 0);
     npp.plan = pv.records;

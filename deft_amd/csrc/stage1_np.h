@@ -120,7 +120,7 @@ struct NpSmem {
 // PEEL: Q fragments built in front of the tile loop (what ROPE needs; for the plain kernel measured neutral, tools/ab.py:
 // north-star 35.96 / 36.10 us, ToT-50 18.41 / 18.20, Llama-3 north-star tree 17.93 / 17.66 -- the loop form stays)
 // NT: K / V rows arrive by non-temporal LDS-DMA (tree modes: a row is read by the few passes of its tile and never again)
-// DYN (with NT; GQA launches and nodes of very many queries): the cache policy is the chunk leader's (desc[6]: a tile folded by many
+// DYN (with NT; GQA launches): the cache policy is the chunk leader's (desc[6]: a tile folded by many
 //      passes wants its rows in L2) and a capped grid may take its further items in mirrored order.  Kept out of the plain
 //      instantiation: the two wave-uniform branches cost the north-star launch 0.2-0.4 us (tools/ab_rules.sh, late round 4).
 // HD2: head_dim 64 (the reference also takes 16 / 32 / 64, tree_attention.py:100, :582).  Two ADJACENT KV heads share one 256-byte
