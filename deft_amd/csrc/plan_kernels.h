@@ -472,12 +472,19 @@ __global__ __launch_bounds__(1024) void flatten_units_kernel(const int64_t* bloc
     // 456 workgroups fit anyway, pairs only make them longer; 200 tokens 18.77 / 19.75 -- 656 become 456; 400 tokens 25.0 / 25.05 and
     // 1000 tokens 38.3 / 37.55 -- far more leaf tiles than slots either way).  Estimated per KV head from the blocks alone: the
     // leaf-like blocks (at most three queries) are a workgroup each, everything else a workgroup per four passes.
-    bool gqa_pairs = false;
+    // The group length is the SHORTEST (2, 3 or 4 tiles) with which the launch fits (300-token branches: 75 leaf tiles -- pairs
+    // leave 560 workgroups, triples 456: 22.8 -> 20.8 us per layer; at 200 tokens pairs fit, and triples cost 1.2 us).
+    int gqa_ulen = 1;
     if (G > 1) {
         ucap = min(ucap, 3);
         const int hk = Hkv < 0 ? -Hkv : Hkv;
         const int64_t rest = (sEst[1] + 3) / 4;
-        gqa_pairs = (rest + sEst[0]) * hk > slots && (rest + (sEst[0] + 1) / 2) * hk <= slots;
+        if ((rest + sEst[0]) * hk > slots)
+            for (int u = 2; u <= 4; ++u)
+                if ((rest + (sEst[0] + u - 1) / u) * hk <= slots) {
+                    gqa_ulen = u;
+                    break;
+                }
     }
     if ((union_len >> 8) > 0) ucap = min(ucap, union_len >> 8);  // (experiments: bits 8.. of the knob cap the union's queries)
     auto union_len_at = [&](int t) {
@@ -485,7 +492,7 @@ __global__ __launch_bounds__(1024) void flatten_units_kernel(const int64_t* bloc
         int ulen = union_len & 0xff;
         // (head pairs, Hkv < 0: groups of two -- their launches want workgroups, tools/ab_step.py on the head_dim-64 north-star tree;
         //  three measured 0.9 us per layer faster in the experiments build and 0.4 slower in the shipped one, tools/ab_lib.sh)
-        if (ulen <= 0) ulen = G > 1 ? (gqa_pairs ? 2 : 1) : (Hkv < 0 ? 2 : ((int64_t)NB * Hkv < 2048 ? 4 : 3));  // measured, tools/np_sweep.sh / tools/ab.py
+        if (ulen <= 0) ulen = G > 1 ? gqa_ulen : (Hkv < 0 ? 2 : ((int64_t)NB * Hkv < 2048 ? 4 : 3));  // measured, tools/np_sweep.sh / tools/ab.py
         return ulen;
     };
     if (np && ucap >= 2)
