@@ -121,6 +121,8 @@ def branch_speculative_decoding(tree: TreeCache, iter: int, max_gen_len: int, lo
 def branch_few_shot(tree: TreeCache, iter: int, max_gen_len: int, logits: torch.Tensor, execution_graph: TreeTemplate) -> bool:
     """branch_func_example.py:12-62 (SimpleTree): branch into `width` leaves after the prefill, then greedy."""
     width = execution_graph.root_width
+    if iter + 1 == max_gen_len:  # (:24-33: the last iteration finishes the branches and appends nothing)
+        return True
     if iter == 0:
         ids = _topk_ids(logits, 0, width)
         for j, leaf in enumerate(tree.branch(tree.root, width)):
@@ -129,7 +131,7 @@ def branch_few_shot(tree: TreeCache, iter: int, max_gen_len: int, logits: torch.
         greedy = _greedy(logits)
         for leaf in tree.leaves.values():
             leaf.append_token(int(greedy[tree.leaf_to_q[leaf.id]]))
-    return iter == max_gen_len - 1
+    return False
 
 
 BRANCH_FUNCS: Dict[str, Callable[..., bool]] = {
@@ -202,6 +204,7 @@ class TemplateReplay:
         self.session = can if session is None else (bool(session) and can)
         # test hook: called after every step's attention with (tree, layer-0 q rows [nq, Hq*D], layer-0 output [nq, Hq*D])
         self.step_hook: Optional[Callable[[TreeCache, torch.Tensor, torch.Tensor], None]] = None
+        self.trace_hook: Optional[Callable[..., None]] = None  # see run()
         if attention:
             from .deft_attention import DeFTAttention
 
@@ -221,13 +224,20 @@ class TemplateReplay:
         return req, pool
 
     def run(self, template: TreeTemplate, task: str, prompt_len: int, max_gen_len: int, max_tokens: Optional[int] = None,
-            max_leaves: int = 512, max_rows: int = 512, pipelined: bool = False) -> ReplayReport:
+            max_leaves: int = 512, max_rows: int = 512, pipelined: bool = False,
+            scores_fn: Optional[Callable[[int, int], np.ndarray]] = None) -> ReplayReport:
         """`pipelined=True`: no per-step synchronisation -- the host builds step t+1's tree state and metadata while the
         GPU still runs step t (the path is launch-only; the synthetic scores do not depend on the GPU's output, as
         in a real engine between branch events, where the tree's SHAPE one step ahead is known).  Per-step attention
         times are then not available; `attention_ms` is the GPU span of the whole replay and `wall_ms` what a caller
-        would see."""
+        would see.
+
+        `scores_fn(iter, rows)`: the next-token scores handed to the branch function at iteration `iter` (default: the
+        replay's own random table).  `self.trace_hook(iter, tree, cache_loc, metadata, session)`, when set, is called once per
+        decode step after the step's slots and metadata exist and before the branch function runs -- tests/test_replay_golden.py
+        compares what it sees with the reference's own loop, step for step."""
         branch = BRANCH_FUNCS[task]
+        score = scores_fn if scores_fn is not None else (lambda _it, rows: self._scores(rows))
         if task == "speculative_decoding":
             max_gen_len = min(max_gen_len, len(template.accept_lengths or []) + 1)
         if max_tokens is None:
@@ -262,7 +272,7 @@ class TemplateReplay:
             sizes = np.zeros(9, dtype=np.int64)
         t_wall = time.perf_counter()
         tree.init_prompt(torch.arange(1, prompt_len + 1, dtype=torch.int32))
-        logits = self._scores(1)
+        logits = score(0, 1)
         stop = branch(tree, 0, max_gen_len, logits, template)  # tree_generate.py:188-197
         it = 1
         first_event = last_event = None
@@ -284,6 +294,8 @@ class TemplateReplay:
                     first_event = e0
                 outs = sess.step()
                 e1.record()
+                if self.trace_hook is not None:
+                    self.trace_hook(it, tree, None, None, sess)
                 last_event = e1
                 if self.step_hook is not None:
                     self.step_hook(tree, q_all[0, :nq], outs[0][:nq])
@@ -297,7 +309,7 @@ class TemplateReplay:
                 check(lib.deft_tree_md_sizes(tree._native, mq, bl, mbl, 0, _ptr(sizes)), "deft_tree_md_sizes")
                 kv_tokens, node_kv_n = int(sizes[2]), int(sizes[4])
                 t1 = time.perf_counter()
-                logits = self._scores(nq)
+                logits = score(it, nq)
                 stop = branch(tree, it, max_gen_len, logits, template)
                 t_br = (time.perf_counter() - t1) * 1e3
                 rep.per_step.append({"iter": it, "nq": nq, "kv_tokens": kv_tokens, "attention_ms": t_attn,
@@ -325,6 +337,8 @@ class TemplateReplay:
                 positions = torch.tensor([lf.positions[-1] for lf in leaves], dtype=torch.int64, device=dev)
                 meta = InputMetadata.from_tree(tree, req, pool, self.forward_mode, positions, updater)
             t_md = (time.perf_counter() - t0) * 1e3
+            if self.trace_hook is not None:
+                self.trace_hook(it, tree, updater.cache_loc, md, None)
             # ---- forward: the attention path of every layer ---------------------------------------------------
             t_attn = 0.0
             if self.attention:
@@ -343,7 +357,7 @@ class TemplateReplay:
                     t_attn = e0.elapsed_time(e1)
             # ---- branch (tree_generate.py:226-236) ------------------------------------------------------------
             t1 = time.perf_counter()
-            logits = self._scores(nq)
+            logits = score(it, nq)
             kv_tokens = md.total_kv_len if md is not None else sum(len(n.kv_indices) for n in tree.nodes.values())
             stop = branch(tree, it, max_gen_len, logits, template)
             t_br = (time.perf_counter() - t1) * 1e3

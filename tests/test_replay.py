@@ -97,7 +97,7 @@ def test_speculative_replay_squeezes_accepted_tokens_into_the_root():
 def test_few_shot_replay_counts():
     tpl = rp.synthetic_few_shot_template(width=5)
     r, rep = _cpu_replay("few_shot", tpl, prompt_len=16, max_gen_len=7)
-    assert rep.steps == 6 and rep.decoded_rows == 30 and rep.generated_tokens == 5 * 7
+    assert rep.steps == 6 and rep.decoded_rows == 30 and rep.generated_tokens == 5 * 6  # (the last iteration appends nothing, :24-33)
     md = deft_amd.TreeMetadata.from_tree_cache(r.tree, device="cpu")
     assert md.query_num == 5 and md.total_kv_len == 16 + 5 * 6
 
