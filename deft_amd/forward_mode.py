@@ -46,10 +46,11 @@ class InputMetadata:
     max_seq_len: int = 0
     total_num_tokens: int = 0
     other_kv_index: Optional[int] = None
+    return_logprob: bool = False
 
     @classmethod
     def from_tree(cls, tree, req_to_token_pool, token_to_kv_pool, forward_mode: ForwardMode, positions: torch.Tensor,
-                  kv_updater: KVCacheUpdater) -> "InputMetadata":
+                  kv_updater: KVCacheUpdater, return_logprob: bool = False) -> "InputMetadata":
         """model_runner.py:162-231 without its host syncs on the tree modes: seq_lens = positions + 1, leaves in id
         order.  `other_kv_index` (a flashinfer-era leftover, read by nobody on this path) stays None."""
         seq_lens = positions + 1
@@ -62,7 +63,7 @@ class InputMetadata:
                    req_to_token_pool=req_to_token_pool,
                    req_pool_indices=torch.tensor(reqs, dtype=torch.int32, device=positions.device),
                    start_loc=start_loc, seq_lens=seq_lens, max_seq_len=max(lens) if lens else 0,
-                   total_num_tokens=sum(lens) if lens else 0)
+                   total_num_tokens=sum(lens) if lens else 0, return_logprob=return_logprob)
 
 
 def forward_mode_from_cli(mode: str, mem: str = "paged") -> ForwardMode:

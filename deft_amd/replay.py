@@ -74,6 +74,9 @@ def branch_from_tree_template(tree: TreeCache, iter: int, max_gen_len: int, logi
     branch_pairs = dict(execution_graph.branch_at.get(iter, ()))
     prune_nodes = set(execution_graph.prune_at.get(iter, ()))
     stop = 0 in prune_nodes  # the root is released: the whole template has run (:315-319)
+    if stop:
+        for leaf in tree.leaves.values():
+            tree.output_branch(dstnode=leaf)
     leaves = [tree.root] if iter == 0 else list(tree.leaves.values())
     greedy = _greedy(logits)
     for leaf in leaves:
@@ -88,7 +91,11 @@ def branch_from_tree_template(tree: TreeCache, iter: int, max_gen_len: int, logi
             tree.cut(tree.nodes[leaf.id], record_deleted=True)
         else:
             leaf.append_token(int(greedy[tree.leaf_to_q[leaf.id]]))
-    return stop or iter == max_gen_len - 1
+    if iter == max_gen_len - 1:  # (:365-369)
+        for leaf in tree.leaves.values():
+            tree.output_branch(dstnode=leaf)
+        stop = True
+    return stop
 
 
 def branch_speculative_decoding(tree: TreeCache, iter: int, max_gen_len: int, logits: torch.Tensor,
@@ -98,7 +105,9 @@ def branch_speculative_decoding(tree: TreeCache, iter: int, max_gen_len: int, lo
     root (their KV slots move to the root), every leaf's own KV is released and its positions shift."""
     accepted = execution_graph.accept_lengths
     assert accepted is not None
-    if iter == len(accepted):
+    if iter == len(accepted):  # (:387-397)
+        for leaf in tree.leaves.values():
+            tree.output_branch(dstnode=leaf)
         return True
     size = execution_graph.node_num
     if iter == 0:
@@ -122,15 +131,20 @@ def branch_few_shot(tree: TreeCache, iter: int, max_gen_len: int, logits: torch.
     """branch_func_example.py:12-62 (SimpleTree): branch into `width` leaves after the prefill, then greedy."""
     width = execution_graph.root_width
     if iter + 1 == max_gen_len:  # (:24-33: the last iteration finishes the branches and appends nothing)
+        for leaf in tree.leaves.values():
+            tree.output_branch(dstnode=leaf)
         return True
+    x = _scores(logits)
     if iter == 0:
         ids = _topk_ids(logits, 0, width)
         for j, leaf in enumerate(tree.branch(tree.root, width)):
-            leaf.append_token(int(ids[j % len(ids)]))
+            tok = int(ids[j % len(ids)])
+            leaf.append_token(tok, logprob=float(np.log(x[0, tok])))  # (:36-48: the scores are probabilities)
     else:
         greedy = _greedy(logits)
         for leaf in tree.leaves.values():
-            leaf.append_token(int(greedy[tree.leaf_to_q[leaf.id]]))
+            row = tree.leaf_to_q[leaf.id]
+            leaf.append_token(int(greedy[row]), logprob=float(np.log(x[row, greedy[row]])))
     return False
 
 

@@ -20,7 +20,7 @@ __all__ = ["RotaryEmbedding", "get_rope"]
 
 class RotaryEmbedding(nn.Module):
     def __init__(self, head_size: int, rotary_dim: int, max_position_embeddings: int, base: float, is_neox_style: bool,
-                 dtype: torch.dtype = torch.float32) -> None:
+                 dtype: torch.dtype) -> None:
         super().__init__()
         if dtype != torch.float32:
             raise NotImplementedError("the cos/sin cache is fp32, as the reference's Llama builds it (llama2.py:86-93)")
@@ -54,10 +54,21 @@ class RotaryEmbedding(nn.Module):
               "deft_rope_qk_f16")
         return query, key
 
+    def forward_native(self, positions: torch.Tensor, query: torch.Tensor, key: torch.Tensor,
+                       offsets: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """The reference's PyTorch spelling (rotary_embedding.py:119-155) returns NEW tensors and leaves its inputs alone; same
+        here -- the same kernel on copies (its results are bit-equal to the reference's forward_native: tests/golden/rope.npz)."""
+        return self.forward(positions, query.clone(), key.clone(), offsets)
+
 
 def get_rope(head_size: int, rotary_dim: int, max_position: int, base: float, is_neox_style: bool = True,
-             rope_scaling=None, dtype: Optional[torch.dtype] = None) -> RotaryEmbedding:
-    """rotary_embedding.py:647-690 for rope_scaling=None."""
+             rope_scaling=None, dtype: Optional[torch.dtype] = None, partial_rotary_factor: float = 1.0) -> RotaryEmbedding:
+    """rotary_embedding.py:647-690 for rope_scaling=None (the reference's Llama passes dtype=float32, llama2.py:86-93; with no
+    dtype the reference takes torch's default dtype, which this class accepts only when it is float32)."""
     if rope_scaling is not None:
         raise NotImplementedError("scaled rotary embeddings are out of scope (rotary_embedding.py:183-650)")
-    return RotaryEmbedding(head_size, rotary_dim, max_position, base, is_neox_style, dtype or torch.float32)
+    if dtype is None:
+        dtype = torch.get_default_dtype()
+    if partial_rotary_factor < 1.0:
+        rotary_dim = int(rotary_dim * partial_rotary_factor)
+    return RotaryEmbedding(head_size, rotary_dim, max_position, base, is_neox_style, dtype)

@@ -32,6 +32,20 @@ __all__ = ["TreeTemplate", "read_reasoning_file", "read_speculative_file", "fit_
 OPEN_ENDED = 1 << 30  # `value` / `end` of a node that generates until the replay's own limit (few-shot leaves)
 
 
+class TemplateNode:
+    """One node of a template as the reference's loader presents it (data_loader.py:9-27)."""
+    __slots__ = ("id", "value", "start_offset", "end_offset", "depth", "width", "children")
+
+    def __init__(self, node_id: int, value: int, start_offset: int, end_offset: int, depth: int = 0, width: int = 0) -> None:
+        self.id, self.value, self.start_offset, self.end_offset = node_id, value, start_offset, end_offset
+        self.depth, self.width = depth, width
+        self.children: List["TemplateNode"] = []
+
+    def __repr__(self) -> str:
+        return (f"TreeNode(id={self.id}, value={self.value}, start={self.start_offset}, end={self.end_offset}, "
+                f"depth={self.depth}, width={self.width})")
+
+
 class TreeTemplate:
     def __init__(self, value: Sequence[int], start: Sequence[int], end: Sequence[int], children: Sequence[Sequence[int]],
                  prompt: Optional[str] = None, accept_lengths: Optional[List[int]] = None) -> None:
@@ -50,6 +64,7 @@ class TreeTemplate:
         self.release = np.zeros(n, dtype=np.int64)  # iteration at which the node is pruned
         self.branch_at: Dict[int, List[Tuple[int, List[int]]]] = {}
         self.prune_at: Dict[int, List[int]] = {}
+        self._nodes: Optional[List["TemplateNode"]] = None
         self._derive_events()
 
     # ---- shape ---------------------------------------------------------------------------------------------
@@ -120,6 +135,31 @@ class TreeTemplate:
     @property
     def prune_record(self) -> Dict[int, List[int]]:
         return {it: list(v) for it, v in self.prune_at.items()}
+
+    # ---- the reference's attribute names (data_loader.py:9-49) -------------------------------------------------
+    @property
+    def accepted_len_list(self) -> Optional[List[int]]:
+        return self.accept_lengths
+
+    @accepted_len_list.setter
+    def accepted_len_list(self, v: Optional[List[int]]) -> None:
+        self.accept_lengths = v
+
+    @property
+    def nodes(self) -> List["TemplateNode"]:
+        """Node records in the reference's form (`id, value, start_offset, end_offset, children, depth, width`), built on first
+        use from the arrays; `root` is `nodes[0]`."""
+        if self._nodes is None:
+            ns = [TemplateNode(i, int(self.value[i]), int(self.start[i]), int(self.end[i]), int(self.level[i]), int(self.rank[i]))
+                  for i in range(self.node_num)]
+            for i, nd in enumerate(ns):
+                nd.children = [ns[c] for c in self.kids(i)]
+            self._nodes = ns
+        return self._nodes
+
+    @property
+    def root(self) -> "TemplateNode":
+        return self.nodes[0]
 
     def token_budget(self) -> int:
         """Tokens all nodes but open-ended ones generate (pool sizing)."""

@@ -40,6 +40,8 @@ from collections.abc import MutableSequence
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Set
 
+import math
+
 import numpy as np
 import torch
 
@@ -61,8 +63,8 @@ class KVCacheUpdater:
         use_paged_memory: bool,
         token_to_kv_pool: Optional[TokenToKVPool],
         cache_loc: Optional[torch.Tensor],
-        leaf_data=None,
-        is_prompt: bool = False,
+        leaf_data,
+        is_prompt: bool,
     ) -> None:
         assert use_paged_memory, "deft_amd covers --mem paged only"
         self.use_paged_memory = use_paged_memory
@@ -262,6 +264,22 @@ class TreeNode:
         return {t.nodes[int(i)] for i in out[:n] if int(i) in t.nodes}
 
 
+class BranchSequence:
+    """tree_cache.py:132-144: one finished branch of the decoding tree (tokens, cumulative log-probability, perplexity)."""
+
+    def __init__(self, id: int):
+        self.id = id
+        self.token_ids: List[int] = []
+        self.cumulative_logprob = 0.0
+        self.PPL = 0.0
+
+    def get_len(self) -> int:
+        return len(self.token_ids)
+
+    def append_tokens(self, tokens: List[int]) -> None:
+        self.token_ids.extend(tokens)
+
+
 class TreeCache:
     def __init__(
         self,
@@ -271,7 +289,7 @@ class TreeCache:
         layer_num: int,
         req_to_token_pool: Optional[ReqToTokenPool],
         token_to_kv_pool: Optional[TokenToKVPool],
-        tree_index_pool=None,
+        tree_index_pool,
         use_paged_memory: bool = True,
         use_tree_index: bool = False,
     ) -> None:
@@ -295,6 +313,7 @@ class TreeCache:
         self.use_tree_index = False
         self.layer_num = layer_num
         self.deleted_token_num = 0
+        self.all_finished_seqs: List[BranchSequence] = []  # finished branches, in the order they were output (:186-188)
         self._native = int(lib.deft_tree_create())
         self._device_tree: Optional["_DeviceTree"] = None
 
@@ -552,6 +571,25 @@ class TreeCache:
         lib.deft_tree_free(self._native)
         self._native = int(lib.deft_tree_create())
         self._device_tree = None
+
+    def output_branch(self, dstnode: TreeNode) -> None:
+        """tree_cache.py:525-541: record the branch root -> `dstnode` (the root's own tokens -- the prompt -- excluded, as
+        `_find_path_to_node` stops below the root) with its cumulative log-probability and perplexity."""
+        branch_seq = BranchSequence(len(self.all_finished_seqs))
+        for node in self._find_path_to_node(dstnode):
+            branch_seq.append_tokens(node.token_ids)
+            branch_seq.cumulative_logprob += node.cumulative_logprob
+        branch_seq.PPL = math.exp(-branch_seq.cumulative_logprob / len(branch_seq.token_ids))
+        self.all_finished_seqs.append(branch_seq)
+
+    def _find_path_to_node(self, dstnode: TreeNode) -> List[TreeNode]:  # :543-550
+        path = []
+        node = dstnode
+        while node.parent is not None:
+            path.append(node)
+            node = node.parent
+        path.reverse()
+        return path
 
     def get_tree_token_number(self) -> int:  # :569-584
         return sum(len(n.token_ids) for n in self.nodes.values()) + self.deleted_token_num

@@ -96,7 +96,8 @@ class _Checker:
     def finish(self, tree, pool):
         g = self.g
         assert self.k == len(g["iter"]) and self.at == len(g["cache_loc"]) and self.snaps_seen == len(self.snaps)
-        nodes, leaves, used, tokens, _ = (int(x) for x in g["end_state"])
+        nodes, leaves, used, tokens, finished = (int(x) for x in g["end_state"])
+        assert len(tree.all_finished_seqs) == finished  # (branches output by the branch function's last iteration)
         assert (len(tree.nodes), len(tree.leaves)) == (nodes, leaves)
         assert int((pool.mem_state != 0).sum()) == used
         assert tree.get_tree_token_number() == tokens
