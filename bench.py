@@ -202,6 +202,11 @@ class Bench:
         256 / 512 / 1024 workgroups."""
         slot_bytes = self.pool.kv_data[0].stride(0) * 2
         nbytes = int(self.n_kv) * slot_bytes
+        # (the ceiling reads the pool's first n_kv slots: say so only while that IS where the tree's tokens are -- ADVICE r4)
+        bk = self.md.block_kv if getattr(self.md, "block_kv", None) is not None else None
+        if bk is not None and bk.numel():
+            top = int(bk.max().item())
+            assert top < int(self.n_kv) + 64 * max(self.w.width, 1) + 256, (top, self.n_kv)
         stream = torch.cuda.current_stream(self.device)
         best = None
         for wgs in (256, 512, 1024):
@@ -687,9 +692,12 @@ def main():
                     "median_launch_us": round(s1["median_us"], 2), "launches_timed": s1["launches"],
                     "timing": ("HIP events around a hipGraph of one launch per layer pool" if s1.get("launch") == "hipgraph"
                                else "HIP events around eager launches") +
-                              "; the launches timed are deft_flatten_stage1_f16 = stage1_np_kernel<128, false, NT> WITHOUT the fused "
-                              "append -- the step's own launches (deft_flatten_decode_append_f16) are the same template "
-                              "instantiation with n_new = nq new rows copied into the pool by its first workgroups",
+                              "; the launches timed are deft_flatten_stage1_f16 = " +
+                              ("stage1_np_kernel<128, false, NT> (MHA: the plain instantiation)" if b.Hq == b.Hkv else
+                               "stage1_np_kernel<128, false, true, false, false, DYN = true> (GQA: per-chunk cache policy, mirrored item "
+                               "order; a GQA launch beyond 16 x CUs items with at most 160 virtual rows runs the plain one)") +
+                              " WITHOUT the fused append -- the step's own launches (deft_flatten_decode_append_f16) are the same "
+                              "template instantiation with n_new = nq new rows copied into the pool by its first workgroups",
                     # the hardware ceiling of a launch of this size: a bare read of the same K/V bytes (deft_probe_stream_read)
                     "ceiling_us": ceil["us"], "ceiling_workgroups": ceil["workgroups"],
                     "launch_over_ceiling": round(s1["mean_us"] / ceil["us"], 3)}

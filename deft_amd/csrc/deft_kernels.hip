@@ -756,8 +756,10 @@ static int launch_stage1_np(const Stage1Params& p, int64_t unit_cap, const PlanV
         // order / 20.4 mirrored; ToT-50 21.8 / 23.3 / 21.6; one 8k x 8 tree equal; NOT the large launches: north-star 36.2 / 41.4 /
         // 39.8, the 8-tree forest 54.8 / 55.0 / 56.6).
         const bool small_gqa = unit_cap * HP <= 16LL * num_cus();
-        mirror = knob("DEFT_NP_MIRROR", p.G > 1 && small_gqa ? 1 : 0) != 0;
-        const int capx = knob("DEFT_NP_GRIDCAP", p.G > 1 ? 1 : 3);
+        // (the mirrored order lives in the DYN instantiations only; a small GQA launch that cannot run one -- the sequential
+        //  comparator's re-reads, which must not be slowed against the tree modes -- keeps hardware dispatch at 2 x slots: ADVICE r4)
+        mirror = knob("DEFT_NP_MIRROR", dyn && small_gqa ? 1 : 0) != 0 && dyn;
+        const int capx = knob("DEFT_NP_GRIDCAP", p.G > 1 ? ((small_gqa && !dyn) ? 2 : 1) : 3);
         const int64_t cap_wgs = (int64_t)capx * 2LL * num_cus();
         if (cap_wgs > 0 && grid > cap_wgs) grid = cap_wgs;
         const int gx = knob("DEFT_NP_GRID", 0);  // (experiments build, tests: a tiny grid = many rounds of the item loop)
@@ -867,8 +869,13 @@ int deft_abi_version(void) { return 1; }
 // Everything a plan's layout depends on besides the caller's arguments.  The shipped library has no such thing (0);
 // the experiments build folds its plan knobs into the value, so that callers which cache plans key them by it.
 int deft_plan_variant(void) {
-    return ((np_chunk_knob() & 0xff) << 4) | ((np_union_knob() & 0xff) << 12) | ((g_plan_serial ? 1 : 0) << 24) |
-           (((g_plan_runcap & 0x3f) << 25) ^ ((np_nt_passes_knob() - 5) & 0xf));
+    // (the union knob's bits 8 and up carry a query cap that changes the plan as well: folded in whole)
+    const unsigned u = (unsigned)np_union_knob();
+    unsigned key = (((unsigned)np_chunk_knob() & 0xff) << 4) | ((u & 0xff) << 12) | ((g_plan_serial ? 1u : 0u) << 24) |
+                   (((unsigned)g_plan_runcap & 0x3f) << 25);
+    key ^= (unsigned)(np_nt_passes_knob() - 5) & 0xf;
+    key ^= (((u >> 8) * 0x9E3779B1u) >> 8) << 4;
+    return (int)(key & 0x7fffffffu);
 }
 
 // Internal hooks of the EXPERIMENTS build only (libdeft_amd_exp.so; the shipped library exports exactly what

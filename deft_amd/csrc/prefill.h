@@ -345,8 +345,9 @@ __global__ __launch_bounds__(256) void prefill_small_kernel(PrefillParams p) {
     const int b = (int)blockIdx.x / per_seq;
     const int qi = ((int)blockIdx.x - b * per_seq) * 4 + w;
     const int head = (int)blockIdx.y;
+    if (b >= p.batch) return;  // (before the load: robust to a grid larger than per_seq * batch)
     const int len = p.b_seq_len[b];
-    if (b >= p.batch || qi >= len) return;
+    if (qi >= len) return;
     const int64_t start = p.b_start_loc[b];
     const int kvh = head / p.G;
     float q[D];

@@ -646,7 +646,10 @@ int deft_tree_layout_fetch(int64_t tree, int32_t* node_start, int32_t* node_len,
     }
     // The image holds every change made so far, journalled or not: whoever uploads it must not replay the journal on top of
     // it (a second device copy made inside one epoch -- another max_q_len / BLOCK_CONFIG / device -- would otherwise see the
-    // pending EXTENDs twice).
+    // pending EXTENDs twice).  Any OTHER device copy of this epoch still lacks those changes and can no longer get them from
+    // the journal: a non-empty journal therefore ends the epoch for everyone (the layout itself stays valid -- the caller
+    // of this function adopts the new epoch number, every other copy sees a mismatch and uploads).
+    if (!t->journal.empty()) ++t->epoch;
     t->journal.clear();
     t->last_ext = -1;
     return DEFT_OK;

@@ -727,7 +727,9 @@ class _DeviceTree:
         sb = int(lib.deft_tree_dev_scratch_bytes(n, nqw, self.nbp_cap))
         self.scratch = torch.zeros(sb, dtype=torch.uint8, device=self.device)  # (dims[] start at zero)
         self.scratch_bytes = sb
-        self.epoch = epoch
+        # (read AFTER the fetch: a fetch that found a non-empty journal ends the epoch for every other copy -- they never saw those
+        #  changes -- and this copy, whose image holds them, adopts the new number)
+        self.epoch = t._epoch()
 
     def sync(self) -> bool:
         """Bring the device copy to the tree's structural epoch; True iff an upload happened (the uploaded image holds

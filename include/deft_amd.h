@@ -45,7 +45,7 @@ extern "C" {
 #endif
 
 /* The library is built with -fvisibility=hidden: the functions declared in this header -- and nothing else -- are its
- * dynamic symbols (tests/test_abi.py compares `nm -D` with the declarations). */
+ * dynamic symbols (tests/test_host_logic.py::test_library_exports_nothing_but_the_declared_symbols compares `nm -D` with the declarations). */
 #if defined(__GNUC__) || defined(__clang__)
 #pragma GCC visibility push(default)
 #endif
@@ -402,6 +402,11 @@ int64_t deft_tree_build_md(int64_t tree, int max_q_len, int block_len, int max_b
  *                           64-bit words per leaf set, total slot capacity, epoch}.  The layout (and the device copy made from
  *                           deft_tree_layout_fetch) stays valid while the epoch does: deft_tree_alloc_step keeps it as long as
  *                           every leaf has room; every other mutation bumps it.
+ *   deft_tree_layout_fetch  fills the upload image of that layout.  SIDE EFFECT: the image holds every change made so far, so
+ *                           the journal of absorbed changes (deft_tree_journal_take) is CLEARED -- and when it was not empty the
+ *                           epoch is bumped (the layout stays valid): other device copies of the old epoch never saw those
+ *                           changes and must upload.  Read the epoch AFTER this call (deft_tree_stats), not from
+ *                           deft_tree_layout's sizes[4].
  *   deft_tree_md_sizes      sizes of the metadata for the current lengths + `grow` tokens per leaf: sizes[0..7] as
  *                           deft_md_sizes, sizes[8] = physical 128-slot blocks (capacity planning and tensor shapes; no slot touched)
  *   deft_tree_dev_advance   device: append cache_loc[r] to query row r's leaf (kept ascending inside the node)

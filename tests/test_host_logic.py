@@ -425,7 +425,13 @@ def test_layout_fetch_hands_over_the_journal_with_the_image():
     assert ln.tolist() == [8, 1 + 3, 1]  # the image has the extend
     buf = np.zeros(64, dtype=np.int32)
     assert lib.deft_tree_journal_take(tree._native, _ptr(buf), 64) == 0  # ... and took the journal with it
-    assert tree._epoch() == e
+    # any OTHER device copy of epoch e never saw that extend and can no longer get it from the journal, so a fetch that
+    # swallowed a non-empty journal ends the epoch (the fetching copy reads the epoch after the call and adopts it) ...
+    assert tree._epoch() == e + 1
+    check(lib.deft_tree_layout(tree._native, 256, _ptr(sizes)), "layout")
+    assert int(sizes[4]) == e + 1 and [int(x) for x in sizes[:4]] == [n, nq, nqw, total_cap]  # ... while the layout itself stays
+    check(lib.deft_tree_layout_fetch(tree._native, _ptr(start), _ptr(ln), _ptr(cap), _ptr(refs), _ptr(leaf_node), _ptr(slots)), "fetch")
+    assert tree._epoch() == e + 1  # a fetch with an empty journal changes nothing
 
 
 def _build_c_program(out_path):

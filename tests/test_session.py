@@ -230,3 +230,58 @@ def test_session_head_dim_64_and_lazy_capture(capture_after):
     assert sess.captures == {1: 4, 3: 1, "auto": 2}[capture_after]
     both_steps(6)  # ... and the last epoch lasts: everyone captures it
     assert sess.captures == {1: 4, 3: 2, "auto": 3}[capture_after]
+
+
+@pytest.mark.parametrize("mode", ["flatten", "node"])
+def test_second_device_copy_between_steps_cannot_starve_the_session_of_journalled_changes(mode):
+    """a session holds its device copy and a captured graph; between two steps the tree absorbs a merge + reset (journalled,
+    not yet taken) and somebody builds metadata of the SAME tree with ANOTHER max_q_len -- a second device copy, whose upload image
+    carries the journalled changes and clears the journal.  The session's copy never saw them: the fetch has to end the epoch
+    for it (it uploads again) instead of leaving it with stale node lengths and wrong attention."""
+    Hq, Hkv, D, layers, prefix, width = 8, 2, 128, 2, 400, 12
+    g = torch.Generator(device="cuda").manual_seed(23)
+    kv_init = torch.randn((layers, 4096, 2, Hkv, D), dtype=torch.float16, device="cuda", generator=g)
+    (te, pe), (ts, ps) = [_mk(Hkv, D, layers, prefix, width, 4096) for _ in range(2)]
+    for p in (pe, ps):
+        p._storage.copy_(kv_init)
+    q = torch.randn((layers, width, Hq * D), dtype=torch.float16, device="cuda", generator=g)
+    k = torch.randn((layers, width, Hkv * D), dtype=torch.float16, device="cuda", generator=g)
+    v = torch.randn((layers, width, Hkv * D), dtype=torch.float16, device="cuda", generator=g)
+    sess = deft_amd.DecodeSession(ts, Hq, Hkv, D, layers, lambda l: (q[l], k[l], v[l]), mode=mode)
+    attn = [deft_amd.DeFTAttention(Hq, D, D ** -0.5, Hkv, l) for l in range(layers)]
+    fmode = deft_amd.forward_mode_from_cli(mode)
+
+    def step_and_compare(tag):
+        for tree in (te, ts):
+            for leaf in tree.leaves.values():
+                leaf.append_token(7)
+        upd = te.alloc()
+        md = deft_amd.TreeMetadata.from_tree_cache(te)
+        deft_amd.register_tree_metadata(md)
+        ref = [attn[l](q[l], k[l], v[l], deft_amd.InputMetadata(fmode, upd, pe)) for l in range(layers)]
+        out = sess.step()
+        torch.cuda.synchronize()
+        for l in range(layers):
+            assert torch.equal(out[l], ref[l]), (tag, l)
+        assert torch.equal(pe._storage, ps._storage)
+
+    def speculative_update(accept):
+        for tree in (te, ts):
+            lv = sorted(tree.leaves.values(), key=lambda n: n.id)
+            before = len(tree.root.kv_indices)
+            for lf in lv[:accept]:
+                tree.merge_nodes(tree.root, lf, pruneB_flag=False)
+            tree.reset_nodes_KV(lv, len(tree.root.kv_indices) - before)
+
+    for i in range(4):  # reach the epoch in which merges are absorbed and the step is captured
+        step_and_compare(("warm", i))
+        speculative_update(2)
+    assert sess.graph is not None
+    epoch_before = ts._epoch()
+    # the interloper: metadata of the session's tree under another configuration, while the journal holds the last update
+    other = deft_amd.TreeMetadata.from_tree_cache(ts, max_q_len=16, copy=True)
+    assert other.query_num == width
+    assert ts._epoch() != epoch_before, "a fetch that swallowed a pending journal must end the epoch for the other copies"
+    step_and_compare("after the second copy")
+    speculative_update(3)
+    step_and_compare("and the step after")
