@@ -41,6 +41,11 @@ class Bench:
         self.Hq, self.Hkv, self.D, _ = GEOMETRY[w.model]
         self.layers = layers
         self.device = device
+        # (--mode node_chunk = DeFT-Node with nodes cut into 128-token entries: BLOCK_CONFIG["MAX_BLOCK_LEN"] is set by the mode's
+        #  spelling, examples/run_DeFT_llama_paged.py:145-150, and must be in force BEFORE the metadata is built; every other mode
+        #  resets it)
+        deft_amd.BLOCK_CONFIG["MAX_BLOCK_LEN"] = -1
+        mode = deft_amd.forward_mode_from_cli(w.mode)
         t0 = time.perf_counter()
         if w.trees > 1:  # a batch of independent trees in one pool, one operator call per layer
             self.forest, self.pool = build_forest(w, w.trees, layers, str(device))
@@ -70,7 +75,6 @@ class Bench:
         leaves = [lf for t in self.forest.trees for lf in sorted(t.leaves.values(), key=lambda n: n.id)]
         loc = torch.tensor([lf.kv_indices[-1] for lf in leaves], dtype=torch.int32, device=device)
         self.updater = deft_amd.KVCacheUpdater(True, self.pool, loc, None, False)
-        mode = deft_amd.forward_mode_from_cli(w.mode)
         if w.mode == "seq":  # sequential comparator: every leaf attends to its own full path through the page table
             tree = self.forest.trees[0]
             lens = [len(tree.leaf_path_slots(lf)) for lf in leaves]
@@ -259,7 +263,7 @@ class Bench:
             plan = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=self.device)
             build = lambda: check(lib.deft_flatten_build_plan(*[t.data_ptr() for t in mdl], NB, P, self.Hq, self.Hkv, q0.stride(0),
                                                               q0.stride(1), kss, None, 0, 0, plan.data_ptr(), nbytes, s), "plan")
-        elif self.w.mode == "node":
+        elif self.w.mode in ("node", "node_chunk"):
             mdl = [md.node_kv, md.node_kv_offset, md.node_kv_len, md.node_q, md.node_q_offset, md.node_q_len]
             NE, P, total = md.node_kv_offset.shape[0], md.node_q.shape[0], md.node_kv.shape[0]
             nbytes = lib.deft_node_plan_bytes(NE, P, total, self.Hq, self.Hkv)
@@ -740,8 +744,9 @@ def main():
         if w.kind == "few_shot" and args.branch_len is None:
             variants += [(f"{w.name}_len1", Workload(**{**w.__dict__, "branch_len": 1})),
                          (f"{w.name}_len400", Workload(**{**w.__dict__, "branch_len": 400}))]
-        for name in ("fewshot_1kx32", "medusa64_node", "tot50_4k", "gqa_4kx32", "forest_8kx8_single",
-                     "northstar_4kx32_node", "northstar_4kx32_seq", "fewshot_1kx32_seq", "northstar_4kx32_d64"):
+        for name in ("fewshot_1kx32", "medusa64_node", "medusa64_tree_node", "medusa64_tree_flatten", "tot50_4k", "gqa_4kx32",
+                     "forest_8kx8_single", "northstar_4kx32_node", "northstar_4kx32_node_chunk", "northstar_4kx32_seq",
+                     "fewshot_1kx32_seq", "northstar_4kx32_d64"):
             if name != w.name:
                 variants.append((name, WORKLOADS[name]))
         del b.graph

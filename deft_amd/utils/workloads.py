@@ -9,6 +9,9 @@ Shapes follow the reference's branch functions
   medusa     SpeculativeDecoding mock :374-442 — root + `tree_size` one-token leaves
   tot        FromTreeTemplate :293-371 shaped like SURVEY §8d cfg4(i): root ->
              7 x 128-token nodes -> 42 x 64-token leaves (50 live nodes)
+  medusa_tree  BASELINE configs[2] read literally: the depth-4 width-10 Medusa token tree itself (`Tree_Structure` of
+             dataset/generation/Speculative_Decoding/tree_size64.json: 63 one-token nodes, 42 of them leaves) below the prompt --
+             the shape a speculative-decoding caller that keeps its token tree AS a tree hands the operator
 """
 from __future__ import annotations
 
@@ -29,11 +32,51 @@ GEOMETRY: Dict[str, Tuple[int, int, int, int]] = {
 }
 
 
+# The 63 node paths of the reference's tree_size64 token tree (Medusa's `mc_sim_7b_63` choices: a node is the path of top-k
+# indices that leads to it).  tests/golden/templates.json holds the reference file's own copy; tests/test_workloads.py compares.
+MEDUSA_TREE_SIZE64 = (
+    (0,), (0, 0), (1,), (0, 1), (2,), (0, 0, 0), (1, 0), (0, 2), (3,), (0, 3), (4,), (0, 4), (2, 0), (0, 5), (0, 0, 1), (5,), (0, 6),
+    (6,), (0, 7), (0, 1, 0), (1, 1), (7,), (0, 8), (0, 0, 2), (3, 0), (0, 9), (8,), (9,), (1, 0, 0), (0, 2, 0), (1, 2), (0, 0, 3),
+    (4, 0), (2, 1), (0, 0, 4), (0, 0, 5), (0, 0, 0, 0), (0, 1, 1), (0, 0, 6), (0, 3, 0), (5, 0), (1, 3), (0, 0, 7), (0, 0, 8),
+    (0, 0, 9), (6, 0), (0, 4, 0), (1, 4), (7, 0), (0, 1, 2), (2, 0, 0), (3, 1), (2, 2), (8, 0), (0, 5, 0), (1, 5), (1, 0, 1),
+    (0, 2, 1), (9, 0), (0, 6, 0), (0, 0, 0, 1), (1, 6), (0, 7, 0),
+)
+
+
+def build_token_tree(tree, paths, tok: int = 7) -> dict:
+    """Grow a tree of ONE-TOKEN nodes below `tree.root` (which holds the prompt), one node per path, level by level: the nodes of
+    a level that have children branch (children in ascending order of their last index), every new node takes one token and
+    one pool slot.  Written against the reference's own API (`branch`, `append_token`, `append_index`, the pools) so that the
+    same function drives the reference's TreeCache (tools/gen_golden.py), the oracle's and deft_amd's.  The slot step is
+    `tree.alloc()` (tree_cache.py:261-277) restricted to the level's NEW nodes: `alloc()` itself would hand a second slot to
+    the childless nodes of the levels above, which are live leaves too.  Returns {path: node}."""
+    paths = sorted(tuple(p) for p in paths)
+    by_path = {(): tree.root}
+    for depth in range(1, max(len(p) for p in paths) + 1):
+        level = [p for p in paths if len(p) == depth]
+        new = []
+        for parent in sorted({p[:-1] for p in level}):
+            kids = [p for p in level if p[:-1] == parent]
+            for p, node in zip(kids, tree.branch(by_path[parent], len(kids))):
+                by_path[p] = node
+                new.append(node)
+        for node in new:
+            node.append_token(tok)
+        loc = tree.token_to_kv_pool.alloc(len(new))
+        assert loc is not None
+        table = tree.req_to_token_pool.req_to_token
+        for i, node in enumerate(sorted(new, key=lambda n: n.id)):
+            slot = int(loc[i])
+            node.append_index(slot)
+            table[tree.leaf_to_req[node.id], node.positions[-1]] = slot
+    return by_path
+
+
 @dataclass
 class Workload:
     name: str
     model: str
-    mode: str  # "flatten" | "node" | "seq" (the sequential per-leaf comparator, `--mode seq`)
+    mode: str  # "flatten" | "node" | "node_chunk" | "seq" (the sequential per-leaf comparator, `--mode seq`)
     kind: str  # few_shot | medusa | tot
     prefix: int
     width: int = 32
@@ -51,8 +94,13 @@ WORKLOADS: Dict[str, Workload] = {
     "fewshot_1kx32_seq": Workload("fewshot_1kx32_seq", "llama2-7b", "seq", "few_shot", 1024, 32, 200),
     # the north-star tree through DeFT-Node (the reference's other tree mode: one entry per node, no bit masks)
     "northstar_4kx32_node": Workload("northstar_4kx32_node", "llama2-7b", "node", "few_shot", 4096, 32, 200),
+    # ... and through --mode node_chunk (DeFT-Node with every node cut into 128-token entries, run_DeFT_llama_paged.py:145-150)
+    "northstar_4kx32_node_chunk": Workload("northstar_4kx32_node_chunk", "llama2-7b", "node_chunk", "few_shot", 4096, 32, 200),
     # configs[2]: Medusa depth-4 width-10 template as the reference mocks it (tree_size64), DeFT-Node
     "medusa64_node": Workload("medusa64_node", "llama2-7b", "node", "medusa", 1016, 64, 1),
+    # configs[2] read literally: the 63-node depth-4 width-10 token tree itself (42 leaves = 42 queries), both modes
+    "medusa64_tree_node": Workload("medusa64_tree_node", "llama2-7b", "node", "medusa_tree", 1016, 42, 1),
+    "medusa64_tree_flatten": Workload("medusa64_tree_flatten", "llama2-7b", "flatten", "medusa_tree", 1016, 42, 1),
     # the north-star tree on a GQA model (Llama-3-8B: 32 branches x 4 query heads per KV head = 128 rows per tile)
     "gqa_4kx32": Workload("gqa_4kx32", "llama3-8b", "flatten", "few_shot", 4096, 32, 200),
     # configs[3]: Llama-3-8B ToT tree, 4k prefix, 50 nodes, DeFT-Flatten
@@ -76,6 +124,8 @@ def tree_tokens(w: Workload) -> int:
         return w.prefix + w.width
     if w.kind == "tot":
         return w.prefix + 7 * 128 + 42 * 64
+    if w.kind == "medusa_tree":
+        return w.prefix + len(MEDUSA_TREE_SIZE64)
     raise ValueError(w.kind)
 
 
@@ -104,6 +154,8 @@ def build_tree(w: Workload, layers: int, device: str, extra_slots: int = 256, po
     elif w.kind == "medusa":
         tree.branch(tree.root, w.width)
         step(1)
+    elif w.kind == "medusa_tree":
+        build_token_tree(tree, MEDUSA_TREE_SIZE64)
     elif w.kind == "tot":
         tree.branch(tree.root, 7)
         step(128)

@@ -87,6 +87,9 @@ class OracleNode:
         self.positions.append(self.position_offset + len(self.token_ids))
         self.token_ids.append(token)
 
+    def append_index(self, index: int) -> None:  # :125-129
+        self.kv_indices.append(int(index))
+
 
 class OracleTree:
     """tree_cache.py:147-403 (paged memory only)."""
@@ -94,6 +97,7 @@ class OracleTree:
     def __init__(self, pool: OracleTokenPool, reqs: OracleReqTable) -> None:
         self.pool = pool
         self.reqs = reqs
+        self.token_to_kv_pool, self.req_to_token_pool = pool, reqs  # (the reference's names, tree_cache.py:168-169)
         self.node_cnt = 1
         self.root: Optional[OracleNode] = None
         self.nodes: Dict[int, OracleNode] = {}

@@ -116,6 +116,20 @@ def s_medusa64(tree, ids):  # BASELINE config 3 as the reference mocks it
     _step(tree, 1)
 
 
+def s_medusa64_tree(tree, ids):
+    """BASELINE config 3 read literally (VERDICT r4 missing #3): the depth-4 width-10 Medusa token tree of
+    dataset/generation/Speculative_Decoding/tree_size64.json (`Tree_Structure`: 63 one-token nodes, 42 leaves) below a
+    1016-token prompt.  The topology comes from tests/golden/templates.json (the reference file's own copy)."""
+    import json
+    import os
+
+    from deft_amd.utils.workloads import build_token_tree
+
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "templates.json")))
+    tree.init_prompt(ids(1016))
+    build_token_tree(tree, gold["speculative"]["tree_size64"]["Tree_Structure"])
+
+
 def s_tot50(tree, ids):  # BASELINE config 4: 4096 root -> 7 x 128 -> 42 x 64
     tree.init_prompt(ids(4096))
     tree.branch(tree.root, 7)
@@ -176,6 +190,7 @@ SCENARIOS: Dict[str, Scenario] = {
     "spec_mock": Scenario(s_spec_mock, pool_size=256),
     "appendix_d": Scenario(s_appendix_d, max_q_len=2, block_len=4, pool_size=32, kernels=False),
     "medusa64": Scenario(s_medusa64, pool_size=2048, kernels=False),
+    "medusa64_tree": Scenario(s_medusa64_tree, pool_size=2048, kernels=False),
     "tot50": Scenario(s_tot50, pool_size=8192, kernels=False),
     "fewshot_1k": Scenario(s_fewshot_1k, pool_size=2048, kernels=False),
     "fewshot_1k_len200": Scenario(s_fewshot_1k_len200, pool_size=7680, kernels=False),
@@ -190,9 +205,9 @@ SMALL_GEOMETRIES = ((4, 4, 128), (8, 2, 128), (4, 4, 64))
 # at branch length 1 and at the benchmarked length 200, configs[2] (Medusa-64) at the model BASELINE names for it
 # (and configs[0], the 256-prefix x 2-branch plumbing case, at its own model's geometry too)
 FULL_GEOMETRY = {"cfgA_256x2": (32, 32, 128), "fewshot_1k": (32, 32, 128), "fewshot_1k_len200": (32, 32, 128), "fewshot_4k": (32, 32, 128),
-                 "fewshot_4k_len200": (32, 32, 128), "medusa64": (32, 32, 128)}
+                 "fewshot_4k_len200": (32, 32, 128), "medusa64": (32, 32, 128), "medusa64_tree": (32, 32, 128)}
 # Llama-3-8B GQA geometry: the Medusa tree, configs[3] (ToT-50) and one tree of configs[4] (8k x 8 x 64)
-GQA_GEOMETRY = {"medusa64": (32, 8, 128), "tot50": (32, 8, 128), "forest_tree_8kx8": (32, 8, 128)}
+GQA_GEOMETRY = {"medusa64": (32, 8, 128), "medusa64_tree": (32, 8, 128), "tot50": (32, 8, 128), "forest_tree_8kx8": (32, 8, 128)}
 
 
 # the reference's other head dims (`assert Lk in {16, 32, 64, 128}`, tree_attention.py:100, :582): two trees each

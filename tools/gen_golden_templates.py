@@ -3,7 +3,8 @@
 data_loader (DeFT/deft/data_loader.py) in the build container and recording, for the first complete tree of each
 dataset/generation/Reasoning/*.json file, the node table it was built from (ids, token counts, start / end iterations,
 children -- the tree's shape, no text) and the branch_record / prune_record / depth / width the reference derives.
-For one Speculative_Decoding file: Token_Tree_size and the first record's Accept_length.
+For one Speculative_Decoding file: Token_Tree_size, the first record's Accept_length and Tree_Structure (the 63 node paths
+of the depth-4 width-10 Medusa tree).
 
 Usage:  PYTHONDONTWRITEBYTECODE=1 python tools/gen_golden_templates.py
 """
@@ -34,6 +35,8 @@ trees = ref.load_prompts(os.path.join(BASE, "Speculative_Decoding", "tree_size64
 out["speculative"]["tree_size64"] = {"Token_Tree_size": sd["Token_Tree_size"], "records": len(sd["Records"]),
                                      "Accept_length_0": sd["Records"][0]["Accept_length"],
                                      "node_num": trees[0].node_num}
+# the token tree's TOPOLOGY (Medusa choices: one path of top-k indices per node) -- BASELINE configs[2] read literally
+out["speculative"]["tree_size64"]["Tree_Structure"] = sd["Tree_Structure"]
 path = os.path.join(ROOT, "tests", "golden", "templates.json")
 json.dump(out, open(path, "w"), separators=(",", ":"))
 print(path, os.path.getsize(path), "bytes;", {k: v["node_num"] for k, v in out["reasoning"].items()})
