@@ -366,6 +366,15 @@ __global__ __launch_bounds__(256) void merge_kernel(const float* partial_o, cons
     if (q >= nq_total) return;
     _Float16* out_q = out + (int64_t)q * o_st;
     int* list = reinterpret_cast<int*>(smem) + w * cap;
+#ifdef DEFT_EXPERIMENTS
+    if (lists >= 2) {  // TIMING ONLY (wrong results): row ids computed, not loaded -- what a merge without its first dependent round trip costs
+        const int n = lists - 1;
+        if (lane < n) list[lane] = (int)(((int64_t)q * n + lane) % rows);
+        __builtin_amdgcn_wave_barrier();
+        merge_heads_wave<D, 0, 1>(partial_o, partial_lse, row_q, rows, q, hq, 1, Hq, list, cap, n, out_q, o_sh, lane);
+        return;
+    }
+#endif
     if (lists) {  // the plan lists every query's rows: ONE round trip for {count, rows}, one for the rows themselves
         const int mine = lane < 16 ? qinl[q * 16 + lane] : 0;
         const int n = __builtin_amdgcn_readfirstlane(mine);
@@ -805,7 +814,10 @@ static int launch_merge(int D, const Workspace& ws, const PlanView* pv, const in
     if (hgroup <= 0 || Hq % hgroup) hgroup = 1;
     dim3 grid((unsigned)Hq, (unsigned)((nq + 3) / 4));
     // the plan's per-query row lists exist iff its row count fits the histogram kernel (launch_qrows): known on the host
-    const int lists = pv && pv->rows > 0 && pv->rows <= QROWS_MAX ? 1 : 0;
+    int lists = pv && pv->rows > 0 && pv->rows <= QROWS_MAX ? 1 : 0;
+#ifdef DEFT_EXPERIMENTS
+    if (const int fake = knob("DEFT_MERGE_FAKE", 0)) lists = 1 + fake;  // (timing experiment: `fake` computed row ids per query)
+#endif
     const int32_t* qoff = pv ? pv->qoff : nullptr;
     const int32_t* qlist = pv ? pv->qlist : nullptr;
     const int32_t* qinl = pv ? pv->qinl : nullptr;
@@ -1241,7 +1253,8 @@ static int launch_node_plan(const Stage1Params& p, int NE, int64_t rows_cap, con
     if (!par)
         while (sizeof(int) * (3 * (size_t)run_cap + 8) > UNIT_LDS && run_cap > 1) run_cap /= 2;
     hipLaunchKernelGGL(node_units_kernel, dim3(1), dim3(1024), sizeof(int) * ((par ? 8 : 3) * (size_t)run_cap + 8), stream,
-                       p.node_kv_len, p.node_q_len, NE, p.G, (int)pv.cap, rows_cap, ul, pv.hdr, pv.row_q, plan_items_per_leader(p),
+                       p.node_kv_len, p.node_q_len, p.node_q, p.node_q_offset, NE, p.G, (int)pv.cap, rows_cap, ul, pv.hdr, pv.row_q,
+                       plan_items_per_leader(p),
                        2 * num_cus(), np_chunk_knob(), (int)run_cap, par, keep_err, dims);
     rc = check_launch("node units launch");
     if (rc) return rc;

@@ -791,9 +791,15 @@ __global__ __launch_bounds__(128) void flatten_records_kernel(const int64_t* blo
 // Small entries (one tile, one pass) that follow each other are PACKED into one tile as long as their slots fit
 // in 128 and their virtual query rows in 32 -- per-slot row masks make that the same arithmetic (a Medusa step
 // has 64 one-token nodes: 2 tiles instead of 64).  A packed unit has aux = -(entries in it).
+// Round 5: consecutive ONE-TILE entries over the same query list -- what `--mode node_chunk` (MAX_BLOCK_LEN = 128,
+// examples/run_DeFT_llama_paged.py:145-150; tree_cache.py:744-760) makes of every node longer than 128 tokens: a 4096-token
+// prompt arrives as 32 entries of 128 slots under one list -- form ONE run (per 32-row pass), so that they fold like the tiles of
+// one entry: the north-star tree through node_chunk 47.2 -> 36 us per layer (32 partial rows per query and head became 4).
+// Run-table aux = 2: unit j of the run is tile 0 of entry e + j.
 // One workgroup.  Wave 0 walks the entries and decides the runs (packs are sequential by nature), all waves then write the units and the record order from the LDS run table -- as in
 // flatten_units_kernel; `par` = 0 (tables beyond the LDS) or an overflowing table: lane 0 emits as it walks.
-__global__ __launch_bounds__(1024) void node_units_kernel(const int64_t* node_kv_len, const int64_t* node_q_len, int NEc, int G,
+__global__ __launch_bounds__(1024) void node_units_kernel(const int64_t* node_kv_len, const int64_t* node_q_len,
+                                                          const int64_t* node_q, const int64_t* node_q_offset, int NEc, int G,
                                                           int cap, int64_t rows_cap, UnitList ul, int32_t* hdr,
                                                           int32_t* row_q, int Hkv, int slots, int chunk_c, int run_cap,
                                                           int par, int keep_err, const int32_t* dims) {
@@ -834,8 +840,8 @@ __global__ __launch_bounds__(1024) void node_units_kernel(const int64_t* node_kv
                     }
                 } else if (lane == 0) {
                     for (int j = 0; j < n; ++j) {
-                        ul.src[first + j] = e;
-                        ul.aux[first + j] = aux > 0 ? j : aux;
+                        ul.src[first + j] = aux == 2 ? e + j : e;
+                        ul.aux[first + j] = aux == 2 ? 0 : (aux > 0 ? j : aux);
                         ul.pass[first + j] = ps;
                         ul.flags[first + j] = (first << 1) | (j == 0 ? 1 : 0);
                         ul.prow[first + j] = prow0 + j * ql;
@@ -856,12 +862,33 @@ __global__ __launch_bounds__(1024) void node_units_kernel(const int64_t* node_kv
               const int vlen = mine < NE ? (int)node_kv_len[mine] : 0;
               const int vql = mine < NE ? (int)node_q_len[mine] : 0;
               const int lim = min(64, NE - base);
+              // lane i: does entry base + i continue a run of one-tile entries -- the entry before it (same batch) is a FULL tile,
+              // this one is one tile, and both have the same query list?  (No list is read unless the lengths already say yes.)
+              bool cont = false;
+              {
+                  const int plen = __shfl_up(vlen, 1, 64), pql = __shfl_up(vql, 1, 64);
+                  if (lane >= 1 && mine < NE && plen == TILE && vlen >= 1 && vlen <= TILE && vql == pql && vql > 0 && node_q) {
+                      const int64_t a = node_q_offset[mine], b = node_q_offset[mine - 1];
+                      cont = true;
+                      for (int t = 0; t < vql; ++t) cont &= node_q[a + t] == node_q[b + t];
+                  }
+              }
+              const unsigned long long contm = __ballot(cont);
               for (int i = 0; i < lim; ++i) {
                 const int e = base + i;
                 const int len = __builtin_amdgcn_readlane(vlen, i);
                 const int nt = (len + TILE - 1) / TILE;
                 const int ql = __builtin_amdgcn_readlane(vql, i);
                 const int npass = (ql * G + MQ - 1) / MQ;
+                const unsigned long long after = i < 63 ? ~(contm >> (i + 1)) : ~0ull;
+                const int more = nt == 1 ? (after ? __builtin_ctzll(after) : 63 - i) : 0;  // entries e + 1 .. e + more continue e's run
+                if (more > 0 && r < cap) {
+                    pack_r = -1;
+                    for (int ps = 0; ps < npass; ++ps) emit_run(e, 1 + more, ps, rowbase, ql, 2);
+                    rowbase += (1 + more) * ql;
+                    i += more;
+                    continue;
+                }
                 if (nt == 1 && npass == 1 && r < cap) {
                     if (pack_r >= 0 && pack_n < MQ && pack_keys + len <= TILE && pack_rows + ql * G <= MQ) {
                         ++pack_n;
@@ -910,8 +937,8 @@ __global__ __launch_bounds__(1024) void node_units_kernel(const int64_t* node_kv
     for (int k = wave; k < NR; k += nwaves) {
         const int first = rt.r0[k], n = rt.nt[k], e = rT0[k], ps = rSp[k], prow0 = rProw[k], ql = rQl[k], aux = rAux[k];
         for (int j = lane; j < n; j += 64) {
-            ul.src[first + j] = e;
-            ul.aux[first + j] = aux > 0 ? j : aux;
+            ul.src[first + j] = aux == 2 ? e + j : e;
+            ul.aux[first + j] = aux == 2 ? 0 : (aux > 0 ? j : aux);
             ul.pass[first + j] = ps;
             ul.flags[first + j] = (first << 1) | (j == 0 ? 1 : 0);
             ul.prow[first + j] = prow0 + j * ql;

@@ -136,14 +136,18 @@ __device__ inline void tree_apply_ops(const TreeDev& t, const int32_t* ops_g, in
                 // where each new slot goes: (existing slots below it) + (new slots below it)
                 if (tid < k) {
                     const int v = sNew[tid];
-                    int lo = 0, hi = len;  // first existing slot >= v
+                    int lo = 0, hi = len;  // first existing slot > v
+                    // (UPPER bound: a slot the node already holds -- merge_nodes(A, B, pruneB_flag=False) twice without the reset in
+                    //  between hands A the same slot again, tree_cache.py:300-325 allows it -- goes BEHIND its twin; with the lower
+                    //  bound the twin, which shifts by the new slots strictly below it, landed on the same position, one of the two was
+                    //  lost and a stale word stayed in the list: a wild slot number in stage 1.  Round 5.)
                     // (a pool hands out ascending slots, so the new one usually goes behind the node's last: ONE load decides
                     //  that; the binary search is eleven dependent loads on a 1000-token node, 8 us of a decode step)
-                    if (len == 0 || s[len - 1] < v) lo = len;
+                    if (len == 0 || s[len - 1] <= v) lo = len;
                     else
                         while (lo < hi) {
                             const int mid = (lo + hi) >> 1;
-                            if (s[mid] < v) lo = mid + 1;
+                            if (s[mid] <= v) lo = mid + 1;
                             else hi = mid;
                         }
                     sPos[tid] = lo;

@@ -328,3 +328,28 @@ def test_malformed_journal_words_raise_the_error_flag_instead_of_spinning():
     check(lib.deft_tree_dev_apply_ops(*dt._tree_args(), ops.data_ptr(), dt.scratch.data_ptr(), stream), "deft_tree_dev_apply_ops")
     torch.cuda.synchronize()
     assert dt.dims()[9] & 4
+
+
+def test_a_slot_merged_into_a_node_twice_keeps_the_device_list_whole():
+    """`merge_nodes(A, B, pruneB_flag=False)` twice without the reset between them hands A a slot it already holds
+    (tree_cache.py:300-325 allows it; the speculative-decoding mock always resets).  The device replay of that EXTEND used the LOWER
+    bound for the new slot's place: its twin, shifted by the new slots strictly below it, landed on the same position, one of the two
+    was lost and a stale word stayed in the node's list -- a wild slot number in stage 1 (round 5: an aperture violation on the
+    GPU).  Device-built metadata must equal the host builder's through the whole sequence."""
+    tree = _two_leaf_tree()
+    _step(tree)
+    _assert_same(*_both(tree))  # the device copy exists and is current
+    leaves = sorted(tree.leaves.values(), key=lambda n: n.id)
+    tree.merge_nodes(tree.root, leaves[0], pruneB_flag=False)  # journalled EXTEND of the root by the leaf's slot
+    _step(tree)
+    _assert_same(*_both(tree))
+    tree.merge_nodes(tree.root, leaves[0], pruneB_flag=False)  # ... again: [the slot the root already holds, the new one]
+    _step(tree)
+    _assert_same(*_both(tree))
+    root_slots = list(tree.root.kv_indices)
+    assert len(root_slots) == 50 + 1 + 2 and len(set(root_slots)) == 50 + 2  # one slot twice
+    for lf in leaves:
+        tree.reset_node_KV(lf, 0)
+    _step(tree)
+    _assert_same(*_both(tree))
+    assert tree._device_tree.dims()[9] == 0  # no error flag raised by the replay

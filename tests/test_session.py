@@ -247,7 +247,7 @@ def test_second_device_copy_between_steps_cannot_starve_the_session_of_journalle
     q = torch.randn((layers, width, Hq * D), dtype=torch.float16, device="cuda", generator=g)
     k = torch.randn((layers, width, Hkv * D), dtype=torch.float16, device="cuda", generator=g)
     v = torch.randn((layers, width, Hkv * D), dtype=torch.float16, device="cuda", generator=g)
-    sess = deft_amd.DecodeSession(ts, Hq, Hkv, D, layers, lambda l: (q[l], k[l], v[l]), mode=mode)
+    sess = deft_amd.DecodeSession(ts, Hq, Hkv, D, layers, lambda l: (q[l], k[l], v[l]), mode=mode, capture_after=1)
     attn = [deft_amd.DeFTAttention(Hq, D, D ** -0.5, Hkv, l) for l in range(layers)]
     fmode = deft_amd.forward_mode_from_cli(mode)
 
@@ -273,12 +273,18 @@ def test_second_device_copy_between_steps_cannot_starve_the_session_of_journalle
                 tree.merge_nodes(tree.root, lf, pruneB_flag=False)
             tree.reset_nodes_KV(lv, len(tree.root.kv_indices) - before)
 
-    for i in range(4):  # reach the epoch in which merges are absorbed and the step is captured
+    for i in range(6):  # reach the epoch in which merges are absorbed and the step is captured
         step_and_compare(("warm", i))
         speculative_update(2)
     assert sess.graph is not None
+    step_and_compare("every leaf holds its token's slot again")
+    # between two steps the tree absorbs a merge (the root takes a leaf's slots; every node still holds KV, so metadata can be
+    # built) -- journalled, not yet handed to anybody ...
+    for tree in (te, ts):
+        lv = sorted(tree.leaves.values(), key=lambda n: n.id)
+        tree.merge_nodes(tree.root, lv[0], pruneB_flag=False)
     epoch_before = ts._epoch()
-    # the interloper: metadata of the session's tree under another configuration, while the journal holds the last update
+    # ... and the interloper builds metadata of the session's tree under another configuration: a second device copy
     other = deft_amd.TreeMetadata.from_tree_cache(ts, max_q_len=16, copy=True)
     assert other.query_num == width
     assert ts._epoch() != epoch_before, "a fetch that swallowed a pending journal must end the epoch for the other copies"

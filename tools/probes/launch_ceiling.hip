@@ -64,6 +64,35 @@ __global__ __launch_bounds__(256, 2) void rd_gather(const char* pool, const int*
     if (reinterpret_cast<unsigned*>(smem)[tid] == 0x12345678u) out[0] = 1;
 }
 
+// The same bytes per step and per wave, but a workgroup serves a GROUP of HG adjacent KV heads: a step stages 128 (token, head)
+// rows, head fastest -- the HG heads of one token are HG x 256 contiguous bytes of the pool ([slot][K|V][Hkv][128]), so every
+// token contributes one 512-byte / 1-KB burst instead of a 256-byte piece per workgroup (would a small launch
+// read faster that way?).  A 128-token tile takes HG steps; chunk c of a run takes tiles c, c + S, ...
+template <int HG>
+__global__ __launch_bounds__(256, 2) void rd_gather_hg(const char* pool, const int* slots, int tiles, int S, int Hkv, int slot_bytes,
+                                                       unsigned* out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63;
+    const int ng = Hkv / HG;
+    const int chunk = blockIdx.x / ng, hg = blockIdx.x % ng;
+    const char* kb = pool + (size_t)hg * HG * 256 + (l & 15) * 16;
+    const char* vb = kb + (size_t)Hkv * 256;
+    for (int t = chunk; t < tiles; t += S) {
+        for (int step = 0; step < HG; ++step) {
+            const int* sl = slots + (size_t)t * 128 + step * (128 / HG);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int r = 32 * w + 4 * i + (l >> 4);  // (token, head) pair of this step, head fastest
+                const size_t row = (size_t)sl[r / HG] * slot_bytes + (size_t)(r % HG) * 256;
+                dma16nt(kb + row, (unsigned)(w * 8192 + i * 1024));
+                dma16nt(vb + row, (unsigned)(32768 + w * 8192 + i * 1024));
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    }
+    if (reinterpret_cast<unsigned*>(smem)[tid] == 0x12345678u) out[0] = 1;
+}
+
 struct Shape {
     const char* name;
     int prefix, width, blen, Hkv;  // tokens: prefix + width * blen; bytes per token slot = 4 * Hkv * 128
@@ -87,6 +116,8 @@ int main() {
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
     CK(hipFuncSetAttribute((const void*)rd_gather, hipFuncAttributeMaxDynamicSharedMemorySize, 77 * 1024));
+    CK(hipFuncSetAttribute((const void*)rd_gather_hg<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 77 * 1024));
+    CK(hipFuncSetAttribute((const void*)rd_gather_hg<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 77 * 1024));
     // an empty launch, back to back: the fixed cost of a kernel boundary on this stream
     {
         std::vector<float> ts;
@@ -155,6 +186,23 @@ int main() {
             run(what, [&](const char* base) {
                 hipLaunchKernelGGL(rd_gather, dim3(S * s.Hkv), dim3(256), 77 * 1024, 0, base, dslots, tiles, S, s.Hkv, slot_bytes, o);
             });
+        }
+        // head groups: the same steps per workgroup as the 1-head row of C tiles (C = HG x tiles per chunk)
+        for (int HG : {2, 4}) {
+            if (s.Hkv % HG) continue;
+            for (int Ct : {1, 2}) {  // tiles per chunk -> HG x Ct steps per workgroup
+                if (tiles / Ct < 1) continue;
+                const int S = (tiles + Ct - 1) / Ct;
+                const int wgs = S * (s.Hkv / HG);
+                char what[112];
+                snprintf(what, sizeof what, "gather, %d heads x %d-tile chunks (%d steps): %d wgs", HG, Ct, HG * Ct, wgs);
+                const double before = ceiling;
+                run(what, [&](const char* base) {
+                    if (HG == 2) hipLaunchKernelGGL(rd_gather_hg<2>, dim3(wgs), dim3(256), 77 * 1024, 0, base, dslots, tiles, S, s.Hkv, slot_bytes, o);
+                    else hipLaunchKernelGGL(rd_gather_hg<4>, dim3(wgs), dim3(256), 77 * 1024, 0, base, dslots, tiles, S, s.Hkv, slot_bytes, o);
+                });
+                ceiling = before;  // (a question about the layout, not part of the shape's ceiling)
+            }
         }
         printf("    ceiling_us %.2f  (%.3f of 8 TB/s on B_algo)\n\n", ceiling, s.algo_mb / ceiling / 8.0);
         CK(hipFree(d));
