@@ -673,20 +673,20 @@ static int launch_plan(const Stage1Params& p, int NB, const PlanView& pv, const 
     int rc = raise_lds(reinterpret_cast<const void*>(&flatten_units_kernel), (int)UNIT_LDS, ATTR_UNITS, "flatten_units");
     if (rc) return rc;
     // block tables (+ the small blocks' query lists for the union groups, when they fit) and a run table.  With an
-    // entry for every possible run (5 words each) the kernel writes units and record order with all its waves;
+    // entry for every possible run (7 words each) the kernel writes units and record order with all its waves;
     // otherwise one lane emits them and the table holds as many runs as fit (beyond that it scans).
     const int qtab = sizeof(int) * 8 * (size_t)NB <= 100 * 1024;
     const size_t blk = (qtab ? 8 : 4) * (size_t)NB;
     int64_t run_cap = pv.cap;
     int par = !g_plan_serial;
-    if (par && sizeof(int) * (blk + 5 * (size_t)run_cap + 8) > UNIT_LDS) {  // as many runs as fit (the kernel falls back if more turn up)
-        run_cap = ((int64_t)(UNIT_LDS / sizeof(int)) - (int64_t)blk - 8) / 5;
+    if (par && sizeof(int) * (blk + 7 * (size_t)run_cap + 8) > UNIT_LDS) {  // as many runs as fit (the kernel falls back if more turn up)
+        run_cap = ((int64_t)(UNIT_LDS / sizeof(int)) - (int64_t)blk - 8) / 7;
         if (run_cap < 256) par = 0, run_cap = pv.cap;
     }
     if (par && g_plan_runcap > 0) run_cap = std::max(1, std::min((int)run_cap, g_plan_runcap));  // tests: force the fallback
     if (!par)
         while (sizeof(int) * (blk + 3 * (size_t)run_cap + 8) > UNIT_LDS && run_cap > 0) run_cap /= 2;
-    const size_t lds = sizeof(int) * (blk + (par ? 5 : 3) * (size_t)run_cap + 8);
+    const size_t lds = sizeof(int) * (blk + (par ? 7 : 3) * (size_t)run_cap + 8);
     const UnitList ul = unit_list(pv);
     hipLaunchKernelGGL(flatten_units_kernel, dim3(1), dim3(1024), lds, stream, p.block_q, p.block_q_cnts, p.block_q_offset, NB,
                        p.G, (int)pv.cap, ul, pv.hdr, plan_items_per_leader(p), 2 * num_cus(), np_chunk_knob(), np_union_knob(), (int)run_cap, qtab,
@@ -1238,21 +1238,21 @@ int deft_flatten_decode_rope_append_f16(const void* q, int64_t q_stride_tok, int
 static int launch_node_plan(const Stage1Params& p, int NE, int64_t rows_cap, const PlanView& pv, const AppendArgs& ap,
                             hipStream_t stream, int keep_err = 0, const int32_t* dims = nullptr) {
     const UnitList ul = unit_list(pv);
-    // a run table in LDS: 8 words per run and every possible run (the kernel then writes units and
+    // a run table in LDS: 10 words per run and every possible run (the kernel then writes units and
     // record order with all its waves), or as many runs as fit (it falls back to one lane if more turn up)
     constexpr size_t UNIT_LDS = 156 * 1024;
     int rc = raise_lds(reinterpret_cast<const void*>(&node_units_kernel), (int)UNIT_LDS, ATTR_NODE_UNITS, "node_units");
     if (rc) return rc;
     int64_t run_cap = pv.cap > 0 ? pv.cap : 1;
     int par = !g_plan_serial;
-    if (par && sizeof(int) * (8 * (size_t)run_cap + 8) > UNIT_LDS) {
-        run_cap = ((int64_t)(UNIT_LDS / sizeof(int)) - 8) / 8;
+    if (par && sizeof(int) * (10 * (size_t)run_cap + 8) > UNIT_LDS) {
+        run_cap = ((int64_t)(UNIT_LDS / sizeof(int)) - 8) / 10;
         if (run_cap < 256) par = 0, run_cap = pv.cap > 0 ? pv.cap : 1;
     }
     if (par && g_plan_runcap > 0) run_cap = std::max(1, std::min((int)run_cap, g_plan_runcap));  // tests: force the fallback
     if (!par)
         while (sizeof(int) * (3 * (size_t)run_cap + 8) > UNIT_LDS && run_cap > 1) run_cap /= 2;
-    hipLaunchKernelGGL(node_units_kernel, dim3(1), dim3(1024), sizeof(int) * ((par ? 8 : 3) * (size_t)run_cap + 8), stream,
+    hipLaunchKernelGGL(node_units_kernel, dim3(1), dim3(1024), sizeof(int) * ((par ? 10 : 3) * (size_t)run_cap + 8), stream,
                        p.node_kv_len, p.node_q_len, p.node_q, p.node_q_offset, NE, p.G, (int)pv.cap, rows_cap, ul, pv.hdr, pv.row_q,
                        plan_items_per_leader(p),
                        2 * num_cus(), np_chunk_knob(), (int)run_cap, par, keep_err, dims);

@@ -212,18 +212,18 @@ __device__ inline void np_record_order(const UnitList& ul, int R, int Hkv, int G
     hdr[1] = NL;
 }
 
-// Record order of the tile-parallel stage 1, written by all waves of the unit kernel from its LDS run table (the
-// rules of np_record_order above, same result).  Called by every thread after the units are written; rT0 / rSp are
-// scratch arrays of run_cap words (the callers' run fields are dead by then), sMeta[2..3] two shared words.
-__device__ inline void record_order_parallel(const UnitList& ul, const RunTable& rt, int NR, int* rT0, int* rSp, int* sMeta,
-                                             int32_t* hdr, int Hkv, int G, int slots, int chunk_c) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+// Record order of the tile-parallel stage 1, from the unit kernel's LDS run table (the rules of np_record_order above, same
+// result), in two parts.  record_order_wave0: ONE wave decides the chunk length C from sums / maxima over the runs, then each
+// run's first leader and first follower record by prefix sums over the runs' chunk counts, into rT0 / rSp -- two arrays of run_cap
+// words OF ITS OWN (round 5: it used to reuse the callers' run fields, so the units had to be written first and the barrier in
+// between drained their stores: 2-4 us of a 17 us kernel; now the other waves write the units WHILE wave 0 decides, and the
+// barrier between the two parts is an LDS barrier).  record_order_write: all waves, after that barrier.  sMeta[2..3]: two shared words.
+__device__ inline void record_order_wave0(const RunTable& rt, int NR, int* rT0, int* rSp, int* sMeta, int32_t* hdr, int Hkv, int G,
+                                          int slots, int chunk_c) {
+    const int lane = threadIdx.x & 63;
     const bool pairs = Hkv < 0;  // (np_record_order: head pairs)
     Hkv = pairs ? -Hkv : Hkv;
-    __syncthreads();  // (rT0 / rSp are reused below)
-    // Wave 0: chunk length C from sums / maxima over the runs, then each run's first leader and first follower record
-    // by prefix sums over the runs' chunk counts.
-    if (threadIdx.x < 64) {
+    {
         auto wave_sum = [&](auto&& f) {
             int acc = 0;
             for (int k = lane; k < NR; k += 64) acc += f(rt.nt[k], rt.uni[k]);
@@ -294,7 +294,11 @@ __device__ inline void record_order_parallel(const UnitList& ul, const RunTable&
             hdr[1] = leadL + leadS;
         }
     }
-    __syncthreads();
+}
+
+__device__ inline void record_order_write(const UnitList& ul, const RunTable& rt, int NR, const int* rT0, const int* rSp,
+                                          const int* sMeta) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     {
         const int C = sMeta[2], NL = sMeta[3];
         for (int k = wave; k < NR; k += nwaves) {
@@ -516,9 +520,11 @@ __global__ __launch_bounds__(1024) void flatten_units_kernel(const int64_t* bloc
     // record order are then written by all waves (phases 3 and 4) -- one thread emitting them costs ~0.4 us per unit
     // and pass, 75 us per decode step for the north-star tree and 2 ms for a 100k-token prefix under 48 branches.
     // Otherwise (tables beyond the LDS) lane 0 emits as it walks.
-    int* sMeta = sRun + (par ? 5 : 3) * run_cap;  // [8]: units, runs, chunk length, leaders, "written by all waves"
-    int* rT0 = sRun + 3 * run_cap;    // par: first block of the run;      later: the run's first leader record
-    int* rSp = sRun + 4 * run_cap;    // par: block stride | pass << 8;   later: the run's first follower record - leaders
+    int* sMeta = sRun + (par ? 7 : 3) * run_cap;  // [8]: units, runs, chunk length, leaders, "written by all waves"
+    int* rT0 = sRun + 3 * run_cap;    // par: first block of the run
+    int* rSp = sRun + 4 * run_cap;    // par: block stride | pass << 8
+    int* rLead = sRun + 5 * run_cap;  // par: the run's first leader record            (record_order_wave0)
+    int* rFoll = sRun + 6 * run_cap;  // par: the run's first follower record - leaders
     const int lane = threadIdx.x & 63;
     const int par_req = par;
     if (threadIdx.x < 64) {
@@ -631,10 +637,12 @@ __global__ __launch_bounds__(1024) void flatten_units_kernel(const int64_t* bloc
     }
     __syncthreads();
     if (!sMeta[4]) return;
-    // Phase 3: the units of run k, one wave per run, one lane per unit.
+    // Phases 3 and 4 side by side: wave 0 decides the record order of the tile-parallel stage 1 (record_order_wave0) while the
+    // other waves write the units of run k, one wave per run, one lane per unit; an LDS barrier; all waves write the order.
     const int NR = sMeta[1];
     const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-    for (int k = wave; k < NR; k += nwaves) {
+    if (np && wave == 0) record_order_wave0(rt, NR, rLead, rFoll, sMeta, hdr, Hkv, G, slots, chunk_c);
+    for (int k = np ? wave - 1 : wave; k < NR && k >= 0; k += np ? nwaves - 1 : nwaves) {
         const int first = rt.r0[k], n = rt.nt[k], aux = rt.uni[k], t0 = rT0[k], st = rSp[k] & 0xff, ps = rSp[k] >> 8;
         if (aux > 0 && lane == 0) {  // a union group: its queries and the rows that carry their partials
             int uq[UNION_CAP], urow[UNION_CAP], un;
@@ -655,8 +663,8 @@ __global__ __launch_bounds__(1024) void flatten_units_kernel(const int64_t* bloc
         }
     }
     if (!np) return;
-    // Phase 4: record order of the tile-parallel stage 1
-    record_order_parallel(ul, rt, NR, rT0, rSp, sMeta, hdr, Hkv, G, slots, chunk_c);
+    lds_barrier();  // (wave 0's rLead / rFoll / sMeta; NOT the unit stores above: nobody in this kernel reads them)
+    record_order_write(ul, rt, NR, rLead, rFoll, sMeta);
 }
 
 // One workgroup of 128 threads per unit (+ the sentinel): pack its record.
@@ -812,11 +820,18 @@ __global__ __launch_bounds__(1024) void node_units_kernel(const int64_t* node_kv
     int* rSp = sRun + 4 * run_cap;    // par: the run's pass;                later: its first follower record - leaders
     int* rProw = sRun + 5 * run_cap;  // par: partial row of the run's first tile
     int* rQl = sRun + 6 * run_cap;    // par: partial rows per tile
-    int* rAux = sRun + 7 * run_cap;   // par: 1 = tiles of one entry (aux = tile index), <= 0 = a pack (aux = -entries)
-    int* sMeta = sRun + (par ? 8 : 3) * run_cap;  // [8]
+    int* rAux = sRun + 7 * run_cap;   // par: 1 = tiles of one entry (aux = tile index), <= 0 = a pack (aux = -entries), 2 = one-tile entries
+    int* rLead = sRun + 8 * run_cap;  // par: the run's first leader record            (record_order_wave0)
+    int* rFoll = sRun + 9 * run_cap;  // par: the run's first follower record - leaders
+    int* sMeta = sRun + (par ? 10 : 3) * run_cap;  // [8]
     for (int64_t i = threadIdx.x; i < rows_cap; i += blockDim.x) row_q[i] = -1;
     const int lane = threadIdx.x & 63;
     const int par_req = par;
+    __shared__ const int64_t* sListPtr[2];  // node_q, node_q_offset for the walk's rare fold test (written and read by wave 0 only)
+    if (threadIdx.x == 0) {
+        sListPtr[0] = node_q;
+        sListPtr[1] = node_q_offset;
+    }
     if (threadIdx.x < 64) {
         for (int attempt = 0; attempt < 2; ++attempt) {
             par = par_req && attempt == 0;
@@ -863,33 +878,38 @@ __global__ __launch_bounds__(1024) void node_units_kernel(const int64_t* node_kv
               const int vql = mine < NE ? (int)node_q_len[mine] : 0;
               const int lim = min(64, NE - base);
               // lane i: does entry base + i continue a run of one-tile entries -- the entry before it (same batch) is a FULL tile,
-              // this one is one tile, and both have the same query list?  (No list is read unless the lengths already say yes.)
-              bool cont = false;
-              {
+              // this one is one tile, and both have the same query list?  Nothing is read, shuffled or counted unless some entry of
+              // the batch is exactly one full tile (uniform test: ordinary Node metadata -- whole nodes -- skips all of it; computed
+              // per entry inside the walk this cost a Medusa step's plan 3-5 us).  vmore: entries that continue lane i's run.
+              int vmore = 0;
+              if (__ballot(mine < NE && vlen == TILE) != 0ull) {
+                  bool cont = false;
                   const int plen = __shfl_up(vlen, 1, 64), pql = __shfl_up(vql, 1, 64);
-                  if (lane >= 1 && mine < NE && plen == TILE && vlen >= 1 && vlen <= TILE && vql == pql && vql > 0 && node_q) {
-                      const int64_t a = node_q_offset[mine], b = node_q_offset[mine - 1];
+                  // (the two list pointers come back from the LDS: as kernel arguments they would stay in SGPRs through the whole
+                  //  walk -- 15 more spilled SGPRs, +1.5 ... +3.5 us on every Node plan that never takes this branch)
+                  const int64_t* nq = sListPtr[0];
+                  const int64_t* nqo = sListPtr[1];
+                  if (lane >= 1 && mine < NE && plen == TILE && vlen >= 1 && vlen <= TILE && vql == pql && vql > 0 && nq) {
+                      const int64_t a = nqo[mine], b = nqo[mine - 1];
                       cont = true;
-                      for (int t = 0; t < vql; ++t) cont &= node_q[a + t] == node_q[b + t];
+                      for (int t = 0; t < vql; ++t) cont &= nq[a + t] == nq[b + t];
                   }
+                  const unsigned long long contm = __ballot(cont);
+                  const unsigned long long after = lane < 63 ? ~(contm >> (lane + 1)) : ~0ull;
+                  vmore = (contm && vlen >= 1 && vlen <= TILE) ? (after ? __builtin_ctzll(after) : 63 - lane) : 0;
               }
-              const unsigned long long contm = __ballot(cont);
               for (int i = 0; i < lim; ++i) {
                 const int e = base + i;
                 const int len = __builtin_amdgcn_readlane(vlen, i);
                 const int nt = (len + TILE - 1) / TILE;
                 const int ql = __builtin_amdgcn_readlane(vql, i);
                 const int npass = (ql * G + MQ - 1) / MQ;
-                const unsigned long long after = i < 63 ? ~(contm >> (i + 1)) : ~0ull;
-                const int more = nt == 1 ? (after ? __builtin_ctzll(after) : 63 - i) : 0;  // entries e + 1 .. e + more continue e's run
-                if (more > 0 && r < cap) {
-                    pack_r = -1;
-                    for (int ps = 0; ps < npass; ++ps) emit_run(e, 1 + more, ps, rowbase, ql, 2);
-                    rowbase += (1 + more) * ql;
-                    i += more;
-                    continue;
-                }
-                if (nt == 1 && npass == 1 && r < cap) {
+                // entries e + 1 .. e + more continue e's run: `1 + more` one-tile entries emitted like the tiles of one entry (no third
+                // emit site: on a lone workgroup every cold instruction line is a dependent round trip, and the ordinary walk
+                // must not pay for this case)
+                const int more = __builtin_amdgcn_readlane(vmore, i);
+                const int nrun = more > 0 ? 1 + more : nt;
+                if (more == 0 && nt == 1 && npass == 1 && r < cap) {
                     if (pack_r >= 0 && pack_n < MQ && pack_keys + len <= TILE && pack_rows + ql * G <= MQ) {
                         ++pack_n;
                         pack_keys += len;
@@ -908,9 +928,10 @@ __global__ __launch_bounds__(1024) void node_units_kernel(const int64_t* node_kv
                     }
                 } else {
                     pack_r = -1;
-                    for (int ps = 0; ps < npass; ++ps) emit_run(e, nt, ps, rowbase, ql, 1);
+                    for (int ps = 0; ps < npass; ++ps) emit_run(e, nrun, ps, rowbase, ql, more > 0 ? 2 : 1);
                 }
-                rowbase += nt * ql;
+                rowbase += nrun * ql;
+                i += more;
               }
             }
             if (lane == 0) {
@@ -934,7 +955,9 @@ __global__ __launch_bounds__(1024) void node_units_kernel(const int64_t* node_kv
     if (!sMeta[4]) return;
     const int NR = sMeta[1];
     const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-    for (int k = wave; k < NR; k += nwaves) {
+    // (flatten_units_kernel: wave 0 decides the record order while the other waves write the units)
+    if (np && wave == 0) record_order_wave0(rt, NR, rLead, rFoll, sMeta, hdr, Hkv, G, slots, chunk_c);
+    for (int k = np ? wave - 1 : wave; k < NR && k >= 0; k += np ? nwaves - 1 : nwaves) {
         const int first = rt.r0[k], n = rt.nt[k], e = rT0[k], ps = rSp[k], prow0 = rProw[k], ql = rQl[k], aux = rAux[k];
         for (int j = lane; j < n; j += 64) {
             ul.src[first + j] = aux == 2 ? e + j : e;
@@ -945,7 +968,8 @@ __global__ __launch_bounds__(1024) void node_units_kernel(const int64_t* node_kv
         }
     }
     if (!np) return;
-    record_order_parallel(ul, rt, NR, rT0, rSp, sMeta, hdr, Hkv, G, slots, chunk_c);
+    lds_barrier();
+    record_order_write(ul, rt, NR, rLead, rFoll, sMeta);
 }
 
 __global__ __launch_bounds__(128) void node_records_kernel(const int64_t* node_kv, const int64_t* node_kv_offset,
