@@ -3,7 +3,7 @@
 # bench line, the rocprofv3 kernel-trace summary of the STEP graph alone and the two PMC passes (own runs, --kernel-trace
 # only), the two-rank rehearsal of the N > 1 path over gloo, the fuzzers.  Writes gpurun_out/<tag>/<tag>_*; the files judged are
 # copied from there into profiles/ (see profiles/README.md).
-TAG=${1:-r4z}
+TAG=${1:-r5z}
 R=$GRAFT_REPO_ROOT; export PYTHONPATH=$R; O=$R/gpurun_out/$TAG; mkdir -p $O
 cd $R
 # replays: through the captured session (default) -- per-step synchronised (per-step attention times) and pipelined (the loop as a
@@ -41,7 +41,7 @@ timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/kt_$TAG -- pyth
 python $R/tools/kernel_gaps.py /tmp/kt_$TAG 0.4 > $O/${TAG}_kernel_gaps.txt 2>&1
 tail -c 600 $O/${TAG}_bench_default.json | head -c 300; echo; head -8 $O/${TAG}_kernel_stats.txt | cut -c1-160
 # the small BASELINE configurations under the kernel trace (configs[2], configs[3]) and head_dim 64
-for wl in medusa64_node tot50_4k gqa_4kx32 northstar_4kx32_d64; do
+for wl in medusa64_node medusa64_tree_node tot50_4k gqa_4kx32 northstar_4kx32_d64 northstar_4kx32_node_chunk; do
   timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_${TAG}_$wl -- python $R/bench.py --workload $wl --steps 100 --warmup 10 --step-only > /dev/null 2>&1
   python $R/tools/prof_summary.py /tmp/prof_${TAG}_$wl 2>&1 | head -6 | cut -c1-160 > $O/${TAG}_kernel_stats_$wl.txt
 done

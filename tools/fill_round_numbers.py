@@ -59,7 +59,9 @@ vals = {
     "LEN1": wl("northstar_4kx32_len1"), "LEN400": wl("northstar_4kx32_len400"), "1K": wl("fewshot_1kx32"),
     "MEDUSA": wl("medusa64_node"), "TOTR": None, "TOT": wl("tot50_4k"), "GQA": wl("gqa_4kx32"), "F1": wl("forest_8kx8_single"),
     "CFG5E2E": c5["end_to_end"]["ms_per_step"], "CFG5": f"{c5['us_per_layer']} ({c5.get('stage1_hbm_frac')})",
-    "NODE": wl("northstar_4kx32_node"), "SEQ": wl("northstar_4kx32_seq"), "D64": wl("northstar_4kx32_d64"),
+    "NODE": wl("northstar_4kx32_node"), "NCHUNK": wl("northstar_4kx32_node_chunk") if "northstar_4kx32_node_chunk" in ow else "n/a",
+    "MTN": wl("medusa64_tree_node") if "medusa64_tree_node" in ow else "n/a",
+    "MTF": wl("medusa64_tree_flatten") if "medusa64_tree_flatten" in ow else "n/a", "SEQ": wl("northstar_4kx32_seq"), "D64": wl("northstar_4kx32_d64"),
     "PF4": pf["4096"]["TFLOPs"], "PF16": pf["16384"]["TFLOPs"],
     "PFD4": (pf.get("4096_head_dim_64") or {}).get("TFLOPs", "?"), "PFD16": (pf.get("16384_head_dim_64") or {}).get("TFLOPs", "?"),
     "CPU16": b["cpu_baseline"]["fp16"]["value"], "CPU": b["cpu_baseline"]["value"],
@@ -78,7 +80,9 @@ except Exception:
     vals.update({"BEAM": "n/a", "BEAMR": "n/a", "BEAMP": "n/a", "BEAMPR": "n/a"})
 # the small-launch table of section 4b: B_algo, ceiling, stage 1, layer
 rows = []
-names = [("medusa64_node", "Medusa-64, DeFT-Node (configs[2])"), ("tot50_4k", "ToT-50, Llama-3-8B (configs[3])"),
+names = [("medusa64_node", "Medusa-64 as the reference mocks it, DeFT-Node (configs[2])"),
+         ("medusa64_tree_node", "the Medusa token tree itself, DeFT-Node (configs[2] read literally)"),
+         ("medusa64_tree_flatten", "the Medusa token tree itself, DeFT-Flatten"), ("tot50_4k", "ToT-50, Llama-3-8B (configs[3])"),
          ("forest_8kx8_single", "one 8k x 8 tree of configs[4]"), ("gqa_4kx32", "north-star tree on Llama-3-8B (GQA 4k x 32)"),
          ("northstar_4kx32_len1", "north-star tree at branch length 1"), ("fewshot_1kx32", "1k x 32 x 200 (configs[1])")]
 for key, label in names:
