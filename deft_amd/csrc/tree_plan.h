@@ -190,8 +190,10 @@ __global__ __launch_bounds__(1024) void tree_ops_kernel(TreeDev t, const int32_t
 }
 
 // exclusive scan of f(i), i < m, into out[0 .. m] by the whole workgroup (1024 threads, chunks of 1024 with a carry)
+// Returns the total (every thread): a caller that needs it does not read out[m] back -- with `out` in global memory that is a
+// store and a dependent load, two round trips of a lone workgroup.
 template <class F>
-__device__ inline void block_exclusive_scan(int m, F f, int32_t* out, int* sWave, int* sCarry) {
+__device__ inline int block_exclusive_scan(int m, F f, int32_t* out, int* sWave, int* sCarry) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) *sCarry = 0;
     __syncthreads();
@@ -213,8 +215,10 @@ __device__ inline void block_exclusive_scan(int m, F f, int32_t* out, int* sWave
         if (tid == 1023) *sCarry = carry + wbase + inc;
         __syncthreads();
     }
-    if (tid == 0) out[m] = *sCarry;
-    __syncthreads();
+    const int total = *sCarry;
+    if (tid == 0) out[m] = total;
+    __syncthreads();  // (everybody has read the carry before the next scan clears it)
+    return total;
 }
 
 __device__ inline int refs_count(const unsigned long long* r, int nqw) {
@@ -247,16 +251,38 @@ __global__ __launch_bounds__(1024) void tree_md_scan_kernel(TreeDev t, TreeScrat
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int n = t.n, nqw = t.nqw;
     const int tid = threadIdx.x;
-    if (ops && ops[0] > 0) {  // the journal of this step's absorbed changes first (uniform branch), then the step's new slots
+    const bool in_lds = n <= TREE_LDS_NODES;
+    // tables: [n+1] each -- LDS when the tree fits, else the global scratch directly
+    int32_t* pos = in_lds ? reinterpret_cast<int32_t*>(smem) : s.pos;
+    int32_t* e_off = in_lds ? pos + (n + 1) : s.e_off;
+    int32_t* q_off = in_lds ? e_off + (n + 1) : s.q_off;
+    int32_t* kv_off = in_lds ? q_off + (n + 1) : s.kv_off;
+    int32_t* nlen = in_lds ? kv_off + (n + 1) : nullptr;   // node_len copy
+    int32_t* nqc = in_lds ? nlen + (n + 1) : nullptr;      // leaf count per node
+    // Round 5: every load that depends on nothing goes out FIRST and together -- the journal's word count, the node table (lengths,
+    // leaf sets), this step's leaves and slots -- instead of one after the other behind the branch on the word count and behind the
+    // advance's fence: a lone workgroup pays 1-2 us per dependent round trip, and this kernel opened with four of them.
+    const int nops = ops ? ops[0] : 0;
+    auto load_tables = [&]() {
+        for (int i = tid; i < n; i += 1024) {
+            nlen[i] = t.node_len[i];
+            nqc[i] = refs_count(t.refs + (size_t)i * nqw, nqw);
+        }
+    };
+    if (in_lds) load_tables();
+    if (nops > 0) {  // the journal of this step's absorbed changes first (uniform branch), then the step's new slots
         __shared__ int sNew[TREE_OPS_NEW], sPos[TREE_OPS_NEW], sMeta[4], sOps[TREE_OPS_LDS];
+        __syncthreads();
         tree_apply_ops(t, ops, s.dims + TREE_ERR, sNew, sPos, sMeta, sOps);
+        if (in_lds) load_tables();  // (the replay changed node lengths: read them again -- speculative-decoding steps only)
     }
     if (cache_loc && pw.table)
         for (int r = tid; r < t.nq; r += 1024) pw.table[pw.rows[r] * pw.stride + pw.cols[r]] = cache_loc[r];
+    if (in_lds) __syncthreads();  // the tables are in the LDS
     if (cache_loc) {  // advance: one slot per live leaf, kept ascending inside the node
         for (int r = tid; r < t.nq; r += 1024) {
             const int i = t.leaf_node[r];
-            const int len = t.node_len[i];
+            const int len = in_lds ? nlen[i] : t.node_len[i];
             if (len >= t.node_cap[i]) {
                 atomicOr(s.dims + TREE_ERR, 1);
                 continue;
@@ -270,23 +296,9 @@ __global__ __launch_bounds__(1024) void tree_md_scan_kernel(TreeDev t, TreeScrat
             }
             sl[p] = v;
             t.node_len[i] = len + 1;
+            if (in_lds) nlen[i] = len + 1;  // (a leaf is one query row: nobody else touches its entry)
         }
-        __threadfence_block();
-        __syncthreads();
-    }
-    const bool in_lds = n <= TREE_LDS_NODES;
-    // tables: [n+1] each -- LDS when the tree fits, else the global scratch directly
-    int32_t* pos = in_lds ? reinterpret_cast<int32_t*>(smem) : s.pos;
-    int32_t* e_off = in_lds ? pos + (n + 1) : s.e_off;
-    int32_t* q_off = in_lds ? e_off + (n + 1) : s.q_off;
-    int32_t* kv_off = in_lds ? q_off + (n + 1) : s.kv_off;
-    int32_t* nlen = in_lds ? kv_off + (n + 1) : nullptr;   // node_len copy
-    int32_t* nqc = in_lds ? nlen + (n + 1) : nullptr;      // leaf count per node
-    if (in_lds) {
-        for (int i = tid; i < n; i += 1024) {
-            nlen[i] = t.node_len[i];
-            nqc[i] = refs_count(t.refs + (size_t)i * nqw, nqw);
-        }
+        if (!in_lds) __threadfence_block();
         __syncthreads();
     }
     auto len_of = [&](int i) { return in_lds ? nlen[i] : t.node_len[i]; };
@@ -297,11 +309,10 @@ __global__ __launch_bounds__(1024) void tree_md_scan_kernel(TreeDev t, TreeScrat
         const int step = max_block_len == -1 ? len : max_block_len;
         return step > 0 ? (len + step - 1) / step : 0;
     };
-    block_exclusive_scan(n, [&](int i) { return len_of(i); }, pos, sWave, &sCarry);
-    block_exclusive_scan(n, [&](int i) { return qch(i) * kch(i); }, e_off, sWave, &sCarry);
-    block_exclusive_scan(n, [&](int i) { return nq_of(i) * kch(i); }, q_off, sWave, &sCarry);
-    block_exclusive_scan(n, [&](int i) { return len_of(i) * qch(i); }, kv_off, sWave, &sCarry);
-    const int total = pos[n];
+    const int total = block_exclusive_scan(n, [&](int i) { return len_of(i); }, pos, sWave, &sCarry);
+    const int tot_e = block_exclusive_scan(n, [&](int i) { return qch(i) * kch(i); }, e_off, sWave, &sCarry);
+    const int tot_q = block_exclusive_scan(n, [&](int i) { return nq_of(i) * kch(i); }, q_off, sWave, &sCarry);
+    const int tot_kv = block_exclusive_scan(n, [&](int i) { return len_of(i) * qch(i); }, kv_off, sWave, &sCarry);
     const int nbp = (total + block_len - 1) / block_len;
     if (nbp > nbp_cap) {
         if (tid == 0) {
@@ -351,8 +362,8 @@ __global__ __launch_bounds__(1024) void tree_md_scan_kernel(TreeDev t, TreeScrat
     }
     __syncthreads();
     auto bcount = [&](int b) { return blk_lds ? b_cnt[b] : refs_count(s.b_union + (size_t)b * nqw, nqw); };
-    block_exclusive_scan(nbp, [&](int b) { return (bcount(b) + max_q_len - 1) / max_q_len; }, s.b_eoff, sWave, &sCarry);
-    block_exclusive_scan(nbp, [&](int b) { return bcount(b); }, s.b_poff, sWave, &sCarry);
+    const int tot_be = block_exclusive_scan(nbp, [&](int b) { return (bcount(b) + max_q_len - 1) / max_q_len; }, s.b_eoff, sWave, &sCarry);
+    const int tot_bp = block_exclusive_scan(nbp, [&](int b) { return bcount(b); }, s.b_poff, sWave, &sCarry);
     if (in_lds)  // the node tables leave the LDS in one pass
         for (int i = tid; i <= n; i += 1024) {
             s.pos[i] = pos[i];
@@ -362,13 +373,13 @@ __global__ __launch_bounds__(1024) void tree_md_scan_kernel(TreeDev t, TreeScrat
         }
     if (tid == 0) {
         s.dims[0] = t.nq;
-        s.dims[1] = e_off[n];
+        s.dims[1] = tot_e;
         s.dims[2] = total;
-        s.dims[3] = q_off[n];
-        s.dims[4] = kv_off[n];
-        s.dims[5] = s.b_eoff[nbp];
-        s.dims[6] = s.b_poff[nbp];
-        s.dims[7] = s.b_eoff[nbp] * block_len;
+        s.dims[3] = tot_q;
+        s.dims[4] = tot_kv;
+        s.dims[5] = tot_be;
+        s.dims[6] = tot_bp;
+        s.dims[7] = tot_be * block_len;
         s.dims[8] = nbp;
     }
 }
