@@ -468,7 +468,7 @@ def test_forest_batch_equals_its_trees_one_by_one(geom, mode):
 # sequential comparator (token_attention_fwd / radix_attention_forward, `--mode seq`)
 # ---------------------------------------------------------------------------
 SEQ_GOLDEN = {"cfgA_256x2": [(4, 4, 128), (8, 2, 128)], "multilevel": [(4, 4, 128), (8, 2, 128), (4, 4, 64)],
-              "wide40": [(8, 2, 128)], "chain_300": [(4, 4, 128)]}
+              "wide40": [(8, 2, 128)], "chain_300": [(4, 4, 128)], "medusa64_tree": [(8, 2, 128)]}
 TOL_SEQ_REF = 2.5e-3  # the reference keeps its logits in fp16 (token_attention.py:312-314): 1.3e-3 from truth by itself
 
 

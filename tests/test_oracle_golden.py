@@ -155,7 +155,7 @@ def test_reference_merge_quirk_documented():
 
 
 SEQ_GOLDEN = {"cfgA_256x2": [(4, 4, 128), (8, 2, 128)], "multilevel": [(4, 4, 128), (8, 2, 128), (4, 4, 64)],
-              "wide40": [(8, 2, 128)], "chain_300": [(4, 4, 128)]}
+              "wide40": [(8, 2, 128)], "chain_300": [(4, 4, 128)], "medusa64_tree": [(8, 2, 128)]}
 
 
 @pytest.mark.parametrize("name", sorted(SEQ_GOLDEN))

@@ -19,6 +19,8 @@ timeout 300 python tools/replay.py --task speculative_decoding --modes node flat
 # the shipped reasoning templates' shape: width 10 per level, a branch (and nine prunes) every 8 steps -- synchronised per step and pipelined
 timeout 300 python tools/replay.py --task reasoning --beam 10,12,8 --prompt-len 4096 --modes flatten --out $O/${TAG}_replay_reasoning_beam10x8.json > $O/replay_beam.log 2>&1
 timeout 300 python tools/replay.py --task reasoning --beam 10,12,8 --prompt-len 4096 --modes flatten --pipelined --out $O/${TAG}_replay_reasoning_beam10x8_pipelined.json > $O/replay_beamp.log 2>&1
+# the reference's OWN reasoning template (first complete tree of docmergeToT.json: 31 nodes, a 1073-token prompt, 2375 decode steps), whole
+timeout 600 python tools/replay.py --task reasoning --golden-template docmergeToT --max-gen-len 100000 --modes flatten node --pipelined --out $O/${TAG}_replay_reasoning_docmergeToT_pipelined.json > $O/replay_docmerge.log 2>&1
 timeout 900 python bench.py > $O/${TAG}_bench_default.json 2> $O/bench.err
 # the N > 1 path on one GPU: two ranks over gloo (RCCL needs a GPU per rank; the driver's 8-GPU run uses it)
 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --dist-backend gloo --steps 50 --warmup 10 --no-extras --no-cpu-baseline --no-traffic 2> $O/bench_2rank.err | grep '^{' > $O/${TAG}_bench_2rank_gloo_one_gpu.json

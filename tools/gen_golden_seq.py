@@ -5,7 +5,7 @@ page table of the reference's own TreeCache.  Build-container only, same shim as
 imported from /root/reference, never copied).  Stored: the page-table rows, request indices and sequence lengths the
 operator was called with, and its fp16 output per geometry; q / kv inputs are regenerated from seeds.
 
-Usage:  PYTHONDONTWRITEBYTECODE=1 TRITON_INTERPRET=1 python tools/gen_golden_seq.py
+Usage:  PYTHONDONTWRITEBYTECODE=1 TRITON_INTERPRET=1 python tools/gen_golden_seq.py [scenario ...]
 """
 from __future__ import annotations
 
@@ -31,7 +31,9 @@ from scenarios import SCENARIOS, input_seeds  # noqa: E402
 from deft_amd.utils.synthetic import dyadic_normal  # noqa: E402
 
 SEQ_CASES = {"cfgA_256x2": [(4, 4, 128), (8, 2, 128)], "multilevel": [(4, 4, 128), (8, 2, 128), (4, 4, 64)],
-             "wide40": [(8, 2, 128)], "chain_300": [(4, 4, 128)]}
+             "wide40": [(8, 2, 128)], "chain_300": [(4, 4, 128)],
+             # the Medusa token tree itself (configs[2] read literally): 42 leaves at depths 1-4, each page-table row = prompt + its chain
+             "medusa64_tree": [(8, 2, 128)]}
 
 
 def main() -> None:
@@ -42,6 +44,8 @@ def main() -> None:
         import deft.layers.attention.token_attention as ref_tok
 
         for name, geoms in SEQ_CASES.items():
+            if len(sys.argv) > 1 and name not in sys.argv[1:]:
+                continue
             sc = SCENARIOS[name]
             t0 = time.time()
             req_pool = ReqToTokenPool(size=128, max_context_len=sc.pool_size + 8)

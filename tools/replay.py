@@ -4,6 +4,7 @@
 
   tools/replay.py --task reasoning --modes flatten node seq                      # synthetic ToT 4k prompt, 7x128 -> 42x64
   tools/replay.py --task reasoning --template .../Reasoning/sorting128ToT.json  # a file of the reference's dataset
+  tools/replay.py --task reasoning --golden-template docmergeToT --max-gen-len 100000   # the same template from tests/golden/templates.json
   tools/replay.py --task speculative_decoding --modes node flatten seq --tree-size 64
   tools/replay.py --task few_shot --width 32 --prompt-len 4096 --max-gen-len 200
 """
@@ -19,6 +20,10 @@ ap.add_argument("--modes", nargs="+", default=["flatten", "node", "seq"])
 ap.add_argument("--model", default="llama2-7b", choices=sorted(GEOMETRY))
 ap.add_argument("--layers", type=int, default=None)
 ap.add_argument("--template", default=None, help="a dataset/generation/** file of the reference repository")
+ap.add_argument("--golden-template", default=None, metavar="NAME",
+                help="reasoning: the node table of the reference's own template NAME (docmergeToT, keywordToT, set128ToT, sorting128ToT: "
+                     "the first complete tree of that dataset file) as recorded in tests/golden/templates.json -- the file itself "
+                     "belongs to the reference repository and is not on the GPU box")
 ap.add_argument("--tree-index", type=int, default=0)
 ap.add_argument("--prompt-len", type=int, default=None)
 ap.add_argument("--max-gen-len", type=int, default=400)
@@ -44,6 +49,9 @@ L = a.layers or L
 
 def template():
     if a.task == "reasoning":
+        if a.golden_template:
+            gold = json.load(open(os.path.join(ROOT, "tests", "golden", "templates.json")))
+            return rp.TreeTemplate.from_node_table(gold["reasoning"][a.golden_template]["data"])
         if a.template:
             return rp.read_reasoning_file(a.template)[a.tree_index]
         if a.beam:
@@ -66,7 +74,7 @@ else:
     a_modes = list(a.modes)
 for idx, mode in enumerate(a_modes):
     tpl = template()
-    prompt_len = a.prompt_len or rp.default_prompt_len(tpl, a.task, from_file=bool(a.template))
+    prompt_len = a.prompt_len or rp.default_prompt_len(tpl, a.task, from_file=bool(a.template or a.golden_template))
     r = rp.TemplateReplay(Hq, Hkv, D, L, mode=mode, device="cuda", attention=True, session=False if a.eager else None,
                           capture_after=a.capture_after if a.capture_after == "auto" else int(a.capture_after))
     rep = r.run(tpl, a.task, prompt_len, a.max_gen_len, max_rows=max(512, a.width, a.tree_size), pipelined=a.pipelined)
