@@ -51,7 +51,16 @@ def all_gather_outputs(o_local: torch.Tensor) -> List[torch.Tensor]:
     if len(set(shapes)) == 1:
         dist.all_gather(outs, o_local.contiguous())
         return outs
-    # ragged: one broadcast per rank (all_gather wants equal shapes); a rank with no rows takes part with an empty tensor
+    # ragged (forests of different sizes per rank): ONE all-gather of row-padded buffers -- a single ring collective over xGMI
+    # instead of a broadcast per rank; a rank with no rows takes part with padding only.  (Rows differ, the trailing shape
+    # -- heads x head_dim -- is the model's; tensors whose trailing shapes differ fall back to one broadcast per rank.)
+    if len({tuple(sh[1:]) for sh in shapes}) == 1 and all(len(sh) >= 1 for sh in shapes):
+        most = max(sh[0] for sh in shapes)
+        padded = torch.zeros((most,) + tuple(shapes[rank][1:]), dtype=o_local.dtype, device=o_local.device)
+        padded[: o_local.shape[0]].copy_(o_local)
+        bufs = [torch.empty_like(padded) for _ in range(world)]
+        dist.all_gather(bufs, padded)
+        return [bufs[r][: shapes[r][0]] for r in range(world)]
     outs[rank].copy_(o_local)
     for src in range(world):
         dist.broadcast(outs[src], src=src)
