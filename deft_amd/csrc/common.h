@@ -16,6 +16,12 @@ const char* get_error();
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// Queries a union group of leaf tiles may hold (plan_kernels.h; sizes the unit list of a plan buffer).  A multiple of four.
+// (Round 5 ran it at 8 to let groups of 5-8 leaf tiles form -- would a launch whose items all fit the resident slots at once do
+//  better?  No: the north-star tree 35.9 us per layer with groups of 3 tiles, 37.3 with 5, 38.1 with 6, 41.6 with 8
+//  (profiles/r5_union_groups_longer_negative.txt) -- a longer item is a longer serial chain at the end of the launch.)
+#define DEFT_UNION_CAP 4
+
 // Workspace carve shared by the Flatten and Node entry points:
 //   partial_o   [Hq][rows][D] f32   normalised stage-1 outputs
 //   partial_lse [Hq][rows]    f32   log-sum-exp of each partial row (natural log)
@@ -56,7 +62,8 @@ inline int64_t node_max_tiles(int NE, int64_t total_kv) { return (int64_t)NE + t
 //   header      4 KB  : int32 hdr[0] = records per KV head, hdr[1] = chunk leaders, hdr[2] = error flags,
 //                       hdr[3] = 1 when the per-query row lists below are valid (plan_records.h)
 //   records     (cap+1) x 2048 B (plan_records.h PLAN_*), cap = units-per-head capacity
-//   unit list   17 x cap int32 (src, aux, pass, flags, prow; tile-parallel order: perm, chunk tiles, first follower; union groups: n, 4 queries, 4 rows)
+//   unit list   (9 + 2 DEFT_UNION_CAP) x cap int32 (src, aux, pass, flags, prow; tile-parallel order: perm, chunk tiles, first follower;
+//               union groups: n, DEFT_UNION_CAP queries, DEFT_UNION_CAP rows)
 //   row_q       rows int32 : partial row -> query row (-1 = dead row)
 //   qoff, qlist rows + 1, rows int32 : per query, its live partial rows in ascending order (what the merge reads)
 struct PlanView {
@@ -81,7 +88,7 @@ inline PlanView plan_view(void* base, int64_t cap, int64_t rows) {
     v.records = p + off;
     off = align_up(off + 2048 * (size_t)(cap + 1), 256);
     v.units = reinterpret_cast<int32_t*>(p + off);
-    off = align_up(off + sizeof(int32_t) * 17 * (size_t)(cap > 0 ? cap : 1), 256);
+    off = align_up(off + sizeof(int32_t) * (9 + 2 * DEFT_UNION_CAP) * (size_t)(cap > 0 ? cap : 1), 256);
     v.row_q = reinterpret_cast<int32_t*>(p + off);
     off = align_up(off + sizeof(int32_t) * (size_t)(rows > 0 ? rows : 1), 256);
     v.qoff = reinterpret_cast<int32_t*>(p + off);

@@ -627,7 +627,7 @@ static UnitList unit_list(const PlanView& pv) {
     ul.ch_fb = pv.units + 7 * pv.cap;
     ul.gn = pv.units + 8 * pv.cap;
     ul.gq = pv.units + 9 * pv.cap;
-    ul.grow = pv.units + 13 * pv.cap;
+    ul.grow = pv.units + (9 + DEFT_UNION_CAP) * pv.cap;
     return ul;
 }
 
@@ -675,8 +675,8 @@ static int launch_plan(const Stage1Params& p, int NB, const PlanView& pv, const 
     // block tables (+ the small blocks' query lists for the union groups, when they fit) and a run table.  With an
     // entry for every possible run (7 words each) the kernel writes units and record order with all its waves;
     // otherwise one lane emits them and the table holds as many runs as fit (beyond that it scans).
-    const int qtab = sizeof(int) * 8 * (size_t)NB <= 100 * 1024;
-    const size_t blk = (qtab ? 8 : 4) * (size_t)NB;
+    const int qtab = sizeof(int) * (4 + DEFT_UNION_CAP) * (size_t)NB <= 100 * 1024;
+    const size_t blk = (qtab ? 4 + DEFT_UNION_CAP : 4) * (size_t)NB;
     int64_t run_cap = pv.cap;
     int par = !g_plan_serial;
     if (par && sizeof(int) * (blk + 7 * (size_t)run_cap + 8) > UNIT_LDS) {  // as many runs as fit (the kernel falls back if more turn up)

@@ -76,7 +76,7 @@ struct UnitList {   // all int32, capacity `cap` each
     int32_t* gq;    // [UNION_CAP][cap] query rows of the union, ascending
     int32_t* grow;  // [UNION_CAP][cap] the partial row that carries each union query (its first occurrence in the group)
 };
-constexpr int UNION_CAP = 4;
+constexpr int UNION_CAP = DEFT_UNION_CAP;
 
 // Record order for the tile-parallel stage 1 (one workgroup per chunk, stage1_np.h).  A run of `nt` units with
 // one query list is cut into S = ceil(nt / C) chunks; chunk p folds units p, p + S, p + 2S, ... of the run
@@ -330,7 +330,7 @@ __device__ inline void record_order_write(const UnitList& ul, const RunTable& rt
 // (lists read from block_q).  Everything lives in registers, every loop is unrolled over UNION_CAP.
 __device__ inline int union_group(int t, int NB, int ulen, int ucap, const int* sCnt, const int* sOff, const int* sQ,
                                   const int64_t* block_q, int (&uq)[UNION_CAP], int (&urow)[UNION_CAP], int& un) {
-    static_assert(UNION_CAP == 4, "the query table is read as int4");
+    static_assert(UNION_CAP % 4 == 0, "the query table is read as int4s");
     un = 0;
 #pragma unroll
     for (int j = 0; j < UNION_CAP; ++j) uq[j] = 0, urow[j] = 0;
@@ -341,8 +341,11 @@ __device__ inline int union_group(int t, int NB, int ulen, int ucap, const int* 
         const int off = sOff[te];
         int qv[UNION_CAP];
         if (sQ) {
-            const int4 v = *reinterpret_cast<const int4*>(sQ + te * UNION_CAP);
-            qv[0] = v.x, qv[1] = v.y, qv[2] = v.z, qv[3] = v.w;
+#pragma unroll
+            for (int i4 = 0; i4 < UNION_CAP / 4; ++i4) {
+                const int4 v = *reinterpret_cast<const int4*>(sQ + te * UNION_CAP + 4 * i4);
+                qv[4 * i4] = v.x, qv[4 * i4 + 1] = v.y, qv[4 * i4 + 2] = v.z, qv[4 * i4 + 3] = v.w;
+            }
         } else {
 #pragma unroll
             for (int i = 0; i < UNION_CAP; ++i) qv[i] = i < cnt ? (int)block_q[off + i] : 0;
@@ -466,7 +469,8 @@ __global__ __launch_bounds__(1024) void flatten_units_kernel(const int64_t* bloc
     __syncthreads();
     // Phase 1b (tile-parallel order): for every block, how many blocks a union group starting there would take
     // (0 = none), one thread per block, into bits 8.. of sOpen -- the walk below then only looks the answer up.
-    int ucap = (UNION_CAP * G <= MQ) ? UNION_CAP : MQ / G;  // union queries whose virtual rows fit one pass
+    // union queries whose virtual rows fit one pass; four unless the group-length rule below (or the experiments knob) asks for more
+    int ucap = (4 * G <= MQ) ? 4 : MQ / G;
     // GQA (late round 4, tools/knob_layer.sh DEFT_NP_UNION=2 | cap << 8, us per layer): pairs of tiles with at most THREE queries
     // between them -- a branch end straddling a block boundary, [a, b] + [b, c] -- fold as one group: the north-star tree on
     // Llama-3-8B 20.4 -> 19.5 (400 one-tile leaf workgroups become 200); pairs of four queries (ToT-50's [l1, l2] + [l3, l4]) cost
@@ -490,7 +494,7 @@ __global__ __launch_bounds__(1024) void flatten_units_kernel(const int64_t* bloc
                     break;
                 }
     }
-    if ((union_len >> 8) > 0) ucap = min(ucap, union_len >> 8);  // (experiments: bits 8.. of the knob cap the union's queries)
+    if ((union_len >> 8) > 0) ucap = min(min(UNION_CAP, MQ / G), union_len >> 8);  // (experiments: bits 8.. of the knob SET the union's query cap)
     auto union_len_at = [&](int t) {
         (void)t;
         int ulen = union_len & 0xff;
