@@ -591,6 +591,15 @@ class TreeCache:
         path.reverse()
         return path
 
+    def print_finished_branches(self, tokenizer) -> None:
+        """tree_cache.py:552-567: every finished branch decoded and printed (`tokenizer` = anything with the Hugging Face
+        `decode(token_ids, skip_special_tokens=True)`)."""
+        print(f"Total number of generated branches={len(self.all_finished_seqs)}! \n")
+        for branch in self.all_finished_seqs:
+            generated_text = tokenizer.decode(branch.token_ids, skip_special_tokens=True)
+            print(f" Branch ID: {branch.id}\n", f"Generated Text: {generated_text}\n", f"Tokens in this path:{branch.token_ids}\n",
+                  f"Token length : {len(branch.token_ids)}\n", f"Perplexity: {branch.PPL}\n")
+
     def get_tree_token_number(self) -> int:  # :569-584
         return sum(len(n.token_ids) for n in self.nodes.values()) + self.deleted_token_num
 

@@ -456,3 +456,29 @@ def test_header_and_library_serve_a_plain_c_program(tmp_path):
     running it needs a GPU (tests/test_gpu_parity.py::test_c_program_through_the_c_abi)."""
     exe = _build_c_program(str(tmp_path / "decode_from_c"))
     assert os.path.getsize(exe) > 0
+
+
+def test_finished_branches_are_recorded_and_printed(capsys):
+    """TreeCache.output_branch / print_finished_branches (tree_cache.py:525-567): the branch below the root, its cumulative
+    log-probability and perplexity."""
+    import math
+
+    tree = _small_tree(prefix=4, size=64)
+    a, b = tree.branch(tree.root, 2)
+    a.append_token(11, logprob=math.log(0.5))
+    a.append_token(12, logprob=math.log(0.25))
+    b.append_token(21)
+    tree.output_branch(dstnode=a)
+    tree.output_branch(dstnode=b)
+    s0, s1 = tree.all_finished_seqs
+    assert (s0.id, s0.token_ids, s1.id, s1.token_ids) == (0, [11, 12], 1, [21])
+    assert s0.cumulative_logprob == pytest.approx(math.log(0.125)) and s0.PPL == pytest.approx(math.exp(-math.log(0.125) / 2))
+    assert s1.PPL == 1.0 and s0.get_len() == 2
+
+    class Tok:
+        def decode(self, ids, skip_special_tokens=True):
+            return " ".join(str(i) for i in ids)
+
+    tree.print_finished_branches(Tok())
+    out = capsys.readouterr().out
+    assert "Total number of generated branches=2" in out and "Generated Text: 11 12" in out and "Token length : 1" in out

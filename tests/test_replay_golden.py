@@ -29,7 +29,8 @@ ARRAYS = ("node_q", "node_kv", "node_q_len", "node_kv_len", "node_q_offset", "no
           "block_q", "block_q_cnts", "block_q_offset", "block_bitmasks", "block_kv", "block_lens")
 WORKLOADS = {  # name -> (task, how the template is rebuilt WITHOUT the reference)
     "simple_w6": "few_shot", "simple_4kx32": "few_shot", "docmergeToT": "reasoning", "sorting128ToT": "reasoning",
-    "speculative64": "speculative_decoding",
+    "keywordToT": "reasoning", "set128ToT": "reasoning", "speculative64": "speculative_decoding",
+    "speculative256": "speculative_decoding",  # 256 candidates: eight query chunks below the root
 }
 
 
@@ -51,6 +52,8 @@ def _template(name, g):
         tpl = rp.TreeTemplate.from_node_table(TEMPLATES["reasoning"][name]["data"])
         assert int(tpl.value[0]) == prompt_len
         return tpl
+    if name != "speculative64":  # (the fitted list as recorded; the fit itself is checked on tree_size64 below)
+        return rp.TreeTemplate.flat(int(g["tree_size"][0]), g["accept_lengths"].tolist())
     sd = TEMPLATES["speculative"]["tree_size64"]
     tpl = rp.TreeTemplate.flat(sd["Token_Tree_size"], sd["Accept_length_0"])
     rp.fit_accept_lengths(tpl, max_gen_len, random.Random(0))  # data_loader.py:200-235 under random.seed(0)
@@ -117,7 +120,7 @@ def _run_cpu(name, mutate=None):
             np.asarray(tree.token_to_kv_pool.mem_state))
 
     r.trace_hook = hook
-    r.run(tpl, WORKLOADS[name], prompt_len, max_gen_len, max_tokens=pool_size, max_leaves=248,
+    r.run(tpl, WORKLOADS[name], prompt_len, max_gen_len, max_tokens=pool_size, max_leaves=300,
           scores_fn=lambda it, rows: permutation_scores(it, rows, vocab))
     chk.finish(r.tree, r.pool)
     return chk
@@ -209,7 +212,7 @@ def test_session_reproduces_the_reference_loop_step_for_step(name, mode):
         chk(it, tree, sess.cache_loc[: sess.nq].cpu().numpy(), arrays, np.asarray(tree.token_to_kv_pool.mem_state))
 
     r.trace_hook = hook
-    r.run(tpl, WORKLOADS[name], prompt_len, max_gen_len, max_tokens=pool_size, max_leaves=248,
+    r.run(tpl, WORKLOADS[name], prompt_len, max_gen_len, max_tokens=pool_size, max_leaves=300,
           scores_fn=lambda it, rows: permutation_scores(it, rows, vocab))
     chk.finish(r.tree, r.pool)
     assert r.graph_captures >= 1  # the steps really ran from captured graphs

@@ -58,8 +58,6 @@ OUT_OF_SCOPE = {
     "deft.tree_decoding.tree_cache.TreeMetadata.from_tree_cache_node": "tree_index",
     # the model runner's batch bookkeeping for prefill / extend: model side, not the attention path
     "deft.model_runner.InputMetadata.create": "model runner",
-    # needs a tokenizer (printing generated text): model side
-    "deft.tree_decoding.tree_cache.TreeCache.print_finished_branches": "tokenizer",
     # the CUDA custom-op spelling of forward_native (vllm _C ops); forward() is the entry point
     "deft.layers.rotary_embedding.RotaryEmbedding.forward_cuda": "cuda custom op",
     # internals of the template loader: deft_amd.templates keeps a template as arrays, not as linked node objects

@@ -90,7 +90,12 @@ WORKLOADS = {
     "simple_4kx32": ("example_branch_Func1_SimpleTree", ("width", 32), 4096, 24, 8192, 2, 8),
     "docmergeToT": ("example_branch_Func3_FromTreeTemplate", ("reasoning", "docmergeToT"), None, 100000, 32768, 3, 800),
     "sorting128ToT": ("example_branch_Func3_FromTreeTemplate", ("reasoning", "sorting128ToT"), None, 100000, 65536, 3, 1200),
+    # the other two shipped reasoning templates (61 and 91 lifetime nodes, a branch every ~94 / ~36 steps)
+    "keywordToT": ("example_branch_Func3_FromTreeTemplate", ("reasoning", "keywordToT"), None, 100000, 16384, 3, 150),
+    "set128ToT": ("example_branch_Func3_FromTreeTemplate", ("reasoning", "set128ToT"), None, 100000, 16384, 3, 100),
     "speculative64": ("example_branch_Func4_SpeculativeDecoding", ("speculative", "tree_size64"), 1016, 120, 8192, 6, 10),
+    # 256 candidates: more than max_q_len queries below one node -- the root's blocks alternate between eight query chunks
+    "speculative256": ("example_branch_Func4_SpeculativeDecoding", ("speculative", "tree_size256"), 1016, 60, 8192, 3, 8),
 }
 
 
@@ -125,6 +130,7 @@ def main() -> None:
                 template = ref_dl.load_prompts(os.path.join(BASE, "Speculative_Decoding", src[1] + ".json"))[0]
                 ref_dl.generate_accepted_len_list(max_gen_len=max_gen_len, tree=template)  # run_DeFT_llama_paged.py:258-263
                 extra["accept_lengths"] = np.asarray(template.accepted_len_list, dtype=np.int64)
+                extra["tree_size"] = np.asarray([template.node_num], dtype=np.int64)
             req_pool = ReqToTokenPool(size=256, max_context_len=pool_size)
             kv_pool = TokenToKVPool(size=pool_size, dtype=torch.float16, head_num=1, head_dim=8, layer_num=0)
             tree = ref_tc.TreeCache(torch.float16, 1, 8, 1, req_to_token_pool=req_pool, token_to_kv_pool=kv_pool,
