@@ -59,6 +59,13 @@ python $R/tools/prof_summary.py /tmp/prof_rp_$TAG 2>&1 | head -18 | cut -c1-160 
 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_sd_$TAG -- python $R/tools/replay.py --task speculative_decoding --modes flatten --tree-size 64 --pipelined --no-warmup > /dev/null 2>&1
 python $R/tools/prof_summary.py /tmp/prof_sd_$TAG 2>&1 | head -18 | cut -c1-160 > $O/${TAG}_replay_speculative_kernel_stats.txt
 cd $R
+# rounds 3, 4 and 5 -- each round's own tree (prev/, see .gitignore) on its own library -- in turn on THIS box: the table of DESIGN 4b
+if [ -d prev/r3 ] && [ -d prev/r4 ]; then
+  timeout 1500 tools/ab_rounds.sh "northstar_4kx32 fewshot_1kx32 medusa64_node tot50_4k forest_8kx8 forest_8kx8_single gqa_4kx32 northstar_4kx32_d64 northstar_4kx32_node" prev/r3 prev/r4 . > $O/${TAG}_ab_rounds.txt 2>&1
+  timeout 600 tools/ab_e2e.sh prev/r4 . > $O/${TAG}_ab_e2e.txt 2>&1
+fi
+# the whole GPU suite on this box
+timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -4 > $O/${TAG}_gputest.txt
 # fuzzers: the captured loop against the eager path bit for bit (with speculative-decoding merge / reset steps); every step of random
 # replays against fp64 attention
 (timeout 400 python tools/fuzz_session.py 240 ${FUZZ_SEED:-31} 2>&1 | tail -2; timeout 300 python tools/fuzz_replay.py 180 ${FUZZ_SEED:-31} 2>&1 | tail -2) > $O/${TAG}_fuzz.txt
