@@ -362,13 +362,17 @@ __global__ __launch_bounds__(256) void merge_kernel(const float* partial_o, cons
     // pair i % HP) runs on XCD i % 8 for grids that are multiples of 8) -- the rows are still in that XCD's L2 (measured round 3:
     // Medusa-64 14.7 -> 13.4 us per layer; the same grid with heads rotated by 3 gains nothing).  hgroup = query heads per item.
     const int ng = Hq / hgroup, bx = blockIdx.x;
-    const int hq = (bx % ng) * hgroup + bx / ng, q = blockIdx.y * 4 + w;
+    // (round 5 measured NH = 2 / 4 heads of one XCD per wave -- a quarter of the workgroups to dispatch, the same round trips per
+    //  wave: +1.5 / +4.6 us per layer on every workload, profiles/r5_merge_heads_per_wave_negative.txt: the merge is bound by what ONE
+    //  wave executes, not by dispatch)
+    const int hq = (bx % ng) * hgroup + bx / ng;
+    const int q = blockIdx.y * 4 + w;
     if (q >= nq_total) return;
     _Float16* out_q = out + (int64_t)q * o_st;
     int* list = reinterpret_cast<int*>(smem) + w * cap;
 #ifdef DEFT_EXPERIMENTS
-    if (lists >= 2) {  // TIMING ONLY (wrong results): row ids computed, not loaded -- what a merge without its first dependent round trip costs
-        const int n = lists - 1;
+    if (lists >= 4) {  // TIMING ONLY (wrong results): row ids computed, not loaded -- what a merge without its first dependent round trip costs
+        const int n = lists - 3;
         if (lane < n) list[lane] = (int)(((int64_t)q * n + lane) % rows);
         __builtin_amdgcn_wave_barrier();
         merge_heads_wave<D, 0, 1>(partial_o, partial_lse, row_q, rows, q, hq, 1, Hq, list, cap, n, out_q, o_sh, lane);
@@ -378,6 +382,12 @@ __global__ __launch_bounds__(256) void merge_kernel(const float* partial_o, cons
     if (lists) {  // the plan lists every query's rows: ONE round trip for {count, rows}, one for the rows themselves
         const int mine = lane < 16 ? qinl[q * 16 + lane] : 0;
         const int n = __builtin_amdgcn_readfirstlane(mine);
+        if constexpr (D == 128) {
+            if (n >= 1 && n <= 8 && lists != 3) {  // (lists == 3: the experiments build's switch back to the general path, for the bit-equality test)
+                merge_small_wave128(partial_o, partial_lse, rows, hq, mine, n, out_q + (int64_t)hq * o_sh, lane);
+                return;
+            }
+        }
         if (n <= 15 && n <= cap) {
             if (lane >= 1 && lane <= n) list[lane - 1] = mine;
             __builtin_amdgcn_wave_barrier();
@@ -816,7 +826,8 @@ static int launch_merge(int D, const Workspace& ws, const PlanView* pv, const in
     // the plan's per-query row lists exist iff its row count fits the histogram kernel (launch_qrows): known on the host
     int lists = pv && pv->rows > 0 && pv->rows <= QROWS_MAX ? 1 : 0;
 #ifdef DEFT_EXPERIMENTS
-    if (const int fake = knob("DEFT_MERGE_FAKE", 0)) lists = 1 + fake;  // (timing experiment: `fake` computed row ids per query)
+    if (const int fake = knob("DEFT_MERGE_FAKE", 0)) lists = 3 + fake;  // (timing experiment: `fake` computed row ids per query)
+    if (lists == 1 && knob("DEFT_MERGE_SMALL", 1) == 0) lists = 3;       // (the general path for short lists too)
 #endif
     const int32_t* qoff = pv ? pv->qoff : nullptr;
     const int32_t* qlist = pv ? pv->qlist : nullptr;
