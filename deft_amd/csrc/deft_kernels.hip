@@ -382,12 +382,6 @@ __global__ __launch_bounds__(256) void merge_kernel(const float* partial_o, cons
     if (lists) {  // the plan lists every query's rows: ONE round trip for {count, rows}, one for the rows themselves
         const int mine = lane < 16 ? qinl[q * 16 + lane] : 0;
         const int n = __builtin_amdgcn_readfirstlane(mine);
-        if constexpr (D == 128) {
-            if (n >= 1 && n <= 8 && lists != 3) {  // (lists == 3: the experiments build's switch back to the general path, for the bit-equality test)
-                merge_small_wave128(partial_o, partial_lse, rows, hq, mine, n, out_q + (int64_t)hq * o_sh, lane);
-                return;
-            }
-        }
         if (n <= 15 && n <= cap) {
             if (lane >= 1 && lane <= n) list[lane - 1] = mine;
             __builtin_amdgcn_wave_barrier();
@@ -827,7 +821,6 @@ static int launch_merge(int D, const Workspace& ws, const PlanView* pv, const in
     int lists = pv && pv->rows > 0 && pv->rows <= QROWS_MAX ? 1 : 0;
 #ifdef DEFT_EXPERIMENTS
     if (const int fake = knob("DEFT_MERGE_FAKE", 0)) lists = 3 + fake;  // (timing experiment: `fake` computed row ids per query)
-    if (lists == 1 && knob("DEFT_MERGE_SMALL", 1) == 0) lists = 3;       // (the general path for short lists too)
 #endif
     const int32_t* qoff = pv ? pv->qoff : nullptr;
     const int32_t* qlist = pv ? pv->qlist : nullptr;

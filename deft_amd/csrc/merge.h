@@ -133,73 +133,10 @@ __device__ inline void merge_finish(const MergeState& st, _Float16* dst, int lan
     }
 }
 
-// The usual case in one piece: ONE head, head_dim 128, a list of 1 ..  8 rows whose ids are wave-uniform (lane 1 + j of `mine`, the
-// query's {count, rows} line).  Same arithmetic, same order, same bits as merge_accumulate + merge_finish on such a list -- that
-// is checked against the general path (tests/test_gpu_parity.py::test_small_list_merge_equals_the_general_path) -- without what the
-// general form spends most of its instructions on for seven rows: the row ids never go through the LDS, every lane reads all (at
-// most eight) log-sum-exps itself -- uniform addresses, one transaction each, requested TOGETHER with the rows -- so the maximum
-// and the sum are a few VALU operations per lane instead of two butterflies of six dependent ds_bpermute steps, the weights
-// need no shuffle, and the two row halves of the wave meet through one v_permlane32_swap per value.  Round 5: merge_kernel
-// see profiles/r5_merge_small_lists.txt.
-__device__ inline void merge_small_wave128(const float* partial_o, const float* partial_lse, int64_t rows, int hq, int mine, int n,
-                                           _Float16* dst, int lane) {
-    constexpr int D = 128;
-    const __amdgpu_buffer_rsrc_t po = make_rsrc(partial_o + (int64_t)hq * rows * D);
-    const __amdgpu_buffer_rsrc_t ls = make_rsrc(partial_lse + (int64_t)hq * rows);
-    // Every load is UNCONDITIONAL and all twelve go out back to back: entries beyond the list alias its first row (a cache hit; their
-    // weights are zero below).  A load inside `if (j < n)` is a branch per load, and the compiler drains the memory counter at every
-    // join -- eight dependent round trips: that form measured 0.8 us SLOWER than the general path.
-    int r[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int rj = __builtin_amdgcn_readlane(mine, 1 + j);  // (lanes 1 .. 15 of the line)
-        r[j] = j < n ? rj : __builtin_amdgcn_readlane(mine, 1);
-    }
-    const int sub = lane >> 5, col = lane & 31;
-    uintx4 v[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {  // rows 2u + sub: the general path's batch 0 (NU = 4, two rows per wave-wide load)
-        const int rj = sub ? r[2 * u + 1] : r[2 * u];
-        v[u] = __builtin_amdgcn_raw_buffer_load_b128(po, rj * (D * 4) + col * 16, 0, 0);
-    }
-    float x[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j)  // (uniform addresses: every lane the same word)
-        x[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ls, r[j] * 4, 0, 0));
-#pragma unroll
-    for (int j = 0; j < 8; ++j) x[j] = j < n ? x[j] : -INFINITY;
-    float M = x[0];
-#pragma unroll
-    for (int j = 1; j < 8; ++j) M = fmaxf(M, x[j]);
-    floatx4 acc = {0.f, 0.f, 0.f, 0.f};
-    float L = 0.f;
-    if (M != -INFINITY) {  // (uniform) otherwise nothing live: the output row is zero, as in the general path
-        float wgt[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) wgt[j] = (x[j] == -INFINITY) ? 0.f : __expf(x[j] - M);
-        // the butterfly's order over lanes 0 .. 7 (xor 4, then 2, then 1); the other lanes held zeros
-        L = ((wgt[0] + wgt[4]) + (wgt[2] + wgt[6])) + ((wgt[1] + wgt[5]) + (wgt[3] + wgt[7]));
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int j = 2 * u + sub;
-            const float wj = sub ? wgt[2 * u + 1] : wgt[2 * u];
-            if (j < n && wj > 0.f) acc += __builtin_bit_cast(floatx4, v[u]) * wj;
-        }
-    }
-    floatx4 a = acc;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {  // own + the other half's (lane ^ 32): v_permlane32_swap instead of a ds_bpermute round trip
-        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(a[e]), __float_as_uint(a[e]), false, false);
-        a[e] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);  // (one of the two is the lane's own value; a + b == b + a bit for bit)
-    }
-    if (lane < 32) {
-        const float inv = L > 0.f ? 1.f / L : 0.f;
-        half2v lo = {(_Float16)(a[0] * inv), (_Float16)(a[1] * inv)};
-        half2v hi = {(_Float16)(a[2] * inv), (_Float16)(a[3] * inv)};
-        *reinterpret_cast<half2v*>(dst + 4 * lane) = lo;
-        *reinterpret_cast<half2v*>(dst + 4 * lane + 2) = hi;
-    }
-}
+// (Round 5 built a specialised form of the above for the usual case -- one head, head_dim 128, up to eight rows: wave-uniform row
+//  ids, every lane reading all log-sum-exps itself so that maximum / weights / sum need no shuffles, one v_permlane32_swap per value
+//  -- bit-identical by construction and 0.4-0.8 us SLOWER per launch: profiles/r5_merge_small_lists_negative.txt.  And NH = 2 / 4
+//  heads of one XCD per wave, a quarter of the workgroups: +1.5 / +4.6 us, r5_merge_heads_per_wave_negative.txt.)
 
 // One query, NH heads (hq0, hq0 + hq_step, ...; those >= Hq are skipped), start to finish: rows of the query from
 // row_q (list area of `cap` ints in LDS, longer lists in further passes), merge, store.  `have` >= 0:

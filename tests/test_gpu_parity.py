@@ -657,22 +657,6 @@ def test_plan_build_forms_give_identical_plans(shape):
         assert 0 < fl < leaders and nd > 0, r.stdout[-500:]
 
 
-def test_small_list_merge_equals_the_general_path():
-    """merge_small_wave128 (deft_amd/csrc/merge.h: lists of up to eight rows, head_dim 128 -- the usual case) against the general
-    merge on the same trees, bit for bit.  The switch back to the general path exists in the EXPERIMENTS build only
-    (DEFT_MERGE_SMALL=0), so the check runs in a child process bound to it (tests/exp_merge_paths.py)."""
-    import subprocess
-    import sys
-
-    exp = os.path.join(ROOT, "deft_amd", "lib", "libdeft_amd_exp.so")
-    assert os.path.exists(exp), "build the experiments library: make -C deft_amd/csrc exp (__graft_entry__.build() does)"
-    env = dict(os.environ, DEFT_AMD_LIB=exp, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "exp_merge_paths.py")], env=env, capture_output=True, text=True,
-                       timeout=600)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    assert "merge paths identical: 12 outputs bit-equal" in r.stdout
-
-
 def test_decode_step_inside_inference_mode():
     """The reference decorates its operators with @torch.inference_mode() and runners wrap the whole loop in it: tensors
     made there keep no version counter (`t._version` raises).  alloc() + from_tree_cache + every layer's forward, Flatten and
