@@ -1,5 +1,7 @@
 #!/bin/bash
 # Same-box comparison of ROUNDS: each tree (a checkout of an earlier round under prev/, built in place -- see .gitignore -- or `.`)
+#   (to make one:  mkdir -p prev/r4 && git archive <the round's last commit> | tar -x -C prev/r4 && make -C prev/r4/deft_amd/csrc ../lib/libdeft_amd.so
+#    -- round 3 ended at aecaf97~1, round 4 at 9cddd5b~1; prev/ is git-ignored and travels to the GPU box with gpurun)
 # runs ITS OWN bench.py on ITS OWN library, in turn, twice:
 #   tools/ab_rounds.sh "<workload> ..." <tree> [<tree> ...]        e.g.  tools/ab_rounds.sh "northstar_4kx32 medusa64_node" prev/r3 prev/r4 .
 # prints us per layer of the captured 32-layer step and the stage-1 average (HIP events) per tree, workload and repetition.
