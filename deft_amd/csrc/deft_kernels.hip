@@ -371,8 +371,8 @@ __global__ __launch_bounds__(256) void merge_kernel(const float* partial_o, cons
     _Float16* out_q = out + (int64_t)q * o_st;
     int* list = reinterpret_cast<int*>(smem) + w * cap;
 #ifdef DEFT_EXPERIMENTS
-    if (lists >= 4) {  // TIMING ONLY (wrong results): row ids computed, not loaded -- what a merge without its first dependent round trip costs
-        const int n = lists - 3;
+    if (lists >= 2) {  // TIMING ONLY (wrong results): row ids computed, not loaded -- what a merge without its first dependent round trip costs
+        const int n = lists - 1;
         if (lane < n) list[lane] = (int)(((int64_t)q * n + lane) % rows);
         __builtin_amdgcn_wave_barrier();
         merge_heads_wave<D, 0, 1>(partial_o, partial_lse, row_q, rows, q, hq, 1, Hq, list, cap, n, out_q, o_sh, lane);
@@ -820,7 +820,7 @@ static int launch_merge(int D, const Workspace& ws, const PlanView* pv, const in
     // the plan's per-query row lists exist iff its row count fits the histogram kernel (launch_qrows): known on the host
     int lists = pv && pv->rows > 0 && pv->rows <= QROWS_MAX ? 1 : 0;
 #ifdef DEFT_EXPERIMENTS
-    if (const int fake = knob("DEFT_MERGE_FAKE", 0)) lists = 3 + fake;  // (timing experiment: `fake` computed row ids per query)
+    if (const int fake = knob("DEFT_MERGE_FAKE", 0)) lists = 1 + fake;  // (timing experiment: `fake` computed row ids per query)
 #endif
     const int32_t* qoff = pv ? pv->qoff : nullptr;
     const int32_t* qlist = pv ? pv->qlist : nullptr;
