@@ -205,7 +205,11 @@ class TemplateReplay:
         self.capture_after = capture_after
         self.Hq, self.Hkv, self.D, self.layers = num_heads, num_kv_heads, head_dim, layers
         self.mode = mode
-        self.forward_mode: ForwardMode = forward_mode_from_cli(mode)
+        self.forward_mode: ForwardMode = forward_mode_from_cli(mode)  # (node / node_chunk set BLOCK_CONFIG["MAX_BLOCK_LEN"], as the CLI does)
+        if mode not in ("node", "node_chunk", "deft_node", "deft_node_chunk"):
+            from .tree_cache import BLOCK_CONFIG
+
+            BLOCK_CONFIG["MAX_BLOCK_LEN"] = -1  # (a process that replays several modes: no chunking left over from a node_chunk replay)
         self.device = device
         self.attention = attention
         self.vocab = vocab
@@ -214,7 +218,7 @@ class TemplateReplay:
         # rolling window -- drawing nq x vocab fresh numbers per decode step cost more host time than the step itself
         self._score_table = self.rng.random((1024 + 257, vocab), dtype=np.float32)
         self._score_at = 0
-        can = attention and mode in ("flatten", "node") and (head_dim == 128 or (head_dim == 64 and num_kv_heads % 2 == 0))
+        can = attention and mode in ("flatten", "node", "node_chunk") and (head_dim == 128 or (head_dim == 64 and num_kv_heads % 2 == 0))
         self.session = can if session is None else (bool(session) and can)
         # test hook: called after every step's attention with (tree, layer-0 q rows [nq, Hq*D], layer-0 output [nq, Hq*D])
         self.step_hook: Optional[Callable[[TreeCache, torch.Tensor, torch.Tensor], None]] = None
@@ -281,7 +285,8 @@ class TemplateReplay:
             from .tree_cache import _ptr
 
             sess = DecodeSession(tree, self.Hq, self.Hkv, self.D, self.layers,
-                                 lambda l: (q_all[l, : nq_now[0]], k_all[l, : nq_now[0]], v_all[l, : nq_now[0]]), mode=self.mode,
+                                 lambda l: (q_all[l, : nq_now[0]], k_all[l, : nq_now[0]], v_all[l, : nq_now[0]]),
+                                 mode="node" if self.mode == "node_chunk" else self.mode,
                                  capture_after=self.capture_after)
             sizes = np.zeros(9, dtype=np.int64)
         t_wall = time.perf_counter()

@@ -104,7 +104,7 @@ def test_few_shot_replay_counts():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("session", [True, False])
-@pytest.mark.parametrize("task,mode", [("reasoning", "flatten"), ("reasoning", "node"), ("reasoning", "seq"),
+@pytest.mark.parametrize("task,mode", [("reasoning", "flatten"), ("reasoning", "node"), ("reasoning", "node_chunk"), ("reasoning", "seq"),
                                        ("speculative_decoding", "node"), ("speculative_decoding", "flatten"), ("few_shot", "flatten")])
 def test_replay_attention_matches_truth_every_step(task, mode, session):
     """Run a small template with attention on the GPU and check, at every step, the output of layer 0 against fp64

@@ -291,3 +291,51 @@ def test_second_device_copy_between_steps_cannot_starve_the_session_of_journalle
     step_and_compare("after the second copy")
     speculative_update(3)
     step_and_compare("and the step after")
+
+
+def test_session_node_chunk_equals_eager_step_for_step():
+    """`--mode node_chunk` (BLOCK_CONFIG["MAX_BLOCK_LEN"] = 128: every node cut into 128-token entries, which the Node plan folds
+    again -- round 5) through the captured session against the eager calls, bit for bit, across block boundaries and a branch."""
+    Hq, Hkv, D, layers, prefix, width = 8, 2, 128, 2, 700, 5
+    fmode = deft_amd.forward_mode_from_cli("node_chunk")
+    try:
+        assert deft_amd.BLOCK_CONFIG["MAX_BLOCK_LEN"] == 128
+        g = torch.Generator(device="cuda").manual_seed(41)
+        kv_init = torch.randn((layers, 4096, 2, Hkv, D), dtype=torch.float16, device="cuda", generator=g)
+        (te, pe), (ts, ps) = [_mk(Hkv, D, layers, prefix, width, 4096) for _ in range(2)]
+        for p in (pe, ps):
+            p._storage.copy_(kv_init)
+        cap = 16
+        q = torch.randn((layers, cap, Hq * D), dtype=torch.float16, device="cuda", generator=g)
+        k = torch.randn((layers, cap, Hkv * D), dtype=torch.float16, device="cuda", generator=g)
+        v = torch.randn((layers, cap, Hkv * D), dtype=torch.float16, device="cuda", generator=g)
+        nq_now = [width]
+        sess = deft_amd.DecodeSession(ts, Hq, Hkv, D, layers, lambda l: (q[l, : nq_now[0]], k[l, : nq_now[0]], v[l, : nq_now[0]]), mode="node")
+        attn = [deft_amd.DeFTAttention(Hq, D, D ** -0.5, Hkv, l) for l in range(layers)]
+
+        def both_steps(steps):
+            for _ in range(steps):
+                for tree in (te, ts):
+                    for leaf in tree.leaves.values():
+                        leaf.append_token(7)
+                upd = te.alloc()
+                md = deft_amd.TreeMetadata.from_tree_cache(te)
+                assert int(md.node_kv_len.max()) <= 128  # the entries really are chunks
+                deft_amd.register_tree_metadata(md)
+                n = md.query_num
+                nq_now[0] = n
+                ref = [attn[l](q[l, :n], k[l, :n], v[l, :n], deft_amd.InputMetadata(fmode, upd, pe)) for l in range(layers)]
+                out = sess.step()
+                torch.cuda.synchronize()
+                for l in range(layers):
+                    assert torch.equal(out[l][:n], ref[l]), l
+                assert torch.equal(pe._storage, ps._storage)
+
+        both_steps(140)  # the leaves cross their first 128-token boundary inside the epoch
+        for tree in (te, ts):
+            lv = sorted(tree.leaves.values(), key=lambda n: n.id)
+            tree.branch(lv[0], 3)
+        both_steps(10)
+        assert sess.captures == 2
+    finally:
+        deft_amd.BLOCK_CONFIG["MAX_BLOCK_LEN"] = -1

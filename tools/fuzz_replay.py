@@ -17,7 +17,7 @@ tight = [0, 0]  # elements beyond 5e-4 + half ulp, elements checked
 while time.time() < t_end and runs < max_runs:
     Hq, Hkv = rng.choice([(32, 32), (32, 8), (8, 2), (4, 4), (16, 1)])
     D = 64 if Hq <= 8 and rng.random() < 0.3 else 128
-    mode = rng.choice(["flatten", "flatten", "node", "seq"])
+    mode = rng.choice(["flatten", "flatten", "node", "node_chunk", "seq"])
     task = rng.choice(["reasoning", "reasoning", "few_shot", "speculative_decoding"])
     if task == "reasoning":
         depth = rng.randint(1, 3)

@@ -15,7 +15,11 @@ runs = steps = captures = sd_runs = 0
 while time.time() < t_end:
     Hq, Hkv = rng.choice([(32, 32), (32, 8), (8, 2), (4, 4), (16, 1)])
     D, layers = 128, rng.choice([1, 2])
-    mode = rng.choice(["flatten", "flatten", "node"])
+    mode = rng.choice(["flatten", "flatten", "node", "node_chunk"])
+    # (--mode node_chunk = DeFT-Node with MAX_BLOCK_LEN = 128, examples/run_DeFT_llama_paged.py:145-150: the metadata cuts every node
+    #  into 128-token entries, the Node plan folds them again -- round 5)
+    deft_amd.BLOCK_CONFIG["MAX_BLOCK_LEN"] = 128 if mode == "node_chunk" else -1
+    smode = "node" if mode == "node_chunk" else mode
     size = 1 << 17 if Hkv <= 8 else 1 << 16
     g = torch.Generator(device="cuda").manual_seed(rng.randint(0, 10 ** 6))
     kv_init = torch.randn((layers, size, 2, Hkv, D), dtype=torch.float16, device="cuda", generator=g)
@@ -40,9 +44,9 @@ while time.time() < t_end:
     k = torch.randn((layers, cap, Hkv * D), dtype=torch.float16, device="cuda", generator=g)
     v = torch.randn((layers, cap, Hkv * D), dtype=torch.float16, device="cuda", generator=g)
     nq_now = [1]
-    sess = deft_amd.DecodeSession(ts, Hq, Hkv, D, layers, lambda l: (q[l, : nq_now[0]], k[l, : nq_now[0]], v[l, : nq_now[0]]), mode=mode)
+    sess = deft_amd.DecodeSession(ts, Hq, Hkv, D, layers, lambda l: (q[l, : nq_now[0]], k[l, : nq_now[0]], v[l, : nq_now[0]]), mode=smode)
     attn = [deft_amd.DeFTAttention(Hq, D, D ** -0.5, Hkv, l) for l in range(layers)]
-    fmode = deft_amd.forward_mode_from_cli(mode)
+    fmode = deft_amd.forward_mode_from_cli(mode)  # (sets BLOCK_CONFIG["MAX_BLOCK_LEN"] for the node modes the same way)
 
     def both(nsteps):
         global steps
@@ -133,5 +137,6 @@ while time.time() < t_end:
         sd_runs += 1
     captures += sess.captures
     deft_amd.unregister_tree_metadata()
+    deft_amd.BLOCK_CONFIG["MAX_BLOCK_LEN"] = -1
     runs += 1
 print(f"session fuzz ok: {runs} trees ({sd_runs} with speculative-decoding merge / reset steps), {steps} steps bit-identical to the eager path, {captures} graph captures")
