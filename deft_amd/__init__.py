@@ -5,6 +5,7 @@ own operator surface.  Importing the package loads libdeft_amd.so and fails loud
 if it has not been built; nothing here falls back to PyTorch or the CPU.
 """
 from ._lib import LIB_PATH, DeftLibraryError, lib  # noqa: F401
+from . import branch_func_example, data_loader  # noqa: F401  (the reference's loader / branch-function names)
 from .context_attention import context_attention_fwd  # noqa: F401
 from .deft_attention import DeFTAttention  # noqa: F401
 from .forest import Forest, concat_metadata_host  # noqa: F401

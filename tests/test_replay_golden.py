@@ -132,6 +132,48 @@ def test_replay_reproduces_the_reference_loop_step_for_step(name):
     assert chk.k >= 20
 
 
+@pytest.mark.parametrize("name", ["simple_w6", "keywordToT", "speculative64"])
+def test_reference_shaped_front_ends_drive_the_same_loop(name):
+    """The same runs through `deft_amd.branch_func_example` (the reference's function names and signatures) and
+    `Branch_Controller`, in a loop written the way `tree_generate.py:92-236` is -- `model` is a bare object with a `.tree` --
+    instead of `TemplateReplay.run`: what a script ported from the reference would execute."""
+    import types
+
+    from deft_amd import branch_func_example as bf
+
+    g = np.load(os.path.join(GOLD_DIR, f"replay_{name}.npz"))
+    prompt_len, max_gen_len, pool_size, width, vocab = (int(x) for x in g["config"])
+    tpl = _template(name, g)
+    fn = {"few_shot": bf.example_branch_Func1_SimpleTree, "reasoning": bf.example_branch_Func3_FromTreeTemplate,
+          "speculative_decoding": bf.example_branch_Func4_SpeculativeDecoding}[WORKLOADS[name]]
+    req = deft_amd.ReqToTokenPool(308, pool_size + 8, device="cpu")
+    pool = deft_amd.TokenToKVPool(pool_size, torch.float16, 1, 8, 0, device="cpu")
+    tree = deft_amd.TreeCache(torch.float16, 1, 8, 1, req, pool, None, True, False)
+    model = types.SimpleNamespace(tree=tree)
+    ctl = bf.Branch_Controller(branching_function=fn)
+    ctl.set_execution_graph(tree_templates=None if WORKLOADS[name] == "few_shot" else tpl)
+
+    def branch(it, rows):
+        return ctl.apply_branching(model=model, iter=it, max_gen_len=max_gen_len, width=width, depth=0,
+                                   logits=permutation_scores(it, rows, vocab), execution_graph=ctl.tree_templates)
+
+    chk = _Checker(g)
+    tree.init_prompt(torch.arange(1, prompt_len + 1, dtype=torch.int32))
+    stop = branch(0, 1)
+    it = 1
+    while not stop and it < max_gen_len:
+        leaves = sorted(tree.leaves.values(), key=lambda x: x.id)
+        if not leaves:
+            break
+        tree.leaf_to_q = {lf.id: i for i, lf in enumerate(leaves)}
+        upd = tree.alloc()
+        md = deft_amd.TreeMetadata.from_tree_cache(tree, device="cpu")
+        chk(it, tree, upd.cache_loc.cpu().numpy(), {a: getattr(md, a).cpu().numpy() for a in ARRAYS}, np.asarray(pool.mem_state))
+        stop = branch(it, len(leaves))
+        it += 1
+    chk.finish(tree, pool)
+
+
 def test_a_wrong_walk_order_is_caught():
     """The pin has teeth: with two siblings swapped in the template's child lists (the order in which a branch hands out
     node ids and the top-k tokens), or with the leaves walked in id order where the reference walks its dict, the replay no

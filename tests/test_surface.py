@@ -13,6 +13,7 @@ import os
 import pytest
 
 import deft_amd
+import deft_amd.branch_func_example
 import deft_amd.context_attention
 import deft_amd.data_loader
 import deft_amd.deft_attention
@@ -35,6 +36,8 @@ COUNTERPART = {
     "deft.memory_pool": deft_amd.memory_pool,
     "deft.model_runner": deft_amd.forward_mode,
     "deft.data_loader": deft_amd.data_loader,
+    "deft.tree_decoding.generation.branch_func_example": deft_amd.branch_func_example,
+    "deft.tree_decoding.branch_controller": deft_amd.branch_func_example,
 }
 
 # optional parameters deft_amd's counterparts take beyond the reference's (each must have a default)

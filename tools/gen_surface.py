@@ -14,6 +14,7 @@ configuration keys of the reference modules the path's callers import:
   DeFT/deft/memory_pool.py                          ReqToTokenPool, TokenToKVPool (:11-108)
   DeFT/deft/model_runner.py                         ForwardMode members, InputMetadata fields (:31-42, :73-94)
   DeFT/deft/data_loader.py                          ExecuteTree, load_trees, load_prompts, generate_accepted_len_list
+  DeFT/deft/tree_decoding/generation/branch_func_example.py, branch_controller.py   the three branch functions, Branch_Controller
 
 Every module is read with `ast` (several cannot be imported without a GPU or flashinfer); where a module DOES import here
 its callables are also read with `inspect.signature` and the two readings must agree.  The output holds names, parameter
@@ -47,6 +48,10 @@ MODULES = {
                                                  "unregister_tree_cache", "get_global_tree_cache", "BLOCK_CONFIG"]),
     "deft.memory_pool": ("classes", ["ReqToTokenPool", "TokenToKVPool"]),
     "deft.model_runner": ("classes", ["ForwardMode", "InputMetadata"]),
+    "deft.tree_decoding.generation.branch_func_example": ("functions", ["example_branch_Func1_SimpleTree",
+                                                                         "example_branch_Func3_FromTreeTemplate",
+                                                                         "example_branch_Func4_SpeculativeDecoding"]),
+    "deft.tree_decoding.branch_controller": ("classes", ["Branch_Controller"]),
     "deft.data_loader": ("mixed", ["ExecuteTreeNode", "ExecuteTree", "build_tree", "build_trees", "load_dataset", "load_trees",
                                    "load_prompts", "generate_accepted_len_list", "build_tree_SD"]),
 }
