@@ -15,6 +15,7 @@ from .rotary_embedding import RotaryEmbedding, get_rope  # noqa: F401
 from .session import DecodeSession, FlattenDecodeSession  # noqa: F401
 from .token_attention import token_attention_fwd  # noqa: F401
 from .tree_attention import kv_append, tree_attention_fwd, tree_attention_subtree_fwd  # noqa: F401
+from .tree_generate import tree_generate  # noqa: F401
 from .tree_cache import (  # noqa: F401
     BLOCK_CONFIG,
     KVCacheUpdater,

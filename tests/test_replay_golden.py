@@ -174,6 +174,66 @@ def test_reference_shaped_front_ends_drive_the_same_loop(name):
     chk.finish(tree, pool)
 
 
+@pytest.mark.parametrize("name", ["simple_w6", "set128ToT", "speculative64"])
+def test_tree_generate_drives_the_same_loop(name):
+    """`deft_amd.tree_generate.tree_generate` (the reference's driver signature, tree_generate.py:20-32) with a stub in place of the
+    Llama model: the stub's `forward_tree_decode` sees, at every step, the reference's slots, tokens, positions and metadata."""
+    import types
+
+    from deft_amd import branch_func_example as bf
+    from deft_amd.tree_generate import tree_generate
+
+    g = np.load(os.path.join(GOLD_DIR, f"replay_{name}.npz"))
+    prompt_len, max_gen_len, pool_size, width, vocab = (int(x) for x in g["config"])
+    tpl = _template(name, g)
+    fn = {"few_shot": bf.example_branch_Func1_SimpleTree, "reasoning": bf.example_branch_Func3_FromTreeTemplate,
+          "speculative_decoding": bf.example_branch_Func4_SpeculativeDecoding}[WORKLOADS[name]]
+    req = deft_amd.ReqToTokenPool(308, pool_size + 8, device="cpu")
+    pool = deft_amd.TokenToKVPool(pool_size, torch.float16, 1, 8, 0, device="cpu")
+    tree = deft_amd.TreeCache(torch.float16, 1, 8, 1, req, pool, None, True, False)
+    chk = _Checker(g)
+    end = {}
+
+    class StubModel:
+        use_paged_memory, use_tree_index = True, False
+
+        def __init__(self):
+            self.tree, self.it = tree, 0
+
+        def forward_prefill(self, input_ids, req_pool_indices, seq_lens, prefix_lens, position_ids_offsets, kv_updater, flag):
+            assert kv_updater.cache_loc.tolist() == list(range(prompt_len)) and req_pool_indices.tolist() == [tree.leaf_to_req[0]]
+            return torch.log(torch.from_numpy(permutation_scores(0, 1, vocab))), None
+
+        def forward_tree_decode(self, forward_mode, token_ids, positions, kv_updater, flag, md):
+            self.it += 1
+            leaves = sorted(tree.leaves.values(), key=lambda n: n.id)
+            assert token_ids.tolist() == [lf.token_ids[-1] for lf in leaves] and positions.tolist() == [lf.positions[-1] for lf in leaves]
+            chk(self.it, tree, kv_updater.cache_loc.cpu().numpy(), {a: getattr(md, a).cpu().numpy() for a in ARRAYS},
+                np.asarray(pool.mem_state))
+            return (torch.log(torch.from_numpy(permutation_scores(self.it, len(leaves), vocab))),), 0.0
+
+    real_free = tree.free
+
+    def free_after_recording():
+        end.update(nodes=len(tree.nodes), leaves=len(tree.leaves), used=int((np.asarray(pool.mem_state) != 0).sum()),
+                   tokens=tree.get_tree_token_number(), finished=len(tree.all_finished_seqs))
+        real_free()
+
+    tree.free = free_after_recording
+    seen = types.SimpleNamespace(updates=0, printed=None)
+    perf = types.SimpleNamespace(update=lambda **kw: setattr(seen, "updates", seen.updates + 1),
+                                 print_latency=lambda **kw: setattr(seen, "printed", kw))
+    tree_generate(model=StubModel(), mode=deft_amd.ForwardMode.TREE_DECODE_FLATTEN, tokenizer=None,
+                  prompt_ids=torch.arange(1, prompt_len + 1, dtype=torch.int32).reshape(1, -1), max_seq_len=prompt_len + max_gen_len,
+                  width=width, depth=0, branch_controller=bf.Branch_Controller(branching_function=fn),
+                  tree_template=None if WORKLOADS[name] == "few_shot" else tpl, perf_metrics=perf)
+    assert chk.k == len(g["iter"]) and chk.snaps_seen == len(chk.snaps)
+    nodes, leaves_n, used, tokens, finished = (int(x) for x in g["end_state"])
+    assert (end["nodes"], end["leaves"], end["used"], end["tokens"], end["finished"]) == (nodes, leaves_n, used, tokens, finished)
+    assert seen.updates == chk.k and seen.printed["prompt_len"] == prompt_len and seen.printed["generated_len"] == tokens - prompt_len
+    assert len(tree.nodes) == 0 and tree.root is None  # tree_generate.py:274
+
+
 def test_a_wrong_walk_order_is_caught():
     """The pin has teeth: with two siblings swapped in the template's child lists (the order in which a branch hands out
     node ids and the top-k tokens), or with the leaves walked in id order where the reference walks its dict, the replay no

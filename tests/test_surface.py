@@ -23,6 +23,7 @@ import deft_amd.rotary_embedding
 import deft_amd.token_attention
 import deft_amd.tree_attention
 import deft_amd.tree_cache
+import deft_amd.tree_generate
 
 SURFACE = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "surface.json")))
 
@@ -38,6 +39,7 @@ COUNTERPART = {
     "deft.data_loader": deft_amd.data_loader,
     "deft.tree_decoding.generation.branch_func_example": deft_amd.branch_func_example,
     "deft.tree_decoding.branch_controller": deft_amd.branch_func_example,
+    "deft.tree_decoding.generation.tree_generate": deft_amd.tree_generate,
 }
 
 # optional parameters deft_amd's counterparts take beyond the reference's (each must have a default)

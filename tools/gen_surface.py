@@ -52,6 +52,7 @@ MODULES = {
                                                                          "example_branch_Func3_FromTreeTemplate",
                                                                          "example_branch_Func4_SpeculativeDecoding"]),
     "deft.tree_decoding.branch_controller": ("classes", ["Branch_Controller"]),
+    "deft.tree_decoding.generation.tree_generate": ("functions", ["tree_generate"]),
     "deft.data_loader": ("mixed", ["ExecuteTreeNode", "ExecuteTree", "build_tree", "build_trees", "load_dataset", "load_trees",
                                    "load_prompts", "generate_accepted_len_list", "build_tree_SD"]),
 }
