@@ -5,7 +5,7 @@ own operator surface.  Importing the package loads libdeft_amd.so and fails loud
 if it has not been built; nothing here falls back to PyTorch or the CPU.
 """
 from ._lib import LIB_PATH, DeftLibraryError, lib  # noqa: F401
-from . import branch_func_example, data_loader  # noqa: F401  (the reference's loader / branch-function names)
+from . import branch_func_example, data_loader, tree_generate  # noqa: F401  (modules under the reference's names: loader, branch functions, driver loop)
 from .context_attention import context_attention_fwd  # noqa: F401
 from .deft_attention import DeFTAttention  # noqa: F401
 from .forest import Forest, concat_metadata_host  # noqa: F401
@@ -15,7 +15,6 @@ from .rotary_embedding import RotaryEmbedding, get_rope  # noqa: F401
 from .session import DecodeSession, FlattenDecodeSession  # noqa: F401
 from .token_attention import token_attention_fwd  # noqa: F401
 from .tree_attention import kv_append, tree_attention_fwd, tree_attention_subtree_fwd  # noqa: F401
-from .tree_generate import tree_generate  # noqa: F401
 from .tree_cache import (  # noqa: F401
     BLOCK_CONFIG,
     KVCacheUpdater,
