@@ -14,5 +14,5 @@ import check_dropin_with_reference_driver as chk  # noqa: E402
 
 @pytest.mark.skipif(not chk.available(), reason="/root/reference is not here (build container only)")
 def test_the_references_own_driver_runs_unchanged_on_deft_amd_objects():
-    done = dict(chk.run(verbose=False))
-    assert done == {"simple_w6": 39, "keywordToT": 564, "set128ToT": 363, "speculative64": 48}
+    done = dict(chk.run(chk.QUICK, verbose=False))
+    assert done == {"simple_w6": 39, "keywordToT": 564, "set128ToT": 363, "speculative64": 48, "speculative256": 28}

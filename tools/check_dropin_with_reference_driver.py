@@ -44,7 +44,12 @@ RUNS = {  # name -> (the reference's branch function, its template source)
     "keywordToT": ("example_branch_Func3_FromTreeTemplate", ("Reasoning", "keywordToT")),
     "set128ToT": ("example_branch_Func3_FromTreeTemplate", ("Reasoning", "set128ToT")),
     "speculative64": ("example_branch_Func4_SpeculativeDecoding", ("Speculative_Decoding", "tree_size64")),
+    "speculative256": ("example_branch_Func4_SpeculativeDecoding", ("Speculative_Decoding", "tree_size256")),
+    # (the two long templates: 2375 and 3708 decode steps -- run by the tool, not by the test)
+    "docmergeToT": ("example_branch_Func3_FromTreeTemplate", ("Reasoning", "docmergeToT")),
+    "sorting128ToT": ("example_branch_Func3_FromTreeTemplate", ("Reasoning", "sorting128ToT")),
 }
+QUICK = ("simple_w6", "keywordToT", "set128ToT", "speculative64", "speculative256")
 
 
 class CudaToCpu(TorchFunctionMode):
