@@ -14,7 +14,8 @@ t_end = time.time() + budget
 runs = steps = captures = sd_runs = 0
 while time.time() < t_end:
     Hq, Hkv = rng.choice([(32, 32), (32, 8), (8, 2), (4, 4), (16, 1)])
-    D, layers = 128, rng.choice([1, 2])
+    # (head_dim 64 -- head pairs on the tile-parallel kernel -- where the geometry allows it: an even number of KV heads)
+    D, layers = (64 if Hkv % 2 == 0 and rng.random() < 0.25 else 128), rng.choice([1, 2])
     mode = rng.choice(["flatten", "flatten", "node", "node_chunk"])
     # (--mode node_chunk = DeFT-Node with MAX_BLOCK_LEN = 128, examples/run_DeFT_llama_paged.py:145-150: the metadata cuts every node
     #  into 128-token entries, the Node plan folds them again -- round 5)
