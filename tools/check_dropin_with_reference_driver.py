@@ -153,6 +153,8 @@ def run(names=None, verbose=True):
                           f"identical to the reference's own run", flush=True)
     finally:
         torch.cuda.synchronize, torch.Tensor.cuda = real_sync, real_cuda
+        if REF in sys.path:
+            sys.path.remove(REF)
         for k, v in saved.items():
             if v is None:
                 sys.modules.pop(k, None)
