@@ -807,11 +807,11 @@ def main():
         cpu = {"value": round(c["tokens_per_s"], 4), "unit": "tokens/s", "cores": c["cores"], "kind": "port",
                "sample": f"1 of {layers} layer-steps of the same tree ({b.nq} leaves, {b.n_kv} unique KV tokens), "
                          f"PyTorch SDPA {c['dtype']} per leaf incl. page-table gather, {c['cores']} threads (best of 8/16/32/all), "
-                         f"best of {c['reps']}, "
+                         f"{c['warmups']} warm-ups, best of {c['reps']} timed repetitions (BASELINE.md section 3), "
                          f"x{layers} layers extrapolated",
                "ms_per_layer_step": round(c["seconds_per_layer_step"] * 1e3, 2), "host_cores": c["host_cores"],
                "fp16": {"value": round(c16["tokens_per_s"], 4), "ms_per_layer_step": round(c16["seconds_per_layer_step"] * 1e3, 2),
-                        "cores": c16["cores"], "reps": c16["reps"]}}
+                        "cores": c16["cores"], "warmups": c16["warmups"], "reps": c16["reps"]}}
 
     if rank == 0:
         Hq, Hkv, D, _ = GEOMETRY[w.model]
