@@ -151,6 +151,13 @@ _TREE_FUNCS = {
                                    [_vp, _i64, _vp, _vp, _vp], C.c_int),
     "deft_tree_dev_apply_ops": ([C.c_int, C.c_int, C.c_int] + [_vp] * 6 + [_vp, _vp, _vp], C.c_int),
     "deft_tree_journal_take": ([_i64, _vp, _i64], _i64),
+    "deft_window_supported": ([C.c_int] * 4, C.c_int),
+    "deft_flatten_build_plan_window": ([_vp] * 6 + [C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _i64, _i64, _i64,
+                                        _vp, _sz, _vp], C.c_int),
+    "deft_node_build_plan_window": ([_vp] * 6 + [C.c_int, C.c_int, _i64, _vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _i64, _i64,
+                                     _i64, _vp, _sz, _vp], C.c_int),
+    "deft_window_patch": ([C.c_int, C.c_int, C.c_int] + [_vp] * 6 + [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int,
+                           C.c_int, _i64, _i64, _vp, _vp], C.c_int),
 }
 for _f, (_a, _r) in _TREE_FUNCS.items():
     getattr(lib, _f).argtypes = _a

@@ -290,6 +290,7 @@ __global__ __launch_bounds__(256, 2) void stage1_kernel(Stage1Params p) {
 #include "plan_records.h"
 #include "plan_kernels.h"
 #include "tree_plan.h"
+#include "window.h"
 #include "merge.h"
 #include "stage1_np.h"
 #include "prefill.h"
@@ -665,7 +666,7 @@ static int plan_items_per_leader(const Stage1Params& p) { return (p.q_sh == 64 &
 
 // Flatten plan: unit list (one workgroup) then one record per unit.
 static int launch_plan(const Stage1Params& p, int NB, const PlanView& pv, const AppendArgs& ap, hipStream_t stream,
-                       const int32_t* dims = nullptr) {
+                       const int32_t* dims = nullptr, int win_tiles = 0, int32_t* win_tab = nullptr) {
     if (NB <= 0) return DEFT_OK;
     // The unit kernel is one workgroup and may use the CU's whole LDS: 9216 blocks = 1.18 M KV tokens per call,
     // more than a 7B model's KV cache fits in 288 GB.
@@ -690,16 +691,20 @@ static int launch_plan(const Stage1Params& p, int NB, const PlanView& pv, const 
     if (par && g_plan_runcap > 0) run_cap = std::max(1, std::min((int)run_cap, g_plan_runcap));  // tests: force the fallback
     if (!par)
         while (sizeof(int) * (blk + 3 * (size_t)run_cap + 8) > UNIT_LDS && run_cap > 0) run_cap /= 2;
+    if (win_tiles > 0 && (!par || run_cap < pv.cap)) {  // (an overflow run must be seen as ONE chunk: the LDS run table says so)
+        set_error("window plan: %lld units exceed the unit kernel's run table", (long long)pv.cap);
+        return DEFT_EUNSUPPORTED;
+    }
     const size_t lds = sizeof(int) * (blk + (par ? 7 : 3) * (size_t)run_cap + 8);
     const UnitList ul = unit_list(pv);
     hipLaunchKernelGGL(flatten_units_kernel, dim3(1), dim3(1024), lds, stream, p.block_q, p.block_q_cnts, p.block_q_offset, NB,
                        p.G, (int)pv.cap, ul, pv.hdr, plan_items_per_leader(p), 2 * num_cus(), np_chunk_knob(), np_union_knob(), (int)run_cap, qtab,
-                       par, dims, pv.row_q, (int)pv.rows);
+                       par, dims, pv.row_q, (int)pv.rows, win_tiles);
     rc = check_launch("flatten units launch");
     if (rc) return rc;
     hipLaunchKernelGGL(flatten_records_kernel, dim3((unsigned)(pv.cap + 1)), dim3(128), 0, stream, p.block_q, p.block_q_cnts,
                        p.block_bitmasks, p.block_kv, p.block_lens, p.G, (int)p.rows, p.q_st, p.q_sh, p.kv_ss, ul, pv.hdr,
-                       pv.records, pv.row_q, ap.cache_loc, ap.n_new, ap.new_st * 2, np_nt_passes_knob(), NB, dims);
+                       pv.records, pv.row_q, ap.cache_loc, ap.n_new, ap.new_st * 2, np_nt_passes_knob(), NB, dims, win_tiles, win_tab);
     rc = check_launch("flatten records launch");
     if (rc) return rc;
     return launch_qrows(pv, stream);
@@ -1240,7 +1245,8 @@ int deft_flatten_decode_rope_append_f16(const void* q, int64_t q_stride_tok, int
 }
 
 static int launch_node_plan(const Stage1Params& p, int NE, int64_t rows_cap, const PlanView& pv, const AppendArgs& ap,
-                            hipStream_t stream, int keep_err = 0, const int32_t* dims = nullptr) {
+                            hipStream_t stream, int keep_err = 0, const int32_t* dims = nullptr, int win_tiles = 0,
+                            int32_t* win_tab = nullptr) {
     const UnitList ul = unit_list(pv);
     // a run table in LDS: 10 words per run and every possible run (the kernel then writes units and
     // record order with all its waves), or as many runs as fit (it falls back to one lane if more turn up)
@@ -1256,15 +1262,20 @@ static int launch_node_plan(const Stage1Params& p, int NE, int64_t rows_cap, con
     if (par && g_plan_runcap > 0) run_cap = std::max(1, std::min((int)run_cap, g_plan_runcap));  // tests: force the fallback
     if (!par)
         while (sizeof(int) * (3 * (size_t)run_cap + 8) > UNIT_LDS && run_cap > 1) run_cap /= 2;
+    if (win_tiles > 0 && (!par || run_cap < pv.cap)) {  // (launch_plan: an overflow run must be seen as ONE chunk)
+        set_error("window plan: %lld units exceed the unit kernel's run table", (long long)pv.cap);
+        return DEFT_EUNSUPPORTED;
+    }
     hipLaunchKernelGGL(node_units_kernel, dim3(1), dim3(1024), sizeof(int) * ((par ? 10 : 3) * (size_t)run_cap + 8), stream,
                        p.node_kv_len, p.node_q_len, p.node_q, p.node_q_offset, NE, p.G, (int)pv.cap, rows_cap, ul, pv.hdr, pv.row_q,
                        plan_items_per_leader(p),
-                       2 * num_cus(), np_chunk_knob(), (int)run_cap, par, keep_err, dims);
+                       2 * num_cus(), np_chunk_knob(), (int)run_cap, par, keep_err, dims, win_tiles);
     rc = check_launch("node units launch");
     if (rc) return rc;
     hipLaunchKernelGGL(node_records_kernel, dim3((unsigned)(pv.cap + 1)), dim3(128), 0, stream, p.node_kv, p.node_kv_offset,
                        p.node_kv_len, p.node_q, p.node_q_offset, p.node_q_len, p.G, (int)p.rows, p.q_st, p.q_sh, p.kv_ss, ul,
-                       pv.hdr, pv.records, pv.row_q, ap.cache_loc, ap.n_new, ap.new_st * 2, np_nt_passes_knob(), NE, dims);
+                       pv.hdr, pv.records, pv.row_q, ap.cache_loc, ap.n_new, ap.new_st * 2, np_nt_passes_knob(), NE, dims, win_tiles,
+                       win_tab);
     rc = check_launch("node records launch");
     if (rc) return rc;
     return launch_qrows(pv, stream);
@@ -2039,6 +2050,118 @@ int deft_tree_dev_build_md_ops(int n_nodes, int nq, int nqw, const int32_t* node
                                   max_block_len, nbp_cap, scratch, scratch_bytes, node_q, node_kv, node_q_len, node_kv_len,
                                   node_q_offset, node_kv_offset, block_q, block_q_cnts, block_q_offset, block_bitmasks, block_kv,
                                   block_lens, advance_loc, ops, PageWrite{page_table, page_stride, page_rows, page_cols}, stream);
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------
+// Window plans (window.h): the incremental per-step head of deft_amd.DecodeSession.
+// ---------------------------------------------------------------------------
+extern "C" {
+
+/* 1 when a tree step of this shape can run on a window plan: every (query chunk, 32-row pass) pair that hosts the overflow tiles
+ * has a place in the tables. */
+int deft_window_supported(int nq, int max_q_len, int Hq, int Hkv) {
+    if (nq <= 0 || max_q_len < 1 || max_q_len > 63 || Hq <= 0 || Hkv <= 0 || Hq % Hkv) return 0;
+    const int G = Hq / Hkv;
+    const int chunks = (nq + max_q_len - 1) / max_q_len;
+    const int passes = (std::min(nq, max_q_len) * G + MQ - 1) / MQ;
+    return passes <= WIN_PASSES && chunks * passes <= 64 ? 1 : 0;
+}
+
+int deft_flatten_build_plan_window(int64_t* block_q, int64_t* block_q_cnts, int64_t* block_q_offset, int64_t* block_bitmasks,
+                                   int64_t* block_kv, int64_t* block_lens, int NB, int P, int32_t* dims, int nq, int max_q_len,
+                                   int win_tiles, int32_t* win_tab, int Hq, int Hkv, int64_t q_stride_tok, int64_t q_stride_head,
+                                   int64_t kv_stride_slot, void* plan, size_t plan_bytes, void* stream) {
+    if (NB <= 0 || P <= 0 || !plan || !dims || !win_tab || win_tiles < 1 || !deft_window_supported(nq, max_q_len, Hq, Hkv) || !block_q ||
+        !block_q_cnts || !block_q_offset || !block_bitmasks || !block_kv || !block_lens) {
+        set_error("bad window plan arguments (NB=%d P=%d nq=%d max_q_len=%d tiles=%d)", NB, P, nq, max_q_len, win_tiles);
+        return DEFT_EINVAL;
+    }
+    const PlanView pv = plan_view(plan, flatten_unit_cap(NB, Hq / Hkv), P);
+    if (plan_bytes < pv.bytes) {
+        set_error("plan buffer too small: %zu < %zu", plan_bytes, pv.bytes);
+        return DEFT_EWORKSPACE;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    TreeMdOut o{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, block_q, block_q_cnts, block_q_offset, block_bitmasks, block_kv, block_lens};
+    hipLaunchKernelGGL(window_blocks_kernel, dim3(1), dim3(256), 0, st, o, dims, nq, max_q_len, win_tiles, TILE, NB, P);
+    int rc = check_launch("window blocks launch");
+    if (rc) return rc;
+    Stage1Params p{};
+    p.block_q = block_q;
+    p.block_q_cnts = block_q_cnts;
+    p.block_q_offset = block_q_offset;
+    p.block_bitmasks = block_bitmasks;
+    p.block_kv = block_kv;
+    p.block_lens = block_lens;
+    p.rows = P;
+    p.G = Hq / Hkv;
+    p.Hkv = Hkv;
+    p.q_st = q_stride_tok;
+    p.q_sh = q_stride_head;
+    p.kv_ss = kv_stride_slot;
+    return launch_plan(p, NB, pv, AppendArgs(), st, dims, win_tiles, win_tab);
+}
+
+int deft_node_build_plan_window(int64_t* node_kv, int64_t* node_kv_offset, int64_t* node_kv_len, int64_t* node_q,
+                                int64_t* node_q_offset, int64_t* node_q_len, int NE, int P, int64_t total_kv, int32_t* dims, int nq,
+                                int max_q_len, int win_tiles, int32_t* win_tab, int Hq, int Hkv, int64_t q_stride_tok,
+                                int64_t q_stride_head, int64_t kv_stride_slot, void* plan, size_t plan_bytes, void* stream) {
+    if (NE <= 0 || P <= 0 || total_kv <= 0 || total_kv > 0x7fffffffLL || !plan || !dims || !win_tab || win_tiles < 1 ||
+        !deft_window_supported(nq, max_q_len, Hq, Hkv) || !node_kv || !node_kv_offset || !node_kv_len || !node_q || !node_q_offset ||
+        !node_q_len) {
+        set_error("bad window plan arguments (NE=%d P=%d total_kv=%lld nq=%d)", NE, P, (long long)total_kv, nq);
+        return DEFT_EINVAL;
+    }
+    const int64_t tiles = node_max_tiles(NE, total_kv);
+    const int64_t rows = tiles * node_rows_per_tile(P);
+    const PlanView pv = plan_view(plan, tiles * (Hq / Hkv), rows);
+    if (plan_bytes < pv.bytes) {
+        set_error("plan buffer too small: %zu < %zu", plan_bytes, pv.bytes);
+        return DEFT_EWORKSPACE;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    TreeMdOut o{node_q, node_kv, node_q_len, node_kv_len, node_q_offset, node_kv_offset, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipLaunchKernelGGL(window_entries_kernel, dim3(1), dim3(256), 0, st, o, dims, nq, max_q_len, win_tiles, NE, P, (int)total_kv);
+    int rc = check_launch("window entries launch");
+    if (rc) return rc;
+    Stage1Params p{};
+    p.node_kv = node_kv;
+    p.node_kv_offset = node_kv_offset;
+    p.node_kv_len = node_kv_len;
+    p.node_q = node_q;
+    p.node_q_offset = node_q_offset;
+    p.node_q_len = node_q_len;
+    p.rows = rows;
+    p.G = Hq / Hkv;
+    p.Hkv = Hkv;
+    p.q_st = q_stride_tok;
+    p.q_sh = q_stride_head;
+    p.kv_ss = kv_stride_slot;
+    return launch_node_plan(p, NE, rows, pv, AppendArgs(), st, 0, dims, win_tiles, win_tab);
+}
+
+int deft_window_patch(int n_nodes, int nq, int nqw, const int32_t* node_start, int32_t* node_len, const int32_t* node_cap,
+                      const uint64_t* refs, const int32_t* leaf_node, int32_t* slots, const int32_t* ops, const int32_t* cache_loc,
+                      int32_t* page_table, int64_t page_stride, const int64_t* page_rows, const int64_t* page_cols,
+                      const int32_t* patch, const int32_t* win_tab, void* plan, int max_q_len, int win_tiles, int Hq, int Hkv,
+                      int64_t kv_stride_slot, int64_t new_stride_tok, void* scratch, void* stream) {
+    if (n_nodes <= 0 || nq <= 0 || nqw < 1 || !node_start || !node_len || !node_cap || !refs || !leaf_node || !slots || !cache_loc ||
+        !patch || !win_tab || !plan || !scratch || win_tiles < 1 || !deft_window_supported(nq, max_q_len, Hq, Hkv)) {
+        set_error("deft_window_patch: bad arguments (nodes=%d nq=%d tiles=%d)", n_nodes, nq, win_tiles);
+        return DEFT_EINVAL;
+    }
+    if (page_table && (!page_rows || !page_cols || page_stride <= 0)) {
+        set_error("deft_window_patch: the page-table write needs rows, cols and a row stride");
+        return DEFT_EINVAL;
+    }
+    TreeDev t{n_nodes, nq, nqw, node_start, node_len, node_cap, reinterpret_cast<const unsigned long long*>(refs), leaf_node, slots};
+    WindowPatch w{ops, cache_loc, patch, win_tab, static_cast<char*>(plan) + PLAN_HDR, static_cast<int32_t*>(scratch) + TREE_ERR,
+                  max_q_len, Hq / Hkv, win_tiles, kv_stride_slot, new_stride_tok * 2};
+    hipLaunchKernelGGL(window_patch_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), t, w,
+                       PageWrite{page_table, page_stride, page_rows, page_cols});
+    return check_launch("window patch launch");
 }
 
 }  // extern "C"

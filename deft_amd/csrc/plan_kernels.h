@@ -118,7 +118,7 @@ __device__ inline void np_record_order(const UnitList& ul, int R, int Hkv, int G
                 const int id = ul.flags[r] >> 1;
                 int e = r + 1;
                 while (e < R && (ul.flags[e] >> 1) == id) ++e;
-                fn(r, e - r, ul.aux[r] > 0 ? 1 : 0);
+                fn(r, e - r, ul.aux[r] != 0 ? 1 : 0);  // (union group, or -1: a window plan's overflow run; a Node pack (< 0) is one unit anyway)
                 r = e;
             }
         }
@@ -389,11 +389,14 @@ __global__ __launch_bounds__(1024) void flatten_units_kernel(const int64_t* bloc
                                                             const int64_t* block_q_offset, int NBc, int G, int cap,
                                                             UnitList ul, int32_t* hdr, int Hkv, int slots, int chunk_c,
                                                             int union_len, int run_cap, int qtab, int par,
-                                                            const int32_t* dims, int32_t* row_q, int rows) {
+                                                            const int32_t* dims, int32_t* row_q, int rows, int win_tiles) {
     constexpr int np = 1;  // records in the tile-parallel order (leaders first); the only stage-1 form
     // NBc = block CAPACITY (sizes the tables); with `dims` (device-side metadata, tree_plan.h) the block count of this
     // step is read from the device, so that one captured launch serves every step of a structural epoch
     const int NB = dims ? min(dims[5], NBc) : NBc;
+    // window plan (window.h): blocks NBreg .. NB - 1 are overflow tiles -- `win_tiles` consecutive blocks per query chunk, each set
+    // ONE run kept in ONE chunk (run-table marker -1), never part of a union group or of an interleaved run
+    const int NBreg = (dims && win_tiles > 0) ? min(dims[WIN_DIM_NB], NB) : NB;
     if (dims)  // rows beyond this step's partial rows must read "dead" (the row lists are built over the capacity)
         for (int i = threadIdx.x; i < rows; i += blockDim.x) row_q[i] = -1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -463,6 +466,7 @@ __global__ __launch_bounds__(1024) void flatten_units_kernel(const int64_t* bloc
                 bits |= (!same_cnt[pd - 1] || any) ? (1 << (pd - 1)) : 0;
             }
             if (!(bits & 1)) bits = 0xe;  // not opening a run: longer periods read as "differs"
+            if (t >= NBreg) bits = ((t - NBreg) % win_tiles == 0) ? 0xf : 0xe;  // (overflow tiles: a run of their own per query chunk)
             if (live && li == 0) sOpen[t] = bits;
         }
     }
@@ -504,15 +508,15 @@ __global__ __launch_bounds__(1024) void flatten_units_kernel(const int64_t* bloc
         return ulen;
     };
     if (np && ucap >= 2)
-        for (int t = threadIdx.x; t < NB; t += blockDim.x) {
+        for (int t = threadIdx.x; t < NBreg; t += blockDim.x) {
             const int ulen = union_len_at(t);
             int g = 0;
             if (ulen > 1 && sCnt[t] <= ucap) {
-                bool short_run = NB - t < ulen;  // the run that opens at t is shorter than a group
-                for (int u = t + 1; u < t + ulen && u < NB; ++u) short_run |= (sOpen[u] & 1) != 0;
+                bool short_run = NBreg - t < ulen;  // the run that opens at t is shorter than a group
+                for (int u = t + 1; u < t + ulen && u < NBreg; ++u) short_run |= (sOpen[u] & 1) != 0;
                 if (short_run) {
                     int uq[UNION_CAP], urow[UNION_CAP], un;
-                    g = union_group(t, NB, ulen, ucap, sCnt, sOff, qtab ? sQ : nullptr, block_q, uq, urow, un);
+                    g = union_group(t, NBreg, ulen, ucap, sCnt, sOff, qtab ? sQ : nullptr, block_q, uq, urow, un);
                     if (g < 2) g = 0;
                 }
             }
@@ -581,6 +585,13 @@ __global__ __launch_bounds__(1024) void flatten_units_kernel(const int64_t* bloc
             r += n;
         };
         for (int ta = 0; ta < NB;) {
+            // ---- overflow tiles of one query chunk (window plan): one run per pass, one chunk each ---------------
+            if (ta >= NBreg) {
+                const int te = min(NB, ta + win_tiles);
+                for (int ps = 0; ps < sPass[ta]; ++ps) emit_run(ta, te, 1, -1, ps);
+                ta = te;
+                continue;
+            }
             // ---- union group starting at ta (phase 1b) ------------------------------------------------------
             const int glen = sOpen[ta] >> 8;
             if (glen >= 2 && r < cap) {
@@ -678,7 +689,8 @@ __global__ __launch_bounds__(128) void flatten_records_kernel(const int64_t* blo
                                                               int64_t q_sh, int64_t kv_stride_slot, UnitList ul,
                                                               const int32_t* hdr, char* plan, int32_t* row_q,
                                                               const int32_t* cache_loc, int n_new, int64_t new_row_bytes,
-                                                              int nt_passes, int NBc, const int32_t* dims) {
+                                                              int nt_passes, int NBc, const int32_t* dims, int win_tiles,
+                                                              int32_t* win_tab) {
     constexpr int np = 1;
     const int NB = dims ? min(dims[5], NBc) : NBc;  // (device-side metadata: this step's block count, see flatten_units_kernel)
     __shared__ int sKeys[NEWMAP_SIZE], sVals[NEWMAP_SIZE];
@@ -794,6 +806,13 @@ __global__ __launch_bounds__(128) void flatten_records_kernel(const int64_t* blo
         for (int o = t + 1; o < NB && passes <= nt_passes && block_kv[(int64_t)o * TILE] == slot0; ++o)
             passes += ((int)block_q_cnts[o] * G + MQ - 1) / MQ;
         desc[6] = passes > nt_passes;
+        // window plan: the leader of an overflow run tells window_patch_kernel where the run's records are -- per (query chunk, pass)
+        // {leader record, first follower record} (followers are consecutive: tile j of the run is record first + j - 1)
+        if (win_tiles > 0 && dims && t >= dims[WIN_DIM_NB] && np && ul.ch_n[r] > 0 && ps < WIN_PASSES) {
+            const int c = (t - dims[WIN_DIM_NB]) / win_tiles;
+            win_tab[(c * WIN_PASSES + ps) * 2] = r;
+            win_tab[(c * WIN_PASSES + ps) * 2 + 1] = ul.ch_fb[r];
+        }
     }
 }
 
@@ -814,9 +833,11 @@ __global__ __launch_bounds__(1024) void node_units_kernel(const int64_t* node_kv
                                                           const int64_t* node_q, const int64_t* node_q_offset, int NEc, int G,
                                                           int cap, int64_t rows_cap, UnitList ul, int32_t* hdr,
                                                           int32_t* row_q, int Hkv, int slots, int chunk_c, int run_cap,
-                                                          int par, int keep_err, const int32_t* dims) {
+                                                          int par, int keep_err, const int32_t* dims, int win_tiles) {
     constexpr int np = 1;
     const int NE = dims ? min(dims[1], NEc) : NEc;  // (device-side metadata: this step's entry count, see flatten_units_kernel)
+    // window plan (window.h): entries NEreg .. NE - 1 are overflow entries, one per query chunk -- each ONE run in ONE chunk, never packed or folded
+    const int NEreg = (dims && win_tiles > 0) ? min(dims[WIN_DIM_NB], NE) : NE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int* sRun = reinterpret_cast<int*>(smem);
     RunTable rt{sRun, sRun + run_cap, sRun + 2 * run_cap, 0, run_cap};
@@ -842,7 +863,7 @@ __global__ __launch_bounds__(1024) void node_units_kernel(const int64_t* node_kv
             rt.n = 0;
             int r = 0, rowbase = 0;
             int pack_r = -1, pack_k = -1, pack_n = 0, pack_keys = 0, pack_rows = 0;  // open pack: unit, run, entries, slots, virtual rows
-            auto emit_run = [&](int e, int n, int ps, int prow0, int ql, int aux) {
+            auto emit_run = [&](int e, int n, int ps, int prow0, int ql, int aux, int uni = 0) {
                 if (n > cap - r) n = cap - r;
                 if (n <= 0) return;
                 const int first = r;
@@ -850,7 +871,7 @@ __global__ __launch_bounds__(1024) void node_units_kernel(const int64_t* node_kv
                     if (lane == 0 && rt.n < rt.cap) {
                         rt.r0[rt.n] = first;
                         rt.nt[rt.n] = n;
-                        rt.uni[rt.n] = 0;
+                        rt.uni[rt.n] = uni;
                         rT0[rt.n] = e;
                         rSp[rt.n] = ps;
                         rProw[rt.n] = prow0;
@@ -868,7 +889,7 @@ __global__ __launch_bounds__(1024) void node_units_kernel(const int64_t* node_kv
                     if (rt.n < rt.cap) {
                         rt.r0[rt.n] = first;
                         rt.nt[rt.n] = n;
-                        rt.uni[rt.n] = 0;
+                        rt.uni[rt.n] = uni;
                     }
                 }
                 ++rt.n;
@@ -893,7 +914,7 @@ __global__ __launch_bounds__(1024) void node_units_kernel(const int64_t* node_kv
                   //  walk -- 15 more spilled SGPRs, +1.5 ... +3.5 us on every Node plan that never takes this branch)
                   const int64_t* nq = sListPtr[0];
                   const int64_t* nqo = sListPtr[1];
-                  if (lane >= 1 && mine < NE && plen == TILE && vlen >= 1 && vlen <= TILE && vql == pql && vql > 0 && nq) {
+                  if (lane >= 1 && mine < NEreg && plen == TILE && vlen >= 1 && vlen <= TILE && vql == pql && vql > 0 && nq) {
                       const int64_t a = nqo[mine], b = nqo[mine - 1];
                       cont = true;
                       for (int t = 0; t < vql; ++t) cont &= nq[a + t] == nq[b + t];
@@ -913,6 +934,12 @@ __global__ __launch_bounds__(1024) void node_units_kernel(const int64_t* node_kv
                 // must not pay for this case)
                 const int more = __builtin_amdgcn_readlane(vmore, i);
                 const int nrun = more > 0 ? 1 + more : nt;
+                if (e >= NEreg) {  // an overflow entry of a window plan: its tiles are one run per pass, each kept in one chunk
+                    pack_r = -1;
+                    for (int ps = 0; ps < npass; ++ps) emit_run(e, nt, ps, rowbase, ql, 1, -1);
+                    rowbase += nt * ql;
+                    continue;
+                }
                 if (more == 0 && nt == 1 && npass == 1 && r < cap) {
                     if (pack_r >= 0 && pack_n < MQ && pack_keys + len <= TILE && pack_rows + ql * G <= MQ) {
                         ++pack_n;
@@ -982,8 +1009,10 @@ __global__ __launch_bounds__(128) void node_records_kernel(const int64_t* node_k
                                                            int rows, int64_t q_st, int64_t q_sh, int64_t kv_stride_slot,
                                                            UnitList ul, const int32_t* hdr, char* plan, int32_t* row_q,
                                                            const int32_t* cache_loc, int n_new, int64_t new_row_bytes,
-                                                           int nt_passes, int NEc, const int32_t* dims) {
+                                                           int nt_passes, int NEc, const int32_t* dims, int win_tiles,
+                                                           int32_t* win_tab) {
     const int NE = dims ? min(dims[1], NEc) : NEc;
+    const int NEreg = (dims && win_tiles > 0) ? min(dims[WIN_DIM_NB], NE) : NE;  // window plan: entries from here on are overflow entries
     __shared__ int sPasses;
     constexpr int np = 1;
     __shared__ int sKeys[NEWMAP_SIZE], sVals[NEWMAP_SIZE];
@@ -1089,7 +1118,12 @@ __global__ __launch_bounds__(128) void node_records_kernel(const int64_t* node_k
     const int nv = min(MQ, ql * G - MQ * ps);
     const bool live = k < len;
     ro[k] = plan_rowoff(node_kv[kv0 + (live ? k : 0)], kv_stride_slot, cache_loc, n_new, new_row_bytes, nm);
-    mk[k] = live ? (nv >= 32 ? 0xffffffffu : ((1u << nv) - 1u)) : 0u;
+    // (an overflow entry's slots start masked: window_patch_kernel gives every token it places there its own rows)
+    mk[k] = (live && e < NEreg) ? (nv >= 32 ? 0xffffffffu : ((1u << nv) - 1u)) : 0u;
+    if (k == 0 && e >= NEreg && tt == 0 && np && ul.ch_n[r] > 0 && ps < WIN_PASSES) {
+        win_tab[((e - NEreg) * WIN_PASSES + ps) * 2] = r;
+        win_tab[((e - NEreg) * WIN_PASSES + ps) * 2 + 1] = ul.ch_fb[r];
+    }
     if (k < MQ) {
         int qs = 0, orow = 0;
         if (k < nv) {

@@ -29,6 +29,11 @@ constexpr int PLAN_HDR = 4096;
 constexpr int HDR_ERR = 2;
 constexpr int HDR_QLISTS = 3;
 
+// Window plans (window.h): per query chunk and 32-row pass, where the overflow run's records are
+constexpr int WIN_PASSES = 16;   // 32-row passes per query chunk the table has room for (max_q_len * G / 32)
+constexpr int WIN_DIM_NB = 10;   // dims[10]: blocks (Flatten) / entries (Node) in front of the overflow ones
+constexpr int WIN_DIM_P = 11;    // dims[11]: block_q / node_q elements in front of the overflow lists
+
 // 64 lanes x 16 bytes, global (per-lane address) -> LDS (lds_dst + 16*lane).  M0 is not
 // otherwise used by the kernels (checked in the .s), so it is written, not saved.
 __device__ __forceinline__ void dma16(const void* gsrc, uint32_t lds_dst) {

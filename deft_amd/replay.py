@@ -196,20 +196,25 @@ class TemplateReplay:
 
     def __init__(self, num_heads: int, num_kv_heads: int, head_dim: int, layers: int, mode: str = "flatten",
                  device: str = "cuda", attention: bool = True, seed: int = 0, vocab: int = 4096, session: Optional[bool] = None,
-                 capture_after="auto") -> None:
+                 capture_after="auto", incremental: bool = True) -> None:
         """`session`: drive the attention path through `deft_amd.DecodeSession` -- the whole decode step (tree advance,
         TreeMetadata, plan, every layer's append + attention) as ONE captured hipGraph per structural epoch of the tree -- instead
         of the reference-shaped eager calls (`tree.alloc()`, `TreeMetadata.from_tree_cache`, `DeFTAttention.forward` per layer).
         None = wherever a session exists (DeFT-Flatten / DeFT-Node, head_dim 128 or 64 as head pairs, attention on).
-        `capture_after`: DecodeSession's -- how many steps of an epoch run eagerly before its step is captured."""
-        self.capture_after = capture_after
+        `capture_after`: DecodeSession's -- how many steps of an epoch run eagerly before its step is captured.
+        `incremental`: DecodeSession's -- window plans (most steps patch the plan instead of rebuilding metadata and plan)."""
+        self.capture_after, self.incremental = capture_after, incremental
         self.Hq, self.Hkv, self.D, self.layers = num_heads, num_kv_heads, head_dim, layers
         self.mode = mode
-        self.forward_mode: ForwardMode = forward_mode_from_cli(mode)  # (node / node_chunk set BLOCK_CONFIG["MAX_BLOCK_LEN"], as the CLI does)
-        if mode not in ("node", "node_chunk", "deft_node", "deft_node_chunk"):
-            from .tree_cache import BLOCK_CONFIG
+        # (node / node_chunk set BLOCK_CONFIG["MAX_BLOCK_LEN"] as the CLI does -- a process-wide setting.  The replay keeps ITS value
+        #  and puts it in force for the duration of run() only: two replays of different modes built before either runs no longer
+        #  overwrite each other's chunking, and a caller's own setting survives the construction of a replay.  ADVICE r5)
+        from .tree_cache import BLOCK_CONFIG
 
-            BLOCK_CONFIG["MAX_BLOCK_LEN"] = -1  # (a process that replays several modes: no chunking left over from a node_chunk replay)
+        before = BLOCK_CONFIG["MAX_BLOCK_LEN"]
+        self.forward_mode: ForwardMode = forward_mode_from_cli(mode)
+        self.max_block_len = BLOCK_CONFIG["MAX_BLOCK_LEN"] if mode in ("node", "node_chunk", "deft_node", "deft_node_chunk") else -1
+        BLOCK_CONFIG["MAX_BLOCK_LEN"] = before
         self.device = device
         self.attention = attention
         self.vocab = vocab
@@ -241,9 +246,20 @@ class TemplateReplay:
                              device=self.device)
         return req, pool
 
-    def run(self, template: TreeTemplate, task: str, prompt_len: int, max_gen_len: int, max_tokens: Optional[int] = None,
-            max_leaves: int = 512, max_rows: int = 512, pipelined: bool = False,
-            scores_fn: Optional[Callable[[int, int], np.ndarray]] = None) -> ReplayReport:
+    def run(self, *args, **kw) -> ReplayReport:
+        """`_run` under this replay's own MAX_BLOCK_LEN (the global is restored afterwards, whatever happens)."""
+        from .tree_cache import BLOCK_CONFIG
+
+        before = BLOCK_CONFIG["MAX_BLOCK_LEN"]
+        BLOCK_CONFIG["MAX_BLOCK_LEN"] = self.max_block_len
+        try:
+            return self._run(*args, **kw)
+        finally:
+            BLOCK_CONFIG["MAX_BLOCK_LEN"] = before
+
+    def _run(self, template: TreeTemplate, task: str, prompt_len: int, max_gen_len: int, max_tokens: Optional[int] = None,
+             max_leaves: int = 512, max_rows: int = 512, pipelined: bool = False,
+             scores_fn: Optional[Callable[[int, int], np.ndarray]] = None) -> ReplayReport:
         """`pipelined=True`: no per-step synchronisation -- the host builds step t+1's tree state and metadata while the
         GPU still runs step t (the path is launch-only; the synthetic scores do not depend on the GPU's output, as
         in a real engine between branch events, where the tree's SHAPE one step ahead is known).  Per-step attention
@@ -287,7 +303,7 @@ class TemplateReplay:
             sess = DecodeSession(tree, self.Hq, self.Hkv, self.D, self.layers,
                                  lambda l: (q_all[l, : nq_now[0]], k_all[l, : nq_now[0]], v_all[l, : nq_now[0]]),
                                  mode="node" if self.mode == "node_chunk" else self.mode,
-                                 capture_after=self.capture_after)
+                                 capture_after=self.capture_after, incremental=self.incremental)
             sizes = np.zeros(9, dtype=np.int64)
         t_wall = time.perf_counter()
         tree.init_prompt(torch.arange(1, prompt_len + 1, dtype=torch.int32))

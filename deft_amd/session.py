@@ -1,4 +1,4 @@
-"""A decode loop over ONE tree as captured hipGraphs: one graph per structural epoch of the tree.
+"""A decode loop over ONE tree as captured hipGraphs: one (legacy) or two (window plan) graphs per structural epoch of the tree.
 
 What a runner does per decode step around the attention path (DeFT/deft/tree_decoding/generation/tree_generate.py:93-131,
 model_runner.py:162-231): `tree.alloc()`, `TreeMetadata.from_tree_cache(tree)`, then the model's forward, whose every
@@ -16,26 +16,127 @@ Per step the host picks the new slots (its allocator mirrors the pool), appends 
 nq slot numbers and page-table coordinates from pinned memory, and replays: ~0.1 ms of host time, nothing else crosses
 PCIe.  A branch / cut / merge (or a leaf outgrowing its room) starts a new epoch: upload the compact tree, capture again.
 
-DeFT-Flatten and DeFT-Node; head_dim 128, and 64 as head pairs.  The eager path (`tree.alloc()` + `TreeMetadata.from_tree_cache` + `DeFTAttention`) gives the same
-results step for step (tests/test_session.py).
+`incremental=True` (the default; round 6, deft_amd/csrc/window.h): the metadata + plan head -- what the reference rebuilds whole on
+every step, tree_cache.py:619-881 -- runs only on REPLAN steps, once per WINDOW of steps; all other steps run ONE small kernel
+that patches the plan: this step's tokens (and the slots a speculative-decoding step merges into a node, and the slots it
+drops) go to overflow tiles at the end of the plan, with per-slot row masks.  The books (which overflow position belongs to which
+node, when a window is full) are kept here on the host; two graphs per epoch, the host picks which one a step replays.  Outputs
+of window steps are another PARTITION of the same keys than the eager path's: equal within the oracle's tolerance, not bit for bit.
+`incremental=False` is the round-5 loop: bit-identical to the eager path step for step (tests/test_session.py).
+
+DeFT-Flatten and DeFT-Node; head_dim 128, and 64 as head pairs.
 """
 from __future__ import annotations
 
-from typing import Callable, List, Optional
+from typing import Callable, Dict, List, Optional
 
 import numpy as np
 import torch
 
-from ._lib import check, lib
+from ._lib import DeftLibraryError, check, lib
 from .tree_cache import BLOCK_CONFIG, TreeCache, _DeviceTree, _FIELDS, _ptr
 
 __all__ = ["DecodeSession", "FlattenDecodeSession"]
+
+_TILE = 128
+_WIN_PASSES = 16  # (plan_records.h WIN_PASSES: the overflow table's passes per query chunk)
+
+
+class _Window:
+    """Host-side books of one window plan (csrc/window.h): which overflow position holds which node's slot.
+
+    Positions are handed out in order; a node that was RESET keeps its positions and its next tokens reuse them (a
+    speculative-decoding leaf is reset and refilled every step).  `begin()` starts a window on a REPLAN step, `step()` continues it
+    on a PATCH step or says that it cannot (None): the overflow is full, or a node was reset whose slots the static part of the
+    plan still holds.  Both return the patch list of the step: {position: (node | -1, slot | -1 - new row)}."""
+
+    def __init__(self, nq: int, tiles: int, leaf_node: np.ndarray, max_entries: int) -> None:
+        self.nq, self.cap, self.leaf_node, self.max_entries = nq, tiles * _TILE, leaf_node, max_entries
+        self.valid = False
+        self.fill = 0
+        self.own: Dict[int, List[int]] = {}   # node -> overflow positions it has been given, in order
+        self.live: Dict[int, int] = {}        # node -> how many of them hold a slot
+        self.clean: set = set()               # nodes whose every slot is in the overflow (none in the static part of the plan)
+        self.prev_new: List[tuple] = []       # (position, node, slot) of the rows the LAST step read from k_new / v_new
+
+    def _place(self, node: int) -> int:
+        own = self.own.setdefault(node, [])
+        n = self.live.get(node, 0)
+        if n < len(own):
+            pos = own[n]
+        else:
+            if self.fill >= self.cap:
+                return -1
+            pos = self.fill
+            self.fill += 1
+            own.append(pos)
+        self.live[node] = n + 1
+        return pos
+
+    def _apply(self, ent: Dict[int, tuple], journal: np.ndarray, loc: np.ndarray, replan: bool) -> Optional[Dict[int, tuple]]:
+        at, nw = 0, len(journal)
+        while at + 2 < nw:
+            op, node, k = int(journal[at]), int(journal[at + 1]), int(journal[at + 2])
+            if op == 2:  # RESET: the node's slots are dropped
+                if replan:  # (the scan kernel replays the journal BEFORE the plan is made: the static part never sees these slots)
+                    self.clean.add(node)
+                else:
+                    if node not in self.clean:
+                        return None
+                    for pos in self.own.get(node, [])[: self.live.get(node, 0)]:
+                        ent[pos] = (-1, 0)
+                    self.live[node] = 0
+                at += 3
+            elif op == 1:  # EXTEND: k slots join the node
+                if replan:
+                    self.clean.discard(node)  # (they are in the static part)
+                else:
+                    for s in journal[at + 3 : at + 3 + k]:
+                        pos = self._place(node)
+                        if pos < 0:
+                            return None
+                        ent[pos] = (node, int(s))
+                at += 3 + k
+            else:
+                return None
+        new = []
+        for r in range(self.nq):
+            node = int(self.leaf_node[r])
+            pos = self._place(node)
+            if pos < 0:
+                return None
+            ent[pos] = (node, -1 - r)
+            new.append((pos, node, int(loc[r])))
+        if len(ent) > self.max_entries:
+            return None
+        self.prev_new = new
+        return ent
+
+    def begin(self, journal: np.ndarray, loc: np.ndarray) -> Optional[Dict[int, tuple]]:
+        self.fill, self.own, self.live, self.clean, self.prev_new = 0, {}, {}, set(), []
+        ent = self._apply({}, journal, loc, True)
+        self.valid = ent is not None
+        return ent
+
+    def step(self, journal: np.ndarray, loc: np.ndarray) -> Optional[Dict[int, tuple]]:
+        if not self.valid:
+            return None
+        # the rows the last step read from k_new / v_new are in the pool now: their positions get the pool offsets
+        ent = {pos: (node, slot) for pos, node, slot in self.prev_new}
+        ent = self._apply(ent, journal, loc, False)
+        if ent is None:
+            self.valid = False  # (the books are half-updated: the replan step starts from scratch)
+        return ent
+
+    @property
+    def active_tiles(self) -> int:
+        return (self.fill + _TILE - 1) // _TILE
 
 
 class DecodeSession:
     def __init__(self, tree: TreeCache, num_heads: int, num_kv_heads: int, head_dim: int, layers: int,
                  qkv: Callable[[int], tuple], max_q_len: int = 32, use_graph: bool = True, mode: str = "flatten",
-                 capture_after="auto") -> None:
+                 capture_after="auto", incremental: bool = True, win_tiles: Optional[int] = None) -> None:
         """`qkv(layer)` -> (q [nq, Hq*D], k_new [nq, Hkv*D], v_new [nq, Hkv*D]) fp16 CUDA tensors at FIXED addresses (the
         model writes this step's projections there); outputs are in `self.out[layer]` ([nq, Hq*D]).
 
@@ -47,7 +148,10 @@ class DecodeSession:
         eagerly: it follows an upload).  1 = at the second step, the round-3 behaviour: a capture costs ~0.65 ms of host time and
         a replayed step ~0.07 ms against ~0.55 ms for an eager one, so it pays from the third step of an epoch on.  "auto": 1,
         unless the LAST epoch ended within three steps -- trees that change shape every step or two (a controller that prunes after
-        every token) then stay eager instead of paying a capture per step, and go back to capturing as soon as an epoch lasts."""
+        every token) then stay eager instead of paying a capture per step, and go back to capturing as soon as an epoch lasts.
+
+        `incremental`: window plans (module docstring).  `win_tiles`: overflow tiles per query chunk (None: enough for ~16 steps of
+        nq tokens, between 2 and 8)."""
         pool = tree.token_to_kv_pool
         assert pool.device.type == "cuda" and mode in ("flatten", "node")
         assert head_dim == 128 or (head_dim == 64 and num_kv_heads % 2 == 0), "DecodeSession: head_dim 128, or 64 with an even number of KV heads"
@@ -56,14 +160,16 @@ class DecodeSession:
         self._epoch_steps = 0       # steps of the current epoch so far (its eager first one included)
         self._last_epoch_steps = 1 << 30
         self.mode = mode
+        self.incremental, self.win_tiles_arg = bool(incremental), win_tiles
         # (the device WITH its index: torch.device("cuda") != torch.device("cuda:0"), and the page-table fold below compares devices --
         #  round 3: with the default "cuda" pool the fold never happened and every step carried an index_put)
         self.tree, self.pool, self.device = tree, pool, pool._storage.device
         self.Hq, self.Hkv, self.D, self.layers = num_heads, num_kv_heads, head_dim, layers
         self.qkv, self.max_q_len, self.use_graph = qkv, max_q_len, use_graph
-        self.graph: Optional[torch.cuda.CUDAGraph] = None
+        self.graphs: Dict[str, Optional[torch.cuda.CUDAGraph]] = {}
         self.graph_epoch = -1
         self.captures = 0
+        self.step_kinds = {"upload": 0, "legacy": 0, "replan": 0, "patch": 0}  # what the steps so far ran (tests, tools/replay.py)
         # the stream captures run on, made AND first used here: a HIP stream is created lazily at its first use, 5.6 ms that would
         # otherwise land in the first captured step
         self._side: Optional[torch.cuda.Stream] = torch.cuda.Stream(device=self.device)
@@ -71,6 +177,11 @@ class DecodeSession:
         self.out: List[torch.Tensor] = []
         self._pin: list = []  # pinned staging buffers in rotation: [buffer, event of its last upload]
         self._pin_k = -1
+        self.win: Optional[_Window] = None
+
+    @property
+    def graph(self):  # (round-5 name: the epoch's captured step, whichever form)
+        return self.graphs.get("legacy") or self.graphs.get("patch") or self.graphs.get("replan")
 
     # ---- per epoch ----------------------------------------------------------------------------------------
     def _epoch_setup(self) -> bool:
@@ -86,52 +197,105 @@ class DecodeSession:
         uploaded = dt.sync()
         self.dt = dt
         self.nq = dt.nq
-        self.NB, self.P = dt.cap_lens["block_lens"], dt.cap_lens["block_q"]
+        Hq, Hkv, D = self.Hq, self.Hkv, self.D
+        nqm = max(self.nq, 1)
+        # ---- window plan: overflow tiles per query chunk, and the room they need in the metadata arrays ------------------------
+        chunks = (nqm + self.max_q_len - 1) // self.max_q_len
+        W = 0
+        if self.incremental and self.nq > 0 and block_len == _TILE and int(lib.deft_window_supported(self.nq, self.max_q_len, Hq, Hkv)):
+            W = int(self.win_tiles_arg) if self.win_tiles_arg else min(8, max(2, (16 * self.nq + _TILE - 1) // _TILE))
+            if W * _TILE < 2 * self.nq:  # (a window must hold at least two steps' tokens)
+                W = 0
+        self.W, self.chunks = W, chunks
+        caps = dict(dt.cap_lens)
+        if W:
+            if self.mode == "flatten":
+                for k in ("block_lens", "block_q_cnts", "block_q_offset"):
+                    caps[k] += chunks * W
+                caps["block_q"] += W * self.nq
+                for k in ("block_kv", "block_bitmasks"):
+                    caps[k] += chunks * W * _TILE
+            else:
+                for k in ("node_q_len", "node_kv_len", "node_q_offset", "node_kv_offset"):
+                    caps[k] += chunks
+                caps["node_q"] += self.nq
+                caps["node_kv"] += chunks * W * _TILE
+        # (the session's own arrays: dt.out belongs to TreeMetadata.from_tree_cache's device builder)
+        self.md_out = torch.empty(sum(caps.values()) + 1, dtype=torch.int64, device=dev)
+        self.md_caps = caps
+        self.NB, self.P = caps["block_lens"], caps["block_q"]
         off, self.md_ptrs = 0, {}
         for k in _FIELDS:
-            self.md_ptrs[k] = dt.out.data_ptr() + 8 * off
-            off += dt.cap_lens[k]
-        Hq, Hkv, D = self.Hq, self.Hkv, self.D
+            self.md_ptrs[k] = self.md_out.data_ptr() + 8 * off
+            off += caps[k]
         if self.mode == "flatten":
             self.plan_bytes = int(lib.deft_flatten_plan_bytes(self.NB, self.P, Hq, Hkv))
             self.ws_bytes = int(lib.deft_flatten_workspace_bytes(self.NB, self.P, self.nq, Hq, Hkv, D))
         else:  # Node arrays: capacities of node_q_len (entries), node_q (pairs), node_kv (slots, repeated per query chunk)
-            self.NE, self.PN, self.TKV = dt.cap_lens["node_q_len"], dt.cap_lens["node_q"], dt.cap_lens["node_kv"]
+            self.NE, self.PN, self.TKV = caps["node_q_len"], caps["node_q"], caps["node_kv"]
             self.plan_bytes = int(lib.deft_node_plan_bytes(self.NE, self.PN, self.TKV, Hq, Hkv))
             self.ws_bytes = int(lib.deft_node_workspace_bytes(self.NE, self.PN, self.TKV, self.nq, Hq, Hkv, D))
         self.plan = torch.empty(max(self.plan_bytes, 1), dtype=torch.uint8, device=dev)
         self.ws = torch.empty(max(self.ws_bytes, 1), dtype=torch.uint8, device=dev)
         # what the host supplies per step, in ONE allocation (one upload):
-        # [cache_loc int32[nq] | page-table coordinates int64[2][nq] | journal of absorbed changes int32 {words, ...}]
-        nqm = max(self.nq, 1)
+        # [cache_loc int32[nq] | page-table coordinates int64[2][nq] | journal of absorbed changes int32 {words, ...} |
+        #  window plan: patch list int32 {entries, active tiles, {position, node, slot} ...}]
         cb = (4 * nqm + 255) // 256 * 256
         self.ops_cap = 64 + 8 * nqm  # one EXTEND of up to nq slots and a RESET per leaf, with room to spare (a speculative-decoding step)
         ob = cb + 16 * nqm
-        self._small = torch.zeros(ob + 4 * (self.ops_cap + 1), dtype=torch.uint8, device=dev)
+        pb = (ob + 4 * (self.ops_cap + 1) + 255) // 256 * 256
+        self.patch_cap = (4 * nqm + self.ops_cap + 64) if W else 0
+        self._small = torch.zeros(pb + 4 * (2 + 3 * self.patch_cap), dtype=torch.uint8, device=dev)
         self.cache_loc = self._small[: 4 * nqm].view(torch.int32)
         self.idx = self._small[cb:ob].view(torch.int64).view(2, nqm)
-        self.ops = self._small[ob:].view(torch.int32)
-        self._ops_off = ob
+        self.ops = self._small[ob:pb].view(torch.int32)
+        self.patch = self._small[pb:].view(torch.int32)
+        self._ops_off, self._patch_off = ob, pb
+        self.win_tab = torch.zeros(max(chunks, 1) * _WIN_PASSES * 2, dtype=torch.int32, device=dev)
+        self.win = _Window(self.nq, W, dt.h_leaf, self.patch_cap) if W else None
         self.out = [torch.empty((self.nq, Hq * D), dtype=torch.float16, device=dev) for _ in range(self.layers)]
         order = sorted(tree.leaves)
         self.leaf_handles = [tree.leaves[i] for i in order]
         self.leaf_reqs = np.asarray([tree.leaf_to_req[i] for i in order], dtype=np.int64)
         self._journal = np.zeros(self.ops_cap, dtype=np.int32)
-        self.graph, self.graph_epoch = None, dt.epoch
+        self.graphs, self.graph_epoch = {}, dt.epoch
         return uploaded
 
-    def _launch_step(self, advance: bool = True) -> None:
-        """The device side of one decode step; identical arguments on every step of the epoch.  `advance=False`: the first
-        step of an epoch when the tree was uploaded just now -- the image already holds this step's slots."""
-        dt, dev = self.dt, self.device
-        stream = torch.cuda.current_stream(dev).cuda_stream
+    def _fold(self, advance: bool) -> bool:
+        """Are the page-table entries of this step's tokens written by the step's first kernel?  (When the table is what the kernel
+        expects -- int32, contiguous rows, on this device; by an index_put otherwise.)"""
         table = self.tree.req_to_token_pool.req_to_token
-        # (page-table entries of this step's tokens: written by the step's first kernel when the table is what the kernel
-        #  expects -- int32, contiguous rows, on this device --, by an index_put otherwise)
-        fold = advance and table.dtype == torch.int32 and table.device == dev and table.dim() == 2 and table.stride(1) == 1
+        fold = advance and table.dtype == torch.int32 and table.device == self.device and table.dim() == 2 and table.stride(1) == 1
         self.page_table_folded = fold  # (tests: the fold must really happen for the pools this package makes)
         if not fold:
             table[self.idx[0], self.idx[1]] = self.cache_loc
+        return fold
+
+    def _launch_layers(self) -> None:
+        Hq, Hkv, D = self.Hq, self.Hkv, self.D
+        kv0 = self.pool.kv_data[0]
+        v_off = kv0.stride(1) * 2
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        if self.mode == "flatten":
+            mdl = [self.md_ptrs[k] for k in ("block_q", "block_q_cnts", "block_q_offset", "block_bitmasks", "block_kv", "block_lens")]
+            fn, tail = lib.deft_flatten_decode_append_f16, (self.NB, self.P, self.nq, Hq, Hkv, D, 1.0 / (D ** 0.5))
+        else:
+            mdl = [self.md_ptrs[k] for k in ("node_kv", "node_kv_offset", "node_kv_len", "node_q", "node_q_offset", "node_q_len")]
+            fn, tail = lib.deft_node_decode_append_f16, (self.NE, self.PN, self.TKV, self.nq, Hq, Hkv, D, 1.0 / (D ** 0.5))
+        for l in range(self.layers):
+            q, k, v = self.qkv(l)
+            kptr = self.pool.kv_data[l].data_ptr()
+            check(fn(q.data_ptr(), q.stride(0), D, kptr, kptr + v_off, kv0.stride(0), kv0.stride(2), self.out[l].data_ptr(), Hq * D, D,
+                     *mdl, *tail, self.cache_loc.data_ptr(), k.data_ptr(), v.data_ptr(), k.stride(0), self.nq, self.plan.data_ptr(),
+                     self.ws.data_ptr(), self.ws_bytes, stream), "decode layer")
+
+    def _launch_step(self, advance: bool = True) -> None:
+        """The device side of one LEGACY decode step (everything rebuilt); identical arguments on every step of the epoch.
+        `advance=False`: the first step of an epoch when the tree was uploaded just now -- the image already holds this step's slots."""
+        dt, dev = self.dt, self.device
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        table = self.tree.req_to_token_pool.req_to_token
+        fold = self._fold(advance)
         mq, bl, mbl = dt.cfg
         # (the append of this step's slots to the device tree rides in the first metadata kernel)
         # (only the six arrays this mode's operator reads are written: the kernel of the other group is not launched)
@@ -146,25 +310,51 @@ class DecodeSession:
         Hq, Hkv, D = self.Hq, self.Hkv, self.D
         q0, k0, _ = self.qkv(0)
         kv0 = self.pool.kv_data[0]
-        v_off = kv0.stride(1) * 2
         if self.mode == "flatten":
             mdl = [self.md_ptrs[k] for k in ("block_q", "block_q_cnts", "block_q_offset", "block_bitmasks", "block_kv", "block_lens")]
             check(lib.deft_flatten_build_plan_dims(*mdl, self.NB, self.P, dt.scratch.data_ptr(), Hq, Hkv, q0.stride(0), D,
                                                    kv0.stride(0), self.cache_loc.data_ptr(), self.nq, k0.stride(0),
                                                    self.plan.data_ptr(), self.plan_bytes, stream), "deft_flatten_build_plan_dims")
-            fn, tail = lib.deft_flatten_decode_append_f16, (self.NB, self.P, self.nq, Hq, Hkv, D, 1.0 / (D ** 0.5))
         else:
             mdl = [self.md_ptrs[k] for k in ("node_kv", "node_kv_offset", "node_kv_len", "node_q", "node_q_offset", "node_q_len")]
             check(lib.deft_node_build_plan_dims(*mdl, self.NE, self.PN, self.TKV, dt.scratch.data_ptr(), Hq, Hkv, q0.stride(0), D,
                                                 kv0.stride(0), self.cache_loc.data_ptr(), self.nq, k0.stride(0),
                                                 self.plan.data_ptr(), self.plan_bytes, stream), "deft_node_build_plan_dims")
-            fn, tail = lib.deft_node_decode_append_f16, (self.NE, self.PN, self.TKV, self.nq, Hq, Hkv, D, 1.0 / (D ** 0.5))
-        for l in range(self.layers):
-            q, k, v = self.qkv(l)
-            kptr = self.pool.kv_data[l].data_ptr()
-            check(fn(q.data_ptr(), q.stride(0), D, kptr, kptr + v_off, kv0.stride(0), kv0.stride(2), self.out[l].data_ptr(), Hq * D, D,
-                     *mdl, *tail, self.cache_loc.data_ptr(), k.data_ptr(), v.data_ptr(), k.stride(0), self.nq, self.plan.data_ptr(),
-                     self.ws.data_ptr(), self.ws_bytes, stream), "decode layer")
+        self._launch_layers()
+
+    def _launch_window_step(self, replan: bool) -> None:
+        """The device side of a window-plan step (csrc/window.h).  REPLAN: metadata and plan of the tree as it stands before this
+        step's tokens (the scan kernel replays the journal, appends nothing), overflow tiles appended; then -- PATCH steps: only --
+        one kernel that advances the device tree and applies the host's patch list; then the layers."""
+        dt, dev = self.dt, self.device
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        table = self.tree.req_to_token_pool.req_to_token
+        fold = self._fold(True)
+        mq, bl, mbl = dt.cfg
+        Hq, Hkv, D = self.Hq, self.Hkv, self.D
+        q0, k0, _ = self.qkv(0)
+        kv0 = self.pool.kv_data[0]
+        if replan:
+            wanted = _FIELDS[6:] if self.mode == "flatten" else _FIELDS[:6]
+            check(lib.deft_tree_dev_build_md_ops(*dt._tree_args(), mq, bl, mbl, dt.nbp_cap, dt.scratch.data_ptr(), dt.scratch_bytes,
+                                                 *[self.md_ptrs[k] if k in wanted else None for k in _FIELDS],
+                                                 None, self.ops.data_ptr(), None, 0, None, None, stream), "deft_tree_dev_build_md_ops")
+            if self.mode == "flatten":
+                mdl = [self.md_ptrs[k] for k in ("block_q", "block_q_cnts", "block_q_offset", "block_bitmasks", "block_kv", "block_lens")]
+                check(lib.deft_flatten_build_plan_window(*mdl, self.NB, self.P, dt.scratch.data_ptr(), self.nq, mq, self.W,
+                                                         self.win_tab.data_ptr(), Hq, Hkv, q0.stride(0), D, kv0.stride(0),
+                                                         self.plan.data_ptr(), self.plan_bytes, stream), "deft_flatten_build_plan_window")
+            else:
+                mdl = [self.md_ptrs[k] for k in ("node_kv", "node_kv_offset", "node_kv_len", "node_q", "node_q_offset", "node_q_len")]
+                check(lib.deft_node_build_plan_window(*mdl, self.NE, self.PN, self.TKV, dt.scratch.data_ptr(), self.nq, mq, self.W,
+                                                      self.win_tab.data_ptr(), Hq, Hkv, q0.stride(0), D, kv0.stride(0),
+                                                      self.plan.data_ptr(), self.plan_bytes, stream), "deft_node_build_plan_window")
+        check(lib.deft_window_patch(*dt._tree_args(), None if replan else self.ops.data_ptr(), self.cache_loc.data_ptr(),
+                                    table.data_ptr() if fold else None, table.stride(0) if fold else 0,
+                                    self.idx[0].data_ptr() if fold else None, self.idx[1].data_ptr() if fold else None,
+                                    self.patch.data_ptr(), self.win_tab.data_ptr(), self.plan.data_ptr(), mq, self.W, Hq, Hkv,
+                                    kv0.stride(0), k0.stride(0), dt.scratch.data_ptr(), stream), "deft_window_patch")
+        self._launch_layers()
 
     # ---- per step ------------------------------------------------------------------------------------------
     def step(self) -> List[torch.Tensor]:
@@ -194,49 +384,80 @@ class DecodeSession:
                 jn = max(int(lib.deft_tree_journal_take(tree._native, _ptr(self._journal), self.ops_cap)), 0)
                 if tree._epoch() != self.graph_epoch:  # too long: that call started another epoch
                     uploaded, jn = self._epoch_setup(), 0
-            self._write_staging(loc, jn)
-            self._launch_step(advance=not uploaded)
+            self._write_staging(loc, jn, None)
+            self._launch_step(advance=not uploaded)  # (a legacy step: the next one starts the epoch's first window)
+            self._moved()
+            self.step_kinds["upload"] += 1
             return self.out
-        self._write_staging(loc, jn)
+        # ---- which form this step takes ------------------------------------------------------------------------------
+        kind, ent = "legacy", None
+        if self.win is not None:
+            journal = self._journal[:jn]
+            if self.dt.version == self._dt_version:  # (nobody else has moved the device copy since this session's last step)
+                ent = self.win.step(journal, loc)
+                kind = "patch"
+            if ent is None:
+                ent = self.win.begin(journal, loc)
+                kind = "replan" if ent is not None else "legacy"
+        self._write_staging(loc, jn, ent)
         self._epoch_steps += 1
-        if self.graph is None:
+        self.step_kinds[kind] += 1
+        launch = self._launch_step if kind == "legacy" else (lambda: self._launch_window_step(kind == "replan"))
+        if self.graphs.get(kind) is None:
             wait = (1 if self._last_epoch_steps > 3 else 4) if self.capture_after == "auto" else int(self.capture_after)
             if not self.use_graph or self._epoch_steps <= wait:  # (this is step `_epoch_steps` of the epoch; `wait` of them run eagerly)
-                self._launch_step()
+                launch()
+                self._moved()
                 return self.out
-            self._capture()
-        self.graph.replay()
+            self._capture(kind, launch)
+        self.graphs[kind].replay()
+        self._moved()
         return self.out
 
-    def _write_staging(self, loc: np.ndarray, journal_words: int = 0) -> None:
-        """This step's slot numbers and page-table coordinates: pinned staging -> the fixed device tensors the graph reads, in
-        one copy.  Four pinned buffers in rotation, each guarded by the event of its last upload (a pageable source would make
-        the copy wait for the stream to drain -- the host would run in lock-step with the GPU)."""
+    def _moved(self) -> None:
+        """This session's launches have advanced the device copy of the tree."""
+        self.dt.version += 1
+        self._dt_version = self.dt.version
+
+    def _write_staging(self, loc: np.ndarray, journal_words: int = 0, ent: Optional[Dict[int, tuple]] = None) -> None:
+        """This step's slot numbers, page-table coordinates, journal and patch list: pinned staging -> the fixed device tensors the
+        graph reads, in one copy.  Four pinned buffers in rotation, each guarded by the event of its last upload (a pageable source
+        would make the copy wait for the stream to drain -- the host would run in lock-step with the GPU)."""
         n, nb = self.nq, self._small.numel()
         self._pin_k = (self._pin_k + 1) % 4
         while len(self._pin) <= self._pin_k:
             self._pin.append(None)
-        ent = self._pin[self._pin_k]
-        if ent is None or ent[0].numel() != nb:
-            ent = self._pin[self._pin_k] = [torch.zeros(nb, dtype=torch.uint8).pin_memory(), None]
-        if ent[1] is not None:
-            ent[1].synchronize()
-        h = ent[0].numpy()
+        slot = self._pin[self._pin_k]
+        if slot is None or slot[0].numel() != nb:
+            slot = self._pin[self._pin_k] = [torch.zeros(nb, dtype=torch.uint8).pin_memory(), None]
+        if slot[1] is not None:
+            slot[1].synchronize()
+        h = slot[0].numpy()
         nqm = max(n, 1)
         h[: 4 * n].view(np.int32)[:] = loc
         idx_h = h[self._ops_off - 16 * nqm : self._ops_off].view(np.int64).reshape(2, nqm)
         idx_h[0, :n] = self.leaf_reqs
         idx_h[1, :n] = [lf.positions[-1] for lf in self.leaf_handles]
-        ops_h = h[self._ops_off :].view(np.int32)
+        ops_h = h[self._ops_off : self._patch_off].view(np.int32)
         ops_h[0] = journal_words
         if journal_words:
             ops_h[1 : 1 + journal_words] = self._journal[:journal_words]
-        self._small.copy_(ent[0], non_blocking=True)
-        if ent[1] is None:
-            ent[1] = torch.cuda.Event()  # (one event per staging buffer, re-recorded: not one hipEventCreate per step)
-        ent[1].record(torch.cuda.current_stream(self.device))
+        used = self._patch_off
+        if ent is not None:
+            ph = h[self._patch_off :].view(np.int32)
+            ne = len(ent)
+            ph[0], ph[1] = ne, self.win.active_tiles
+            if ne:
+                arr = np.fromiter((x for pos, (node, val) in ent.items() for x in (pos, node, val)), dtype=np.int32, count=3 * ne)
+                ph[2 : 2 + 3 * ne] = arr
+            used += 4 * (2 + 3 * ne)
+        # (only what this step wrote crosses PCIe: the journal and patch areas are sized for the worst step)
+        self._small[:used].copy_(slot[0][:used], non_blocking=True)
+        if slot[1] is None:
+            slot[1] = torch.cuda.Event()  # (one event per staging buffer, re-recorded: not one hipEventCreate per step)
+        slot[1].record(torch.cuda.current_stream(self.device))
 
-    def _capture(self) -> None:
+    def _capture(self, kind: str, launch) -> None:
         dev = self.device
         graph = torch.cuda.CUDAGraph()
         # ONE capture stream per session: a new stream's first use costs 5.6 ms (measured round 3: the HIP stream is created
@@ -251,11 +472,11 @@ class DecodeSession:
             # next epoch then comes from hipMalloc again
             graph.capture_begin()
             try:
-                self._launch_step()
+                launch()
             finally:
                 graph.capture_end()
         torch.cuda.current_stream(dev).wait_stream(side)
-        self.graph = graph
+        self.graphs[kind] = graph
         self.captures += 1
 
 

@@ -695,6 +695,8 @@ class _DeviceTree:
         self.tree, self.device = tree, device
         self.cfg = (int(max_q_len), int(block_len), int(max_block_len))
         self.epoch = -1
+        self.version = 0   # bumped by everything that changes the device copy (upload, journal replay, advance): a DecodeSession on a
+                           # window plan re-plans when somebody else moved the copy between two of its steps
         self.stage = None  # pinned staging buffer of the upload image
         self.stage_event = None
 
@@ -718,6 +720,8 @@ class _DeviceTree:
         v_refs = img[n32:words].view(np.uint64)
         check(lib.deft_tree_layout_fetch(t._native, _ptr(v_start), _ptr(v_len), _ptr(v_cap), _ptr(v_refs), _ptr(v_leaf),
                                          _ptr(v_slots)), "deft_tree_layout_fetch")
+        self.h_leaf = v_leaf.copy()  # query row -> DFS index of its leaf (fixed for the epoch; DecodeSession's window bookkeeping)
+        self.version += 1
         dev = self.stage[:words].to(self.device, non_blocking=True)
         self.stage_event = torch.cuda.Event()
         self.stage_event.record(torch.cuda.current_stream(self.device))
@@ -769,6 +773,7 @@ class _DeviceTree:
         ops = torch.from_numpy(buf[: nw + 1]).to(self.device)
         stream = torch.cuda.current_stream(self.device).cuda_stream
         check(lib.deft_tree_dev_apply_ops(*self._tree_args(), ops.data_ptr(), self.scratch.data_ptr(), stream), "deft_tree_dev_apply_ops")
+        self.version += 1
         return nw
 
     def _tree_args(self):
@@ -778,6 +783,7 @@ class _DeviceTree:
         stream = torch.cuda.current_stream(self.device).cuda_stream
         check(lib.deft_tree_dev_advance(*self._tree_args(), cache_loc.data_ptr(), self.scratch.data_ptr(), stream),
               "deft_tree_dev_advance")
+        self.version += 1
 
     def build(self) -> Dict[str, object]:
         """Launch the metadata kernels; returns device tensors (views of the epoch's buffers) shaped by sizes the

@@ -458,6 +458,37 @@ int deft_tree_dev_build_md_ops(int n_nodes, int nq, int nqw, const int32_t* node
                                int32_t* page_table /* nullable */, int64_t page_stride, const int64_t* page_rows,
                                const int64_t* page_cols, void* stream);
 
+/* Window plans: the INCREMENTAL per-step head of a captured decode loop (deft_amd.DecodeSession; deft_amd/csrc/window.h).
+ * Replaces, for most steps of a structural epoch, what the reference rebuilds whole on every decode step --
+ * TreeMetadata.from_tree_cache, DeFT/deft/tree_decoding/tree_cache.py:619-881, timed at tree_generate.py:123-131.
+ *   deft_window_supported            1 iff steps of this shape can run on a window plan
+ *   deft_flatten_build_plan_window   a REPLAN step's plan: the device-built block arrays (deft_tree_dev_build_md_ops WITHOUT the
+ *                                    step's advance: the tree as it stands before the step's tokens) get `win_tiles` overflow blocks
+ *                                    per chunk of max_q_len query rows appended (NB, P = capacities INCLUDING them; dims[5..7] are
+ *                                    raised, dims[10] / dims[11] keep the counts in front of them), then units, records, row lists.
+ *                                    `win_tab` (int32 [chunks][16][2], device) receives {leader record, first follower record} of
+ *                                    every overflow run
+ *   deft_node_build_plan_window      the same for the node arrays: one overflow entry of win_tiles * 128 slots per query chunk
+ *   deft_window_patch                EVERY step of a window, replan steps included (ONE workgroup): journal replay (`ops`, nullable:
+ *                                    a replan step's scan already did), page-table write, the step's slots appended to the device
+ *                                    tree, and the host's patch list applied to the plan: int32 {entries, active overflow tiles,
+ *                                    {overflow position, DFS node | -1 = clear, pool slot | -1 - new row} ...}; the row mask of an
+ *                                    entry is its node's leaf set, in every (chunk, pass) record that hosts the position */
+int deft_window_supported(int nq, int max_q_len, int Hq, int Hkv);
+int deft_flatten_build_plan_window(int64_t* block_q, int64_t* block_q_cnts, int64_t* block_q_offset, int64_t* block_bitmasks,
+                                   int64_t* block_kv, int64_t* block_lens, int NB, int P, int32_t* dims, int nq, int max_q_len,
+                                   int win_tiles, int32_t* win_tab, int Hq, int Hkv, int64_t q_stride_tok, int64_t q_stride_head,
+                                   int64_t kv_stride_slot, void* plan, size_t plan_bytes, void* stream);
+int deft_node_build_plan_window(int64_t* node_kv, int64_t* node_kv_offset, int64_t* node_kv_len, int64_t* node_q,
+                                int64_t* node_q_offset, int64_t* node_q_len, int NE, int P, int64_t total_kv, int32_t* dims, int nq,
+                                int max_q_len, int win_tiles, int32_t* win_tab, int Hq, int Hkv, int64_t q_stride_tok,
+                                int64_t q_stride_head, int64_t kv_stride_slot, void* plan, size_t plan_bytes, void* stream);
+int deft_window_patch(int n_nodes, int nq, int nqw, const int32_t* node_start, int32_t* node_len, const int32_t* node_cap,
+                      const uint64_t* refs, const int32_t* leaf_node, int32_t* slots, const int32_t* ops /* nullable */,
+                      const int32_t* cache_loc, int32_t* page_table /* nullable */, int64_t page_stride, const int64_t* page_rows,
+                      const int64_t* page_cols, const int32_t* patch, const int32_t* win_tab, void* plan, int max_q_len,
+                      int win_tiles, int Hq, int Hkv, int64_t kv_stride_slot, int64_t new_stride_tok, void* scratch, void* stream);
+
 #if defined(__GNUC__) || defined(__clang__)
 #pragma GCC visibility pop
 #endif

@@ -141,8 +141,9 @@ def test_replay_attention_matches_truth_every_step(task, mode, session):
     rep = r.run(tpl, task, prompt_len=200, max_gen_len=12)
     assert seen["steps"] == rep.steps > 3 and rep.attention_ms > 0
     if session and task == "speculative_decoding":
-        # epochs: the branch into leaves; the first merge into a root without room.  Not one per step.
-        assert r.graph_captures <= 2 and rep.steps >= 8
+        # epochs: the branch into leaves; the first merge into a root without room.  Not one per step (window plans: a replan graph
+        # and a patch graph per epoch).
+        assert r.graph_captures <= 4 and rep.steps >= 8
 
 
 @pytest.mark.gpu

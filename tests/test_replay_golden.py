@@ -288,11 +288,11 @@ def _session_arrays(sess, fields):
     lens = _lens_from_sizes(sizes)
     torch.cuda.synchronize()
     out, off = {}, 0
-    host = dt.out.cpu().numpy()
+    host = sess.md_out.cpu().numpy()  # (the session's own arrays; dt.out belongs to TreeMetadata.from_tree_cache's device builder)
     for k in _FIELDS:
         if k in fields:
             out[k] = host[off : off + lens[k]].copy()
-        off += dt.cap_lens[k]
+        off += sess.md_caps[k]
     return out
 
 
@@ -305,7 +305,9 @@ def test_session_reproduces_the_reference_loop_step_for_step(name, mode):
     tpl = _template(name, g)
     fields = ARRAYS[6:] if mode == "flatten" else ARRAYS[:6]
     chk = _Checker(g, fields, "digest_block" if mode == "flatten" else "digest_node")
-    r = rp.TemplateReplay(2, 1, 128, layers=1, mode=mode, device="cuda", attention=True, session=True)
+    # (incremental=False: the twelve arrays are rebuilt on EVERY step, which is what this test reads; window plans rebuild them once
+    #  per window -- their outputs are checked against fp64 attention by tests/test_fuzz_slices.py and tests/test_session.py)
+    r = rp.TemplateReplay(2, 1, 128, layers=1, mode=mode, device="cuda", attention=True, session=True, incremental=False)
     assert r.session
 
     def hook(it, tree, cache_loc, md, sess):
