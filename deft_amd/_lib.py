@@ -152,6 +152,9 @@ _TREE_FUNCS = {
     "deft_tree_dev_apply_ops": ([C.c_int, C.c_int, C.c_int] + [_vp] * 6 + [_vp, _vp, _vp], C.c_int),
     "deft_tree_journal_take": ([_i64, _vp, _i64], _i64),
     "deft_window_supported": ([C.c_int] * 4, C.c_int),
+    "deft_window_create": ([C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int], _i64),
+    "deft_window_free": ([_i64], C.c_int),
+    "deft_window_step": ([_i64, C.c_int, _vp, _i64, _vp, _vp, _i64], _i64),
     "deft_flatten_build_plan_window": ([_vp] * 6 + [C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _i64, _i64, _i64,
                                         _vp, _sz, _vp], C.c_int),
     "deft_node_build_plan_window": ([_vp] * 6 + [C.c_int, C.c_int, _i64, _vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _i64, _i64,

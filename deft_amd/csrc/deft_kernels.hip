@@ -691,10 +691,6 @@ static int launch_plan(const Stage1Params& p, int NB, const PlanView& pv, const 
     if (par && g_plan_runcap > 0) run_cap = std::max(1, std::min((int)run_cap, g_plan_runcap));  // tests: force the fallback
     if (!par)
         while (sizeof(int) * (blk + 3 * (size_t)run_cap + 8) > UNIT_LDS && run_cap > 0) run_cap /= 2;
-    if (win_tiles > 0 && (!par || run_cap < pv.cap)) {  // (an overflow run must be seen as ONE chunk: the LDS run table says so)
-        set_error("window plan: %lld units exceed the unit kernel's run table", (long long)pv.cap);
-        return DEFT_EUNSUPPORTED;
-    }
     const size_t lds = sizeof(int) * (blk + (par ? 7 : 3) * (size_t)run_cap + 8);
     const UnitList ul = unit_list(pv);
     hipLaunchKernelGGL(flatten_units_kernel, dim3(1), dim3(1024), lds, stream, p.block_q, p.block_q_cnts, p.block_q_offset, NB,
@@ -1262,10 +1258,6 @@ static int launch_node_plan(const Stage1Params& p, int NE, int64_t rows_cap, con
     if (par && g_plan_runcap > 0) run_cap = std::max(1, std::min((int)run_cap, g_plan_runcap));  // tests: force the fallback
     if (!par)
         while (sizeof(int) * (3 * (size_t)run_cap + 8) > UNIT_LDS && run_cap > 1) run_cap /= 2;
-    if (win_tiles > 0 && (!par || run_cap < pv.cap)) {  // (launch_plan: an overflow run must be seen as ONE chunk)
-        set_error("window plan: %lld units exceed the unit kernel's run table", (long long)pv.cap);
-        return DEFT_EUNSUPPORTED;
-    }
     hipLaunchKernelGGL(node_units_kernel, dim3(1), dim3(1024), sizeof(int) * ((par ? 10 : 3) * (size_t)run_cap + 8), stream,
                        p.node_kv_len, p.node_q_len, p.node_q, p.node_q_offset, NE, p.G, (int)pv.cap, rows_cap, ul, pv.hdr, pv.row_q,
                        plan_items_per_leader(p),

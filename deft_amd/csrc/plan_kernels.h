@@ -118,7 +118,7 @@ __device__ inline void np_record_order(const UnitList& ul, int R, int Hkv, int G
                 const int id = ul.flags[r] >> 1;
                 int e = r + 1;
                 while (e < R && (ul.flags[e] >> 1) == id) ++e;
-                fn(r, e - r, ul.aux[r] != 0 ? 1 : 0);  // (union group, or -1: a window plan's overflow run; a Node pack (< 0) is one unit anyway)
+                fn(r, e - r, (ul.aux[r] != 0 || (ul.pass[r] >> 16)) ? 1 : 0);  // (union group; a window plan's overflow run: Flatten aux -1, Node bit 16 of pass; a Node pack (< 0) is one unit anyway)
                 r = e;
             }
         }
@@ -190,12 +190,12 @@ __device__ inline void np_record_order(const UnitList& ul, int R, int Hkv, int G
     for_runs([&](int, int nt, int uni) {
         const int S = uni ? 1 : (nt + C - 1) / C;
         NL += S;
-        if (!uni && nt / S >= LONG_CHUNK) NLong += S;
+        if ((!uni || uni == -1) && nt / S >= LONG_CHUNK) NLong += S;  // (-1: a window plan's overflow run -- one chunk of up to nt tiles, dispatched early)
     });
     int liL = 0, liS = NLong, fi = NL;
     for_runs([&](int r, int nt, int uni) {
         const int S = uni ? 1 : (nt + C - 1) / C;  // a union group is one chunk
-        int& li = (!uni && nt / S >= LONG_CHUNK) ? liL : liS;
+        int& li = ((!uni || uni == -1) && nt / S >= LONG_CHUNK) ? liL : liS;
         for (int p = 0; p < S; ++p) {
             const int cnt = (nt - p + S - 1) / S;
             ul.perm[li] = r + p;
@@ -268,7 +268,7 @@ __device__ inline void record_order_wave0(const RunTable& rt, int NR, int* rT0, 
             const int k = base + lane;
             const int nt = k < NR ? rt.nt[k] : 0;
             const int S = k < NR ? (rt.uni[k] ? 1 : (nt + C - 1) / C) : 0;
-            const bool lng = k < NR && !rt.uni[k] && S > 0 && nt / S >= LONG_CHUNK;
+            const bool lng = k < NR && (!rt.uni[k] || rt.uni[k] == -1) && S > 0 && nt / S >= LONG_CHUNK;  // (-1: an overflow run of a window plan)
             int aL = lng ? S : 0, aS = lng ? 0 : S, b = nt - S;  // inclusive scans over the lanes
             for (int d = 1; d < 64; d <<= 1) {
                 const int uL = __shfl_up(aL, d, 64), uS = __shfl_up(aS, d, 64), ub = __shfl_up(b, d, 64);
@@ -882,7 +882,7 @@ __global__ __launch_bounds__(1024) void node_units_kernel(const int64_t* node_kv
                     for (int j = 0; j < n; ++j) {
                         ul.src[first + j] = aux == 2 ? e + j : e;
                         ul.aux[first + j] = aux == 2 ? 0 : (aux > 0 ? j : aux);
-                        ul.pass[first + j] = ps;
+                        ul.pass[first + j] = ps | (uni ? 1 << 16 : 0);  // (bit 16: an overflow run of a window plan -- one chunk)
                         ul.flags[first + j] = (first << 1) | (j == 0 ? 1 : 0);
                         ul.prow[first + j] = prow0 + j * ql;
                     }
@@ -990,10 +990,11 @@ __global__ __launch_bounds__(1024) void node_units_kernel(const int64_t* node_kv
     if (np && wave == 0) record_order_wave0(rt, NR, rLead, rFoll, sMeta, hdr, Hkv, G, slots, chunk_c);
     for (int k = np ? wave - 1 : wave; k < NR && k >= 0; k += np ? nwaves - 1 : nwaves) {
         const int first = rt.r0[k], n = rt.nt[k], e = rT0[k], ps = rSp[k], prow0 = rProw[k], ql = rQl[k], aux = rAux[k];
+        const int ovf = rt.uni[k] ? 1 << 16 : 0;
         for (int j = lane; j < n; j += 64) {
             ul.src[first + j] = aux == 2 ? e + j : e;
             ul.aux[first + j] = aux == 2 ? 0 : (aux > 0 ? j : aux);
-            ul.pass[first + j] = ps;
+            ul.pass[first + j] = ps | ovf;
             ul.flags[first + j] = (first << 1) | (j == 0 ? 1 : 0);
             ul.prow[first + j] = prow0 + j * ql;
         }
@@ -1045,7 +1046,7 @@ __global__ __launch_bounds__(128) void node_records_kernel(const int64_t* node_k
         desc[4] = np ? ul.ch_n[r] : 0;
         desc[5] = np ? ul.ch_fb[r] : 0;
     }
-    const int e0 = ul.src[u], aux = ul.aux[u], ps = ul.pass[u], prow = ul.prow[u];
+    const int e0 = ul.src[u], aux = ul.aux[u], ps = ul.pass[u] & 0xffff, prow = ul.prow[u];  // (bit 16 of pass: node_units_kernel)
     if (aux < 0) {
         // ---- packed unit: entries e0 .. e0 - aux - 1, each one tile and one pass -------------------------
         const int cnt = -aux;

@@ -12,11 +12,13 @@
 //     max_q_len)), `win_tiles` OVERFLOW tiles: blocks (Flatten) or one entry (Node) whose query list is rows [c * max_q_len, ...),
 //     all masks zero.  The unit kernels keep an overflow run in ONE chunk (leader + followers, its own partial rows);
 //   * every step -- the replan step included -- then runs window_patch_kernel, ONE workgroup: the journal replay and the advance
-//     of the device tree (what tree_md_scan_kernel did), the page-table write, and a PATCH LIST the host made: {overflow position,
-//     node, slot | new row}.  A token appended to leaf r lands at an overflow position with the mask "query r only" -- computed
-//     from the node's leaf set, so a slot merged into an inner node (speculative decoding's accepted tokens) gets that node's
-//     queries -- in every record (chunk c, 32-row pass) that hosts the position; a RESET clears its node's positions, which the
-//     node's next tokens reuse.  The leaders' tile count grows as tiles fill: a dormant tile costs nothing.
+//     of the device tree (what tree_md_scan_kernel did), the page-table write, and a PATCH LIST the host made: {overflow region and
+//     position, node, slot | new row}.  Every (chunk c, 32-row pass) pair is a REGION with overflow tiles of its own; a token
+//     appended to leaf r lands in the one region that holds query r's rows, with the mask "query r only" -- computed from the
+//     node's leaf set, so a slot merged into an inner node (speculative decoding's accepted tokens) gets that node's queries, in
+//     every region that has one of them (with GQA a tile shared by all passes would be folded G times; a region's tile is folded
+//     once, like a leaf tile of the exact plan); a RESET clears its node's positions, which the node's next tokens reuse.  The
+//     leaders' tile count grows as tiles fill: a dormant tile costs nothing.
 //   * when the overflow is full (or something happens the window cannot express) the host replays the REPLAN graph instead of the
 //     PATCH graph.  deft_amd/session.py keeps the books; the device side below is deliberately dumb.
 //
@@ -110,10 +112,13 @@ __global__ __launch_bounds__(256) void window_entries_kernel(TreeMdOut o, int32_
     }
 }
 
+constexpr int WIN_REGIONS = 64;  // hosting records -- (query chunk, 32-row pass) pairs -- a window plan's tables have room for
+
 struct WindowPatch {
     const int32_t* ops;        // journal {words, ...} to replay on the device tree first, or null (a replan step: the scan did)
     const int32_t* cache_loc;  // this step's slots: appended to the leaves of the device tree
-    const int32_t* patch;      // {entries, active overflow tiles, {position, node | -1 = clear, slot | -1 - new row} ...}
+    const int32_t* patch;      // {entries, active overflow tiles of region 0 .. 63, {region << 20 | position, node | -1 = clear,
+                               //  slot | -1 - new row} ...} (window_host.cpp)
     const int32_t* tab;        // [chunk][WIN_PASSES][2]: leader record, first follower record (the record kernels write it)
     char* records;             // plan records
     int32_t* err;              // dims + TREE_ERR
@@ -122,21 +127,22 @@ struct WindowPatch {
     int64_t new_row_bytes;
 };
 
-// ONE workgroup of 1024 threads per decode step.
+// ONE workgroup of 1024 threads per decode step.  Region h of the overflow = the h-th hosting record, chunk by chunk, pass by pass
+// (window_host.cpp hands out positions per region: a leaf's token lands in the ONE region that holds its query's rows).
 __global__ __launch_bounds__(1024) void window_patch_kernel(TreeDev t, WindowPatch w, PageWrite pw) {
     __shared__ int sNew[TREE_OPS_NEW], sPos[TREE_OPS_NEW], sMeta[4], sOps[TREE_OPS_LDS];
-    __shared__ int sHost[64 * 2];  // hosting records: (chunk, pass) pairs
+    __shared__ int sHost[WIN_REGIONS * 2];  // hosting records: (chunk, pass) pairs
     __shared__ int sNH;
     const int tid = threadIdx.x;
     // the patch list's loads first: they depend on nothing
-    const int n_ent = w.patch[0], n_act = w.patch[1];
+    const int n_ent = w.patch[0];
     const int chunks = (t.nq + w.max_q_len - 1) / w.max_q_len;
     if (tid == 0) {
         int nh = 0;
         for (int c = 0; c < chunks; ++c) {
             const int cnt = min(w.max_q_len, t.nq - c * w.max_q_len);
             const int pc = (cnt * w.G + MQ - 1) / MQ;
-            for (int ps = 0; ps < pc && ps < WIN_PASSES && nh < 64; ++ps, ++nh) {
+            for (int ps = 0; ps < pc && ps < WIN_PASSES && nh < WIN_REGIONS; ++ps, ++nh) {
                 sHost[2 * nh] = c;
                 sHost[2 * nh + 1] = ps;
             }
@@ -168,17 +174,18 @@ __global__ __launch_bounds__(1024) void window_patch_kernel(TreeDev t, WindowPat
         t.node_len[i] = len + 1;
     }
     __syncthreads();
-    // ---- the plan: every entry into every record that hosts its position -----------------------------------------------
+    // ---- the plan: one thread per entry ------------------------------------------------------------------------------------
     const int NH = sNH;
-    for (int x = tid; x < n_ent * NH; x += 1024) {
-        const int e = x / NH, hi = x - e * NH;
-        const int c = sHost[2 * hi], ps = sHost[2 * hi + 1];
-        const int pos = w.patch[2 + 3 * e], node = w.patch[3 + 3 * e], val = w.patch[4 + 3 * e];
+    const int32_t* ent = w.patch + 1 + WIN_REGIONS;
+    for (int e = tid; e < n_ent; e += 1024) {
+        const int key = ent[3 * e], node = ent[3 * e + 1], val = ent[3 * e + 2];
+        const int hi = key >> 20, pos = key & 0xfffff;
         const int j = pos >> 7, k = pos & (TILE - 1);
-        if (j >= w.win_tiles || pos < 0) {
+        if (hi < 0 || hi >= NH || j >= w.win_tiles) {
             atomicOr(w.err, WIN_ERR);
             continue;
         }
+        const int c = sHost[2 * hi], ps = sHost[2 * hi + 1];
         const int32_t* tb = w.tab + (c * WIN_PASSES + ps) * 2;
         const int rec = j == 0 ? tb[0] : tb[1] + j - 1;
         char* rp = w.records + (int64_t)rec * PLAN_BYTES;
@@ -200,7 +207,7 @@ __global__ __launch_bounds__(1024) void window_patch_kernel(TreeDev t, WindowPat
     // the leaders' tile count: tiles that hold nothing yet are not visited (the leader's own tile always is)
     for (int hi = tid; hi < NH; hi += 1024) {
         const int32_t* tb = w.tab + (sHost[2 * hi] * WIN_PASSES + sHost[2 * hi + 1]) * 2;
-        reinterpret_cast<int32_t*>(w.records + (int64_t)tb[0] * PLAN_BYTES + PLAN_DESC)[4] = max(1, min(n_act, w.win_tiles));
+        reinterpret_cast<int32_t*>(w.records + (int64_t)tb[0] * PLAN_BYTES + PLAN_DESC)[4] = max(1, min(w.patch[1 + hi], w.win_tiles));
     }
 }
 

@@ -196,14 +196,14 @@ class TemplateReplay:
 
     def __init__(self, num_heads: int, num_kv_heads: int, head_dim: int, layers: int, mode: str = "flatten",
                  device: str = "cuda", attention: bool = True, seed: int = 0, vocab: int = 4096, session: Optional[bool] = None,
-                 capture_after="auto", incremental: bool = True) -> None:
+                 capture_after="auto", incremental: bool = True, win_tiles: Optional[int] = None) -> None:
         """`session`: drive the attention path through `deft_amd.DecodeSession` -- the whole decode step (tree advance,
         TreeMetadata, plan, every layer's append + attention) as ONE captured hipGraph per structural epoch of the tree -- instead
         of the reference-shaped eager calls (`tree.alloc()`, `TreeMetadata.from_tree_cache`, `DeFTAttention.forward` per layer).
         None = wherever a session exists (DeFT-Flatten / DeFT-Node, head_dim 128 or 64 as head pairs, attention on).
         `capture_after`: DecodeSession's -- how many steps of an epoch run eagerly before its step is captured.
         `incremental`: DecodeSession's -- window plans (most steps patch the plan instead of rebuilding metadata and plan)."""
-        self.capture_after, self.incremental = capture_after, incremental
+        self.capture_after, self.incremental, self.win_tiles = capture_after, incremental, win_tiles
         self.Hq, self.Hkv, self.D, self.layers = num_heads, num_kv_heads, head_dim, layers
         self.mode = mode
         # (node / node_chunk set BLOCK_CONFIG["MAX_BLOCK_LEN"] as the CLI does -- a process-wide setting.  The replay keeps ITS value
@@ -303,7 +303,7 @@ class TemplateReplay:
             sess = DecodeSession(tree, self.Hq, self.Hkv, self.D, self.layers,
                                  lambda l: (q_all[l, : nq_now[0]], k_all[l, : nq_now[0]], v_all[l, : nq_now[0]]),
                                  mode="node" if self.mode == "node_chunk" else self.mode,
-                                 capture_after=self.capture_after, incremental=self.incremental)
+                                 capture_after=self.capture_after, incremental=self.incremental, win_tiles=self.win_tiles)
             sizes = np.zeros(9, dtype=np.int64)
         t_wall = time.perf_counter()
         tree.init_prompt(torch.arange(1, prompt_len + 1, dtype=torch.int32))
@@ -419,4 +419,5 @@ class TemplateReplay:
         rep.generated_tokens = tree.get_tree_token_number() - prompt_len
         self.tree, self.pool, self.req = tree, pool, req  # left for inspection by tests
         self.graph_captures = sess.captures if sess is not None else None
+        self.step_kinds = dict(sess.step_kinds) if sess is not None else None  # (DecodeSession: upload / legacy / replan / patch steps)
         return rep

@@ -33,104 +33,13 @@ from typing import Callable, Dict, List, Optional
 import numpy as np
 import torch
 
-from ._lib import DeftLibraryError, check, lib
+from ._lib import check, lib
 from .tree_cache import BLOCK_CONFIG, TreeCache, _DeviceTree, _FIELDS, _ptr
 
 __all__ = ["DecodeSession", "FlattenDecodeSession"]
 
 _TILE = 128
 _WIN_PASSES = 16  # (plan_records.h WIN_PASSES: the overflow table's passes per query chunk)
-
-
-class _Window:
-    """Host-side books of one window plan (csrc/window.h): which overflow position holds which node's slot.
-
-    Positions are handed out in order; a node that was RESET keeps its positions and its next tokens reuse them (a
-    speculative-decoding leaf is reset and refilled every step).  `begin()` starts a window on a REPLAN step, `step()` continues it
-    on a PATCH step or says that it cannot (None): the overflow is full, or a node was reset whose slots the static part of the
-    plan still holds.  Both return the patch list of the step: {position: (node | -1, slot | -1 - new row)}."""
-
-    def __init__(self, nq: int, tiles: int, leaf_node: np.ndarray, max_entries: int) -> None:
-        self.nq, self.cap, self.leaf_node, self.max_entries = nq, tiles * _TILE, leaf_node, max_entries
-        self.valid = False
-        self.fill = 0
-        self.own: Dict[int, List[int]] = {}   # node -> overflow positions it has been given, in order
-        self.live: Dict[int, int] = {}        # node -> how many of them hold a slot
-        self.clean: set = set()               # nodes whose every slot is in the overflow (none in the static part of the plan)
-        self.prev_new: List[tuple] = []       # (position, node, slot) of the rows the LAST step read from k_new / v_new
-
-    def _place(self, node: int) -> int:
-        own = self.own.setdefault(node, [])
-        n = self.live.get(node, 0)
-        if n < len(own):
-            pos = own[n]
-        else:
-            if self.fill >= self.cap:
-                return -1
-            pos = self.fill
-            self.fill += 1
-            own.append(pos)
-        self.live[node] = n + 1
-        return pos
-
-    def _apply(self, ent: Dict[int, tuple], journal: np.ndarray, loc: np.ndarray, replan: bool) -> Optional[Dict[int, tuple]]:
-        at, nw = 0, len(journal)
-        while at + 2 < nw:
-            op, node, k = int(journal[at]), int(journal[at + 1]), int(journal[at + 2])
-            if op == 2:  # RESET: the node's slots are dropped
-                if replan:  # (the scan kernel replays the journal BEFORE the plan is made: the static part never sees these slots)
-                    self.clean.add(node)
-                else:
-                    if node not in self.clean:
-                        return None
-                    for pos in self.own.get(node, [])[: self.live.get(node, 0)]:
-                        ent[pos] = (-1, 0)
-                    self.live[node] = 0
-                at += 3
-            elif op == 1:  # EXTEND: k slots join the node
-                if replan:
-                    self.clean.discard(node)  # (they are in the static part)
-                else:
-                    for s in journal[at + 3 : at + 3 + k]:
-                        pos = self._place(node)
-                        if pos < 0:
-                            return None
-                        ent[pos] = (node, int(s))
-                at += 3 + k
-            else:
-                return None
-        new = []
-        for r in range(self.nq):
-            node = int(self.leaf_node[r])
-            pos = self._place(node)
-            if pos < 0:
-                return None
-            ent[pos] = (node, -1 - r)
-            new.append((pos, node, int(loc[r])))
-        if len(ent) > self.max_entries:
-            return None
-        self.prev_new = new
-        return ent
-
-    def begin(self, journal: np.ndarray, loc: np.ndarray) -> Optional[Dict[int, tuple]]:
-        self.fill, self.own, self.live, self.clean, self.prev_new = 0, {}, {}, set(), []
-        ent = self._apply({}, journal, loc, True)
-        self.valid = ent is not None
-        return ent
-
-    def step(self, journal: np.ndarray, loc: np.ndarray) -> Optional[Dict[int, tuple]]:
-        if not self.valid:
-            return None
-        # the rows the last step read from k_new / v_new are in the pool now: their positions get the pool offsets
-        ent = {pos: (node, slot) for pos, node, slot in self.prev_new}
-        ent = self._apply(ent, journal, loc, False)
-        if ent is None:
-            self.valid = False  # (the books are half-updated: the replan step starts from scratch)
-        return ent
-
-    @property
-    def active_tiles(self) -> int:
-        return (self.fill + _TILE - 1) // _TILE
 
 
 class DecodeSession:
@@ -177,7 +86,14 @@ class DecodeSession:
         self.out: List[torch.Tensor] = []
         self._pin: list = []  # pinned staging buffers in rotation: [buffer, event of its last upload]
         self._pin_k = -1
-        self.win: Optional[_Window] = None
+        self.win = 0  # native books of the epoch's window plans (deft_window_create), 0 = none
+
+    def __del__(self) -> None:
+        try:
+            if self.win:
+                lib.deft_window_free(self.win)
+        except Exception:
+            pass
 
     @property
     def graph(self):  # (round-5 name: the epoch's captured step, whichever form)
@@ -202,9 +118,17 @@ class DecodeSession:
         # ---- window plan: overflow tiles per query chunk, and the room they need in the metadata arrays ------------------------
         chunks = (nqm + self.max_q_len - 1) // self.max_q_len
         W = 0
+        G = Hq // Hkv
+        # (a REGION of the overflow = one (query chunk, 32-row pass) pair; it takes the tokens of the queries whose rows it holds)
+        regions = sum((min(self.max_q_len, nqm - c * self.max_q_len) * G + 31) // 32 for c in range(chunks))
+        per_region = min(nqm, self.max_q_len, (32 + G - 1) // G)  # queries (= tokens per step) of a full region
         if self.incremental and self.nq > 0 and block_len == _TILE and int(lib.deft_window_supported(self.nq, self.max_q_len, Hq, Hkv)):
-            W = int(self.win_tiles_arg) if self.win_tiles_arg else min(8, max(2, (16 * self.nq + _TILE - 1) // _TILE))
-            if W * _TILE < 2 * self.nq:  # (a window must hold at least two steps' tokens)
+            # default: room for ~16 steps, at most 4 tiles.  A replan costs what EVERY step used to cost (~58 us), but an overflow
+            # run is ONE chunk -- a serial chain of up to W tiles inside every layer's launch: measured (tools/replay.py --win-tiles,
+            # profiles/r6_window_tiles.txt, us per step against the legacy loop) few-shot 4k x 32 on Llama-2-7B -52 / -55 at 4 / 8
+            # tiles, the same tree on Llama-3-8B (a region holds 8 queries) -34 at 1 tile, +24 at 4, +94 at 8 (its chunks are 4 tiles)
+            W = int(self.win_tiles_arg) if self.win_tiles_arg else min(4, max(1, (16 * per_region + _TILE - 1) // _TILE))
+            if W * _TILE < 2 * per_region:  # (a window must hold at least two steps' tokens)
                 W = 0
         self.W, self.chunks = W, chunks
         caps = dict(dt.cap_lens)
@@ -244,15 +168,22 @@ class DecodeSession:
         self.ops_cap = 64 + 8 * nqm  # one EXTEND of up to nq slots and a RESET per leaf, with room to spare (a speculative-decoding step)
         ob = cb + 16 * nqm
         pb = (ob + 4 * (self.ops_cap + 1) + 255) // 256 * 256
-        self.patch_cap = (4 * nqm + self.ops_cap + 64) if W else 0
-        self._small = torch.zeros(pb + 4 * (2 + 3 * self.patch_cap), dtype=torch.uint8, device=dev)
+        self.patch_cap = (4 * nqm + 64 + 2 * nqm * regions) if W else 0  # (a slot merged into the root is an entry in every region)
+        self._small = torch.zeros(pb + 4 * (1 + 64 + 3 * self.patch_cap), dtype=torch.uint8, device=dev)
         self.cache_loc = self._small[: 4 * nqm].view(torch.int32)
         self.idx = self._small[cb:ob].view(torch.int64).view(2, nqm)
         self.ops = self._small[ob:pb].view(torch.int32)
         self.patch = self._small[pb:].view(torch.int32)
         self._ops_off, self._patch_off = ob, pb
         self.win_tab = torch.zeros(max(chunks, 1) * _WIN_PASSES * 2, dtype=torch.int32, device=dev)
-        self.win = _Window(self.nq, W, dt.h_leaf, self.patch_cap) if W else None
+        if self.win:
+            lib.deft_window_free(self.win)
+        self.win = 0
+        if W:
+            self.win = int(lib.deft_window_create(dt.n, self.nq, dt.nqw, W, _ptr(dt.h_leaf), _ptr(dt.h_refs), self.max_q_len, Hq // Hkv,
+                                                  self.patch_cap))
+            if self.win < 0:
+                check(self.win, "deft_window_create")
         self.out = [torch.empty((self.nq, Hq * D), dtype=torch.float16, device=dev) for _ in range(self.layers)]
         order = sorted(tree.leaves)
         self.leaf_handles = [tree.leaves[i] for i in order]
@@ -384,22 +315,13 @@ class DecodeSession:
                 jn = max(int(lib.deft_tree_journal_take(tree._native, _ptr(self._journal), self.ops_cap)), 0)
                 if tree._epoch() != self.graph_epoch:  # too long: that call started another epoch
                     uploaded, jn = self._epoch_setup(), 0
-            self._write_staging(loc, jn, None)
+            self._stage(loc, jn, False)
             self._launch_step(advance=not uploaded)  # (a legacy step: the next one starts the epoch's first window)
             self._moved()
             self.step_kinds["upload"] += 1
             return self.out
-        # ---- which form this step takes ------------------------------------------------------------------------------
-        kind, ent = "legacy", None
-        if self.win is not None:
-            journal = self._journal[:jn]
-            if self.dt.version == self._dt_version:  # (nobody else has moved the device copy since this session's last step)
-                ent = self.win.step(journal, loc)
-                kind = "patch"
-            if ent is None:
-                ent = self.win.begin(journal, loc)
-                kind = "replan" if ent is not None else "legacy"
-        self._write_staging(loc, jn, ent)
+        # ---- which form this step takes: the books decide while the staging buffer is written --------------------------------
+        kind = self._stage(loc, jn, bool(self.win))
         self._epoch_steps += 1
         self.step_kinds[kind] += 1
         launch = self._launch_step if kind == "legacy" else (lambda: self._launch_window_step(kind == "replan"))
@@ -419,10 +341,11 @@ class DecodeSession:
         self.dt.version += 1
         self._dt_version = self.dt.version
 
-    def _write_staging(self, loc: np.ndarray, journal_words: int = 0, ent: Optional[Dict[int, tuple]] = None) -> None:
-        """This step's slot numbers, page-table coordinates, journal and patch list: pinned staging -> the fixed device tensors the
-        graph reads, in one copy.  Four pinned buffers in rotation, each guarded by the event of its last upload (a pageable source
-        would make the copy wait for the stream to drain -- the host would run in lock-step with the GPU)."""
+    def _stage(self, loc: np.ndarray, journal_words: int, window: bool) -> str:
+        """This step's slot numbers, page-table coordinates, journal and -- window plans -- patch list: pinned staging -> the fixed
+        device tensors the graph reads, in one copy.  Four pinned buffers in rotation, each guarded by the event of its last upload
+        (a pageable source would make the copy wait for the stream to drain -- the host would run in lock-step with the GPU).
+        Returns the form the step takes: "patch" (the window goes on), "replan" (a new window starts) or "legacy"."""
         n, nb = self.nq, self._small.numel()
         self._pin_k = (self._pin_k + 1) % 4
         while len(self._pin) <= self._pin_k:
@@ -434,7 +357,8 @@ class DecodeSession:
             slot[1].synchronize()
         h = slot[0].numpy()
         nqm = max(n, 1)
-        h[: 4 * n].view(np.int32)[:] = loc
+        loc32 = h[: 4 * n].view(np.int32)
+        loc32[:] = loc
         idx_h = h[self._ops_off - 16 * nqm : self._ops_off].view(np.int64).reshape(2, nqm)
         idx_h[0, :n] = self.leaf_reqs
         idx_h[1, :n] = [lf.positions[-1] for lf in self.leaf_handles]
@@ -442,20 +366,29 @@ class DecodeSession:
         ops_h[0] = journal_words
         if journal_words:
             ops_h[1 : 1 + journal_words] = self._journal[:journal_words]
-        used = self._patch_off
-        if ent is not None:
+        kind, used = "legacy", self._patch_off
+        if window:
             ph = h[self._patch_off :].view(np.int32)
-            ne = len(ent)
-            ph[0], ph[1] = ne, self.win.active_tiles
-            if ne:
-                arr = np.fromiter((x for pos, (node, val) in ent.items() for x in (pos, node, val)), dtype=np.int32, count=3 * ne)
-                ph[2 : 2 + 3 * ne] = arr
-            used += 4 * (2 + 3 * ne)
+            words = -1
+            # (nobody else has moved the device copy since this session's last step?  Otherwise the plan's static part is stale: replan)
+            if self.dt.version == self._dt_version:
+                words = int(lib.deft_window_step(self.win, 0, _ptr(self._journal), journal_words, _ptr(loc32), _ptr(ph), ph.size))
+                kind = "patch"
+            if words < 0:
+                words = int(lib.deft_window_step(self.win, 1, _ptr(self._journal), journal_words, _ptr(loc32), _ptr(ph), ph.size))
+                kind = "replan"
+            if words < -1:
+                check(words, "deft_window_step")
+            if words < 0:
+                kind = "legacy"
+            else:
+                used += 4 * words
         # (only what this step wrote crosses PCIe: the journal and patch areas are sized for the worst step)
         self._small[:used].copy_(slot[0][:used], non_blocking=True)
         if slot[1] is None:
             slot[1] = torch.cuda.Event()  # (one event per staging buffer, re-recorded: not one hipEventCreate per step)
         slot[1].record(torch.cuda.current_stream(self.device))
+        return kind
 
     def _capture(self, kind: str, launch) -> None:
         dev = self.device

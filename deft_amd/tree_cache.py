@@ -721,6 +721,7 @@ class _DeviceTree:
         check(lib.deft_tree_layout_fetch(t._native, _ptr(v_start), _ptr(v_len), _ptr(v_cap), _ptr(v_refs), _ptr(v_leaf),
                                          _ptr(v_slots)), "deft_tree_layout_fetch")
         self.h_leaf = v_leaf.copy()  # query row -> DFS index of its leaf (fixed for the epoch; DecodeSession's window bookkeeping)
+        self.h_refs = v_refs.copy()  # ... and the nodes' leaf sets
         self.version += 1
         dev = self.stage[:words].to(self.device, non_blocking=True)
         self.stage_event = torch.cuda.Event()

@@ -471,9 +471,9 @@ int deft_tree_dev_build_md_ops(int n_nodes, int nq, int nqw, const int32_t* node
  *   deft_node_build_plan_window      the same for the node arrays: one overflow entry of win_tiles * 128 slots per query chunk
  *   deft_window_patch                EVERY step of a window, replan steps included (ONE workgroup): journal replay (`ops`, nullable:
  *                                    a replan step's scan already did), page-table write, the step's slots appended to the device
- *                                    tree, and the host's patch list applied to the plan: int32 {entries, active overflow tiles,
- *                                    {overflow position, DFS node | -1 = clear, pool slot | -1 - new row} ...}; the row mask of an
- *                                    entry is its node's leaf set, in every (chunk, pass) record that hosts the position */
+ *                                    tree, and the host's patch list applied to the plan: int32 {entries, active overflow tiles of
+ *                                    regions 0 .. 63, {region << 20 | position, DFS node | -1 = clear, pool slot | -1 - new row} ...}
+ *                                    (deft_window_step writes it); the row mask of an entry is its node's leaf set within the region */
 int deft_window_supported(int nq, int max_q_len, int Hq, int Hkv);
 int deft_flatten_build_plan_window(int64_t* block_q, int64_t* block_q_cnts, int64_t* block_q_offset, int64_t* block_bitmasks,
                                    int64_t* block_kv, int64_t* block_lens, int NB, int P, int32_t* dims, int nq, int max_q_len,
@@ -488,6 +488,21 @@ int deft_window_patch(int n_nodes, int nq, int nqw, const int32_t* node_start, i
                       const int32_t* cache_loc, int32_t* page_table /* nullable */, int64_t page_stride, const int64_t* page_rows,
                       const int64_t* page_cols, const int32_t* patch, const int32_t* win_tab, void* plan, int max_q_len,
                       int win_tiles, int Hq, int Hkv, int64_t kv_stride_slot, int64_t new_stride_tok, void* scratch, void* stream);
+
+/* The host-side books of a window plan: which overflow position holds which node's slot (deft_amd/csrc/window_host.cpp).
+ *   deft_window_create   books for one structural epoch: `leaf_node[r]` = DFS index of query row r's leaf, `refs` = the nodes' leaf sets
+ *                        (both as deft_tree_layout_fetch returns them), `group` = Hq / Hkv, `tiles` overflow tiles per region -- a
+ *                        region = one (chunk of max_q_len query rows, 32-row pass) pair --, at most `max_entries` patch entries per
+ *                        step; returns a handle (< 0: error)
+ *   deft_window_step     one decode step: the journal deft_tree_journal_take handed over and the step's nq slots -> the step's patch
+ *                        list in `out` (what deft_window_patch reads); returns the int32 words written, or -1: the window cannot
+ *                        express this step (replan = 0: run a replan step and call again with replan = 1; replan = 1: run the step
+ *                        without a window) */
+int64_t deft_window_create(int n_nodes, int nq, int nqw, int tiles, const int32_t* leaf_node, const uint64_t* refs, int max_q_len,
+                           int group, int max_entries);
+int deft_window_free(int64_t window);
+int64_t deft_window_step(int64_t window, int replan, const int32_t* journal, int64_t journal_words, const int32_t* loc, int32_t* out,
+                         int64_t out_cap);
 
 #if defined(__GNUC__) || defined(__clang__)
 #pragma GCC visibility pop

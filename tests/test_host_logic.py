@@ -482,3 +482,72 @@ def test_finished_branches_are_recorded_and_printed(capsys):
     tree.print_finished_branches(Tok())
     out = capsys.readouterr().out
     assert "Total number of generated branches=2" in out and "Generated Text: 11 12" in out and "Token length : 1" in out
+
+
+def test_window_books_patch_lists():
+    """The host-side books of a window plan (deft_amd/csrc/window_host.cpp; deft_amd.DecodeSession's incremental steps): overflow
+    positions are handed out in order per REGION (one per (query chunk, 32-row pass) pair), the rows a step read from k_new / v_new
+    get their pool slot on the NEXT step, a RESET node keeps its positions and refills them, a RESET of a node the static plan
+    still holds -- and a full region -- ask for a replan."""
+    import ctypes as C
+
+    from deft_amd._lib import lib
+
+    ptr = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    leaf = np.asarray([1, 2, 3], dtype=np.int32)
+    refs = np.asarray([0b111, 0b001, 0b010, 0b100], dtype=np.uint64)  # root above all three leaves
+
+    def make(group, max_q_len=32):
+        w = int(lib.deft_window_create(4, 3, 1, 1, ptr(leaf), ptr(refs), max_q_len, group, 64))
+        assert w > 0
+        return w
+
+    out = np.zeros(1 + 64 + 3 * 64, dtype=np.int32)
+    none = np.zeros(1, dtype=np.int32)
+
+    def step(w, replan, journal, loc):
+        j = np.asarray(journal, dtype=np.int32) if len(journal) else none
+        n = int(lib.deft_window_step(w, replan, ptr(j), len(journal), ptr(np.asarray(loc, dtype=np.int32)), ptr(out), out.size))
+        if n < 0:
+            return None
+        assert n == 65 + 3 * out[0]
+        return [int(x) for x in out[1:65] if x], {(int(k) >> 20, int(k) & 0xfffff): (int(a), int(b)) for k, a, b in out[65:n].reshape(-1, 3)}
+
+    w = make(1)  # MHA, three queries: one chunk, one pass, one region
+    assert step(w, 0, [], [10, 11, 12]) is None  # no window yet
+    assert step(w, 1, [], [10, 11, 12]) == ([1], {(0, 0): (1, -1), (0, 1): (2, -2), (0, 2): (3, -3)})
+    # the next step: last step's rows are pool rows now, this step's go behind them
+    assert step(w, 0, [], [13, 14, 15])[1] == {(0, 0): (1, 10), (0, 1): (2, 11), (0, 2): (3, 12), (0, 3): (1, -1), (0, 4): (2, -2), (0, 5): (3, -3)}
+    # a RESET of a leaf whose first tokens sit in the static part of the plan cannot be patched
+    assert step(w, 0, [2, 1, 0], [16, 17, 18]) is None
+    assert step(w, 0, [], [16, 17, 18]) is None  # ... and the books stay invalid until a replan
+    # a speculative-decoding loop: the replan step's journal resets every leaf (they are "clean" from now on) ...
+    assert step(w, 1, [1, 0, 1, 15, 2, 1, 0, 2, 2, 0, 2, 3, 0], [20, 21, 22])[1] == {(0, 0): (1, -1), (0, 1): (2, -2), (0, 2): (3, -3)}
+    # ... and every later step merges a slot into the root (node 0: a new position, the root's rows), drops the leaves' slots and
+    # refills the SAME positions
+    assert step(w, 0, [1, 0, 1, 20, 2, 1, 0, 2, 2, 0, 2, 3, 0], [23, 24, 25])[1] == {(0, 3): (0, 20), (0, 0): (1, -1), (0, 1): (2, -2), (0, 2): (3, -3)}
+    assert step(w, 0, [1, 0, 2, 23, 24, 2, 1, 0, 2, 2, 0, 2, 3, 0], [26, 27, 28])[1] == {(0, 4): (0, 23), (0, 5): (0, 24), (0, 0): (1, -1), (0, 1): (2, -2),
+                                                                                       (0, 2): (3, -3)}
+    # without resets the region fills up: 128 positions
+    fill, steps = 6, 0
+    while True:
+        r = step(w, 0, [1, 0, 3, 1, 2, 3], [30, 31, 32])  # three more slots into the root per step, the leaves keep growing
+        if r is None:
+            break
+        fill += 6
+        steps += 1
+        assert r[0] == [(fill + 127) // 128]
+    assert steps == (128 - 6) // 6 and fill <= 128
+    assert step(w, 1, [], [40, 41, 42])[1] == {(0, 0): (1, -1), (0, 1): (2, -2), (0, 2): (3, -3)}  # the replan starts afresh
+    assert lib.deft_window_free(w) == 0 and lib.deft_window_free(w) != 0
+    # GQA, 16 query heads per KV head: two queries to a 32-row pass -- queries 0, 1 in region 0, query 2 in region 1; a leaf's token
+    # goes to ITS region only, a slot merged into the root to both
+    w = make(16)
+    assert step(w, 1, [], [10, 11, 12]) == ([1, 1], {(0, 0): (1, -1), (0, 1): (2, -2), (1, 0): (3, -3)})
+    assert step(w, 0, [1, 0, 1, 99], [13, 14, 15])[1] == {(0, 0): (1, 10), (0, 1): (2, 11), (1, 0): (3, 12), (0, 2): (0, 99), (1, 1): (0, 99),
+                                                          (0, 3): (1, -1), (0, 4): (2, -2), (1, 2): (3, -3)}
+    lib.deft_window_free(w)
+    # one query per chunk (max_q_len = 1): three chunks, three regions
+    w = make(1, max_q_len=1)
+    assert step(w, 1, [], [10, 11, 12]) == ([1, 1, 1], {(0, 0): (1, -1), (1, 0): (2, -2), (2, 0): (3, -3)})
+    lib.deft_window_free(w)

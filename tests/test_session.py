@@ -12,12 +12,13 @@ pytestmark = pytest.mark.gpu
 def _agree(out, ref, incremental, tag=None):
     """Legacy steps (incremental=False) are the eager path bit for bit.  A window-plan step (csrc/window.h) folds the SAME keys in
     another partition -- the step's tokens sit in overflow tiles -- so it differs in the order of fp32 additions: held to the
-    operator's tolerance against the eager result (1e-3, plus half an fp16 step of the value)."""
+    operator's tolerance against the eager result: 1e-3, plus ONE fp16 step of the value (two correctly rounded fp16 results of
+    nearly equal sums may land on neighbouring grid points; tools/fuzz_session.py found exactly that on an output of magnitude 4)."""
     if not incremental:
         assert torch.equal(out, ref), tag
         return
     err = (out.float() - ref.float()).abs()
-    tol = 1e-3 + ref.float().abs() * 2.0 ** -11
+    tol = 1e-3 + ref.float().abs() * 2.0 ** -10
     assert bool((err <= tol).all()), (tag, float(err.max()))
 
 
@@ -77,8 +78,8 @@ def test_session_equals_eager_step_for_step(use_graph, mode, incremental):
     both_steps(140)  # crosses 128-slot block boundaries many times inside one epoch (window plans: several windows)
     per_epoch = 2 if incremental else 1  # (window plans: a replan graph and a patch graph)
     assert sess.captures == (per_epoch if use_graph else 0)
-    if incremental:  # most steps only patched the plan; the overflow (2 tiles, 6 tokens a step) was re-planned every ~42 steps
-        assert sess.step_kinds["patch"] >= 130 and 3 <= sess.step_kinds["replan"] <= 5 and sess.step_kinds["legacy"] == 0, sess.step_kinds
+    if incremental:  # most steps only patched the plan; the overflow (one 128-slot tile, 6 tokens a step) was re-planned every ~21 steps
+        assert sess.step_kinds["patch"] >= 125 and 5 <= sess.step_kinds["replan"] <= 9 and sess.step_kinds["legacy"] == 0, sess.step_kinds
     for tree in (te, ts):  # structural change: cut two leaves, branch one
         lv = sorted(tree.leaves.values(), key=lambda n: n.id)
         tree.cut(lv[1])

@@ -2,7 +2,7 @@
 """Randomised check of the captured decode loop: random multi-level trees (or batches of trees as one tree object), random cuts
 and branches between runs of decode steps; deft_amd.DecodeSession (hipGraphs per structural epoch) against the eager path
 (tree.alloc + TreeMetadata.from_tree_cache + DeFTAttention) at every step: pool bytes and page tables bit for bit; outputs BIT FOR
-BIT for legacy sessions (incremental=False), within 1e-3 + 2^-11 |ref| for window-plan sessions (incremental=True, csrc/window.h:
+BIT for legacy sessions (incremental=False), within 1e-3 + 2^-10 |ref| (one fp16 step of the value: both sides are ROUNDED results) for window-plan sessions (incremental=True, csrc/window.h:
 the same keys in another partition).
    tools/fuzz_session.py [seconds] [seed] [incremental: 0 | 1 | mix (default)]"""
 import os, sys, time, random
@@ -26,7 +26,12 @@ def agree(out, ref, inc, tag):
         return
     err = (out.float() - ref.float()).abs()
     worst = max(worst, float(err.max()) if err.numel() else 0.0)
-    assert bool((err <= 1e-3 + ref.float().abs() * 2.0 ** -11).all()), (tag, float(err.max()))
+    ok = bool((err <= 1e-3 + ref.float().abs() * 2.0 ** -10).all())
+    if not ok and os.environ.get("FUZZ_VERBOSE"):
+        bad = (err > 1e-3 + ref.float().abs() * 2.0 ** -10)
+        rows = bad.view(bad.shape[0], -1).any(dim=1).nonzero().flatten().tolist()
+        print("MISMATCH", tag, "rows", rows, "of", bad.shape[0], "W", sess.W, "kinds", sess.step_kinds, "max err per bad row", [round(float(err[r].max()), 5) for r in rows[:8]], flush=True)
+    assert ok, (tag, float(err.max()))
 
 
 while time.time() < t_end:

@@ -37,6 +37,8 @@ ap.add_argument("--eager", action="store_true", help="the reference-shaped eager
 ap.add_argument("--beam", default=None, metavar="WIDTH,DEPTH,LEN",
                 help="reasoning: the shipped templates' shape instead of the ToT-50 tree -- the kept node branches into WIDTH candidates "
                      "every LEN steps, DEPTH levels (deft_amd.templates.synthetic_beam_template)")
+ap.add_argument("--legacy", action="store_true", help="DecodeSession(incremental=False): metadata and plan rebuilt on every step (the round-5 loop)")
+ap.add_argument("--win-tiles", type=int, default=None, help="DecodeSession(win_tiles=): overflow tiles per query chunk of a window plan")
 ap.add_argument("--capture-after", default="auto", help="DecodeSession(capture_after=): 1, 2, ... or auto")
 ap.add_argument("--out", default=None)
 a = ap.parse_args()
@@ -76,11 +78,11 @@ for idx, mode in enumerate(a_modes):
     tpl = template()
     prompt_len = a.prompt_len or rp.default_prompt_len(tpl, a.task, from_file=bool(a.template or a.golden_template))
     r = rp.TemplateReplay(Hq, Hkv, D, L, mode=mode, device="cuda", attention=True, session=False if a.eager else None,
-                          capture_after=a.capture_after if a.capture_after == "auto" else int(a.capture_after))
+                          capture_after=a.capture_after if a.capture_after == "auto" else int(a.capture_after), incremental=not a.legacy, win_tiles=a.win_tiles)
     rep = r.run(tpl, a.task, prompt_len, a.max_gen_len, max_rows=max(512, a.width, a.tree_size), pipelined=a.pipelined)
     s = rep.summary(); s["model"] = a.model; s["layers"] = L
     s["path"] = "session (one hipGraph per structural epoch)" if r.session else "eager calls"
-    s["graph_captures"] = r.graph_captures; s["pipelined"] = bool(a.pipelined); s["capture_after"] = a.capture_after
+    s["graph_captures"] = r.graph_captures; s["step_kinds"] = getattr(r, "step_kinds", None); s["pipelined"] = bool(a.pipelined); s["capture_after"] = a.capture_after
     s["wall_over_attention"] = round(s["wall_ms"] / max(s["attention_latency_ms"], 1e-9), 3)
     if not a.no_warmup and idx == 0:
         del r
