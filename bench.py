@@ -309,7 +309,7 @@ class Bench:
         pick = lambda f: round(ts[min(len(ts) - 1, int(f * len(ts)))], 1)
         return {"p10_us": pick(0.10), "p50_us": pick(0.50), "p90_us": pick(0.90), "steps": steps}
 
-    def end_to_end(self, steps: int, graphed: bool):
+    def end_to_end(self, steps: int, graphed: bool, incremental: bool = True, win_tiles=None):
         """The decode loop a runner really executes, with the tree ADVANCING: per step every leaf takes a token, the host
         allocator hands out nq slots (the only thing that crosses PCIe), the device copy of the tree is advanced by a
         kernel, TreeMetadata and the per-step plan are built on the GPU, then the 32 attention layers (fused append +
@@ -322,13 +322,16 @@ class Bench:
         mode = deft_amd.forward_mode_from_cli(self.w.mode)
         if graphed:
             sess = deft_amd.FlattenDecodeSession(tree, self.Hq, self.Hkv, self.D, self.layers,
-                                                 lambda l: (self.q[l], self.k_new[l], self.v_new[l]))
+                                                 lambda l: (self.q[l], self.k_new[l], self.v_new[l]), incremental=incremental,
+                                                 win_tiles=win_tiles)
 
             def one():
                 for leaf in tree.leaves.values():
                     leaf.append_token(7)
                 sess.step()
         else:
+            sess = None
+
             def one():
                 for leaf in tree.leaves.values():
                     leaf.append_token(7)
@@ -358,7 +361,11 @@ class Bench:
                 #  step of THAT tree, `frozen_step_at_mean_len` below, not with the headline's shorter one)
                 "mean_branch_len": round(end_len - (steps - 1) / 2.0, 1),
                 "gpu_ms_per_step": round(e0.elapsed_time(e1) / steps, 4), "host_ms_per_step": round(host_s / steps * 1e3, 4),
-                "launch": "one hipGraph per structural epoch of the tree (deft_amd.FlattenDecodeSession)" if graphed
+                **({"step_kinds": dict(sess.step_kinds), "graph_captures": sess.captures} if sess is not None else {}),
+                "launch": ("hipGraphs per structural epoch of the tree (deft_amd.FlattenDecodeSession): window plans -- one patch kernel "
+                           "in front of most steps' layers, metadata + plan rebuilt once per window" if incremental else
+                           "one hipGraph per structural epoch of the tree (deft_amd.FlattenDecodeSession(incremental=False): metadata + "
+                           "plan rebuilt on every step, the round-5 loop)") if graphed
                           else "eager (tree.alloc, TreeMetadata.from_tree_cache, DeFTAttention.forward per layer)"}
 
 
@@ -595,6 +602,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 FETCH_SIZE child pass")
     ap.add_argument("--no-e2e", action="store_true", help="skip the advancing-tree end-to-end loop")
+    ap.add_argument("--win-tiles", type=int, default=None, help="end-to-end loop: DecodeSession(win_tiles=), overflow tiles per region of a window plan")
     ap.add_argument("--no-cfg5", action="store_true", help="skip the sharded-forest (BASELINE configs[4]) measurement")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
     ap.add_argument("--step-only", action="store_true",
@@ -711,12 +719,12 @@ def main():
         e2e = {"what": "the decode loop with the tree ADVANCING (one token per leaf and step, from the benchmarked tree on): "
                        "host slot allocation + nq slot numbers over PCIe + device tree advance + TreeMetadata and plan built on the "
                        "GPU + 32 x (fused append, stage 1, merge); wall clock over the loop, no host sync inside"}
-        for key, graphed in (("graphed", True), ("eager", False)):
+        for key, graphed, inc in (("graphed", True, True), ("graphed_rebuild_every_step", True, False), ("eager", False, False)):
             try:  # each on a fresh tree (the loop grows it)
                 torch.cuda.empty_cache()
                 be = Bench(w, layers, device, seed=7)
                 be.prepare(use_graph=False)
-                e2e[key] = be.end_to_end(min(50, max(10, args.steps // 4)), graphed)
+                e2e[key] = be.end_to_end(min(50, max(10, args.steps // 4)), graphed, incremental=inc, win_tiles=args.win_tiles)
                 del be
             except Exception as e:
                 e2e[key] = {"error": f"{type(e).__name__}: {e}"}
@@ -731,7 +739,7 @@ def main():
                 dtf = run_timed(bf, nf, 5, False)
                 fz = dtf / nf * 1e3
                 e2e["frozen_step_at_mean_len"] = {"branch_len": int(round(mean_len)), "ms_per_step": round(fz, 4), "steps": nf}
-                for key in ("graphed", "eager"):
+                for key in ("graphed", "graphed_rebuild_every_step", "eager"):
                     if isinstance(e2e.get(key), dict) and "ms_per_step" in e2e[key]:
                         e2e[key]["over_frozen_step_at_mean_len"] = round(e2e[key]["ms_per_step"] / fz, 4)
                 del bf

@@ -2138,7 +2138,8 @@ int deft_window_patch(int n_nodes, int nq, int nqw, const int32_t* node_start, i
                       const uint64_t* refs, const int32_t* leaf_node, int32_t* slots, const int32_t* ops, const int32_t* cache_loc,
                       int32_t* page_table, int64_t page_stride, const int64_t* page_rows, const int64_t* page_cols,
                       const int32_t* patch, const int32_t* win_tab, void* plan, int max_q_len, int win_tiles, int Hq, int Hkv,
-                      int64_t kv_stride_slot, int64_t new_stride_tok, void* scratch, void* stream) {
+                      int64_t kv_stride_slot, int64_t new_stride_tok, void* scratch, const void* fetch_ring, int fetch_slot_bytes,
+                      int fetch_ring_n, void* fetch_dst, int32_t* fetch_counter, void* stream) {
     if (n_nodes <= 0 || nq <= 0 || nqw < 1 || !node_start || !node_len || !node_cap || !refs || !leaf_node || !slots || !cache_loc ||
         !patch || !win_tab || !plan || !scratch || win_tiles < 1 || !deft_window_supported(nq, max_q_len, Hq, Hkv)) {
         set_error("deft_window_patch: bad arguments (nodes=%d nq=%d tiles=%d)", n_nodes, nq, win_tiles);
@@ -2151,9 +2152,27 @@ int deft_window_patch(int n_nodes, int nq, int nqw, const int32_t* node_start, i
     TreeDev t{n_nodes, nq, nqw, node_start, node_len, node_cap, reinterpret_cast<const unsigned long long*>(refs), leaf_node, slots};
     WindowPatch w{ops, cache_loc, patch, win_tab, static_cast<char*>(plan) + PLAN_HDR, static_cast<int32_t*>(scratch) + TREE_ERR,
                   max_q_len, Hq / Hkv, win_tiles, kv_stride_slot, new_stride_tok * 2};
+    if (fetch_ring && (!fetch_dst || !fetch_counter || fetch_slot_bytes < 32 || fetch_slot_bytes % 16 || fetch_ring_n < 1)) {
+        set_error("deft_window_patch: bad fetch arguments");
+        return DEFT_EINVAL;
+    }
     hipLaunchKernelGGL(window_patch_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), t, w,
-                       PageWrite{page_table, page_stride, page_rows, page_cols});
+                       PageWrite{page_table, page_stride, page_rows, page_cols},
+                       StageFetch{static_cast<const char*>(fetch_ring), static_cast<char*>(fetch_dst), fetch_counter, fetch_slot_bytes, fetch_ring_n});
     return check_launch("window patch launch");
+}
+
+/* The step's host-written words fetched from a ring of pinned host slots by a kernel (window.h, StageFetch) -- what a
+ * hipMemcpyAsync in front of the step's graph did, without the idle queue around a stand-alone copy.  Slot k (k = *counter modulo
+ * ring_n, then *counter += 1) = {uint32 used bytes, 12 bytes of padding, payload}: the payload's first `used` bytes go to dst. */
+int deft_stage_fetch(const void* ring, int slot_bytes, int ring_n, void* dst, int32_t* counter, void* stream) {
+    if (!ring || !dst || !counter || slot_bytes < 32 || slot_bytes % 16 || ring_n < 1) {
+        set_error("deft_stage_fetch: bad arguments");
+        return DEFT_EINVAL;
+    }
+    hipLaunchKernelGGL(stage_fetch_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream),
+                       StageFetch{static_cast<const char*>(ring), static_cast<char*>(dst), counter, slot_bytes, ring_n});
+    return check_launch("stage fetch launch");
 }
 
 }  // extern "C"

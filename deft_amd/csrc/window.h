@@ -112,12 +112,47 @@ __global__ __launch_bounds__(256) void window_entries_kernel(TreeMdOut o, int32_
     }
 }
 
+// The step's host-written words -- slot numbers, page-table coordinates, journal, patch list -- FETCHED by the step's first kernel
+// straight from pinned host memory instead of arriving by a copy in front of the graph: between a graph's last kernel and a
+// stand-alone hipMemcpyAsync's blit kernel the queue idled ~20 us, and ~6 more between the blit and the graph's first kernel (kernel
+// + copy trace of an advancing loop, profiles/r6_step_boundary.txt) -- more than the patch kernel itself.  The host writes a RING of
+// slots ({used bytes, 12 bytes of padding, payload}); the kernel's slot is a device-side step counter modulo the ring, so that one
+// captured launch serves every step while the host runs slots ahead (an event per slot keeps it from lapping the GPU).
+struct StageFetch {
+    const char* ring;   // pinned host memory, device-accessible; null = nothing to fetch
+    char* dst;          // the session's device-side staging area (what every later kernel of the step reads)
+    int32_t* counter;   // steps fetched so far
+    int slot_bytes, ring_n;
+};
+
+// whole workgroup; ends with a barrier behind which every thread may read dst
+__device__ inline void stage_fetch(const StageFetch& f) {
+    if (!f.ring) return;
+    const int s = *f.counter;
+    const uintx4* src = reinterpret_cast<const uintx4*>(f.ring + (size_t)(s % f.ring_n) * (size_t)f.slot_bytes);
+    uintx4* dst = reinterpret_cast<uintx4*>(f.dst);
+    const int cap16 = f.slot_bytes / 16 - 1;  // payload chunks the slot can hold
+    // header and first payload chunk of every thread in ONE round trip over PCIe (the chunk speculatively: it is inside the slot)
+    const int tid = threadIdx.x, nth = blockDim.x;
+    const uintx4 hdr = __builtin_nontemporal_load(src);
+    uintx4 v = {0u, 0u, 0u, 0u};
+    if (tid < cap16) v = __builtin_nontemporal_load(src + 1 + tid);
+    const int used16 = min(cap16, (int)((hdr[0] + 15u) / 16u));
+    if (tid < used16) dst[tid] = v;
+    for (int i = tid + nth; i < used16; i += nth) dst[i] = __builtin_nontemporal_load(src + 1 + i);
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) *f.counter = s + 1;
+}
+
+__global__ __launch_bounds__(1024) void stage_fetch_kernel(StageFetch f) { stage_fetch(f); }
+
 constexpr int WIN_REGIONS = 64;  // hosting records -- (query chunk, 32-row pass) pairs -- a window plan's tables have room for
 
 struct WindowPatch {
     const int32_t* ops;        // journal {words, ...} to replay on the device tree first, or null (a replan step: the scan did)
     const int32_t* cache_loc;  // this step's slots: appended to the leaves of the device tree
-    const int32_t* patch;      // {entries, active overflow tiles of region 0 .. 63, {region << 20 | position, node | -1 = clear,
+    const int32_t* patch;      // {entries, active overflow tiles of region 0 .. 63, {region << 20 | position, row mask (0 = cleared),
                                //  slot | -1 - new row} ...} (window_host.cpp)
     const int32_t* tab;        // [chunk][WIN_PASSES][2]: leader record, first follower record (the record kernels write it)
     char* records;             // plan records
@@ -128,87 +163,112 @@ struct WindowPatch {
 };
 
 // ONE workgroup of 1024 threads per decode step.  Region h of the overflow = the h-th hosting record, chunk by chunk, pass by pass
-// (window_host.cpp hands out positions per region: a leaf's token lands in the ONE region that holds its query's rows).
-__global__ __launch_bounds__(1024) void window_patch_kernel(TreeDev t, WindowPatch w, PageWrite pw) {
+// (window_host.cpp hands out positions per region -- a leaf's token lands in the ONE region that holds its query's rows -- and
+// computes every entry's row mask).
+// A lone workgroup pays 1-2 us per dependent round trip, and this kernel stands between two steps' layers, so its chains run SIDE BY
+// SIDE in different waves (s_waitcnt counts per wave): waves 0-7 bring the step's words over PCIe (stage_fetch: counter, then header
+// and payload in one round trip) while waves 8-15 walk the device tree -- leaf row -> node -> length, room, last slot: three
+// dependent loads -- and read the overflow runs' record table; one barrier; then the stores.  (13 us -> 8 as one chain after the
+// other, profiles/r6_step_boundary.txt.)
+__global__ __launch_bounds__(1024) void window_patch_kernel(TreeDev t, WindowPatch w, PageWrite pw, StageFetch fetch) {
     __shared__ int sNew[TREE_OPS_NEW], sPos[TREE_OPS_NEW], sMeta[4], sOps[TREE_OPS_LDS];
     __shared__ int sHost[WIN_REGIONS * 2];  // hosting records: (chunk, pass) pairs
+    __shared__ int sTab[WIN_REGIONS * 2];   // ... and their {leader record, first follower record}
     __shared__ int sNH;
     const int tid = threadIdx.x;
-    // the patch list's loads first: they depend on nothing
-    const int n_ent = w.patch[0];
-    const int chunks = (t.nq + w.max_q_len - 1) / w.max_q_len;
-    if (tid == 0) {
-        int nh = 0;
-        for (int c = 0; c < chunks; ++c) {
-            const int cnt = min(w.max_q_len, t.nq - c * w.max_q_len);
-            const int pc = (cnt * w.G + MQ - 1) / MQ;
-            for (int ps = 0; ps < pc && ps < WIN_PASSES && nh < WIN_REGIONS; ++ps, ++nh) {
-                sHost[2 * nh] = c;
-                sHost[2 * nh + 1] = ps;
+    const bool tree_side = tid >= 512;  // (wave-uniform)
+    const int r0 = tid - 512;
+    // ---- tree side, in front of the barrier: everything that does not depend on the step's words -------------------------
+    int li = -1, llen = 0, lstart = 0, lroom = 0, llast = 0;
+    if (tree_side) {
+        if (r0 == 0) {
+            const int chunks = (t.nq + w.max_q_len - 1) / w.max_q_len;
+            int nh = 0;
+            for (int c = 0; c < chunks; ++c) {
+                const int cnt = min(w.max_q_len, t.nq - c * w.max_q_len);
+                const int pc = (cnt * w.G + MQ - 1) / MQ;
+                for (int ps = 0; ps < pc && ps < WIN_PASSES && nh < WIN_REGIONS; ++ps, ++nh) {
+                    sHost[2 * nh] = c;
+                    sHost[2 * nh + 1] = ps;
+                    sTab[2 * nh] = w.tab[(c * WIN_PASSES + ps) * 2];
+                    sTab[2 * nh + 1] = w.tab[(c * WIN_PASSES + ps) * 2 + 1];
+                }
             }
+            sNH = nh;
         }
-        sNH = nh;
+        for (int r = r0; r < t.nq && r == r0; r += 512) {  // (the first 512 query rows ahead of time; more than that: below)
+            li = t.leaf_node[r];
+            llen = t.node_len[li];
+            lstart = t.node_start[li];
+            lroom = t.node_cap[li];
+            llast = llen > 0 ? t.slots[lstart + llen - 1] : (int)0x80000000;
+        }
+    } else {
+        // (waves 0-7 fetch; with nothing to fetch -- a caller that copied the words itself -- they only meet the barrier)
     }
+    if (fetch.ring) {
+        // the fetch's own barrier is the one both sides meet: every thread takes part (the tree side's threads copy too, behind
+        // their loads -- harmless, the chunks are distributed over all 1024 threads)
+        stage_fetch(fetch);
+    } else {
+        __syncthreads();
+    }
+    const int n_ent = w.patch[0];
+    const int nops = w.ops ? w.ops[0] : 0;
     // ---- the device tree: journal, page table, this step's slots (tree_md_scan_kernel's opening) -----------------------
-    if (w.ops && w.ops[0] > 0) {
+    if (nops > 0) {  // (uniform; speculative-decoding steps: the journal changes node lengths, the walk above is void)
         __syncthreads();
         tree_apply_ops(t, w.ops, w.err, sNew, sPos, sMeta, sOps);
     }
     if (pw.table)
         for (int r = tid; r < t.nq; r += 1024) pw.table[pw.rows[r] * pw.stride + pw.cols[r]] = w.cache_loc[r];
-    for (int r = tid; r < t.nq; r += 1024) {
-        const int i = t.leaf_node[r];
-        const int len = t.node_len[i];
-        if (len >= t.node_cap[i]) {
-            atomicOr(w.err, 1);
-            continue;
+    if (tree_side) {
+        for (int r = r0; r < t.nq; r += 512) {
+            int i = li, len = llen, start = lstart, room = lroom, last = llast;
+            if (nops > 0 || r != r0) {
+                i = t.leaf_node[r];
+                len = t.node_len[i];
+                start = t.node_start[i];
+                room = t.node_cap[i];
+                last = len > 0 ? t.slots[start + len - 1] : (int)0x80000000;
+            }
+            if (len >= room) {
+                atomicOr(w.err, 1);
+                continue;
+            }
+            int32_t* sl = t.slots + start;
+            const int32_t v = w.cache_loc[r];
+            int p = len;
+            if (last > v)  // (rare: a slot freed by a cut came back lower -- keep the node's list ascending)
+                while (p > 0 && sl[p - 1] > v) {
+                    sl[p] = sl[p - 1];
+                    --p;
+                }
+            sl[p] = v;
+            t.node_len[i] = len + 1;
         }
-        int32_t* sl = t.slots + t.node_start[i];
-        const int32_t v = w.cache_loc[r];
-        int p = len;
-        while (p > 0 && sl[p - 1] > v) {
-            sl[p] = sl[p - 1];
-            --p;
-        }
-        sl[p] = v;
-        t.node_len[i] = len + 1;
     }
-    __syncthreads();
     // ---- the plan: one thread per entry ------------------------------------------------------------------------------------
     const int NH = sNH;
     const int32_t* ent = w.patch + 1 + WIN_REGIONS;
     for (int e = tid; e < n_ent; e += 1024) {
-        const int key = ent[3 * e], node = ent[3 * e + 1], val = ent[3 * e + 2];
+        const int key = ent[3 * e], val = ent[3 * e + 2];
+        const uint32_t mask = (uint32_t)ent[3 * e + 1];
         const int hi = key >> 20, pos = key & 0xfffff;
         const int j = pos >> 7, k = pos & (TILE - 1);
         if (hi < 0 || hi >= NH || j >= w.win_tiles) {
             atomicOr(w.err, WIN_ERR);
             continue;
         }
-        const int c = sHost[2 * hi], ps = sHost[2 * hi + 1];
-        const int32_t* tb = w.tab + (c * WIN_PASSES + ps) * 2;
-        const int rec = j == 0 ? tb[0] : tb[1] + j - 1;
+        const int rec = j == 0 ? sTab[2 * hi] : sTab[2 * hi + 1] + j - 1;
         char* rp = w.records + (int64_t)rec * PLAN_BYTES;
-        uint32_t mask = 0u;
-        int64_t ro = 0;
-        if (node >= 0) {
-            const unsigned long long* rf = t.refs + (size_t)node * t.nqw;
-            const int cnt = min(w.max_q_len, t.nq - c * w.max_q_len);
-            for (int v = 0; v < MQ; ++v) {
-                const int qi = (MQ * ps + v) / w.G;
-                const int q = c * w.max_q_len + qi;
-                if (qi < cnt && ((rf[q >> 6] >> (q & 63)) & 1ull)) mask |= 1u << v;
-            }
-            ro = val >= 0 ? (int64_t)val * w.kv_stride_slot * 2 : (((int64_t)1 << 63) | ((int64_t)(-1 - val) * w.new_row_bytes));
-        }
+        const int64_t ro = val >= 0 ? (int64_t)val * w.kv_stride_slot * 2 : (((int64_t)1 << 63) | ((int64_t)(-1 - val) * w.new_row_bytes));
         reinterpret_cast<int64_t*>(rp + PLAN_ROWOFF)[k] = ro;
         reinterpret_cast<uint32_t*>(rp + PLAN_MASK)[k] = mask;
     }
     // the leaders' tile count: tiles that hold nothing yet are not visited (the leader's own tile always is)
-    for (int hi = tid; hi < NH; hi += 1024) {
-        const int32_t* tb = w.tab + (sHost[2 * hi] * WIN_PASSES + sHost[2 * hi + 1]) * 2;
-        reinterpret_cast<int32_t*>(w.records + (int64_t)tb[0] * PLAN_BYTES + PLAN_DESC)[4] = max(1, min(w.patch[1 + hi], w.win_tiles));
-    }
+    for (int hi = tid; hi < NH; hi += 1024)
+        reinterpret_cast<int32_t*>(w.records + (int64_t)sTab[2 * hi] * PLAN_BYTES + PLAN_DESC)[4] = max(1, min(w.patch[1 + hi], w.win_tiles));
 }
 
 }  // namespace deft

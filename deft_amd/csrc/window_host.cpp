@@ -26,6 +26,7 @@ struct WindowBooks {
     int nq = 0, n_nodes = 0, cap = 0, max_entries = 0, regions = 0;
     std::vector<int32_t> leaf_node;            // query row -> DFS index of its leaf
     std::vector<uint64_t> node_regions;        // node -> bit h: a query below the node has a row in region h
+    std::vector<std::vector<uint32_t>> node_masks;  // node -> per set bit of node_regions (ascending h): bit v = virtual row v of region h belongs to a query below the node
     std::vector<std::vector<int32_t>> own;     // node -> overflow positions (region << 20 | position) it has been given, in order
     std::vector<int32_t> live;                 // node -> how many of them hold a slot
     std::vector<uint8_t> clean;                // node: none of its slots is in the static part of the plan
@@ -36,7 +37,7 @@ struct WindowBooks {
     };
     std::vector<New> prev_new;                 // the rows the LAST step read from k_new / v_new
     // this step's patch entries: last write to a position wins
-    std::vector<int32_t> ent_node, ent_val, stamp, touched;
+    std::vector<int32_t> ent_node /* the entry's row mask */, ent_val, stamp, touched;
     int32_t step_no = 0;
     std::mutex mu;
 
@@ -44,7 +45,8 @@ struct WindowBooks {
     bool place(int node, int val) {
         auto& o = own[(size_t)node];
         int n = live[(size_t)node];
-        for (uint64_t m = node_regions[(size_t)node]; m; m &= m - 1) {
+        int ord = 0;
+        for (uint64_t m = node_regions[(size_t)node]; m; m &= m - 1, ++ord) {
             const int h = __builtin_ctzll(m);
             int key;
             if (n < (int)o.size()) {
@@ -55,18 +57,24 @@ struct WindowBooks {
                 o.push_back(key);
             }
             ++n;
-            put(key, node, val);
+            put(key, (int32_t)node_masks[(size_t)node][(size_t)ord], val);
         }
         live[(size_t)node] = n;
         return true;
     }
-    void put(int key, int node, int val) {
+    // the row mask of `node` in the region of `key`
+    int32_t mask_of(int key, int node) const {
+        const int h = key >> 20;
+        const uint64_t below = node_regions[(size_t)node] & ((1ull << h) - 1ull);
+        return (int32_t)node_masks[(size_t)node][(size_t)__builtin_popcountll(below)];
+    }
+    void put(int key, int32_t mask, int val) {
         const size_t at = (size_t)(key >> 20) * (size_t)cap + (size_t)(key & 0xfffff);
         if (stamp[at] != step_no) {
             stamp[at] = step_no;
             touched.push_back(key);
         }
-        ent_node[at] = node;
+        ent_node[at] = mask;
         ent_val[at] = val;
     }
 };
@@ -118,9 +126,27 @@ int64_t deft_window_create(int n_nodes, int nq, int nqw, int tiles, const int32_
     }
     w->regions = h0;
     w->node_regions.assign((size_t)n_nodes, 0);
-    for (int i = 0; i < n_nodes; ++i)
+    w->node_masks.assign((size_t)n_nodes, {});
+    auto below = [&](int i, int q) { return ((refs[(size_t)i * (size_t)nqw + (size_t)(q >> 6)] >> (q & 63)) & 1ull) != 0; };
+    for (int i = 0; i < n_nodes; ++i) {
         for (int q = 0; q < nq; ++q)
-            if ((refs[(size_t)i * (size_t)nqw + (size_t)(q >> 6)] >> (q & 63)) & 1ull) w->node_regions[(size_t)i] |= row_regions[(size_t)q];
+            if (below(i, q)) w->node_regions[(size_t)i] |= row_regions[(size_t)q];
+        // virtual row v of region (c, ps) is head (32 ps + v) % group of query c * max_q_len + (32 ps + v) / group
+        int hh = 0;
+        for (int c = 0; c * max_q_len < nq; ++c) {
+            const int cnt = std::min(max_q_len, nq - c * max_q_len);
+            const int passes = (cnt * group + DEFT_MAX_Q_LEN - 1) / DEFT_MAX_Q_LEN;
+            for (int ps = 0; ps < passes; ++ps, ++hh) {
+                if (!((w->node_regions[(size_t)i] >> hh) & 1ull)) continue;
+                uint32_t mask = 0;
+                for (int v = 0; v < DEFT_MAX_Q_LEN; ++v) {
+                    const int qi = (DEFT_MAX_Q_LEN * ps + v) / group;
+                    if (qi < cnt && below(i, c * max_q_len + qi)) mask |= 1u << v;
+                }
+                w->node_masks[(size_t)i].push_back(mask);
+            }
+        }
+    }
     for (int r = 0; r < nq; ++r)
         if (leaf_node[r] < 0 || leaf_node[r] >= n_nodes) {
             set_error("deft_window_create: leaf row %d names node %d of %d", r, leaf_node[r], n_nodes);
@@ -146,7 +172,7 @@ int deft_window_free(int64_t window) {
 /* One decode step's books.  `journal`: the words deft_tree_journal_take handed over ({1 = EXTEND, node, n, n slots} | {2 = RESET, node,
  * 0}); `loc`: this step's nq slots, by query row.  replan = 0: continue the window; replan = 1: start one (the plan is being rebuilt on
  * this step).  Writes the patch list of the step -- {entries, active overflow tiles of regions 0 .. 63, {region << 20 | position,
- * node | -1, slot | -1 - new row} ...}, what deft_window_patch reads -- and returns the number of int32 words written; -1: this step cannot be expressed (replan = 0: run
+ * row mask (0 = cleared), slot | -1 - new row} ...}, what deft_window_patch reads -- and returns the number of int32 words written; -1: this step cannot be expressed (replan = 0: run
  * a replan step; replan = 1: run the step without a window), and the books are invalid until the next replan. */
 int64_t deft_window_step(int64_t window, int replan, const int32_t* journal, int64_t journal_words, const int32_t* loc, int32_t* out,
                          int64_t out_cap) {
@@ -168,7 +194,7 @@ int64_t deft_window_step(int64_t window, int replan, const int32_t* journal, int
         w->prev_new.clear();
     } else {
         // the rows the last step read from k_new / v_new are in the pool now: their positions get the pool offsets
-        for (const auto& p : w->prev_new) w->put(p.pos, p.node, p.slot);
+        for (const auto& p : w->prev_new) w->put(p.pos, w->mask_of(p.pos, p.node), p.slot);
     }
     w->valid = false;  // (until this step's books are complete)
     for (int64_t at = 0; at + 2 < journal_words;) {
@@ -180,7 +206,7 @@ int64_t deft_window_step(int64_t window, int replan, const int32_t* journal, int
             } else {
                 if (!w->clean[(size_t)node]) return -1;
                 const auto& o = w->own[(size_t)node];
-                for (int i = 0; i < w->live[(size_t)node]; ++i) w->put(o[(size_t)i], -1, 0);
+                for (int i = 0; i < w->live[(size_t)node]; ++i) w->put(o[(size_t)i], 0, 0);  // (no row sees the position: cleared)
                 w->live[(size_t)node] = 0;
             }
             at += 3;

@@ -323,15 +323,20 @@ class TemplateReplay:
             if sess is not None:
                 # ---- the captured step: slots from the host allocator, everything else on the GPU ----------------------------
                 nq_now[0] = nq
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                if pipelined and first_event is None:
-                    first_event = e0
+                # (pipelined: ONE timing event in front of the first step and one behind the last -- two events per step between the
+                #  captured graphs cost the loop ~12 us of idle queue per step, tools/step_boundary.py)
+                if not pipelined or first_event is None:
+                    e0 = torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    if pipelined:
+                        first_event = e0
                 outs = sess.step()
-                e1.record()
+                if not pipelined:
+                    e1 = torch.cuda.Event(enable_timing=True)
+                    e1.record()
                 if self.trace_hook is not None:
                     self.trace_hook(it, tree, None, None, sess)
-                last_event = e1
+                last_event = None if pipelined else e1
                 if self.step_hook is not None:
                     self.step_hook(tree, q_all[0, :nq], outs[0][:nq])
                 t_md = (time.perf_counter() - t0) * 1e3  # (host time of the whole step call: allocator, staging, graph launch)
@@ -412,7 +417,10 @@ class TemplateReplay:
             rep.metadata_ms += t_md
             rep.branch_ms += t_br
             it += 1
-        if pipelined and last_event is not None:
+        if pipelined and first_event is not None:
+            if last_event is None:  # (the session path records nothing per step)
+                last_event = torch.cuda.Event(enable_timing=True)
+                last_event.record()
             last_event.synchronize()
             rep.attention_ms = first_event.elapsed_time(last_event)
         rep.wall_ms = (time.perf_counter() - t_wall) * 1e3

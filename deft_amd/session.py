@@ -43,6 +43,10 @@ _WIN_PASSES = 16  # (plan_records.h WIN_PASSES: the overflow table's passes per 
 
 
 class DecodeSession:
+    RING = 8        # pinned staging slots: how many steps the host may run ahead of the GPU
+    EVENT_EVERY = 4  # ... kept from lapping it by an event behind every fourth step (an event per step sits between two captured
+                     # graphs and costs the queue idle time: tools/step_boundary.py)
+
     def __init__(self, tree: TreeCache, num_heads: int, num_kv_heads: int, head_dim: int, layers: int,
                  qkv: Callable[[int], tuple], max_q_len: int = 32, use_graph: bool = True, mode: str = "flatten",
                  capture_after="auto", incremental: bool = True, win_tiles: Optional[int] = None) -> None:
@@ -84,8 +88,13 @@ class DecodeSession:
         self._side: Optional[torch.cuda.Stream] = torch.cuda.Stream(device=self.device)
         self._side.wait_stream(torch.cuda.current_stream(self.device))
         self.out: List[torch.Tensor] = []
-        self._pin: list = []  # pinned staging buffers in rotation: [buffer, event of its last upload]
-        self._pin_k = -1
+        # the host's words of a step reach the GPU through a RING of pinned slots that the step's first kernel reads itself
+        # (csrc/window.h StageFetch): the slot is picked by a device-side step counter, an event per slot keeps the host from lapping
+        self._ring: Optional[torch.Tensor] = None
+        self._ring_slot = 0
+        self._ring_events: List[Optional[torch.cuda.Event]] = [None] * (2 * self.RING // self.EVENT_EVERY)
+        self._stage_no = 0   # steps staged so far (== the device counter once the GPU has caught up)
+        self._ctr = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.win = 0  # native books of the epoch's window plans (deft_window_create), 0 = none
 
     def __del__(self) -> None:
@@ -175,6 +184,11 @@ class DecodeSession:
         self.ops = self._small[ob:pb].view(torch.int32)
         self.patch = self._small[pb:].view(torch.int32)
         self._ops_off, self._patch_off = ob, pb
+        need = (16 + self._small.numel() + 15) // 16 * 16
+        if self._ring is None or need > self._ring_slot:  # (grown only: between epochs, once every slot has been read)
+            torch.cuda.current_stream(dev).synchronize()
+            self._ring_slot = max(need, 4096)
+            self._ring = torch.zeros(self.RING * self._ring_slot, dtype=torch.uint8).pin_memory()
         self.win_tab = torch.zeros(max(chunks, 1) * _WIN_PASSES * 2, dtype=torch.int32, device=dev)
         if self.win:
             lib.deft_window_free(self.win)
@@ -192,11 +206,19 @@ class DecodeSession:
         self.graphs, self.graph_epoch = {}, dt.epoch
         return uploaded
 
+    def _fetch(self, stream: int) -> None:
+        check(lib.deft_stage_fetch(self._ring.data_ptr(), self._ring_slot, self.RING, self._small.data_ptr(), self._ctr.data_ptr(), stream),
+              "deft_stage_fetch")
+
+    def _can_fold(self, advance: bool) -> bool:
+        table = self.tree.req_to_token_pool.req_to_token
+        return advance and table.dtype == torch.int32 and table.device == self.device and table.dim() == 2 and table.stride(1) == 1
+
     def _fold(self, advance: bool) -> bool:
         """Are the page-table entries of this step's tokens written by the step's first kernel?  (When the table is what the kernel
         expects -- int32, contiguous rows, on this device; by an index_put otherwise.)"""
         table = self.tree.req_to_token_pool.req_to_token
-        fold = advance and table.dtype == torch.int32 and table.device == self.device and table.dim() == 2 and table.stride(1) == 1
+        fold = self._can_fold(advance)
         self.page_table_folded = fold  # (tests: the fold must really happen for the pools this package makes)
         if not fold:
             table[self.idx[0], self.idx[1]] = self.cache_loc
@@ -226,6 +248,7 @@ class DecodeSession:
         dt, dev = self.dt, self.device
         stream = torch.cuda.current_stream(dev).cuda_stream
         table = self.tree.req_to_token_pool.req_to_token
+        self._fetch(stream)
         fold = self._fold(advance)
         mq, bl, mbl = dt.cfg
         # (the append of this step's slots to the device tree rides in the first metadata kernel)
@@ -260,6 +283,11 @@ class DecodeSession:
         dt, dev = self.dt, self.device
         stream = torch.cuda.current_stream(dev).cuda_stream
         table = self.tree.req_to_token_pool.req_to_token
+        # a PATCH step whose page-table write rides in the patch kernel has that kernel fetch the step's words too (one launch
+        # in front of the layers); everything else fetches with a launch of its own, in front of whatever reads them
+        folded_fetch = not replan and self._can_fold(True)
+        if not folded_fetch:
+            self._fetch(stream)
         fold = self._fold(True)
         mq, bl, mbl = dt.cfg
         Hq, Hkv, D = self.Hq, self.Hkv, self.D
@@ -284,7 +312,9 @@ class DecodeSession:
                                     table.data_ptr() if fold else None, table.stride(0) if fold else 0,
                                     self.idx[0].data_ptr() if fold else None, self.idx[1].data_ptr() if fold else None,
                                     self.patch.data_ptr(), self.win_tab.data_ptr(), self.plan.data_ptr(), mq, self.W, Hq, Hkv,
-                                    kv0.stride(0), k0.stride(0), dt.scratch.data_ptr(), stream), "deft_window_patch")
+                                    kv0.stride(0), k0.stride(0), dt.scratch.data_ptr(),
+                                    *((self._ring.data_ptr(), self._ring_slot, self.RING, self._small.data_ptr(), self._ctr.data_ptr())
+                                      if folded_fetch else (None, 0, 0, None, None)), stream), "deft_window_patch")
         self._launch_layers()
 
     # ---- per step ------------------------------------------------------------------------------------------
@@ -317,6 +347,7 @@ class DecodeSession:
                     uploaded, jn = self._epoch_setup(), 0
             self._stage(loc, jn, False)
             self._launch_step(advance=not uploaded)  # (a legacy step: the next one starts the epoch's first window)
+            self._staged()
             self._moved()
             self.step_kinds["upload"] += 1
             return self.out
@@ -329,12 +360,24 @@ class DecodeSession:
             wait = (1 if self._last_epoch_steps > 3 else 4) if self.capture_after == "auto" else int(self.capture_after)
             if not self.use_graph or self._epoch_steps <= wait:  # (this is step `_epoch_steps` of the epoch; `wait` of them run eagerly)
                 launch()
+                self._staged()
                 self._moved()
                 return self.out
             self._capture(kind, launch)
         self.graphs[kind].replay()
+        self._staged()
         self._moved()
         return self.out
+
+    def _staged(self) -> None:
+        """The launches that read the ring slot written by the last `_stage` are in the stream; every EVENT_EVERY-th step leaves an event."""
+        s = self._stage_no - 1  # the step just launched
+        if s % self.EVENT_EVERY != self.EVENT_EVERY - 1:
+            return
+        k = (s // self.EVENT_EVERY) % len(self._ring_events)
+        if self._ring_events[k] is None:
+            self._ring_events[k] = torch.cuda.Event()  # (re-recorded: not one hipEventCreate per step)
+        self._ring_events[k].record(torch.cuda.current_stream(self.device))
 
     def _moved(self) -> None:
         """This session's launches have advanced the device copy of the tree."""
@@ -342,20 +385,20 @@ class DecodeSession:
         self._dt_version = self.dt.version
 
     def _stage(self, loc: np.ndarray, journal_words: int, window: bool) -> str:
-        """This step's slot numbers, page-table coordinates, journal and -- window plans -- patch list: pinned staging -> the fixed
-        device tensors the graph reads, in one copy.  Four pinned buffers in rotation, each guarded by the event of its last upload
-        (a pageable source would make the copy wait for the stream to drain -- the host would run in lock-step with the GPU).
+        """This step's slot numbers, page-table coordinates, journal and -- window plans -- patch list, written into a slot of the
+        pinned ring; the step's first kernel copies it into the fixed device tensors the graph reads (`_fetch`, csrc/window.h).
         Returns the form the step takes: "patch" (the window goes on), "replan" (a new window starts) or "legacy"."""
-        n, nb = self.nq, self._small.numel()
-        self._pin_k = (self._pin_k + 1) % 4
-        while len(self._pin) <= self._pin_k:
-            self._pin.append(None)
-        slot = self._pin[self._pin_k]
-        if slot is None or slot[0].numel() != nb:
-            slot = self._pin[self._pin_k] = [torch.zeros(nb, dtype=torch.uint8).pin_memory(), None]
-        if slot[1] is not None:
-            slot[1].synchronize()
-        h = slot[0].numpy()
+        n = self.nq
+        k = self._stage_no % self.RING
+        need = self._stage_no - self.RING  # the step that read this slot last must have run: wait for the first event at or behind it
+        self._stage_no += 1
+        if need >= 0:
+            e = need + (self.EVENT_EVERY - 1 - need) % self.EVENT_EVERY
+            ev = self._ring_events[(e // self.EVENT_EVERY) % len(self._ring_events)]
+            if ev is not None:
+                ev.synchronize()
+        slot = self._ring.numpy()[k * self._ring_slot : (k + 1) * self._ring_slot]
+        h = slot[16:]
         nqm = max(n, 1)
         loc32 = h[: 4 * n].view(np.int32)
         loc32[:] = loc
@@ -368,7 +411,7 @@ class DecodeSession:
             ops_h[1 : 1 + journal_words] = self._journal[:journal_words]
         kind, used = "legacy", self._patch_off
         if window:
-            ph = h[self._patch_off :].view(np.int32)
+            ph = h[self._patch_off : self._small.numel()].view(np.int32)  # (what the device-side patch area holds)
             words = -1
             # (nobody else has moved the device copy since this session's last step?  Otherwise the plan's static part is stale: replan)
             if self.dt.version == self._dt_version:
@@ -383,11 +426,7 @@ class DecodeSession:
                 kind = "legacy"
             else:
                 used += 4 * words
-        # (only what this step wrote crosses PCIe: the journal and patch areas are sized for the worst step)
-        self._small[:used].copy_(slot[0][:used], non_blocking=True)
-        if slot[1] is None:
-            slot[1] = torch.cuda.Event()  # (one event per staging buffer, re-recorded: not one hipEventCreate per step)
-        slot[1].record(torch.cuda.current_stream(self.device))
+        slot[:4].view(np.uint32)[0] = used  # (only what this step wrote crosses PCIe: the journal and patch areas are sized for the worst step)
         return kind
 
     def _capture(self, kind: str, launch) -> None:

@@ -472,8 +472,8 @@ int deft_tree_dev_build_md_ops(int n_nodes, int nq, int nqw, const int32_t* node
  *   deft_window_patch                EVERY step of a window, replan steps included (ONE workgroup): journal replay (`ops`, nullable:
  *                                    a replan step's scan already did), page-table write, the step's slots appended to the device
  *                                    tree, and the host's patch list applied to the plan: int32 {entries, active overflow tiles of
- *                                    regions 0 .. 63, {region << 20 | position, DFS node | -1 = clear, pool slot | -1 - new row} ...}
- *                                    (deft_window_step writes it); the row mask of an entry is its node's leaf set within the region */
+ *                                    regions 0 .. 63, {region << 20 | position, row mask (0 = cleared), pool slot | -1 - new row} ...}
+ *                                    (deft_window_step writes it: an entry's row mask is its node's leaf set within the region) */
 int deft_window_supported(int nq, int max_q_len, int Hq, int Hkv);
 int deft_flatten_build_plan_window(int64_t* block_q, int64_t* block_q_cnts, int64_t* block_q_offset, int64_t* block_bitmasks,
                                    int64_t* block_kv, int64_t* block_lens, int NB, int P, int32_t* dims, int nq, int max_q_len,
@@ -487,7 +487,15 @@ int deft_window_patch(int n_nodes, int nq, int nqw, const int32_t* node_start, i
                       const uint64_t* refs, const int32_t* leaf_node, int32_t* slots, const int32_t* ops /* nullable */,
                       const int32_t* cache_loc, int32_t* page_table /* nullable */, int64_t page_stride, const int64_t* page_rows,
                       const int64_t* page_cols, const int32_t* patch, const int32_t* win_tab, void* plan, int max_q_len,
-                      int win_tiles, int Hq, int Hkv, int64_t kv_stride_slot, int64_t new_stride_tok, void* scratch, void* stream);
+                      int win_tiles, int Hq, int Hkv, int64_t kv_stride_slot, int64_t new_stride_tok, void* scratch,
+                      /* optional (fetch_ring nullable): deft_stage_fetch folded into the kernel's opening */
+                      const void* fetch_ring, int fetch_slot_bytes, int fetch_ring_n, void* fetch_dst, int32_t* fetch_counter,
+                      void* stream);
+/* A decode step's host-written words (slot numbers, page-table coordinates, journal, patch list) FETCHED by a kernel from a ring of
+ * pinned, device-accessible host slots -- slot (*counter mod ring_n) = {uint32 used bytes, 12 bytes padding, payload}; its first `used`
+ * payload bytes go to `dst`, then *counter += 1 -- instead of a hipMemcpyAsync in front of the captured step (the queue idles ~25 us
+ * around a stand-alone copy).  One workgroup; identical arguments on every step, so it sits in the step's hipGraph. */
+int deft_stage_fetch(const void* ring, int slot_bytes, int ring_n, void* dst, int32_t* counter, void* stream);
 
 /* The host-side books of a window plan: which overflow position holds which node's slot (deft_amd/csrc/window_host.cpp).
  *   deft_window_create   books for one structural epoch: `leaf_node[r]` = DFS index of query row r's leaf, `refs` = the nodes' leaf sets

@@ -513,22 +513,28 @@ def test_window_books_patch_lists():
         assert n == 65 + 3 * out[0]
         return [int(x) for x in out[1:65] if x], {(int(k) >> 20, int(k) & 0xfffff): (int(a), int(b)) for k, a, b in out[65:n].reshape(-1, 3)}
 
+    # (an entry = position: (row mask, slot | -1 - new row); MHA: leaf r is row r of the one region, the root is above all three)
     w = make(1)  # MHA, three queries: one chunk, one pass, one region
     assert step(w, 0, [], [10, 11, 12]) is None  # no window yet
-    assert step(w, 1, [], [10, 11, 12]) == ([1], {(0, 0): (1, -1), (0, 1): (2, -2), (0, 2): (3, -3)})
+    assert step(w, 1, [], [10, 11, 12]) == ([1], {(0, 0): (1, -1), (0, 1): (2, -2), (0, 2): (4, -3)})
     # the next step: last step's rows are pool rows now, this step's go behind them
-    assert step(w, 0, [], [13, 14, 15])[1] == {(0, 0): (1, 10), (0, 1): (2, 11), (0, 2): (3, 12), (0, 3): (1, -1), (0, 4): (2, -2), (0, 5): (3, -3)}
+    assert step(w, 0, [], [13, 14, 15])[1] == {(0, 0): (1, 10), (0, 1): (2, 11), (0, 2): (4, 12), (0, 3): (1, -1), (0, 4): (2, -2), (0, 5): (4, -3)}
     # a RESET of a leaf whose first tokens sit in the static part of the plan cannot be patched
     assert step(w, 0, [2, 1, 0], [16, 17, 18]) is None
     assert step(w, 0, [], [16, 17, 18]) is None  # ... and the books stay invalid until a replan
     # a speculative-decoding loop: the replan step's journal resets every leaf (they are "clean" from now on) ...
-    assert step(w, 1, [1, 0, 1, 15, 2, 1, 0, 2, 2, 0, 2, 3, 0], [20, 21, 22])[1] == {(0, 0): (1, -1), (0, 1): (2, -2), (0, 2): (3, -3)}
-    # ... and every later step merges a slot into the root (node 0: a new position, the root's rows), drops the leaves' slots and
+    assert step(w, 1, [1, 0, 1, 15, 2, 1, 0, 2, 2, 0, 2, 3, 0], [20, 21, 22])[1] == {(0, 0): (1, -1), (0, 1): (2, -2), (0, 2): (4, -3)}
+    # ... and every later step merges a slot into the root (node 0: a new position, all three rows), drops the leaves' slots and
     # refills the SAME positions
-    assert step(w, 0, [1, 0, 1, 20, 2, 1, 0, 2, 2, 0, 2, 3, 0], [23, 24, 25])[1] == {(0, 3): (0, 20), (0, 0): (1, -1), (0, 1): (2, -2), (0, 2): (3, -3)}
-    assert step(w, 0, [1, 0, 2, 23, 24, 2, 1, 0, 2, 2, 0, 2, 3, 0], [26, 27, 28])[1] == {(0, 4): (0, 23), (0, 5): (0, 24), (0, 0): (1, -1), (0, 1): (2, -2),
-                                                                                       (0, 2): (3, -3)}
+    assert step(w, 0, [1, 0, 1, 20, 2, 1, 0, 2, 2, 0, 2, 3, 0], [23, 24, 25])[1] == {(0, 3): (7, 20), (0, 0): (1, -1), (0, 1): (2, -2), (0, 2): (4, -3)}
+    assert step(w, 0, [1, 0, 2, 23, 24, 2, 1, 0, 2, 2, 0, 2, 3, 0], [26, 27, 28])[1] == {(0, 4): (7, 23), (0, 5): (7, 24), (0, 0): (1, -1), (0, 1): (2, -2),
+                                                                                       (0, 2): (4, -3)}
+    # a RESET without a refill: the positions are cleared (no row sees them)
+    assert step(w, 1, [2, 1, 0, 2, 2, 0, 2, 3, 0], [50, 51, 52]) is not None
+    r = step(w, 0, [2, 1, 0], [53, 54, 55])
+    assert r[1] == {(0, 0): (1, -1), (0, 1): (2, 51), (0, 2): (4, 52), (0, 3): (2, -2), (0, 4): (4, -3)}  # leaf 1's position: cleared, then refilled
     # without resets the region fills up: 128 positions
+    assert step(w, 1, [], [10, 11, 12]) is not None and step(w, 0, [], [13, 14, 15]) is not None
     fill, steps = 6, 0
     while True:
         r = step(w, 0, [1, 0, 3, 1, 2, 3], [30, 31, 32])  # three more slots into the root per step, the leaves keep growing
@@ -538,16 +544,17 @@ def test_window_books_patch_lists():
         steps += 1
         assert r[0] == [(fill + 127) // 128]
     assert steps == (128 - 6) // 6 and fill <= 128
-    assert step(w, 1, [], [40, 41, 42])[1] == {(0, 0): (1, -1), (0, 1): (2, -2), (0, 2): (3, -3)}  # the replan starts afresh
+    assert step(w, 1, [], [40, 41, 42])[1] == {(0, 0): (1, -1), (0, 1): (2, -2), (0, 2): (4, -3)}  # the replan starts afresh
     assert lib.deft_window_free(w) == 0 and lib.deft_window_free(w) != 0
     # GQA, 16 query heads per KV head: two queries to a 32-row pass -- queries 0, 1 in region 0, query 2 in region 1; a leaf's token
-    # goes to ITS region only, a slot merged into the root to both
+    # goes to ITS region only, a slot merged into the root to both (masks: 16 rows per query)
     w = make(16)
-    assert step(w, 1, [], [10, 11, 12]) == ([1, 1], {(0, 0): (1, -1), (0, 1): (2, -2), (1, 0): (3, -3)})
-    assert step(w, 0, [1, 0, 1, 99], [13, 14, 15])[1] == {(0, 0): (1, 10), (0, 1): (2, 11), (1, 0): (3, 12), (0, 2): (0, 99), (1, 1): (0, 99),
-                                                          (0, 3): (1, -1), (0, 4): (2, -2), (1, 2): (3, -3)}
+    lo, hi, full = 0xffff, -0x10000, -1  # (int32 views of 0x0000ffff, 0xffff0000, 0xffffffff)
+    assert step(w, 1, [], [10, 11, 12]) == ([1, 1], {(0, 0): (lo, -1), (0, 1): (hi, -2), (1, 0): (lo, -3)})
+    assert step(w, 0, [1, 0, 1, 99], [13, 14, 15])[1] == {(0, 0): (lo, 10), (0, 1): (hi, 11), (1, 0): (lo, 12), (0, 2): (full, 99), (1, 1): (lo, 99),
+                                                          (0, 3): (lo, -1), (0, 4): (hi, -2), (1, 2): (lo, -3)}
     lib.deft_window_free(w)
     # one query per chunk (max_q_len = 1): three chunks, three regions
     w = make(1, max_q_len=1)
-    assert step(w, 1, [], [10, 11, 12]) == ([1, 1, 1], {(0, 0): (1, -1), (1, 0): (2, -2), (2, 0): (3, -3)})
+    assert step(w, 1, [], [10, 11, 12]) == ([1, 1, 1], {(0, 0): (1, -1), (1, 0): (1, -2), (2, 0): (1, -3)})
     lib.deft_window_free(w)
