@@ -36,7 +36,7 @@ HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s p
 
 
 class Bench:
-    def __init__(self, w: Workload, layers: int, device: torch.device, seed: int = 0):
+    def __init__(self, w: Workload, layers: int, device: torch.device, seed: int = 0, extra_steps: int = 64):
         self.w = w
         self.Hq, self.Hkv, self.D, _ = GEOMETRY[w.model]
         self.layers = layers
@@ -51,7 +51,7 @@ class Bench:
             self.forest, self.pool = build_forest(w, w.trees, layers, str(device))
         else:
             # (room for the advancing-tree loop: every leaf grows by a token per step)
-            tree, self.pool = build_tree(w, layers, str(device), extra_slots=256 + 64 * max(w.width, 1))
+            tree, self.pool = build_tree(w, layers, str(device), extra_slots=256 + extra_steps * max(w.width, 1))
             self.forest = deft_amd.Forest([tree])
         self.tree_build_s = time.perf_counter() - t0
         builds = []
@@ -369,6 +369,102 @@ class Bench:
                           else "eager (tree.alloc, TreeMetadata.from_tree_cache, DeFTAttention.forward per layer)"}
 
 
+def run_level(w: Workload, layers: int, device, gen_len: int, incremental: bool):
+    """The reference's few-shot experiment AS A RUN (README.md:214-219: a 4000-token prompt, 400 generated tokens per branch; logs in
+    DeFT/experiments/few_shot_prompting/few_shot.ipynb): the north-star tree growing from 1 to `gen_len` tokens per branch through
+    deft_amd.FlattenDecodeSession, no host sync inside -- every step of it, the epochs' first (eager) steps and graph captures
+    included.  `run_hbm_frac` = the algorithmic bytes of all its attention launches / the GPU time of the run / 8 TB/s: what the >= 60 %
+    target looks like averaged over the branch lengths a generation run actually passes through."""
+    b = Bench(Workload(**{**w.__dict__, "branch_len": 1}), layers, device, seed=11, extra_steps=gen_len + 8)
+    tree = b.forest.trees[0]
+    sess = deft_amd.FlattenDecodeSession(tree, b.Hq, b.Hkv, b.D, layers, lambda l: (b.q[l], b.k_new[l], b.v_new[l]), incremental=incremental)
+    steps = gen_len - 1
+    n_kv, total_bytes = b.n_kv, 0
+    torch.cuda.synchronize(device)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(steps):
+        for leaf in tree.leaves.values():
+            leaf.append_token(7)
+        sess.step()
+        n_kv += b.nq
+        total_bytes += algorithmic_bytes(n_kv, b.nq, b.Hq, b.Hkv, b.D) * layers
+    e1.record()
+    torch.cuda.synchronize(device)
+    wall = time.perf_counter() - t0
+    gpu_s = e0.elapsed_time(e1) * 1e-3
+    out = {"steps": steps, "branch_len": [1, gen_len], "generated_tokens": steps * b.nq, "wall_ms": round(wall * 1e3, 2),
+           "gpu_ms": round(gpu_s * 1e3, 2), "ms_per_step": round(wall / steps * 1e3, 4), "tokens_per_s": round(steps * b.nq / wall, 1),
+           "algorithmic_TB": round(total_bytes / 1e12, 4), "run_GBps": round(total_bytes / gpu_s / 1e9, 1),
+           "run_hbm_frac": round(total_bytes / gpu_s / 1e9 / HBM_PEAK_GBPS, 4), "step_kinds": dict(sess.step_kinds),
+           "graph_captures": sess.captures}
+    del sess, b
+    return out
+
+
+def in_situ(b: "Bench", steps: int = 60):
+    """Attention timed where the reference times it: INSIDE the model's forward (DeFT/deft/layers/attention/deft_attention.py:117-149
+    runs inside model_runner.py:410-424), i.e. with the layer's dense kernels -- weight streams that sweep L2 and the Infinity Cache --
+    between two attention calls.  Harness only: one hipGraph of `layers` x [qkv projection (F.linear, 4096 -> 12288 for Llama-2-7B) ->
+    DeFTAttention.forward on strided views of its output -> o projection -> MLP up -> MLP down] at nq rows, fp16 synthetic weights, and
+    the same graph WITHOUT the attention call; their difference per layer is the attention's cost in situ, next to the back-to-back
+    number of the headline.  (Kernel by kernel: `rocprofv3 --kernel-trace --stats -- python bench.py --in-situ-only`,
+    profiles/r6_in_situ_kernel_stats.txt.)"""
+    import torch.nn.functional as F
+
+    dev, L, nq = b.device, b.layers, b.nq
+    H, Hkv_d, inter = b.Hq * b.D, b.Hkv * b.D, 11008 if b.Hq == b.Hkv else 14336
+    g = torch.Generator(device=dev)
+    g.manual_seed(99)
+    mk = lambda o, i: torch.randn((L, o, i), dtype=torch.float16, device=dev, generator=g) * (i ** -0.5)  # noqa: E731
+    Wqkv, Wo, Wup, Wdn = mk(H + 2 * Hkv_d, H), mk(H, H), mk(inter, H), mk(H, inter)
+    x = torch.randn((nq, H), dtype=torch.float16, device=dev, generator=g)
+    sink = torch.zeros((nq, H), dtype=torch.float16, device=dev)
+
+    def forward(with_attention: bool):
+        for l in range(L):
+            qkv = F.linear(x, Wqkv[l])
+            q, k, v = qkv.split([H, Hkv_d, Hkv_d], dim=-1)
+            o = b.attn[l](q, k, v, b.meta) if with_attention else q
+            y = F.linear(o.reshape(nq, H), Wo[l])
+            z = F.linear(F.linear(y, Wup[l]), Wdn[l])
+        sink.copy_(z)
+
+    def capture(with_attention: bool):
+        forward(with_attention)
+        torch.cuda.synchronize(dev)
+        gr = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(gr, stream=side):
+                forward(with_attention)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        return gr
+
+    def timed(gr):
+        for _ in range(5):
+            gr.replay()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            gr.replay()
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t0) / steps
+
+    g_with, g_without = capture(True), capture(False)
+    reps = [(timed(g_with), timed(g_without)) for _ in range(3)]
+    t_with, t_without = min(r[0] for r in reps), min(r[1] for r in reps)
+    weights_mb = (Wqkv[0].numel() + Wo[0].numel() + Wup[0].numel() + Wdn[0].numel()) * 2 / 1e6
+    return {"what": "attention inside a model-shaped step: per layer qkv projection -> DeFTAttention.forward -> o projection -> MLP up -> MLP "
+                    "down (F.linear at nq rows, synthetic fp16 weights), one hipGraph; attention = that graph minus the same graph without "
+                    "the attention call",
+            "layers": L, "dense_weights_MB_per_layer": round(weights_mb, 1), "steps": steps,
+            "ms_per_step_with_attention": round(t_with * 1e3, 4), "ms_per_step_dense_only": round(t_without * 1e3, 4),
+            "attention_us_per_layer_in_situ": round((t_with - t_without) * 1e6 / L, 2)}
+
+
 def _ctl_device(b: "Bench"):
     """Where the control-plane tensors of the bracket live: the GPU under RCCL, host memory under gloo."""
     import torch.distributed as dist
@@ -605,6 +701,9 @@ def main():
     ap.add_argument("--win-tiles", type=int, default=None, help="end-to-end loop: DecodeSession(win_tiles=), overflow tiles per region of a window plan")
     ap.add_argument("--no-cfg5", action="store_true", help="skip the sharded-forest (BASELINE configs[4]) measurement")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
+    ap.add_argument("--in-situ-only", action="store_true",
+                    help="run the model-shaped step (dense layer kernels between the attention calls, bench.in_situ) and nothing else: for "
+                         "`rocprofv3 --kernel-trace --stats`, so that the stage-1 / merge averages are those of launches with neighbours")
     ap.add_argument("--step-only", action="store_true",
                     help="run the timed step graph and nothing else (no stage-1-only sweeps, percentiles, plan timing): for "
                          "`rocprofv3 --kernel-trace --stats`, so that the per-kernel averages are those of the STEP's launches")
@@ -663,6 +762,10 @@ def main():
     if args.child:  # PMC child: the parent only wants the kernels to have run
         if w.mode == "flatten":
             b.time_stage1(reps=1)
+        return
+    if args.in_situ_only:
+        if rank == 0:
+            print(json.dumps({"in_situ": in_situ(b), "attention_us_per_layer_back_to_back": round(ms_per_step * 1e3 / layers, 2)}), flush=True)
         return
     if args.step_only:
         if rank == 0:
@@ -745,6 +848,48 @@ def main():
                 del bf
         except Exception as e:
             e2e["frozen_step_at_mean_len"] = {"error": f"{type(e).__name__}: {e}"}
+
+    situ = None
+    if rank == 0 and not dist_on and not args.no_extras:
+        try:  # attention timed where the reference times it -- between the dense kernels of a layer
+            torch.cuda.empty_cache()
+            situ = in_situ(b)
+            situ["attention_us_per_layer_back_to_back"] = round(ms_per_step * 1e3 / layers, 2)
+            situ["in_situ_over_back_to_back"] = round(situ["attention_us_per_layer_in_situ"] / max(ms_per_step * 1e3 / layers, 1e-9), 3)
+        except Exception as e:
+            situ = {"error": f"{type(e).__name__}: {e}"}
+        torch.cuda.empty_cache()
+
+    few_shot_run = None
+    if rank == 0 and not dist_on and not args.no_e2e and not args.no_extras and w.kind == "few_shot" and w.trees == 1 and w.mode == "flatten":
+        # the run-level fraction of the reference's few-shot workload, and where along the branch length it is lost
+        few_shot_run = {"what": "the tree of the headline growing from 1 to 400 tokens per branch (the reference's few-shot experiment, "
+                                "README.md:214-219) through deft_amd.FlattenDecodeSession: algorithmic bytes of every attention launch "
+                                "of the run / GPU time of the run / 8 TB/s; `by_branch_len`: a frozen step at that length"}
+        del b.graph
+        b.graph = None
+        for key, inc in (("window_plans", True), ("rebuild_every_step", False)):
+            try:
+                torch.cuda.empty_cache()
+                few_shot_run[key] = run_level(w, layers, device, 400, inc)
+            except Exception as e:
+                few_shot_run[key] = {"error": f"{type(e).__name__}: {e}"}
+        sweep = {}
+        for L in (1, 25, 50, 100, 150, 200, 300, 400):
+            try:
+                torch.cuda.empty_cache()
+                bl = Bench(Workload(**{**w.__dict__, "branch_len": L}), layers, device, seed=3)
+                bl.prepare(use_graph=not args.no_graph)
+                dtl = run_timed(bl, 100, 10, False)
+                al = bl.algorithmic_bytes_per_layer()
+                s1l = bl.time_stage1(reps=1)
+                sweep[str(L)] = {"us_per_layer": round(dtl / 100 * 1e6 / layers, 2),
+                                 "step_hbm_frac": round(al * layers / (dtl / 100) / 1e9 / HBM_PEAK_GBPS, 4),
+                                 "stage1_hbm_frac": round(al / (s1l["mean_us"] * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4) if s1l else None}
+                del bl
+            except Exception as e:
+                sweep[str(L)] = {"error": f"{type(e).__name__}: {e}"}
+        few_shot_run["by_branch_len"] = sweep
 
     extras = {}
     if not args.no_extras and rank == 0 and not dist_on:
@@ -847,7 +992,7 @@ def main():
             "step_hbm_frac": round(step_achieved / HBM_PEAK_GBPS, 4),
             "metadata_build_ms": round(b.metadata_build_ms, 3),
             "plan_build_us_per_step": round(plan_us, 1) if plan_us is not None else None,
-            "end_to_end": e2e, "gpu_state": gpu_state(),
+            "end_to_end": e2e, "few_shot_run": few_shot_run, "in_situ": situ, "gpu_state": gpu_state(),
             "dist": ({"backend": args.dist_backend, "world_size": world, "ranks_share_gpus": bool(shared_gpus),
                       "visible_gpus": torch.cuda.device_count()} if dist_on else None),
             "roofline": roofline, "cpu_baseline": cpu, "cfg5_sharded_forest": cfg5, "prefill": prefill,
