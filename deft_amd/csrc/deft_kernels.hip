@@ -695,7 +695,7 @@ static int launch_plan(const Stage1Params& p, int NB, const PlanView& pv, const 
     const UnitList ul = unit_list(pv);
     hipLaunchKernelGGL(flatten_units_kernel, dim3(1), dim3(1024), lds, stream, p.block_q, p.block_q_cnts, p.block_q_offset, NB,
                        p.G, (int)pv.cap, ul, pv.hdr, plan_items_per_leader(p), 2 * num_cus(), np_chunk_knob(), np_union_knob(), (int)run_cap, qtab,
-                       par, dims, pv.row_q, (int)pv.rows, win_tiles);
+                       par, dims, pv.row_q, (int)pv.rows, win_tiles, p.block_lens, p.G == 1 ? knob("DEFT_NP_SOLO_FULL", 1) : 0);
     rc = check_launch("flatten units launch");
     if (rc) return rc;
     hipLaunchKernelGGL(flatten_records_kernel, dim3((unsigned)(pv.cap + 1)), dim3(128), 0, stream, p.block_q, p.block_q_cnts,

@@ -389,7 +389,8 @@ __global__ __launch_bounds__(1024) void flatten_units_kernel(const int64_t* bloc
                                                             const int64_t* block_q_offset, int NBc, int G, int cap,
                                                             UnitList ul, int32_t* hdr, int Hkv, int slots, int chunk_c,
                                                             int union_len, int run_cap, int qtab, int par,
-                                                            const int32_t* dims, int32_t* row_q, int rows, int win_tiles) {
+                                                            const int32_t* dims, int32_t* row_q, int rows, int win_tiles,
+                                                            const int64_t* block_lens, int solo_full) {
     constexpr int np = 1;  // records in the tile-parallel order (leaders first); the only stage-1 form
     // NBc = block CAPACITY (sizes the tables); with `dims` (device-side metadata, tree_plan.h) the block count of this
     // step is read from the device, so that one captured launch serves every step of a structural epoch
@@ -467,6 +468,13 @@ __global__ __launch_bounds__(1024) void flatten_units_kernel(const int64_t* bloc
             }
             if (!(bits & 1)) bits = 0xe;  // not opening a run: longer periods read as "differs"
             if (t >= NBreg) bits = ((t - NBreg) % win_tiles == 0) ? 0xf : 0xe;  // (overflow tiles: a run of their own per query chunk)
+            // bit 4 (round 6, MHA): a FULL tile of ONE query.  A union group that would hold nothing but such tiles is not formed (phase
+            // 1b): at branch lengths that are multiples of 128 every leaf tile is one, the launch ends with the eight-tile root chunks'
+            // serial chains, and many one-tile items keep the other slots streaming until then where groups of three all start at
+            // t = 0 and leave them idle (profiles/r5_flatten_vs_node_aligned.txt: DeFT-Node's one-item-per-tile plan beat Flatten by
+            // 1.0-1.5 us per layer there).  Groups that MIX full tiles with the straddling tiles around them stay: un-grouping every
+            // full tile cost the 200- / 300- / 400-token trees 1.7-2.5 us per layer (profiles/r6_solo_full_tiles.txt)
+            if (solo_full && live && li == 0 && cnt == 1 && t < NBreg && (int)block_lens[t] == TILE) bits |= 16;
             if (live && li == 0) sOpen[t] = bits;
         }
     }
@@ -518,9 +526,12 @@ __global__ __launch_bounds__(1024) void flatten_units_kernel(const int64_t* bloc
                     int uq[UNION_CAP], urow[UNION_CAP], un;
                     g = union_group(t, NBreg, ulen, ucap, sCnt, sOff, qtab ? sQ : nullptr, block_q, uq, urow, un);
                     if (g < 2) g = 0;
+                    bool all_solo = g >= 2;  // (nothing but full tiles of one query each: no group)
+                    for (int u = t; u < t + g; ++u) all_solo &= (sOpen[u] & 16) != 0;
+                    if (all_solo) g = 0;
                 }
             }
-            sOpen[t] = (sOpen[t] & 0xf) | (g << 8);
+            sOpen[t] = (sOpen[t] & 0x1f) | (g << 8);
         }
     __syncthreads();
     // Phase 2: wave 0 walks the blocks and decides the runs (every lane takes the same decisions; the lanes only split
