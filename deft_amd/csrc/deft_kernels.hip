@@ -881,7 +881,7 @@ using namespace deft;
 
 extern "C" {
 
-int deft_abi_version(void) { return 1; }
+int deft_abi_version(void) { return 2; }  // (2: deft_tree_layout swallows the pending journal; window plans; deft_stage_fetch)
 
 // Everything a plan's layout depends on besides the caller's arguments.  The shipped library has no such thing (0);
 // the experiments build folds its plan knobs into the value, so that callers which cache plans key them by it.

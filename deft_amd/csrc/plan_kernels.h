@@ -868,6 +868,7 @@ __global__ __launch_bounds__(1024) void node_units_kernel(const int64_t* node_kv
         sListPtr[0] = node_q;
         sListPtr[1] = node_q_offset;
     }
+    __builtin_amdgcn_wave_barrier();  // (lane 0's stores in front of the other lanes' reads of wave 0 -- made explicit)
     if (threadIdx.x < 64) {
         for (int attempt = 0; attempt < 2; ++attempt) {
             par = par_req && attempt == 0;
@@ -917,6 +918,9 @@ __global__ __launch_bounds__(1024) void node_units_kernel(const int64_t* node_kv
               // this one is one tile, and both have the same query list?  Nothing is read, shuffled or counted unless some entry of
               // the batch is exactly one full tile (uniform test: ordinary Node metadata -- whole nodes -- skips all of it; computed
               // per entry inside the walk this cost a Medusa step's plan 3-5 us).  vmore: entries that continue lane i's run.
+              // (A run is detected INSIDE a batch of 64 entries: lane 0 of a batch never continues the previous batch's run, so a
+              //  node_chunk run that straddles a batch boundary is cut there -- two runs, two partial rows per query instead of one:
+              //  it costs folding, not correctness.  ADVICE r5.)
               int vmore = 0;
               if (__ballot(mine < NE && vlen == TILE) != 0ull) {
                   bool cont = false;

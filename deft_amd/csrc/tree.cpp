@@ -596,6 +596,15 @@ int deft_tree_layout(int64_t tree, int slack, int64_t sizes[5]) {
         set_error("deft_tree_layout: the tree has no root, unreachable nodes, or more than 2^31 slots");
         return DEFT_EINVAL;
     }
+    // A caller of this function is about to fetch an upload image, which holds every change made so far, journalled or not: the
+    // pending journal is swallowed HERE (see deft_tree_layout_fetch for why that ends the epoch for every other device copy), so that
+    // sizes[4] already is the epoch the image will carry -- a C caller that adopts it, the documented pattern, no longer sees a
+    // mismatch at its next sync (until round 5 the bump happened inside the fetch, behind the number handed out here).
+    if (!t->journal.empty()) {
+        ++t->epoch;
+        t->journal.clear();
+        t->last_ext = -1;
+    }
     sizes[0] = (int64_t)t->lay.dfs.size();
     sizes[1] = (int64_t)t->lay.leaf_node.size();
     sizes[2] = t->lay.nqw;
@@ -649,6 +658,7 @@ int deft_tree_layout_fetch(int64_t tree, int32_t* node_start, int32_t* node_len,
     // pending EXTENDs twice).  Any OTHER device copy of this epoch still lacks those changes and can no longer get them from
     // the journal: a non-empty journal therefore ends the epoch for everyone (the layout itself stays valid -- the caller
     // of this function adopts the new epoch number, every other copy sees a mismatch and uploads).
+    // (deft_tree_layout has already done this for the journal it found; what is caught here are changes journalled BETWEEN the two calls.)
     if (!t->journal.empty()) ++t->epoch;
     t->journal.clear();
     t->last_ext = -1;

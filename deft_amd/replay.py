@@ -134,14 +134,16 @@ def branch_few_shot(tree: TreeCache, iter: int, max_gen_len: int, logits: torch.
         for leaf in tree.leaves.values():
             tree.output_branch(dstnode=leaf)
         return True
+    # (ONE conversion of the scores per step, arg-max and top-k taken from it: with GPU probabilities -- tree_generate passes the
+    #  [nq, vocab] softmax -- every further _scores() call was another device-to-host copy and host sync of the whole matrix.  ADVICE r5)
     x = _scores(logits)
     if iter == 0:
-        ids = _topk_ids(logits, 0, width)
+        ids = _topk_ids(x, 0, width)
         for j, leaf in enumerate(tree.branch(tree.root, width)):
             tok = int(ids[j % len(ids)])
             leaf.append_token(tok, logprob=float(np.log(x[0, tok])))  # (:36-48: the scores are probabilities)
     else:
-        greedy = _greedy(logits)
+        greedy = x.argmax(axis=1)
         for leaf in tree.leaves.values():
             row = tree.leaf_to_q[leaf.id]
             leaf.append_token(int(greedy[row]), logprob=float(np.log(x[row, greedy[row]])))

@@ -401,12 +401,13 @@ int64_t deft_tree_build_md(int64_t tree, int max_q_len, int block_len, int max_b
  *   deft_tree_layout        nodes in DFS pre-order, room for `slack` more tokens per live leaf; sizes = {nodes, queries,
  *                           64-bit words per leaf set, total slot capacity, epoch}.  The layout (and the device copy made from
  *                           deft_tree_layout_fetch) stays valid while the epoch does: deft_tree_alloc_step keeps it as long as
- *                           every leaf has room; every other mutation bumps it.
- *   deft_tree_layout_fetch  fills the upload image of that layout.  SIDE EFFECT: the image holds every change made so far, so
- *                           the journal of absorbed changes (deft_tree_journal_take) is CLEARED -- and when it was not empty the
- *                           epoch is bumped (the layout stays valid): other device copies of the old epoch never saw those
- *                           changes and must upload.  Read the epoch AFTER this call (deft_tree_stats), not from
- *                           deft_tree_layout's sizes[4].
+ *                           every leaf has room; every other mutation bumps it.  SIDE EFFECT (ABI version 2): the caller is about
+ *                           to fetch an image that holds every change made so far, so the journal of absorbed changes
+ *                           (deft_tree_journal_take) is CLEARED here -- and when it was not empty the epoch is bumped first (the
+ *                           layout stays valid): other device copies of the old epoch never saw those changes and must upload.
+ *                           sizes[4] is the epoch the image will carry.
+ *   deft_tree_layout_fetch  fills the upload image of that layout (and swallows, the same way, whatever was journalled between the
+ *                           two calls: a caller that mutates the tree in between reads the epoch again, deft_tree_stats).
  *   deft_tree_md_sizes      sizes of the metadata for the current lengths + `grow` tokens per leaf: sizes[0..7] as
  *                           deft_md_sizes, sizes[8] = physical 128-slot blocks (capacity planning and tensor shapes; no slot touched)
  *   deft_tree_dev_advance   device: append cache_loc[r] to query row r's leaf (kept ascending inside the node)

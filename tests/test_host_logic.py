@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     so = ctypes.CDLL(LIB_PATH)
     for name in declared:
         assert hasattr(so, name), name
-    assert so.deft_abi_version() == 1
+    assert so.deft_abi_version() == 2
 
 
 def test_library_exports_nothing_but_the_declared_symbols():
