@@ -54,7 +54,7 @@ static float rnd(void) { /* a dyadic value in [-2, 2): exact in fp16 */
 enum { HQ = 4, HKV = 2, D = 128, NQ = 2, SLOTS = 512, NB = 4, P = 6, PREFIX = 150, LEN0 = 40, LEN1 = 7 };
 
 int main(void) {
-    if (deft_abi_version() != 1 || !deft_supported(HQ, HKV, D)) {
+    if (deft_abi_version() != 2 || !deft_supported(HQ, HKV, D)) {
         fprintf(stderr, "abi / geometry\n");
         return 1;
     }
