@@ -2054,7 +2054,7 @@ extern "C" {
 /* 1 when a tree step of this shape can run on a window plan: every (query chunk, 32-row pass) pair that hosts the overflow tiles
  * has a place in the tables. */
 int deft_window_supported(int nq, int max_q_len, int Hq, int Hkv) {
-    if (nq <= 0 || max_q_len < 1 || max_q_len > 63 || Hq <= 0 || Hkv <= 0 || Hq % Hkv) return 0;
+    if (nq <= 0 || max_q_len < 1 || max_q_len > MQ || Hq <= 0 || Hkv <= 0 || Hq % Hkv) return 0;  // (at most one 32-query tile per chunk)
     const int G = Hq / Hkv;
     const int chunks = (nq + max_q_len - 1) / max_q_len;
     const int passes = (std::min(nq, max_q_len) * G + MQ - 1) / MQ;

@@ -171,6 +171,17 @@ def _decode_step(mode, md, input_metadata, q, k, Hq, Hkv, D):
     return step
 
 
+def _check_query_tile(md) -> None:
+    """The operators fold at most 32 queries per block / entry -- the reference's BLOCK_M = 32 (tree_attention.py:98, :586).  Metadata
+    built with a coarser `max_q_len` is what the reference's builder would emit, but no kernel of either implementation reads it
+    right: refused loudly (found by tools/fuzz_session.py, round 6)."""
+    if getattr(md, "max_q_len", 32) > 32:
+        from ._lib import DeftLibraryError
+
+        raise DeftLibraryError(f"TreeMetadata was built with max_q_len={md.max_q_len}: the attention operators take at most 32 queries "
+                               "per block (the reference's BLOCK_M)")
+
+
 class DeFTAttention(nn.Module):
     def __init__(self, num_heads: int, head_dim: int, scaling: float, num_kv_heads: int, layer_id: int) -> None:
         super().__init__()
@@ -188,6 +199,7 @@ class DeFTAttention(nn.Module):
                           input_metadata: InputMetadata) -> torch.Tensor:
         md = get_global_tree_metadata()
         assert md is not None
+        _check_query_tile(md)
         assert input_metadata.token_to_kv_pool is not None
         step = _decode_step(ForwardMode.TREE_DECODE_NODE, md, input_metadata, q, k, self.tp_q_head_num,
                             self.tp_k_head_num, self.head_dim)
@@ -222,6 +234,7 @@ class DeFTAttention(nn.Module):
                              input_metadata: InputMetadata) -> torch.Tensor:
         md = get_global_tree_metadata()
         assert md is not None
+        _check_query_tile(md)
         assert input_metadata.token_to_kv_pool is not None
         step = _decode_step(ForwardMode.TREE_DECODE_FLATTEN, md, input_metadata, q, k, self.tp_q_head_num,
                             self.tp_k_head_num, self.head_dim)

@@ -69,6 +69,9 @@ class DecodeSession:
         assert pool.device.type == "cuda" and mode in ("flatten", "node")
         assert head_dim == 128 or (head_dim == 64 and num_kv_heads % 2 == 0), "DecodeSession: head_dim 128, or 64 with an even number of KV heads"
         assert capture_after == "auto" or int(capture_after) >= 1
+        # (the operators fold at most 32 queries per block / entry -- the reference's BLOCK_M = 32, tree_attention.py:98, :586 -- so
+        #  the metadata must not chunk the queries any coarser; tools/fuzz_session.py runs 7 / 16 / 32)
+        assert 1 <= int(max_q_len) <= 32, "DecodeSession: max_q_len between 1 and 32 (the attention operators' query tile)"
         self.capture_after = capture_after
         self._epoch_steps = 0       # steps of the current epoch so far (its eager first one included)
         self._last_epoch_steps = 1 << 30
@@ -96,6 +99,7 @@ class DecodeSession:
         self._stage_no = 0   # steps staged so far (== the device counter once the GPU has caught up)
         self._ctr = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.win = 0  # native books of the epoch's window plans (deft_window_create), 0 = none
+        self.debug, self.last_staged = False, None
 
     def __del__(self) -> None:
         try:
@@ -178,7 +182,7 @@ class DecodeSession:
         ob = cb + 16 * nqm
         pb = (ob + 4 * (self.ops_cap + 1) + 255) // 256 * 256
         self.patch_cap = (4 * nqm + 64 + 2 * nqm * regions) if W else 0  # (a slot merged into the root is an entry in every region)
-        self._small = torch.zeros(pb + 4 * (1 + 64 + 3 * self.patch_cap), dtype=torch.uint8, device=dev)
+        self._small = torch.zeros((pb + 4 * (1 + 64 + 3 * self.patch_cap) + 15) // 16 * 16, dtype=torch.uint8, device=dev)  # (fetched in 16-byte chunks)
         self.cache_loc = self._small[: 4 * nqm].view(torch.int32)
         self.idx = self._small[cb:ob].view(torch.int64).view(2, nqm)
         self.ops = self._small[ob:pb].view(torch.int32)
@@ -426,6 +430,9 @@ class DecodeSession:
                 kind = "legacy"
             else:
                 used += 4 * words
+        if self.debug:  # (tools/fuzz_session.py: what this step staged, for a failure report)
+            self.last_staged = {"kind": kind, "journal": self._journal[:journal_words].copy(), "loc": loc32.copy(),
+                                "patch": h[self._patch_off : used].view(np.int32).copy() if kind != "legacy" else None}
         slot[:4].view(np.uint32)[0] = used  # (only what this step wrote crosses PCIe: the journal and patch areas are sized for the worst step)
         return kind
 

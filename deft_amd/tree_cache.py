@@ -873,7 +873,9 @@ class TreeMetadata:
             views = dt.build()
             if copy:
                 views = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in views.items()}
-            return cls(block_len=block_len, **views)
+            md = cls(block_len=block_len, **views)
+            md.max_q_len = int(max_q_len)  # (the operators check it: at most 32 queries per block, deft_attention.py)
+            return md
         if dev.type == "cpu":
             host = build_metadata_host(tree, max_q_len, block_len, max_block_len)
             packed = torch.from_numpy(host["_packed"])
@@ -901,10 +903,12 @@ class TreeMetadata:
             n = host["_lens"][k]
             views[k] = packed[off : off + n]
             off += n
-        return cls(
+        md = cls(
             query_num=host["query_num"], node_num=host["node_num"], total_kv_len=host["total_kv_len"],
             leaf_to_q=host["leaf_to_q"], block_len=block_len, **views,
         )
+        md.max_q_len = int(max_q_len)
+        return md
 
 
 GLOBAL_TREE_METADATA: Optional[TreeMetadata] = None

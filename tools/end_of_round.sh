@@ -3,7 +3,7 @@
 # bench line, the rocprofv3 kernel-trace summary of the STEP graph alone and the two PMC passes (own runs, --kernel-trace
 # only), the two-rank rehearsal of the N > 1 path over gloo, the fuzzers.  Writes gpurun_out/<tag>/<tag>_*; the files judged are
 # copied from there into profiles/ (see profiles/README.md).
-TAG=${1:-r5z}
+TAG=${1:-r6z}
 R=$GRAFT_REPO_ROOT; export PYTHONPATH=$R; O=$R/gpurun_out/$TAG; mkdir -p $O
 cd $R
 # replays: through the captured session (default) -- per-step synchronised (per-step attention times) and pipelined (the loop as a
@@ -21,6 +21,13 @@ timeout 300 python tools/replay.py --task reasoning --beam 10,12,8 --prompt-len 
 timeout 300 python tools/replay.py --task reasoning --beam 10,12,8 --prompt-len 4096 --modes flatten --pipelined --out $O/${TAG}_replay_reasoning_beam10x8_pipelined.json > $O/replay_beamp.log 2>&1
 # the reference's OWN reasoning template (first complete tree of docmergeToT.json: 31 nodes, a 1073-token prompt, 2375 decode steps), whole
 timeout 600 python tools/replay.py --task reasoning --golden-template docmergeToT --max-gen-len 100000 --modes flatten node --pipelined --out $O/${TAG}_replay_reasoning_docmergeToT_pipelined.json > $O/replay_docmerge.log 2>&1
+# round 6: the same replays through sessions that rebuild metadata and plan on every step (DecodeSession(incremental=False), the round-5 loop)
+timeout 300 python tools/replay.py --task few_shot --width 32 --prompt-len 4096 --max-gen-len 200 --modes flatten --pipelined --legacy --out $O/${TAG}_replay_few_shot_4kx32_pipelined_rebuild.json > $O/replay_fspl.log 2>&1
+timeout 300 python tools/replay.py --task speculative_decoding --modes node flatten --tree-size 64 --pipelined --legacy --out $O/${TAG}_replay_speculative_64_pipelined_rebuild.json > $O/replay_sdpl.log 2>&1
+timeout 300 python tools/replay.py --task speculative_decoding --modes node flatten --tree-size 64 --legacy --out $O/${TAG}_replay_speculative_64_rebuild.json > $O/replay_sdl.log 2>&1
+timeout 300 python tools/replay.py --task reasoning --modes flatten node --pipelined --legacy --out $O/${TAG}_replay_reasoning_tot50_pipelined_rebuild.json > $O/replay_totpl.log 2>&1
+timeout 300 python tools/replay.py --task reasoning --model llama3-8b --modes flatten --pipelined --out $O/${TAG}_replay_reasoning_tot50_llama3_pipelined.json > $O/replay_tot3p.log 2>&1
+timeout 300 python tools/replay.py --task reasoning --model llama3-8b --modes flatten --pipelined --legacy --out $O/${TAG}_replay_reasoning_tot50_llama3_pipelined_rebuild.json > $O/replay_tot3pl.log 2>&1
 timeout 900 python bench.py > $O/${TAG}_bench_default.json 2> $O/bench.err
 # the N > 1 path on one GPU: two ranks over gloo (RCCL needs a GPU per rank; the driver's 8-GPU run uses it)
 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --dist-backend gloo --steps 50 --warmup 10 --no-extras --no-cpu-baseline --no-traffic 2> $O/bench_2rank.err | grep '^{' > $O/${TAG}_bench_2rank_gloo_one_gpu.json
@@ -58,15 +65,24 @@ timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_rp_$TAG -- python $R/t
 python $R/tools/prof_summary.py /tmp/prof_rp_$TAG 2>&1 | head -18 | cut -c1-160 > $O/${TAG}_replay_kernel_stats.txt
 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_sd_$TAG -- python $R/tools/replay.py --task speculative_decoding --modes flatten --tree-size 64 --pipelined --no-warmup > /dev/null 2>&1
 python $R/tools/prof_summary.py /tmp/prof_sd_$TAG 2>&1 | head -18 | cut -c1-160 > $O/${TAG}_replay_speculative_kernel_stats.txt
+# round 6: what stands between two steps' layers -- window plans against the rebuild-every-step loop (kernel trace of a pipelined replay)
+for leg in "" "--legacy"; do
+  timeout 600 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d /tmp/kt_b_$TAG$leg -- python $R/tools/replay.py --task few_shot --width 32 --prompt-len 4096 --max-gen-len 200 --modes flatten --pipelined --no-warmup $leg > /dev/null 2>&1
+  (echo "== tools/replay.py --task few_shot --width 32 --prompt-len 4096 --max-gen-len 200 --modes flatten --pipelined --no-warmup $leg"; python $R/tools/step_boundary.py /tmp/kt_b_$TAG$leg 1) >> $O/${TAG}_step_boundary.txt 2>&1
+done
+# ... and attention IN SITU: the model-shaped step (dense layer kernels between the attention calls) under the kernel trace
+timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_situ_$TAG -- python $R/bench.py --in-situ-only > $O/${TAG}_in_situ_under_rocprof.json 2>/dev/null
+python $R/tools/prof_summary.py /tmp/prof_situ_$TAG 2>&1 | head -8 | cut -c1-170 > $O/${TAG}_in_situ_kernel_stats.txt
 cd $R
 # rounds 3, 4 and 5 -- each round's own tree (prev/, see .gitignore) on its own library -- in turn on THIS box: the table of DESIGN 4b
-if [ -d prev/r3 ] && [ -d prev/r4 ]; then
-  timeout 1500 tools/ab_rounds.sh "northstar_4kx32 fewshot_1kx32 medusa64_node tot50_4k forest_8kx8 forest_8kx8_single gqa_4kx32 northstar_4kx32_d64 northstar_4kx32_node" prev/r3 prev/r4 . > $O/${TAG}_ab_rounds.txt 2>&1
-  timeout 600 tools/ab_e2e.sh prev/r4 . > $O/${TAG}_ab_e2e.txt 2>&1
+PREV=$(ls -d prev/r* 2>/dev/null | sort | tr '\n' ' ')
+if [ -n "$PREV" ]; then
+  timeout 1500 tools/ab_rounds.sh "northstar_4kx32 fewshot_1kx32 medusa64_node tot50_4k forest_8kx8 forest_8kx8_single gqa_4kx32 northstar_4kx32_d64 northstar_4kx32_node" $PREV . > $O/${TAG}_ab_rounds.txt 2>&1
+  timeout 600 tools/ab_e2e.sh $(ls -d prev/r* | sort | tail -1) . > $O/${TAG}_ab_e2e.txt 2>&1
 fi
 # the whole GPU suite on this box
 timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -4 > $O/${TAG}_gputest.txt
 # fuzzers: the captured loop against the eager path bit for bit (with speculative-decoding merge / reset steps); every step of random
 # replays against fp64 attention
-(timeout 400 python tools/fuzz_session.py 240 ${FUZZ_SEED:-31} 2>&1 | tail -2; timeout 300 python tools/fuzz_replay.py 180 ${FUZZ_SEED:-31} 2>&1 | tail -2) > $O/${TAG}_fuzz.txt
+(timeout 400 python tools/fuzz_session.py 240 ${FUZZ_SEED:-31} mix 2>&1 | tail -2; timeout 300 python tools/fuzz_replay.py 180 ${FUZZ_SEED:-31} 2>&1 | tail -2) > $O/${TAG}_fuzz.txt
 cat $O/${TAG}_fuzz.txt
