@@ -70,6 +70,30 @@ vals = {
     "FS": per_step(replay("few_shot_4kx32", "flatten")), "2R": two["ms_per_step"],
 }
 vals["TOTR"] = per_step(replay("reasoning_tot50", "flatten"))
+# round 6: window plans against the rebuild-every-step loop, the run-level fraction, attention in situ
+def opt(fn, default="n/a"):
+    try:
+        return fn()
+    except Exception:
+        return default
+
+
+fr = b.get("few_shot_run") or {}
+situ = b.get("in_situ") or {}
+vals.update({
+    "E2EL": opt(lambda: e["graphed_rebuild_every_step"]["ms_per_step"]), "RATIOL": opt(lambda: e["graphed_rebuild_every_step"]["over_frozen_step_at_mean_len"]),
+    "RUNFRACL": opt(lambda: fr["rebuild_every_step"]["run_hbm_frac"]), "RUNFRAC": opt(lambda: fr["window_plans"]["run_hbm_frac"]),
+    "RUNMS": opt(lambda: fr["window_plans"]["ms_per_step"]),
+    "SWEEP": opt(lambda: ", ".join(f"{v['step_hbm_frac']} at {k}" for k, v in fr["by_branch_len"].items())),
+    "SITUB": opt(lambda: situ["attention_us_per_layer_back_to_back"]), "SITU": opt(lambda: situ["attention_us_per_layer_in_situ"]),
+    "SDL": opt(lambda: per_step(replay("speculative_64_pipelined_rebuild", "flatten"))),
+    "SDNL": opt(lambda: per_step(replay("speculative_64_pipelined_rebuild", "node"))), "SDN": opt(lambda: per_step(replay("speculative_64_pipelined", "node"))),
+    "SDSL": opt(lambda: per_step(replay("speculative_64_rebuild", "flatten"))),
+    "TOTPL": opt(lambda: per_step(replay("reasoning_tot50_pipelined_rebuild", "flatten"))), "TOTP": opt(lambda: per_step(replay("reasoning_tot50_pipelined", "flatten"))),
+    "TOT3PL": opt(lambda: per_step(replay("reasoning_tot50_llama3_pipelined_rebuild", "flatten"))),
+    "TOT3P": opt(lambda: per_step(replay("reasoning_tot50_llama3_pipelined", "flatten"))),
+    "FSPL": opt(lambda: per_step(replay("few_shot_4kx32_pipelined_rebuild", "flatten"))), "FSP": opt(lambda: per_step(replay("few_shot_4kx32_pipelined", "flatten"))),
+})
 rf = b["roofline"]
 vals.update({"CEIL": rf.get("ceiling_us", "n/a"), "OVERCEIL": rf.get("launch_over_ceiling", "n/a"),
              "8R": eight["ms_per_step"] if eight else "n/a", "RCCL": rccl["ms_per_step"] if rccl else "n/a"})

@@ -64,6 +64,38 @@ __global__ __launch_bounds__(256, 2) void rd_gather(const char* pool, const int*
     if (reinterpret_cast<unsigned*>(smem)[tid] == 0x12345678u) out[0] = 1;
 }
 
+// TWO tiles in flight per wave (the gather above is a depth-1 pipeline -- tile i + 1 is requested when tile i has
+// landed -- so is its number a ceiling?).  Double-buffered slices: 128 KB of LDS per workgroup, hence ONE workgroup per CU instead
+// of two; tile i + 2 is requested as soon as tile i has landed (counted s_waitcnt: 16 requests may stay in flight).
+__global__ __launch_bounds__(256, 1) void rd_gather_d2(const char* pool, const int* slots, int tiles, int S, int Hkv, int slot_bytes,
+                                                       unsigned* out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63;
+    const int chunk = blockIdx.x / Hkv, head = blockIdx.x % Hkv;
+    const char* kb = pool + (size_t)head * 256 + (l & 15) * 16;
+    const char* vb = kb + (size_t)Hkv * 256;
+    auto issue = [&](int t, int buf) {
+        const int* sl = slots + (size_t)t * 128 + 32 * w;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const size_t row = (size_t)sl[4 * i + (l >> 4)] * slot_bytes;
+            dma16nt(kb + row, (unsigned)(buf * 65536 + w * 8192 + i * 1024));
+            dma16nt(vb + row, (unsigned)(buf * 65536 + 32768 + w * 8192 + i * 1024));
+        }
+    };
+    int t = chunk, buf = 0;
+    if (t < tiles) issue(t, 0);
+    for (; t < tiles; t += S, buf ^= 1) {
+        if (t + S < tiles) {
+            issue(t + S, buf ^ 1);
+            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");  // tile t has landed, tile t + S is in flight
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    }
+    if (reinterpret_cast<unsigned*>(smem)[tid] == 0x12345678u) out[0] = 1;
+}
+
 // The same bytes per step and per wave, but a workgroup serves a GROUP of HG adjacent KV heads: a step stages 128 (token, head)
 // rows, head fastest -- the HG heads of one token are HG x 256 contiguous bytes of the pool ([slot][K|V][Hkv][128]), so every
 // token contributes one 512-byte / 1-KB burst instead of a 256-byte piece per workgroup (would a small launch
@@ -116,6 +148,7 @@ int main() {
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
     CK(hipFuncSetAttribute((const void*)rd_gather, hipFuncAttributeMaxDynamicSharedMemorySize, 77 * 1024));
+    CK(hipFuncSetAttribute((const void*)rd_gather_d2, hipFuncAttributeMaxDynamicSharedMemorySize, 130 * 1024));
     CK(hipFuncSetAttribute((const void*)rd_gather_hg<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 77 * 1024));
     CK(hipFuncSetAttribute((const void*)rd_gather_hg<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 77 * 1024));
     // an empty launch, back to back: the fixed cost of a kernel boundary on this stream
@@ -185,6 +218,16 @@ int main() {
             snprintf(what, sizeof what, "gather, %d-tile chunks: %d workgroups", C, S * s.Hkv);
             run(what, [&](const char* base) {
                 hipLaunchKernelGGL(rd_gather, dim3(S * s.Hkv), dim3(256), 77 * 1024, 0, base, dslots, tiles, S, s.Hkv, slot_bytes, o);
+            });
+        }
+        // two tiles in flight per wave, one workgroup per CU (a question about pipeline depth, not part of the shape's ceiling unless it wins)
+        for (int C : {2, 4, 8}) {
+            if (tiles / C < 1) continue;
+            const int S = (tiles + C - 1) / C;
+            char what[96];
+            snprintf(what, sizeof what, "gather depth 2, %d-tile chunks: %d workgroups", C, S * s.Hkv);
+            run(what, [&](const char* base) {
+                hipLaunchKernelGGL(rd_gather_d2, dim3(S * s.Hkv), dim3(256), 130 * 1024, 0, base, dslots, tiles, S, s.Hkv, slot_bytes, o);
             });
         }
         // head groups: the same steps per workgroup as the 1-head row of C tiles (C = HG x tiles per chunk)
