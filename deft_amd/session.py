@@ -383,6 +383,13 @@ class DecodeSession:
             self._ring_events[k] = torch.cuda.Event()  # (re-recorded: not one hipEventCreate per step)
         self._ring_events[k].record(torch.cuda.current_stream(self.device))
 
+    def device_errors(self) -> int:
+        """Error flags the step's kernels raised on the device since the epoch's upload (SYNCHRONISES; tests and fuzzers call it at
+        the end of a run): bit 0 a leaf outgrew its room, bit 1 more blocks than the buffers hold, bit 2 a malformed journal, bit 3 a
+        window plan's overflow tiles or patch entries out of range.  0 = none."""
+        torch.cuda.current_stream(self.device).synchronize()
+        return int(self.dt.scratch[:64].view(torch.int32)[9].item())
+
     def _moved(self) -> None:
         """This session's launches have advanced the device copy of the tree."""
         self.dt.version += 1

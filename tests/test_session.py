@@ -87,6 +87,7 @@ def test_session_equals_eager_step_for_step(use_graph, mode, incremental):
         tree.branch(lv[0], 3)
     both_steps(20)
     assert sess.captures == (2 * per_epoch if use_graph else 0)
+    assert sess.device_errors() == 0  # (no kernel of any step flagged anything: room, capacities, journal, window tables)
 
 
 @pytest.mark.parametrize("incremental", [False, True])
@@ -200,6 +201,7 @@ def test_session_speculative_decoding_steps_replay_one_graph(mode, incremental):
     assert sess.captures <= (3 if incremental else 2), sess.captures
     if incremental:  # a leaf is reset and refilled every step: its overflow position is reused, the window lasts
         assert sess.step_kinds["patch"] >= 30 and sess.step_kinds["legacy"] == 0, sess.step_kinds
+    assert sess.device_errors() == 0
 
 
 @pytest.mark.parametrize("capture_after", [1, 3, "auto"])

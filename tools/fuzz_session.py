@@ -172,6 +172,7 @@ while time.time() < t_end:
         assert sess.captures - cap_before <= (3 if not inc else 9) + sd_steps // 200, (sess.captures - cap_before, sd_steps)  # not one epoch per step
         sd_runs += 1
     captures += sess.captures
+    assert sess.device_errors() == 0, ("device error flags", sess.device_errors(), runs)
     inc_runs += int(inc)
     for kk in kinds:
         kinds[kk] += sess.step_kinds[kk]
