@@ -174,9 +174,9 @@ class DecodeSession:
             self.ws_bytes = int(lib.deft_node_workspace_bytes(self.NE, self.PN, self.TKV, self.nq, Hq, Hkv, D))
         self.plan = torch.empty(max(self.plan_bytes, 1), dtype=torch.uint8, device=dev)
         self.ws = torch.empty(max(self.ws_bytes, 1), dtype=torch.uint8, device=dev)
-        # what the host supplies per step, in ONE allocation (one upload):
+        # what the host supplies per step, in ONE allocation (fetched from the pinned ring by the step's first kernel):
         # [cache_loc int32[nq] | page-table coordinates int64[2][nq] | journal of absorbed changes int32 {words, ...} |
-        #  window plan: patch list int32 {entries, active tiles, {position, node, slot} ...}]
+        #  window plan: patch list int32 {entries, active tiles of 64 regions, {region << 20 | position, row mask, slot | new row} ...}]
         cb = (4 * nqm + 255) // 256 * 256
         self.ops_cap = 64 + 8 * nqm  # one EXTEND of up to nq slots and a RESET per leaf, with room to spare (a speculative-decoding step)
         ob = cb + 16 * nqm
