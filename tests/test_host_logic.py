@@ -458,6 +458,25 @@ def test_header_and_library_serve_a_plain_c_program(tmp_path):
     assert os.path.getsize(exe) > 0
 
 
+def test_window_books_from_a_plain_c_program(tmp_path):
+    """The window plan's host-side entry points (deft_window_supported / _create / _step / _free) called from C11 through the header
+    alone: host-only, so this one RUNS here (tests/c_abi/window_books_from_c.c)."""
+    import shutil
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib_dir = os.path.join(root, "deft_amd", "lib")
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    exe = str(tmp_path / "window_books_from_c")
+    cmd = ["gcc", "-std=c11", "-O1", "-Wall", "-Werror", "-I", os.path.join(root, "include"), os.path.join(root, "tests", "c_abi", "window_books_from_c.c"),
+           "-L", lib_dir, "-ldeft_amd", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib", "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+
+
 def test_finished_branches_are_recorded_and_printed(capsys):
     """TreeCache.output_branch / print_finished_branches (tree_cache.py:525-567): the branch below the root, its cumulative
     log-probability and perplexity."""
