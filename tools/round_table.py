@@ -28,8 +28,8 @@ for line in open(src):
     if tree not in trees:
         trees.append(tree)
     vals[wl][tree].append(float(us))
-name = {"prev/r3": "round 3", "prev/r4": "round 4", ".": "round 5"}
-t = ("**Round 3 → 4 → 5 on ONE box** (`%s`: `tools/ab_rounds.sh`, every round's own tree and library in turn, mean of the repetitions; "
+name = {"prev/r3": "round 3", "prev/r4": "round 4", "prev/r5": "round 5", ".": "this tree"}
+t = ("**Rounds on ONE box** (`%s`: `tools/ab_rounds.sh`, every round's own tree and library in turn, mean of the repetitions; "
      "process to process ±0.3 µs), µs per layer of the captured 32-layer step:\n\n| workload | %s |\n|---|%s\n"
      % (os.path.relpath(src, ROOT), " | ".join(name.get(x, x) for x in trees), "---|" * len(trees)))
 for wl, label in LABEL.items():
