@@ -154,6 +154,22 @@ __device__ inline void np_record_order(const UnitList& ul, int R, int Hkv, int G
         // shared prefix is one more partial row for EVERY query below it, and the merge reads its rows 16 at a time
         // (one 8192-token prefix under 8 branches, Llama-3-8B: 32 chunks of 2 tiles 23.7 us per layer, 16 of 4 tiles 21.1).
         while (C < 8 && lmax > 16 * C) C <<= 1;
+        // MHA, a shared prefix that DOMINATES the tree (round 6, profiles/r6_chunk_sweep_short.txt): with 8-tile chunks a 4096-token
+        // prefix is 4 chunks per KV head -- 128 workgroups for 80 % of the launch's bytes when the branches are short, half the CUs
+        // pulling on them, each through a serial chain of 8 tiles.  While the rest of the tree is no larger than the prefix (T_other
+        // <= lmax) and the prefix's chunks do not fill the CUs, it is cut into 6 chunks (5-6 tiles), into 7 (4-5 tiles) while the
+        // rest is at most a quarter of it: north-star tree at 1 / 25 / 50 / 100 / 125 tokens per branch 20.7 -> 18.9, 23.9 -> 21.3,
+        // 25.0 -> 23.4, 29.6 -> 27.7, 30.7 -> 29.3 us per layer; from 150 tokens on (and for every other BASELINE shape) nothing
+        // changes -- there the leaf items keep the other CUs busy and longer chunks mean fewer partial rows.
+        if (G == 1 && !pairs && C == 8) {
+            int64_t tiles_all = 0, n8 = 0;
+            for_runs([&](int, int nt, int uni) {
+                tiles_all += nt;
+                n8 += uni ? 1 : (nt + 7) / 8;
+            });
+            const int64_t t_other = tiles_all - lmax;
+            if ((int64_t)((lmax + 7) / 8) * Hkv * 2 < slots && t_other <= lmax && n8 * Hkv * 4 <= 5LL * slots) C = (4 * t_other <= lmax) ? 5 : 6;
+        }
         // A launch that leaves CUs empty (fewer chunks than CUs = slots / 2) takes the next shorter chunk length -- powers
         // of two or not -- as long as that still fits one workgroup per CU: Medusa-64 (an 8-tile root under two query
         // chunks, 32 KV heads) 192 workgroups of 4 tiles -> 256 of 3: 15.8 -> 14.9 us per layer.  Such a launch may also cut its
@@ -248,6 +264,12 @@ __device__ inline void record_order_wave0(const RunTable& rt, int NR, int* rT0, 
                 if ((pairs ? 4 : 10) * n * Hkv >= 3LL * slots) break;
             }
             while (C < 8 && lmax > 16 * C) C <<= 1;  // (np_record_order: at most 16 chunks per run while C < 8)
+            if (G == 1 && !pairs && C == 8) {  // (np_record_order: a shared prefix that dominates an MHA tree is cut shorter)
+                const int64_t tiles_all = wave_sum([](int nt, int) { return nt; });
+                const int64_t n8 = wave_sum([](int nt, int uni) { return uni ? 1 : (nt + 7) / 8; });
+                const int64_t t_other = tiles_all - lmax;
+                if ((int64_t)((lmax + 7) / 8) * Hkv * 2 < slots && t_other <= lmax && n8 * Hkv * 4 <= 5LL * slots) C = (4 * t_other <= lmax) ? 5 : 6;
+            }
             if (C > 2 && lmax <= 24 * (C - 1)) {       // (np_record_order: fill the CUs of a launch that leaves some empty)
                 const int64_t n0 = wave_sum([C](int nt, int uni) { return uni ? 1 : (nt + C - 1) / C; });
                 const int64_t n1 = wave_sum([C](int nt, int uni) { return uni ? 1 : (nt + C - 2) / (C - 1); });
