@@ -157,8 +157,8 @@ __device__ inline void np_record_order(const UnitList& ul, int R, int Hkv, int G
         // MHA, a shared prefix that DOMINATES the tree (round 6, profiles/r6_chunk_sweep_short.txt): with 8-tile chunks a 4096-token
         // prefix is 4 chunks per KV head -- 128 workgroups for 80 % of the launch's bytes when the branches are short, half the CUs
         // pulling on them, each through a serial chain of 8 tiles.  While the rest of the tree is no larger than the prefix (T_other
-        // <= lmax) and the prefix's chunks do not fill the CUs, it is cut into 6 chunks (5-6 tiles), into 7 (4-5 tiles) while the
-        // rest is at most a quarter of it: north-star tree at 1 / 25 / 50 / 100 / 125 tokens per branch 20.7 -> 18.9, 23.9 -> 21.3,
+        // <= lmax) and the prefix's chunks do not fill the CUs, it is cut into 6 chunks per KV head, into 7 while the rest is at most a
+        // quarter of it (4k prefix: 5-6 and 4-5 tiles per chunk; a 6k prefix: 8 and 7 -- measured there too, profiles/r6_chunk_sweep_short.txt): north-star tree at 1 / 25 / 50 / 100 / 125 tokens per branch 20.7 -> 18.9, 23.9 -> 21.3,
         // 25.0 -> 23.4, 29.6 -> 27.7, 30.7 -> 29.3 us per layer; from 150 tokens on (and for every other BASELINE shape) nothing
         // changes -- there the leaf items keep the other CUs busy and longer chunks mean fewer partial rows.
         if (G == 1 && !pairs && C == 8) {
@@ -168,7 +168,10 @@ __device__ inline void np_record_order(const UnitList& ul, int R, int Hkv, int G
                 n8 += uni ? 1 : (nt + 7) / 8;
             });
             const int64_t t_other = tiles_all - lmax;
-            if ((int64_t)((lmax + 7) / 8) * Hkv * 2 < slots && t_other <= lmax && n8 * Hkv * 4 <= 5LL * slots) C = (4 * t_other <= lmax) ? 5 : 6;
+            if ((int64_t)((lmax + 7) / 8) * Hkv * 2 < slots && t_other <= lmax && n8 * Hkv * 4 <= 5LL * slots) {
+                const int S = (4 * t_other <= lmax) ? 7 : 6;  // chunks per KV head: 7 x 32 heads = 224 workgroups, 6 x 32 = 192
+                C = min(8, (lmax + S - 1) / S);
+            }
         }
         // A launch that leaves CUs empty (fewer chunks than CUs = slots / 2) takes the next shorter chunk length -- powers
         // of two or not -- as long as that still fits one workgroup per CU: Medusa-64 (an 8-tile root under two query
@@ -268,7 +271,10 @@ __device__ inline void record_order_wave0(const RunTable& rt, int NR, int* rT0, 
                 const int64_t tiles_all = wave_sum([](int nt, int) { return nt; });
                 const int64_t n8 = wave_sum([](int nt, int uni) { return uni ? 1 : (nt + 7) / 8; });
                 const int64_t t_other = tiles_all - lmax;
-                if ((int64_t)((lmax + 7) / 8) * Hkv * 2 < slots && t_other <= lmax && n8 * Hkv * 4 <= 5LL * slots) C = (4 * t_other <= lmax) ? 5 : 6;
+                if ((int64_t)((lmax + 7) / 8) * Hkv * 2 < slots && t_other <= lmax && n8 * Hkv * 4 <= 5LL * slots) {
+                    const int S = (4 * t_other <= lmax) ? 7 : 6;
+                    C = min(8, (lmax + S - 1) / S);
+                }
             }
             if (C > 2 && lmax <= 24 * (C - 1)) {       // (np_record_order: fill the CUs of a launch that leaves some empty)
                 const int64_t n0 = wave_sum([C](int nt, int uni) { return uni ? 1 : (nt + C - 1) / C; });

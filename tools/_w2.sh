@@ -1,15 +1,4 @@
 cd $GRAFT_REPO_ROOT; export PYTHONPATH=$GRAFT_REPO_ROOT
-for wl in medusa64_node medusa64_tree_node medusa64_tree_flatten; do
-  for c in 1 2 3 4; do
-    export DEFT_AMD_LIB=$GRAFT_REPO_ROOT/deft_amd/lib/libdeft_amd_rules_c$c.so
-    python bench.py --workload $wl --no-cpu-baseline --no-extras --no-traffic --no-e2e --no-cfg5 --steps 100 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$wl C=$c  layer %7.2f  stage1 %s' % (d['attention_latency_us_per_layer'], (d['roofline'] or {}).get('avg_launch_us')))"
-  done
-  unset DEFT_AMD_LIB
-  python bench.py --workload $wl --no-cpu-baseline --no-extras --no-traffic --no-e2e --no-cfg5 --steps 100 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$wl shipped  layer %7.2f  stage1 %s' % (d['attention_latency_us_per_layer'], (d['roofline'] or {}).get('avg_launch_us')))"
-done
-for L in 75 150; do
-  for c in 2 3 4; do
-    export DEFT_AMD_LIB=$GRAFT_REPO_ROOT/deft_amd/lib/libdeft_amd_rules_c$c.so
-    python bench.py --workload fewshot_1kx32 --branch-len $L --no-cpu-baseline --no-extras --no-traffic --no-e2e --no-cfg5 --steps 100 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('1k L=$L C=$c  layer %7.2f  stage1 %s' % (d['attention_latency_us_per_layer'], (d['roofline'] or {}).get('avg_launch_us')))"
-  done
-done
+python -m pytest tests/test_gpu_parity.py -m gpu -x -q 2>&1 | tail -1
+SH="llama2-7b flatten few_shot:4096:32:1 few_shot:4096:32:25 few_shot:4096:32:50 few_shot:4096:32:100 few_shot:4096:32:125 few_shot:4096:32:150 few_shot:5120:32:10 few_shot:5120:32:50 few_shot:5120:32:125 few_shot:6144:32:10 few_shot:6144:32:25 few_shot:6144:32:60 few_shot:6144:32:100 few_shot:7168:32:25 few_shot:7168:32:100 few_shot:4096:24:30 few_shot:4096:48:20"
+bash tools/shape_ab.sh "$SH" deft_amd/lib/libdeft_amd.so deft_amd/lib/libdeft_amd_rules_c5.so deft_amd/lib/libdeft_amd_rules_c6.so deft_amd/lib/libdeft_amd_rules_c7.so deft_amd/lib/libdeft_amd_rules_c8.so
