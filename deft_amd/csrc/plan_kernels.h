@@ -161,10 +161,10 @@ __device__ inline void np_record_order(const UnitList& ul, int R, int Hkv, int G
         // quarter of it (4k prefix: 5-6 and 4-5 tiles per chunk; a 6k prefix: 8 and 7 -- measured there too, profiles/r6_chunk_sweep_short.txt): north-star tree at 1 / 25 / 50 / 100 / 125 tokens per branch 20.7 -> 18.9, 23.9 -> 21.3,
         // 25.0 -> 23.4, 29.6 -> 27.7, 30.7 -> 29.3 us per layer; from 150 tokens on (and for every other BASELINE shape) nothing
         // changes -- there the leaf items keep the other CUs busy and longer chunks mean fewer partial rows.
-        if (G == 1 && !pairs && C == 8) {
+        if (G == 1 && !pairs && C == 8 && chunk_c == 0) {  // (chunk_c = -1: the rules WITHOUT this one -- A/B builds, DEFT_NP_CHUNK=-1)
             int64_t tiles_all = 0, n8 = 0;
             for_runs([&](int, int nt, int uni) {
-                tiles_all += nt;
+                tiles_all += uni == -1 ? 1 : nt;  // (a window plan's overflow run: mostly dormant tiles -- counted as one)
                 n8 += uni ? 1 : (nt + 7) / 8;
             });
             const int64_t t_other = tiles_all - lmax;
@@ -267,8 +267,8 @@ __device__ inline void record_order_wave0(const RunTable& rt, int NR, int* rT0, 
                 if ((pairs ? 4 : 10) * n * Hkv >= 3LL * slots) break;
             }
             while (C < 8 && lmax > 16 * C) C <<= 1;  // (np_record_order: at most 16 chunks per run while C < 8)
-            if (G == 1 && !pairs && C == 8) {  // (np_record_order: a shared prefix that dominates an MHA tree is cut shorter)
-                const int64_t tiles_all = wave_sum([](int nt, int) { return nt; });
+            if (G == 1 && !pairs && C == 8 && chunk_c == 0) {  // (np_record_order: a shared prefix that dominates an MHA tree is cut shorter)
+                const int64_t tiles_all = wave_sum([](int nt, int uni) { return uni == -1 ? 1 : nt; });  // (np_record_order: overflow runs count as one tile)
                 const int64_t n8 = wave_sum([](int nt, int uni) { return uni ? 1 : (nt + 7) / 8; });
                 const int64_t t_other = tiles_all - lmax;
                 if ((int64_t)((lmax + 7) / 8) * Hkv * 2 < slots && t_other <= lmax && n8 * Hkv * 4 <= 5LL * slots) {
