@@ -112,12 +112,14 @@ __global__ __launch_bounds__(256) void window_entries_kernel(TreeMdOut o, int32_
     }
 }
 
-// The step's host-written words -- slot numbers, page-table coordinates, journal, patch list -- FETCHED by the step's first kernel
-// straight from pinned host memory instead of arriving by a copy in front of the graph: between a graph's last kernel and a
-// stand-alone hipMemcpyAsync's blit kernel the queue idled ~20 us, and ~6 more between the blit and the graph's first kernel (kernel
-// + copy trace of an advancing loop, profiles/r6_step_boundary.txt) -- more than the patch kernel itself.  The host writes a RING of
-// slots ({used bytes, 12 bytes of padding, payload}); the kernel's slot is a device-side step counter modulo the ring, so that one
-// captured launch serves every step while the host runs slots ahead (an event per slot keeps it from lapping the GPU).
+// OPTIONAL (DecodeSession(staging="kernel"); the default is one async copy in front of the step): the step's host-written words --
+// slot numbers, page-table coordinates, journal, patch list -- FETCHED by the step's first kernel straight from pinned host memory.
+// Built against the idle queue around a stand-alone hipMemcpyAsync (~20 us in front of its blit kernel, ~6 behind it in round 5's
+// loop); most of that turned out to be the per-step EVENTS in the stream, and with those gone the two forms measure equal -- while the
+// kernel form, in about one run in twenty, ran a whole decode loop 2.6 x slower (reads over PCIe from a kernel; never seen with the
+// copy: profiles/r6_staging_kernel_vs_copy.txt).  The host writes a RING of slots ({used bytes, 12 bytes of padding, payload}); the
+// kernel's slot is a device-side step counter modulo the ring, so that one captured launch serves every step while the host runs
+// slots ahead (an event behind every fourth step keeps it from lapping the GPU).
 struct StageFetch {
     const char* ring;   // pinned host memory, device-accessible; null = nothing to fetch
     char* dst;          // the session's device-side staging area (what every later kernel of the step reads)
@@ -166,8 +168,8 @@ struct WindowPatch {
 // (window_host.cpp hands out positions per region -- a leaf's token lands in the ONE region that holds its query's rows -- and
 // computes every entry's row mask).
 // A lone workgroup pays 1-2 us per dependent round trip, and this kernel stands between two steps' layers, so its chains run SIDE BY
-// SIDE in different waves (s_waitcnt counts per wave): waves 0-7 bring the step's words over PCIe (stage_fetch: counter, then header
-// and payload in one round trip) while waves 8-15 walk the device tree -- leaf row -> node -> length, room, last slot: three
+// SIDE in different waves (s_waitcnt counts per wave): waves 0-7 bring the step's words over PCIe where the session asks for that
+// (stage_fetch: counter, then header and payload in one round trip) while waves 8-15 walk the device tree -- leaf row -> node -> length, room, last slot: three
 // dependent loads -- and read the overflow runs' record table; one barrier; then the stores.  (13 us -> 8 as one chain after the
 // other, profiles/r6_step_boundary.txt.)
 __global__ __launch_bounds__(1024) void window_patch_kernel(TreeDev t, WindowPatch w, PageWrite pw, StageFetch fetch) {

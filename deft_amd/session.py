@@ -49,7 +49,7 @@ class DecodeSession:
 
     def __init__(self, tree: TreeCache, num_heads: int, num_kv_heads: int, head_dim: int, layers: int,
                  qkv: Callable[[int], tuple], max_q_len: int = 32, use_graph: bool = True, mode: str = "flatten",
-                 capture_after="auto", incremental: bool = True, win_tiles: Optional[int] = None) -> None:
+                 capture_after="auto", incremental: bool = True, win_tiles: Optional[int] = None, staging: Optional[str] = None) -> None:
         """`qkv(layer)` -> (q [nq, Hq*D], k_new [nq, Hkv*D], v_new [nq, Hkv*D]) fp16 CUDA tensors at FIXED addresses (the
         model writes this step's projections there); outputs are in `self.out[layer]` ([nq, Hq*D]).
 
@@ -77,6 +77,15 @@ class DecodeSession:
         self._last_epoch_steps = 1 << 30
         self.mode = mode
         self.incremental, self.win_tiles_arg = bool(incremental), win_tiles
+        # how a step's host-written words reach the GPU.  "copy" (default): ONE async copy from the pinned ring slot in front of the
+        # step.  "kernel": fetched by the step's first kernel itself (csrc/window.h StageFetch; nothing but graph launches in the
+        # stream) -- built to get rid of the idle queue around the copy, measured EQUAL once the per-step events were out of the stream
+        # (few-shot replay 946.8 / 947.0 us per step, advancing loop 1.015-1.018 / 1.018-1.020 x a frozen step), and in about one run in
+        # twenty the whole loop ran 2.6 x slower with it (kernel reads over PCIe; never with the copy: profiles/r6_staging_kernel_vs_copy.txt).
+        import os as _os
+
+        self.staging = staging or _os.environ.get("DEFT_SESSION_STAGING", "copy")
+        assert self.staging in ("kernel", "copy")
         # (the device WITH its index: torch.device("cuda") != torch.device("cuda:0"), and the page-table fold below compares devices --
         #  round 3: with the default "cuda" pool the fold never happened and every step carried an index_put)
         self.tree, self.pool, self.device = tree, pool, pool._storage.device
@@ -91,8 +100,8 @@ class DecodeSession:
         self._side: Optional[torch.cuda.Stream] = torch.cuda.Stream(device=self.device)
         self._side.wait_stream(torch.cuda.current_stream(self.device))
         self.out: List[torch.Tensor] = []
-        # the host's words of a step reach the GPU through a RING of pinned slots that the step's first kernel reads itself
-        # (csrc/window.h StageFetch): the slot is picked by a device-side step counter, an event per slot keeps the host from lapping
+        # the host's words of a step reach the GPU through a RING of pinned slots (copied from in front of the step, or read by the
+        # step's first kernel: `staging`); an event behind every fourth step keeps the host from lapping the GPU
         self._ring: Optional[torch.Tensor] = None
         self._ring_slot = 0
         self._ring_events: List[Optional[torch.cuda.Event]] = [None] * (2 * self.RING // self.EVENT_EVERY)
@@ -211,6 +220,8 @@ class DecodeSession:
         return uploaded
 
     def _fetch(self, stream: int) -> None:
+        if self.staging == "copy":  # (the words were copied in front of the step: nothing to fetch)
+            return
         check(lib.deft_stage_fetch(self._ring.data_ptr(), self._ring_slot, self.RING, self._small.data_ptr(), self._ctr.data_ptr(), stream),
               "deft_stage_fetch")
 
@@ -289,7 +300,7 @@ class DecodeSession:
         table = self.tree.req_to_token_pool.req_to_token
         # a PATCH step whose page-table write rides in the patch kernel has that kernel fetch the step's words too (one launch
         # in front of the layers); everything else fetches with a launch of its own, in front of whatever reads them
-        folded_fetch = not replan and self._can_fold(True)
+        folded_fetch = not replan and self._can_fold(True) and self.staging == "kernel"
         if not folded_fetch:
             self._fetch(stream)
         fold = self._fold(True)
@@ -441,6 +452,8 @@ class DecodeSession:
             self.last_staged = {"kind": kind, "journal": self._journal[:journal_words].copy(), "loc": loc32.copy(),
                                 "patch": h[self._patch_off : used].view(np.int32).copy() if kind != "legacy" else None}
         slot[:4].view(np.uint32)[0] = used  # (only what this step wrote crosses PCIe: the journal and patch areas are sized for the worst step)
+        if self.staging == "copy":
+            self._small[:used].copy_(self._ring[k * self._ring_slot + 16 : k * self._ring_slot + 16 + used], non_blocking=True)
         return kind
 
     def _capture(self, kind: str, launch) -> None:

@@ -494,8 +494,9 @@ int deft_window_patch(int n_nodes, int nq, int nqw, const int32_t* node_start, i
                       void* stream);
 /* A decode step's host-written words (slot numbers, page-table coordinates, journal, patch list) FETCHED by a kernel from a ring of
  * pinned, device-accessible host slots -- slot (*counter mod ring_n) = {uint32 used bytes, 12 bytes padding, payload}; its first `used`
- * payload bytes go to `dst`, then *counter += 1 -- instead of a hipMemcpyAsync in front of the captured step (the queue idles ~25 us
- * around a stand-alone copy).  One workgroup; identical arguments on every step, so it sits in the step's hipGraph. */
+ * payload bytes go to `dst`, then *counter += 1 -- instead of a hipMemcpyAsync in front of the captured step.  One workgroup; identical
+ * arguments on every step, so it sits in the step's hipGraph.  OPTIONAL: deft_amd.DecodeSession copies by default -- the two forms
+ * measure equal, and about one run in twenty ran 2.6 x slower with kernel-side PCIe reads (profiles/r6_staging_kernel_vs_copy.txt). */
 int deft_stage_fetch(const void* ring, int slot_bytes, int ring_n, void* dst, int32_t* counter, void* stream);
 
 /* The host-side books of a window plan: which overflow position holds which node's slot (deft_amd/csrc/window_host.cpp).

@@ -204,6 +204,50 @@ def test_session_speculative_decoding_steps_replay_one_graph(mode, incremental):
     assert sess.device_errors() == 0
 
 
+@pytest.mark.parametrize("mode", ["flatten", "node"])
+def test_session_fetch_by_kernel_form(mode):
+    """`staging="kernel"`: the step's words read from the pinned ring by the step's first kernel (csrc/window.h StageFetch) instead of
+    copied in front of the step -- not the default (profiles/r6_staging_kernel_vs_copy.txt), kept correct: window plans and the
+    rebuild-every-step form against the eager path, through an epoch change."""
+    Hq, Hkv, D, layers, prefix, width = 8, 2, 128, 2, 300, 5
+    for incremental in (True, False):
+        g = torch.Generator(device="cuda").manual_seed(5)
+        kv_init = torch.randn((layers, 2048, 2, Hkv, D), dtype=torch.float16, device="cuda", generator=g)
+        (te, pe), (ts, ps) = [_mk(Hkv, D, layers, prefix, width, 2048) for _ in range(2)]
+        for p in (pe, ps):
+            p._storage.copy_(kv_init)
+        cap = 16
+        q = torch.randn((layers, cap, Hq * D), dtype=torch.float16, device="cuda", generator=g)
+        k = torch.randn((layers, cap, Hkv * D), dtype=torch.float16, device="cuda", generator=g)
+        v = torch.randn((layers, cap, Hkv * D), dtype=torch.float16, device="cuda", generator=g)
+        nq_now = [width]
+        sess = deft_amd.DecodeSession(ts, Hq, Hkv, D, layers, lambda l: (q[l, : nq_now[0]], k[l, : nq_now[0]], v[l, : nq_now[0]]), mode=mode,
+                                      incremental=incremental, staging="kernel")
+        attn = [deft_amd.DeFTAttention(Hq, D, D ** -0.5, Hkv, l) for l in range(layers)]
+        fmode = deft_amd.forward_mode_from_cli(mode)
+        for phase in range(2):
+            for _ in range(30):
+                for tree in (te, ts):
+                    for leaf in tree.leaves.values():
+                        leaf.append_token(7)
+                upd = te.alloc()
+                md = deft_amd.TreeMetadata.from_tree_cache(te)
+                deft_amd.register_tree_metadata(md)
+                n = md.query_num
+                nq_now[0] = n
+                ref = [attn[l](q[l, :n], k[l, :n], v[l, :n], deft_amd.InputMetadata(fmode, upd, pe)) for l in range(layers)]
+                out = sess.step()
+                torch.cuda.synchronize()
+                for l in range(layers):
+                    _agree(out[l][:n], ref[l], incremental, (incremental, phase, l))
+                assert torch.equal(pe._storage, ps._storage)
+            for tree in (te, ts):
+                lv = sorted(tree.leaves.values(), key=lambda x: x.id)
+                tree.cut(lv[1])
+                tree.branch(lv[0], 2)
+        assert sess.device_errors() == 0 and sess.staging == "kernel"
+
+
 @pytest.mark.parametrize("capture_after", [1, 3, "auto"])
 def test_session_head_dim_64_and_lazy_capture(capture_after):
     """head_dim 64 through the captured loop (two KV heads to a 256-byte pool row: the tile-parallel kernel's head pairs read a
