@@ -169,8 +169,10 @@ __device__ inline void np_record_order(const UnitList& ul, int R, int Hkv, int G
             });
             const int64_t t_other = tiles_all - lmax;
             if ((int64_t)((lmax + 7) / 8) * Hkv * 2 < slots && t_other <= lmax && n8 * Hkv * 4 <= 5LL * slots) {
-                const int S = (4 * t_other <= lmax) ? 7 : 6;  // chunks per KV head: 7 x 32 heads = 224 workgroups, 6 x 32 = 192
-                C = min(8, (lmax + S - 1) / S);
+                // chunks per KV head for 7/16 (the rest is small) or 3/8 of the resident slots: 224 or 192 workgroups on this part --
+                // 7 or 6 chunks under Llama-2-7B's 32 KV heads, where the rule was measured
+                const int S = max(1, (int)(((4 * t_other <= lmax) ? 7LL * slots / 16 : 3LL * slots / 8) / Hkv));
+                C = max(3, min(8, (lmax + S - 1) / S));
             }
         }
         // A launch that leaves CUs empty (fewer chunks than CUs = slots / 2) takes the next shorter chunk length -- powers
@@ -272,8 +274,8 @@ __device__ inline void record_order_wave0(const RunTable& rt, int NR, int* rT0, 
                 const int64_t n8 = wave_sum([](int nt, int uni) { return uni ? 1 : (nt + 7) / 8; });
                 const int64_t t_other = tiles_all - lmax;
                 if ((int64_t)((lmax + 7) / 8) * Hkv * 2 < slots && t_other <= lmax && n8 * Hkv * 4 <= 5LL * slots) {
-                    const int S = (4 * t_other <= lmax) ? 7 : 6;
-                    C = min(8, (lmax + S - 1) / S);
+                    const int S = max(1, (int)(((4 * t_other <= lmax) ? 7LL * slots / 16 : 3LL * slots / 8) / Hkv));
+                    C = max(3, min(8, (lmax + S - 1) / S));
                 }
             }
             if (C > 2 && lmax <= 24 * (C - 1)) {       // (np_record_order: fill the CUs of a launch that leaves some empty)
