@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Rewrites DESIGN.md's round-over-round table (between the ROUNDS_TABLE markers) from a SAME-BOX run of tools/ab_rounds.sh -- every
+"""(Round 6: DESIGN.md's table is now a hand-merged pair of such tables -- rounds 3-5 and 5-6, two boxes; this tool still PRINTS the table of one run,
+but only writes it with --write.)
+Rewrites DESIGN.md's round-over-round table (between the ROUNDS_TABLE markers) from a SAME-BOX run of tools/ab_rounds.sh -- every
 round's own tree (prev/r3, prev/r4, the working tree) running its own bench.py on its own library, in turn, on one GPU box:
 
     tools/ab_rounds.sh "<workloads>" prev/r3 prev/r4 . > profiles/r5z_ab_rounds.txt ;  python tools/round_table.py profiles/r5z_ab_rounds.txt
@@ -39,5 +41,6 @@ t += "\n"
 p = os.path.join(ROOT, "DESIGN.md")
 s = open(p).read()
 s = re.sub(r"(<!-- ROUNDS_TABLE_BEGIN -->\n).*?(<!-- ROUNDS_TABLE_END -->\n)", lambda m: m.group(1) + t + m.group(2), s, flags=re.S)
-open(p, "w").write(s)
+if "--write" in sys.argv:
+    open(p, "w").write(s)
 print(t)
