@@ -204,6 +204,43 @@ def test_session_speculative_decoding_steps_replay_one_graph(mode, incremental):
     assert sess.device_errors() == 0
 
 
+def test_session_falls_back_when_a_window_plan_cannot_host_the_step():
+    """More (query chunk, pass) regions than a window plan's tables hold -- 200 leaves under 16 query heads per KV head: 7 chunks x 16
+    passes -- and the session runs the rebuild-every-step form instead (deft_window_supported = 0): bit-identical to the eager path."""
+    Hq, Hkv, D, layers, prefix, width = 16, 1, 128, 1, 200, 200
+    assert deft_amd.lib.deft_window_supported(width, 32, Hq, Hkv) == 0
+    g = torch.Generator(device="cuda").manual_seed(9)
+    kv_init = torch.randn((layers, 8192, 2, Hkv, D), dtype=torch.float16, device="cuda", generator=g)
+    trees = []
+    for _ in range(2):
+        req = deft_amd.ReqToTokenPool(256, 8192, device="cuda")
+        pool = deft_amd.TokenToKVPool(8192, torch.float16, Hkv, D, layers, device="cuda")
+        tree = deft_amd.TreeCache(torch.float16, Hkv, D, layers, req, pool, None, True, False)
+        tree.init_prompt(torch.arange(1, prefix + 1, dtype=torch.int32))
+        tree.branch(tree.root, width)
+        pool._storage.copy_(kv_init)
+        trees.append((tree, pool))
+    (te, pe), (ts, ps) = trees
+    q = torch.randn((layers, width, Hq * D), dtype=torch.float16, device="cuda", generator=g)
+    k = torch.randn((layers, width, Hkv * D), dtype=torch.float16, device="cuda", generator=g)
+    v = torch.randn((layers, width, Hkv * D), dtype=torch.float16, device="cuda", generator=g)
+    sess = deft_amd.DecodeSession(ts, Hq, Hkv, D, layers, lambda l: (q[l], k[l], v[l]))  # (incremental=True asked for)
+    attn = [deft_amd.DeFTAttention(Hq, D, D ** -0.5, Hkv, l) for l in range(layers)]
+    fmode = deft_amd.forward_mode_from_cli("flatten")
+    for step in range(6):
+        for tree in (te, ts):
+            for leaf in tree.leaves.values():
+                leaf.append_token(7)
+        upd = te.alloc()
+        md = deft_amd.TreeMetadata.from_tree_cache(te)
+        deft_amd.register_tree_metadata(md)
+        ref = attn[0](q[0], k[0], v[0], deft_amd.InputMetadata(fmode, upd, pe))
+        out = sess.step()
+        torch.cuda.synchronize()
+        assert torch.equal(out[0], ref), step
+    assert sess.step_kinds["legacy"] == 5 and sess.step_kinds["patch"] == 0 and sess.device_errors() == 0, sess.step_kinds
+
+
 @pytest.mark.parametrize("mode", ["flatten", "node"])
 def test_session_fetch_by_kernel_form(mode):
     """`staging="kernel"`: the step's words read from the pinned ring by the step's first kernel (csrc/window.h StageFetch) instead of
