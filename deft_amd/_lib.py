@@ -162,6 +162,7 @@ _TREE_FUNCS = {
     "deft_window_patch": ([C.c_int, C.c_int, C.c_int] + [_vp] * 6 + [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int,
                            C.c_int, _i64, _i64, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp], C.c_int),
     "deft_stage_fetch": ([_vp, C.c_int, C.c_int, _vp, _vp, _vp], C.c_int),
+    "deft_stage_copy": ([_vp, C.c_int, C.c_int, _vp, C.c_size_t, _vp], C.c_int),
 }
 for _f, (_a, _r) in _TREE_FUNCS.items():
     getattr(lib, _f).argtypes = _a

@@ -2175,4 +2175,27 @@ int deft_stage_fetch(const void* ring, int slot_bytes, int ring_n, void* dst, in
     return check_launch("stage fetch launch");
 }
 
+/* The default form of the same hand-over: slot `slot` of the ring copied to dst by ONE hipMemcpyAsync on `stream`, `used` read from
+ * the slot's header by the host.  (What deft_amd.DecodeSession did through two tensor slices and Tensor.copy_: ~10 us of host time.) */
+int deft_stage_copy(const void* ring, int slot_bytes, int slot, void* dst, size_t dst_bytes, void* stream) {
+    if (!ring || !dst || slot_bytes < 32 || slot_bytes % 16 || slot < 0) {
+        set_error("deft_stage_copy: bad arguments");
+        return DEFT_EINVAL;
+    }
+    const char* src = static_cast<const char*>(ring) + static_cast<size_t>(slot) * slot_bytes;
+    uint32_t used;
+    memcpy(&used, src, 4);
+    if (used > dst_bytes || used + 16 > static_cast<size_t>(slot_bytes)) {
+        set_error("deft_stage_copy: the slot's header names more bytes than the slot or the destination holds");
+        return DEFT_EINVAL;
+    }
+    if (used == 0) return DEFT_OK;
+    hipError_t e = hipMemcpyAsync(dst, src + 16, used, hipMemcpyHostToDevice, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) {
+        set_error("deft_stage_copy: %s", hipGetErrorString(e));
+        return DEFT_EHIP;
+    }
+    return DEFT_OK;
+}
+
 }  // extern "C"

@@ -90,6 +90,13 @@ class TokenToKVPool:
         costs microseconds whatever the pool's size (a full scan of a 500k-slot pool is ~0.4 ms, per step)."""
         if need_size <= 0:
             return np.zeros(0, dtype=np.int32)
+        lo, ms = self._lo, self.mem_state
+        if lo + need_size <= self.size and not ms[lo : lo + need_size].any():
+            # (the usual decode step: the lowest free slots are the next ones in a row)
+            ms[lo : lo + need_size] = 1
+            self._lo = lo + need_size
+            self.alloc_ct += need_size
+            return np.arange(lo, lo + need_size, dtype=np.int32)
         idx = self._lowest_free(self._lo, need_size)
         if idx is None and self._lo > 0:
             idx = self._lowest_free(0, need_size)  # (entries of mem_state cleared directly, below the hint)

@@ -216,6 +216,9 @@ class DecodeSession:
         self.leaf_handles = [tree.leaves[i] for i in order]
         self.leaf_reqs = np.asarray([tree.leaf_to_req[i] for i in order], dtype=np.int64)
         self._journal = np.zeros(self.ops_cap, dtype=np.int32)
+        self._journal_p = _ptr(self._journal)
+        self._slot_views = [None] * self.RING  # (per ring slot: numpy views of this epoch's layout, `_stage`)
+        self._ring_p, self._small_p, self._small_n = self._ring.data_ptr(), self._small.data_ptr(), self._small.numel()
         self.graphs, self.graph_epoch = {}, dt.epoch
         return uploaded
 
@@ -345,7 +348,7 @@ class DecodeSession:
         # this step's upload and is replayed by the step's first kernel.  One that does not fit starts a new epoch instead.
         jn = 0
         if tree._epoch() == self.graph_epoch:
-            jn = int(lib.deft_tree_journal_take(tree._native, _ptr(self._journal), self.ops_cap))
+            jn = int(lib.deft_tree_journal_take(tree._native, self._journal_p, self.ops_cap))
             if jn < 0 and jn != -5:
                 check(jn, "deft_tree_journal_take")
             jn = max(jn, 0)
@@ -357,7 +360,7 @@ class DecodeSession:
             uploaded = self._epoch_setup()
             jn = 0
             if not uploaded:  # (a device copy that stays may still owe the journal)
-                jn = max(int(lib.deft_tree_journal_take(tree._native, _ptr(self._journal), self.ops_cap)), 0)
+                jn = max(int(lib.deft_tree_journal_take(tree._native, self._journal_p, self.ops_cap)), 0)
                 if tree._epoch() != self.graph_epoch:  # too long: that call started another epoch
                     uploaded, jn = self._epoch_setup(), 0
             self._stage(loc, jn, False)
@@ -419,28 +422,31 @@ class DecodeSession:
             ev = self._ring_events[(e // self.EVENT_EVERY) % len(self._ring_events)]
             if ev is not None:
                 ev.synchronize()
-        slot = self._ring.numpy()[k * self._ring_slot : (k + 1) * self._ring_slot]
-        h = slot[16:]
-        nqm = max(n, 1)
-        loc32 = h[: 4 * n].view(np.int32)
+        sv = self._slot_views[k]
+        if sv is None:  # (numpy views of ring slot k and their addresses: made once per epoch, not per step)
+            slot = self._ring.numpy()[k * self._ring_slot : (k + 1) * self._ring_slot]
+            h = slot[16:]
+            nqm = max(n, 1)
+            loc32 = h[: 4 * n].view(np.int32)
+            ph = h[self._patch_off : self._small.numel()].view(np.int32)  # (what the device-side patch area holds)
+            sv = self._slot_views[k] = (slot[:4].view(np.uint32), h, loc32, h[self._ops_off - 16 * nqm : self._ops_off].view(np.int64).reshape(2, nqm),
+                                        h[self._ops_off : self._patch_off].view(np.int32), ph, _ptr(loc32), _ptr(ph), ph.size)
+            sv[3][0, :n] = self.leaf_reqs  # (the leaves' request rows do not change within an epoch)
+        hdr, h, loc32, idx_h, ops_h, ph, loc_p, ph_p, ph_n = sv
         loc32[:] = loc
-        idx_h = h[self._ops_off - 16 * nqm : self._ops_off].view(np.int64).reshape(2, nqm)
-        idx_h[0, :n] = self.leaf_reqs
         idx_h[1, :n] = [lf.positions[-1] for lf in self.leaf_handles]
-        ops_h = h[self._ops_off : self._patch_off].view(np.int32)
         ops_h[0] = journal_words
         if journal_words:
             ops_h[1 : 1 + journal_words] = self._journal[:journal_words]
         kind, used = "legacy", self._patch_off
         if window:
-            ph = h[self._patch_off : self._small.numel()].view(np.int32)  # (what the device-side patch area holds)
             words = -1
             # (nobody else has moved the device copy since this session's last step?  Otherwise the plan's static part is stale: replan)
             if self.dt.version == self._dt_version:
-                words = int(lib.deft_window_step(self.win, 0, _ptr(self._journal), journal_words, _ptr(loc32), _ptr(ph), ph.size))
+                words = int(lib.deft_window_step(self.win, 0, self._journal_p, journal_words, loc_p, ph_p, ph_n))
                 kind = "patch"
             if words < 0:
-                words = int(lib.deft_window_step(self.win, 1, _ptr(self._journal), journal_words, _ptr(loc32), _ptr(ph), ph.size))
+                words = int(lib.deft_window_step(self.win, 1, self._journal_p, journal_words, loc_p, ph_p, ph_n))
                 kind = "replan"
             if words < -1:
                 check(words, "deft_window_step")
@@ -451,9 +457,10 @@ class DecodeSession:
         if self.debug:  # (tools/fuzz_session.py: what this step staged, for a failure report)
             self.last_staged = {"kind": kind, "journal": self._journal[:journal_words].copy(), "loc": loc32.copy(),
                                 "patch": h[self._patch_off : used].view(np.int32).copy() if kind != "legacy" else None}
-        slot[:4].view(np.uint32)[0] = used  # (only what this step wrote crosses PCIe: the journal and patch areas are sized for the worst step)
+        hdr[0] = used  # (only what this step wrote crosses PCIe: the journal and patch areas are sized for the worst step)
         if self.staging == "copy":
-            self._small[:used].copy_(self._ring[k * self._ring_slot + 16 : k * self._ring_slot + 16 + used], non_blocking=True)
+            check(lib.deft_stage_copy(self._ring_p, self._ring_slot, k, self._small_p, self._small_n,
+                                      torch.cuda.current_stream(self.device).cuda_stream), "deft_stage_copy")
         return kind
 
     def _capture(self, kind: str, launch) -> None:

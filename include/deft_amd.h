@@ -498,6 +498,9 @@ int deft_window_patch(int n_nodes, int nq, int nqw, const int32_t* node_start, i
  * arguments on every step, so it sits in the step's hipGraph.  OPTIONAL: deft_amd.DecodeSession copies by default -- the two forms
  * measure equal, and about one run in twenty ran 2.6 x slower with kernel-side PCIe reads (profiles/r6_staging_kernel_vs_copy.txt). */
 int deft_stage_fetch(const void* ring, int slot_bytes, int ring_n, void* dst, int32_t* counter, void* stream);
+/* The default hand-over of the same words: slot `slot` of the ring -- the host wrote `used` into its header -- copied to `dst` (room
+ * for dst_bytes) by one hipMemcpyAsync on `stream`.  DEFT_EINVAL when the header names more than the slot or `dst` holds. */
+int deft_stage_copy(const void* ring, int slot_bytes, int slot, void* dst, size_t dst_bytes, void* stream);
 
 /* The host-side books of a window plan: which overflow position holds which node's slot (deft_amd/csrc/window_host.cpp).
  *   deft_window_create   books for one structural epoch: `leaf_node[r]` = DFS index of query row r's leaf, `refs` = the nodes' leaf sets

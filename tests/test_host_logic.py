@@ -458,6 +458,25 @@ def test_header_and_library_serve_a_plain_c_program(tmp_path):
     assert os.path.getsize(exe) > 0
 
 
+def test_stage_copy_refuses_a_slot_header_that_names_too_much():
+    """deft_stage_copy reads `used` from the slot's header on the host: more than the slot or the destination holds is DEFT_EINVAL
+    before any HIP call (so is a null pointer); zero bytes is a no-op."""
+    lib = deft_amd.lib
+    ring = np.zeros(2 * 4096, dtype=np.uint8)
+    p = ring.ctypes.data_as(ctypes.c_void_p)
+    dst = ctypes.c_void_p(0x1000)  # (never dereferenced on these paths)
+    assert lib.deft_stage_copy(None, 4096, 0, dst, 4096, None) == -1
+    assert lib.deft_stage_copy(p, 4096, 0, None, 4096, None) == -1
+    assert lib.deft_stage_copy(p, 4096, -1, dst, 4096, None) == -1
+    assert lib.deft_stage_copy(p, 4090, 0, dst, 4096, None) == -1  # (slots are multiples of 16 bytes)
+    ring[4096:4100].view(np.uint32)[0] = 4090  # slot 1: 4090 + 16 > 4096
+    assert lib.deft_stage_copy(p, 4096, 1, dst, 1 << 20, None) == -1
+    assert b"header" in lib.deft_last_error()
+    ring[4096:4100].view(np.uint32)[0] = 512
+    assert lib.deft_stage_copy(p, 4096, 1, dst, 256, None) == -1  # (the destination is smaller)
+    assert lib.deft_stage_copy(p, 4096, 0, dst, 4096, None) == 0  # used = 0: nothing to copy
+
+
 def test_window_books_from_a_plain_c_program(tmp_path):
     """The window plan's host-side entry points (deft_window_supported / _create / _step / _free) called from C11 through the header
     alone: host-only, so this one RUNS here (tests/c_abi/window_books_from_c.c)."""
