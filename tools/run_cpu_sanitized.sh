@@ -18,4 +18,4 @@ cd $ROOT
 if [ $# -eq 0 ]; then set -- tests/test_host_logic.py tests/test_forest_tree.py tests/test_replay.py tests/test_replay_golden.py tests/test_workloads.py; fi
 # (not under the sanitized library: the tests that compare `nm -D` of the SHIPPED library with the header, the C program linked
 #  against it, and the two that call entry points of deft_kernels.hip -- stubs here)
-python -m pytest -q -m "not gpu" -p no:cacheprovider "$@" -k "not exports and not plain_c_program and not supported_geometries and not argument_errors"
+python -m pytest -q -m "not gpu" -p no:cacheprovider "$@" -k "not exports and not plain_c_program and not supported_geometries and not argument_errors and not stage_copy"
