@@ -188,6 +188,21 @@ __device__ inline void np_record_order(const UnitList& ul, int R, int Hkv, int G
             });
             if (2 * n0 * Hkv < slots && 2 * n1 * Hkv <= slots) --C;
         }
+        // MHA, ONE short shared prefix (<= 8 tiles: configs[1]'s 1024-token prompt) under one query chunk, the rest of the tree no
+        // more than four times its tiles (branches of up to 128 tokens): 2-tile chunks.  The 4-tile chain of the prefix is the
+        // launch's critical path there -- everything else is single tiles, and the prefix's chunks take at most half the CUs either
+        // way (late round 6, forced chunk lengths, profiles/r6_chunk_sweep_short.txt block 5: 1k x 32 at 10 / 25 / 50 / 75 tokens per
+        // branch 12.6 -> 11.9, 15.2 -> 13.8, 16.9 -> 14.8, 18.9 -> 17.3 us per layer; 100: 19.7 -> 20.0; from 129 on nothing
+        // changes).  Two query chunks (Medusa-64: two runs over the root) measured the other way and keep their rule.
+        if (G == 1 && !pairs && chunk_c == 0 && C > 2 && lmax <= 8) {
+            int64_t tiles_all = 0;
+            int long_runs = 0;
+            for_runs([&](int, int nt, int uni) {
+                tiles_all += uni == -1 ? 1 : nt;
+                long_runs += (!uni && nt >= 3) ? 1 : 0;
+            });
+            if (long_runs == 1 && (int64_t)((lmax + 1) / 2) * Hkv * 4 <= slots && tiles_all - lmax <= 4 * lmax) C = 2;
+        }
         // GQA: the launch should fit the resident slots -- chunks grow (up to 8 tiles) until there are fewer workgroups than slots:
         // a second round of workgroups, every one with its ramp and its epilogue, costs more than longer chunks do (late round 4,
         // rule variants of the shipped build, tools/ab_rules.sh: ToT-50 on Llama-3-8B, 6 passes over 32 root tiles + 28 leaf
@@ -282,6 +297,11 @@ __device__ inline void record_order_wave0(const RunTable& rt, int NR, int* rT0, 
                 const int64_t n0 = wave_sum([C](int nt, int uni) { return uni ? 1 : (nt + C - 1) / C; });
                 const int64_t n1 = wave_sum([C](int nt, int uni) { return uni ? 1 : (nt + C - 2) / (C - 1); });
                 if (2 * n0 * Hkv < slots && 2 * n1 * Hkv <= slots) --C;
+            }
+            if (G == 1 && !pairs && chunk_c == 0 && C > 2 && lmax <= 8) {  // (np_record_order: one short shared prefix under single-tile branches)
+                const int64_t tiles_all = wave_sum([](int nt, int uni) { return uni == -1 ? 1 : nt; });
+                const int long_runs = wave_sum([](int nt, int uni) { return (!uni && nt >= 3) ? 1 : 0; });
+                if (long_runs == 1 && (int64_t)((lmax + 1) / 2) * Hkv * 4 <= slots && tiles_all - lmax <= 4 * lmax) C = 2;
             }
             if (G > 1 && !pairs)  // (np_record_order: a GQA launch should fit the resident slots)
                 for (int c2 = C; c2 <= 8; ++c2) {
