@@ -369,7 +369,7 @@ class Bench:
                           else "eager (tree.alloc, TreeMetadata.from_tree_cache, DeFTAttention.forward per layer)"}
 
 
-def run_level(w: Workload, layers: int, device, gen_len: int, incremental: bool):
+def run_level(w: Workload, layers: int, device, gen_len: int, incremental: bool, win_tiles=None):
     """The reference's few-shot experiment AS A RUN (README.md:214-219: a 4000-token prompt, 400 generated tokens per branch; logs in
     DeFT/experiments/few_shot_prompting/few_shot.ipynb): the north-star tree growing from 1 to `gen_len` tokens per branch through
     deft_amd.FlattenDecodeSession, no host sync inside -- every step of it, the epochs' first (eager) steps and graph captures
@@ -377,7 +377,8 @@ def run_level(w: Workload, layers: int, device, gen_len: int, incremental: bool)
     target looks like averaged over the branch lengths a generation run actually passes through."""
     b = Bench(Workload(**{**w.__dict__, "branch_len": 1}), layers, device, seed=11, extra_steps=gen_len + 8)
     tree = b.forest.trees[0]
-    sess = deft_amd.FlattenDecodeSession(tree, b.Hq, b.Hkv, b.D, layers, lambda l: (b.q[l], b.k_new[l], b.v_new[l]), incremental=incremental)
+    sess = deft_amd.FlattenDecodeSession(tree, b.Hq, b.Hkv, b.D, layers, lambda l: (b.q[l], b.k_new[l], b.v_new[l]), incremental=incremental,
+                                         win_tiles=win_tiles)
     steps = gen_len - 1
     n_kv, total_bytes = b.n_kv, 0
     torch.cuda.synchronize(device)
