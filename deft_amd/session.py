@@ -38,8 +38,52 @@ from .tree_cache import BLOCK_CONFIG, TreeCache, _DeviceTree, _FIELDS, _ptr
 
 __all__ = ["DecodeSession", "FlattenDecodeSession"]
 
+import threading
+
 _TILE = 128
 _WIN_PASSES = 16  # (plan_records.h WIN_PASSES: the overflow table's passes per query chunk)
+
+# What a session needs from the DRIVER -- pinned host memory for its staging ring, a stream to capture on -- is kept per process and
+# handed from session to session: hipHostMalloc and a stream's first use cost 1-8 ms each on a quiet box and 20-60 ms when the
+# node's driver is busy (profiles/r6_slow_run_hunt.txt), a decode step 0.06 ms of host time.
+_POOL_LOCK = threading.Lock()
+_PINNED_RINGS: Dict[int, list] = {}  # bytes -> [(pinned uint8 tensor, event behind its last reader | None)]
+_CAPTURE_STREAMS: Dict[tuple, "torch.cuda.Stream"] = {}  # (device index, thread) -> the stream that thread's sessions capture on
+
+
+def _ring_acquire(nbytes: int) -> torch.Tensor:
+    with _POOL_LOCK:
+        have = _PINNED_RINGS.get(nbytes)
+        item = have.pop() if have else None
+    if item is None:
+        return torch.zeros(nbytes, dtype=torch.uint8).pin_memory()
+    ring, ev = item
+    if ev is not None:
+        ev.synchronize()  # (the last copy / kernel that read it has run)
+    return ring.zero_()
+
+
+def _ring_release(ring: Optional[torch.Tensor], stream: Optional["torch.cuda.Stream"]) -> None:
+    if ring is None:
+        return
+    ev = None
+    if stream is not None:
+        ev = torch.cuda.Event()
+        ev.record(stream)
+    with _POOL_LOCK:
+        have = _PINNED_RINGS.setdefault(ring.numel(), [])
+        if len(have) < 64:  # (beyond that the memory goes back to the driver)
+            have.append((ring, ev))
+
+
+def _capture_stream(device: torch.device) -> "torch.cuda.Stream":
+    key = (device.index, threading.get_ident())
+    side = _CAPTURE_STREAMS.get(key)
+    if side is None:
+        # made AND first used here: a HIP stream is created lazily at its first use, 5.6 ms that would otherwise land in a captured step
+        side = _CAPTURE_STREAMS[key] = torch.cuda.Stream(device=device)
+        side.wait_stream(torch.cuda.current_stream(device))
+    return side
 
 
 class DecodeSession:
@@ -95,10 +139,9 @@ class DecodeSession:
         self.graph_epoch = -1
         self.captures = 0
         self.step_kinds = {"upload": 0, "legacy": 0, "replan": 0, "patch": 0}  # what the steps so far ran (tests, tools/replay.py)
-        # the stream captures run on, made AND first used here: a HIP stream is created lazily at its first use, 5.6 ms that would
-        # otherwise land in the first captured step
-        self._side: Optional[torch.cuda.Stream] = torch.cuda.Stream(device=self.device)
-        self._side.wait_stream(torch.cuda.current_stream(self.device))
+        # the stream captures run on: one per device and thread, shared by the sessions (captures are serial on a thread)
+        self._side: Optional[torch.cuda.Stream] = _capture_stream(self.device)
+        self._last_stream: Optional[torch.cuda.Stream] = None  # the stream the last step's launches went to
         self.out: List[torch.Tensor] = []
         # the host's words of a step reach the GPU through a RING of pinned slots (copied from in front of the step, or read by the
         # step's first kernel: `staging`); an event behind every fourth step keeps the host from lapping the GPU
@@ -114,6 +157,12 @@ class DecodeSession:
         try:
             if self.win:
                 lib.deft_window_free(self.win)
+            self.win = 0
+        except Exception:
+            pass
+        try:  # (the pinned ring goes to the next session, behind an event on the stream that read it last)
+            _ring_release(self._ring, self._last_stream)
+            self._ring = None
         except Exception:
             pass
 
@@ -199,9 +248,11 @@ class DecodeSession:
         self._ops_off, self._patch_off = ob, pb
         need = (16 + self._small.numel() + 15) // 16 * 16
         if self._ring is None or need > self._ring_slot:  # (grown only: between epochs, once every slot has been read)
-            torch.cuda.current_stream(dev).synchronize()
-            self._ring_slot = max(need, 4096)
-            self._ring = torch.zeros(self.RING * self._ring_slot, dtype=torch.uint8).pin_memory()
+            if self._ring is not None:
+                torch.cuda.current_stream(dev).synchronize()
+                _ring_release(self._ring, self._last_stream)
+            self._ring_slot = max(4096, 1 << (need - 1).bit_length())  # (powers of two: rings are handed from session to session)
+            self._ring = _ring_acquire(self.RING * self._ring_slot)
         self.win_tab = torch.zeros(max(chunks, 1) * _WIN_PASSES * 2, dtype=torch.int32, device=dev)
         if self.win:
             lib.deft_window_free(self.win)
@@ -420,8 +471,15 @@ class DecodeSession:
         if need >= 0:
             e = need + (self.EVENT_EVERY - 1 - need) % self.EVENT_EVERY
             ev = self._ring_events[(e // self.EVENT_EVERY) % len(self._ring_events)]
-            if ev is not None:
-                ev.synchronize()
+            if ev is not None and not ev.query():
+                # (polled, not hipEventSynchronize: on some boxes that call returns 10 or 20 ms late -- the wake-up is missed and a
+                #  timer finds the finished event, profiles/r6_slow_run_hunt.txt -- while the query reads the signal itself)
+                spins = 0
+                while not ev.query():
+                    spins += 1
+                    if spins > 2000000:
+                        ev.synchronize()
+                        break
         sv = self._slot_views[k]
         if sv is None:  # (numpy views of ring slot k and their addresses: made once per epoch, not per step)
             slot = self._ring.numpy()[k * self._ring_slot : (k + 1) * self._ring_slot]
@@ -458,9 +516,9 @@ class DecodeSession:
             self.last_staged = {"kind": kind, "journal": self._journal[:journal_words].copy(), "loc": loc32.copy(),
                                 "patch": h[self._patch_off : used].view(np.int32).copy() if kind != "legacy" else None}
         hdr[0] = used  # (only what this step wrote crosses PCIe: the journal and patch areas are sized for the worst step)
+        cur = self._last_stream = torch.cuda.current_stream(self.device)  # (where this step's copy and launches go)
         if self.staging == "copy":
-            check(lib.deft_stage_copy(self._ring_p, self._ring_slot, k, self._small_p, self._small_n,
-                                      torch.cuda.current_stream(self.device).cuda_stream), "deft_stage_copy")
+            check(lib.deft_stage_copy(self._ring_p, self._ring_slot, k, self._small_p, self._small_n, cur.cuda_stream), "deft_stage_copy")
         return kind
 
     def _capture(self, kind: str, launch) -> None:
@@ -469,7 +527,7 @@ class DecodeSession:
         # ONE capture stream per session: a new stream's first use costs 5.6 ms (measured round 3: the HIP stream is created
         # lazily, at the wait below) -- per structural epoch, more than everything else a capture does (0.8 ms)
         if self._side is None:
-            self._side = torch.cuda.Stream(device=dev)
+            self._side = _capture_stream(dev)
         side = self._side
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
