@@ -39,6 +39,7 @@ from .tree_cache import BLOCK_CONFIG, TreeCache, _DeviceTree, _FIELDS, _ptr
 __all__ = ["DecodeSession", "FlattenDecodeSession"]
 
 import threading
+import time
 
 _TILE = 128
 _WIN_PASSES = 16  # (plan_records.h WIN_PASSES: the overflow table's passes per query chunk)
@@ -474,12 +475,11 @@ class DecodeSession:
             if ev is not None and not ev.query():
                 # (polled, not hipEventSynchronize: on some boxes that call returns 10 or 20 ms late -- the wake-up is missed and a
                 #  timer finds the finished event, profiles/r6_slow_run_hunt.txt -- while the query reads the signal itself)
-                spins = 0
+                #  -- spinning for 0.2 ms, then between short sleeps: the host is 4-8 steps ahead here, a late look costs the GPU nothing)
+                t_spin = time.perf_counter() + 2e-4
                 while not ev.query():
-                    spins += 1
-                    if spins > 2000000:
-                        ev.synchronize()
-                        break
+                    if time.perf_counter() > t_spin:
+                        time.sleep(5e-5)
         sv = self._slot_views[k]
         if sv is None:  # (numpy views of ring slot k and their addresses: made once per epoch, not per step)
             slot = self._ring.numpy()[k * self._ring_slot : (k + 1) * self._ring_slot]
