@@ -448,3 +448,49 @@ def test_session_node_chunk_equals_eager_step_for_step(incremental):
         assert sess.captures == (4 if incremental else 2)
     finally:
         deft_amd.BLOCK_CONFIG["MAX_BLOCK_LEN"] = -1
+
+
+def test_sessions_hand_their_pinned_ring_on():
+    """The staging ring (pinned host memory) and the capture stream are kept per process: a session made after another one of the same
+    size was dropped takes over its ring -- no hipHostMalloc per session -- while the first session's last steps may still be in the
+    queue (the ring waits behind an event), and decodes correctly from it."""
+    import gc
+
+    from deft_amd import session as S
+
+    Hq, Hkv, D, layers, prefix, width = 8, 2, 128, 2, 300, 5
+    g = torch.Generator(device="cuda").manual_seed(21)
+    kv_init = torch.randn((layers, 4096, 2, Hkv, D), dtype=torch.float16, device="cuda", generator=g)
+    q = torch.randn((layers, width, Hq * D), dtype=torch.float16, device="cuda", generator=g)
+    k = torch.randn((layers, width, Hkv * D), dtype=torch.float16, device="cuda", generator=g)
+    v = torch.randn((layers, width, Hkv * D), dtype=torch.float16, device="cuda", generator=g)
+    attn = [deft_amd.DeFTAttention(Hq, D, D ** -0.5, Hkv, l) for l in range(layers)]
+    fmode = deft_amd.forward_mode_from_cli("flatten")
+    rings, sides = [], []
+    for round_ in range(3):
+        trees = []
+        for _ in range(2):
+            tree, pool = _mk(Hkv, D, layers, prefix, width, 4096)
+            pool._storage.copy_(kv_init)
+            trees.append((tree, pool))
+        (te, pe), (ts, ps) = trees
+        sess = deft_amd.DecodeSession(ts, Hq, Hkv, D, layers, lambda l: (q[l], k[l], v[l]))
+        for step in range(12):
+            for tree in (te, ts):
+                for leaf in tree.leaves.values():
+                    leaf.append_token(3)
+            upd = te.alloc()
+            md = deft_amd.TreeMetadata.from_tree_cache(te)
+            deft_amd.register_tree_metadata(md)
+            meta = deft_amd.InputMetadata(fmode, upd, pe)
+            ref = [attn[l](q[l], k[l], v[l], meta) for l in range(layers)]
+            out = sess.step()
+            for l in range(layers):
+                _agree(out[l], ref[l], True, (round_, step, l))
+        assert sess.step_kinds["patch"] > 0 and sess.device_errors() == 0
+        rings.append(sess._ring.data_ptr())
+        sides.append(sess._side.cuda_stream)
+        del sess  # (no synchronisation: its last steps may still be running)
+        gc.collect()
+        assert any(r.data_ptr() == rings[-1] for have in S._PINNED_RINGS.values() for r, _ in have)
+    assert rings[0] == rings[1] == rings[2] and sides[0] == sides[1] == sides[2]
