@@ -847,6 +847,25 @@ def main():
                     if isinstance(e2e.get(key), dict) and "ms_per_step" in e2e[key]:
                         e2e[key]["over_frozen_step_at_mean_len"] = round(e2e[key]["ms_per_step"] / fz, 4)
                 del bf
+                # A frozen step's time is NOT linear in the branch length (the Flatten split packs the branches' tokens into 128-slot
+                # blocks across leaf boundaries, and the leaf blocks' groups of three leave a remainder: 240 -> 254 tokens per branch
+                # +11 % for +4 % of bytes, profiles/r6_union_len_sweep.txt), so the frozen step AT the mean length understates what the
+                # loop's steps cost frozen: the second reference is the mean of frozen steps at five lengths across the loop's range.
+                n_loop = e2e["graphed"]["steps"]
+                first = mean_len - (n_loop - 1) / 2.0
+                lens = sorted({int(round(first + f * (n_loop - 1))) for f in (0.0, 0.25, 0.5, 0.75, 1.0)})
+                per_len = {}
+                for bl in lens:
+                    torch.cuda.empty_cache()
+                    bf = Bench(Workload(**{**w.__dict__, "branch_len": bl}), layers, device, seed=7)
+                    bf.prepare(use_graph=not args.no_graph)
+                    per_len[str(bl)] = round(run_timed(bf, 30, 5, False) / 30 * 1e3, 4)
+                    del bf
+                fzm = sum(per_len.values()) / len(per_len)
+                e2e["frozen_steps_across_the_loop"] = {"ms_per_step_by_branch_len": per_len, "mean_ms_per_step": round(fzm, 4)}
+                for key in ("graphed", "graphed_rebuild_every_step", "eager"):
+                    if isinstance(e2e.get(key), dict) and "ms_per_step" in e2e[key]:
+                        e2e[key]["over_frozen_steps_across_the_loop"] = round(e2e[key]["ms_per_step"] / fzm, 4)
         except Exception as e:
             e2e["frozen_step_at_mean_len"] = {"error": f"{type(e).__name__}: {e}"}
 

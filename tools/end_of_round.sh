@@ -14,7 +14,7 @@ timeout 300 python tools/replay.py --task reasoning --out $O/${TAG}_replay_reaso
 timeout 300 python tools/replay.py --task reasoning --modes flatten node --pipelined --out $O/${TAG}_replay_reasoning_tot50_pipelined.json > $O/replay_totp.log 2>&1
 timeout 300 python tools/replay.py --task reasoning --model llama3-8b --out $O/${TAG}_replay_reasoning_tot50_llama3.json > $O/replay_tot3.log 2>&1
 timeout 300 python tools/replay.py --task speculative_decoding --modes node flatten seq --tree-size 64 --out $O/${TAG}_replay_speculative_64.json > $O/replay_sd.log 2>&1
-timeout 300 python tools/replay.py --task speculative_decoding --modes node flatten --tree-size 64 --pipelined --out $O/${TAG}_replay_speculative_64_pipelined.json > $O/replay_sdp.log 2>&1
+timeout 300 python tools/replay.py --task speculative_decoding --modes node flatten --tree-size 64 --pipelined --reps 3 --out $O/${TAG}_replay_speculative_64_pipelined.json > $O/replay_sdp.log 2>&1
 timeout 300 python tools/replay.py --task speculative_decoding --modes node flatten --tree-size 64 --eager --out $O/${TAG}_replay_speculative_64_eager.json > $O/replay_sde.log 2>&1
 # the shipped reasoning templates' shape: width 10 per level, a branch (and nine prunes) every 8 steps -- synchronised per step and pipelined
 timeout 300 python tools/replay.py --task reasoning --beam 10,12,8 --prompt-len 4096 --modes flatten --out $O/${TAG}_replay_reasoning_beam10x8.json > $O/replay_beam.log 2>&1
@@ -23,7 +23,7 @@ timeout 300 python tools/replay.py --task reasoning --beam 10,12,8 --prompt-len 
 timeout 600 python tools/replay.py --task reasoning --golden-template docmergeToT --max-gen-len 100000 --modes flatten node --pipelined --out $O/${TAG}_replay_reasoning_docmergeToT_pipelined.json > $O/replay_docmerge.log 2>&1
 # round 6: the same replays through sessions that rebuild metadata and plan on every step (DecodeSession(incremental=False), the round-5 loop)
 timeout 300 python tools/replay.py --task few_shot --width 32 --prompt-len 4096 --max-gen-len 200 --modes flatten --pipelined --legacy --out $O/${TAG}_replay_few_shot_4kx32_pipelined_rebuild.json > $O/replay_fspl.log 2>&1
-timeout 300 python tools/replay.py --task speculative_decoding --modes node flatten --tree-size 64 --pipelined --legacy --out $O/${TAG}_replay_speculative_64_pipelined_rebuild.json > $O/replay_sdpl.log 2>&1
+timeout 300 python tools/replay.py --task speculative_decoding --modes node flatten --tree-size 64 --pipelined --legacy --reps 3 --out $O/${TAG}_replay_speculative_64_pipelined_rebuild.json > $O/replay_sdpl.log 2>&1
 timeout 300 python tools/replay.py --task speculative_decoding --modes node flatten --tree-size 64 --legacy --out $O/${TAG}_replay_speculative_64_rebuild.json > $O/replay_sdl.log 2>&1
 timeout 300 python tools/replay.py --task reasoning --modes flatten node --pipelined --legacy --out $O/${TAG}_replay_reasoning_tot50_pipelined_rebuild.json > $O/replay_totpl.log 2>&1
 timeout 300 python tools/replay.py --task reasoning --model llama3-8b --modes flatten --pipelined --out $O/${TAG}_replay_reasoning_tot50_llama3_pipelined.json > $O/replay_tot3p.log 2>&1

@@ -13,7 +13,8 @@ from deft_amd.utils.workloads import WORKLOADS, Workload, build_tree
 w0 = WORKLOADS["northstar_4kx32"]
 Hq = Hkv = 32
 D = 128
-for L in (1, 10, 25, 40, 50, 75, 100, 125, 150, 175, 200, 300, 400):
+LENS = [int(x) for x in sys.argv[1:]] or [1, 10, 25, 40, 50, 75, 100, 125, 150, 175, 200, 300, 400]
+for L in LENS:
     w = Workload(**{**w0.__dict__, "branch_len": L})
     tree, pool = build_tree(w, 1, "cuda:0")
     md = deft_amd.TreeMetadata.from_tree_cache(tree)

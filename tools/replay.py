@@ -40,6 +40,8 @@ ap.add_argument("--beam", default=None, metavar="WIDTH,DEPTH,LEN",
 ap.add_argument("--legacy", action="store_true", help="DecodeSession(incremental=False): metadata and plan rebuilt on every step (the round-5 loop)")
 ap.add_argument("--win-tiles", type=int, default=None, help="DecodeSession(win_tiles=): overflow tiles per query chunk of a window plan")
 ap.add_argument("--capture-after", default="auto", help="DecodeSession(capture_after=): 1, 2, ... or auto")
+ap.add_argument("--reps", type=int, default=1, help="timed replays per mode; the table keeps the one with the least attention time and lists all "
+                "(a 50 ms replay is doubled by ONE 50 ms stall of the box's driver: profiles/r6_slow_run_hunt.txt)")
 ap.add_argument("--out", default=None)
 a = ap.parse_args()
 if a.host_metadata:
@@ -70,10 +72,11 @@ def template():
 rows = []
 # The first replay of a process is ~200 us per step slower than any later one (module loads, pinned staging buffers, the
 # driver's first allocations of every workspace size the growing tree asks for): run the first mode once, untimed.
-if not a.no_warmup:
-    a_modes = [a.modes[0]] + list(a.modes)
-else:
-    a_modes = list(a.modes)
+# ... and the first replay of every MODE pays that mode's own first launches (the kernels of its plan and operator: ~100 ms once, three
+# times a 100-step speculative-decoding replay -- profiles/r6_slow_run_hunt.txt): every mode runs once untimed, then the table.
+n_warm = 0 if a.no_warmup else len(a.modes)
+a_modes = (list(a.modes) if n_warm else []) + [m for m in a.modes for _ in range(max(a.reps, 1))]
+best = {}
 for idx, mode in enumerate(a_modes):
     tpl = template()
     prompt_len = a.prompt_len or rp.default_prompt_len(tpl, a.task, from_file=bool(a.template or a.golden_template))
@@ -84,12 +87,22 @@ for idx, mode in enumerate(a_modes):
     s["path"] = "session (one hipGraph per structural epoch)" if r.session else "eager calls"
     s["graph_captures"] = r.graph_captures; s["step_kinds"] = getattr(r, "step_kinds", None); s["pipelined"] = bool(a.pipelined); s["capture_after"] = a.capture_after
     s["wall_over_attention"] = round(s["wall_ms"] / max(s["attention_latency_ms"], 1e-9), 3)
-    if not a.no_warmup and idx == 0:
+    if idx < n_warm:
         del r
         torch.cuda.empty_cache()
         continue
-    rows.append(s)
-    print(json.dumps(s), flush=True)
+    if a.reps > 1:  # (the least attention time of the mode's replays stands in the table; every repetition's time is listed with it)
+        prev = best.get(mode)
+        times = (prev["reps_attention_ms"] if prev else []) + [s["attention_latency_ms"]]
+        if prev is None or s["attention_latency_ms"] < prev["attention_latency_ms"]:
+            best[mode] = s
+        best[mode]["reps_attention_ms"] = times
+        if len(times) == a.reps:
+            rows.append(best[mode])
+            print(json.dumps(best[mode]), flush=True)
+    else:
+        rows.append(s)
+        print(json.dumps(s), flush=True)
     del r
     torch.cuda.empty_cache()
 base = next((x for x in rows if x["mode"] == "seq"), None)
