@@ -656,7 +656,7 @@ static int np_chunk_knob() { return knob("DEFT_NP_CHUNK", 0); }  // tiles per ch
 // a chunk whose tiles are folded by more 32-row passes than this asks for its K / V rows with the temporal cache policy
 // (launch_stage1_np; the record kernels write the flag)
 static int np_nt_passes_knob() { return knob("DEFT_NP_NT_PASSES", 5); }
-static int np_union_knob() { return knob("DEFT_NP_UNION", 0); }  // leaf tiles per union group (1 = off, 0 = rule)
+static int np_union_knob() { return knob("DEFT_NP_UNION", 0) | (knob("DEFT_NP_TAPER", 0) << 16); }  // leaf tiles per union group (1 = off, 0 = rule)
 
 // Work items of stage 1 per chunk leader, for the plan's chunk-length rules (they weigh the number of workgroups against the
 // resident slots): one per KV head -- per head PAIR where stage 1 will run head_dim 64 two heads to a row (hd2_geometry).  The plan

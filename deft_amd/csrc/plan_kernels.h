@@ -556,10 +556,15 @@ __global__ __launch_bounds__(1024) void flatten_units_kernel(const int64_t* bloc
                     break;
                 }
     }
-    if ((union_len >> 8) > 0) ucap = min(min(UNION_CAP, MQ / G), union_len >> 8);  // (experiments: bits 8.. of the knob SET the union's query cap)
+    if (((union_len >> 8) & 0xff) > 0) ucap = min(min(UNION_CAP, MQ / G), (union_len >> 8) & 0xff);  // (experiments: bits 8..15 of the knob SET the union's query cap)
+    const int taper = (union_len >> 16) & 0xff;  // (experiments: bits 16..23 -- the last `taper` % of the blocks stay single, the `taper` % in front of them pair)
     auto union_len_at = [&](int t) {
-        (void)t;
         int ulen = union_len & 0xff;
+        if (taper && G == 1 && Hkv > 0) {
+            const int k1 = NBreg * taper / 100;
+            if (t >= NBreg - k1) return 1;
+            if (t >= NBreg - 2 * k1) return 2;
+        }
         // (head pairs, Hkv < 0: groups of two -- their launches want workgroups, tools/ab_step.py on the head_dim-64 north-star tree;
         //  three measured 0.9 us per layer faster in the experiments build and 0.4 slower in the shipped one, tools/ab_lib.sh)
         if (ulen <= 0) ulen = G > 1 ? gqa_ulen : (Hkv < 0 ? 2 : ((int64_t)NB * Hkv < 2048 ? 4 : 3));  // measured, tools/np_sweep.sh / tools/ab.py
