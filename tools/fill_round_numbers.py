@@ -81,6 +81,9 @@ def opt(fn, default="n/a"):
 fr = b.get("few_shot_run") or {}
 situ = b.get("in_situ") or {}
 vals.update({
+    "ACROSSL": opt(lambda: e["graphed_rebuild_every_step"]["over_frozen_steps_across_the_loop"]),
+    "ACROSSF": opt(lambda: e["frozen_steps_across_the_loop"]["mean_ms_per_step"]),
+    "ACROSS": opt(lambda: e["graphed"]["over_frozen_steps_across_the_loop"]),
     "E2EL": opt(lambda: e["graphed_rebuild_every_step"]["ms_per_step"]), "RATIOL": opt(lambda: e["graphed_rebuild_every_step"]["over_frozen_step_at_mean_len"]),
     "RUNFRACL": opt(lambda: fr["rebuild_every_step"]["run_hbm_frac"]), "RUNFRAC": opt(lambda: fr["window_plans"]["run_hbm_frac"]),
     "RUNMS": opt(lambda: fr["window_plans"]["ms_per_step"]),
