@@ -789,6 +789,9 @@ static int launch_stage1_np(const Stage1Params& p, int64_t unit_cap, const PlanV
     // know the item count.  Not adopted.)
     npp.fast_n = knob("DEFT_NP_FAST", 2 * num_cus());
     npp.mirror = mirror ? 1 : 0;
+#ifdef DEFT_EXPERIMENTS
+    npp.skew_full = mirror ? 0 : knob("DEFT_NP_XCDSKEW", 0);
+#endif
     npp.s.ablate = knob("DEFT_STAGE1_ABLATE", 0);
     npp.plan = pv.records;
     npp.k_new = ap.k_new;

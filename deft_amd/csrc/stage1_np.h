@@ -39,6 +39,9 @@ struct NpParams {
     const int32_t* hdr;  // plan header (plan_records.h): hdr[1] = number of chunk leaders
     int mirror;        // capped grids: workgroup b takes items b, 2W-1-b, 2W+b, 4W-1-b, ... (the SHORT first items get the extra ones)
     int fast_n;        // workgroups < fast_n (the ones resident at launch) request tile 0's offsets before anything else
+#ifdef DEFT_EXPERIMENTS
+    int skew_full;     // > 0: only the first 8 x skew_full workgroups take item = index; behind them the EVEN ones (index % 8 = XCD) take the remaining items, the odd ones none
+#endif
     // fused paged append (optional): rows whose plan offset has bit 63 set are read from k_new / v_new
     const _Float16* k_new;
     const _Float16* v_new;
@@ -206,6 +209,20 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
     // further items (capped grids) takes item + W, item + 2 W, ... in a loop.
     int NI = 0x7fffffff;  // leaders x heads, read with the first item's descriptor
     int item = bid, round = 0;
+#ifdef DEFT_EXPERIMENTS
+    // (DEFT_NP_XCDSKEW: the odd XCDs stream ~18 % slower -- more items to the even ones.  The timeline evens out, the layer gains 2 % at
+    //  ONE setting and nothing at its neighbours, profiles/r6_union_len_sweep.txt (4): not shipped)
+    bool dead = false;
+    if (np.skew_full > 0) {
+        const int r = bid >> 3, x = bid & 7;
+        if (r >= np.skew_full) {
+            if (x & 1) dead = true;
+            else item = 8 * np.skew_full + 4 * (r - np.skew_full) + (x >> 1);
+        }
+    }
+#else
+    constexpr bool dead = false;
+#endif
     auto next_item = [&](int it) __attribute__((always_inline)) {
         if constexpr (DYN) {
             if (np.mirror) return (++round & 1) ? (round + 1) * W - 1 - bid : round * W + bid;  // b, 2W-1-b, 2W+b, 4W-1-b, ...
@@ -353,7 +370,7 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
                      : "s"(rec_lead + PLAN_DESC), "s"(np.hdr + 1)
                      : "memory");
         NI = nl * HP;
-        if (item >= NI) {  // this record slot leads no chunk (speculative read of valid memory): nothing to do
+        if (item >= NI || dead) {  // this record slot leads no chunk (speculative read of valid memory): nothing to do
             if (spec) wait_vm<0>();
             break;
         }

@@ -34,6 +34,13 @@ for bl in [int(x) for x in sys.argv[1:]]:
             m = n == nn
             q = lambda x: "%5.1f %5.1f %5.1f" % (np.min(x), np.median(x), np.max(x))
             print(f"   n={int(nn)}: {int(m.sum()):4d} items   start min/med/max {q(t0[m])}   end {q(t1[m])}   duration {q(t1[m] - t0[m])}")
+        xcc = (d[ok, 5] >> 32) & 0xff
+        ws, we = d[ok, 0] / 100.0 - base, d[ok, 3] / 100.0 - base  # the workgroup's whole stay on the item (prologue .. epilogue)
+        print("   per XCD: items / tiles / first start / last end (us) / tile-loop us per tile (median):")
+        for x in sorted(set(xcc.tolist())):
+            m = xcc == x
+            print(f"      XCD {int(x)}: {int(m.sum()):4d} items {int(n[m].sum()):5d} tiles   {ws[m].min():5.1f} .. {we[m].max():5.1f}   "
+                  f"{np.median((t1[m] - t0[m]) / n[m]):.2f}   ends of its last 5 items: {' '.join('%.1f' % v for v in np.sort(we[m])[-5:])}")
         # how many items are running at 2-us marks
         marks = np.arange(0, t1.max() + 2, 2.0)
         print("   running at t =", " ".join(f"{int(((t0 <= t) & (t1 > t)).sum())}" for t in marks), "  (every 2 us)")
