@@ -791,6 +791,7 @@ static int launch_stage1_np(const Stage1Params& p, int64_t unit_cap, const PlanV
     npp.mirror = mirror ? 1 : 0;
 #ifdef DEFT_EXPERIMENTS
     npp.skew_full = mirror ? 0 : knob("DEFT_NP_XCDSKEW", 0);
+    npp.head_rot = knob("DEFT_NP_HEADROT", 0);
 #endif
     npp.s.ablate = knob("DEFT_STAGE1_ABLATE", 0);
     npp.plan = pv.records;

@@ -40,6 +40,7 @@ struct NpParams {
     int mirror;        // capped grids: workgroup b takes items b, 2W-1-b, 2W+b, 4W-1-b, ... (the SHORT first items get the extra ones)
     int fast_n;        // workgroups < fast_n (the ones resident at launch) request tile 0's offsets before anything else
 #ifdef DEFT_EXPERIMENTS
+    int head_rot;      // heads of record r rotated by r * head_rot
     int skew_full;     // > 0: only the first 8 x skew_full workgroups take item = index; behind them the EVEN ones (index % 8 = XCD) take the remaining items, the odd ones none
 #endif
     // fused paged append (optional): rows whose plan offset has bit 63 set are read from k_new / v_new
@@ -347,6 +348,11 @@ __global__ __launch_bounds__(256, 2) void stage1_np_kernel(NpParams np) {
     // (wave-uniform by construction, made so explicitly: the quotient comes out of the vector ALU)
     rec0 = __builtin_amdgcn_readfirstlane(item / HP);
     kvh = __builtin_amdgcn_readfirstlane(item - (item / HP) * HP);  // (HD2: the head PAIR)
+#ifdef DEFT_EXPERIMENTS
+    // (DEFT_NP_HEADROT: the heads of record r handed out rotated by r -- workgroup index % 8 = XCD, so with 32 KV heads every XCD otherwise
+    //  reads the same four heads of every record, i.e. the same address bits 8..12 of every row)
+    if (np.head_rot) kvh = __builtin_amdgcn_readfirstlane((kvh + rec0 * np.head_rot) % HP);
+#endif
     const char* rec_lead = np.plan + (int64_t)rec0 * PLAN_BYTES;
     // The workgroups that are resident when the launch starts set the ramp: for them tile 0's offsets / masks /
     // partial rows are requested (LDS-DMA) before anything is known about the record -- its address only depends
