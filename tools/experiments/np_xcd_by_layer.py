@@ -21,6 +21,10 @@ for l in range(0, 32, 3):
     dbg = torch.zeros(2 * NW * 8 + 8, dtype=torch.int64, device="cuda")
     torch.cuda.synchronize()
     lib.deft_debug_set_buffer(dbg.data_ptr())
+    # SUSTAINED=n: n launches back to back in front of the sampled one (every launch stamps the same buffer; the last one's stamps stay)
+    for k in range(int(os.environ.get("SUSTAINED", "0")), 0, -1):
+        j = (l - k) % 32
+        b.attn[j](b.q[j], b.k_new[j], b.v_new[j], b.meta)
     b.attn[l](b.q[l], b.k_new[l], b.v_new[l], b.meta)
     torch.cuda.synchronize()
     lib.deft_debug_set_buffer(None)
