@@ -3,7 +3,7 @@
 # builder and the error text -- 1170 lines) built with AddressSanitizer + UndefinedBehaviorSanitizer and driven by the CPU test
 # suites that exercise it.  CPU only (GPU sanitizers are not available on this pool): every entry point that lives in
 # deft_kernels.hip is a STUB here that returns DEFT_EUNSUPPORTED, generated from the library's own symbol table, so that
-# deft_amd/_lib.py finds all 65 names.
+# deft_amd/_lib.py finds all its names (74).
 #   tools/run_cpu_sanitized.sh [pytest args ...]        (default: tests/test_host_logic.py tests/test_forest_tree.py tests/test_replay.py
 #                                                         tests/test_replay_golden.py tests/test_workloads.py, -m "not gpu")
 # A sanitizer report makes the run fail (halt_on_error, abort).  `make -C deft_amd/csrc asan` builds the library only.
