@@ -469,10 +469,10 @@ __global__ __launch_bounds__(1024) void flatten_units_kernel(const int64_t* bloc
         sPass[t] = (cnt * G + MQ - 1) / MQ;
     }
     __syncthreads();
-    if (G > 1) {
+    if (G > 1 || Hkv > 0) {  // (MHA: blocks a union group may hold -- at most four queries -- and all others, among the plan's own blocks)
         int small = 0, passes = 0;
-        for (int t = threadIdx.x; t < NB; t += blockDim.x) {
-            if (sCnt[t] <= 3) ++small;
+        for (int t = threadIdx.x; t < (G > 1 ? NB : NBreg); t += blockDim.x) {
+            if (sCnt[t] <= (G > 1 ? 3 : 4)) ++small;
             else passes += sPass[t];
         }
         for (int m = 32; m > 0; m >>= 1) {
@@ -556,6 +556,46 @@ __global__ __launch_bounds__(1024) void flatten_units_kernel(const int64_t* bloc
                     break;
                 }
     }
+    // MHA, large launches (where groups of three were the measured rule): three or four leaf blocks per group by LIST SCHEDULING the
+    // launch's work items in tile times on the slots one KV head has (late round 6, profiles/r6_union_len_sweep.txt).  The shared
+    // prefix's chunks start first and run C tiles; the groups fill the other slots round by round (the prefix's slots join when it is
+    // done), the remainder -- a work item of its own -- takes the first free slot.  Fours are taken where threes finish BEFORE the prefix
+    // does -- leaving its few workgroups alone with the memory system -- and fours keep the slots busy for longer without a longer
+    // makespan: the north-star tree from ~205 to ~270 tokens per branch (forced lengths, shipped build: 254 tokens 41.4 -> 37.9 us per
+    // layer, 262 41.6 -> 39.8, 220 / 240 within 1-2 %; 150 / 180 / 200 / 300 / 400 stay with three, which measures 1-5 % faster there).
+    // A frozen step used to jump +11 % from 240 to 254 tokens per branch.
+    int mha_ulen = 3;
+    if (G == 1 && Hkv > 0) {
+        const int S = slots / Hkv, nL = sEst[0], nP = NBreg - nL;
+        const int Cest = nP >= 32 ? 8 : (nP >= 8 ? 4 : (nP >= 4 ? 2 : 1));
+        const int npre = (nP + Cest - 1) / Cest;
+        // (only where the model was validated: a prefix of >= 32 blocks in 8-tile chunks.  On the 1k prefix it picks four at 400 tokens per
+        //  branch where three measure 3 % faster.)
+        if (nP >= 32 && npre < S && nL > 0) {
+            auto sched = [&](int u, int& M, int& F) {
+                int g = nL / u, t = 0, last_take = 0, last_avail = 0;
+                const int r = nL - g * u;
+                F = 0;
+                while (g > 0) {
+                    const int avail = (S - npre) + (t >= Cest ? npre : 0);
+                    const int take = min(avail, g);
+                    g -= take;
+                    last_take = take;
+                    last_avail = avail;
+                    t += u;
+                    F = t;
+                }
+                if (r > 0) F = (last_take < last_avail || F == 0) ? max(F, (F > 0 ? F - u : 0) + r) : F + r;
+                M = max(F, Cest);
+            };
+            int M3, F3, M4, F4;
+            sched(3, M3, F3);
+            sched(4, M4, F4);
+            // (four only where threes leave the prefix alone, F3 < C, and fours do so for less time: at 300 tokens per branch threes
+            //  already end a round behind the prefix, the model's makespan says four, and the shipped build measures three 3 % faster)
+            if (F3 < Cest && F4 > F3 && M4 <= M3) mha_ulen = 4;
+        }
+    }
     if (((union_len >> 8) & 0xff) > 0) ucap = min(min(UNION_CAP, MQ / G), (union_len >> 8) & 0xff);  // (experiments: bits 8..15 of the knob SET the union's query cap)
     const int taper = (union_len >> 16) & 0xff;  // (experiments: bits 16..23 -- the last `taper` % of the blocks stay single, the `taper` % in front of them pair)
     auto union_len_at = [&](int t) {
@@ -567,7 +607,7 @@ __global__ __launch_bounds__(1024) void flatten_units_kernel(const int64_t* bloc
         }
         // (head pairs, Hkv < 0: groups of two -- their launches want workgroups, tools/ab_step.py on the head_dim-64 north-star tree;
         //  three measured 0.9 us per layer faster in the experiments build and 0.4 slower in the shipped one, tools/ab_lib.sh)
-        if (ulen <= 0) ulen = G > 1 ? gqa_ulen : (Hkv < 0 ? 2 : ((int64_t)NB * Hkv < 2048 ? 4 : 3));  // measured, tools/np_sweep.sh / tools/ab.py
+        if (ulen <= 0) ulen = G > 1 ? gqa_ulen : (Hkv < 0 ? 2 : ((int64_t)NB * Hkv < 2048 ? 4 : mha_ulen));  // measured, tools/np_sweep.sh / tools/ab.py
         return ulen;
     };
     if (np && ucap >= 2)
