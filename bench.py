@@ -847,10 +847,11 @@ def main():
                     if isinstance(e2e.get(key), dict) and "ms_per_step" in e2e[key]:
                         e2e[key]["over_frozen_step_at_mean_len"] = round(e2e[key]["ms_per_step"] / fz, 4)
                 del bf
-                # A frozen step's time is NOT linear in the branch length (the Flatten split packs the branches' tokens into 128-slot
-                # blocks across leaf boundaries, and the leaf blocks' groups of three leave a remainder: 240 -> 254 tokens per branch
-                # +11 % for +4 % of bytes, profiles/r6_union_len_sweep.txt), so the frozen step AT the mean length understates what the
-                # loop's steps cost frozen: the second reference is the mean of frozen steps at five lengths across the loop's range.
+                # A frozen step's time need not be linear in the branch length (the Flatten split packs the branches' tokens into 128-slot
+                # blocks across leaf boundaries, and the leaf blocks' groups leave a remainder: 240 -> 254 tokens per branch was +11 % for
+                # +4 % of bytes before round 6's last plan rule, profiles/r6_union_len_sweep.txt), so the frozen step AT the mean length can
+                # understate what the loop's steps cost frozen: the second reference is the mean of frozen steps at five lengths across
+                # the loop's range.
                 n_loop = e2e["graphed"]["steps"]
                 first = mean_len - (n_loop - 1) / 2.0
                 lens = sorted({int(round(first + f * (n_loop - 1))) for f in (0.0, 0.25, 0.5, 0.75, 1.0)})
@@ -864,11 +865,11 @@ def main():
                 fzm = sum(per_len.values()) / len(per_len)
                 e2e["frozen_steps_across_the_loop"] = {
                     "ms_per_step_by_branch_len": per_len, "mean_ms_per_step": round(fzm, 4),
-                    "why": "a frozen step is not linear in the branch length (the Flatten split's leaf blocks are grouped in threes and the "
-                           "remainder is a work item of its own: 240 -> 254 tokens per branch +11 % for +4 % of bytes, "
-                           "profiles/r6_union_len_sweep.txt), so the one frozen step at the loop's MEAN length is cheaper than the loop's steps "
-                           "are frozen; `over_frozen_steps_across_the_loop` is the loop against the mean of these five, "
-                           "`over_frozen_step_at_mean_len` (kept for continuity with rounds 4-5) against the one"}
+                    "why": "a frozen step need not be linear in the branch length (the Flatten split's leaf blocks are grouped in threes or "
+                           "fours and the remainder is a work item of its own: before round 6's last plan rule 240 -> 254 tokens per branch was "
+                           "+11 % for +4 % of bytes, profiles/r6_union_len_sweep.txt), so the one frozen step at the loop's MEAN length can be "
+                           "cheaper than the loop's steps are frozen; `over_frozen_steps_across_the_loop` is the loop against the mean of these "
+                           "five, `over_frozen_step_at_mean_len` (kept for continuity with rounds 4-5) against the one"}
                 for key in ("graphed", "graphed_rebuild_every_step", "eager"):
                     if isinstance(e2e.get(key), dict) and "ms_per_step" in e2e[key]:
                         e2e[key]["over_frozen_steps_across_the_loop"] = round(e2e[key]["ms_per_step"] / fzm, 4)
