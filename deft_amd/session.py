@@ -473,9 +473,9 @@ class DecodeSession:
             e = need + (self.EVENT_EVERY - 1 - need) % self.EVENT_EVERY
             ev = self._ring_events[(e // self.EVENT_EVERY) % len(self._ring_events)]
             if ev is not None and not ev.query():
-                # (polled, not hipEventSynchronize: on some boxes that call returns 10 or 20 ms late -- the wake-up is missed and a
-                #  timer finds the finished event, profiles/r6_slow_run_hunt.txt -- while the query reads the signal itself)
-                #  -- spinning for 0.2 ms, then between short sleeps: the host is 4-8 steps ahead here, a late look costs the GPU nothing)
+                # Polled, not hipEventSynchronize: on some boxes that call returns 10 or 20 ms late (the wake-up is missed and a timer
+                # finds the finished event, profiles/r6_slow_run_hunt.txt) while the query reads the signal itself.  Spinning for
+                # 0.2 ms, then between short sleeps: the host is 4-8 steps ahead here, a late look costs the GPU nothing.
                 t_spin = time.perf_counter() + 2e-4
                 while not ev.query():
                     if time.perf_counter() > t_spin:
